@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the UNMODIFIED reference (jafarinia/snuffy @ /root/reference).
+
+Run ONLY in the build container (the reference cannot travel to the GPU box):
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+What is captured:
+  F1  layer math    : MILNet forward in eval mode over a grid of shapes  -> classes, logits, A, S per layer
+  F2  selection     : top-k index vectors for tie-free and tie-heavy scores, k1/k2 table
+  F3  gradients     : loss.backward() of the SmallWeightTrainer loss (train.py:828-846) in eval mode
+  F4  trainer step  : one AdamW step post-update weights (train.py:468-473, 809-826)
+  F5  loader        : utils.dropout_patches on the seeded global numpy RNG (utils.py:244-250)
+  F6  multiclass    : snuffy_multiclass.MILNet forward (C=2)
+
+Only inputs/outputs (data) are stored -- no reference source text.
+"""
+import copy
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+np.float = float  # pos_embed.py:57 (MAE only)
+_sk = types.ModuleType("skimage")
+for _n in ("exposure", "io", "img_as_ubyte", "transform"):
+    setattr(_sk, _n, types.ModuleType("skimage." + _n))
+sys.modules["skimage"] = _sk
+_timm = types.ModuleType("timm")
+_td = types.ModuleType("timm.data")
+_td.IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)
+_td.IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
+_timm.data = _td
+sys.modules["timm"] = _timm
+sys.modules["timm.data"] = _td
+sys.path.insert(0, "/root/reference")
+
+import snuffy as ref_snuffy  # noqa: E402
+import snuffy_multiclass as ref_multi  # noqa: E402
+import utils as ref_utils  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(8)
+
+
+def build_ref(mod, D, C, h, mlp, act, enc_drop, big_lambda, r, depth, seed, multiclass=False):
+    """Same construction sequence as train.py:861-911 (binary) / 923-971 (multiclass)."""
+    torch.manual_seed(seed)
+    i_classifier = mod.FCLayer(in_size=D, out_size=C)
+    attn = mod.MultiHeadedAttention(h, D)
+    if multiclass:
+        ff = mod.PositionwiseFeedForward(D, D * mlp, act)
+        layer = mod.EncoderLayer(D, copy.deepcopy(attn), copy.deepcopy(ff), C, enc_drop, big_lambda, r)
+    else:
+        ff = mod.PositionwiseFeedForward(D, D * mlp, act, enc_drop)
+        layer = mod.EncoderLayer(D, copy.deepcopy(attn), copy.deepcopy(ff), enc_drop, big_lambda, r)
+    b_classifier = mod.BClassifier(mod.Encoder(layer, depth), C, D)
+    net = mod.MILNet(i_classifier, b_classifier)
+    for _, p in net.named_parameters():
+        if p.dim() > 1:
+            torch.nn.init.xavier_normal_(p)
+    # make biases / LN affine non-trivial so that the vectors discriminate (train.py zero-inits them;
+    # any value is a legal state_dict)
+    g = torch.Generator().manual_seed(seed + 1000)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if p.dim() == 1:
+                if "norm.weight" in name:
+                    p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(0.2 * torch.randn(p.shape, generator=g))
+    return net
+
+
+def capture_choice():
+    """Wrap np.random.choice to record the random index draws (snuffy.py:141-143)."""
+    rec = []
+    orig = np.random.choice
+
+    def wrapped(a, size=None, replace=True, p=None):
+        out = orig(a, size, replace, p)
+        rec.append(np.array(out, dtype=np.int64).reshape(-1))
+        return out
+
+    return rec, orig, wrapped
+
+
+def sd_to_np(net):
+    return {"sd." + k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items()}
+
+
+def run_f1():
+    cases = [
+        # name,        N,    D,  h, Lam,  r,                depth, act,         seed
+        ("musk40",     40,   166, 2, 200, 0.0,               1, "relu",       1),
+        ("n1",         1,    64,  2, 10,  0.0,               1, "relu",       2),
+        ("n2_rand",    2,    64,  4, 10,  0.5,               1, "relu",       3),
+        ("n5_rand",    5,    64,  2, 10,  0.5,               1, "relu",       4),
+        ("n150_gelu",  150,  64,  4, 10,  0.0,               1, "gelu",       5),
+        ("n1000",      1000, 96,  6, 200, 0.0,               1, "relu",       6),
+        ("n1000_d2",   1000, 96,  4, 300, 0.5,               2, "gelu",       7),
+        ("n3000_900",  3000, 96,  4, 900, 0.7777777777777778, 1, "leakyrelu", 8),
+        ("n150_d5",    150,  64,  2, 10,  0.5,               5, "selu",       9),
+        ("n777_h1",    777,  128, 1, 64,  0.25,              1, "relu",       10),
+    ]
+    for name, N, D, h, lam, r, depth, act, seed in cases:
+        net = build_ref(ref_snuffy, D, 1, h, 4, act, 0.0, lam, r, depth, seed).eval()
+        g = torch.Generator().manual_seed(1234 + seed)
+        x = torch.randn(1, N, D, generator=g)
+        rec, orig, wrapped = capture_choice()
+        np.random.seed(seed)
+        np.random.choice = wrapped
+        try:
+            with torch.no_grad():
+                classes, logits, A = net(x)
+        finally:
+            np.random.choice = orig
+        c = classes.reshape(-1)
+        k1 = min(math.ceil(lam * (1.0 - r)), N)
+        top = torch.sort(classes, 1, descending=True)[1][:, :k1, :].reshape(-1).numpy().astype(np.int64)
+        out = dict(
+            x=x.numpy(), classes=classes.numpy(), logits=logits.numpy(),
+            cfg=np.array([N, D, h, lam, depth, seed], dtype=np.int64), r=np.float64(r), act=np.array(act),
+            top=top,
+        )
+        A_np = A.numpy()
+        if A_np.size <= 600_000:
+            out["A"] = A_np
+        else:
+            rows = np.arange(0, N, 37)
+            out["A_rows"] = rows.astype(np.int64)
+            out["A_sub"] = A_np[:, :, rows, :]
+            out["A_colsum"] = A_np.astype(np.float64).sum(axis=2)  # [1,h,K]
+        for li, rnd in enumerate(rec):
+            out[f"rnd{li}"] = rnd
+        out["n_rnd"] = np.int64(len(rec))
+        out.update(sd_to_np(net))
+        np.savez_compressed(os.path.join(HERE, f"f1_{name}.npz"), **out)
+        print(f"F1 {name}: logits={logits.reshape(-1).tolist()} A={tuple(A.shape)} rnd_layers={len(rec)}")
+
+
+def run_f2():
+    out = {}
+    # k1/k2 table (snuffy.py:124,129,137-140), python float arithmetic
+    tab = []
+    for lam, r, N in [(900, 0.7777777777777778, 3000), (200, 0.0, 8192), (200, 0.0, 40), (300, 0.5, 1000),
+                      (10, 0.5, 5), (10, 0.5, 2), (512, 0.0, 100000), (10, 0.3, 7), (200, 0.1, 150), (7, 0.9, 3)]:
+        share = 1.0 - r
+        k1 = min(math.ceil(lam * share), N)
+        k2 = min(int(lam * r), max(0, N - math.ceil(lam * share)))
+        tab.append((lam, r, N, k1, k2))
+    out["k_table"] = np.array(tab, dtype=np.float64)
+    # tie-free scores: reference sort order (snuffy.py:128-130)
+    g = torch.Generator().manual_seed(77)
+    for N in (5000, 32768):
+        cu = torch.unique(torch.randn(2 * N, generator=g))
+        cu = cu[torch.randperm(cu.numel(), generator=g)[:N]]
+        assert torch.unique(cu).numel() == N, "scores must be tie-free"
+        c = cu.view(1, N, 1)
+        idx = torch.sort(c, 1, descending=True)[1].reshape(-1).numpy().astype(np.int64)
+        out[f"tiefree_c_{N}"] = c.reshape(-1).numpy()
+        out[f"tiefree_order_{N}"] = idx[:1024]
+    # tie-heavy scores: the build's rule is descending score, ties by ascending index
+    c = torch.randint(0, 50, (1, 4000, 1), generator=g).float() / 8.0
+    ref_idx = torch.sort(c, 1, descending=True)[1].reshape(-1).numpy().astype(np.int64)
+    stable_idx = torch.sort(c, dim=1, descending=True, stable=True)[1].reshape(-1).numpy().astype(np.int64)
+    out["ties_c"] = c.reshape(-1).numpy()
+    out["ties_ref_order"] = ref_idx[:1024]
+    out["ties_stable_order"] = stable_idx[:1024]
+    out["ties_ref_equals_stable"] = np.bool_(np.array_equal(ref_idx, stable_idx))
+    # special values: +-0, +-inf, denormals
+    sp = torch.tensor([0.0, -0.0, 1e-45, -1e-45, float("inf"), float("-inf"), 1.0, -1.0, 0.0, -0.0, 3.5, 3.5])
+    out["special_c"] = sp.numpy()
+    out["special_stable_order"] = torch.sort(sp.view(1, -1, 1), dim=1, descending=True, stable=True)[1].reshape(-1).numpy()
+    out["special_ref_order"] = torch.sort(sp.view(1, -1, 1), 1, descending=True)[1].reshape(-1).numpy()
+    np.savez_compressed(os.path.join(HERE, "f2_selection.npz"), **out)
+    print("F2 ties_ref_equals_stable =", bool(out["ties_ref_equals_stable"]), "k_table rows", len(tab))
+
+
+def trainer_loss(net, x, y, w, criterion):
+    """train.py:828-846 restated around the reference model (train.py itself needs wandb/lightly)."""
+    ins_prediction, bag_prediction, _ = net(x)
+    if len(ins_prediction.shape) == 2:
+        max_prediction, _ = torch.max(ins_prediction, 0)
+    else:
+        max_prediction, _ = torch.max(ins_prediction, 1)
+    bag_loss = criterion(bag_prediction.view(1, -1), y.view(1, -1))
+    max_loss = criterion(max_prediction.view(1, -1), y.view(1, -1))
+    loss = w * bag_loss + (1 - w) * max_loss
+    with torch.no_grad():
+        bag_pred = ((1 - w) * torch.sigmoid(max_prediction) + w * torch.sigmoid(bag_prediction)).squeeze().cpu().numpy()
+    return bag_pred, loss, ins_prediction
+
+
+def run_f3_f4():
+    for name, N, D, h, lam, r, depth, act, seed, label in [
+        ("g_n600", 600, 64, 4, 50, 0.0, 1, "relu", 21, 1.0),
+        ("g_n900_d2", 900, 96, 6, 120, 0.25, 2, "gelu", 22, 0.0),
+        ("g_n300_selu", 300, 64, 2, 400, 0.0, 1, "selu", 23, 1.0),
+        ("g_n500_lrelu", 500, 64, 4, 64, 0.0, 1, "leakyrelu", 24, 0.0),
+    ]:
+        net = build_ref(ref_snuffy, D, 1, h, 4, act, 0.0, lam, r, depth, seed).eval()  # eval: dropouts off
+        g = torch.Generator().manual_seed(4321 + seed)
+        x = torch.randn(1, N, D, generator=g)
+        y = torch.tensor([label])
+        w = torch.tensor(0.5, requires_grad=True)
+        crit = torch.nn.BCEWithLogitsLoss()
+        rec, orig, wrapped = capture_choice()
+        np.random.seed(seed)
+        np.random.choice = wrapped
+        try:
+            bag_pred, loss, ins = trainer_loss(net, x, y, w, crit)
+        finally:
+            np.random.choice = orig
+        loss.backward()
+        out = dict(x=x.numpy(), y=y.numpy(), cfg=np.array([N, D, h, lam, depth, seed], dtype=np.int64),
+                   r=np.float64(r), act=np.array(act), loss=loss.detach().numpy(), bag_pred=np.array(bag_pred),
+                   ins_sigmoid=torch.sigmoid(ins.detach().view(-1, 1)).numpy(), w_grad=w.grad.numpy())
+        for li, rnd in enumerate(rec):
+            out[f"rnd{li}"] = rnd
+        out["n_rnd"] = np.int64(len(rec))
+        out.update(sd_to_np(net))
+        for k, p in net.named_parameters():
+            out["grad." + k] = p.grad.numpy().copy()
+        # F4: one AdamW step with the SmallWeightTrainer param groups (train.py:809-826), defaults of train.py:54-115
+        opt = torch.optim.AdamW(
+            params=[{"params": w, "lr": 2e-4 * 0.1}, {"params": net.parameters()}],
+            lr=2e-4, betas=(0.5, 0.9), weight_decay=5e-3)
+        opt.step()
+        with torch.no_grad():
+            w.data.clamp_(0, 1)
+        for k, p in net.named_parameters():
+            out["post." + k] = p.detach().numpy().copy()
+        out["post_w"] = w.detach().numpy().copy()
+        np.savez_compressed(os.path.join(HERE, f"f3_{name}.npz"), **out)
+        print(f"F3/F4 {name}: loss={float(loss):.6f} bag_pred={float(bag_pred):.6f}")
+
+
+def run_f5():
+    out = {}
+    g = np.random.RandomState(5)
+    feats = g.randn(37, 6).astype(np.float32)
+    out["feats"] = feats
+    for p in (0.0, 0.2, 0.5):
+        np.random.seed(11)
+        res = ref_utils.dropout_patches(feats, p)
+        out[f"out_p{p}"] = res
+        out[f"next_rand_p{p}"] = np.float64(np.random.rand())  # pins how much of the RNG stream was consumed
+    np.savez_compressed(os.path.join(HERE, "f5_loader.npz"), **out)
+    print("F5 done")
+
+
+def run_f6():
+    for name, B, N, D, h, lam, r, depth, seed in [
+        ("mc_b1_n100", 1, 100, 64, 4, 10, 0.0, 1, 31),
+        ("mc_b2_n60", 2, 60, 64, 2, 6, 0.3, 1, 32),
+        ("mc_b1_n8", 1, 8, 64, 2, 10, 0.0, 2, 33),
+        ("mc_b1_n400", 1, 400, 96, 6, 40, 0.5, 1, 34),
+    ]:
+        net = build_ref(ref_multi, D, 2, h, 4, "relu", 0.0, lam, r, depth, seed, multiclass=True).eval()
+        g = torch.Generator().manual_seed(999 + seed)
+        x = torch.randn(B, N, D, generator=g)
+        rec, orig, wrapped = capture_choice()
+        np.random.seed(seed)
+        np.random.choice = wrapped
+        try:
+            with torch.no_grad():
+                classes, logits, A = net(x)
+        finally:
+            np.random.choice = orig
+        out = dict(x=x.numpy(), classes=classes.numpy(), logits=logits.numpy(), A=A.numpy(),
+                   cfg=np.array([B, N, D, h, lam, depth, seed], dtype=np.int64), r=np.float64(r))
+        for li, rnd in enumerate(rec):
+            out[f"rnd{li}"] = rnd
+        out["n_rnd"] = np.int64(len(rec))
+        out.update(sd_to_np(net))
+        np.savez_compressed(os.path.join(HERE, f"f6_{name}.npz"), **out)
+        print(f"F6 {name}: K={A.shape[-1]} logits={logits.reshape(-1).tolist()}")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6"]
+    if "f1" in which:
+        run_f1()
+    if "f2" in which:
+        run_f2()
+    if "f3" in which:
+        run_f3_f4()
+    if "f5" in which:
+        run_f5()
+    if "f6" in which:
+        run_f6()
