@@ -1,0 +1,148 @@
+/*
+ * snuffy_hip.h -- C ABI of libsnuffy_hip.so: hand-written HIP (gfx950 / CDNA4) kernels for the hot path of
+ * jafarinia/snuffy: the sparse-attention MIL aggregator (snuffy.py) and, in later rounds, the ViT extractor.
+ *
+ * The reference has NO native layer: its boundary is the Python nn.Module API.  This header is
+ * the FFI a maintainer would bind *underneath* that API (INTEGRATION.md shows the ctypes stub).  Each entry point
+ * names the reference code it replaces (file:line, relative to the reference repo).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes; every buffer (inputs, outputs, workspace) is DEVICE memory owned by the caller;
+ *   - row-major, contiguous unless a leading dimension is passed; index tensors are int64 (torch.long);
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); never synchronises, never allocates;
+ *   - returns 0 on success, a negative SNF_E* code on failure; message via snf_last_error() (thread-local);
+ *   - stateless, re-entrant, thread-safe; results are deterministic run-to-run (no float atomics).
+ */
+#ifndef SNUFFY_HIP_H
+#define SNUFFY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* snf_stream_t; /* hipStream_t */
+
+#define SNF_OK 0
+#define SNF_EINVAL (-1)      /* bad argument (null pointer, unsupported shape) */
+#define SNF_ELAUNCH (-2)     /* hipLaunch / runtime error */
+#define SNF_EUNSUPPORTED (-3) /* shape outside what the fast kernel handles; caller picks the generic entry */
+#define SNF_EWORKSPACE (-4)  /* workspace too small */
+
+/* activation codes: PositionwiseFeedForward activation_dictionary, snuffy.py:215-221 */
+#define SNF_ACT_RELU 0
+#define SNF_ACT_GELU 1       /* erf form (nn.GELU default) */
+#define SNF_ACT_LEAKYRELU 2  /* slope 0.01 (nn.LeakyReLU default) */
+#define SNF_ACT_SELU 3
+#define SNF_ACT_NONE 4
+
+/* element types of q / v^T operands of the MFMA attention kernel */
+#define SNF_DT_F32 0
+#define SNF_DT_BF16 1
+
+const char* snf_version(void);
+const char* snf_last_error(void);
+/* Number of compute units of the current device (grid sizing on the host side); <0 on error. */
+int snf_device_cu_count(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K1  critic scores  c = x w^T + b            replaces FCLayer.forward, snuffy.py:39-41 (nn.Linear(D, C))
+ *     plus column max over the bag             replaces torch.max(ins_prediction, 1), train.py:831-834
+ *   x [n, d] f32, w [c_out, d], b [c_out] (nullable) -> scores [n, c_out]
+ *   colmax_val [c_out] f32 / colmax_idx [c_out] i64 nullable (first index on ties, as torch.max on CPU).
+ * --------------------------------------------------------------------------------------------------------- */
+int snf_critic_f32(const float* x, int64_t n, int d, const float* w, const float* b, int c_out, float* scores,
+                   float* colmax_val, int64_t* colmax_idx, snf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K2  top-k patch selector                    replaces torch.sort(c,1,descending=True)[:k], snuffy.py:128-130
+ *   scores: n values at stride `stride` (elements).  idx_out [k] int64: the k largest, in descending score
+ *   order, ties by ascending index (== torch.sort(stable=True, descending=True)[:k]); -0.0 == +0.0; NaN sorts
+ *   first like torch.  Requires 1 <= k <= n, k <= SNF_TOPK_MAX_K.  Chunked bitonic sort of 64-bit (score,index)
+ *   composites in LDS, repeated on the survivors (integer compare-exchange only: bit-exact on every run).
+ * K4  fused gather  xs[j,:] = x[idx[j],:]      replaces index_select/cat, snuffy.py:131,145-147,103-106
+ *   snf_topk_gather_f32 = selector then gather in one call (x, xs nullable -> selector only).
+ * --------------------------------------------------------------------------------------------------------- */
+#define SNF_TOPK_MAX_K 2048
+size_t snf_topk_workspace_bytes(int64_t n, int k); /* 0 when n <= 4096 */
+int snf_topk_f32(const float* scores, int64_t n, int64_t stride, int k, int64_t* idx_out, void* workspace,
+                 size_t workspace_bytes, snf_stream_t stream);
+int snf_topk_gather_f32(const float* scores, int64_t n, int64_t stride, int k, int64_t* idx_out, const float* x,
+                        int d, float* xs, void* workspace, size_t workspace_bytes, snf_stream_t stream);
+int snf_gather_rows_f32(const float* x, int64_t n, int d, const int64_t* idx, int k, float* out,
+                        snf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K9  scatter of the K updated rows            replaces y = x.clone(); y[:, S, :] = x_sel, snuffy.py:152-155
+ *   snf_scatter_rows_f32 : y = x (skipped when y == x) then y[idx[j],:] = rows[j,:]
+ *   snf_scatter_add_rows_f32 : z[idx[j],:] += delta[j,:]   (idx distinct)
+ *   snf_slot_map_i32 : map[i] = j if idx[j] == i else -1   (row -> slot lookup used by the fused row passes)
+ * --------------------------------------------------------------------------------------------------------- */
+int snf_scatter_rows_f32(const float* x, int64_t n, int d, const int64_t* idx, int k, const float* rows, float* y,
+                         snf_stream_t stream);
+int snf_scatter_add_rows_f32(float* z, int64_t n, int d, const int64_t* idx, int k, const float* delta,
+                             snf_stream_t stream);
+int snf_slot_map_i32(const int64_t* idx, int k, int64_t n, int32_t* map, snf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K5  LayerNorm over rows, with the K9 scatter fused into the read
+ *     replaces SublayerConnection.norm, snuffy.py:97,107,110 (nn.LayerNorm(size), eps 1e-5)
+ *   src row i = (slot_map && slot_map[i] >= 0) ? patch_rows[slot_map[i]] : x[i]      (slot_map nullable)
+ *   out = (src - mean) * rstd * gamma + beta   (gamma/beta nullable -> plain normalisation, affine folded into
+ *   the following GEMM's weights by the host).  Any of out_f32 / out_bf16 / mean / rstd may be null.
+ *   out_row_idx (nullable): output row of input row i is out_row_idx[i] (re-normalising the K patched rows in place).
+ * --------------------------------------------------------------------------------------------------------- */
+int snf_layernorm_rows_f32(const float* x, int64_t n, int d, const int32_t* slot_map, const float* patch_rows,
+                           const float* gamma, const float* beta, float eps, float* out_f32, void* out_bf16,
+                           float* mean, float* rstd, const int64_t* out_row_idx, snf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K10 epilogue  h = act(h + bias) in place     replaces activation(w_1(x)) of snuffy.py:224-225
+ *   h [n, f] f32 or bf16 (dtype = SNF_DT_*), bias [f] f32 nullable.
+ * --------------------------------------------------------------------------------------------------------- */
+int snf_bias_act(void* h, int dtype, int64_t n, int f, const float* bias, int act, snf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K11 head: logits = W_head * mean_n(LayerNorm_f(z)) + b_head
+ *     replaces Encoder.norm + x.mean(dim=1) + BClassifier.linear, snuffy.py:86,71
+ *   row value = z[i] (+ add_bf16[i]) (+ add_bias) (+ delta_rows[slot_map[i]] when slot_map[i] >= 0): the FFN
+ *   residual  z = y + W2(...) + b2  of snuffy.py:110 and the K9 scatter are fused into this read; z_out (nullable)
+ *   receives the assembled rows (needed only when another layer follows).
+ *   workspace: snf_ln_mean_head_workspace_bytes(d) bytes.  pooled [d] nullable output (= mean_n LN(z) before the
+ *   head).  Deterministic two-stage column reduction.
+ * --------------------------------------------------------------------------------------------------------- */
+size_t snf_ln_mean_head_workspace_bytes(int d);
+int snf_ln_mean_head_f32(const float* z, int64_t n, int d, const void* add_bf16, const float* add_bias,
+                         const int32_t* slot_map, const float* delta_rows, float* z_out, const float* gamma,
+                         const float* beta, float eps, const float* w_head, const float* b_head, int c_out,
+                         float* logits, float* pooled, void* workspace, size_t workspace_bytes, snf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K7  sparse attention forward                 replaces attention(), snuffy.py:160-168 (+ head split/merge of
+ *                                              MultiHeadedAttention.forward, snuffy.py:187-203)
+ *   For every head a (column block a*dk..(a+1)*dk):
+ *       P_a = softmax_j( Q_a Kp_a^T * scale )   [n, k]   softmax over the k selected keys
+ *       O_a = P_a^T V_a                         [k, dk]
+ *   out [k, d] = heads concatenated.  attn [h, n, k] f32 (nullable) = P;  lse [h, n] f32 (nullable) =
+ *   log-sum-exp of the scaled scores (saved for backward).
+ *
+ *   snf_sparse_attn_fwd_f32 : exact fp32 arithmetic, any n/k/h/dk.  q, v [n, d]; kp [k, d].
+ *   snf_sparse_attn_fwd_mfma: bf16 MFMA (fp32 accumulate), softmax in fp32.  q [n, d] row-major,
+ *       vt = V TRANSPOSED [d, ldv] (ldv >= n, multiple of 8), both of dtype qv_dtype (f32 converted in
+ *       registers, or bf16); kp [k, d] f32.  Supported: dk in {64, 128}, k <= 256.  Otherwise SNF_EUNSUPPORTED.
+ *   workspace: deterministic cross-workgroup reduction of the [h, k, dk] accumulators.
+ * --------------------------------------------------------------------------------------------------------- */
+size_t snf_sparse_attn_fwd_workspace_bytes(int64_t n, int k, int h, int dk, int mfma);
+int snf_sparse_attn_fwd_f32(const float* q, const float* kp, const float* v, int64_t n, int k, int h, int dk,
+                            float scale, float* out, float* attn, float* lse, void* workspace,
+                            size_t workspace_bytes, snf_stream_t stream);
+int snf_sparse_attn_fwd_mfma(const void* q, const void* vt, int qv_dtype, int64_t ldv, const float* kp, int64_t n,
+                             int k, int h, int dk, float scale, float* out, float* attn, float* lse,
+                             void* workspace, size_t workspace_bytes, snf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNUFFY_HIP_H */

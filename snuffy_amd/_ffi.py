@@ -1,0 +1,85 @@
+"""ctypes binding of libsnuffy_hip.so (the C ABI of include/snuffy_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, this raises.  (The CPU oracle under oracle/ is test
+infrastructure and is never imported from here.)
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsnuffy_hip.so")
+
+SNF_OK = 0
+SNF_EINVAL = -1
+SNF_ELAUNCH = -2
+SNF_EUNSUPPORTED = -3
+SNF_EWORKSPACE = -4
+
+ACT_CODES = {"relu": 0, "gelu": 1, "leakyrelu": 2, "selu": 3, "none": 4}
+DT_F32 = 0
+DT_BF16 = 1
+TOPK_MAX_K = 2048
+
+# name -> (restype, argtypes); mirrors include/snuffy_hip.h one to one
+SIGNATURES = {
+    "snf_version": (c_char_p, []),
+    "snf_last_error": (c_char_p, []),
+    "snf_device_cu_count": (c_int, []),
+    "snf_critic_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                               c_void_p]),
+    "snf_topk_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "snf_topk_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "snf_topk_gather_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                    c_size_t, c_void_p]),
+    "snf_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "snf_scatter_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "snf_scatter_add_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "snf_slot_map_i32": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "snf_layernorm_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "snf_bias_act": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p]),
+    "snf_ln_mean_head_workspace_bytes": (c_size_t, [c_int]),
+    "snf_ln_mean_head_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
+    "snf_sparse_attn_fwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
+    "snf_sparse_attn_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "snf_sparse_attn_fwd_mfma": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
+                                         c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+}
+
+_lib = None
+
+
+class SnuffyHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once). Raises SnuffyHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SnuffyHipError(
+            "libsnuffy_hip.so not found at %s -- build it with `python -m snuffy_amd.build` "
+            "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != SNF_OK:
+        msg = load().snf_last_error()
+        raise SnuffyHipError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def version():
+    return load().snf_version().decode()

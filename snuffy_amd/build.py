@@ -1,0 +1,69 @@
+"""Build libsnuffy_hip.so (hand-written HIP for gfx950) in-tree with hipcc.  No torch, no cmake: plain C ABI."""
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libsnuffy_hip.so")
+OBJDIR = os.path.join(HERE, "build")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-result"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: cannot build libsnuffy_hip.so")
+    return exe
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "snuffy_hip.h"))
+    return max(os.path.getmtime(d) for d in deps)
+
+
+def _compile(src, force, hdr_mtime):
+    obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
+            and os.path.getmtime(obj) >= hdr_mtime):
+        return obj, False
+    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    return obj, True
+
+
+def build_lib(force=False, verbose=False, jobs=4):
+    os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    hdr = _deps_mtime()
+    srcs = sources()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+        res = list(ex.map(lambda s: _compile(s, force, hdr), srcs))
+    objs = [o for o, _ in res]
+    rebuilt = any(c for _, c in res)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("built", LIB)
+    elif verbose:
+        print("up to date:", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_lib(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,692 @@
+// Row-wise HBM-bound kernels of the Snuffy aggregator: critic GEMV (+ column max), LayerNorm with fused row patch,
+// gather / scatter of the K selected rows, bias+activation epilogue, LayerNorm + mean-pool + head.
+//
+// Layout: one 64-lane wave owns one row at a time (4 rows per 256-thread workgroup, grid-stride over rows);
+// a lane holds NV vectors of VEC floats of its row in registers (coalesced 16-B loads when d % 4 == 0), so every
+// row is read from HBM exactly once per pass.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int WG = 256;
+constexpr int WAVES = WG / 64;
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<4> {
+    using type = float4;
+};
+template <>
+struct VecT<1> {
+    using type = float;
+};
+
+template <int VEC, int NV>
+struct RowRegs {
+    float v[NV * VEC];
+};
+
+// load a row (d floats) into registers: element e = (i*64 + lane)*VEC + t; out-of-range -> 0
+template <int VEC, int NV>
+__device__ __forceinline__ void load_row(const float* __restrict__ row, int d, int lane, float (&r)[NV * VEC]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int e = (i * 64 + lane) * VEC;
+        if constexpr (VEC == 4) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < d) t = *reinterpret_cast<const float4*>(row + e);
+            r[i * 4 + 0] = t.x;
+            r[i * 4 + 1] = t.y;
+            r[i * 4 + 2] = t.z;
+            r[i * 4 + 3] = t.w;
+        } else {
+            r[i] = (e < d) ? row[e] : 0.f;
+        }
+    }
+}
+
+template <int VEC, int NV>
+__device__ __forceinline__ void store_row_f32(float* __restrict__ row, int d, int lane, const float (&r)[NV * VEC]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int e = (i * 64 + lane) * VEC;
+        if (e < d) {
+            if constexpr (VEC == 4) {
+                *reinterpret_cast<float4*>(row + e) = make_float4(r[i * 4], r[i * 4 + 1], r[i * 4 + 2], r[i * 4 + 3]);
+            } else {
+                row[e] = r[i];
+            }
+        }
+    }
+}
+
+template <int VEC, int NV>
+__device__ __forceinline__ void store_row_bf16(unsigned short* __restrict__ row, int d, int lane,
+                                               const float (&r)[NV * VEC]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int e = (i * 64 + lane) * VEC;
+        if (e < d) {
+            if constexpr (VEC == 4) {
+                uint2 p;
+                p.x = pack_bf16x2(r[i * 4], r[i * 4 + 1]);
+                p.y = pack_bf16x2(r[i * 4 + 2], r[i * 4 + 3]);
+                *reinterpret_cast<uint2*>(row + e) = p;
+            } else {
+                row[e] = f32_to_bf16_bits(r[i]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1 critic: scores[i, c] = x[i,:] . w[c,:] + b[c]          (FCLayer.forward, snuffy.py:39-41)
+// ---------------------------------------------------------------------------------------------------------------
+template <int VEC, int NV>
+__global__ __launch_bounds__(WG) void critic_kernel(const float* __restrict__ x, int64_t n, int d,
+                                                    const float* __restrict__ w, const float* __restrict__ b,
+                                                    int c_out, float* __restrict__ scores) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int64_t row = (int64_t)blockIdx.x * WAVES + wave; row < n; row += (int64_t)gridDim.x * WAVES) {
+        float r[NV * VEC];
+        load_row<VEC, NV>(x + row * d, d, lane, r);
+        for (int c = 0; c < c_out; ++c) {
+            float wr[NV * VEC];
+            load_row<VEC, NV>(w + (int64_t)c * d, d, lane, wr);
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV * VEC; ++i) acc = fmaf(r[i], wr[i], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) scores[row * c_out + c] = acc + (b ? b[c] : 0.f);
+        }
+    }
+}
+
+// column max + first index of the max (torch.max(ins_prediction, 1), train.py:831-834). One workgroup per class.
+__global__ __launch_bounds__(1024) void colmax_kernel(const float* __restrict__ scores, int64_t n, int c_out,
+                                                      float* __restrict__ out_val, int64_t* __restrict__ out_idx) {
+    const int c = blockIdx.x;
+    float best = -INFINITY;
+    int64_t bi = INT64_MAX;
+    bool has_nan = false;
+    int64_t nan_i = INT64_MAX;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = scores[i * c_out + c];
+        if (v != v) {
+            if (!has_nan) nan_i = i;
+            has_nan = true;
+        } else if (v > best || (v == best && i < bi)) {
+            best = v;
+            bi = i;
+        }
+    }
+    __shared__ float sv[1024];
+    __shared__ int64_t si[1024];
+    __shared__ int64_t sn[1024];
+    sv[threadIdx.x] = best;
+    si[threadIdx.x] = bi;
+    sn[threadIdx.x] = has_nan ? nan_i : INT64_MAX;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            float ov = sv[threadIdx.x + s];
+            int64_t oi = si[threadIdx.x + s];
+            if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) {
+                sv[threadIdx.x] = ov;
+                si[threadIdx.x] = oi;
+            }
+            if (sn[threadIdx.x + s] < sn[threadIdx.x]) sn[threadIdx.x] = sn[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (sn[0] != INT64_MAX) {  // NaN propagates like torch.max
+            if (out_val) out_val[c] = NAN;
+            if (out_idx) out_idx[c] = sn[0];
+        } else {
+            if (out_val) out_val[c] = sv[0];
+            if (out_idx) out_idx[c] = si[0];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K5 LayerNorm rows with fused patch-row read (snuffy.py:97,107,110 + 152-155)
+// ---------------------------------------------------------------------------------------------------------------
+template <int VEC, int NV>
+__global__ __launch_bounds__(WG) void layernorm_rows_kernel(const float* __restrict__ x, int64_t n, int d,
+                                                            const int32_t* __restrict__ slot_map,
+                                                            const float* __restrict__ patch_rows,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            float* __restrict__ out_f32,
+                                                            unsigned short* __restrict__ out_bf16,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            const int64_t* __restrict__ out_row_idx) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float g[NV * VEC], bt[NV * VEC];
+    if (gamma) load_row<VEC, NV>(gamma, d, lane, g);
+    if (beta) load_row<VEC, NV>(beta, d, lane, bt);
+    const float inv_d = 1.0f / (float)d;
+    for (int64_t row = (int64_t)blockIdx.x * WAVES + wave; row < n; row += (int64_t)gridDim.x * WAVES) {
+        const float* src = x + row * d;
+        if (slot_map) {
+            int s = slot_map[row];
+            if (s >= 0) src = patch_rows + (int64_t)s * d;
+        }
+        float r[NV * VEC];
+        load_row<VEC, NV>(src, d, lane, r);
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV * VEC; ++i) s1 += r[i];
+        const float mean = wave_sum(s1) * inv_d;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) {
+                int e = (i * 64 + lane) * VEC + t;
+                float dv = (e < d) ? (r[i * VEC + t] - mean) : 0.f;
+                s2 = fmaf(dv, dv, s2);
+            }
+        }
+        const float var = wave_sum(s2) * inv_d;
+        const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int i = 0; i < NV * VEC; ++i) {
+            float v = (r[i] - mean) * rstd;
+            if (gamma) v *= g[i];
+            if (beta) v += bt[i];
+            r[i] = v;
+        }
+        const int64_t orow = out_row_idx ? out_row_idx[row] : row;
+        if (out_f32) store_row_f32<VEC, NV>(out_f32 + orow * d, d, lane, r);
+        if (out_bf16) store_row_bf16<VEC, NV>(out_bf16 + orow * d, d, lane, r);
+        if (lane == 0) {
+            if (mean_out) mean_out[orow] = mean;
+            if (rstd_out) rstd_out[orow] = rstd;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gather / scatter of the K selected rows
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void gather_rows_kernel(const float* __restrict__ x, int64_t n, int d,
+                                                         const int64_t* __restrict__ idx, int k,
+                                                         float* __restrict__ out) {
+    const int j = blockIdx.x;
+    if (j >= k) return;
+    int64_t src = idx[j];
+    if (src < 0 || src >= n) return;  // guarded on the host in debug paths; never write garbage
+    const float* s = x + src * d;
+    float* o = out + (int64_t)j * d;
+    for (int e = threadIdx.x; e < d; e += blockDim.x) o[e] = s[e];
+}
+
+__global__ __launch_bounds__(WG) void copy_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t total) {
+    int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (; i4 + 3 < total; i4 += stride) *reinterpret_cast<float4*>(y + i4) = *reinterpret_cast<const float4*>(x + i4);
+    // tail (total % 4) handled by the last thread range
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int64_t i = total & ~(int64_t)3; i < total; ++i) y[i] = x[i];
+    }
+}
+
+template <bool ADD>
+__global__ __launch_bounds__(WG) void scatter_rows_kernel(float* __restrict__ y, int64_t n, int d,
+                                                          const int64_t* __restrict__ idx, int k,
+                                                          const float* __restrict__ rows) {
+    const int j = blockIdx.x;
+    if (j >= k) return;
+    int64_t dst = idx[j];
+    if (dst < 0 || dst >= n) return;
+    float* o = y + dst * d;
+    const float* s = rows + (int64_t)j * d;
+    for (int e = threadIdx.x; e < d; e += blockDim.x) {
+        if (ADD)
+            o[e] += s[e];
+        else
+            o[e] = s[e];
+    }
+}
+
+__global__ void fill_i32_kernel(int32_t* __restrict__ p, int64_t n, int32_t v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void slot_map_kernel(const int64_t* __restrict__ idx, int k, int64_t n, int32_t* __restrict__ map) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < k) {
+        int64_t i = idx[j];
+        if (i >= 0 && i < n) map[i] = j;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K10 epilogue: h = act(h + bias)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case SNF_ACT_RELU:
+            return fmaxf(v, 0.f);
+        case SNF_ACT_GELU:
+            return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case SNF_ACT_LEAKYRELU:
+            return v > 0.f ? v : 0.01f * v;
+        case SNF_ACT_SELU: {
+            const float alpha = 1.6732632423543772848170429916717f, scale = 1.0507009873554804934193349852946f;
+            return scale * (v > 0.f ? v : alpha * expm1f(v));
+        }
+        default:
+            return v;
+    }
+}
+
+__global__ __launch_bounds__(WG) void bias_act_f32_kernel(float* __restrict__ h, int64_t n, int f,
+                                                          const float* __restrict__ bias, int act) {
+    const int64_t total = n * (int64_t)f;
+    if ((f & 3) == 0) {
+        for (int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i4 < total;
+             i4 += (int64_t)gridDim.x * blockDim.x * 4) {
+            float4 v = *reinterpret_cast<float4*>(h + i4);
+            int col = (int)(i4 % f);
+            if (bias) {
+                float4 bb = *reinterpret_cast<const float4*>(bias + col);
+                v.x += bb.x;
+                v.y += bb.y;
+                v.z += bb.z;
+                v.w += bb.w;
+            }
+            v.x = apply_act(v.x, act);
+            v.y = apply_act(v.y, act);
+            v.z = apply_act(v.z, act);
+            v.w = apply_act(v.w, act);
+            *reinterpret_cast<float4*>(h + i4) = v;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            float v = h[i] + (bias ? bias[i % f] : 0.f);
+            h[i] = apply_act(v, act);
+        }
+    }
+}
+
+__global__ __launch_bounds__(WG) void bias_act_bf16_kernel(unsigned short* __restrict__ h, int64_t n, int f,
+                                                           const float* __restrict__ bias, int act) {
+    const int64_t total = n * (int64_t)f;
+    if ((f & 7) == 0) {
+        for (int64_t i8 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i8 < total;
+             i8 += (int64_t)gridDim.x * blockDim.x * 8) {
+            uint4 p = *reinterpret_cast<uint4*>(h + i8);
+            unsigned int w[4] = {p.x, p.y, p.z, p.w};
+            int col = (int)(i8 % f);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float lo = __uint_as_float(w[t] << 16), hi = __uint_as_float(w[t] & 0xffff0000u);
+                if (bias) {
+                    lo += bias[col + 2 * t];
+                    hi += bias[col + 2 * t + 1];
+                }
+                w[t] = pack_bf16x2(apply_act(lo, act), apply_act(hi, act));
+            }
+            *reinterpret_cast<uint4*>(h + i8) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            float v = bf16_bits_to_f32(h[i]) + (bias ? bias[i % f] : 0.f);
+            h[i] = f32_to_bf16_bits(apply_act(v, act));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K11 head: stage 1 -- per-workgroup column sums of the normalised rows; stage 2 -- fixed-order reduction, affine,
+// mean, GEMV with the head.
+// ---------------------------------------------------------------------------------------------------------------
+template <int VEC, int NV>
+__device__ __forceinline__ void add_row_bf16(const unsigned short* __restrict__ row, int d, int lane, float (&r)[NV * VEC]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int e = (i * 64 + lane) * VEC;
+        if (e < d) {
+            if constexpr (VEC == 4) {
+                uint2 p = *reinterpret_cast<const uint2*>(row + e);
+                r[i * 4 + 0] += __uint_as_float(p.x << 16);
+                r[i * 4 + 1] += __uint_as_float(p.x & 0xffff0000u);
+                r[i * 4 + 2] += __uint_as_float(p.y << 16);
+                r[i * 4 + 3] += __uint_as_float(p.y & 0xffff0000u);
+            } else {
+                r[i] += bf16_bits_to_f32(row[e]);
+            }
+        }
+    }
+}
+
+template <int VEC, int NV>
+__global__ __launch_bounds__(WG) void ln_colsum_kernel(const float* __restrict__ z, int64_t n, int d, float eps,
+                                                       const unsigned short* __restrict__ add_bf16,
+                                                       const float* __restrict__ add_bias,
+                                                       const int32_t* __restrict__ slot_map,
+                                                       const float* __restrict__ delta_rows,
+                                                       float* __restrict__ z_out,
+                                                       float* __restrict__ partial /*[grid, d]*/) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float acc[NV * VEC];
+#pragma unroll
+    for (int i = 0; i < NV * VEC; ++i) acc[i] = 0.f;
+    float bias_r[NV * VEC];
+    if (add_bias) load_row<VEC, NV>(add_bias, d, lane, bias_r);
+    const float inv_d = 1.0f / (float)d;
+    for (int64_t row = (int64_t)blockIdx.x * WAVES + wave; row < n; row += (int64_t)gridDim.x * WAVES) {
+        float r[NV * VEC];
+        load_row<VEC, NV>(z + row * d, d, lane, r);
+        if (add_bf16) add_row_bf16<VEC, NV>(add_bf16 + row * d, d, lane, r);
+        if (add_bias) {
+#pragma unroll
+            for (int i = 0; i < NV * VEC; ++i) r[i] += bias_r[i];
+        }
+        if (slot_map) {
+            int sl = slot_map[row];
+            if (sl >= 0) {
+                float dr[NV * VEC];
+                load_row<VEC, NV>(delta_rows + (int64_t)sl * d, d, lane, dr);
+#pragma unroll
+                for (int i = 0; i < NV * VEC; ++i) r[i] += dr[i];
+            }
+        }
+        if (z_out) store_row_f32<VEC, NV>(z_out + row * d, d, lane, r);
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV * VEC; ++i) s1 += r[i];
+        const float mean = wave_sum(s1) * inv_d;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) {
+                int e = (i * 64 + lane) * VEC + t;
+                float dv = (e < d) ? (r[i * VEC + t] - mean) : 0.f;
+                s2 = fmaf(dv, dv, s2);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) * inv_d + eps);
+#pragma unroll
+        for (int i = 0; i < NV * VEC; ++i) acc[i] += (r[i] - mean) * rstd;
+    }
+    // combine the 4 waves of the workgroup in a fixed order through LDS
+    extern __shared__ float lds[];  // [WAVES][NV*VEC*64]
+    float* mine = lds + wave * (NV * VEC * 64);
+#pragma unroll
+    for (int i = 0; i < NV * VEC; ++i) mine[i * 64 + lane] = acc[i];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) {
+                float s = 0.f;
+                for (int w2 = 0; w2 < WAVES; ++w2) s += lds[w2 * (NV * VEC * 64) + (i * VEC + t) * 64 + lane];
+                int e = (i * 64 + lane) * VEC + t;
+                if (e < d) partial[(int64_t)blockIdx.x * d + e] = s;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void ln_head_finalize_kernel(const float* __restrict__ partial, int nparts,
+                                                                int64_t n, int d, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                const float* __restrict__ w_head,
+                                                                const float* __restrict__ b_head, int c_out,
+                                                                float* __restrict__ pooled_ws /*[d]*/,
+                                                                float* __restrict__ pooled_out,
+                                                                float* __restrict__ logits) {
+    const float inv_n = 1.0f / (float)n;
+    for (int e = threadIdx.x; e < d; e += blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * d + e];
+        float m = s * inv_n;
+        float v = (gamma ? gamma[e] : 1.f) * m + (beta ? beta[e] : 0.f);
+        pooled_ws[e] = v;
+        if (pooled_out) pooled_out[e] = v;
+    }
+    __syncthreads();
+    __shared__ float red[1024];
+    for (int c = 0; c < c_out; ++c) {
+        float acc = 0.f;
+        for (int e = threadIdx.x; e < d; e += blockDim.x) acc = fmaf(w_head[(int64_t)c * d + e], pooled_ws[e], acc);
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int s = 512; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) logits[c] = red[0] + (b_head ? b_head[c] : 0.f);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host-side dispatch helpers
+// ---------------------------------------------------------------------------------------------------------------
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// picks (VEC, NV) for a row width d; returns false if d is too wide for the register-resident row kernels
+struct RowCfg {
+    int vec, nv;
+};
+inline bool pick_row_cfg(int d, bool all_aligned, RowCfg* cfg) {
+    if ((d & 3) == 0 && all_aligned) {
+        int need = (d / 4 + 63) / 64;
+        const int opts[] = {1, 2, 3, 4, 6, 8};
+        for (int o : opts)
+            if (o >= need) {
+                *cfg = {4, o};
+                return true;
+            }
+        return false;
+    }
+    int need = (d + 63) / 64;
+    const int opts[] = {1, 2, 3, 4, 8, 16, 32};
+    for (int o : opts)
+        if (o >= need) {
+            *cfg = {1, o};
+            return true;
+        }
+    return false;
+}
+
+inline int row_grid(int64_t n) {
+    int64_t want = (n + WAVES - 1) / WAVES;
+    int64_t cap = (int64_t)snf::cu_count() * 8;
+    return (int)(want < cap ? (want > 0 ? want : 1) : cap);
+}
+
+#define SNF_ROW_DISPATCH(cfg, ...)                                \
+    do {                                                          \
+        if (cfg.vec == 4) {                                       \
+            switch (cfg.nv) {                                     \
+                case 1: { constexpr int VEC = 4, NV = 1; __VA_ARGS__; } break; \
+                case 2: { constexpr int VEC = 4, NV = 2; __VA_ARGS__; } break; \
+                case 3: { constexpr int VEC = 4, NV = 3; __VA_ARGS__; } break; \
+                case 4: { constexpr int VEC = 4, NV = 4; __VA_ARGS__; } break; \
+                case 6: { constexpr int VEC = 4, NV = 6; __VA_ARGS__; } break; \
+                default: { constexpr int VEC = 4, NV = 8; __VA_ARGS__; } break; \
+            }                                                     \
+        } else {                                                  \
+            switch (cfg.nv) {                                     \
+                case 1: { constexpr int VEC = 1, NV = 1; __VA_ARGS__; } break; \
+                case 2: { constexpr int VEC = 1, NV = 2; __VA_ARGS__; } break; \
+                case 3: { constexpr int VEC = 1, NV = 3; __VA_ARGS__; } break; \
+                case 4: { constexpr int VEC = 1, NV = 4; __VA_ARGS__; } break; \
+                case 8: { constexpr int VEC = 1, NV = 8; __VA_ARGS__; } break; \
+                case 16: { constexpr int VEC = 1, NV = 16; __VA_ARGS__; } break; \
+                default: { constexpr int VEC = 1, NV = 32; __VA_ARGS__; } break; \
+            }                                                     \
+        }                                                         \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int snf_critic_f32(const float* x, int64_t n, int d, const float* w, const float* b, int c_out, float* scores,
+                   float* colmax_val, int64_t* colmax_idx, snf_stream_t stream) {
+    SNF_REQUIRE(x && w && scores, "snf_critic_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && d >= 1 && c_out >= 1, "snf_critic_f32: bad shape n=%lld d=%d c=%d", (long long)n, d, c_out);
+    RowCfg cfg;
+    SNF_REQUIRE(pick_row_cfg(d, aligned16(x) && aligned16(w), &cfg), "snf_critic_f32: d=%d too wide (max 2048)", d);
+    hipStream_t s = snf::as_stream(stream);
+    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((critic_kernel<VEC, NV>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w, b,
+                                              c_out, scores));
+    int rc = snf::check_launch("critic_kernel");
+    if (rc) return rc;
+    if (colmax_val || colmax_idx) {
+        hipLaunchKernelGGL(colmax_kernel, dim3(c_out), dim3(1024), 0, s, scores, n, c_out, colmax_val, colmax_idx);
+        rc = snf::check_launch("colmax_kernel");
+    }
+    return rc;
+}
+
+int snf_layernorm_rows_f32(const float* x, int64_t n, int d, const int32_t* slot_map, const float* patch_rows,
+                           const float* gamma, const float* beta, float eps, float* out_f32, void* out_bf16,
+                           float* mean, float* rstd, const int64_t* out_row_idx, snf_stream_t stream) {
+    SNF_REQUIRE(x, "snf_layernorm_rows_f32: null x");
+    SNF_REQUIRE(n >= 1 && d >= 1, "snf_layernorm_rows_f32: bad shape");
+    SNF_REQUIRE(!slot_map || patch_rows, "snf_layernorm_rows_f32: slot_map without patch_rows");
+    bool al = aligned16(x) && (!patch_rows || aligned16(patch_rows)) && (!gamma || aligned16(gamma)) &&
+              (!beta || aligned16(beta)) && (!out_f32 || aligned16(out_f32)) && (!out_bf16 || aligned16(out_bf16));
+    RowCfg cfg;
+    SNF_REQUIRE(pick_row_cfg(d, al, &cfg), "snf_layernorm_rows_f32: d=%d too wide (max 2048)", d);
+    hipStream_t s = snf::as_stream(stream);
+    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((layernorm_rows_kernel<VEC, NV>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d,
+                                              slot_map, patch_rows, gamma, beta, eps, out_f32,
+                                              reinterpret_cast<unsigned short*>(out_bf16), mean, rstd, out_row_idx));
+    return snf::check_launch("layernorm_rows_kernel");
+}
+
+int snf_gather_rows_f32(const float* x, int64_t n, int d, const int64_t* idx, int k, float* out, snf_stream_t stream) {
+    SNF_REQUIRE(x && idx && out, "snf_gather_rows_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && d >= 1 && k >= 0, "snf_gather_rows_f32: bad shape");
+    if (k == 0) return SNF_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(k), dim3(WG), 0, snf::as_stream(stream), x, n, d, idx, k, out);
+    return snf::check_launch("gather_rows_kernel");
+}
+
+int snf_scatter_rows_f32(const float* x, int64_t n, int d, const int64_t* idx, int k, const float* rows, float* y,
+                         snf_stream_t stream) {
+    SNF_REQUIRE(x && y && (k == 0 || (idx && rows)), "snf_scatter_rows_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && d >= 1 && k >= 0, "snf_scatter_rows_f32: bad shape");
+    hipStream_t s = snf::as_stream(stream);
+    if (x != y) {
+        const int64_t total = n * (int64_t)d;
+        if (aligned16(x) && aligned16(y)) {
+            int64_t want = (total / 4 + WG - 1) / WG;
+            int grid = (int)(want < (int64_t)snf::cu_count() * 8 ? (want > 0 ? want : 1) : (int64_t)snf::cu_count() * 8);
+            hipLaunchKernelGGL(copy_f32_kernel, dim3(grid), dim3(WG), 0, s, x, y, total);
+            int rc = snf::check_launch("copy_f32_kernel");
+            if (rc) return rc;
+        } else {
+            if (hipMemcpyAsync(y, x, total * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+                snf::set_error("snf_scatter_rows_f32: hipMemcpyAsync failed");
+                return SNF_ELAUNCH;
+            }
+        }
+    }
+    if (k == 0) return SNF_OK;
+    hipLaunchKernelGGL(scatter_rows_kernel<false>, dim3(k), dim3(WG), 0, s, y, n, d, idx, k, rows);
+    return snf::check_launch("scatter_rows_kernel");
+}
+
+int snf_scatter_add_rows_f32(float* z, int64_t n, int d, const int64_t* idx, int k, const float* delta,
+                             snf_stream_t stream) {
+    SNF_REQUIRE(z && (k == 0 || (idx && delta)), "snf_scatter_add_rows_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && d >= 1 && k >= 0, "snf_scatter_add_rows_f32: bad shape");
+    if (k == 0) return SNF_OK;
+    hipLaunchKernelGGL(scatter_rows_kernel<true>, dim3(k), dim3(WG), 0, snf::as_stream(stream), z, n, d, idx, k, delta);
+    return snf::check_launch("scatter_add_rows_kernel");
+}
+
+int snf_slot_map_i32(const int64_t* idx, int k, int64_t n, int32_t* map, snf_stream_t stream) {
+    SNF_REQUIRE(map && (k == 0 || idx), "snf_slot_map_i32: null pointer");
+    SNF_REQUIRE(n >= 1 && k >= 0, "snf_slot_map_i32: bad shape");
+    hipStream_t s = snf::as_stream(stream);
+    int64_t want = (n + 255) / 256;
+    int grid = (int)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(grid), dim3(256), 0, s, map, n, -1);
+    int rc = snf::check_launch("fill_i32_kernel");
+    if (rc || k == 0) return rc;
+    hipLaunchKernelGGL(slot_map_kernel, dim3((k + 255) / 256), dim3(256), 0, s, idx, k, n, map);
+    return snf::check_launch("slot_map_kernel");
+}
+
+int snf_bias_act(void* h, int dtype, int64_t n, int f, const float* bias, int act, snf_stream_t stream) {
+    SNF_REQUIRE(h, "snf_bias_act: null h");
+    SNF_REQUIRE(n >= 1 && f >= 1, "snf_bias_act: bad shape");
+    SNF_REQUIRE(act >= SNF_ACT_RELU && act <= SNF_ACT_NONE, "snf_bias_act: unknown activation %d", act);
+    SNF_REQUIRE(dtype == SNF_DT_F32 || dtype == SNF_DT_BF16, "snf_bias_act: unknown dtype %d", dtype);
+    SNF_REQUIRE(aligned16(h) && (!bias || aligned16(bias)), "snf_bias_act: buffers must be 16-byte aligned");
+    const int64_t total = n * (int64_t)f;
+    const int per = dtype == SNF_DT_F32 ? 4 : 8;
+    int64_t want = (total / per + WG - 1) / WG;
+    int64_t cap = (int64_t)snf::cu_count() * 8;
+    int grid = (int)(want < cap ? (want > 0 ? want : 1) : cap);
+    hipStream_t s = snf::as_stream(stream);
+    if (dtype == SNF_DT_F32)
+        hipLaunchKernelGGL(bias_act_f32_kernel, dim3(grid), dim3(WG), 0, s, reinterpret_cast<float*>(h), n, f, bias, act);
+    else
+        hipLaunchKernelGGL(bias_act_bf16_kernel, dim3(grid), dim3(WG), 0, s, reinterpret_cast<unsigned short*>(h), n, f,
+                           bias, act);
+    return snf::check_launch("bias_act_kernel");
+}
+
+static int ln_head_parts(int64_t n) {
+    int64_t want = (n + WAVES - 1) / WAVES;
+    int64_t cap = (int64_t)snf::cu_count() * 4;
+    return (int)(want < cap ? (want > 0 ? want : 1) : cap);
+}
+
+size_t snf_ln_mean_head_workspace_bytes(int d) {
+    if (d < 1) return 0;
+    // worst-case number of partial rows (cu_count*4) + one pooled row
+    return ((size_t)snf::cu_count() * 4 + 1) * (size_t)d * sizeof(float);
+}
+
+int snf_ln_mean_head_f32(const float* z, int64_t n, int d, const void* add_bf16, const float* add_bias,
+                         const int32_t* slot_map, const float* delta_rows, float* z_out, const float* gamma,
+                         const float* beta, float eps, const float* w_head, const float* b_head, int c_out, float* logits,
+                         float* pooled, void* workspace, size_t workspace_bytes, snf_stream_t stream) {
+    SNF_REQUIRE(z && w_head && logits && workspace, "snf_ln_mean_head_f32: null pointer");
+    SNF_REQUIRE(!slot_map || delta_rows, "snf_ln_mean_head_f32: slot_map without delta_rows");
+    SNF_REQUIRE(n >= 1 && d >= 1 && c_out >= 1, "snf_ln_mean_head_f32: bad shape");
+    const int parts = ln_head_parts(n);
+    if (workspace_bytes < ((size_t)parts + 1) * d * sizeof(float)) {
+        snf::set_error("snf_ln_mean_head_f32: workspace %zu < %zu", workspace_bytes, ((size_t)parts + 1) * d * sizeof(float));
+        return SNF_EWORKSPACE;
+    }
+    RowCfg cfg;
+    const bool al = aligned16(z) && (!add_bf16 || aligned16(add_bf16)) && (!add_bias || aligned16(add_bias)) &&
+                    (!delta_rows || aligned16(delta_rows)) && (!z_out || aligned16(z_out));
+    SNF_REQUIRE(pick_row_cfg(d, al, &cfg), "snf_ln_mean_head_f32: d=%d too wide (max 2048)", d);
+    hipStream_t s = snf::as_stream(stream);
+    float* partial = reinterpret_cast<float*>(workspace);
+    float* pooled_ws = partial + (size_t)parts * d;
+    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((ln_colsum_kernel<VEC, NV>), dim3(parts), dim3(WG),
+                                              WAVES * NV * VEC * 64 * sizeof(float), s, z, n, d, eps,
+                                              reinterpret_cast<const unsigned short*>(add_bf16), add_bias, slot_map,
+                                              delta_rows, z_out, partial));
+    int rc = snf::check_launch("ln_colsum_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(ln_head_finalize_kernel, dim3(1), dim3(1024), 0, s, partial, parts, n, d, gamma, beta, w_head,
+                       b_head, c_out, pooled_ws, pooled, logits);
+    return snf::check_launch("ln_head_finalize_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,234 @@
+// K7 (exact-fp32, any-shape form): sparse attention of snuffy.py:160-168.
+//
+//   P_a = softmax_j(Q_a Kp_a^T * scale)   [n, k]       O_a = P_a^T V_a   [k, dk]
+//
+// Two kernels + a fixed-order reduction, all fp32 FMA (reference-class numerics, used by the fp32 parity path and
+// as the fallback for shapes the MFMA kernel does not take):
+//   1. scores_softmax: a workgroup owns 16 query rows of one head (a wave owns 4 of them, a lane owns keys
+//      lane, lane+64, ...), Kp streamed through LDS in 64-key chunks, the whole softmax row lives in registers;
+//      writes P (coalesced along keys) and the row log-sum-exp.
+//   2. pt_v: O_a = P_a^T V_a as an LDS-tiled fp32 GEMM over a slice of the n rows -> partial [slice, h, k, dk].
+//   3. reduce: out[k, d] = sum over slices in ascending order (deterministic).
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS_PER_WG = 16;
+constexpr int KCHUNK = 64;
+
+template <int KPL>  // keys per lane: k <= 64 * KPL
+__global__ __launch_bounds__(256) void scores_softmax_kernel(const float* __restrict__ q, const float* __restrict__ kp,
+                                                             int64_t n, int k, int h, int dk, float scale,
+                                                             float* __restrict__ p_out /*[h,n,k]*/,
+                                                             float* __restrict__ lse /*[h,n] nullable*/) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int dkp = (dk + 3) & ~3;
+    const int kpitch = dkp + 4;
+    float* lq = lds;                      // [16][dkp]
+    float* lk = lds + ROWS_PER_WG * dkp;  // [64][kpitch]
+    const int a = blockIdx.y;
+    const int d_model = h * dk;
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS_PER_WG;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    for (int e = threadIdx.x; e < ROWS_PER_WG * dkp; e += 256) {
+        int r = e / dkp, d = e - r * dkp;
+        int64_t row = row0 + r;
+        lq[e] = (row < n && d < dk) ? q[row * d_model + a * dk + d] : 0.f;
+    }
+    float s[4][KPL];
+#pragma unroll
+    for (int c = 0; c < KPL; ++c) {
+        __syncthreads();  // previous chunk fully consumed (and lq visible on c == 0)
+        for (int e = threadIdx.x; e < KCHUNK * dkp; e += 256) {
+            int j = e / dkp, d = e - j * dkp;
+            int key = c * KCHUNK + j;
+            lk[j * kpitch + d] = (key < k && d < dk) ? kp[(int64_t)key * d_model + a * dk + d] : 0.f;
+        }
+        __syncthreads();
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float4* kv4 = reinterpret_cast<const float4*>(lk + lane * kpitch);
+        for (int d4 = 0; d4 < dkp / 4; ++d4) {
+            float4 kv = kv4[d4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float4 qv = reinterpret_cast<const float4*>(lq + (wave * 4 + r) * dkp)[d4];
+                acc[r] = fmaf(qv.x, kv.x, acc[r]);
+                acc[r] = fmaf(qv.y, kv.y, acc[r]);
+                acc[r] = fmaf(qv.z, kv.z, acc[r]);
+                acc[r] = fmaf(qv.w, kv.w, acc[r]);
+            }
+        }
+        const bool valid = (c * KCHUNK + lane) < k;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r][c] = valid ? acc[r] * scale : -INFINITY;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + wave * 4 + r;
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) m = fmaxf(m, s[r][c]);
+        m = wave_max(m);
+        float l = 0.f;
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+            float e = expf(s[r][c] - m);  // exp(-inf) = 0 for padded keys
+            s[r][c] = e;
+            l += e;
+        }
+        l = wave_sum(l);
+        const float inv = 1.0f / l;
+        if (row < n) {
+            float* prow = p_out + ((int64_t)a * n + row) * k;
+#pragma unroll
+            for (int c = 0; c < KPL; ++c) {
+                int key = c * KCHUNK + lane;
+                if (key < k) prow[key] = s[r][c] * inv;
+            }
+            if (lse && lane == 0) lse[(int64_t)a * n + row] = m + logf(l);
+        }
+    }
+}
+
+// O_a partial: tile 64 keys x 64 cols, rows [r_begin, r_end) of one slice; 256 threads, 4x4 micro-tiles.
+__global__ __launch_bounds__(256) void pt_v_kernel(const float* __restrict__ p /*[h,n,k]*/, const float* __restrict__ v,
+                                                   int64_t n, int k, int h, int dk, int64_t rows_per_slice,
+                                                   float* __restrict__ partial /*[slices,h,k,dk]*/) {
+    __shared__ float lp[16][64 + 4];
+    __shared__ float lv[16][64 + 4];
+    const int a = blockIdx.z % h;
+    const int slice = blockIdx.z / h;
+    const int j0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int d_model = h * dk;
+    const int tj = threadIdx.x & 15, tc = threadIdx.x >> 4;
+    const int64_t r_begin = (int64_t)slice * rows_per_slice;
+    int64_t r_end = r_begin + rows_per_slice;
+    if (r_end > n) r_end = n;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    const int lr = threadIdx.x >> 4;        // 0..15: row within the 16-row step
+    const int lc = (threadIdx.x & 15) * 4;  // 0..60
+    for (int64_t r = r_begin; r < r_end; r += 16) {
+        const int64_t row = r + lr;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int key = j0 + lc + t, col = c0 + lc + t;
+            lp[lr][lc + t] = (row < r_end && key < k) ? p[((int64_t)a * n + row) * k + key] : 0.f;
+            lv[lr][lc + t] = (row < r_end && col < dk) ? v[row * d_model + a * dk + col] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            float pv[4], vv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pv[i] = lp[rr][tj * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vv[j] = lv[rr][tc * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(pv[i], vv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    float* dst = partial + ((int64_t)slice * h + a) * (int64_t)k * dk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int key = j0 + tj * 4 + i;
+        if (key >= k) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int col = c0 + tc * 4 + j;
+            if (col < dk) dst[(int64_t)key * dk + col] = acc[i][j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ partial, int slices, int k, int h,
+                                                            int dk, float* __restrict__ out /*[k, h*dk]*/) {
+    const int64_t total = (int64_t)h * k * dk;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int sl = 0; sl < slices; ++sl) s += partial[(int64_t)sl * total + e];
+        int a = (int)(e / ((int64_t)k * dk));
+        int64_t rem = e - (int64_t)a * k * dk;
+        int key = (int)(rem / dk), col = (int)(rem - (int64_t)key * dk);
+        out[(int64_t)key * (h * dk) + a * dk + col] = s;
+    }
+}
+
+inline int generic_slices(int64_t n) {
+    int64_t s = (n + 511) / 512;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+}  // namespace
+
+namespace snf {
+size_t generic_attn_workspace_bytes(int64_t n, int k, int h, int dk) {
+    size_t pbytes = (size_t)h * (size_t)n * (size_t)k * sizeof(float);
+    size_t part = (size_t)generic_slices(n) * h * (size_t)k * dk * sizeof(float);
+    return ((pbytes + 255) & ~(size_t)255) + part;
+}
+}  // namespace snf
+
+extern "C" {
+
+int snf_sparse_attn_fwd_f32(const float* q, const float* kp, const float* v, int64_t n, int k, int h, int dk, float scale,
+                            float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
+                            snf_stream_t stream) {
+    SNF_REQUIRE(q && kp && v && out, "snf_sparse_attn_fwd_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && k >= 1 && h >= 1 && dk >= 1, "snf_sparse_attn_fwd_f32: bad shape n=%lld k=%d h=%d dk=%d",
+                (long long)n, k, h, dk);
+    SNF_REQUIRE(k <= 2048, "snf_sparse_attn_fwd_f32: k=%d > 2048 not supported", k);
+    SNF_REQUIRE(dk <= 256, "snf_sparse_attn_fwd_f32: dk=%d > 256 not supported", dk);
+    SNF_REQUIRE(h <= 65535, "snf_sparse_attn_fwd_f32: too many heads");
+    const size_t pbytes = ((size_t)h * (size_t)n * (size_t)k * sizeof(float) + 255) & ~(size_t)255;
+    const int slices = generic_slices(n);
+    const size_t part_bytes = (size_t)slices * h * (size_t)k * dk * sizeof(float);
+    const size_t need = (attn ? 0 : pbytes) + part_bytes;
+    if (!workspace || workspace_bytes < need) {
+        snf::set_error("snf_sparse_attn_fwd_f32: workspace %zu < %zu", workspace_bytes, need);
+        return SNF_EWORKSPACE;
+    }
+    float* p = attn ? attn : reinterpret_cast<float*>(workspace);
+    float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (attn ? 0 : pbytes));
+    hipStream_t s = snf::as_stream(stream);
+
+    const int dkp = (dk + 3) & ~3;
+    const size_t lds = (size_t)(ROWS_PER_WG * dkp + KCHUNK * (dkp + 4)) * sizeof(float);
+    dim3 grid1((unsigned)((n + ROWS_PER_WG - 1) / ROWS_PER_WG), (unsigned)h);
+    const int kpl = (k + 63) / 64;
+#define LAUNCH_SS(KPL)                                                                                              \
+    hipLaunchKernelGGL((scores_softmax_kernel<KPL>), grid1, dim3(256), lds, s, q, kp, n, k, h, dk, scale, p, lse)
+    if (kpl <= 1) LAUNCH_SS(1);
+    else if (kpl <= 2) LAUNCH_SS(2);
+    else if (kpl <= 4) LAUNCH_SS(4);
+    else if (kpl <= 8) LAUNCH_SS(8);
+    else if (kpl <= 16) LAUNCH_SS(16);
+    else LAUNCH_SS(32);
+#undef LAUNCH_SS
+    int rc = snf::check_launch("scores_softmax_kernel");
+    if (rc) return rc;
+
+    const int64_t rows_per_slice = (((n + slices - 1) / slices) + 15) & ~(int64_t)15;
+    dim3 grid2((unsigned)((k + 63) / 64), (unsigned)((dk + 63) / 64), (unsigned)(slices * h));
+    hipLaunchKernelGGL(pt_v_kernel, grid2, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, partial);
+    rc = snf::check_launch("pt_v_kernel");
+    if (rc) return rc;
+    const int64_t total = (int64_t)h * k * dk;
+    int rgrid = (int)((total + 255) / 256);
+    if (rgrid > 2048) rgrid = 2048;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3(rgrid), dim3(256), 0, s, partial, slices, k, h, dk, out);
+    return snf::check_launch("reduce_slices_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,462 @@
+// K7 (fast form): Snuffy's sparse attention on the CDNA4 matrix cores.
+//
+//   per head a:   P_a = softmax_j(Q_a Kp_a^T * scale)  [n, k]      O_a = P_a^T V_a  [k, dk]        (snuffy.py:160-168)
+//
+// All n patches are queries, only the k selected rows are keys, and the probability matrix is used TRANSPOSED to pool
+// the values of all n patches into k output rows.  The contraction of the second product runs over the QUERY axis, so
+// the natural MFMA dataflow is the opposite of flash attention:
+//
+//   GEMM1  S[q, key] = Q Kp^T    v_mfma_f32_32x32x16_bf16, A = Q fragment (global -> regs), B = Kp fragment (LDS).
+//          The C layout puts keys on lanes and 16 query rows in registers -- exactly the A-operand layout the second
+//          product needs (A[i = key][k = query]), so P never needs a transpose.
+//   softmax over keys = across the 32 lanes of a half-wave: DPP row rotations + one cross-row exchange, fp32.
+//   GEMM2  O[key, col] += P^T V   A = P fragment (bf16, via LDS so the 4 waves can share it), B = V fragment read
+//          straight from V^T [d, n] in HBM (8 consecutive query rows of one column = one 16-byte load).
+//
+// The row permutation pi() below is chosen so that the 8 query rows a lane holds in C registers 8ks..8ks+7 are 8
+// CONSECUTIVE bag rows -- that is what makes the V^T fragment a single contiguous load.
+//
+// Workgroup = 4 waves = 128 query rows per step of one head: wave w runs GEMM1 + softmax for rows 32w..32w+31 against
+// all keys, publishes its P fragments in LDS, then every wave accumulates its own share of the [k, dk] output tiles
+// over all 128 rows.  One workgroup per CU walks a contiguous range of (head, row-tile) work items; its accumulators
+// stay in registers until the head changes; partial tiles are written in fragment order and summed in a fixed order by
+// a second kernel (no float atomics -> bit-reproducible).
+//
+// HBM traffic per launch (algorithmic): read Q and V once (2*n*d*elt), Kp once per workgroup (L2), write partials.
+#include <math.h>
+
+#include "common.h"
+
+namespace snf {
+size_t generic_attn_workspace_bytes(int64_t n, int k, int h, int dk);
+}
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr int TILE_ROWS = 128;  // query rows per workgroup step (4 waves x 32)
+
+struct AttnParams {
+    const void* q;     // [n, ldq]  (ldq = h*dk)
+    const void* vt;    // [h*dk, ldv]
+    const float* kp;   // [k, h*dk] f32
+    int64_t n, ldq, ldv;
+    int k, h;
+    float scale;
+    float* attn;     // [h, n, k] or null
+    float* lse;      // [h, n] or null
+    float* partial;  // [num_wg * seg_count][tiles][16][64]
+    int tiles_per_head, tiles_per_wg, total_tiles, seg_count;
+};
+
+__device__ __forceinline__ int pi_row(int i) {  // MFMA row slot -> row offset inside the wave's 32 rows
+    return (i & 3) | (((i >> 3) & 1) << 2) | (((i >> 2) & 1) << 3) | (i & 16);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+// all-reduce over the 32 lanes of a half-wave (lanes 0-31 and 32-63 independently)
+__device__ __forceinline__ float half_allmax(float v) {
+    v = fmaxf(v, dpp_mov<0x128>(v));  // row_ror:8
+    v = fmaxf(v, dpp_mov<0x124>(v));  // row_ror:4
+    v = fmaxf(v, dpp_mov<0x122>(v));  // row_ror:2
+    v = fmaxf(v, dpp_mov<0x121>(v));  // row_ror:1
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return v;
+}
+__device__ __forceinline__ float half_allsum(float v) {
+    v += dpp_mov<0x128>(v);
+    v += dpp_mov<0x124>(v);
+    v += dpp_mov<0x122>(v);
+    v += dpp_mov<0x121>(v);
+    v += __shfl_xor(v, 16, 64);
+    return v;
+}
+
+__device__ __forceinline__ bf16x8 zero_frag() {
+    u32x4 z = {0u, 0u, 0u, 0u};
+    return __builtin_bit_cast(bf16x8, z);
+}
+
+// 8 consecutive elements -> bf16x8 (f32 source converted with v_cvt_pk_bf16_f32, round-to-nearest-even)
+__device__ __forceinline__ bf16x8 load_frag(const float* p) {
+    f32x4 lo = *reinterpret_cast<const f32x4*>(p);
+    f32x4 hi = *reinterpret_cast<const f32x4*>(p + 4);
+    f32x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_convertvector(v, bf16x8);
+}
+__device__ __forceinline__ bf16x8 load_frag(const unsigned short* p) {
+    u32x4 v = *reinterpret_cast<const u32x4*>(p);
+    return __builtin_bit_cast(bf16x8, v);
+}
+// tail form: elements at index >= valid are zero
+__device__ __forceinline__ bf16x8 load_frag_masked(const float* p, int valid) {
+    f32x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (e < valid) ? p[e] : 0.f;
+    return __builtin_convertvector(v, bf16x8);
+}
+__device__ __forceinline__ bf16x8 load_frag_masked(const unsigned short* p, int valid) {
+    unsigned short t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (e < valid) ? p[e] : (unsigned short)0;
+    u32x4 v = {(unsigned)t[0] | ((unsigned)t[1] << 16), (unsigned)t[2] | ((unsigned)t[3] << 16),
+               (unsigned)t[4] | ((unsigned)t[5] << 16), (unsigned)t[6] | ((unsigned)t[7] << 16)};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int DK, int NKB, typename QT>
+__global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) {
+    constexpr int NKS = DK / 16;            // k-steps of GEMM1
+    constexpr int NCB = DK / 32;            // 32-wide column blocks of the output
+    constexpr int NT = (NKB * NCB + 3) / 4;  // output tiles owned by one wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* lds_kp = reinterpret_cast<u32x4*>(smem);                    // [NKB][NKS][64]
+    u32x4* lds_p = lds_kp + NKB * NKS * 64;                            // [4 waves][NKB][2][64]
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, hf = lane >> 5;
+    const QT* __restrict__ q = reinterpret_cast<const QT*>(P.q);
+    const QT* __restrict__ vt = reinterpret_cast<const QT*>(P.vt);
+    const float c_exp = P.scale * 1.44269504088896340736f;
+
+    const int f_begin = blockIdx.x * P.tiles_per_wg;
+    int f_end = f_begin + P.tiles_per_wg;
+    if (f_end > P.total_tiles) f_end = P.total_tiles;
+    const int first_head = f_begin / P.tiles_per_head;
+
+    f32x16 acc_o[NT];
+    int cur_head = -1;
+
+    auto flush = [&](int head) {
+        const int seg = head - first_head;
+        float* dst = P.partial + ((int64_t)blockIdx.x * P.seg_count + seg) * (int64_t)(NKB * NCB) * 1024;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            const int t_idx = w + 4 * ti;
+            if (t_idx < NKB * NCB) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    f32x4 v = {acc_o[ti][q4 * 4], acc_o[ti][q4 * 4 + 1], acc_o[ti][q4 * 4 + 2], acc_o[ti][q4 * 4 + 3]};
+                    *reinterpret_cast<f32x4*>(dst + ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4) = v;
+                }
+            }
+        }
+    };
+
+    for (int f = f_begin; f < f_end; ++f) {
+        const int a = f / P.tiles_per_head;
+        const int t = f - a * P.tiles_per_head;
+        if (a != cur_head) {
+            if (cur_head >= 0) flush(cur_head);
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[ti][r] = 0.f;
+            __syncthreads();  // everyone finished reading the previous head's Kp
+            for (int fr = w; fr < NKB * NKS; fr += 4) {
+                const int jb = fr / NKS, kb = fr - jb * NKS;
+                const int key = 32 * jb + j;
+                bf16x8 v = zero_frag();
+                if (key < P.k) v = load_frag(P.kp + (int64_t)key * P.ldq + a * DK + 16 * kb + 8 * hf);
+                lds_kp[fr * 64 + lane] = __builtin_bit_cast(u32x4, v);
+            }
+            __syncthreads();
+            cur_head = a;
+        }
+        const int64_t row0 = (int64_t)t * TILE_ROWS;
+        const int64_t my_row0 = row0 + 32 * w;
+        const bool tail = (row0 + TILE_ROWS > P.n);
+
+        // ---- V fragments of this step (consumed by GEMM2; issued first so HBM latency hides under GEMM1+softmax)
+        constexpr int NVF = 8;  // 4 sub-tiles x 2 k-steps of this wave's column block
+        bf16x8 vf[NVF];
+        {
+            const int cb = (NCB == 4) ? w : (w & (NCB - 1));
+            const QT* vcol = vt + (int64_t)(a * DK + 32 * cb + j) * P.ldv;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int64_t rb = row0 + 32 * s + 16 * ks + 8 * hf;
+                    if (!tail) {
+                        vf[s * 2 + ks] = load_frag(vcol + rb);
+                    } else {
+                        int64_t valid = P.n - rb;
+                        vf[s * 2 + ks] = valid >= 8 ? load_frag(vcol + rb)
+                                                    : (valid > 0 ? load_frag_masked(vcol + rb, (int)valid) : zero_frag());
+                    }
+                }
+        }
+
+        // ---- Q fragments of this wave's 32 rows
+        bf16x8 qf[NKS];
+        {
+            const int64_t qrow = my_row0 + pi_row(j);
+            const bool qvalid = qrow < P.n;
+            const QT* qp = q + qrow * P.ldq + a * DK + 8 * hf;
+#pragma unroll
+            for (int kb = 0; kb < NKS; ++kb) qf[kb] = qvalid ? load_frag(qp + 16 * kb) : zero_frag();
+        }
+
+        // ---- GEMM1: S[32 rows, 32*NKB keys]
+        f32x16 s_acc[NKB];
+#pragma unroll
+        for (int jb = 0; jb < NKB; ++jb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_acc[jb][r] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < NKS; ++kb) {
+                bf16x8 kf = __builtin_bit_cast(bf16x8, lds_kp[(jb * NKS + kb) * 64 + lane]);
+                s_acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kb], kf, s_acc[jb], 0, 0, 0);
+            }
+        }
+
+        // ---- softmax over keys (lanes of a half-wave x NKB blocks), fp32
+        {
+            const int first_pad_blk = P.k >> 5;  // wave-uniform: blocks below it are fully valid
+#pragma unroll
+            for (int jb = 0; jb < NKB; ++jb) {
+                if (jb >= first_pad_blk && 32 * jb + j >= P.k) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s_acc[jb][r] = -INFINITY;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float m = s_acc[0][r];
+#pragma unroll
+            for (int jb = 1; jb < NKB; ++jb) m = fmaxf(m, s_acc[jb][r]);
+            m = half_allmax(m);
+            const float mc = m * c_exp;
+            float l = 0.f;
+#pragma unroll
+            for (int jb = 0; jb < NKB; ++jb) {
+                float e = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r], c_exp, -mc));
+                s_acc[jb][r] = e;
+                l += e;
+            }
+            l = half_allsum(l);
+            const int64_t row = my_row0 + (r & 7) + 8 * hf + 16 * (r >> 3);
+            const bool rvalid = row < P.n;
+            const float inv = rvalid ? __builtin_amdgcn_rcpf(l) : 0.f;
+#pragma unroll
+            for (int jb = 0; jb < NKB; ++jb) s_acc[jb][r] *= inv;
+            if (P.lse && rvalid && j == 0) P.lse[(int64_t)a * P.n + row] = m * P.scale + __logf(l);
+            if (P.attn && rvalid) {
+                float* arow = P.attn + ((int64_t)a * P.n + row) * P.k;
+#pragma unroll
+                for (int jb = 0; jb < NKB; ++jb) {
+                    const int key = 32 * jb + j;
+                    if (key < P.k) arow[key] = s_acc[jb][r];
+                }
+            }
+        }
+
+        // ---- publish P fragments (bf16) for the 4 waves
+        __syncthreads();  // previous step's GEMM2 reads are complete
+#pragma unroll
+        for (int jb = 0; jb < NKB; ++jb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f32x8 pv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pv[e] = s_acc[jb][8 * ks + e];
+                bf16x8 pb = __builtin_convertvector(pv, bf16x8);
+                lds_p[((w * NKB + jb) * 2 + ks) * 64 + lane] = __builtin_bit_cast(u32x4, pb);
+            }
+        __syncthreads();
+
+        // ---- GEMM2: O tiles of this wave += P^T V over the 128 rows of the step
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) {
+                    const int t_idx = w + 4 * ti;  // tile = kb * NCB + cb ; cb == t_idx % NCB is constant per wave
+                    if (t_idx < NKB * NCB) {
+                        const int kb = t_idx / NCB;
+                        bf16x8 pf = __builtin_bit_cast(bf16x8, lds_p[((s * NKB + kb) * 2 + ks) * 64 + lane]);
+                        acc_o[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vf[s * 2 + ks], acc_o[ti], 0, 0, 0);
+                    }
+                }
+            }
+    }
+    if (cur_head >= 0) flush(cur_head);
+}
+
+// out[key, a*DK + col] = sum over the (workgroup, segment) partials of head a, ascending workgroup order
+template <int DK, int NKB>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int num_wg, int seg_count,
+                                                              int tiles_per_head, int tiles_per_wg, int total_tiles,
+                                                              int k, int h, float* __restrict__ out) {
+    constexpr int NCB = DK / 32;
+    constexpr int TILES = NKB * NCB;
+    const int a = blockIdx.y;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);  // (tile, q4)
+    if (unit >= TILES * 4) return;
+    const int lane = threadIdx.x & 63;
+    const int t_idx = unit >> 2, q4 = unit & 3;
+    const int f_lo = a * tiles_per_head, f_hi = (a + 1) * tiles_per_head - 1;
+    int b_lo = f_lo / tiles_per_wg, b_hi = f_hi / tiles_per_wg;
+    if (b_hi > num_wg - 1) b_hi = num_wg - 1;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int b = b_lo; b <= b_hi; ++b) {
+        const int seg = a - (b * tiles_per_wg) / tiles_per_head;
+        const float* src = partial + ((int64_t)b * seg_count + seg) * (int64_t)TILES * 1024;
+        f32x4 v = *reinterpret_cast<const f32x4*>(src + ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4);
+        s += v;
+    }
+    const int kb = t_idx / NCB, cb = t_idx - kb * NCB;
+    const int col = a * DK + 32 * cb + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int key = 32 * kb + i + 8 * q4 + 4 * (lane >> 5);
+        if (key < k) out[(int64_t)key * (h * DK) + col] = s[i];
+    }
+}
+
+struct Plan {
+    int num_wg, tiles_per_head, tiles_per_wg, total_tiles, seg_count, nkb;
+};
+
+inline bool make_plan(int64_t n, int k, int h, int dk, Plan* pl) {
+    if (!(dk == 64 || dk == 128) || k < 1 || k > 256) return false;
+    int nkb = (k + 31) / 32;
+    // instantiated key-block counts
+    const int opts[] = {1, 2, 4, 6, 7, 8};
+    int sel = 0;
+    for (int o : opts)
+        if (o >= nkb) {
+            sel = o;
+            break;
+        }
+    if (!sel) return false;
+    int64_t tph = (n + TILE_ROWS - 1) / TILE_ROWS;
+    int64_t total = tph * h;
+    if (total > 0x7fffffff) return false;
+    int cus = snf::cu_count();
+    int64_t num_wg = total < cus ? total : cus;
+    int64_t tpw = (total + num_wg - 1) / num_wg;
+    num_wg = (total + tpw - 1) / tpw;
+    pl->num_wg = (int)num_wg;
+    pl->tiles_per_head = (int)tph;
+    pl->tiles_per_wg = (int)tpw;
+    pl->total_tiles = (int)total;
+    pl->seg_count = (int)((tpw + tph - 1) / tph + 1);
+    pl->nkb = sel;
+    return true;
+}
+
+template <int DK, int NKB, typename QT>
+int launch_variant(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
+    constexpr int NKS = DK / 16;
+    const size_t lds = (size_t)(NKB * NKS + 4 * NKB * 2) * 1024;
+    static thread_local bool attr_set = false;
+    auto kern = sparse_attn_mfma_kernel<DK, NKB, QT>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            snf::set_error("sparse_attn_mfma: cannot reserve %zu bytes of LDS", lds);
+            (void)hipGetLastError();
+            return SNF_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(pl.num_wg), dim3(256), lds, s, P);
+    int rc = snf::check_launch("sparse_attn_mfma_kernel");
+    if (rc) return rc;
+    constexpr int TILES = NKB * (DK / 32);
+    hipLaunchKernelGGL((reduce_partials_kernel<DK, NKB>), dim3(TILES, P.h), dim3(256), 0, s, P.partial, pl.num_wg,
+                       pl.seg_count, pl.tiles_per_head, pl.tiles_per_wg, pl.total_tiles, P.k, P.h, out);
+    return snf::check_launch("reduce_partials_kernel");
+}
+
+template <int DK, typename QT>
+int launch_nkb(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
+    switch (pl.nkb) {
+        case 1: return launch_variant<DK, 1, QT>(P, pl, out, s);
+        case 2: return launch_variant<DK, 2, QT>(P, pl, out, s);
+        case 4: return launch_variant<DK, 4, QT>(P, pl, out, s);
+        case 6: return launch_variant<DK, 6, QT>(P, pl, out, s);
+        case 7: return launch_variant<DK, 7, QT>(P, pl, out, s);
+        default: return launch_variant<DK, 8, QT>(P, pl, out, s);
+    }
+}
+
+inline size_t mfma_workspace_bytes(const Plan& pl, int dk) {
+    return (size_t)pl.num_wg * pl.seg_count * (size_t)(pl.nkb * (dk / 32)) * 1024 * sizeof(float);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t snf_sparse_attn_fwd_workspace_bytes(int64_t n, int k, int h, int dk, int mfma) {
+    if (n < 1 || k < 1 || h < 1 || dk < 1) return 0;
+    if (mfma) {
+        Plan pl;
+        if (!make_plan(n, k, h, dk, &pl)) return 0;
+        return mfma_workspace_bytes(pl, dk);
+    }
+    return snf::generic_attn_workspace_bytes(n, k, h, dk);
+}
+
+int snf_sparse_attn_fwd_mfma(const void* q, const void* vt, int qv_dtype, int64_t ldv, const float* kp, int64_t n, int k,
+                             int h, int dk, float scale, float* out, float* attn, float* lse, void* workspace,
+                             size_t workspace_bytes, snf_stream_t stream) {
+    SNF_REQUIRE(q && vt && kp && out, "snf_sparse_attn_fwd_mfma: null pointer");
+    SNF_REQUIRE(n >= 1 && k >= 1 && h >= 1, "snf_sparse_attn_fwd_mfma: bad shape");
+    SNF_REQUIRE(qv_dtype == SNF_DT_F32 || qv_dtype == SNF_DT_BF16, "snf_sparse_attn_fwd_mfma: bad dtype %d", qv_dtype);
+    Plan pl;
+    if (!make_plan(n, k, h, dk, &pl)) {
+        snf::set_error("snf_sparse_attn_fwd_mfma: unsupported shape k=%d dk=%d (need dk in {64,128}, k <= 256)", k, dk);
+        return SNF_EUNSUPPORTED;
+    }
+    SNF_REQUIRE(ldv >= n && (ldv % 8) == 0, "snf_sparse_attn_fwd_mfma: ldv=%lld must be >= n and a multiple of 8",
+                (long long)ldv);
+    SNF_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (reinterpret_cast<uintptr_t>(vt) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(kp) & 15) == 0,
+                "snf_sparse_attn_fwd_mfma: q / vt / kp must be 16-byte aligned");
+    const size_t need = mfma_workspace_bytes(pl, dk);
+    if (!workspace || workspace_bytes < need) {
+        snf::set_error("snf_sparse_attn_fwd_mfma: workspace %zu < %zu", workspace_bytes, need);
+        return SNF_EWORKSPACE;
+    }
+    AttnParams P;
+    P.q = q;
+    P.vt = vt;
+    P.kp = kp;
+    P.n = n;
+    P.ldq = (int64_t)h * dk;
+    P.ldv = ldv;
+    P.k = k;
+    P.h = h;
+    P.scale = scale;
+    P.attn = attn;
+    P.lse = lse;
+    P.partial = reinterpret_cast<float*>(workspace);
+    P.tiles_per_head = pl.tiles_per_head;
+    P.tiles_per_wg = pl.tiles_per_wg;
+    P.total_tiles = pl.total_tiles;
+    P.seg_count = pl.seg_count;
+    hipStream_t s = snf::as_stream(stream);
+    if (dk == 128) {
+        if (qv_dtype == SNF_DT_F32) return launch_nkb<128, float>(P, pl, out, s);
+        return launch_nkb<128, unsigned short>(P, pl, out, s);
+    }
+    if (qv_dtype == SNF_DT_F32) return launch_nkb<64, float>(P, pl, out, s);
+    return launch_nkb<64, unsigned short>(P, pl, out, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,247 @@
+"""Fused forward pipeline of the Snuffy aggregator on top of the HIP kernels (ops.py).
+
+Data layout in HBM for one bag (N patches, D features, K selected rows, F = mlp_multiplier * D):
+  x      [N, D]  fp32   the bag (never cloned; the K updated rows live in small [K, D] side buffers)
+  c      [N]     fp32   critic scores
+  S      [K]     int64  selected rows (top-Lambda ++ random)
+  fp32 path : Xn [N, D] fp32, Q / V [N, D] fp32, hidden [N, F] fp32, z [N, D] fp32
+  bf16 path : xhat [N8, D] bf16 (row-normalised x, affine folded into the GEMM weights; shared by the Q/V projection and,
+              after re-normalising the K patched rows in place, by the FFN), Q [N, D] bf16, V^T [D, N8] bf16,
+              hidden [N, F] bf16, FFN out [N, D] bf16; the fp32 residual stream is re-assembled inside the final
+              LayerNorm + mean + head kernel.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from ._ffi import SnuffyHipError
+
+ACTIVATIONS = ("relu", "gelu", "leakyrelu", "selu")      # reference snuffy.py:215-220
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# shape helpers
+# ----------------------------------------------------------------------------------------------------------------------
+def as_2d(x):
+    if x.dim() == 3:
+        if x.shape[0] != 1:
+            # the reference's binary model indexes with a 1-D index tensor and breaks for B > 1 (snuffy.py:130-131)
+            raise IndexError("snuffy (binary) supports a single bag per forward: got batch %d" % x.shape[0])
+        x = x[0]
+    if x.dim() != 2:
+        raise ValueError("expected [1, N, D] or [N, D], got %s" % (tuple(x.shape),))
+    if not x.is_cuda:
+        raise SnuffyHipError("input must be a GPU tensor: snuffy_amd has no CPU fallback")
+    if x.dtype != torch.float32:
+        x = x.float()
+    return x.contiguous()
+
+
+def check_bag(x, c):
+    x2 = as_2d(x)
+    n = x2.shape[0]
+    if c.numel() != n:
+        raise IndexError("binary snuffy needs one critic score per patch: c has %d values for %d patches"
+                         % (c.numel(), n))
+    c1 = c.reshape(-1)
+    if c1.dtype != torch.float32:
+        c1 = c1.float()
+    return x2, c1
+
+
+def critic_scores(feats, w, b):
+    lead = feats.shape[:-1]
+    f2 = feats.reshape(-1, feats.shape[-1])
+    if not f2.is_cuda:
+        raise SnuffyHipError("input must be a GPU tensor: snuffy_amd has no CPU fallback")
+    s = ops.critic(f2.float().contiguous(), w, b)
+    return s.view(*lead, w.shape[0])
+
+
+def select_top(c1, big_lambda, top_share, n):
+    k1 = min(math.ceil(big_lambda * top_share), n)          # python float arithmetic, snuffy.py:129
+    if k1 < 1:
+        return torch.empty(0, dtype=torch.int64, device=c1.device)
+    return ops.topk(c1, k1)
+
+
+def gather(x2, idx):
+    return ops.gather_rows(x2, idx)
+
+
+def layer_norm(x2, norm):
+    return ops.layernorm_rows(x2, norm.weight, norm.bias, norm.eps)
+
+
+def act_name(ff):
+    return ff.activation_name
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# attention building blocks (API-fidelity entry points)
+# ----------------------------------------------------------------------------------------------------------------------
+def attention_4d(query, key, value, dropout=None):
+    """attention() of snuffy.py:160-168 on [1, h, N, dk] tensors."""
+    if dropout is not None and getattr(dropout, "training", False) and getattr(dropout, "p", 0.0) > 0:
+        raise NotImplementedError("attention dropout inside the fused kernel is not implemented yet")
+    b, h, n, dk = query.shape
+    if b != 1:
+        raise IndexError("single bag only")
+    k = key.shape[2]
+    q2 = query[0].transpose(0, 1).reshape(n, h * dk).contiguous()
+    k2 = key[0].transpose(0, 1).reshape(k, h * dk).contiguous()
+    v2 = value[0].transpose(0, 1).reshape(n, h * dk).contiguous()
+    out, attn, _ = ops.sparse_attn_fwd(q2, k2, v2, h, need_attn=True)
+    return out.view(k, h, dk).transpose(0, 1).unsqueeze(0), attn.unsqueeze(0)
+
+
+def mha_forward(mha, q_in, key_in, v_in, need_attn, precision):
+    """MultiHeadedAttention.forward (snuffy.py:183-205) on 2-D inputs; fp32 projections, exact attention kernel."""
+    lq, lk, lv, lo = mha.linears
+    q = F.linear(q_in, lq.weight, lq.bias)
+    kp = F.linear(key_in, lk.weight, lk.bias)
+    v = F.linear(v_in, lv.weight, lv.bias)
+    o, attn, _ = ops.sparse_attn_fwd(q, kp, v, mha.h, need_attn=need_attn)
+    out = F.linear(o, lo.weight, lo.bias)
+    return out, (attn.unsqueeze(0) if attn is not None else None)
+
+
+def ffn_forward(ff, x2, precision):
+    """PositionwiseFeedForward.forward (snuffy.py:224-225), eval semantics."""
+    hid = torch.mm(x2, ff.w_1.weight.t())
+    ops.bias_act_(hid, ff.w_1.bias, ff.activation_name)
+    return F.linear(hid, ff.w_2.weight, ff.w_2.bias)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fused encoder layer
+# ----------------------------------------------------------------------------------------------------------------------
+class Parts:
+    """z = base (+ add_bf16) (+ add_bias) (+ delta[slot]) -- the residual stream after a layer, not yet assembled."""
+
+    __slots__ = ("base", "add_bf16", "add_bias", "slot", "delta")
+
+    def __init__(self, base, add_bf16=None, add_bias=None, slot=None, delta=None):
+        self.base, self.add_bf16, self.add_bias, self.slot, self.delta = base, add_bf16, add_bias, slot, delta
+
+    @property
+    def plain(self):
+        return self.add_bf16 is None and self.add_bias is None and self.slot is None
+
+
+def materialize(parts):
+    if parts.plain:
+        return parts.base
+    d = parts.base.shape[1]
+    dummy_w = torch.zeros(1, d, dtype=torch.float32, device=parts.base.device)
+    ones = torch.ones(d, dtype=torch.float32, device=parts.base.device)
+    _, _, z = ops.ln_mean_head(parts.base, ones, dummy_w[0], 1e-5, dummy_w, None, parts.add_bf16, parts.add_bias,
+                               parts.slot, parts.delta, want_z=True)
+    return z
+
+
+def head(parts, norm, linear):
+    """logits = Linear(mean_n LayerNorm(z))  (snuffy.py:86,71), residual assembly fused into the read."""
+    logits, _, _ = ops.ln_mean_head(parts.base, norm.weight, norm.bias, norm.eps, linear.weight, linear.bias,
+                                    parts.add_bf16, parts.add_bias, parts.slot, parts.delta)
+    return logits
+
+
+_fold_cache = {}
+
+
+def _folded(layer):
+    """bf16 path: LayerNorm affine folded into the following projection, cached until a parameter changes.
+
+    LN(x) W^T + b = xhat (W * gamma)^T + (W beta + b)   with xhat = (x - mean) * rstd.
+    """
+    n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
+    lq, lk, lv, lo = layer.self_attn.linears
+    ff = layer.feed_forward
+    plist = [n0.weight, n0.bias, n1.weight, n1.bias, lq.weight, lq.bias, lv.weight, lv.bias, ff.w_1.weight,
+             ff.w_1.bias, ff.w_2.weight]
+    key = tuple((p.data_ptr(), p._version) for p in plist)
+    ent = _fold_cache.get(id(layer))
+    if ent is not None and ent[0] == key:
+        return ent[1]
+    with torch.no_grad():
+        g0, b0, g1, b1 = n0.weight, n0.bias, n1.weight, n1.bias
+        out = dict(
+            wq=(lq.weight * g0).to(torch.bfloat16), bq=(lq.weight @ b0 + lq.bias).to(torch.bfloat16),
+            wv=(lv.weight * g0).to(torch.bfloat16), bv=(lv.weight @ b0 + lv.bias).to(torch.bfloat16),
+            w1=(ff.w_1.weight * g1).to(torch.bfloat16), b1=(ff.w_1.weight @ b1 + ff.w_1.bias).contiguous(),
+            w2=ff.w_2.weight.to(torch.bfloat16),
+        )
+    _fold_cache[id(layer)] = (key, out)
+    return out
+
+
+def encoder_layer(x2, sel, layer, need_attn, precision):
+    """EncoderLayer.forward (snuffy.py:126-157) for x2 [N, D] and selected rows sel [K].  Returns (Parts, A)."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in layer.parameters()):
+        from . import autograd as SA  # training path (custom backward kernels)
+        return SA.encoder_layer_train(x2, sel, layer, need_attn, precision)
+    n, d = x2.shape
+    mha, ff = layer.self_attn, layer.feed_forward
+    h = mha.h
+    k = sel.shape[0]
+    n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
+    lq, lk, lv, lo = mha.linears
+    if k == 0:
+        # nothing selected (possible only when N == 0 rows qualify): the attention sublayer is the identity
+        attn = torch.empty(1, h, n, 0, device=x2.device) if need_attn else None
+        yn = ops.layernorm_rows(x2, n1.weight, n1.bias, n1.eps)
+        hid = torch.mm(yn, ff.w_1.weight.t())
+        ops.bias_act_(hid, ff.w_1.bias, ff.activation_name)
+        z = torch.addmm(x2, hid, ff.w_2.weight.t())
+        ops.bias_act_(z, ff.w_2.bias, "none")
+        return Parts(z), attn
+
+    xs = ops.gather_rows(x2, sel)                                                   # snuffy.py:131,145-147
+    kp = F.linear(xs, lk.weight, lk.bias)                                           # keys = RAW selected rows
+    if precision == "fp32":
+        xn = ops.layernorm_rows(x2, n0.weight, n0.bias, n0.eps)                     # snuffy.py:107
+        q = F.linear(xn, lq.weight, lq.bias)
+        v = F.linear(xn, lv.weight, lv.bias)
+        o, attn, _ = ops.sparse_attn_fwd(q, kp, v, h, need_attn=need_attn)           # snuffy.py:160-168
+        del q, v, xn
+        delta = F.linear(o, lo.weight, lo.bias)                                     # snuffy.py:205
+        x_sel = xs + delta                                                          # snuffy.py:108
+        slot = ops.slot_map(sel, n)
+        yn = ops.layernorm_rows(x2, n1.weight, n1.bias, n1.eps, slot=slot, patch_rows=x_sel)  # LN(y), y never built
+        hid = torch.mm(yn, ff.w_1.weight.t())
+        del yn
+        ops.bias_act_(hid, ff.w_1.bias, ff.activation_name)                         # snuffy.py:224-225
+        z = torch.addmm(x2, hid, ff.w_2.weight.t())                                 # x + W2 hid  (residual in the GEMM)
+        del hid
+        ops.bias_act_(z, ff.w_2.bias, "none")
+        ops.scatter_add_rows_(z, sel, delta)                                        # rows S: x -> x_sel (snuffy.py:155)
+        return Parts(z), (attn.unsqueeze(0) if attn is not None else None)
+
+    # ---- bf16 path -------------------------------------------------------------------------------------------------
+    if n0.eps != n1.eps:
+        raise NotImplementedError("bf16 path shares one normalisation between both sublayers: eps must match")
+    fw = _folded(layer)
+    n8 = (n + 7) // 8 * 8
+    xhat = torch.empty(n8, d, dtype=torch.bfloat16, device=x2.device)
+    if n8 > n:
+        xhat[n:].zero_()
+    ops.layernorm_rows(x2, None, None, n0.eps, out=xhat[:n])
+    q = torch.addmm(fw["bq"], xhat[:n], fw["wq"].t())                               # [N, D]  bf16
+    vt = torch.addmm(fw["bv"].unsqueeze(1), fw["wv"], xhat.t())                     # [D, N8] bf16  (V transposed)
+    if ops.mfma_attn_supported(k, d // h):
+        o, attn, _ = ops.sparse_attn_fwd_mfma(q, vt, kp, n, h, need_attn=need_attn)
+    else:
+        o, attn, _ = ops.sparse_attn_fwd(q.float(), kp, vt[:, :n].t().float().contiguous(), h, need_attn=need_attn)
+    del q, vt
+    delta = F.linear(o, lo.weight, lo.bias)
+    x_sel = xs + delta
+    ops.layernorm_rows(x_sel, None, None, n1.eps, out=xhat, out_row_idx=sel)        # re-normalise the K rows in place
+    hid = torch.mm(xhat[:n], fw["w1"].t())                                          # [N, F] bf16
+    ops.bias_act_(hid, fw["b1"], ff.activation_name)
+    zb = torch.mm(hid, fw["w2"].t())                                                # [N, D] bf16
+    del hid
+    parts = Parts(x2, add_bf16=zb, add_bias=ff.w_2.bias, slot=ops.slot_map(sel, n), delta=delta)
+    return parts, (attn.unsqueeze(0) if attn is not None else None)

@@ -1,0 +1,261 @@
+"""Tensor-level wrappers over the C ABI (include/snuffy_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every kernel is ours.  All functions require CUDA
+(ROCm) tensors and raise otherwise -- there is no CPU path in the product.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _ffi
+from ._ffi import ACT_CODES, DT_BF16, DT_F32, check
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, dtype, name, dim=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _ffi.SnuffyHipError(
+            "%s must be a GPU tensor: snuffy_amd runs on MI355X only (no CPU fallback)" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if dim is not None and t.dim() != dim:
+        raise ValueError("%s must be %d-D, got shape %s" % (name, dim, tuple(t.shape)))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def critic(x, w, b=None, want_max=False):
+    """scores = x w^T + b  (FCLayer, snuffy.py:39-41); optionally the column max / argmax (train.py:831-834)."""
+    x = _req(x, torch.float32, "x", 2)
+    w = _req(w, torch.float32, "w", 2)
+    if b is not None:
+        b = _req(b, torch.float32, "b", 1)
+    n, d = x.shape
+    c = w.shape[0]
+    if w.shape[1] != d:
+        raise ValueError("critic: w is %s but x has %d features" % (tuple(w.shape), d))
+    scores = torch.empty(n, c, dtype=torch.float32, device=x.device)
+    mv = mi = None
+    if want_max:
+        mv = torch.empty(c, dtype=torch.float32, device=x.device)
+        mi = torch.empty(c, dtype=torch.int64, device=x.device)
+    check(_ffi.load().snf_critic_f32(_p(x), n, d, _p(w), _p(b), c, _p(scores), _p(mv), _p(mi), _stream()),
+          "snf_critic_f32")
+    return (scores, mv, mi) if want_max else scores
+
+
+def topk(scores, k, x=None):
+    """Indices of the k largest scores, descending, ties by ascending index (snuffy.py:128-130).
+
+    scores: 1-D (any stride) f32.  With x [n, d] also returns the gathered rows x[idx] (snuffy.py:131).
+    """
+    if not scores.is_cuda:
+        raise _ffi.SnuffyHipError("topk: scores must be a GPU tensor (no CPU fallback)")
+    if scores.dtype != torch.float32 or scores.dim() != 1:
+        raise TypeError("topk: scores must be 1-D float32")
+    n = scores.shape[0]
+    stride = scores.stride(0) if n > 1 else 1
+    if stride < 1:
+        scores = scores.contiguous()
+        stride = 1
+    k = int(k)
+    if not (1 <= k <= n):
+        raise ValueError("topk: need 1 <= k <= n (k=%d, n=%d)" % (k, n))
+    lib = _ffi.load()
+    idx = torch.empty(k, dtype=torch.int64, device=scores.device)
+    wsb = lib.snf_topk_workspace_bytes(n, k)
+    ws = _ws(wsb, scores.device)
+    if x is None:
+        check(lib.snf_topk_f32(_p(scores), n, stride, k, _p(idx), _p(ws), wsb, _stream()), "snf_topk_f32")
+        return idx
+    x = _req(x, torch.float32, "x", 2)
+    xs = torch.empty(k, x.shape[1], dtype=torch.float32, device=x.device)
+    check(lib.snf_topk_gather_f32(_p(scores), n, stride, k, _p(idx), _p(x), x.shape[1], _p(xs), _p(ws), wsb,
+                                  _stream()), "snf_topk_gather_f32")
+    return idx, xs
+
+
+def gather_rows(x, idx):
+    x = _req(x, torch.float32, "x", 2)
+    idx = _req(idx, torch.int64, "idx", 1)
+    out = torch.empty(idx.shape[0], x.shape[1], dtype=torch.float32, device=x.device)
+    check(_ffi.load().snf_gather_rows_f32(_p(x), x.shape[0], x.shape[1], _p(idx), idx.shape[0], _p(out), _stream()),
+          "snf_gather_rows_f32")
+    return out
+
+
+def scatter_rows(x, idx, rows, inplace=False):
+    """y = x.clone(); y[idx] = rows  (snuffy.py:154-155); in place when asked."""
+    x = _req(x, torch.float32, "x", 2)
+    idx = _req(idx, torch.int64, "idx", 1)
+    rows = _req(rows, torch.float32, "rows", 2)
+    y = x if inplace else torch.empty_like(x)
+    check(_ffi.load().snf_scatter_rows_f32(_p(x), x.shape[0], x.shape[1], _p(idx), idx.shape[0], _p(rows), _p(y),
+                                           _stream()), "snf_scatter_rows_f32")
+    return y
+
+
+def scatter_add_rows_(z, idx, delta):
+    z = _req(z, torch.float32, "z", 2)
+    idx = _req(idx, torch.int64, "idx", 1)
+    delta = _req(delta, torch.float32, "delta", 2)
+    check(_ffi.load().snf_scatter_add_rows_f32(_p(z), z.shape[0], z.shape[1], _p(idx), idx.shape[0], _p(delta),
+                                               _stream()), "snf_scatter_add_rows_f32")
+    return z
+
+
+def slot_map(idx, n):
+    idx = _req(idx, torch.int64, "idx", 1)
+    m = torch.empty(n, dtype=torch.int32, device=idx.device)
+    check(_ffi.load().snf_slot_map_i32(_p(idx), idx.shape[0], n, _p(m), _stream()), "snf_slot_map_i32")
+    return m
+
+
+def layernorm_rows(x, gamma=None, beta=None, eps=1e-5, slot=None, patch_rows=None, out_dtype=torch.float32,
+                   want_stats=False, out=None, out_row_idx=None):
+    """LayerNorm over rows (snuffy.py:97,107); rows listed in `slot` are read from patch_rows instead of x.
+
+    out / out_row_idx: write row i of the result to out[out_row_idx[i]] (re-normalise patched rows in place)."""
+    x = _req(x, torch.float32, "x", 2)
+    n, d = x.shape
+    if gamma is not None:
+        gamma = _req(gamma, torch.float32, "gamma", 1)
+    if beta is not None:
+        beta = _req(beta, torch.float32, "beta", 1)
+    if slot is not None:
+        slot = _req(slot, torch.int32, "slot", 1)
+        patch_rows = _req(patch_rows, torch.float32, "patch_rows", 2)
+    if out is None:
+        if out_row_idx is not None:
+            raise ValueError("layernorm_rows: out_row_idx needs an explicit out buffer")
+        out = torch.empty(n, d, dtype=out_dtype, device=x.device)
+    else:
+        out_dtype = out.dtype
+        if not out.is_contiguous() or out.shape[1] != d:
+            raise ValueError("layernorm_rows: bad out buffer")
+    if out_row_idx is not None:
+        out_row_idx = _req(out_row_idx, torch.int64, "out_row_idx", 1)
+        if want_stats:
+            raise ValueError("layernorm_rows: stats with out_row_idx not supported")
+    of32 = out if out_dtype == torch.float32 else None
+    obf = out if out_dtype == torch.bfloat16 else None
+    if of32 is None and obf is None:
+        raise TypeError("layernorm_rows: out_dtype must be float32 or bfloat16")
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty(n, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(n, dtype=torch.float32, device=x.device)
+    check(_ffi.load().snf_layernorm_rows_f32(_p(x), n, d, _p(slot), _p(patch_rows), _p(gamma), _p(beta), float(eps),
+                                             _p(of32), _p(obf), _p(mean), _p(rstd), _p(out_row_idx), _stream()),
+          "snf_layernorm_rows_f32")
+    return (out, mean, rstd) if want_stats else out
+
+
+def bias_act_(h, bias, act):
+    """h = act(h + bias) in place (snuffy.py:224-225)."""
+    if not h.is_cuda or not h.is_contiguous() or h.dim() != 2:
+        raise _ffi.SnuffyHipError("bias_act_: h must be a contiguous 2-D GPU tensor")
+    dt = {torch.float32: DT_F32, torch.bfloat16: DT_BF16}.get(h.dtype)
+    if dt is None:
+        raise TypeError("bias_act_: h must be float32 or bfloat16")
+    if bias is not None:
+        bias = _req(bias, torch.float32, "bias", 1)
+    check(_ffi.load().snf_bias_act(_p(h), dt, h.shape[0], h.shape[1], _p(bias), ACT_CODES[act], _stream()),
+          "snf_bias_act")
+    return h
+
+
+def ln_mean_head(z, gamma, beta, eps, w_head, b_head, add_bf16=None, add_bias=None, slot=None, delta_rows=None,
+                 want_z=False):
+    """logits = W_head mean_n(LN(z')) + b_head  (snuffy.py:86,71) where z' = z (+ add_bf16) (+ add_bias)
+    (+ delta_rows[slot]).  Returns (logits [C], pooled [D], z' or None)."""
+    z = _req(z, torch.float32, "z", 2)
+    n, d = z.shape
+    if add_bf16 is not None:
+        add_bf16 = _req(add_bf16, torch.bfloat16, "add_bf16", 2)
+    if add_bias is not None:
+        add_bias = _req(add_bias, torch.float32, "add_bias", 1)
+    if slot is not None:
+        slot = _req(slot, torch.int32, "slot", 1)
+        delta_rows = _req(delta_rows, torch.float32, "delta_rows", 2)
+    z_out = torch.empty_like(z) if want_z else None
+    gamma = _req(gamma, torch.float32, "gamma", 1)
+    beta = _req(beta, torch.float32, "beta", 1)
+    w_head = _req(w_head, torch.float32, "w_head", 2)
+    if b_head is not None:
+        b_head = _req(b_head, torch.float32, "b_head", 1)
+    c = w_head.shape[0]
+    lib = _ffi.load()
+    logits = torch.empty(c, dtype=torch.float32, device=z.device)
+    pooled = torch.empty(d, dtype=torch.float32, device=z.device)
+    wsb = lib.snf_ln_mean_head_workspace_bytes(d)
+    ws = _ws(wsb, z.device)
+    check(lib.snf_ln_mean_head_f32(_p(z), n, d, _p(add_bf16), _p(add_bias), _p(slot), _p(delta_rows), _p(z_out),
+                                   _p(gamma), _p(beta), float(eps), _p(w_head), _p(b_head), c, _p(logits), _p(pooled),
+                                   _p(ws), wsb, _stream()), "snf_ln_mean_head_f32")
+    return logits, pooled, z_out
+
+
+def mfma_attn_supported(k, dk):
+    return dk in (64, 128) and 1 <= k <= 256
+
+
+def sparse_attn_fwd(q, kp, v, h, scale=None, need_attn=False, need_lse=False):
+    """Exact-fp32 sparse attention (snuffy.py:160-168). q, v [n, d]; kp [k, d] -> (out [k, d], attn [h,n,k], lse)."""
+    q = _req(q, torch.float32, "q", 2)
+    kp = _req(kp, torch.float32, "kp", 2)
+    v = _req(v, torch.float32, "v", 2)
+    n, d = q.shape
+    k = kp.shape[0]
+    if d % h:
+        raise ValueError("d_model %d not divisible by h %d" % (d, h))
+    dk = d // h
+    scale = 1.0 / math.sqrt(dk) if scale is None else scale
+    lib = _ffi.load()
+    out = torch.empty(k, d, dtype=torch.float32, device=q.device)
+    attn = torch.empty(h, n, k, dtype=torch.float32, device=q.device) if need_attn else None
+    lse = torch.empty(h, n, dtype=torch.float32, device=q.device) if need_lse else None
+    wsb = lib.snf_sparse_attn_fwd_workspace_bytes(n, k, h, dk, 0)
+    if need_attn:  # P lives in `attn`; only the partial-sum part of the workspace is needed
+        wsb -= ((h * n * k * 4 + 255) // 256) * 256
+    ws = _ws(wsb, q.device)
+    check(lib.snf_sparse_attn_fwd_f32(_p(q), _p(kp), _p(v), n, k, h, dk, float(scale), _p(out), _p(attn), _p(lse),
+                                      _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_f32")
+    return out, attn, lse
+
+
+def sparse_attn_fwd_mfma(q, vt, kp, n, h, scale=None, need_attn=False, need_lse=False):
+    """bf16-MFMA sparse attention. q [n, d]; vt = V^T [d, ldv] (ldv >= n, multiple of 8), both f32 or both bf16;
+    kp [k, d] f32."""
+    if q.dtype not in (torch.float32, torch.bfloat16) or vt.dtype != q.dtype:
+        raise TypeError("sparse_attn_fwd_mfma: q and vt must both be float32 or both bfloat16")
+    q = _req(q, q.dtype, "q", 2)
+    vt = _req(vt, vt.dtype, "vt", 2)
+    kp = _req(kp, torch.float32, "kp", 2)
+    d = q.shape[1]
+    k = kp.shape[0]
+    dk = d // h
+    ldv = vt.shape[1]
+    scale = 1.0 / math.sqrt(dk) if scale is None else scale
+    lib = _ffi.load()
+    out = torch.empty(k, d, dtype=torch.float32, device=q.device)
+    attn = torch.empty(h, n, k, dtype=torch.float32, device=q.device) if need_attn else None
+    lse = torch.empty(h, n, dtype=torch.float32, device=q.device) if need_lse else None
+    wsb = lib.snf_sparse_attn_fwd_workspace_bytes(n, k, h, dk, 1)
+    ws = _ws(wsb, q.device)
+    dt = DT_F32 if q.dtype == torch.float32 else DT_BF16
+    check(lib.snf_sparse_attn_fwd_mfma(_p(q), _p(vt), dt, ldv, _p(kp), n, k, h, dk, float(scale), _p(out), _p(attn),
+                                       _p(lse), _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_mfma")
+    return out, attn, lse

@@ -1,0 +1,260 @@
+"""MI355X-native drop-in for the reference's ``snuffy.py`` module API (binary / single-logit Snuffy MIL model).
+
+Same class names, constructor signatures, forward signatures, return tuples and state-dict keys as the reference
+(reference snuffy.py:34-238), so ``train.py`` / ``roi.py`` style callers switch by changing the import.
+Underneath, every op on the hot path is a hand-written HIP kernel reached through the C ABI of
+``include/snuffy_hip.h``; the dense projections are plain library GEMMs (hipBLASLt via torch.mm).
+
+Differences that are deliberate and documented:
+  * top-Lambda tie order is defined (descending score, ascending index) where torch.sort leaves it unspecified;
+  * ``BClassifier`` / ``EncoderLayer`` run a fused pipeline (no x.clone(), LayerNorm reads the K patched rows in place,
+    final LayerNorm + mean + head in one pass); results equal the unfused composition;
+  * ``configure(precision=..., return_attention=...)`` selects fp32 (reference-class numerics) or bf16-MFMA arithmetic,
+    and lets a caller that discards ``A`` (train.py:830 does) skip materialising the [1,h,N,K] tensor;
+  * inputs must live on the GPU: there is no CPU fallback.
+"""
+import copy
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as SF
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")  # reference snuffy.py:31
+
+
+class RuntimeConfig:
+    """Execution knobs shared by the modules of one MILNet (not part of the state dict)."""
+
+    def __init__(self, precision="fp32", return_attention=True):
+        self.set(precision, return_attention)
+
+    def set(self, precision=None, return_attention=None):
+        if precision is not None:
+            if precision not in ("fp32", "bf16"):
+                raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (precision,))
+            self.precision = precision
+        if return_attention is not None:
+            self.return_attention = bool(return_attention)
+
+
+def _share_config(module, cfg):
+    for m in module.modules():
+        if hasattr(m, "cfg"):
+            m.cfg = cfg
+
+
+class FCLayer(nn.Module):
+    """Critic: one Linear(in_size, out_size) over every patch.  Reference snuffy.py:34-41."""
+
+    def __init__(self, in_size, out_size=1):
+        super(FCLayer, self).__init__()
+        self.fc = nn.Sequential(nn.Linear(in_size, out_size))
+
+    def forward(self, feats):
+        lin = self.fc[0]
+        x = SF.critic_scores(feats, lin.weight, lin.bias)
+        return feats, x
+
+
+class IClassifier(nn.Module):
+    """feature_extractor + Linear head, returns (feats, c).  Reference snuffy.py:44-54."""
+
+    def __init__(self, feature_extractor, feature_size, output_class):
+        super(IClassifier, self).__init__()
+        self.feature_extractor = feature_extractor
+        self.fc = nn.Linear(feature_size, output_class)
+
+    def forward(self, x):
+        feats = self.feature_extractor(x)
+        feats = feats.view(feats.shape[0], -1)
+        c = SF.critic_scores(feats, self.fc.weight, self.fc.bias)
+        return feats, c
+
+
+def clones(module, N):
+    "Produce N identical layers (independent deep copies).  Reference snuffy.py:57-59."
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+class BClassifier(nn.Module):
+    """Encoder stack + mean-pool + Linear.  Reference snuffy.py:62-71."""
+
+    def __init__(self, encoder, num_classes, input_size: int):
+        super(BClassifier, self).__init__()
+        self.encoder = encoder
+        self.linear = nn.Linear(input_size, num_classes)
+        self.cfg = RuntimeConfig()
+        _share_config(self, self.cfg)
+
+    def configure(self, precision=None, return_attention=None):
+        self.cfg.set(precision, return_attention)
+        return self
+
+    def forward(self, x, c):
+        """x [1, N, D], c [1, N, 1] -> (logits [1, C], A [1, h, N, K])."""
+        x2, c1 = SF.check_bag(x, c)
+        z_parts, attn = self.encoder.run_layers(x2, c1)
+        logits = SF.head(z_parts, self.encoder.norm, self.linear)
+        return logits.view(1, -1), attn
+
+
+class Encoder(nn.Module):
+    "Core encoder is a stack of N layers followed by LayerNorm.  Reference snuffy.py:74-86."
+
+    def __init__(self, layer, N):
+        super(Encoder, self).__init__()
+        self.layers = clones(layer, N)
+        self.norm = nn.LayerNorm(layer.size)
+        self.cfg = RuntimeConfig()
+        _share_config(self, self.cfg)
+
+    def run_layers(self, x2, c1):
+        """Fused layer stack on x2 [N, D], c1 [N].  Returns (pending-z description of the last layer, A)."""
+        top = None
+        attn = None
+        parts = None
+        n_layers = len(self.layers)
+        for li, layer in enumerate(self.layers):
+            if parts is not None:
+                x2 = SF.materialize(parts)
+            if top is None:
+                top = SF.select_top(c1, layer.big_lambda, layer.top_big_lambda_share, x2.shape[0])
+            parts, attn = layer.run(x2, c1, top, need_attn=(li == n_layers - 1) and self.cfg.return_attention)
+        return parts, attn
+
+    def forward(self, x, c):
+        x2, c1 = SF.check_bag(x, c)
+        parts, attn = self.run_layers(x2, c1)
+        z = SF.materialize(parts)
+        zn = SF.layer_norm(z, self.norm)
+        return zn.unsqueeze(0), attn
+
+
+class SublayerConnection(nn.Module):
+    """Residual connection with the norm first.  Reference snuffy.py:89-110."""
+
+    def __init__(self, size, dropout):
+        super(SublayerConnection, self).__init__()
+        self.norm = nn.LayerNorm(size)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x, sublayer, c, top_big_lambda_indices, random_indices, mode):
+        if mode == 'attn':
+            x2 = SF.as_2d(x)
+            idx = top_big_lambda_indices if random_indices is None else torch.cat(
+                (top_big_lambda_indices, random_indices))
+            top_big_lambda = SF.gather(x2, idx).unsqueeze(0)
+            multiheadedattn = sublayer(SF.layer_norm(x2, self.norm).unsqueeze(0))
+            return top_big_lambda + self.dropout(multiheadedattn[0]), multiheadedattn[1]
+        elif mode == 'ff':
+            x2 = SF.as_2d(x)
+            return x + self.dropout(sublayer(SF.layer_norm(x2, self.norm).unsqueeze(0)))
+
+
+class EncoderLayer(nn.Module):
+    "Top-Lambda (+random) selection, sparse self-attention on the selected rows, feed forward.  snuffy.py:113-157."
+
+    def __init__(self, size, self_attn, feed_forward, dropout, big_lambda, random_patch_share):
+        super(EncoderLayer, self).__init__()
+        self.self_attn = self_attn
+        self.feed_forward = feed_forward
+        self.sublayer = clones(SublayerConnection(size, dropout), 2)
+        self.size = size
+        self.big_lambda = big_lambda
+        self.random_patch_share = random_patch_share
+        self.top_big_lambda_share = 1.0 - random_patch_share
+        self.last_selection = None
+        self.cfg = RuntimeConfig()
+        _share_config(self, self.cfg)
+
+    def select(self, c1, n, top=None):
+        """Selected row indices S = top ++ random (snuffy.py:128-147). The random part follows the reference exactly:
+        np.random.choice on the global numpy RNG over the ascending complement of `top`."""
+        if top is None:
+            top = SF.select_top(c1, self.big_lambda, self.top_big_lambda_share, n)
+        k2 = min(int(self.big_lambda * self.random_patch_share),
+                 max(0, n - math.ceil(self.big_lambda * self.top_big_lambda_share)))
+        if k2 == 0:
+            return top, None
+        mask = np.ones(n, dtype=bool)
+        mask[top.cpu().numpy()] = False                      # device->host sync, as .tolist() in snuffy.py:136
+        remaining = np.nonzero(mask)[0]
+        rnd = np.random.choice(remaining, k2, replace=False)
+        return top, torch.from_numpy(rnd.astype(np.int64)).to(top.device)
+
+    def run(self, x2, c1, top=None, need_attn=True):
+        top, rnd = self.select(c1, x2.shape[0], top)
+        self.last_selection = (top, rnd)                    # inspection hook (tests / heat-maps)
+        sel = top if rnd is None else torch.cat((top, rnd))
+        return SF.encoder_layer(x2, sel, self, need_attn, self.cfg.precision)
+
+    def forward(self, x, c):
+        "x [1, N, D], c [1, N, 1] -> (z [1, N, D], A [1, h, N, K])"
+        x2, c1 = SF.check_bag(x, c)
+        parts, attn = self.run(x2, c1, None, self.cfg.return_attention)
+        return SF.materialize(parts).unsqueeze(0), attn
+
+
+def attention(query, key, value, dropout=None):
+    """'Scaled Dot Product Attention' with the transposed pooling of the reference (snuffy.py:160-168).
+
+    query, value [1, h, N, dk]; key [1, h, K, dk] -> (p_attn^T value [1, h, K, dk], p_attn [1, h, N, K])."""
+    return SF.attention_4d(query, key, value, dropout)
+
+
+class MultiHeadedAttention(nn.Module):
+    "Reference snuffy.py:171-205."
+
+    def __init__(self, h, d_model, dropout=0.1):
+        super(MultiHeadedAttention, self).__init__()
+        assert d_model % h == 0
+        self.d_big_lambda = d_model // h
+        self.h = h
+        self.linears = clones(nn.Linear(d_model, d_model), 4)
+        self.attn = None
+        self.dropout = nn.Dropout(p=dropout)
+        self.cfg = RuntimeConfig()
+
+    def forward(self, query, key, value):
+        "query = value = LN(x) [1, N, D]; key = selected raw rows [1, K, D] -> (out [1, K, D], P [1, h, N, K])"
+        out, self.attn = SF.mha_forward(self, SF.as_2d(query), SF.as_2d(key), SF.as_2d(value), True,
+                                        self.cfg.precision)
+        return out.unsqueeze(0), self.attn
+
+
+class PositionwiseFeedForward(nn.Module):
+    "FFN: w_2(dropout(activation(w_1(x)))).  Reference snuffy.py:208-225."
+
+    def __init__(self, d_model, d_ff, activation, dropout=0.1):
+        super(PositionwiseFeedForward, self).__init__()
+        self.w_1 = nn.Linear(d_model, d_ff)
+        self.w_2 = nn.Linear(d_ff, d_model)
+        self.dropout = nn.Dropout(dropout)
+        if activation not in SF.ACTIVATIONS:
+            raise KeyError(activation)                      # same failure as the reference's dictionary lookup
+        self.activation_name = activation
+        self.cfg = RuntimeConfig()
+
+    def forward(self, x):
+        return SF.ffn_forward(self, SF.as_2d(x), self.cfg.precision).view(x.shape)
+
+
+class MILNet(nn.Module):
+    "Reference snuffy.py:228-238."
+
+    def __init__(self, i_classifier, b_classifier):
+        super(MILNet, self).__init__()
+        self.i_classifier = i_classifier
+        self.b_classifier = b_classifier
+
+    def configure(self, precision=None, return_attention=None):
+        self.b_classifier.configure(precision, return_attention)
+        return self
+
+    def forward(self, x):
+        feats, classes = self.i_classifier(x)
+        prediction_bag, A = self.b_classifier(feats, classes)
+        return classes, prediction_bag, A

@@ -39,3 +39,24 @@ class ReplayRNG:
 
     def permutation(self, n):
         return self.rs.permutation(n)
+
+
+def build_amd_milnet(D, h, act, big_lambda, r, depth, C=1, mlp=4, enc_drop=0.0):
+    """Same construction sequence as the reference's train.Snuffy._get_milnet (train.py:861-890)."""
+    import copy
+
+    from snuffy_amd import snuffy
+    i_classifier = snuffy.FCLayer(in_size=D, out_size=C)
+    attn = snuffy.MultiHeadedAttention(h, D)
+    ff = snuffy.PositionwiseFeedForward(D, D * mlp, act, enc_drop)
+    b_classifier = snuffy.BClassifier(
+        snuffy.Encoder(snuffy.EncoderLayer(D, copy.deepcopy(attn), copy.deepcopy(ff), enc_drop, big_lambda, r), depth),
+        C, D)
+    return snuffy.MILNet(i_classifier, b_classifier)
+
+
+def rel_err(a, b):
+    """max |a-b| / max |b| (normalised max error)."""
+    a = a.double()
+    b = b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))

@@ -1,0 +1,256 @@
+"""Parity of every HIP kernel (through the C ABI / ctypes) against the CPU oracle.  Needs a real MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import snuffy_oracle as orc
+from tests.helpers import golden_files, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def ops():
+    from snuffy_amd import ops as o
+    return o
+
+
+# ---------------------------------------------------------------- K2 top-k: bit-exact
+def test_topk_golden_tiefree_and_ties():
+    z = np.load(golden_files("f2_")[0])
+    for n in (5000, 32768):
+        c = torch.from_numpy(z[f"tiefree_c_{n}"]).to(DEV)
+        for k in (1, 10, 200, 512, 1024):
+            idx = ops().topk(c, k).cpu().numpy()
+            assert np.array_equal(idx, z[f"tiefree_order_{n}"][:k]), (n, k)
+    c = torch.from_numpy(z["ties_c"]).to(DEV)
+    assert np.array_equal(ops().topk(c, 1024).cpu().numpy(), z["ties_stable_order"])
+    sp = torch.from_numpy(z["special_c"]).to(DEV)
+    assert np.array_equal(ops().topk(sp, sp.numel()).cpu().numpy(), z["special_stable_order"])
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (2, 2), (63, 10), (4096, 200), (4097, 200), (8192, 2048), (100000, 512),
+                                 (100000, 1), (40, 40), (300000, 900)])
+def test_topk_random_vs_oracle(n, k):
+    g = torch.Generator().manual_seed(n * 7 + k)
+    c = torch.randn(n, generator=g)
+    m = min(c[::5].numel(), c[1::5].numel())
+    c[::5][:m] = c[1::5][:m]  # inject exact ties
+    want = orc.topk_desc_stable(c, k).numpy()
+    got = ops().topk(c.to(DEV), k).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_topk_strided_and_gather_and_nan():
+    g = torch.Generator().manual_seed(3)
+    c2 = torch.randn(5000, 3, generator=g)
+    x = torch.randn(5000, 96, generator=g)
+    cd = c2.to(DEV)
+    idx, xs = ops().topk(cd[:, 1], 77, x=x.to(DEV))
+    want = orc.topk_desc_stable(c2[:, 1], 77)
+    assert np.array_equal(idx.cpu().numpy(), want.numpy())
+    assert torch.equal(xs.cpu(), x[want])
+    c = torch.randn(1000, generator=g)
+    c[17] = float("nan")
+    c[500] = float("inf")
+    got = ops().topk(c.to(DEV), 3).cpu().tolist()
+    assert got[:2] == [17, 500]          # NaN first (torch.sort semantics), then +inf
+
+
+# ---------------------------------------------------------------- K1 critic
+@pytest.mark.parametrize("n,d,c", [(1, 64, 1), (1000, 166, 1), (4099, 384, 2), (513, 768, 1), (100, 2048, 3)])
+def test_critic(n, d, c):
+    g = torch.Generator().manual_seed(n + d)
+    x, w, b = torch.randn(n, d, generator=g), torch.randn(c, d, generator=g) / math.sqrt(d), torch.randn(c, generator=g)
+    s, mv, mi = ops().critic(x.to(DEV), w.to(DEV), b.to(DEV), want_max=True)
+    ref = F.linear(x.double(), w.double(), b.double())
+    assert (s.cpu().double() - ref).abs().max() < 2e-5
+    s_cpu = s.cpu()
+    mvr, mir = s_cpu.max(dim=0)
+    assert torch.equal(mv.cpu(), mvr)
+    assert torch.equal(mi.cpu(), mir)
+
+
+# ---------------------------------------------------------------- K5 LayerNorm (+ fused patch rows)
+@pytest.mark.parametrize("n,d", [(1, 64), (333, 166), (2050, 384), (1000, 768), (64, 2048)])
+def test_layernorm_rows(n, d):
+    g = torch.Generator().manual_seed(d)
+    x = torch.randn(n, d, generator=g) * 3 + 1
+    gam, bet = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    ref = F.layer_norm(x.double(), (d,), gam.double(), bet.double(), 1e-5)
+    out, mean, rstd = ops().layernorm_rows(x.to(DEV), gam.to(DEV), bet.to(DEV), 1e-5, want_stats=True)
+    assert (out.cpu().double() - ref).abs().max() < 2e-5
+    assert (mean.cpu() - x.mean(1)).abs().max() < 1e-5
+    assert rel_err(rstd.cpu(), 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)) < 1e-5
+    # plain normalisation to bf16
+    ob = ops().layernorm_rows(x.to(DEV), None, None, 1e-5, out_dtype=torch.bfloat16)
+    refn = F.layer_norm(x.double(), (d,), None, None, 1e-5)
+    assert (ob.cpu().double() - refn).abs().max() < 2e-2
+    # patched rows
+    k = min(n, 7)
+    sel = torch.randperm(n, generator=g)[:k]
+    rows = torch.randn(k, d, generator=g)
+    y = x.clone()
+    y[sel] = rows
+    slot = ops().slot_map(sel.to(DEV), n)
+    m = torch.full((n,), -1, dtype=torch.int32)
+    m[sel] = torch.arange(k, dtype=torch.int32)
+    assert torch.equal(slot.cpu(), m)
+    outp = ops().layernorm_rows(x.to(DEV), gam.to(DEV), bet.to(DEV), 1e-5, slot=slot, patch_rows=rows.to(DEV))
+    refp = F.layer_norm(y.double(), (d,), gam.double(), bet.double(), 1e-5)
+    assert (outp.cpu().double() - refp).abs().max() < 2e-5
+    # re-normalise K rows into an existing bf16 buffer
+    buf = ob.clone()
+    ops().layernorm_rows(rows.to(DEV), None, None, 1e-5, out=buf, out_row_idx=sel.to(DEV))
+    refb = F.layer_norm(y.double(), (d,), None, None, 1e-5)
+    assert (buf.cpu().double() - refb).abs().max() < 2e-2
+
+
+def test_gather_scatter():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1000, 166, generator=g)
+    sel = torch.randperm(1000, generator=g)[:200]
+    rows = torch.randn(200, 166, generator=g)
+    xd, sd, rd = x.to(DEV), sel.to(DEV), rows.to(DEV)
+    assert torch.equal(ops().gather_rows(xd, sd).cpu(), x[sel])
+    y = x.clone()
+    y[sel] = rows
+    assert torch.equal(ops().scatter_rows(xd, sd, rd).cpu(), y)
+    assert torch.equal(xd.cpu(), x)                      # input untouched
+    z = xd.clone()
+    ops().scatter_add_rows_(z, sd, rd)
+    w = x.clone()
+    w[sel] += rows
+    assert torch.equal(z.cpu(), w)
+
+
+@pytest.mark.parametrize("act", ["relu", "gelu", "leakyrelu", "selu", "none"])
+def test_bias_act(act):
+    g = torch.Generator().manual_seed(9)
+    for n, f in [(100, 256), (37, 166), (513, 3072)]:
+        h = torch.randn(n, f, generator=g) * 2
+        b = torch.randn(f, generator=g)
+        ref = (h + b).double()
+        ref = ref if act == "none" else orc.ACTIVATIONS[act](ref)
+        hd = h.to(DEV)
+        ops().bias_act_(hd, b.to(DEV), act)
+        assert (hd.cpu().double() - ref).abs().max() < 1e-5
+        if f % 8 == 0:
+            hb = h.to(DEV).to(torch.bfloat16)
+            refb = (hb.cpu().float() + b).double()
+            refb = refb if act == "none" else orc.ACTIVATIONS[act](refb)
+            ops().bias_act_(hb, b.to(DEV), act)
+            assert rel_err(hb.cpu().float(), refb.float()) < 1e-2
+
+
+@pytest.mark.parametrize("n,d,c", [(1, 64, 1), (1000, 166, 1), (5000, 384, 2), (3001, 768, 1)])
+def test_ln_mean_head(n, d, c):
+    g = torch.Generator().manual_seed(n)
+    z = torch.randn(n, d, generator=g) * 2 + 0.5
+    gam, bet = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    w, b = torch.randn(c, d, generator=g) / math.sqrt(d), torch.randn(c, generator=g)
+    pooled_ref = F.layer_norm(z.double(), (d,), gam.double(), bet.double(), 1e-5).mean(0)
+    ref = F.linear(pooled_ref, w.double(), b.double())
+    logits, pooled, _ = ops().ln_mean_head(z.to(DEV), gam.to(DEV), bet.to(DEV), 1e-5, w.to(DEV), b.to(DEV))
+    assert (pooled.cpu().double() - pooled_ref).abs().max() < 1e-5
+    assert (logits.cpu().double() - ref).abs().max() < 1e-5
+    # fused residual assembly
+    k = min(n, 9)
+    sel = torch.randperm(n, generator=g)[:k]
+    delta = torch.randn(k, d, generator=g)
+    addb = (torch.randn(n, d, generator=g)).to(torch.bfloat16)
+    bias = torch.randn(d, generator=g)
+    zz = z + addb.float() + bias
+    zz[sel] += delta
+    ref2 = F.linear(F.layer_norm(zz.double(), (d,), gam.double(), bet.double(), 1e-5).mean(0), w.double(), b.double())
+    slot = ops().slot_map(sel.to(DEV), n)
+    l2, _, zo = ops().ln_mean_head(z.to(DEV), gam.to(DEV), bet.to(DEV), 1e-5, w.to(DEV), b.to(DEV), add_bf16=addb.to(DEV),
+                                   add_bias=bias.to(DEV), slot=slot, delta_rows=delta.to(DEV), want_z=True)
+    assert (l2.cpu().double() - ref2).abs().max() < 1e-5
+    assert (zo.cpu() - zz).abs().max() < 1e-5
+
+
+# ---------------------------------------------------------------- K7 sparse attention
+def attn_ref(q, kp, v, h):
+    o, p = orc.sparse_attention(q.double(), kp.double(), v.double(), h)
+    return o, p
+
+
+@pytest.mark.parametrize("n,k,h,dk", [(40, 40, 2, 83), (1000, 200, 6, 16), (3000, 900, 4, 24), (777, 64, 1, 128),
+                                      (257, 5, 3, 7), (1, 1, 2, 32), (5000, 512, 6, 128), (17, 17, 2, 256)])
+def test_sparse_attn_exact(n, k, h, dk):
+    g = torch.Generator().manual_seed(n + k)
+    d = h * dk
+    q, kp, v = torch.randn(n, d, generator=g), torch.randn(k, d, generator=g), torch.randn(n, d, generator=g)
+    o_ref, p_ref = attn_ref(q, kp, v, h)
+    o, attn, lse = ops().sparse_attn_fwd(q.to(DEV), kp.to(DEV), v.to(DEV), h, need_attn=True, need_lse=True)
+    assert (attn.cpu().double() - p_ref).abs().max() < 1e-6
+    assert rel_err(o.cpu(), o_ref) < 1e-5
+    s = torch.matmul(q.double().view(n, h, dk).transpose(0, 1), kp.double().view(k, h, dk).transpose(0, 1).transpose(1, 2))
+    lse_ref = torch.logsumexp(s / math.sqrt(dk), dim=-1)
+    assert (lse.cpu().double() - lse_ref).abs().max() < 1e-4
+    o2, _, _ = ops().sparse_attn_fwd(q.to(DEV), kp.to(DEV), v.to(DEV), h)     # P in workspace
+    assert torch.equal(o2, o)
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("n,k,h,dk", [(1, 1, 1, 64), (100, 31, 2, 64), (128, 32, 6, 64), (129, 33, 3, 128),
+                                      (1000, 64, 6, 128), (4099, 100, 6, 64), (2500, 200, 6, 128), (3000, 224, 2, 128),
+                                      (777, 256, 6, 64), (1500, 250, 1, 128), (8192, 200, 6, 64), (640, 129, 4, 128)])
+def test_sparse_attn_mfma(n, k, h, dk, dt):
+    g = torch.Generator().manual_seed(n * 3 + k)
+    d = h * dk
+    q, kp, v = torch.randn(n, d, generator=g), torch.randn(k, d, generator=g), torch.randn(n, d, generator=g)
+    n8 = (n + 7) // 8 * 8
+    vt = torch.full((d, n8), float("nan"))          # poison the pad: the kernel must never read it
+    vt[:, :n] = v.t()
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    o, attn, lse = ops().sparse_attn_fwd_mfma(q.to(DEV).to(tdt), vt.to(DEV).to(tdt), kp.to(DEV), n, h,
+                                              need_attn=True, need_lse=True)
+    # (a) against the exact oracle: bf16-class tolerance (north star: 1e-2)
+    o_ref, p_ref = attn_ref(q, kp, v, h)
+    assert (attn.cpu().double() - p_ref).abs().max() < 1e-2
+    assert rel_err(o.cpu(), o_ref) < 1e-2
+    # (b) against the oracle fed with the same bf16-rounded operands: tight (catches any layout slip)
+    o_r, p_r = attn_ref(bf16r(q), bf16r(kp), bf16r(v), h)
+    assert (attn.cpu().double() - p_r).abs().max() < 2e-5 + 2e-3 * float(p_r.max())
+    assert rel_err(o.cpu(), o_r) < 3e-3
+    # rows of P sum to one; sum over keys of O equals the column sums of V (size-independent checksum)
+    assert (attn.sum(-1) - 1).abs().max() < 1e-4
+    assert rel_err(o.cpu().view(k, h, dk).sum(0), bf16r(v).view(n, h, dk).sum(0)) < 5e-3
+    # run-to-run determinism
+    o2, attn2, _ = ops().sparse_attn_fwd_mfma(q.to(DEV).to(tdt), vt.to(DEV).to(tdt), kp.to(DEV), n, h, need_attn=True)
+    assert torch.equal(o2, o) and torch.equal(attn2, attn)
+    # without materialising A the output is the same
+    o3, a3, _ = ops().sparse_attn_fwd_mfma(q.to(DEV).to(tdt), vt.to(DEV).to(tdt), kp.to(DEV), n, h)
+    assert a3 is None and torch.equal(o3, o)
+
+
+def test_sparse_attn_mfma_online_max_spike():
+    """A key row that dominates one query (score >> others) must not overflow or lose the other rows."""
+    n, k, h, dk = 512, 200, 6, 128
+    g = torch.Generator().manual_seed(0)
+    d = h * dk
+    q, kp, v = torch.randn(n, d, generator=g), torch.randn(k, d, generator=g), torch.randn(n, d, generator=g)
+    q[7] *= 40.0
+    kp[3] *= 25.0
+    vt = v.t().contiguous()
+    o, attn, _ = ops().sparse_attn_fwd_mfma(q.to(DEV), vt.to(DEV), kp.to(DEV), n, h, need_attn=True)
+    assert torch.isfinite(o).all() and torch.isfinite(attn).all()
+    o_r, p_r = attn_ref(bf16r(q), bf16r(kp), bf16r(v), h)
+    assert (attn.cpu().double() - p_r).abs().max() < 5e-3
+    assert rel_err(o.cpu(), o_r) < 3e-3
+
+
+def test_mfma_rejects_unsupported_shapes():
+    from snuffy_amd import SnuffyHipError
+    q = torch.zeros(64, 96, device=DEV)
+    with pytest.raises(SnuffyHipError):
+        ops().sparse_attn_fwd_mfma(q, torch.zeros(96, 64, device=DEV), torch.zeros(8, 96, device=DEV), 64, 2)  # dk=48

@@ -1,0 +1,154 @@
+"""Model-level parity on the GPU: snuffy_amd.snuffy.MILNet (HIP kernels through the C ABI) against
+(a) the golden vectors captured from the reference, (b) the CPU oracle at the benchmark sizes."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import snuffy_oracle as orc
+from tests.helpers import ReplayRNG, build_amd_milnet, forced_sel, golden_files, load_case, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+# north-star tolerances: fp32 1e-3, bf16 1e-2 (attention / logits)
+TOL = {"fp32": 1e-3, "bf16": 1e-2}
+
+
+def load_net(z, sd, precision):
+    N, D, h, lam, depth, seed = [int(v) for v in z["cfg"]]
+    net = build_amd_milnet(D, h, str(z["act"]), lam, float(z["r"]), depth)
+    net.load_state_dict(sd, strict=True)        # same key names as the reference's checkpoints
+    return net.to(DEV).eval().configure(precision=precision, return_attention=True)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("path", golden_files("f1_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_f1_golden_forward(path, precision):
+    z, sd = load_case(path)
+    N, D, h, lam, depth, seed = [int(v) for v in z["cfg"]]
+    net = load_net(z, sd, precision)
+    x = torch.from_numpy(z["x"]).to(DEV)
+    np.random.seed(seed)                         # the random share draws from the global numpy RNG like the reference
+    with torch.no_grad():
+        classes, logits, A = net(x)
+    assert classes.shape == (1, N, 1) and logits.shape == (1, 1)
+    np.testing.assert_allclose(classes.cpu().numpy(), z["classes"], rtol=0, atol=2e-5)
+    tol = TOL[precision]
+    np.testing.assert_allclose(logits.cpu().numpy(), z["logits"], rtol=0, atol=tol)
+    if "A" in z.files:
+        assert A.shape == z["A"].shape
+        np.testing.assert_allclose(A.cpu().numpy(), z["A"], rtol=0, atol=tol)
+    else:
+        np.testing.assert_allclose(A[:, :, torch.from_numpy(z["A_rows"]).to(DEV), :].cpu().numpy(), z["A_sub"],
+                                   rtol=0, atol=tol)
+    if precision == "fp32":                      # tight check too: the fp32 path is reference-class
+        np.testing.assert_allclose(logits.cpu().numpy(), z["logits"], rtol=0, atol=3e-5)
+
+
+@pytest.mark.parametrize("path", golden_files("f1_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_f1_selection_bit_exact_at_bclassifier_boundary(path):
+    """With the reference's own critic scores as input, top-Lambda and the random draw are bit-identical."""
+    z, sd = load_case(path)
+    N, D, h, lam, depth, seed = [int(v) for v in z["cfg"]]
+    net = load_net(z, sd, "fp32")
+    x = torch.from_numpy(z["x"]).to(DEV)
+    c = torch.from_numpy(z["classes"]).to(DEV)
+    np.random.seed(seed)
+    with torch.no_grad():
+        logits, A = net.b_classifier(x, c)
+    k1, k2 = orc.k_split(lam, float(z["r"]), N)
+    for l, layer in enumerate(net.b_classifier.encoder.layers):
+        top, rnd = layer.last_selection
+        assert np.array_equal(top.cpu().numpy(), z["top"])
+        if k2:
+            assert np.array_equal(rnd.cpu().numpy(), z[f"rnd{l}"])
+        else:
+            assert rnd is None
+    np.testing.assert_allclose(logits.cpu().numpy(), z["logits"], rtol=0, atol=3e-5)
+
+
+def synth_state(D, h, depth, seed=0):
+    """train.py defaults: xavier_normal weights, zero biases (train.py:68-72, utils.py:69-75)."""
+    torch.manual_seed(seed)
+    net = build_amd_milnet(D, h, "relu", 200, 0.0, depth)
+    for _, p in net.named_parameters():
+        if p.dim() > 1:
+            torch.nn.init.xavier_normal_(p)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.zeros_(m.bias)
+    return net
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("N,D,lam", [(8192, 384, 200), (32768, 768, 200), (100000, 768, 512)])
+def test_benchmark_sizes_vs_oracle(N, D, lam, precision):
+    """BASELINE.json configs A / B / C: full-size comparison against the CPU oracle (seconds on the host)."""
+    h = 6
+    net = synth_state(D, h, 1)
+    net.b_classifier.encoder.layers[0].big_lambda = lam
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(N, D, generator=g)
+    classes_ref, logits_ref, p_ref, sels = orc.milnet_forward(x, sd, h, "relu", lam, 0.0, 1)
+    net = net.to(DEV).eval().configure(precision=precision, return_attention=True)
+    with torch.no_grad():
+        classes, logits, A = net(x.to(DEV).unsqueeze(0))
+        # selection is bit-exact when the scores are the oracle's
+        _, A2 = net.b_classifier(x.to(DEV).unsqueeze(0), classes_ref.to(DEV).unsqueeze(0))
+    top, _ = net.b_classifier.encoder.layers[0].last_selection
+    assert np.array_equal(top.cpu().numpy(), sels[0].numpy())
+    tol = TOL[precision]
+    assert (classes.cpu()[0] - classes_ref).abs().max() < 2e-5
+    assert (logits.cpu()[0] - logits_ref).abs().max() < tol
+    rows = torch.arange(0, N, 97)
+    assert (A2[0][:, rows.to(DEV), :].cpu() - p_ref[:, rows, :]).abs().max() < tol
+    assert (A2.sum(-1) - 1).abs().max() < 1e-4
+    # return_attention=False gives the same logits without the [1,h,N,K] tensor
+    net.configure(return_attention=False)
+    with torch.no_grad():
+        _, logits2, A3 = net(x.to(DEV).unsqueeze(0))
+    assert A3 is None and torch.equal(logits2, logits)
+
+
+def test_ragged_and_edge_bags():
+    """N < Lambda (K = N), N == 1, depth 5, every activation -- through both precisions, vs the oracle."""
+    for N, D, h, lam, r, depth, act in [(1, 64, 2, 10, 0.0, 1, "relu"), (7, 128, 2, 200, 0.0, 2, "gelu"),
+                                        (300, 384, 6, 200, 0.25, 5, "selu"), (1025, 128, 1, 64, 0.5, 1, "leakyrelu")]:
+        net = synth_state(D, h, depth, seed=N)
+        for layer in net.b_classifier.encoder.layers:
+            layer.big_lambda, layer.random_patch_share, layer.top_big_lambda_share = lam, r, 1.0 - r
+            layer.feed_forward.activation_name = act
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        x = torch.randn(N, D, generator=torch.Generator().manual_seed(N))
+        _, logits_ref, p_ref, _ = orc.milnet_forward(x, sd, h, act, lam, r, depth, ReplayRNG(5))
+        for precision in ("fp32", "bf16"):
+            net = net.to(DEV).eval().configure(precision=precision)
+            np.random.seed(5)
+            with torch.no_grad():
+                _, logits, A = net(x.to(DEV).unsqueeze(0))
+            assert (logits.cpu()[0] - logits_ref).abs().max() < TOL[precision], (N, precision)
+            assert (A.cpu()[0] - p_ref).abs().max() < TOL[precision]
+
+
+def test_module_level_api_matches_reference_call_sites():
+    """roi.py:177-194 style: i_classifier then b_classifier; Encoder / EncoderLayer / MHA callable on their own."""
+    z, sd = load_case(golden_files("f1_n1000")[0])
+    net = load_net(z, sd, "fp32")
+    x = torch.from_numpy(z["x"]).to(DEV)
+    with torch.no_grad():
+        feats, c = net.i_classifier(x)
+        logits, A = net.b_classifier(feats, c)
+        zn, A2 = net.b_classifier.encoder(feats, c)
+        lz, A3 = net.b_classifier.encoder.layers[0](feats, c)
+    assert feats.shape == x.shape and c.shape == (1, 1000, 1)
+    np.testing.assert_allclose(logits.cpu().numpy(), z["logits"], rtol=0, atol=3e-5)
+    assert zn.shape == x.shape and lz.shape == x.shape
+    lin = net.b_classifier.linear
+    np.testing.assert_allclose(torch.nn.functional.linear(zn.mean(dim=1), lin.weight, lin.bias).cpu().numpy(),
+                               z["logits"], rtol=0, atol=3e-5)
+    assert torch.equal(A, A2) and torch.equal(A, A3)
+    with pytest.raises(IndexError):
+        net(torch.cat([x, x]))                    # binary model: one bag per forward (as the reference)
