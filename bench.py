@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: slides/sec of the Snuffy MIL aggregator + sparse-attention HBM GB/s on MI355X.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step = one bag (slide) through MILNet (critic -> top-Lambda -> sparse attention -> FFN -> head) per rank, bags already
+resident in HBM.  Workload = BASELINE.json's metric shape (config B): N=32768 patches, D=768, h=6, Lambda=200.
+Bag-parallel (weak scaling): every rank owns its own bags; --mode train adds backward + AdamW + ONE RCCL all-reduce of
+the flat gradient per step.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "cfgB": dict(N=32768, D=768, h=6, lam=200),    # BASELINE.json metric shape
+    "cfgA": dict(N=8192, D=384, h=6, lam=200),
+    "cfgC": dict(N=100000, D=768, h=6, lam=512),
+}
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def build_net(D, h, lam, precision, device):
+    from tests.helpers import build_amd_milnet
+    torch.manual_seed(0)
+    net = build_amd_milnet(D, h, "relu", lam, 0.0, 1)
+    for _, p in net.named_parameters():
+        if p.dim() > 1:
+            torch.nn.init.xavier_normal_(p)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.zeros_(m.bias)
+    return net.to(device).configure(precision=precision, return_attention=False)
+
+
+def timed(fn, iters, warmup=2):
+    """Average ms per call measured with HIP events on torch's current stream (the stream our kernels launch on)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def kernel_rooflines(wl, precision, device):
+    """Live timing of the north-star kernels on synthetic operands of the workload's shape."""
+    from snuffy_amd import ops
+    N, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
+    K, dk = min(lam, N), D // h
+    g = torch.Generator(device="cpu").manual_seed(7)
+    dt = torch.bfloat16 if precision == "bf16" else torch.float32
+    elt = 2 if precision == "bf16" else 4
+    n8 = (N + 7) // 8 * 8
+    out = {}
+    scores = torch.randn(N, generator=g).to(device)
+    t_topk = timed(lambda: ops.topk(scores, K), 20)
+    kp = torch.randn(K, D, generator=g).to(device)
+    # rotate over several operand sets so the 256 MiB Infinity Cache cannot serve the re-reads
+    nset = max(2, int(math.ceil(600e6 / (2 * N * D * elt))))
+    qs = [torch.randn(N, D, generator=g).to(device).to(dt) for _ in range(nset)]
+    vts = [torch.randn(D, n8, generator=g).to(device).to(dt) for _ in range(nset)]
+    state = {"i": 0}
+    if ops.mfma_attn_supported(K, dk):
+        def attn():
+            i = state["i"] = (state["i"] + 1) % nset
+            ops.sparse_attn_fwd_mfma(qs[i], vts[i], kp, N, h)
+        kern = "sparse_attn_mfma_kernel+reduce_partials_kernel"
+    else:
+        vs = [v[:, :N].t().float().contiguous() for v in vts]
+        qf = [q.float() for q in qs]
+
+        def attn():
+            i = state["i"] = (state["i"] + 1) % nset
+            ops.sparse_attn_fwd(qf[i], kp, vs[i], h)
+        kern = "scores_softmax_kernel+pt_v_kernel+reduce_slices_kernel"
+        elt = 4
+    t_attn = timed(attn, 20, warmup=3)
+    # algorithmic bytes: read Q and V once, read Kp, write O;  top-k: read N scores, write K indices
+    b_attn = 2 * N * D * elt + K * D * 4 + K * D * 4
+    b_topk = 4 * N + 8 * K
+    b_gather = 2 * K * D * 4
+    out["roofline"] = dict(bound="hbm", kernel=kern, achieved=round(b_attn / (t_attn * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS,
+                           unit="GB/s", frac=round(b_attn / (t_attn * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
+                           us_per_launch=round(t_attn * 1e3, 2), algorithmic_bytes=b_attn,
+                           flops=4 * N * K * D, operand_dtype=precision)
+    t_unit = t_attn + t_topk
+    b_unit = b_attn + b_topk + b_gather
+    out["roofline_topk_attn"] = dict(bound="hbm", achieved=round(b_unit / (t_unit * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS,
+                                     unit="GB/s", frac=round(b_unit / (t_unit * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     us_topk=round(t_topk * 1e3, 2), us_attn=round(t_attn * 1e3, 2),
+                                     algorithmic_bytes=b_unit)
+    del qs, vts
+    return out
+
+
+def cpu_baseline(wl, budget_s=25.0):
+    """The CPU oracle (a torch-CPU port of the reference's op sequence) timed on this host's cores."""
+    from oracle import snuffy_oracle as orc          # cpu_baseline leg: the only place bench.py touches oracle/
+    N, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
+    cores = os.cpu_count() or 1
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or cores
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    net = build_net(D, h, lam, "fp32", "cpu")
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = torch.randn(N, D, generator=torch.Generator().manual_seed(1234))
+    with torch.no_grad():
+        orc.milnet_forward(x, sd, h, "relu", lam, 0.0, 1)           # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            orc.milnet_forward(x, sd, h, "relu", lam, 0.0, 1)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 20:
+                break
+    return dict(value=round(n / el, 4), unit="slides/s", cores=cores, kind="port",
+                sample="%d eval forwards of one synthetic bag N=%d D=%d (oracle/snuffy_oracle.py, torch-CPU fp32, %d threads)"
+                       % (n, N, D, cores))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfgB", choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--mode", default="eval", choices=["eval", "train"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: snuffy_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # "nccl" == RCCL on ROCm
+
+    wl = WORKLOADS[args.workload]
+    N, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
+    net = build_net(D, h, lam, args.precision, device)
+    # bags resident in HBM before the timed region; several distinct bags per rank, cycled
+    nbags = max(2, min(8, int(2.0e9 // (N * D * 4))))
+    g = torch.Generator().manual_seed(1234 + rank)
+    bags = [torch.randn(1, N, D, generator=g).to(device) for _ in range(nbags)]
+    labels = [torch.tensor([float(i % 2)], device=device) for i in range(nbags)]
+
+    if args.mode == "train":
+        from snuffy_amd.train import BagParallelStepper
+        stepper = BagParallelStepper(net, world_size=world, dist=dist, device=device)
+
+        def step(i):
+            stepper.step(bags[i % nbags], labels[i % nbags])
+    else:
+        net.eval()
+
+        def step(i):
+            with torch.no_grad():
+                net(bags[i % nbags])
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        K = min(lam, N)
+        flops_fwd = 20 * N * D * D + 4 * N * K * D + 4 * K * D * D
+        line = {
+            "metric": "slides/sec", "value": round(world * args.steps / elapsed, 3), "unit": "slides/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "%s: MILNet %s, 1 bag/step/rank, N=%d patches D=%d h=%d Lambda=%d (K=%d) depth=1 relu mlp x4"
+                                   % (args.workload, "train step (fwd+bwd+AdamW+all-reduce)" if args.mode == "train" else
+                                      "eval forward", N, D, h, lam, K),
+                       "parallelism": "bag-parallel x%d" % world, "bags_resident_per_rank": nbags,
+                       "model_tflops_per_s": round(flops_fwd * (3 if args.mode == "train" else 1) * world * args.steps
+                                                   / elapsed / 1e12, 2)},
+        }
+        if world == 1 and not args.no_roofline:
+            line.update(kernel_rooflines(wl, args.precision, device))
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

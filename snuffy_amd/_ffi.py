@@ -66,6 +66,9 @@ def load():
         raise SnuffyHipError(
             "libsnuffy_hip.so not found at %s -- build it with `python -m snuffy_amd.build` "
             "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    # torch owns device memory and streams, so the kernels must run on the SAME HIP runtime instance torch uses:
+    # import torch first so that its bundled libamdhip64 is the one already mapped when our NEEDED entry resolves.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here == header / library mismatch

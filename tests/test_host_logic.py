@@ -1,0 +1,100 @@
+"""Host-side logic of the drop-in (no GPU): constructor / state-dict compatibility with the reference's checkpoints,
+the k1/k2 arithmetic, and the random-share draw on the global numpy RNG."""
+import inspect
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import build_amd_milnet, golden_files, load_case
+
+
+def test_state_dict_keys_and_shapes_match_reference_checkpoints():
+    for path in golden_files("f1_"):
+        z, sd = load_case(path)
+        N, D, h, lam, depth, seed = [int(v) for v in z["cfg"]]
+        net = build_amd_milnet(D, h, str(z["act"]), lam, float(z["r"]), depth)
+        own = net.state_dict()
+        assert list(own.keys()) == list(sd.keys())           # same names, same ORDER (positional loaders rely on it)
+        for k in own:
+            assert tuple(own[k].shape) == tuple(sd[k].shape), k
+        net.load_state_dict(sd, strict=True)
+
+
+def test_constructor_signatures_match_reference():
+    from snuffy_amd import snuffy
+    want = {
+        "FCLayer": ["in_size", "out_size"],
+        "IClassifier": ["feature_extractor", "feature_size", "output_class"],
+        "BClassifier": ["encoder", "num_classes", "input_size"],
+        "Encoder": ["layer", "N"],
+        "SublayerConnection": ["size", "dropout"],
+        "EncoderLayer": ["size", "self_attn", "feed_forward", "dropout", "big_lambda", "random_patch_share"],
+        "MultiHeadedAttention": ["h", "d_model", "dropout"],
+        "PositionwiseFeedForward": ["d_model", "d_ff", "activation", "dropout"],
+        "MILNet": ["i_classifier", "b_classifier"],
+    }
+    for cls, params in want.items():
+        got = list(inspect.signature(getattr(snuffy, cls).__init__).parameters)[1:]
+        assert got == params, (cls, got)
+    assert snuffy.MultiHeadedAttention(2, 8).dropout.p == 0.1        # reference default, train.py never overrides it
+    with pytest.raises(AssertionError):
+        snuffy.MultiHeadedAttention(3, 8)                             # d_model % h (snuffy.py:176)
+    with pytest.raises(KeyError):
+        snuffy.PositionwiseFeedForward(8, 32, "swish")                # unknown activation (snuffy.py:215-221)
+    assert list(inspect.signature(snuffy.attention).parameters) == ["query", "key", "value", "dropout"]
+
+
+@pytest.mark.parametrize("path", golden_files("f1_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_random_share_draw_replays_reference(path):
+    """Given the reference's top indices, EncoderLayer.select() reproduces its np.random.choice draws layer by layer."""
+    z, sd = load_case(path)
+    N, D, h, lam, depth, seed = [int(v) for v in z["cfg"]]
+    net = build_amd_milnet(D, h, str(z["act"]), lam, float(z["r"]), depth)
+    top = torch.from_numpy(z["top"])
+    np.random.seed(seed)
+    for l, layer in enumerate(net.b_classifier.encoder.layers):
+        t, rnd = layer.select(None, N, top)
+        assert t is top
+        if int(z["n_rnd"]):
+            assert np.array_equal(rnd.numpy(), z[f"rnd{l}"])
+        else:
+            assert rnd is None
+
+
+def test_k_split_table():
+    from snuffy_amd import snuffy
+    z = np.load(golden_files("f2_")[0])
+    import math
+    for lam, r, n, k1, k2 in z["k_table"]:
+        layer = snuffy.EncoderLayer(8, snuffy.MultiHeadedAttention(2, 8), snuffy.PositionwiseFeedForward(8, 32, "relu"),
+                                    0.0, int(lam), float(r))
+        assert min(math.ceil(layer.big_lambda * layer.top_big_lambda_share), int(n)) == int(k1)
+        top = torch.arange(int(k1))
+        np.random.seed(0)
+        _, rnd = layer.select(None, int(n), top)
+        assert (0 if rnd is None else rnd.numel()) == int(k2)
+        if rnd is not None:
+            assert len(set(rnd.tolist()) & set(top.tolist())) == 0 and len(set(rnd.tolist())) == int(k2)
+
+
+def test_configure_is_shared_and_validated():
+    net = build_amd_milnet(64, 2, "relu", 10, 0.0, 3)
+    net.configure(precision="bf16", return_attention=False)
+    for m in net.b_classifier.modules():
+        if hasattr(m, "cfg"):
+            assert m.cfg is net.b_classifier.cfg
+    assert net.b_classifier.encoder.layers[2].cfg.precision == "bf16"
+    with pytest.raises(ValueError):
+        net.configure(precision="fp8")
+    import copy
+    net2 = copy.deepcopy(net)
+    assert net2.b_classifier.encoder.layers[0].cfg is net2.b_classifier.cfg
+    assert net2.b_classifier.cfg is not net.b_classifier.cfg
+
+
+def test_forward_refuses_cpu_tensors():
+    from snuffy_amd import SnuffyHipError
+    net = build_amd_milnet(64, 2, "relu", 10, 0.0, 1)
+    with pytest.raises(SnuffyHipError):
+        net(torch.zeros(1, 5, 64))
