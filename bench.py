@@ -66,7 +66,7 @@ def kernel_rooflines(wl, precision, device):
     g = torch.Generator(device="cpu").manual_seed(7)
     dt = torch.bfloat16 if precision == "bf16" else torch.float32
     elt = 2 if precision == "bf16" else 4
-    n8 = (N + 7) // 8 * 8
+    n8 = ops.vt_leading_dim(N, elt)
     out = {}
     scores = torch.randn(N, generator=g).to(device)
     t_topk = timed(lambda: ops.topk(scores, K), 20)

@@ -130,8 +130,9 @@ int snf_ln_mean_head_f32(const float* z, int64_t n, int d, const void* add_bf16,
  *
  *   snf_sparse_attn_fwd_f32 : exact fp32 arithmetic, any n/k/h/dk.  q, v [n, d]; kp [k, d].
  *   snf_sparse_attn_fwd_mfma: bf16 MFMA (fp32 accumulate), softmax in fp32.  q [n, d] row-major,
- *       vt = V TRANSPOSED [d, ldv] (ldv >= n, multiple of 8), both of dtype qv_dtype (f32 converted in
- *       registers, or bf16); kp [k, d] f32.  Supported: dk in {64, 128}, k <= 256.  Otherwise SNF_EUNSUPPORTED.
+ *       vt = V TRANSPOSED [d, ldv] (ldv >= round_up(n, 128), multiple of 8; columns n..ldv-1 are read but
+ *       bit-masked, any content is fine), both of dtype qv_dtype (f32 converted in registers, or bf16);
+ *       kp [k, d] f32.  Supported: dk in {64, 128}, k <= 256.  Otherwise SNF_EUNSUPPORTED.
  *   workspace: deterministic cross-workgroup reduction of the [h, k, dk] accumulators.
  * --------------------------------------------------------------------------------------------------------- */
 size_t snf_sparse_attn_fwd_workspace_bytes(int64_t n, int k, int h, int dk, int mfma);

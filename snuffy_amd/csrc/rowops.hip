@@ -440,37 +440,42 @@ __global__ __launch_bounds__(WG) void ln_colsum_kernel(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(1024) void ln_head_finalize_kernel(const float* __restrict__ partial, int nparts,
-                                                                int64_t n, int d, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta,
-                                                                const float* __restrict__ w_head,
-                                                                const float* __restrict__ b_head, int c_out,
-                                                                float* __restrict__ pooled_ws /*[d]*/,
-                                                                float* __restrict__ pooled_out,
-                                                                float* __restrict__ logits) {
-    const float inv_n = 1.0f / (float)n;
-    for (int e = threadIdx.x; e < d; e += blockDim.x) {
-        float s = 0.f;
-        for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * d + e];
-        float m = s * inv_n;
-        float v = (gamma ? gamma[e] : 1.f) * m + (beta ? beta[e] : 0.f);
+// stage 2a: pooled[e] = gamma[e] * (sum_p partial[p][e]) / n + beta[e]; 64 columns per workgroup, the partial rows are
+// split over the 4 waves and combined through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void ln_colreduce_kernel(const float* __restrict__ partial, int nparts, int64_t n, int d,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ pooled_ws, float* __restrict__ pooled_out) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + c;
+    float s = 0.f;
+    if (e < d)
+        for (int p = sl; p < nparts; p += 4) s += partial[(int64_t)p * d + e];
+    red[sl][c] = s;
+    __syncthreads();
+    if (sl == 0 && e < d) {
+        float t = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+        float v = (gamma ? gamma[e] : 1.f) * (t / (float)n) + (beta ? beta[e] : 0.f);
         pooled_ws[e] = v;
         if (pooled_out) pooled_out[e] = v;
     }
+}
+
+// stage 2b: logits[c] = w_head[c,:] . pooled + b_head[c]
+__global__ __launch_bounds__(256) void head_gemv_kernel(const float* __restrict__ pooled, int d,
+                                                        const float* __restrict__ w_head, const float* __restrict__ b_head,
+                                                        float* __restrict__ logits) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < d; e += 256) acc = fmaf(w_head[(int64_t)c * d + e], pooled[e], acc);
+    red[threadIdx.x] = acc;
     __syncthreads();
-    __shared__ float red[1024];
-    for (int c = 0; c < c_out; ++c) {
-        float acc = 0.f;
-        for (int e = threadIdx.x; e < d; e += blockDim.x) acc = fmaf(w_head[(int64_t)c * d + e], pooled_ws[e], acc);
-        red[threadIdx.x] = acc;
-        __syncthreads();
-        for (int s = 512; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) logits[c] = red[0] + (b_head ? b_head[c] : 0.f);
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
+    if (threadIdx.x == 0) logits[c] = red[0] + (b_head ? b_head[c] : 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -684,9 +689,12 @@ int snf_ln_mean_head_f32(const float* z, int64_t n, int d, const void* add_bf16,
                                               delta_rows, z_out, partial));
     int rc = snf::check_launch("ln_colsum_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_head_finalize_kernel, dim3(1), dim3(1024), 0, s, partial, parts, n, d, gamma, beta, w_head,
-                       b_head, c_out, pooled_ws, pooled, logits);
-    return snf::check_launch("ln_head_finalize_kernel");
+    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((d + 63) / 64), dim3(256), 0, s, partial, parts, n, d, gamma, beta,
+                       pooled_ws, pooled);
+    rc = snf::check_launch("ln_colreduce_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(head_gemv_kernel, dim3(c_out), dim3(256), 0, s, pooled_ws, d, w_head, b_head, logits);
+    return snf::check_launch("head_gemv_kernel");
 }
 
 }  // extern "C"

@@ -25,6 +25,8 @@
 // HBM traffic per launch (algorithmic): read Q and V once (2*n*d*elt), Kp once per workgroup (L2), write partials.
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace snf {
@@ -96,20 +98,15 @@ __device__ __forceinline__ bf16x8 load_frag(const unsigned short* p) {
     u32x4 v = *reinterpret_cast<const u32x4*>(p);
     return __builtin_bit_cast(bf16x8, v);
 }
-// tail form: elements at index >= valid are zero
-__device__ __forceinline__ bf16x8 load_frag_masked(const float* p, int valid) {
-    f32x8 v;
+// zero the elements of a fragment whose row index is >= valid (bit mask on the bf16 pairs: NaN-proof)
+__device__ __forceinline__ bf16x8 mask_frag(bf16x8 f, int valid) {
+    u32x4 w = __builtin_bit_cast(u32x4, f);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (e < valid) ? p[e] : 0.f;
-    return __builtin_convertvector(v, bf16x8);
-}
-__device__ __forceinline__ bf16x8 load_frag_masked(const unsigned short* p, int valid) {
-    unsigned short t[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) t[e] = (e < valid) ? p[e] : (unsigned short)0;
-    u32x4 v = {(unsigned)t[0] | ((unsigned)t[1] << 16), (unsigned)t[2] | ((unsigned)t[3] << 16),
-               (unsigned)t[4] | ((unsigned)t[5] << 16), (unsigned)t[6] | ((unsigned)t[7] << 16)};
-    return __builtin_bit_cast(bf16x8, v);
+    for (int e = 0; e < 4; ++e) {
+        const unsigned m = valid >= 2 * e + 2 ? 0xffffffffu : (valid == 2 * e + 1 ? 0x0000ffffu : 0u);
+        w[e] &= m;
+    }
+    return __builtin_bit_cast(bf16x8, w);
 }
 
 template <int DK, int NKB, typename QT>
@@ -127,6 +124,8 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     const QT* __restrict__ q = reinterpret_cast<const QT*>(P.q);
     const QT* __restrict__ vt = reinterpret_cast<const QT*>(P.vt);
     const float c_exp = P.scale * 1.44269504088896340736f;
+    const int cb = (NCB == 4) ? w : (w & (NCB - 1));
+    const int pj = pi_row(j);
 
     const int f_begin = blockIdx.x * P.tiles_per_wg;
     int f_end = f_begin + P.tiles_per_wg;
@@ -134,7 +133,25 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     const int first_head = f_begin / P.tiles_per_head;
 
     f32x16 acc_o[NT];
-    int cur_head = -1;
+    bf16x8 qf[NKS];  // Q fragments of the CURRENT tile (prefetched during the previous tile's GEMM2)
+    bf16x8 vf[8];    // V fragments of the CURRENT tile: 4 sub-tiles x 2 k-steps of this wave's column block
+
+    // All loads of a tile are unconditional and in bounds: Q rows are clamped to n-1 (their probabilities are zeroed),
+    // V^T is read up to round_up(n, 128) <= ldv (the tail is bit-masked before use).
+    auto load_tile = [&](int f, bf16x8(&qd)[NKS], bf16x8(&vd)[8]) {
+        const int a = f / P.tiles_per_head;
+        const int64_t row0 = (int64_t)(f - a * P.tiles_per_head) * TILE_ROWS;
+        const QT* vcol = vt + (int64_t)(a * DK + 32 * cb + j) * P.ldv + row0 + 8 * hf;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) vd[s * 2 + ks] = load_frag(vcol + 32 * s + 16 * ks);
+        int64_t qrow = row0 + 32 * w + pj;
+        if (qrow > P.n - 1) qrow = P.n - 1;
+        const QT* qp = q + qrow * P.ldq + a * DK + 8 * hf;
+#pragma unroll
+        for (int kb = 0; kb < NKS; ++kb) qd[kb] = load_frag(qp + 16 * kb);
+    };
 
     auto flush = [&](int head) {
         const int seg = head - first_head;
@@ -152,9 +169,12 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
         }
     };
 
+    if (f_begin < f_end) load_tile(f_begin, qf, vf);
+    int cur_head = -1;
     for (int f = f_begin; f < f_end; ++f) {
         const int a = f / P.tiles_per_head;
-        const int t = f - a * P.tiles_per_head;
+        const int64_t row0 = (int64_t)(f - a * P.tiles_per_head) * TILE_ROWS;
+        const int64_t my_row0 = row0 + 32 * w;
         if (a != cur_head) {
             if (cur_head >= 0) flush(cur_head);
 #pragma unroll
@@ -172,42 +192,8 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
             __syncthreads();
             cur_head = a;
         }
-        const int64_t row0 = (int64_t)t * TILE_ROWS;
-        const int64_t my_row0 = row0 + 32 * w;
-        const bool tail = (row0 + TILE_ROWS > P.n);
 
-        // ---- V fragments of this step (consumed by GEMM2; issued first so HBM latency hides under GEMM1+softmax)
-        constexpr int NVF = 8;  // 4 sub-tiles x 2 k-steps of this wave's column block
-        bf16x8 vf[NVF];
-        {
-            const int cb = (NCB == 4) ? w : (w & (NCB - 1));
-            const QT* vcol = vt + (int64_t)(a * DK + 32 * cb + j) * P.ldv;
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int64_t rb = row0 + 32 * s + 16 * ks + 8 * hf;
-                    if (!tail) {
-                        vf[s * 2 + ks] = load_frag(vcol + rb);
-                    } else {
-                        int64_t valid = P.n - rb;
-                        vf[s * 2 + ks] = valid >= 8 ? load_frag(vcol + rb)
-                                                    : (valid > 0 ? load_frag_masked(vcol + rb, (int)valid) : zero_frag());
-                    }
-                }
-        }
-
-        // ---- Q fragments of this wave's 32 rows
-        bf16x8 qf[NKS];
-        {
-            const int64_t qrow = my_row0 + pi_row(j);
-            const bool qvalid = qrow < P.n;
-            const QT* qp = q + qrow * P.ldq + a * DK + 8 * hf;
-#pragma unroll
-            for (int kb = 0; kb < NKS; ++kb) qf[kb] = qvalid ? load_frag(qp + 16 * kb) : zero_frag();
-        }
-
-        // ---- GEMM1: S[32 rows, 32*NKB keys]
+        // ---- GEMM1: S[32 rows, 32*NKB keys] = Q Kp^T
         f32x16 s_acc[NKB];
 #pragma unroll
         for (int jb = 0; jb < NKB; ++jb) {
@@ -276,6 +262,22 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
             }
         __syncthreads();
 
+        // ---- prefetch the next tile's Q and V fragments: their HBM latency hides under GEMM2 (+ the next GEMM1)
+        bf16x8 qn[NKS], vn[8];
+        const bool has_next = (f + 1 < f_end);
+        if (has_next) load_tile(f + 1, qn, vn);
+
+        // ---- tail of a bag: zero the V rows past n (bit mask, so garbage / NaN in the pad never reaches the MFMA)
+        if (row0 + TILE_ROWS > P.n) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int64_t valid = P.n - (row0 + 32 * s + 16 * ks + 8 * hf);
+                    vf[s * 2 + ks] = mask_frag(vf[s * 2 + ks], valid > 8 ? 8 : (valid < 0 ? 0 : (int)valid));
+                }
+        }
+
         // ---- GEMM2: O tiles of this wave += P^T V over the 128 rows of the step
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -291,6 +293,12 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
                     }
                 }
             }
+        if (has_next) {
+#pragma unroll
+            for (int kb = 0; kb < NKS; ++kb) qf[kb] = qn[kb];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vf[i] = vn[i];
+        }
     }
     if (cur_head >= 0) flush(cur_head);
 }
@@ -423,8 +431,8 @@ int snf_sparse_attn_fwd_mfma(const void* q, const void* vt, int qv_dtype, int64_
         snf::set_error("snf_sparse_attn_fwd_mfma: unsupported shape k=%d dk=%d (need dk in {64,128}, k <= 256)", k, dk);
         return SNF_EUNSUPPORTED;
     }
-    SNF_REQUIRE(ldv >= n && (ldv % 8) == 0, "snf_sparse_attn_fwd_mfma: ldv=%lld must be >= n and a multiple of 8",
-                (long long)ldv);
+    SNF_REQUIRE(ldv >= ((n + 127) / 128) * 128 && (ldv % 8) == 0,
+                "snf_sparse_attn_fwd_mfma: ldv=%lld must be >= round_up(n, 128) and a multiple of 8", (long long)ldv);
     SNF_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (reinterpret_cast<uintptr_t>(vt) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(kp) & 15) == 0,
                 "snf_sparse_attn_fwd_mfma: q / vt / kp must be 16-byte aligned");

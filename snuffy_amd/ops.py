@@ -212,6 +212,16 @@ def mfma_attn_supported(k, dk):
     return dk in (64, 128) and 1 <= k <= 256
 
 
+def vt_leading_dim(n, elt_bytes=2):
+    """Leading dimension (in elements) of the V^T [d, ldv] operand: >= round_up(n, 128) (the kernel reads whole 128-row
+    tiles) and NOT a multiple of 2 KiB in bytes -- a power-of-two pitch makes the 32 column rows one MFMA fragment load
+    touches land on the same HBM channel."""
+    ld = (n + 127) // 128 * 128
+    if (ld * elt_bytes) % 2048 == 0:
+        ld += 64
+    return ld
+
+
 def sparse_attn_fwd(q, kp, v, h, scale=None, need_attn=False, need_lse=False):
     """Exact-fp32 sparse attention (snuffy.py:160-168). q, v [n, d]; kp [k, d] -> (out [k, d], attn [h,n,k], lse)."""
     q = _req(q, torch.float32, "q", 2)

@@ -208,8 +208,9 @@ def test_sparse_attn_mfma(n, k, h, dk, dt):
     g = torch.Generator().manual_seed(n * 3 + k)
     d = h * dk
     q, kp, v = torch.randn(n, d, generator=g), torch.randn(k, d, generator=g), torch.randn(n, d, generator=g)
-    n8 = (n + 7) // 8 * 8
-    vt = torch.full((d, n8), float("nan"))          # poison the pad: the kernel must never read it
+    from snuffy_amd.ops import vt_leading_dim
+    n8 = vt_leading_dim(n, 4 if dt == "f32" else 2)
+    vt = torch.full((d, n8), float("nan"))          # poison the pad: it is read but must be masked before use
     vt[:, :n] = v.t()
     tdt = torch.float32 if dt == "f32" else torch.bfloat16
     o, attn, lse = ops().sparse_attn_fwd_mfma(q.to(DEV).to(tdt), vt.to(DEV).to(tdt), kp.to(DEV), n, h,
@@ -241,7 +242,8 @@ def test_sparse_attn_mfma_online_max_spike():
     q, kp, v = torch.randn(n, d, generator=g), torch.randn(k, d, generator=g), torch.randn(n, d, generator=g)
     q[7] *= 40.0
     kp[3] *= 25.0
-    vt = v.t().contiguous()
+    vt = torch.zeros(d, ops().vt_leading_dim(n, 4))
+    vt[:, :n] = v.t()
     o, attn, _ = ops().sparse_attn_fwd_mfma(q.to(DEV), vt.to(DEV), kp.to(DEV), n, h, need_attn=True)
     assert torch.isfinite(o).all() and torch.isfinite(attn).all()
     o_r, p_r = attn_ref(bf16r(q), bf16r(kp), bf16r(v), h)
@@ -253,4 +255,4 @@ def test_mfma_rejects_unsupported_shapes():
     from snuffy_amd import SnuffyHipError
     q = torch.zeros(64, 96, device=DEV)
     with pytest.raises(SnuffyHipError):
-        ops().sparse_attn_fwd_mfma(q, torch.zeros(96, 64, device=DEV), torch.zeros(8, 96, device=DEV), 64, 2)  # dk=48
+        ops().sparse_attn_fwd_mfma(q, torch.zeros(96, 128, device=DEV), torch.zeros(8, 96, device=DEV), 64, 2)  # dk=48
