@@ -56,13 +56,23 @@ struct AttnParams {
     int tiles_per_head, tiles_per_wg, total_tiles, seg_count;
 };
 
+// compile-time loop: every index into the register-resident fragment arrays must be a constant, or the arrays go to
+// scratch (a "#pragma unroll" is only a hint and gives up on the larger variants)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 __device__ __forceinline__ int pi_row(int i) {  // MFMA row slot -> row offset inside the wave's 32 rows
     return (i & 3) | (((i >> 3) & 1) << 2) | (((i >> 2) & 1) << 3) | (i & 16);
 }
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
 }
 // all-reduce over the 32 lanes of a half-wave (lanes 0-31 and 32-63 independently)
 __device__ __forceinline__ float half_allmax(float v) {
@@ -109,11 +119,21 @@ __device__ __forceinline__ bf16x8 mask_frag(bf16x8 f, int valid) {
     return __builtin_bit_cast(bf16x8, w);
 }
 
-template <int DK, int NKB, typename QT>
+// AUX = the caller asked for the attention matrix and/or the row log-sum-exp (extra stores in the softmax loop).
+//
+// Software pipeline of one wave (one wave per SIMD, so MFMA and VALU only overlap inside the wave's own stream):
+//   step t:   GEMM1(t)                                     MFMA   (Kp fragments double-buffered out of LDS)
+//             softmax(t)  ||  GEMM2(t-1)                   VALU   ||  MFMA: the 8*NT MFMAs of the PREVIOUS tile are spread
+//                                                          over the 16 row iterations of the softmax
+//             barrier, publish P(t) in LDS, barrier
+//   loads:    Q(t+1) is issued right after GEMM1(t) (its registers are free), V(t+1) right after GEMM2(t-1): both have
+//             a whole softmax (thousands of cycles) to land.
+template <int DK, int NKB, typename QT, bool AUX>
 __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) {
-    constexpr int NKS = DK / 16;            // k-steps of GEMM1
-    constexpr int NCB = DK / 32;            // 32-wide column blocks of the output
+    constexpr int NKS = DK / 16;             // k-steps of GEMM1
+    constexpr int NCB = DK / 32;             // 32-wide column blocks of the output
     constexpr int NT = (NKB * NCB + 3) / 4;  // output tiles owned by one wave
+    constexpr int M2 = 8 * NT;               // GEMM2 MFMAs per tile and wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* lds_kp = reinterpret_cast<u32x4*>(smem);                    // [NKB][NKS][64]
     u32x4* lds_p = lds_kp + NKB * NKS * 64;                            // [4 waves][NKB][2][64]
@@ -133,27 +153,70 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     const int first_head = f_begin / P.tiles_per_head;
 
     f32x16 acc_o[NT];
-    bf16x8 qf[NKS];  // Q fragments of the CURRENT tile (prefetched during the previous tile's GEMM2)
-    bf16x8 vf[8];    // V fragments of the CURRENT tile: 4 sub-tiles x 2 k-steps of this wave's column block
+    bf16x8 qf[NKS];  // Q fragments of the tile about to enter GEMM1
+    bf16x8 vf[8];    // V fragments of the tile whose GEMM2 is pending (P already in LDS)
+    bf16x8 vn[8];    // V fragments of the tile in GEMM1 / softmax
 
-    // All loads of a tile are unconditional and in bounds: Q rows are clamped to n-1 (their probabilities are zeroed),
-    // V^T is read up to round_up(n, 128) <= ldv (the tail is bit-masked before use).
-    auto load_tile = [&](int f, bf16x8(&qd)[NKS], bf16x8(&vd)[8]) {
+    // All loads are unconditional and in bounds: Q rows are clamped to n-1 (their probabilities are zeroed), V^T is
+    // read up to round_up(n, 128) <= ldv (the tail is bit-masked before use).
+    auto load_q = [&](int f) __attribute__((always_inline)) {
         const int a = f / P.tiles_per_head;
         const int64_t row0 = (int64_t)(f - a * P.tiles_per_head) * TILE_ROWS;
-        const QT* vcol = vt + (int64_t)(a * DK + 32 * cb + j) * P.ldv + row0 + 8 * hf;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) vd[s * 2 + ks] = load_frag(vcol + 32 * s + 16 * ks);
         int64_t qrow = row0 + 32 * w + pj;
         if (qrow > P.n - 1) qrow = P.n - 1;
         const QT* qp = q + qrow * P.ldq + a * DK + 8 * hf;
-#pragma unroll
-        for (int kb = 0; kb < NKS; ++kb) qd[kb] = load_frag(qp + 16 * kb);
+        static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) { qf[kb] = load_frag(qp + 16 * kb); });
+    };
+    auto load_v = [&](int f, bf16x8(&vd)[8]) {
+        const int a = f / P.tiles_per_head;
+        const int64_t row0 = (int64_t)(f - a * P.tiles_per_head) * TILE_ROWS;
+        const QT* vcol = vt + (int64_t)(a * DK + 32 * cb + j) * P.ldv + row0 + 8 * hf;
+        static_for<0, 8>([&](auto sk) __attribute__((always_inline)) { vd[sk] = load_frag(vcol + 32 * (sk >> 1) + 16 * (sk & 1)); });
+        if (row0 + TILE_ROWS > P.n) {  // tail of a bag: zero the rows past n (bit mask: pad garbage never reaches the MFMA)
+            static_for<0, 8>([&](auto sk) __attribute__((always_inline)) {
+                const int64_t valid = P.n - (row0 + 32 * (sk >> 1) + 16 * (sk & 1) + 8 * hf);
+                vd[sk] = mask_frag(vd[sk], valid > 8 ? 8 : (valid < 0 ? 0 : (int)valid));
+            });
+        }
+    };
+    // one GEMM2 MFMA of the pending tile: m = (s*2 + ks) * NT + ti
+    auto gemm2_one = [&](auto m_tag) __attribute__((always_inline)) {
+        constexpr int m = decltype(m_tag)::value;
+        constexpr int sk = m / NT, ti = m % NT;
+        const int t_idx = w + 4 * ti;  // tile = kb * NCB + cb ; cb == t_idx % NCB is constant per wave
+        if (NT * 4 == NKB * NCB || t_idx < NKB * NCB) {
+            const int kb = t_idx / NCB;
+            bf16x8 pf = __builtin_bit_cast(bf16x8, lds_p[(((sk >> 1) * NKB + kb) * 2 + (sk & 1)) * 64 + lane]);
+            acc_o[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vf[sk], acc_o[ti], 0, 0, 0);
+        }
+    };
+    auto gemm2_range = [&](auto lo_tag, auto hi_tag) __attribute__((always_inline)) {
+        constexpr int lo = decltype(lo_tag)::value, hi = decltype(hi_tag)::value;
+        if constexpr (lo < hi) {
+            gemm2_one(std::integral_constant<int, lo>{});
+            if constexpr (lo + 1 < hi) gemm2_one(std::integral_constant<int, lo + 1>{});
+            if constexpr (lo + 2 < hi) gemm2_one(std::integral_constant<int, lo + 2>{});
+            if constexpr (lo + 3 < hi) gemm2_one(std::integral_constant<int, lo + 3>{});
+            if constexpr (lo + 4 < hi) gemm2_one(std::integral_constant<int, lo + 4>{});
+            if constexpr (lo + 5 < hi) gemm2_one(std::integral_constant<int, lo + 5>{});
+            if constexpr (lo + 6 < hi) gemm2_one(std::integral_constant<int, lo + 6>{});
+            if constexpr (lo + 7 < hi) gemm2_one(std::integral_constant<int, lo + 7>{});
+            static_assert(hi - lo <= 8, "GEMM2 slice too long");
+        }
+    };
+    auto gemm2_all = [&]() __attribute__((always_inline)) {
+        gemm2_range(std::integral_constant<int, 0>{}, std::integral_constant<int, (M2 >= 8 ? 8 : M2)>{});
+        if constexpr (M2 > 8) gemm2_range(std::integral_constant<int, 8>{}, std::integral_constant<int, (M2 >= 16 ? 16 : M2)>{});
+        if constexpr (M2 > 16) gemm2_range(std::integral_constant<int, 16>{}, std::integral_constant<int, (M2 >= 24 ? 24 : M2)>{});
+        if constexpr (M2 > 24) gemm2_range(std::integral_constant<int, 24>{}, std::integral_constant<int, (M2 >= 32 ? 32 : M2)>{});
+        if constexpr (M2 > 32) gemm2_range(std::integral_constant<int, 32>{}, std::integral_constant<int, (M2 >= 40 ? 40 : M2)>{});
+        if constexpr (M2 > 40) gemm2_range(std::integral_constant<int, 40>{}, std::integral_constant<int, (M2 >= 48 ? 48 : M2)>{});
+        if constexpr (M2 > 48) gemm2_range(std::integral_constant<int, 48>{}, std::integral_constant<int, (M2 >= 56 ? 56 : M2)>{});
+        if constexpr (M2 > 56) gemm2_range(std::integral_constant<int, 56>{}, std::integral_constant<int, M2>{});
+        static_assert(M2 <= 64, "GEMM2 too long");
     };
 
-    auto flush = [&](int head) {
+    auto flush = [&](int head) __attribute__((always_inline)) {
         const int seg = head - first_head;
         float* dst = P.partial + ((int64_t)blockIdx.x * P.seg_count + seg) * (int64_t)(NKB * NCB) * 1024;
 #pragma unroll
@@ -169,19 +232,34 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
         }
     };
 
-    if (f_begin < f_end) load_tile(f_begin, qf, vf);
+    // pipeline fill: nothing pending -> P image and V fragments are zero, so the first interleaved GEMM2 adds 0
+    {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int i = threadIdx.x; i < 4 * NKB * 2 * 64; i += 256) lds_p[i] = z;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vf[i] = zero_frag();
+    }
+    if (f_begin < f_end) {
+        load_q(f_begin);
+        load_v(f_begin, vn);
+    }
     int cur_head = -1;
     for (int f = f_begin; f < f_end; ++f) {
         const int a = f / P.tiles_per_head;
         const int64_t row0 = (int64_t)(f - a * P.tiles_per_head) * TILE_ROWS;
         const int64_t my_row0 = row0 + 32 * w;
         if (a != cur_head) {
-            if (cur_head >= 0) flush(cur_head);
+            if (cur_head >= 0) {  // drain the pending tile of the previous head, then flush its accumulators
+                gemm2_all();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) vf[i] = zero_frag();
+                flush(cur_head);
+            }
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc_o[ti][r] = 0.f;
-            __syncthreads();  // everyone finished reading the previous head's Kp
+            __syncthreads();  // everyone finished reading the previous head's Kp (and the zero-fill of lds_p is visible)
             for (int fr = w; fr < NKB * NKS; fr += 4) {
                 const int jb = fr / NKS, kb = fr - jb * NKS;
                 const int key = 32 * jb + j;
@@ -193,65 +271,81 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
             cur_head = a;
         }
 
-        // ---- GEMM1: S[32 rows, 32*NKB keys] = Q Kp^T
+        // ---- GEMM1: S[32 rows, 32*NKB keys] = Q Kp^T ; Kp fragments of the next key block are fetched from LDS while
+        //      the MFMAs of the current one issue
         f32x16 s_acc[NKB];
+        {
+            bf16x8 kfa[NKS], kfb[NKS];
+            static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) { kfa[kb] = __builtin_bit_cast(bf16x8, lds_kp[kb * 64 + lane]); });
+            static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
+                constexpr int jb = decltype(jb_t)::value;
 #pragma unroll
-        for (int jb = 0; jb < NKB; ++jb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s_acc[jb][r] = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < NKS; ++kb) {
-                bf16x8 kf = __builtin_bit_cast(bf16x8, lds_kp[(jb * NKS + kb) * 64 + lane]);
-                s_acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kb], kf, s_acc[jb], 0, 0, 0);
-            }
+                for (int r = 0; r < 16; ++r) s_acc[jb][r] = 0.f;
+                if constexpr (jb + 1 < NKB) {
+                    static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) {
+                        bf16x8 nx = __builtin_bit_cast(bf16x8, lds_kp[((jb + 1) * NKS + kb) * 64 + lane]);
+                        if constexpr (jb & 1) kfa[kb] = nx; else kfb[kb] = nx;
+                    });
+                }
+                static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) {
+                    if constexpr (jb & 1)
+                        s_acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kb], kfb[kb], s_acc[jb], 0, 0, 0);
+                    else
+                        s_acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kb], kfa[kb], s_acc[jb], 0, 0, 0);
+                });
+            });
         }
+        if (f + 1 < f_end) load_q(f + 1);  // qf is free: next tile's Q lands during the softmax
 
-        // ---- softmax over keys (lanes of a half-wave x NKB blocks), fp32
+        // ---- softmax over keys (lanes of a half-wave x NKB blocks), fp32, with GEMM2 of the pending tile interleaved
         {
             const int first_pad_blk = P.k >> 5;  // wave-uniform: blocks below it are fully valid
-#pragma unroll
-            for (int jb = 0; jb < NKB; ++jb) {
+            static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
                 if (jb >= first_pad_blk && 32 * jb + j >= P.k) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s_acc[jb][r] = -INFINITY;
                 }
-            }
+            });
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        auto softmax_row = [&](auto r_tag) __attribute__((always_inline)) {
+            constexpr int r = decltype(r_tag)::value;
             float m = s_acc[0][r];
-#pragma unroll
-            for (int jb = 1; jb < NKB; ++jb) m = fmaxf(m, s_acc[jb][r]);
+            static_for<1, NKB>([&](auto jb) __attribute__((always_inline)) { m = fmaxf(m, s_acc[jb][r]); });
             m = half_allmax(m);
             const float mc = m * c_exp;
             float l = 0.f;
-#pragma unroll
-            for (int jb = 0; jb < NKB; ++jb) {
+            static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
                 float e = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r], c_exp, -mc));
                 s_acc[jb][r] = e;
                 l += e;
-            }
+            });
             l = half_allsum(l);
             const int64_t row = my_row0 + (r & 7) + 8 * hf + 16 * (r >> 3);
             const bool rvalid = row < P.n;
             const float inv = rvalid ? __builtin_amdgcn_rcpf(l) : 0.f;
-#pragma unroll
-            for (int jb = 0; jb < NKB; ++jb) s_acc[jb][r] *= inv;
-            if (P.lse && rvalid && j == 0) P.lse[(int64_t)a * P.n + row] = m * P.scale + __logf(l);
-            if (P.attn && rvalid) {
-                float* arow = P.attn + ((int64_t)a * P.n + row) * P.k;
-#pragma unroll
-                for (int jb = 0; jb < NKB; ++jb) {
-                    const int key = 32 * jb + j;
-                    if (key < P.k) arow[key] = s_acc[jb][r];
+            static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) { s_acc[jb][r] *= inv; });
+            if constexpr (AUX) {
+                if (P.lse && rvalid && j == 0) P.lse[(int64_t)a * P.n + row] = m * P.scale + __logf(l);
+                if (P.attn && rvalid) {
+                    float* arow = P.attn + ((int64_t)a * P.n + row) * P.k;
+                    static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
+                        const int key = 32 * jb + j;
+                        if (key < P.k) arow[key] = s_acc[jb][r];
+                    });
                 }
             }
-        }
+            // slice r of the pending GEMM2
+            gemm2_range(std::integral_constant<int, (r * M2) / 16>{}, std::integral_constant<int, ((r + 1) * M2) / 16>{});
+        };
+        static_for<0, 16>(softmax_row);
+
+        // ---- the pending tile is consumed: this tile becomes pending; fetch the V fragments of the one after it
+        static_for<0, 8>([&](auto i) __attribute__((always_inline)) { vf[i] = vn[i]; });
+        if (f + 1 < f_end) load_v(f + 1, vn);
 
         // ---- publish P fragments (bf16) for the 4 waves
-        __syncthreads();  // previous step's GEMM2 reads are complete
-#pragma unroll
-        for (int jb = 0; jb < NKB; ++jb)
+        __syncthreads();  // every wave finished the GEMM2 reads of the previous image
+        static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 f32x8 pv;
@@ -260,47 +354,13 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
                 bf16x8 pb = __builtin_convertvector(pv, bf16x8);
                 lds_p[((w * NKB + jb) * 2 + ks) * 64 + lane] = __builtin_bit_cast(u32x4, pb);
             }
+        });
         __syncthreads();
-
-        // ---- prefetch the next tile's Q and V fragments: their HBM latency hides under GEMM2 (+ the next GEMM1)
-        bf16x8 qn[NKS], vn[8];
-        const bool has_next = (f + 1 < f_end);
-        if (has_next) load_tile(f + 1, qn, vn);
-
-        // ---- tail of a bag: zero the V rows past n (bit mask, so garbage / NaN in the pad never reaches the MFMA)
-        if (row0 + TILE_ROWS > P.n) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int64_t valid = P.n - (row0 + 32 * s + 16 * ks + 8 * hf);
-                    vf[s * 2 + ks] = mask_frag(vf[s * 2 + ks], valid > 8 ? 8 : (valid < 0 ? 0 : (int)valid));
-                }
-        }
-
-        // ---- GEMM2: O tiles of this wave += P^T V over the 128 rows of the step
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int ti = 0; ti < NT; ++ti) {
-                    const int t_idx = w + 4 * ti;  // tile = kb * NCB + cb ; cb == t_idx % NCB is constant per wave
-                    if (t_idx < NKB * NCB) {
-                        const int kb = t_idx / NCB;
-                        bf16x8 pf = __builtin_bit_cast(bf16x8, lds_p[((s * NKB + kb) * 2 + ks) * 64 + lane]);
-                        acc_o[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vf[s * 2 + ks], acc_o[ti], 0, 0, 0);
-                    }
-                }
-            }
-        if (has_next) {
-#pragma unroll
-            for (int kb = 0; kb < NKS; ++kb) qf[kb] = qn[kb];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) vf[i] = vn[i];
-        }
     }
-    if (cur_head >= 0) flush(cur_head);
+    if (cur_head >= 0) {
+        gemm2_all();  // drain the last pending tile
+        flush(cur_head);
+    }
 }
 
 // out[key, a*DK + col] = sum over the (workgroup, segment) partials of head a, ascending workgroup order
@@ -366,12 +426,12 @@ inline bool make_plan(int64_t n, int k, int h, int dk, Plan* pl) {
     return true;
 }
 
-template <int DK, int NKB, typename QT>
+template <int DK, int NKB, typename QT, bool AUX>
 int launch_variant(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
     constexpr int NKS = DK / 16;
     const size_t lds = (size_t)(NKB * NKS + 4 * NKB * 2) * 1024;
     static thread_local bool attr_set = false;
-    auto kern = sparse_attn_mfma_kernel<DK, NKB, QT>;
+    auto kern = sparse_attn_mfma_kernel<DK, NKB, QT, AUX>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
@@ -392,13 +452,14 @@ int launch_variant(const AttnParams& P, const Plan& pl, float* out, hipStream_t 
 
 template <int DK, typename QT>
 int launch_nkb(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
+    const bool aux = P.attn != nullptr || P.lse != nullptr;
     switch (pl.nkb) {
-        case 1: return launch_variant<DK, 1, QT>(P, pl, out, s);
-        case 2: return launch_variant<DK, 2, QT>(P, pl, out, s);
-        case 4: return launch_variant<DK, 4, QT>(P, pl, out, s);
-        case 6: return launch_variant<DK, 6, QT>(P, pl, out, s);
-        case 7: return launch_variant<DK, 7, QT>(P, pl, out, s);
-        default: return launch_variant<DK, 8, QT>(P, pl, out, s);
+        case 1: return aux ? launch_variant<DK, 1, QT, true>(P, pl, out, s) : launch_variant<DK, 1, QT, false>(P, pl, out, s);
+        case 2: return aux ? launch_variant<DK, 2, QT, true>(P, pl, out, s) : launch_variant<DK, 2, QT, false>(P, pl, out, s);
+        case 4: return aux ? launch_variant<DK, 4, QT, true>(P, pl, out, s) : launch_variant<DK, 4, QT, false>(P, pl, out, s);
+        case 6: return aux ? launch_variant<DK, 6, QT, true>(P, pl, out, s) : launch_variant<DK, 6, QT, false>(P, pl, out, s);
+        case 7: return aux ? launch_variant<DK, 7, QT, true>(P, pl, out, s) : launch_variant<DK, 7, QT, false>(P, pl, out, s);
+        default: return aux ? launch_variant<DK, 8, QT, true>(P, pl, out, s) : launch_variant<DK, 8, QT, false>(P, pl, out, s);
     }
 }
 

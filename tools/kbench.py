@@ -69,6 +69,8 @@ def rows():
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "attnB":
+        attn("cfgB", dts=("bf16",), iters=10)
     if what in ("attn", "all"):
         attn("cfgB")
         attn("cfgA", dts=("bf16",))
