@@ -440,35 +440,40 @@ __global__ __launch_bounds__(WG) void ln_colsum_kernel(const float* __restrict__
     }
 }
 
-// stage 2a: pooled[e] = gamma[e] * (sum_p partial[p][e]) / n + beta[e]; 64 columns per workgroup, the partial rows are
-// split over the 4 waves and combined through LDS in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void ln_colreduce_kernel(const float* __restrict__ partial, int nparts, int64_t n, int d,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* __restrict__ pooled_ws, float* __restrict__ pooled_out) {
+// stage 2a: second-level partial sums.  grid (ceil(d/64), NSLICE): workgroup (cx, sl) sums the partial rows
+// p = sl, sl+NSLICE, ... of 64 columns; its 4 waves split those rows again and combine through LDS in a fixed order.
+constexpr int HEAD_NSLICE = 16;
+__global__ __launch_bounds__(256) void ln_colreduce_kernel(const float* __restrict__ partial, int nparts, int d,
+                                                           float* __restrict__ partial2 /*[NSLICE, d]*/) {
     __shared__ float red[4][64];
-    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + c;
+    const int sl = blockIdx.y;
     float s = 0.f;
     if (e < d)
-        for (int p = sl; p < nparts; p += 4) s += partial[(int64_t)p * d + e];
-    red[sl][c] = s;
+        for (int p = sl + HEAD_NSLICE * wv; p < nparts; p += HEAD_NSLICE * 4) s += partial[(int64_t)p * d + e];
+    red[wv][c] = s;
     __syncthreads();
-    if (sl == 0 && e < d) {
-        float t = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
-        float v = (gamma ? gamma[e] : 1.f) * (t / (float)n) + (beta ? beta[e] : 0.f);
-        pooled_ws[e] = v;
-        if (pooled_out) pooled_out[e] = v;
-    }
+    if (wv == 0 && e < d) partial2[(int64_t)sl * d + e] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
 }
 
-// stage 2b: logits[c] = w_head[c,:] . pooled + b_head[c]
-__global__ __launch_bounds__(256) void head_gemv_kernel(const float* __restrict__ pooled, int d,
+// stage 2b: pooled[e] = gamma[e] * (sum_sl partial2[sl][e]) / n + beta[e];  logits[c] = w_head[c,:] . pooled + b_head[c]
+__global__ __launch_bounds__(256) void head_gemv_kernel(const float* __restrict__ partial2, int64_t n, int d,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ w_head, const float* __restrict__ b_head,
-                                                        float* __restrict__ logits) {
+                                                        float* __restrict__ pooled_out, float* __restrict__ logits) {
     __shared__ float red[256];
     const int c = blockIdx.x;
+    const float inv_n = 1.0f / (float)n;
     float acc = 0.f;
-    for (int e = threadIdx.x; e < d; e += 256) acc = fmaf(w_head[(int64_t)c * d + e], pooled[e], acc);
+    for (int e = threadIdx.x; e < d; e += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < HEAD_NSLICE; ++sl) t += partial2[(int64_t)sl * d + e];
+        const float v = (gamma ? gamma[e] : 1.f) * (t * inv_n) + (beta ? beta[e] : 0.f);
+        if (c == 0 && pooled_out) pooled_out[e] = v;
+        acc = fmaf(w_head[(int64_t)c * d + e], v, acc);
+    }
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -660,8 +665,8 @@ static int ln_head_parts(int64_t n) {
 
 size_t snf_ln_mean_head_workspace_bytes(int d) {
     if (d < 1) return 0;
-    // worst-case number of partial rows (cu_count*4) + one pooled row
-    return ((size_t)snf::cu_count() * 4 + 1) * (size_t)d * sizeof(float);
+    // worst-case number of partial rows (cu_count*4) + the second-level partial rows
+    return ((size_t)snf::cu_count() * 4 + HEAD_NSLICE) * (size_t)d * sizeof(float);
 }
 
 int snf_ln_mean_head_f32(const float* z, int64_t n, int d, const void* add_bf16, const float* add_bias,
@@ -672,8 +677,9 @@ int snf_ln_mean_head_f32(const float* z, int64_t n, int d, const void* add_bf16,
     SNF_REQUIRE(!slot_map || delta_rows, "snf_ln_mean_head_f32: slot_map without delta_rows");
     SNF_REQUIRE(n >= 1 && d >= 1 && c_out >= 1, "snf_ln_mean_head_f32: bad shape");
     const int parts = ln_head_parts(n);
-    if (workspace_bytes < ((size_t)parts + 1) * d * sizeof(float)) {
-        snf::set_error("snf_ln_mean_head_f32: workspace %zu < %zu", workspace_bytes, ((size_t)parts + 1) * d * sizeof(float));
+    if (workspace_bytes < ((size_t)parts + HEAD_NSLICE) * d * sizeof(float)) {
+        snf::set_error("snf_ln_mean_head_f32: workspace %zu < %zu", workspace_bytes,
+                       ((size_t)parts + HEAD_NSLICE) * d * sizeof(float));
         return SNF_EWORKSPACE;
     }
     RowCfg cfg;
@@ -682,18 +688,18 @@ int snf_ln_mean_head_f32(const float* z, int64_t n, int d, const void* add_bf16,
     SNF_REQUIRE(pick_row_cfg(d, al, &cfg), "snf_ln_mean_head_f32: d=%d too wide (max 2048)", d);
     hipStream_t s = snf::as_stream(stream);
     float* partial = reinterpret_cast<float*>(workspace);
-    float* pooled_ws = partial + (size_t)parts * d;
+    float* partial2 = partial + (size_t)parts * d;
     SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((ln_colsum_kernel<VEC, NV>), dim3(parts), dim3(WG),
                                               WAVES * NV * VEC * 64 * sizeof(float), s, z, n, d, eps,
                                               reinterpret_cast<const unsigned short*>(add_bf16), add_bias, slot_map,
                                               delta_rows, z_out, partial));
     int rc = snf::check_launch("ln_colsum_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((d + 63) / 64), dim3(256), 0, s, partial, parts, n, d, gamma, beta,
-                       pooled_ws, pooled);
+    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((d + 63) / 64, HEAD_NSLICE), dim3(256), 0, s, partial, parts, d, partial2);
     rc = snf::check_launch("ln_colreduce_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(head_gemv_kernel, dim3(c_out), dim3(256), 0, s, pooled_ws, d, w_head, b_head, logits);
+    hipLaunchKernelGGL(head_gemv_kernel, dim3(c_out), dim3(256), 0, s, partial2, n, d, gamma, beta, w_head, b_head, pooled,
+                       logits);
     return snf::check_launch("head_gemv_kernel");
 }
 

@@ -24,6 +24,7 @@
 //
 // HBM traffic per launch (algorithmic): read Q and V once (2*n*d*elt), Kp once per workgroup (L2), write partials.
 #include <math.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -54,6 +55,8 @@ struct AttnParams {
     float* lse;      // [h, n] or null
     float* partial;  // [num_wg * seg_count][tiles][16][64]
     int tiles_per_head, tiles_per_wg, total_tiles, seg_count;
+    int debug_linear;  // timing experiment only: fully coalesced (wrong) addresses
+    unsigned long long* trace;  // debug: s_memtime stamps of workgroup 0 (tools/attn_trace.py), normally null
 };
 
 // compile-time loop: every index into the register-resident fragment arrays must be a constant, or the arrays go to
@@ -74,22 +77,26 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
 }
+// v_permlane16_swap(x, x) returns {x.row0, x.row0, x.row2, x.row2} and {x.row1, x.row1, x.row3, x.row3}: combining the
+// two results reduces across the two 16-lane rows of each half-wave on the VALU (no LDS round trip like ds_bpermute).
 // all-reduce over the 32 lanes of a half-wave (lanes 0-31 and 32-63 independently)
 __device__ __forceinline__ float half_allmax(float v) {
     v = fmaxf(v, dpp_mov<0x128>(v));  // row_ror:8
     v = fmaxf(v, dpp_mov<0x124>(v));  // row_ror:4
     v = fmaxf(v, dpp_mov<0x122>(v));  // row_ror:2
     v = fmaxf(v, dpp_mov<0x121>(v));  // row_ror:1
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return v;
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float half_allsum(float v) {
     v += dpp_mov<0x128>(v);
     v += dpp_mov<0x124>(v);
     v += dpp_mov<0x122>(v);
     v += dpp_mov<0x121>(v);
-    v += __shfl_xor(v, 16, 64);
-    return v;
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 __device__ __forceinline__ bf16x8 zero_frag() {
@@ -126,8 +133,8 @@ __device__ __forceinline__ bf16x8 mask_frag(bf16x8 f, int valid) {
 //             softmax(t)  ||  GEMM2(t-1)                   VALU   ||  MFMA: the 8*NT MFMAs of the PREVIOUS tile are spread
 //                                                          over the 16 row iterations of the softmax
 //             barrier, publish P(t) in LDS, barrier
-//   loads:    Q(t+1) is issued right after GEMM1(t) (its registers are free), V(t+1) right after GEMM2(t-1): both have
-//             a whole softmax (thousands of cycles) to land.
+//   loads:    one 16-byte fragment per softmax row (Q(t+1) on even rows, V(t) on odd rows, each into the register its
+//             last user just released): HBM requests stream continuously, a full step ahead of their use.
 template <int DK, int NKB, typename QT, bool AUX>
 __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) {
     constexpr int NKS = DK / 16;             // k-steps of GEMM1
@@ -146,6 +153,16 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     const float c_exp = P.scale * 1.44269504088896340736f;
     const int cb = (NCB == 4) ? w : (w & (NCB - 1));
     const int pj = pi_row(j);
+    const int n32 = (int)P.n;
+    int trace_it = 0;
+    auto stamp = [&](int phase) __attribute__((always_inline)) {
+        if (P.trace && blockIdx.x == 0 && lane == 0)
+            P.trace[(trace_it * 8 + phase) * 4 + w] = __builtin_amdgcn_s_memtime();
+    };
+    auto stamp_abs = [&](int slot) __attribute__((always_inline)) {  // slots 60..63 of the trace: kernel milestones
+        if (P.trace && blockIdx.x == 0 && lane == 0) P.trace[(slot * 8) * 4 + w] = __builtin_amdgcn_s_memtime();
+    };
+    stamp_abs(60);
 
     const int f_begin = blockIdx.x * P.tiles_per_wg;
     int f_end = f_begin + P.tiles_per_wg;
@@ -155,29 +172,31 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     f32x16 acc_o[NT];
     bf16x8 qf[NKS];  // Q fragments of the tile about to enter GEMM1
     bf16x8 vf[8];    // V fragments of the tile whose GEMM2 is pending (P already in LDS)
-    bf16x8 vn[8];    // V fragments of the tile in GEMM1 / softmax
 
     // All loads are unconditional and in bounds: Q rows are clamped to n-1 (their probabilities are zeroed), V^T is
     // read up to round_up(n, 128) <= ldv (the tail is bit-masked before use).
-    auto load_q = [&](int f) __attribute__((always_inline)) {
-        const int a = f / P.tiles_per_head;
-        const int64_t row0 = (int64_t)(f - a * P.tiles_per_head) * TILE_ROWS;
+    auto q_ptr = [&](int a, int t) __attribute__((always_inline)) -> const QT* {
+        const int64_t row0 = (int64_t)t * TILE_ROWS;
         int64_t qrow = row0 + 32 * w + pj;
         if (qrow > P.n - 1) qrow = P.n - 1;
-        const QT* qp = q + qrow * P.ldq + a * DK + 8 * hf;
-        static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) { qf[kb] = load_frag(qp + 16 * kb); });
+        if (P.debug_linear) return q + (row0 + 32 * w) * P.ldq + a * DK + 8 * lane;
+        return q + qrow * P.ldq + a * DK + 8 * hf;
     };
-    auto load_v = [&](int f, bf16x8(&vd)[8]) {
-        const int a = f / P.tiles_per_head;
-        const int64_t row0 = (int64_t)(f - a * P.tiles_per_head) * TILE_ROWS;
-        const QT* vcol = vt + (int64_t)(a * DK + 32 * cb + j) * P.ldv + row0 + 8 * hf;
-        static_for<0, 8>([&](auto sk) __attribute__((always_inline)) { vd[sk] = load_frag(vcol + 32 * (sk >> 1) + 16 * (sk & 1)); });
-        if (row0 + TILE_ROWS > P.n) {  // tail of a bag: zero the rows past n (bit mask: pad garbage never reaches the MFMA)
-            static_for<0, 8>([&](auto sk) __attribute__((always_inline)) {
-                const int64_t valid = P.n - (row0 + 32 * (sk >> 1) + 16 * (sk & 1) + 8 * hf);
-                vd[sk] = mask_frag(vd[sk], valid > 8 ? 8 : (valid < 0 ? 0 : (int)valid));
-            });
-        }
+    auto v_ptr = [&](int a, int t) __attribute__((always_inline)) -> const QT* {
+        const int64_t row0 = (int64_t)t * TILE_ROWS;
+        if (P.debug_linear) return vt + (int64_t)(a * DK + 32 * cb) * P.ldv + row0 * 32 + 8 * lane;
+        return vt + (int64_t)(a * DK + 32 * cb + j) * P.ldv + row0 + 8 * hf;
+    };
+    auto tile_is_tail = [&](int t) __attribute__((always_inline)) -> bool {
+        return (int64_t)(t + 1) * TILE_ROWS > P.n;
+    };
+    // tail of a bag: zero the V rows past n (bit mask, so pad garbage / NaN never reaches the MFMA)
+    auto mask_v_tail = [&](int t) __attribute__((always_inline)) {
+        const int64_t row0 = (int64_t)t * TILE_ROWS;
+        static_for<0, 8>([&](auto sk) __attribute__((always_inline)) {
+            const int64_t valid = P.n - (row0 + 32 * (sk >> 1) + 16 * (sk & 1) + 8 * hf);
+            vf[sk] = mask_frag(vf[sk], valid > 8 ? 8 : (valid < 0 ? 0 : (int)valid));
+        });
     };
     // one GEMM2 MFMA of the pending tile: m = (s*2 + ks) * NT + ti
     auto gemm2_one = [&](auto m_tag) __attribute__((always_inline)) {
@@ -239,17 +258,31 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
 #pragma unroll
         for (int i = 0; i < 8; ++i) vf[i] = zero_frag();
     }
+    int a = first_head, t = f_begin - first_head * P.tiles_per_head;   // (head, row tile) of the current work item
     if (f_begin < f_end) {
-        load_q(f_begin);
-        load_v(f_begin, vn);
+        const QT* qp0 = q_ptr(a, t);
+        static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) { qf[kb] = load_frag(qp0 + 16 * kb); });
     }
+    bool pending_tail = false;   // the pending tile (P published, GEMM2 not yet run) is the last tile of a bag
+    bool published = false;      // a P image was written and its closing barrier has not been passed yet
+    int pend_t = 0;
     int cur_head = -1;
     for (int f = f_begin; f < f_end; ++f) {
-        const int a = f / P.tiles_per_head;
-        const int64_t row0 = (int64_t)(f - a * P.tiles_per_head) * TILE_ROWS;
-        const int64_t my_row0 = row0 + 32 * w;
+        const int64_t row0 = (int64_t)t * TILE_ROWS;
+        const int my_row0 = (int)row0 + 32 * w;
+        int an = a, tn = t + 1;   // next work item
+        if (tn == P.tiles_per_head) {
+            tn = 0;
+            an = a + 1;
+        }
         if (a != cur_head) {
+            if (published) {
+                __syncthreads();   // P image of the pending tile is complete
+                published = false;
+            }
             if (cur_head >= 0) {  // drain the pending tile of the previous head, then flush its accumulators
+                if (pending_tail) mask_v_tail(pend_t);
+                pending_tail = false;
                 gemm2_all();
 #pragma unroll
                 for (int i = 0; i < 8; ++i) vf[i] = zero_frag();
@@ -259,54 +292,90 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc_o[ti][r] = 0.f;
+            stamp_abs(57);
             __syncthreads();  // everyone finished reading the previous head's Kp (and the zero-fill of lds_p is visible)
-            for (int fr = w; fr < NKB * NKS; fr += 4) {
-                const int jb = fr / NKS, kb = fr - jb * NKS;
-                const int key = 32 * jb + j;
-                bf16x8 v = zero_frag();
-                if (key < P.k) v = load_frag(P.kp + (int64_t)key * P.ldq + a * DK + 16 * kb + 8 * hf);
-                lds_kp[fr * 64 + lane] = __builtin_bit_cast(u32x4, v);
+            stamp_abs(58);
+            {   // Kp_a -> LDS as bf16 MFMA fragments: each wave owns fragments w, w+4, ...; all of its global loads are
+                // issued back to back (one latency, not one per fragment); padded keys re-read the last row and are
+                // zeroed by a select (their probabilities are forced to 0 through the -inf accumulator init anyway).
+                // (Keeping these fragments live across the main loop to prefetch them at kernel entry was measured:
+                // +56 registers of pressure cost 25 % in the loop -- do not.)
+                constexpr int NF = (NKB * NKS + 3) / 4;
+                bf16x8 kfr[NF];
+                static_for<0, NF>([&](auto i) __attribute__((always_inline)) {
+                    int fr = w + 4 * i;
+                    if (fr > NKB * NKS - 1) fr = NKB * NKS - 1;
+                    const int jb = fr / NKS, kb = fr - jb * NKS;
+                    int key = 32 * jb + j;
+                    if (key > P.k - 1) key = P.k - 1;
+                    kfr[i] = load_frag(P.kp + (int64_t)key * P.ldq + a * DK + 16 * kb + 8 * hf);
+                });
+                stamp_abs(59);
+                static_for<0, NF>([&](auto i) __attribute__((always_inline)) {
+                    const int fr = w + 4 * i;
+                    if (fr < NKB * NKS) {
+                        const int jb = fr / NKS;
+                        u32x4 v = __builtin_bit_cast(u32x4, kfr[i]);
+                        if (32 * jb + j >= P.k) v = u32x4{0u, 0u, 0u, 0u};
+                        lds_kp[fr * 64 + lane] = v;
+                    }
+                });
             }
             __syncthreads();
             cur_head = a;
+            stamp_abs(61);
         }
 
+        stamp(0);
         // ---- GEMM1: S[32 rows, 32*NKB keys] = Q Kp^T ; Kp fragments of the next key block are fetched from LDS while
         //      the MFMAs of the current one issue
         f32x16 s_acc[NKB];
         {
-            bf16x8 kfa[NKS], kfb[NKS];
-            static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) { kfa[kb] = __builtin_bit_cast(bf16x8, lds_kp[kb * 64 + lane]); });
-            static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
-                constexpr int jb = decltype(jb_t)::value;
+            // k-step outer, key block inner: consecutive MFMAs hit different accumulators (no dependent-issue stall).
+            // The NKB Kp fragments of step kb+1 are requested from LDS BEFORE the NKB MFMAs of step kb issue, so the
+            // LDS latency hides under ~NKB*32 cycles of matrix work; the sched_barrier fences pin that order (the
+            // scheduler otherwise sinks every read next to its use and the wave parks on lgkmcnt 56 times per tile).
+            bf16x8 kfa[NKB], kfb[NKB];
+            static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
+                kfa[jb] = __builtin_bit_cast(bf16x8, lds_kp[(jb * NKS) * 64 + lane]);
+                // padded keys (only possible in the last two blocks, see make_plan) start at -inf: exp() gives 0
+                const float init = (jb >= NKB - 2 && 32 * jb + j >= P.k) ? -INFINITY : 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s_acc[jb][r] = 0.f;
-                if constexpr (jb + 1 < NKB) {
-                    static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) {
-                        bf16x8 nx = __builtin_bit_cast(bf16x8, lds_kp[((jb + 1) * NKS + kb) * 64 + lane]);
-                        if constexpr (jb & 1) kfa[kb] = nx; else kfb[kb] = nx;
+                for (int r = 0; r < 16; ++r) s_acc[jb][r] = (jb >= NKB - 2) ? init : 0.f;
+            });
+            static_for<0, NKS>([&](auto kb_t) __attribute__((always_inline)) {
+                constexpr int kb = decltype(kb_t)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (kb + 1 < NKS) {
+                    static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
+                        bf16x8 nx = __builtin_bit_cast(bf16x8, lds_kp[(jb * NKS + kb + 1) * 64 + lane]);
+                        if constexpr (kb & 1) kfa[jb] = nx; else kfb[jb] = nx;
                     });
                 }
-                static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) {
-                    if constexpr (jb & 1)
-                        s_acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kb], kfb[kb], s_acc[jb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
+                    if constexpr (kb & 1)
+                        s_acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kb], kfb[jb], s_acc[jb], 0, 0, 0);
                     else
-                        s_acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kb], kfa[kb], s_acc[jb], 0, 0, 0);
+                        s_acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kb], kfa[jb], s_acc[jb], 0, 0, 0);
                 });
             });
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (f + 1 < f_end) load_q(f + 1);  // qf is free: next tile's Q lands during the softmax
+        stamp(1);
+        if (published) {
+            __syncthreads();   // closes the previous publish: placed AFTER GEMM1 so that the matrix work of this tile
+            published = false; // overlaps the other waves' bf16 conversion + LDS writes
+        }
+        // Streaming loads, one 16-byte fragment per softmax row so HBM requests flow continuously instead of in one
+        // burst per step: Q(t+1) fragment kb goes out after row 2kb (qf is free since GEMM1), V(t) fragment sk after
+        // row 2sk+1 (the pending GEMM2 slices of rows <= 2sk+1 were the last users of vf[sk]).
+        const bool has_next = f + 1 < f_end;
+        const QT* qnext = q_ptr(has_next ? an : a, has_next ? tn : t);
+        const QT* vcur = v_ptr(a, t);
+        if (pending_tail) mask_v_tail(pend_t);
 
         // ---- softmax over keys (lanes of a half-wave x NKB blocks), fp32, with GEMM2 of the pending tile interleaved
-        {
-            const int first_pad_blk = P.k >> 5;  // wave-uniform: blocks below it are fully valid
-            static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
-                if (jb >= first_pad_blk && 32 * jb + j >= P.k) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s_acc[jb][r] = -INFINITY;
-                }
-            });
-        }
         auto softmax_row = [&](auto r_tag) __attribute__((always_inline)) {
             constexpr int r = decltype(r_tag)::value;
             float m = s_acc[0][r];
@@ -320,8 +389,8 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
                 l += e;
             });
             l = half_allsum(l);
-            const int64_t row = my_row0 + (r & 7) + 8 * hf + 16 * (r >> 3);
-            const bool rvalid = row < P.n;
+            const int row = my_row0 + (r & 7) + 8 * hf + 16 * (r >> 3);
+            const bool rvalid = row < n32;
             const float inv = rvalid ? __builtin_amdgcn_rcpf(l) : 0.f;
             static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) { s_acc[jb][r] *= inv; });
             if constexpr (AUX) {
@@ -337,14 +406,24 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
             // slice r of the pending GEMM2
             gemm2_range(std::integral_constant<int, (r * M2) / 16>{}, std::integral_constant<int, ((r + 1) * M2) / 16>{});
         };
-        static_for<0, 16>(softmax_row);
+        static_for<0, 16>([&](auto r_tag) __attribute__((always_inline)) {
+            constexpr int r = decltype(r_tag)::value;
+            softmax_row(r_tag);
+            if constexpr ((r & 1) == 0) {
+                if constexpr (r / 2 < NKS) qf[r / 2] = load_frag(qnext + 16 * (r / 2));
+            } else {
+                constexpr int sk = r / 2;
+                vf[sk] = load_frag(vcur + 32 * (sk >> 1) + 16 * (sk & 1));
+            }
+        });
+        pending_tail = tile_is_tail(t);
+        pend_t = t;
+        stamp(2);
 
-        // ---- the pending tile is consumed: this tile becomes pending; fetch the V fragments of the one after it
-        static_for<0, 8>([&](auto i) __attribute__((always_inline)) { vf[i] = vn[i]; });
-        if (f + 1 < f_end) load_v(f + 1, vn);
 
         // ---- publish P fragments (bf16) for the 4 waves
         __syncthreads();  // every wave finished the GEMM2 reads of the previous image
+        stamp(3);
         static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -355,12 +434,20 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
                 lds_p[((w * NKB + jb) * 2 + ks) * 64 + lane] = __builtin_bit_cast(u32x4, pb);
             }
         });
-        __syncthreads();
+        published = true;
+        stamp(4);
+        ++trace_it;
+        a = an;
+        t = tn;
     }
+    stamp_abs(62);
+    if (published) __syncthreads();
     if (cur_head >= 0) {
+        if (pending_tail) mask_v_tail(pend_t);
         gemm2_all();  // drain the last pending tile
         flush(cur_head);
     }
+    stamp_abs(63);
 }
 
 // out[key, a*DK + col] = sum over the (workgroup, segment) partials of head a, ascending workgroup order
@@ -379,12 +466,20 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     int b_lo = f_lo / tiles_per_wg, b_hi = f_hi / tiles_per_wg;
     if (b_hi > num_wg - 1) b_hi = num_wg - 1;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int b = b_lo; b <= b_hi; ++b) {
+    const int64_t off = ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4;
+    auto src_of = [&](int b) -> const float* {
         const int seg = a - (b * tiles_per_wg) / tiles_per_head;
-        const float* src = partial + ((int64_t)b * seg_count + seg) * (int64_t)TILES * 1024;
-        f32x4 v = *reinterpret_cast<const f32x4*>(src + ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4);
-        s += v;
+        return partial + ((int64_t)b * seg_count + seg) * (int64_t)TILES * 1024 + off;
+    };
+    int b = b_lo;
+    for (; b + 7 <= b_hi; b += 8) {  // 8 loads in flight; the summation order stays ascending in b (deterministic)
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src_of(b + u));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
     }
+    for (; b <= b_hi; ++b) s += *reinterpret_cast<const f32x4*>(src_of(b));
     const int kb = t_idx / NCB, cb = t_idx - kb * NCB;
     const int col = a * DK + 32 * cb + (lane & 31);
 #pragma unroll
@@ -393,6 +488,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
         if (key < k) out[(int64_t)key * (h * DK) + col] = s[i];
     }
 }
+
+unsigned long long* g_attn_trace = nullptr;  // debug hook, see snf_debug_attn_trace
 
 struct Plan {
     int num_wg, tiles_per_head, tiles_per_wg, total_tiles, seg_count, nkb;
@@ -410,6 +507,7 @@ inline bool make_plan(int64_t n, int k, int h, int dk, Plan* pl) {
             break;
         }
     if (!sel) return false;
+    if (n > 0x7fffff00ll) return false;   // 32-bit row arithmetic inside the kernel
     int64_t tph = (n + TILE_ROWS - 1) / TILE_ROWS;
     int64_t total = tph * h;
     if (total > 0x7fffffff) return false;
@@ -471,6 +569,9 @@ inline size_t mfma_workspace_bytes(const Plan& pl, int dk) {
 
 extern "C" {
 
+// debug only (not part of the public header): device buffer of >= 64*8*4 u64 receiving s_memtime stamps of workgroup 0
+void snf_debug_attn_trace(void* buf) { g_attn_trace = reinterpret_cast<unsigned long long*>(buf); }
+
 size_t snf_sparse_attn_fwd_workspace_bytes(int64_t n, int k, int h, int dk, int mfma) {
     if (n < 1 || k < 1 || h < 1 || dk < 1) return 0;
     if (mfma) {
@@ -519,6 +620,8 @@ int snf_sparse_attn_fwd_mfma(const void* q, const void* vt, int qv_dtype, int64_
     P.tiles_per_wg = pl.tiles_per_wg;
     P.total_tiles = pl.total_tiles;
     P.seg_count = pl.seg_count;
+    P.debug_linear = getenv("SNF_DEBUG_LINEAR") ? 1 : 0;
+    P.trace = g_attn_trace;
     hipStream_t s = snf::as_stream(stream);
     if (dk == 128) {
         if (qv_dtype == SNF_DT_F32) return launch_nkb<128, float>(P, pl, out, s);

@@ -12,17 +12,17 @@ from snuffy_amd import ops  # noqa: E402
 dev = torch.device("cuda")
 
 
-def attn(wlname="cfgB", dts=("bf16", "f32"), iters=30):
+def attn(wlname="cfgB", dts=("bf16", "f32"), iters=30, K=None, nset=4, N=None):
     wl = WORKLOADS[wlname]
-    N, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
-    K = min(lam, 256)
+    N0, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
+    N = N or N0
+    K = K or min(lam, 256)
     g = torch.Generator().manual_seed(1)
     kp = torch.randn(K, D, generator=g).to(dev)
     for dt in dts:
         tdt = torch.bfloat16 if dt == "bf16" else torch.float32
         elt = 2 if dt == "bf16" else 4
         ld = ops.vt_leading_dim(N, elt)
-        nset = 4
         qs = [torch.randn(N, D, generator=g).to(dev).to(tdt) for _ in range(nset)]
         vts = [torch.randn(D, ld, generator=g).to(dev).to(tdt) for _ in range(nset)]
         st = {"i": 0}
@@ -32,7 +32,7 @@ def attn(wlname="cfgB", dts=("bf16", "f32"), iters=30):
             ops.sparse_attn_fwd_mfma(qs[st["i"]], vts[st["i"]], kp, N, h)
         t = timed(f, iters, warmup=3)
         b = 2 * N * D * elt + 2 * K * D * 4
-        print(f"attn_mfma {wlname} {dt}: {t*1e3:8.1f} us  {b/t/1e6:8.1f} GB/s algorithmic  ({b/t/1e6/8000*100:.1f}% of 8 TB/s)"
+        print(f"attn_mfma {wlname} N={N} K={K} nset={nset} {dt}: {t*1e3:8.1f} us  {b/t/1e6:8.1f} GB/s algorithmic  ({b/t/1e6/8000*100:.1f}% of 8 TB/s)"
               f"  {4*N*K*D/t/1e9:.1f} TFLOP/s")
         del qs, vts
 
@@ -69,6 +69,12 @@ def rows():
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "attnx":   # experiments: where does the time go?
+        attn("cfgB", dts=("bf16",))
+        attn("cfgB", dts=("bf16",), nset=1)           # operands stay in the 256 MiB Infinity Cache
+        attn("cfgB", dts=("bf16",), N=4096, nset=1)   # L2-resident, 1/8 of the work
+        attn("cfgB", dts=("bf16",), K=32)             # 1 key block: memory traffic unchanged, 1/7 of the math
+        attn("cfgB", dts=("bf16",), K=128)
     if what == "attnB":
         attn("cfgB", dts=("bf16",), iters=10)
     if what in ("attn", "all"):

@@ -12,7 +12,7 @@ run() { # name, counters...
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS
 run sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM
-run fetch FETCH_SIZE
-run write WRITE_SIZE
-run tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
-run grbm GRBM_GUI_ACTIVE GRBM_COUNT
+#run fetch FETCH_SIZE
+#run write WRITE_SIZE
+#run tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
+#run grbm GRBM_GUI_ACTIVE GRBM_COUNT
