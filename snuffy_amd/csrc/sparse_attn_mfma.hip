@@ -55,7 +55,6 @@ struct AttnParams {
     float* lse;      // [h, n] or null
     float* partial;  // [num_wg * seg_count][tiles][16][64]
     int tiles_per_head, tiles_per_wg, total_tiles, seg_count;
-    int debug_linear;  // timing experiment only: fully coalesced (wrong) addresses
     unsigned long long* trace;  // debug: s_memtime stamps of workgroup 0 (tools/attn_trace.py), normally null
 };
 
@@ -179,12 +178,10 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
         const int64_t row0 = (int64_t)t * TILE_ROWS;
         int64_t qrow = row0 + 32 * w + pj;
         if (qrow > P.n - 1) qrow = P.n - 1;
-        if (P.debug_linear) return q + (row0 + 32 * w) * P.ldq + a * DK + 8 * lane;
         return q + qrow * P.ldq + a * DK + 8 * hf;
     };
     auto v_ptr = [&](int a, int t) __attribute__((always_inline)) -> const QT* {
         const int64_t row0 = (int64_t)t * TILE_ROWS;
-        if (P.debug_linear) return vt + (int64_t)(a * DK + 32 * cb) * P.ldv + row0 * 32 + 8 * lane;
         return vt + (int64_t)(a * DK + 32 * cb + j) * P.ldv + row0 + 8 * hf;
     };
     auto tile_is_tail = [&](int t) __attribute__((always_inline)) -> bool {
@@ -620,7 +617,6 @@ int snf_sparse_attn_fwd_mfma(const void* q, const void* vt, int qv_dtype, int64_
     P.tiles_per_wg = pl.tiles_per_wg;
     P.total_tiles = pl.total_tiles;
     P.seg_count = pl.seg_count;
-    P.debug_linear = getenv("SNF_DEBUG_LINEAR") ? 1 : 0;
     P.trace = g_attn_trace;
     hipStream_t s = snf::as_stream(stream);
     if (dk == 128) {

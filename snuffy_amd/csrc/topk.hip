@@ -2,7 +2,8 @@
 //
 // Exact, deterministic, tie rule = descending score then ascending index (torch.sort(stable=True) order).
 // Each score becomes a 64-bit composite key  (orderable(score) << 32) | ~index ; larger composite == earlier in the
-// output.  Round r: every workgroup bitonic-sorts a chunk of 4096 composites in LDS and keeps its top min(k, chunk);
+// output.  Round r: every workgroup bitonic-sorts a chunk of 4096 composites (registers + wave shuffles, LDS only for
+// the cross-wave steps) and keeps its top min(k, chunk);
 // rounds repeat on the survivors until one chunk is left, whose top k indices are the answer.  Integer compare-exchange
 // only -- bit-exact on every run.
 #include "common.h"
@@ -19,27 +20,67 @@ __device__ __forceinline__ unsigned int orderable_desc(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// in-LDS bitonic sort, descending, of CHUNK 64-bit keys by TPB threads
-__device__ __forceinline__ void bitonic_sort_desc(unsigned long long* s) {
+// Bitonic sort (descending) of CHUNK = 4 * TPB 64-bit keys, 4 consecutive keys per thread held in REGISTERS:
+//   partner distance 1, 2        -> inside the thread
+//   partner distance 4 .. 128    -> another lane of the same wave (64-bit shuffle, no barrier)
+//   partner distance >= 256      -> another wave: through LDS (10 of the 78 network steps)
+// Element i of the chunk lives in thread i / 4, slot i % 4.
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
+    unsigned int lo = (unsigned int)v, hi = (unsigned int)(v >> 32);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ void cmpx(unsigned long long& mine, unsigned long long other, bool take_max) {
+    const bool other_gt = other > mine;
+    mine = (other_gt == take_max) ? other : mine;
+}
+
+__device__ __forceinline__ void bitonic_sort_desc_regs(unsigned long long (&v)[4], unsigned long long* s) {
+    const int tid = threadIdx.x;
     for (int size = 2; size <= CHUNK; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
+            if (stride >= 256) {
+                __syncthreads();
 #pragma unroll
-            for (int t = 0; t < CHUNK / 2 / TPB; ++t) {
-                int p = threadIdx.x + t * TPB;                       // pair id in [0, CHUNK/2)
-                int lo = 2 * p - (p & (stride - 1));                 // index with the `stride` bit clear
-                int hi = lo + stride;
-                bool desc = ((lo & size) == 0);                      // direction of this bitonic block
-                unsigned long long a = s[lo], b = s[hi];
-                bool swap = desc ? (a < b) : (a > b);
-                if (swap) {
-                    s[lo] = b;
-                    s[hi] = a;
+                for (int e = 0; e < 4; ++e) s[4 * tid + e] = v[e];
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * tid + e;
+                    const bool lower = (i & stride) == 0, desc = (i & size) == 0;
+                    cmpx(v[e], s[i ^ stride], lower == desc);
                 }
+            } else if (stride >= 4) {
+                const int lm = stride >> 2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * tid + e;
+                    const bool lower = (i & stride) == 0, desc = (i & size) == 0;
+                    cmpx(v[e], shfl_xor_u64(v[e], lm), lower == desc);
+                }
+            } else {
+                const bool desc = ((4 * tid) & size) == 0;  // size >= 2: all 4 slots of a thread share it unless size < 8
+                if (stride == 2) {
+                    const bool d0 = ((4 * tid + 0) & size) == 0, d1 = ((4 * tid + 1) & size) == 0;
+                    unsigned long long a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+                    cmpx(v[0], a2, d0);        // slot 0 is the lower element of the pair (0,2)
+                    cmpx(v[2], a0, !d0);
+                    cmpx(v[1], a3, d1);
+                    cmpx(v[3], a1, !d1);
+                } else {
+                    const bool d0 = ((4 * tid + 0) & size) == 0, d2 = ((4 * tid + 2) & size) == 0;
+                    unsigned long long a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+                    cmpx(v[0], a1, d0);
+                    cmpx(v[1], a0, !d0);
+                    cmpx(v[2], a3, d2);
+                    cmpx(v[3], a2, !d2);
+                }
+                (void)desc;
             }
         }
     }
-    __syncthreads();
 }
 
 // FROM_SCORES: src is float scores (stride elements apart), else src is a composite list of length m.
@@ -49,31 +90,34 @@ __global__ __launch_bounds__(TPB) void topk_round_kernel(const void* __restrict_
                                                         void* __restrict__ dst) {
     __shared__ unsigned long long s[CHUNK];
     const int64_t base = (int64_t)blockIdx.x * CHUNK;
+    unsigned long long v[4];
 #pragma unroll
-    for (int t = 0; t < CHUNK / TPB; ++t) {
-        int li = threadIdx.x + t * TPB;
-        int64_t gi = base + li;
+    for (int e = 0; e < 4; ++e) {
+        const int li = 4 * threadIdx.x + e;
+        const int64_t gi = base + li;
         unsigned long long key = 0ull;  // below every real composite (index part of a real key is never ~0 here)
         if (gi < m) {
             if (FROM_SCORES) {
-                float v = reinterpret_cast<const float*>(src)[gi * stride];
-                key = ((unsigned long long)orderable_desc(v) << 32) | (unsigned long long)(0xffffffffu - (unsigned int)gi);
+                float f = reinterpret_cast<const float*>(src)[gi * stride];
+                key = ((unsigned long long)orderable_desc(f) << 32) | (unsigned long long)(0xffffffffu - (unsigned int)gi);
             } else {
                 key = reinterpret_cast<const unsigned long long*>(src)[gi];
             }
         }
-        s[li] = key;
+        v[e] = key;
     }
-    bitonic_sort_desc(s);
+    bitonic_sort_desc_regs(v, s);
     int64_t remain = m - base;
     int cnt = (int)(remain < CHUNK ? remain : CHUNK);
     int keep = cnt < k ? cnt : k;
-    for (int li = threadIdx.x; li < keep; li += TPB) {
-        unsigned long long key = s[li];
-        if (TO_INDEX) {
-            reinterpret_cast<int64_t*>(dst)[li] = (int64_t)(0xffffffffu - (unsigned int)(key & 0xffffffffull));
-        } else {
-            reinterpret_cast<unsigned long long*>(dst)[(int64_t)blockIdx.x * k + li] = key;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int li = 4 * threadIdx.x + e;
+        if (li < keep) {
+            if (TO_INDEX)
+                reinterpret_cast<int64_t*>(dst)[li] = (int64_t)(0xffffffffu - (unsigned int)(v[e] & 0xffffffffull));
+            else
+                reinterpret_cast<unsigned long long*>(dst)[(int64_t)blockIdx.x * k + li] = v[e];
         }
     }
 }
