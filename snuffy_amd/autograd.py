@@ -1,0 +1,162 @@
+"""Training path of the Snuffy aggregator (loss.backward() of reference train.py:259).
+
+Round-1 status: the FORWARD of every custom op runs on the hand-written HIP kernels; the BACKWARD of those
+ops is composed from library GPU ops (torch.bmm / elementwise) inside ``torch.autograd.Function`` -- the hand-written
+backward kernels (K7-bwd: recompute P, stream dQ/dV, reduce dKp) are the next item.  Dense projections are library GEMMs
+with torch's own autograd.  Everything stays on the GPU; nothing here touches the CPU oracle.
+
+Semantics follow the reference in train mode:
+  * attention dropout p = MultiHeadedAttention.dropout.p (0.1 -- train.py:866-869 never overrides it) on P, snuffy.py:166-167
+  * encoder dropout (default 0) after the attention output, inside the FFN and after it, snuffy.py:108,110,225
+  * no gradient flows through the selection (snuffy.py:128-147); x itself is data (no grad) in layer 0
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+_ACT = {
+    "relu": F.relu,
+    "gelu": F.gelu,
+    "leakyrelu": lambda t: F.leaky_relu(t, 0.01),
+    "selu": F.selu,
+}
+
+
+class LayerNormRowsFn(torch.autograd.Function):
+    """y = LayerNorm(x) * gamma + beta (forward: snf_layernorm_rows_f32, statistics saved for backward)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y, mean, rstd = ops.layernorm_rows(x, gamma, beta, eps, want_stats=True)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        xhat = (x - mean.unsqueeze(1)) * rstd.unsqueeze(1)
+        dgamma = (dy * xhat).sum(0)
+        dbeta = dy.sum(0)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxhat = dy * gamma
+            m1 = dxhat.mean(1, keepdim=True)
+            m2 = (dxhat * xhat).mean(1, keepdim=True)
+            dx = (dxhat - m1 - xhat * m2) * rstd.unsqueeze(1)
+        return dx, dgamma, dbeta, None
+
+
+class ScatterRowsFn(torch.autograd.Function):
+    """y = x.clone(); y[sel] = rows  (snuffy.py:154-155; forward: snf_scatter_rows_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, sel, rows):
+        ctx.save_for_backward(sel)
+        return ops.scatter_rows(x, sel, rows)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (sel,) = ctx.saved_tensors
+        drows = dy.index_select(0, sel)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = dy.clone()
+            dx.index_fill_(0, sel, 0.0)
+        return dx, None, drows
+
+
+class SparseAttnFn(torch.autograd.Function):
+    """O = dropout(softmax_K(Q Kp^T / sqrt(dk)))^T V per head (snuffy.py:160-168).
+
+    Forward: snf_sparse_attn_fwd_f32 (P materialised: the backward below needs it).  Backward: library bmm's.
+    """
+
+    @staticmethod
+    def forward(ctx, q, kp, v, h, dropout_p):
+        n, d = q.shape
+        k = kp.shape[0]
+        dk = d // h
+        out, p, _ = ops.sparse_attn_fwd(q, kp, v, h, need_attn=True)
+        mask = None
+        if dropout_p > 0.0:
+            mask = (torch.rand_like(p) >= dropout_p).to(p.dtype) / (1.0 - dropout_p)
+            vh = v.view(n, h, dk).transpose(0, 1)
+            out = torch.bmm((p * mask).transpose(1, 2), vh).transpose(0, 1).reshape(k, d)
+        ctx.save_for_backward(q, kp, v, p, mask)
+        ctx.h = h
+        return out, p
+
+    @staticmethod
+    def backward(ctx, dout, _dp_unused):
+        q, kp, v, p, mask = ctx.saved_tensors
+        h = ctx.h
+        n, d = q.shape
+        k = kp.shape[0]
+        dk = d // h
+        scale = 1.0 / math.sqrt(dk)
+        do = dout.reshape(k, h, dk).transpose(0, 1)               # [h, K, dk]
+        vh = v.view(n, h, dk).transpose(0, 1)                     # [h, N, dk]
+        qh = q.view(n, h, dk).transpose(0, 1)
+        kh = kp.view(k, h, dk).transpose(0, 1)
+        pd = p if mask is None else p * mask
+        dv = torch.bmm(pd, do)                                    # [h, N, dk]
+        dpd = torch.bmm(vh, do.transpose(1, 2))                   # [h, N, K]
+        dp = dpd if mask is None else dpd * mask
+        ds = p * (dp - (dp * p).sum(-1, keepdim=True))
+        ds.mul_(scale)
+        dq = torch.bmm(ds, kh)                                    # [h, N, dk]
+        dkp = torch.bmm(ds.transpose(1, 2), qh)                   # [h, K, dk]
+        return (dq.transpose(0, 1).reshape(n, d), dkp.transpose(0, 1).reshape(k, d),
+                dv.transpose(0, 1).reshape(n, d), None, None)
+
+
+def critic_train(feats2, w, b):
+    """Critic scores with autograd (library GEMV); the selection itself uses them detached."""
+    return F.linear(feats2, w, b)
+
+
+def encoder_layer_train(x2, sel, layer, need_attn, precision):
+    """Differentiable EncoderLayer.forward (snuffy.py:126-157).  Returns (functional.Parts, A)."""
+    from .functional import Parts
+    if precision != "fp32":
+        raise NotImplementedError("training runs the fp32 path in this round (bf16 training is on the list)")
+    mha, ff = layer.self_attn, layer.feed_forward
+    n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
+    drop0, drop1 = layer.sublayer[0].dropout, layer.sublayer[1].dropout
+    lq, lk, lv, lo = mha.linears
+    training = layer.training
+    if sel.numel() == 0:
+        y = x2
+        attn = torch.empty(1, mha.h, x2.shape[0], 0, device=x2.device) if need_attn else None
+    else:
+        xs = x2.index_select(0, sel)                                            # snuffy.py:131,145-147
+        xn = LayerNormRowsFn.apply(x2, n0.weight, n0.bias, n0.eps)              # snuffy.py:107
+        q = F.linear(xn, lq.weight, lq.bias)
+        kp = F.linear(xs, lk.weight, lk.bias)
+        v = F.linear(xn, lv.weight, lv.bias)
+        p_drop = mha.dropout.p if training else 0.0
+        o, p = SparseAttnFn.apply(q, kp, v, mha.h, p_drop)
+        delta = F.linear(o, lo.weight, lo.bias)                                 # snuffy.py:205
+        if training and drop0.p > 0:
+            delta = F.dropout(delta, drop0.p, True)
+        x_sel = xs + delta                                                      # snuffy.py:108
+        y = ScatterRowsFn.apply(x2, sel, x_sel)                                 # snuffy.py:154-155
+        attn = p.detach().unsqueeze(0) if need_attn else None
+    yn = LayerNormRowsFn.apply(y, n1.weight, n1.bias, n1.eps)
+    hid = _ACT[ff.activation_name](F.linear(yn, ff.w_1.weight, ff.w_1.bias))    # snuffy.py:224-225
+    if training and ff.dropout.p > 0:
+        hid = F.dropout(hid, ff.dropout.p, True)
+    f = F.linear(hid, ff.w_2.weight, ff.w_2.bias)
+    if training and drop1.p > 0:
+        f = F.dropout(f, drop1.p, True)
+    z = y + f                                                                   # snuffy.py:110
+    return Parts(z), attn
+
+
+def head_train(z, norm, linear):
+    """logits = Linear(mean_n LayerNorm(z)) with autograd (snuffy.py:86,71)."""
+    zn = LayerNormRowsFn.apply(z, norm.weight, norm.bias, norm.eps)
+    return F.linear(zn.mean(dim=0), linear.weight, linear.bias)

@@ -56,7 +56,12 @@ def critic_scores(feats, w, b):
     f2 = feats.reshape(-1, feats.shape[-1])
     if not f2.is_cuda:
         raise SnuffyHipError("input must be a GPU tensor: snuffy_amd has no CPU fallback")
-    s = ops.critic(f2.float().contiguous(), w, b)
+    f2 = f2.float().contiguous()
+    if torch.is_grad_enabled() and (w.requires_grad or f2.requires_grad):
+        from . import autograd as SA
+        s = SA.critic_train(f2, w, b)                    # training: library GEMV with autograd
+    else:
+        s = ops.critic(f2, w, b)
     return s.view(*lead, w.shape[0])
 
 
@@ -64,7 +69,7 @@ def select_top(c1, big_lambda, top_share, n):
     k1 = min(math.ceil(big_lambda * top_share), n)          # python float arithmetic, snuffy.py:129
     if k1 < 1:
         return torch.empty(0, dtype=torch.int64, device=c1.device)
-    return ops.topk(c1, k1)
+    return ops.topk(c1.detach(), k1)                         # no gradient through the selection (snuffy.py:128-130)
 
 
 def gather(x2, idx):
@@ -144,6 +149,9 @@ def materialize(parts):
 
 def head(parts, norm, linear):
     """logits = Linear(mean_n LayerNorm(z))  (snuffy.py:86,71), residual assembly fused into the read."""
+    if torch.is_grad_enabled() and (parts.base.requires_grad or norm.weight.requires_grad or linear.weight.requires_grad):
+        from . import autograd as SA
+        return SA.head_train(materialize(parts), norm, linear)
     logits, _, _ = ops.ln_mean_head(parts.base, norm.weight, norm.bias, norm.eps, linear.weight, linear.bias,
                                     parts.add_bf16, parts.add_bias, parts.slot, parts.delta)
     return logits

@@ -1,0 +1,339 @@
+"""MI355X-native mirror of the reference's MIL trainer for the Snuffy path (train.py: Trainer / SmallWeightTrainer /
+Snuffy / Runner hooks), plus the bag-parallel multi-GPU step the reference does not have.
+
+Kept from the reference (same names, same meaning):
+  get_args_parser            the hot-path flags of train.py:54-135 with identical names and defaults
+  Trainer._get_milnet/_get_criterion/_get_optimizer/_get_scheduler/_load_init_weights/_run_model/
+          _after_run_model_in_training_mode/train/valid
+  SmallWeightTrainer         single_weight_parameter (init 0.5, clamped to [0,1], own lr multiplier), loss mix train.py:828-846
+  Snuffy                     _get_milnet exactly as train.py:861-911
+
+Deliberately different:
+  * bags can be staged in HBM once (utils.stage_bags) instead of a host->device copy per bag per epoch;
+  * per-bag scalars (loss, prediction) stay on the device and are read back once per epoch, not three times per bag;
+  * wandb / FROC / ECE / ROC plumbing is out of scope; AUC is computed with sklearn when present;
+  * world_size > 1: bags are sharded rank::world, gradients are averaged with ONE flat all-reduce per optimizer step
+    (RCCL over xGMI) -> effective batch = world_size bags; world_size == 1 is exactly the reference's step.
+"""
+import argparse
+import copy
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch import optim
+
+from . import snuffy
+from .utils import OPTIMIZERS, WEIGHT_INITS, compute_pos_weight, dropout_patches
+
+MIL_DATASETS = ('musk1', 'musk2', 'elephant', 'fox', 'tiger')
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+def get_args_parser():
+    """Hot-path subset of reference train.py:54-135 (same flag names / defaults)."""
+    p = argparse.ArgumentParser(description='Train the Snuffy MIL aggregator on precomputed patch features (MI355X)')
+    p.add_argument('--num_classes', default=1, type=int)
+    p.add_argument('--feats_size', default=512, type=int)
+    p.add_argument('--lr', default=2e-4, type=float)
+    p.add_argument('--num_epochs', default=200, type=int)
+    p.add_argument('--weight_decay', default=5e-3, type=float)
+    p.add_argument('--eta_min', default=5e-06, type=float)
+    p.add_argument('--dataset', default='camelyon16', type=str)
+    p.add_argument('--dropout_patch', default=0, type=float)
+    p.add_argument('--weight_init__weight_init_i__weight_init_b',
+                   default=['xavier_normal', 'xavier_normal', 'xavier_normal'])
+    p.add_argument('--optimizer', default='adam', type=str, choices=['adam', 'adamw', 'sgd'])
+    p.add_argument('--scheduler', default='cosine', type=str, choices=['cosinewarmup', 'cosine'])
+    p.add_argument('--arch', default='snuffy', type=str)
+    p.add_argument('--soft_average', default=0, choices=[0, 1], type=int)
+    p.add_argument('--single_weight__lr_multiplier', default=0.1, type=float)
+    p.add_argument('--num_heads', default=6, type=int)
+    p.add_argument('--big_lambda', default=200, type=int)
+    p.add_argument('--random_patch_share', default=0.0, type=float)
+    p.add_argument('--mlp_multiplier', default=4, type=int)
+    p.add_argument('--encoder_dropout', default=0.0, type=float)
+    p.add_argument('--activation', default='relu', type=str)
+    p.add_argument('--clip_grad', default=None, type=float)
+    p.add_argument('--depth', default=1, type=int)
+    p.add_argument('--betas', default=[0.5, 0.9])
+    p.add_argument('--l2normed_embeddings', default=0, type=int)
+    p.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help='eval-forward arithmetic (snuffy_amd)')
+    return p
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# bag-parallel gradient exchange (new)
+# ----------------------------------------------------------------------------------------------------------------------
+class FlatGradAllReduce:
+    """One flat fp32 buffer over all trainable parameters; ONE all-reduce (sum, then / world) per optimizer step.
+
+    dist is torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" in the CPU tests) or None for a single process.
+    """
+
+    def __init__(self, params, dist=None, world_size=1):
+        self.params = [p for p in params if p.requires_grad]
+        self.dist = dist if world_size > 1 else None
+        self.world_size = world_size
+        self.flat = None
+
+    def __call__(self):
+        if self.dist is None:
+            return
+        if self.flat is None:
+            n = sum(p.numel() for p in self.params)
+            self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                self.flat[off:off + n].zero_()
+            else:
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM)
+        self.flat.div_(self.world_size)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = self.flat[off:off + n].view_as(p).clone()
+            else:
+                p.grad.copy_(self.flat[off:off + n].view_as(p))
+            off += n
+
+
+class Trainer:
+    def __init__(self, args, dist=None, rank=0, world_size=1):
+        self.args = args
+        self.dist, self.rank, self.world_size = dist, rank, world_size
+        self.milnet = self._get_milnet()
+        self._load_init_weights()
+        self._criterion_is_set = False
+        self.criterion = self._get_criterion()
+        self.optimizer = self._get_optimizer()
+        self.scheduler = self._get_scheduler()
+        self._grad_sync = FlatGradAllReduce(self._trainable(), dist, world_size)
+
+    # -- hooks (reference names) --------------------------------------------------------------------------------------
+    def _get_milnet(self) -> nn.Module:
+        raise NotImplementedError
+
+    def _trainable(self):
+        return list(self.milnet.parameters())
+
+    def _get_criterion(self):
+        self._criterion_is_set = self.args.dataset not in MIL_DATASETS        # train.py:158-164
+        return nn.BCEWithLogitsLoss()
+
+    def _get_optimizer(self) -> optim.Optimizer:
+        try:
+            cls = OPTIMIZERS[self.args.optimizer]
+        except KeyError:
+            raise Exception(f'Optimizer not found. Given: {self.args.optimizer}, Have: {OPTIMIZERS.keys()}')
+        return cls(params=self.milnet.parameters(), lr=self.args.lr, betas=(self.args.betas[0], self.args.betas[1]),
+                   weight_decay=self.args.weight_decay)
+
+    def _get_scheduler(self):
+        if self.args.scheduler == 'cosine':
+            return torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=self.args.num_epochs,
+                                                              eta_min=self.args.eta_min)
+        return None
+
+    def _load_init_weights(self):
+        names = self.args.weight_init__weight_init_i__weight_init_b
+        try:
+            init_i, init_b = WEIGHT_INITS[names[1]], WEIGHT_INITS[names[2]]
+        except KeyError:
+            if names[0] is not None:
+                raise Exception(f'Weight init not found. Given: {names[0]}, Have: {WEIGHT_INITS.keys()} ')
+            return
+        self.milnet.i_classifier.apply(init_i)
+        self.milnet.b_classifier.apply(init_b)
+
+    def _run_model(self, bag_feats, bag_label):
+        raise NotImplementedError
+
+    def _after_run_model_in_training_mode(self, step, num_bags, batch_idx):
+        self._grad_sync()                                                       # no-op unless world_size > 1
+        if self.args.clip_grad is not None:
+            torch.nn.utils.clip_grad_norm_(self.milnet.parameters(), max_norm=self.args.clip_grad)
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+
+    # -- epoch loops -------------------------------------------------------------------------------------------------
+    def _bag_to_device(self, feats):
+        if torch.is_tensor(feats):
+            x = feats if feats.dim() == 3 else feats.unsqueeze(0)
+            return x.to(device)
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(feats, dtype=np.float32))).unsqueeze(0).to(device)
+
+    def train(self, data, cur_epoch):
+        """One epoch over (labels, feats, feat_labels, positions) (reference train.py:223-293).
+
+        feats entries are [N_i, D] numpy arrays (as utils.load_data returns them) or [1, N_i, D] device tensors
+        (utils.stage_bags).  Bags are visited in a seeded shuffle; rank r takes positions r::world_size."""
+        from sklearn.utils import shuffle
+        self.milnet.train()
+        labels, feats = data[0], data[1]
+        order = shuffle(np.arange(len(labels)))                                 # consumes the global numpy RNG once
+        if not self._criterion_is_set:
+            pw = torch.tensor(compute_pos_weight(labels), device=device, dtype=torch.float32)
+            self.criterion = nn.BCEWithLogitsLoss(pw)
+            self._criterion_is_set = True
+        num_bags = len(order)
+        steps = (num_bags + self.world_size - 1) // self.world_size
+        losses, preds, seen = [], [], []
+        for s in range(steps):
+            pos = s * self.world_size + self.rank
+            i = int(order[pos % num_bags])                                      # wrap: every rank steps every time
+            f = feats[i]
+            if not torch.is_tensor(f):
+                if self.args.l2normed_embeddings == 1:
+                    f = f / np.linalg.norm(f, axis=1, keepdims=True)
+                f = dropout_patches(f, self.args.dropout_patch)
+            bag_feats = self._bag_to_device(f)
+            bag_label = torch.as_tensor(np.asarray(labels[i], dtype=np.float32).reshape(1, -1), device=device)
+            bag_prediction, loss, _ = self._run_model(bag_feats, bag_label)
+            loss.backward()
+            self._after_run_model_in_training_mode(step=num_bags * (cur_epoch - 1) + s, num_bags=num_bags, batch_idx=s)
+            losses.append(loss.detach())
+            preds.append(bag_prediction)
+            seen.append(i)
+        total = torch.stack(losses).sum().item()                                # ONE device->host read per epoch
+        preds = torch.stack([p.reshape(-1) for p in preds]).cpu().numpy()
+        return {'epoch_train_loss': total / max(1, len(losses)), 'predictions': preds,
+                'labels': np.array([labels[i] for i in seen])}
+
+    @torch.no_grad()
+    def valid(self, data):
+        """Per-bag evaluation loop (reference train.py:295-360): returns mean loss, predictions, labels (+ AUC)."""
+        self.milnet.eval()
+        labels, feats = data[0], data[1]
+        losses, preds = [], []
+        for i in range(len(labels)):
+            f = feats[i]
+            if not torch.is_tensor(f) and self.args.l2normed_embeddings == 1:
+                f = f / np.linalg.norm(f, axis=1, keepdims=True)
+            bag_feats = self._bag_to_device(f)
+            bag_label = torch.as_tensor(np.asarray(labels[i], dtype=np.float32).reshape(1, -1), device=device)
+            bag_prediction, loss, _ = self._run_model(bag_feats, bag_label)
+            losses.append(loss)
+            preds.append(bag_prediction.reshape(-1))
+        preds = torch.stack(preds).cpu().numpy()
+        lab = np.array(labels).reshape(len(labels), -1)
+        res = {'epoch_valid_loss': torch.stack(losses).mean().item(), 'predictions': preds, 'labels': lab}
+        try:
+            from sklearn.metrics import roc_auc_score
+            if len(np.unique(lab[:, 0])) > 1:
+                res['epoch_valid_aucs'] = [float(roc_auc_score(lab[:, c], preds[:, c])) for c in range(lab.shape[1])]
+        except Exception:
+            pass
+        return res
+
+
+class SmallWeightTrainer(Trainer):
+    """Bag loss and max-instance loss mixed by one scalar w (reference train.py:797-858)."""
+
+    def __init__(self, args, dist=None, rank=0, world_size=1):
+        self.args = args
+        self.single_weight_parameter = self._get_single_weight_parameter()
+        super().__init__(args, dist, rank, world_size)
+
+    def _get_single_weight_parameter(self):
+        w = torch.tensor(0.5, requires_grad=bool(self.args.soft_average), device=device)
+        w.data.clamp_(0, 1)
+        return w
+
+    def _trainable(self):
+        extra = [self.single_weight_parameter] if self.single_weight_parameter.requires_grad else []
+        return extra + list(self.milnet.parameters())
+
+    def _get_optimizer(self) -> optim.Optimizer:
+        try:
+            cls = OPTIMIZERS[self.args.optimizer]
+        except KeyError:
+            raise Exception(f'Optimizer not found. Given: {self.args.optimizer}, Have: {OPTIMIZERS.keys()}')
+        return cls(params=[{'params': self.single_weight_parameter,
+                            'lr': self.args.lr * self.args.single_weight__lr_multiplier},
+                           {'params': self.milnet.parameters()}],
+                   lr=self.args.lr, betas=(self.args.betas[0], self.args.betas[1]), weight_decay=self.args.weight_decay)
+
+    def _run_model(self, bag_feats, bag_label):
+        ins_prediction, bag_prediction, _ = self.milnet(bag_feats)
+        max_prediction, _ = torch.max(ins_prediction, 0 if ins_prediction.dim() == 2 else 1)
+        bag_loss = self.criterion(bag_prediction.view(1, -1), bag_label.view(1, -1))
+        max_loss = self.criterion(max_prediction.view(1, -1), bag_label.view(1, -1))
+        w = self.single_weight_parameter
+        loss = w * bag_loss + (1 - w) * max_loss
+        with torch.no_grad():                      # stays on the device: the reference's .cpu().numpy() sync is deferred
+            bag_pred = ((1 - w) * torch.sigmoid(max_prediction) + w * torch.sigmoid(bag_prediction)).squeeze()
+        return bag_pred, loss, ins_prediction
+
+    def _after_run_model_in_training_mode(self, step, num_bags, batch_idx):
+        super()._after_run_model_in_training_mode(step, num_bags, batch_idx)
+        self.single_weight_parameter.data.clamp_(0, 1)
+
+    def __str__(self):
+        return f'Single_Weight__sa{self.args.soft_average}'
+
+
+class Snuffy(SmallWeightTrainer):
+    def _get_milnet(self) -> nn.Module:
+        """Same construction + init order as reference train.py:861-911."""
+        a = self.args
+        i_classifier = snuffy.FCLayer(in_size=a.feats_size, out_size=a.num_classes).to(device)
+        c = copy.deepcopy
+        attn = snuffy.MultiHeadedAttention(a.num_heads, a.feats_size).to(device)
+        ff = snuffy.PositionwiseFeedForward(a.feats_size, a.feats_size * a.mlp_multiplier, a.activation,
+                                            a.encoder_dropout).to(device)
+        b_classifier = snuffy.BClassifier(
+            snuffy.Encoder(snuffy.EncoderLayer(a.feats_size, c(attn), c(ff), a.encoder_dropout, a.big_lambda,
+                                               a.random_patch_share), a.depth),
+            a.num_classes, a.feats_size).to(device)
+        milnet = snuffy.MILNet(i_classifier, b_classifier).to(device)
+        registry = {'trunc_normal': nn.init.trunc_normal_, 'kaiming_uniform': nn.init.kaiming_uniform_,
+                    'kaiming_normal': nn.init.kaiming_normal_, 'xavier_uniform': nn.init.xavier_uniform_,
+                    'xavier_normal': nn.init.xavier_normal_, 'orthogonal': nn.init.orthogonal_}
+        names = a.weight_init__weight_init_i__weight_init_b
+        for init_name, module_name in [(names[1], 'i_classifier'), (names[2], 'b_classifier')]:
+            fn = registry.get(init_name)
+            for name, p in milnet.named_parameters():
+                if p.dim() > 1 and name.split(".")[0] == module_name:
+                    fn(p)
+        milnet.configure(precision=getattr(a, 'precision', 'fp32'), return_attention=False)   # A is discarded, train.py:830
+        return milnet
+
+    def _run_model(self, bag_feats, bag_label):
+        bag_prediction, loss, ins_prediction = super()._run_model(bag_feats, bag_label)
+        return bag_prediction, loss, torch.sigmoid(ins_prediction.view(-1, 1))
+
+    def __str__(self):
+        return f'Snuffy_k{self.args.big_lambda}_sa{self.args.soft_average}_depth{self.args.depth}'
+
+
+ARCH_REGISTRY = {'snuffy': Snuffy}
+
+
+class BagParallelStepper:
+    """bench.py's training step: one resident bag per rank, backward, flat-gradient all-reduce, AdamW (train.py defaults)."""
+
+    def __init__(self, milnet, world_size=1, dist=None, device=None, lr=2e-4, betas=(0.5, 0.9), weight_decay=5e-3):
+        self.milnet = milnet.train()
+        self.milnet.configure(precision="fp32", return_attention=False)
+        self.w = torch.tensor(0.5, device=device)
+        self.criterion = nn.BCEWithLogitsLoss()
+        self.optimizer = torch.optim.AdamW(self.milnet.parameters(), lr=lr, betas=betas, weight_decay=weight_decay)
+        self.sync = FlatGradAllReduce(self.milnet.parameters(), dist, world_size)
+
+    def step(self, bag, label):
+        ins, logits, _ = self.milnet(bag)
+        max_pred, _ = torch.max(ins, 1)
+        loss = self.w * self.criterion(logits.view(1, -1), label.view(1, -1)) + \
+            (1 - self.w) * self.criterion(max_pred.view(1, -1), label.view(1, -1))
+        loss.backward()
+        self.sync()
+        self.optimizer.step()
+        self.optimizer.zero_grad(set_to_none=False)
+        return loss.detach()

@@ -1,0 +1,102 @@
+"""Training path on the GPU: gradients / AdamW step against the golden vectors (F3 / F4), trainer classes end to end."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import build_amd_milnet, golden_files, load_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("path", golden_files("f3_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_f3_f4_gradients_and_adamw_step(path):
+    z, sd = load_case(path)
+    N, D, h, lam, depth, seed = [int(v) for v in z["cfg"]]
+    net = build_amd_milnet(D, h, str(z["act"]), lam, float(z["r"]), depth)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()                       # eval: dropouts off (the fixture was captured that way), grads on
+    net.configure(precision="fp32", return_attention=False)
+    x = torch.from_numpy(z["x"]).to(DEV)
+    y = torch.from_numpy(z["y"]).to(DEV)
+    w = torch.tensor(0.5, requires_grad=True, device=DEV)
+    crit = torch.nn.BCEWithLogitsLoss()
+    np.random.seed(seed)
+    ins, logits, A = net(x)
+    assert A is None
+    max_pred, _ = torch.max(ins, 1)
+    loss = w * crit(logits.view(1, -1), y.view(1, -1)) + (1 - w) * crit(max_pred.view(1, -1), y.view(1, -1))
+    bag_pred = ((1 - w) * torch.sigmoid(max_pred) + w * torch.sigmoid(logits)).squeeze()
+    np.testing.assert_allclose(loss.item(), float(z["loss"]), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(bag_pred.item(), float(z["bag_pred"]), rtol=0, atol=1e-5)
+    loss.backward()
+    np.testing.assert_allclose(w.grad.item(), float(z["w_grad"]), rtol=0, atol=1e-5)
+    for k, p in net.named_parameters():
+        g = z["grad." + k]
+        scale = max(1e-6, float(np.abs(g).max()))
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g, rtol=0, atol=3e-4 * scale + 1e-8, err_msg=k)
+    opt = torch.optim.AdamW([{"params": w, "lr": 2e-4 * 0.1}, {"params": net.parameters()}], lr=2e-4, betas=(0.5, 0.9),
+                            weight_decay=5e-3)
+    opt.step()
+    for k, p in net.named_parameters():
+        atol = 4.2e-4 if k.endswith("self_attn.linears.1.bias") else 2e-6   # zero-gradient key bias: Adam amplifies noise
+        np.testing.assert_allclose(p.detach().cpu().numpy(), z["post." + k], rtol=0, atol=atol, err_msg=k)
+
+
+def tiny_args(**kw):
+    from snuffy_amd.train import get_args_parser
+    a = get_args_parser().parse_args([])
+    a.feats_size, a.num_heads, a.big_lambda, a.optimizer, a.num_epochs = 64, 2, 16, 'adamw', 2
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def toy_data(n_bags=8, d=64, seed=0):
+    g = np.random.RandomState(seed)
+    labels, feats = [], []
+    for i in range(n_bags):
+        y = float(i % 2)
+        f = g.randn(int(g.randint(30, 90)), d).astype(np.float32)
+        if y:
+            f[:5] += 2.0                               # a few "tumour" patches
+        labels.append(np.array([y], dtype=np.float32))
+        feats.append(f)
+    return labels, feats, None, None
+
+
+def test_snuffy_trainer_epoch_runs_and_learns():
+    from snuffy_amd.train import Snuffy
+    from snuffy_amd.utils import stage_bags
+    torch.manual_seed(0)
+    np.random.seed(0)
+    tr = Snuffy(tiny_args(lr=2e-3))
+    assert str(tr) == 'Snuffy_k16_sa0_depth1'
+    data = toy_data()
+    first = tr.train(data, 1)['epoch_train_loss']
+    for e in range(2, 9):
+        last = tr.train(data, e)['epoch_train_loss']
+    assert np.isfinite(first) and last < first
+    res = tr.valid(data)
+    assert res['predictions'].shape == (8, 1) and np.isfinite(res['epoch_valid_loss'])
+    assert 0.0 <= float(tr.single_weight_parameter) <= 1.0
+    # resident bags give the same forward as host bags
+    staged = stage_bags(data[1], DEV)
+    res2 = tr.valid((data[0], staged, None, None))
+    np.testing.assert_allclose(res2['predictions'], res['predictions'], atol=1e-6)
+
+
+def test_training_mode_attention_dropout_is_active_like_the_reference():
+    """train.py never overrides MultiHeadedAttention's dropout (p = 0.1): train-mode forwards differ run to run."""
+    net = build_amd_milnet(64, 2, "relu", 16, 0.0, 1).to(DEV).train().configure(return_attention=False)
+    x = torch.randn(1, 200, 64, device=DEV)
+    torch.manual_seed(1)
+    a = net(x)[1].item()
+    torch.manual_seed(2)
+    b = net(x)[1].item()
+    assert a != b
+    net.eval()
+    with torch.no_grad():
+        assert net(x)[1].item() == net(x)[1].item()
