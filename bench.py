@@ -174,7 +174,7 @@ def main():
 
     if args.mode == "train":
         from snuffy_amd.train import BagParallelStepper
-        stepper = BagParallelStepper(net, world_size=world, dist=dist, device=device)
+        stepper = BagParallelStepper(net, world_size=world, dist=dist, device=device, precision=args.precision)
 
         def step(i):
             stepper.step(bags[i % nbags], labels[i % nbags])

@@ -29,12 +29,14 @@ class LayerNormRowsFn(torch.autograd.Function):
     """y = LayerNorm(x) * gamma + beta (forward: snf_layernorm_rows_f32, statistics saved for backward)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, gamma, beta, eps):
         y, mean, rstd = ops.layernorm_rows(x, gamma, beta, eps, want_stats=True)
         ctx.save_for_backward(x, gamma, mean, rstd)
         return y
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
         xhat = (x - mean.unsqueeze(1)) * rstd.unsqueeze(1)
@@ -53,6 +55,7 @@ class ScatterRowsFn(torch.autograd.Function):
     """y = x.clone(); y[sel] = rows  (snuffy.py:154-155; forward: snf_scatter_rows_f32)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, sel, rows):
         ctx.save_for_backward(sel)
         return ops.scatter_rows(x, sel, rows)
@@ -75,6 +78,7 @@ class SparseAttnFn(torch.autograd.Function):
     """
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, q, kp, v, h, dropout_p):
         n, d = q.shape
         k = kp.shape[0]
@@ -90,6 +94,7 @@ class SparseAttnFn(torch.autograd.Function):
         return out, p
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dout, _dp_unused):
         q, kp, v, p, mask = ctx.saved_tensors
         h = ctx.h
@@ -121,8 +126,14 @@ def critic_train(feats2, w, b):
 def encoder_layer_train(x2, sel, layer, need_attn, precision):
     """Differentiable EncoderLayer.forward (snuffy.py:126-157).  Returns (functional.Parts, A)."""
     from .functional import Parts
-    if precision != "fp32":
-        raise NotImplementedError("training runs the fp32 path in this round (bf16 training is on the list)")
+    # precision "bf16": the dense projections run under torch.autocast (bf16 operands, fp32 accumulate, fp32 master
+    # weights); LayerNorm, softmax / attention and the residual stream stay fp32.
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(precision == "bf16")):
+        return _encoder_layer_train(x2, sel, layer, need_attn)
+
+
+def _encoder_layer_train(x2, sel, layer, need_attn):
+    from .functional import Parts
     mha, ff = layer.self_attn, layer.feed_forward
     n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
     drop0, drop1 = layer.sublayer[0].dropout, layer.sublayer[1].dropout
@@ -142,7 +153,7 @@ def encoder_layer_train(x2, sel, layer, need_attn, precision):
         delta = F.linear(o, lo.weight, lo.bias)                                 # snuffy.py:205
         if training and drop0.p > 0:
             delta = F.dropout(delta, drop0.p, True)
-        x_sel = xs + delta                                                      # snuffy.py:108
+        x_sel = xs + delta.float()                                              # snuffy.py:108
         y = ScatterRowsFn.apply(x2, sel, x_sel)                                 # snuffy.py:154-155
         attn = p.detach().unsqueeze(0) if need_attn else None
     yn = LayerNormRowsFn.apply(y, n1.weight, n1.bias, n1.eps)
@@ -152,7 +163,7 @@ def encoder_layer_train(x2, sel, layer, need_attn, precision):
     f = F.linear(hid, ff.w_2.weight, ff.w_2.bias)
     if training and drop1.p > 0:
         f = F.dropout(f, drop1.p, True)
-    z = y + f                                                                   # snuffy.py:110
+    z = y + f.float()                                                           # snuffy.py:110
     return Parts(z), attn
 
 

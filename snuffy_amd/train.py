@@ -319,9 +319,10 @@ ARCH_REGISTRY = {'snuffy': Snuffy}
 class BagParallelStepper:
     """bench.py's training step: one resident bag per rank, backward, flat-gradient all-reduce, AdamW (train.py defaults)."""
 
-    def __init__(self, milnet, world_size=1, dist=None, device=None, lr=2e-4, betas=(0.5, 0.9), weight_decay=5e-3):
+    def __init__(self, milnet, world_size=1, dist=None, device=None, lr=2e-4, betas=(0.5, 0.9), weight_decay=5e-3,
+                 precision="fp32"):
         self.milnet = milnet.train()
-        self.milnet.configure(precision="fp32", return_attention=False)
+        self.milnet.configure(precision=precision, return_attention=False)
         self.w = torch.tensor(0.5, device=device)
         self.criterion = nn.BCEWithLogitsLoss()
         self.optimizer = torch.optim.AdamW(self.milnet.parameters(), lr=lr, betas=betas, weight_decay=weight_decay)

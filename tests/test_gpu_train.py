@@ -41,8 +41,15 @@ def test_f3_f4_gradients_and_adamw_step(path):
                             weight_decay=5e-3)
     opt.step()
     for k, p in net.named_parameters():
-        atol = 4.2e-4 if k.endswith("self_attn.linears.1.bias") else 2e-6   # zero-gradient key bias: Adam amplifies noise
-        np.testing.assert_allclose(p.detach().cpu().numpy(), z["post." + k], rtol=0, atol=atol, err_msg=k)
+        # Adam normalises each element's step to ~lr: where the gradient is rounding noise (|g| << max|g|, and the whole
+        # key bias, whose true gradient is zero) the step direction is noise too -> allow 2*lr there, 6e-6 elsewhere.
+        g = np.abs(z["grad." + k])
+        noisy = g < 1e-4 * max(1e-12, g.max())
+        if k.endswith("self_attn.linears.1.bias"):
+            noisy = np.ones_like(noisy)
+        diff = np.abs(p.detach().cpu().numpy() - z["post." + k])
+        assert diff[~noisy].max(initial=0.0) < 6e-6, k
+        assert diff[noisy].max(initial=0.0) < 4.2e-4, k
 
 
 def tiny_args(**kw):
@@ -100,3 +107,24 @@ def test_training_mode_attention_dropout_is_active_like_the_reference():
     net.eval()
     with torch.no_grad():
         assert net(x)[1].item() == net(x)[1].item()
+
+
+def test_bf16_autocast_training_tracks_fp32():
+    """precision='bf16' in training = library GEMMs under autocast; gradients stay close to the fp32 path."""
+    z, sd = load_case(golden_files("f3_g_n600")[0])
+    N, D, h, lam, depth, seed = [int(v) for v in z["cfg"]]
+    grads = {}
+    for precision in ("fp32", "bf16"):
+        net = build_amd_milnet(D, h, str(z["act"]), lam, float(z["r"]), depth)
+        net.load_state_dict(sd, strict=True)
+        net = net.to(DEV).eval().configure(precision=precision, return_attention=False)
+        x = torch.from_numpy(z["x"]).to(DEV)
+        ins, logits, _ = net(x)
+        (logits.sum() + ins.max()).backward()
+        grads[precision] = {k: p.grad.float().clone() for k, p in net.named_parameters()}
+    for k in grads["fp32"]:
+        if k.endswith("self_attn.linears.1.bias"):
+            continue                                   # mathematically zero gradient: pure rounding noise in both paths
+        a, b = grads["bf16"][k].double(), grads["fp32"][k].double()
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-12))
+        assert rel < 0.1, (k, rel)
