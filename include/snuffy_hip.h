@@ -143,6 +143,35 @@ int snf_sparse_attn_fwd_mfma(const void* q, const void* vt, int qv_dtype, int64_
                              int k, int h, int dk, float scale, float* out, float* attn, float* lse,
                              void* workspace, size_t workspace_bytes, snf_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * K12-K14  ViT patch-embedding extractor (compute_feats.py:239-247 -> IClassifier -> VisionTransformer.forward)
+ *   reference model files: utils_ssls_cf/vision_transformer_with_adapter_dino_version.py (vd), vision_transformer_dino.py,
+ *   adapter.py, models_adapter_mae.py.  Dense projections stay library GEMMs; these entry points are the rest.
+ *
+ *   snf_vit_patchify         im2col of PatchEmbed's Conv2d(3, D, p, p)                vd:141-146
+ *       img [b, c, hgt, wid] f32 -> cols [b * (hgt/p) * (wid/p), c*p*p] (f32 or bf16), column order (c, i, j) = the
+ *       flattening of the conv weight [D, c, p, p].
+ *   snf_vit_assemble_tokens  tokens[b,0] = cls + pos[0]; tokens[b,1+i] = patch_emb[b*P+i] + pos[1+i]   vd:218-229
+ *       (identical arithmetic for the MAE encoder, models_adapter_mae.py:176-186).  tokens [b, P+1, d] f32.
+ *   snf_vit_residual_ln      x += add1 + scale2 * add2 (bf16 addends, nullable); ln_out = LayerNorm(x) (bf16, nullable);
+ *       x_bf16 = x (nullable): the two residual adds of Block.forward fused with the following norm      vd:120-127
+ *   snf_vit_attention_f32    exact multi-head self-attention  softmax(q k^T * scale) v                  vd:82-94
+ *       qkv [b*t, 3*h*dk] f32 laid out as the reference's qkv Linear output (q | k | v, each [h][dk]);
+ *       out [b*t, h*dk]; attn [b, h, t, t] nullable.  dk in {32, 64, 96, 128}.
+ *   snf_vit_attention_mfma   same on the matrix cores, bf16 in / bf16 out, dk == 64, t <= 256 (else SNF_EUNSUPPORTED).
+ * --------------------------------------------------------------------------------------------------------- */
+int snf_vit_patchify(const float* img, int b, int c, int hgt, int wid, int patch, void* cols, int out_dtype,
+                     snf_stream_t stream);
+int snf_vit_assemble_tokens(const void* patch_emb, int pe_dtype, const float* cls_token, const float* pos_embed, int b,
+                            int num_patches, int d, float* tokens, snf_stream_t stream);
+int snf_vit_residual_ln(float* x, int64_t n, int d, const void* add1_bf16, const void* add2_bf16, float scale2,
+                        const float* gamma, const float* beta, float eps, void* ln_out_bf16, void* x_bf16,
+                        snf_stream_t stream);
+int snf_vit_attention_f32(const float* qkv, int b, int t, int h, int dk, float scale, float* out, float* attn,
+                          snf_stream_t stream);
+int snf_vit_attention_mfma(const void* qkv_bf16, int b, int t, int h, int dk, float scale, void* out_bf16,
+                           snf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,486 @@
+// ViT patch-embedding extractor kernels (compute_feats.py path; DINO / MAE ViT with adapters).
+//
+//   snf_vit_patchify        16x16 (or any) patch unfold of the image batch into the im2col matrix of PatchEmbed's conv
+//   snf_vit_assemble_tokens [cls ; patch embeddings] + pos_embed  -> fp32 token matrix
+//   snf_vit_residual_ln     x += a1 + s2*a2 ; LayerNorm(x) -> bf16 ; optional bf16 copy of x   (Block residuals + next norm)
+//   snf_vit_attention_f32   exact fp32 multi-head self-attention, any T / dk <= 128 (parity path, returns attn on request)
+//   snf_vit_attention_mfma  bf16 MFMA self-attention for dk = 64, T <= 256 (ViT-S/B at 224/16: T = 197):
+//                           S^T = K Q^T  (v_mfma_f32_32x32x16_bf16, A = K fragment from LDS, B = Q fragment from HBM):
+//                           queries land on lanes, keys in registers -> the row softmax is lane-local (+1 cross-half step),
+//                           and P^T in C layout is directly the B operand of  O^T = V^T P^T  (A = V^T fragment from an LDS
+//                           image transposed while staging).  One workgroup per (image, head); K and V^T stay in LDS.
+#include <math.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// patchify: cols[(b*gh + gy)*gw + gx][(c*ps + i)*ps + j] = img[b][c][gy*ps + i][gx*ps + j]
+// one thread per (patch row-segment): ps consecutive pixels of one image row
+// ---------------------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int B, int C, int H, int W, int ps,
+                                                       void* __restrict__ cols) {
+    const int gh = H / ps, gw = W / ps;
+    const int64_t total = (int64_t)B * C * gh * ps * gw;  // number of ps-long segments
+    const int kdim = C * ps * ps;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (int64_t)gridDim.x * blockDim.x) {
+        // decompose with gx fastest: neighbouring threads read neighbouring segments of one image row (coalesced)
+        int gx = (int)(s % gw);
+        int64_t t = s / gw;
+        int i = (int)(t % ps);
+        t /= ps;
+        int gy = (int)(t % gh);
+        t /= gh;
+        int c = (int)(t % C);
+        int b = (int)(t / C);
+        const float* src = img + (((int64_t)b * C + c) * H + (gy * ps + i)) * W + gx * ps;
+        const int64_t row = ((int64_t)b * gh + gy) * gw + gx;
+        const int64_t off = row * kdim + (c * ps + i) * ps;
+        if (BF16) {
+            unsigned short* dst = reinterpret_cast<unsigned short*>(cols) + off;
+            for (int j = 0; j < ps; ++j) dst[j] = f32_to_bf16_bits(src[j]);
+        } else {
+            float* dst = reinterpret_cast<float*>(cols) + off;
+            for (int j = 0; j < ps; ++j) dst[j] = src[j];
+        }
+    }
+}
+
+// tokens[b][0] = cls + pos[0]; tokens[b][1+p] = pe[b*P + p] + pos[1+p]
+template <bool BF16>
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const void* __restrict__ pe, const float* __restrict__ cls,
+                                                              const float* __restrict__ pos, int B, int P, int D,
+                                                              float* __restrict__ tokens) {
+    const int T = P + 1;
+    const int64_t total = (int64_t)B * T * D;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int d = (int)(e % D);
+        int64_t r = e / D;
+        int t = (int)(r % T);
+        int b = (int)(r / T);
+        float v;
+        if (t == 0) {
+            v = cls[d];
+        } else {
+            int64_t src = ((int64_t)b * P + (t - 1)) * D + d;
+            v = BF16 ? bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(pe)[src]) : reinterpret_cast<const float*>(pe)[src];
+        }
+        tokens[e] = v + pos[(int64_t)t * D + d];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// x += a1 + s2 * a2 (bf16 addends, nullable); ln_out = LN(x) (bf16, nullable); x_bf16 = x (nullable).  Wave per row.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NV>  // row width d <= 256 * NV, d % 4 == 0
+__global__ __launch_bounds__(256) void residual_ln_kernel(float* __restrict__ x, int64_t n, int d,
+                                                          const unsigned short* __restrict__ a1,
+                                                          const unsigned short* __restrict__ a2, float s2,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, unsigned short* __restrict__ ln_out,
+                                                          unsigned short* __restrict__ x_bf16) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_d = 1.0f / (float)d;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n; row += (int64_t)gridDim.x * 4) {
+        float r[NV * 4];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = (i * 64 + lane) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < d) {
+                v = *reinterpret_cast<const f32x4*>(x + row * d + e);
+                if (a1) {
+                    u32x2 p = *reinterpret_cast<const u32x2*>(a1 + row * d + e);
+                    v[0] += __uint_as_float(p[0] << 16);
+                    v[1] += __uint_as_float(p[0] & 0xffff0000u);
+                    v[2] += __uint_as_float(p[1] << 16);
+                    v[3] += __uint_as_float(p[1] & 0xffff0000u);
+                }
+                if (a2) {
+                    u32x2 p = *reinterpret_cast<const u32x2*>(a2 + row * d + e);
+                    v[0] = fmaf(s2, __uint_as_float(p[0] << 16), v[0]);
+                    v[1] = fmaf(s2, __uint_as_float(p[0] & 0xffff0000u), v[1]);
+                    v[2] = fmaf(s2, __uint_as_float(p[1] << 16), v[2]);
+                    v[3] = fmaf(s2, __uint_as_float(p[1] & 0xffff0000u), v[3]);
+                }
+                if (a1 || a2) *reinterpret_cast<f32x4*>(x + row * d + e) = v;
+                if (x_bf16) {
+                    u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(x_bf16 + row * d + e) = o;
+                }
+            }
+            r[i * 4 + 0] = v[0];
+            r[i * 4 + 1] = v[1];
+            r[i * 4 + 2] = v[2];
+            r[i * 4 + 3] = v[3];
+        }
+        if (!ln_out) continue;
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV * 4; ++i) s1 += r[i];
+        const float mean = wave_sum(s1) * inv_d;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int e = (i * 64 + lane) * 4 + t;
+                const float dv = e < d ? r[i * 4 + t] - mean : 0.f;
+                sq = fmaf(dv, dv, sq);
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = (i * 64 + lane) * 4;
+            if (e < d) {
+                f32x4 g = *reinterpret_cast<const f32x4*>(gamma + e);
+                f32x4 bb = *reinterpret_cast<const f32x4*>(beta + e);
+                float o0 = (r[i * 4 + 0] - mean) * rstd * g[0] + bb[0];
+                float o1 = (r[i * 4 + 1] - mean) * rstd * g[1] + bb[1];
+                float o2 = (r[i * 4 + 2] - mean) * rstd * g[2] + bb[2];
+                float o3 = (r[i * 4 + 3] - mean) * rstd * g[3] + bb[3];
+                u32x2 o = {pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
+                *reinterpret_cast<u32x2*>(ln_out + row * d + e) = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// exact fp32 self-attention: qkv [B*T, 3*h*dk] (q | k | v, each [h][dk]); out [B*T, h*dk]; attn [B, h, T, T] nullable.
+// workgroup = (head, image); a thread owns one query row; keys / values stream through LDS in chunks of 64.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DK>
+__global__ __launch_bounds__(256) void vit_attention_f32_kernel(const float* __restrict__ qkv, int B, int T, int h, float scale,
+                                                                float* __restrict__ out, float* __restrict__ attn) {
+    constexpr int KC = 64;
+    __shared__ float lk[KC][DK + 1];
+    __shared__ float lv[KC][DK + 1];
+    const int a = blockIdx.x, b = blockIdx.y;
+    const int D = h * DK;
+    const int64_t base = (int64_t)b * T;
+    for (int q0 = 0; q0 < T; q0 += 256) {
+        const int qi = q0 + threadIdx.x;
+        const bool qv = qi < T;
+        float q[DK];
+#pragma unroll
+        for (int e = 0; e < DK; ++e) q[e] = qv ? qkv[(base + qi) * 3 * D + a * DK + e] * scale : 0.f;
+        // pass 1: row max and sum (online)
+        float m = -INFINITY, l = 0.f;
+        for (int k0 = 0; k0 < T; k0 += KC) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < KC * DK; e += 256) {
+                int kk = e / DK, dd = e - kk * DK;
+                lk[kk][dd] = (k0 + kk < T) ? qkv[(base + k0 + kk) * 3 * D + D + a * DK + dd] : 0.f;
+            }
+            __syncthreads();
+            const int kn = (T - k0) < KC ? (T - k0) : KC;
+            for (int kk = 0; kk < kn; ++kk) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < DK; ++e) s = fmaf(q[e], lk[kk][e], s);
+                if (s > m) {
+                    l = l * expf(m - s);
+                    m = s;
+                }
+                l += expf(s - m);
+            }
+        }
+        // pass 2: probabilities and P V
+        float o[DK];
+#pragma unroll
+        for (int e = 0; e < DK; ++e) o[e] = 0.f;
+        const float inv_l = 1.0f / l;
+        for (int k0 = 0; k0 < T; k0 += KC) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < KC * DK; e += 256) {
+                int kk = e / DK, dd = e - kk * DK;
+                const bool ok = k0 + kk < T;
+                lk[kk][dd] = ok ? qkv[(base + k0 + kk) * 3 * D + D + a * DK + dd] : 0.f;
+                lv[kk][dd] = ok ? qkv[(base + k0 + kk) * 3 * D + 2 * D + a * DK + dd] : 0.f;
+            }
+            __syncthreads();
+            const int kn = (T - k0) < KC ? (T - k0) : KC;
+            for (int kk = 0; kk < kn; ++kk) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < DK; ++e) s = fmaf(q[e], lk[kk][e], s);
+                const float p = expf(s - m) * inv_l;
+                if (attn && qv) attn[(((int64_t)b * h + a) * T + qi) * T + k0 + kk] = p;
+#pragma unroll
+                for (int e = 0; e < DK; ++e) o[e] = fmaf(p, lv[kk][e], o[e]);
+            }
+        }
+        if (qv) {
+#pragma unroll
+            for (int e = 0; e < DK; ++e) out[(base + qi) * D + a * DK + e] = o[e];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 MFMA self-attention, dk = 64, T <= 32 * NKB.  qkv bf16 [B*T, 3*h*64]; out bf16 [B*T, h*64].
+// ---------------------------------------------------------------------------------------------------------------
+template <int NKB>
+__global__ __launch_bounds__(256, 2) void vit_attention_mfma_kernel(const unsigned short* __restrict__ qkv, int B, int T, int h,
+                                                                    float scale, unsigned short* __restrict__ out) {
+    constexpr int DK = 64;
+    constexpr int KPITCH = DK + 8;            // bf16 elements; 144 B rows: conflict-free ds_read_b128 of a K fragment
+    constexpr int VPITCH = 32 * NKB + 12;     // bf16 elements; pitch/2 dwords == 2 (mod 4): conflict-free ds_read_b64
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short* lds_k = reinterpret_cast<unsigned short*>(smem);                       // [32*NKB][KPITCH]
+    unsigned short* lds_vt = lds_k + 32 * NKB * KPITCH;                                     // [DK][VPITCH]
+    const int a = blockIdx.x, b = blockIdx.y;
+    const int D = h * DK;
+    const int64_t base = (int64_t)b * T;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, hf = lane >> 5;
+
+    // stage K (row-major) and V^T (transposed) of this (image, head); rows >= T are zero
+    for (int c = threadIdx.x; c < 32 * NKB * (DK / 8); c += 256) {
+        const int key = c >> 3, part = c & 7;
+        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+        if (key < T) {
+            const unsigned short* rowp = qkv + (base + key) * 3 * D + a * DK + part * 8;
+            kv = *reinterpret_cast<const u32x4*>(rowp + D);
+            vv = *reinterpret_cast<const u32x4*>(rowp + 2 * D);
+        }
+        *reinterpret_cast<u32x4*>(lds_k + key * KPITCH + part * 8) = kv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lds_vt[(part * 8 + 2 * e) * VPITCH + key] = (unsigned short)(vv[e] & 0xffffu);
+            lds_vt[(part * 8 + 2 * e + 1) * VPITCH + key] = (unsigned short)(vv[e] >> 16);
+        }
+    }
+    __syncthreads();
+
+    const float c_exp = scale * 1.44269504088896340736f;
+    const int ntile = (T + 31) / 32;
+    for (int tile = w; tile < ntile; tile += 4) {
+        // Q fragments (B operand: lane = query, 8 consecutive dk per k-step)
+        int qrow = 32 * tile + j;
+        if (qrow > T - 1) qrow = T - 1;
+        const unsigned short* qp = qkv + (base + qrow) * 3 * D + a * DK + 8 * hf;
+        bf16x8 qf[4];
+        static_for<0, 4>([&](auto ks) __attribute__((always_inline)) {
+            qf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp + 16 * ks));
+        });
+        // GEMM1: S^T[key, q] = K Q^T ; keys beyond T start at -inf
+        f32x16 s_acc[NKB];
+        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
+            constexpr int jb = decltype(jb_t)::value;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                s_acc[jb][r] = (key >= T) ? -INFINITY : 0.f;
+            }
+            static_for<0, 4>([&](auto ks) __attribute__((always_inline)) {
+                bf16x8 kf = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const u32x4*>(lds_k + (32 * jb + j) * KPITCH + 16 * ks + 8 * hf));
+                s_acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc[jb], 0, 0, 0);
+            });
+        });
+        // softmax over keys: registers of this lane + the partner half-wave
+        float m = -INFINITY;
+        static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, s_acc[jb][r]);
+        });
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float mc = m * c_exp;
+        float l = 0.f;
+        static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r], c_exp, -mc));
+                s_acc[jb][r] = e;
+                l += e;
+            }
+        });
+        l += __shfl_xor(l, 32, 64);
+        const float inv = __builtin_amdgcn_rcpf(l);
+        // GEMM2: O^T[d, q] = V^T P^T ; B operand = P^T fragments straight from the C registers
+        f32x16 o_acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o_acc[0][r] = 0.f;
+            o_acc[1][r] = 0.f;
+        }
+        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
+            constexpr int jb = decltype(jb_t)::value;
+            static_for<0, 2>([&](auto u_t) __attribute__((always_inline)) {
+                constexpr int u = decltype(u_t)::value;
+                f32x8 pv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pv[e] = s_acc[jb][8 * u + e] * inv;
+                const bf16x8 pf = __builtin_convertvector(pv, bf16x8);
+                // this lane's 8 keys of the k-step: {16u + 4hf + 0..3} and {16u + 8 + 4hf + 0..3} of block jb
+                const int k0 = 32 * jb + 16 * u + 4 * hf;
+                static_for<0, 2>([&](auto db) __attribute__((always_inline)) {
+                    const unsigned short* vp = lds_vt + (32 * db + j) * VPITCH + k0;
+                    u32x2 lo = *reinterpret_cast<const u32x2*>(vp);
+                    u32x2 hi = *reinterpret_cast<const u32x2*>(vp + 8);
+                    u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
+                    o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, o_acc[db], 0, 0, 0);
+                });
+            });
+        });
+        // store O: lane = query row, 4 consecutive d per register group
+        const int q_out = 32 * tile + j;
+        if (q_out < T) {
+            unsigned short* op = out + (base + q_out) * D + a * DK;
+            static_for<0, 2>([&](auto db) __attribute__((always_inline)) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = 32 * db + 8 * g + 4 * hf;
+                    u32x2 o = {pack_bf16x2(o_acc[db][4 * g], o_acc[db][4 * g + 1]),
+                               pack_bf16x2(o_acc[db][4 * g + 2], o_acc[db][4 * g + 3])};
+                    *reinterpret_cast<u32x2*>(op + d0) = o;
+                }
+            });
+        }
+    }
+}
+
+template <int NKB>
+int launch_vit_mfma(const unsigned short* qkv, int B, int T, int h, float scale, unsigned short* out, hipStream_t s) {
+    const size_t lds = (size_t)(32 * NKB * (64 + 8) + 64 * (32 * NKB + 12)) * sizeof(unsigned short);
+    static thread_local bool attr_set = false;
+    auto kern = vit_attention_mfma_kernel<NKB>;
+    if (!attr_set && lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            snf::set_error("vit_attention_mfma: cannot reserve %zu bytes of LDS", lds);
+            (void)hipGetLastError();
+            return SNF_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(h, B), dim3(256), lds, s, qkv, B, T, h, scale, out);
+    return snf::check_launch("vit_attention_mfma_kernel");
+}
+
+inline int grid_for(int64_t work_items, int per_block) {
+    int64_t want = (work_items + per_block - 1) / per_block;
+    int64_t cap = (int64_t)snf::cu_count() * 8;
+    return (int)(want < 1 ? 1 : (want < cap ? want : cap));
+}
+
+}  // namespace
+
+extern "C" {
+
+int snf_vit_patchify(const float* img, int b, int c, int hgt, int wid, int patch, void* cols, int out_dtype,
+                     snf_stream_t stream) {
+    SNF_REQUIRE(img && cols, "snf_vit_patchify: null pointer");
+    SNF_REQUIRE(b >= 1 && c >= 1 && patch >= 1 && hgt >= patch && wid >= patch, "snf_vit_patchify: bad shape");
+    SNF_REQUIRE(hgt % patch == 0 && wid % patch == 0, "snf_vit_patchify: image %dx%d not a multiple of patch %d", hgt, wid, patch);
+    SNF_REQUIRE(out_dtype == SNF_DT_F32 || out_dtype == SNF_DT_BF16, "snf_vit_patchify: bad dtype");
+    const int64_t segs = (int64_t)b * c * hgt * (wid / patch);
+    hipStream_t s = snf::as_stream(stream);
+    if (out_dtype == SNF_DT_BF16)
+        hipLaunchKernelGGL(patchify_kernel<true>, dim3(grid_for(segs, 256)), dim3(256), 0, s, img, b, c, hgt, wid, patch, cols);
+    else
+        hipLaunchKernelGGL(patchify_kernel<false>, dim3(grid_for(segs, 256)), dim3(256), 0, s, img, b, c, hgt, wid, patch, cols);
+    return snf::check_launch("patchify_kernel");
+}
+
+int snf_vit_assemble_tokens(const void* patch_emb, int pe_dtype, const float* cls_token, const float* pos_embed, int b,
+                            int num_patches, int d, float* tokens, snf_stream_t stream) {
+    SNF_REQUIRE(patch_emb && cls_token && pos_embed && tokens, "snf_vit_assemble_tokens: null pointer");
+    SNF_REQUIRE(b >= 1 && num_patches >= 1 && d >= 1, "snf_vit_assemble_tokens: bad shape");
+    SNF_REQUIRE(pe_dtype == SNF_DT_F32 || pe_dtype == SNF_DT_BF16, "snf_vit_assemble_tokens: bad dtype");
+    const int64_t total = (int64_t)b * (num_patches + 1) * d;
+    hipStream_t s = snf::as_stream(stream);
+    if (pe_dtype == SNF_DT_BF16)
+        hipLaunchKernelGGL(assemble_tokens_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, s, patch_emb, cls_token,
+                           pos_embed, b, num_patches, d, tokens);
+    else
+        hipLaunchKernelGGL(assemble_tokens_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, s, patch_emb, cls_token,
+                           pos_embed, b, num_patches, d, tokens);
+    return snf::check_launch("assemble_tokens_kernel");
+}
+
+int snf_vit_residual_ln(float* x, int64_t n, int d, const void* add1_bf16, const void* add2_bf16, float scale2,
+                        const float* gamma, const float* beta, float eps, void* ln_out_bf16, void* x_bf16,
+                        snf_stream_t stream) {
+    SNF_REQUIRE(x, "snf_vit_residual_ln: null x");
+    SNF_REQUIRE(n >= 1 && d >= 4 && (d % 4) == 0 && d <= 2048, "snf_vit_residual_ln: need d %% 4 == 0 and d <= 2048 (d=%d)", d);
+    SNF_REQUIRE(!ln_out_bf16 || (gamma && beta), "snf_vit_residual_ln: LayerNorm output needs gamma and beta");
+    hipStream_t s = snf::as_stream(stream);
+    const int grid = grid_for(n, 4);
+    const int nv = (d / 4 + 63) / 64;
+    const unsigned short* a1 = reinterpret_cast<const unsigned short*>(add1_bf16);
+    const unsigned short* a2 = reinterpret_cast<const unsigned short*>(add2_bf16);
+    unsigned short* lo = reinterpret_cast<unsigned short*>(ln_out_bf16);
+    unsigned short* xb = reinterpret_cast<unsigned short*>(x_bf16);
+#define LAUNCH_RL(NV) \
+    hipLaunchKernelGGL(residual_ln_kernel<NV>, dim3(grid), dim3(256), 0, s, x, n, d, a1, a2, scale2, gamma, beta, eps, lo, xb)
+    if (nv <= 1) LAUNCH_RL(1);
+    else if (nv <= 2) LAUNCH_RL(2);
+    else if (nv <= 3) LAUNCH_RL(3);
+    else if (nv <= 4) LAUNCH_RL(4);
+    else LAUNCH_RL(8);
+#undef LAUNCH_RL
+    return snf::check_launch("residual_ln_kernel");
+}
+
+int snf_vit_attention_f32(const float* qkv, int b, int t, int h, int dk, float scale, float* out, float* attn,
+                          snf_stream_t stream) {
+    SNF_REQUIRE(qkv && out, "snf_vit_attention_f32: null pointer");
+    SNF_REQUIRE(b >= 1 && t >= 1 && h >= 1, "snf_vit_attention_f32: bad shape");
+    SNF_REQUIRE(b <= 65535, "snf_vit_attention_f32: batch too large for one launch");
+    hipStream_t s = snf::as_stream(stream);
+    dim3 grid(h, b);
+    switch (dk) {
+        case 32: hipLaunchKernelGGL(vit_attention_f32_kernel<32>, grid, dim3(256), 0, s, qkv, b, t, h, scale, out, attn); break;
+        case 64: hipLaunchKernelGGL(vit_attention_f32_kernel<64>, grid, dim3(256), 0, s, qkv, b, t, h, scale, out, attn); break;
+        case 96: hipLaunchKernelGGL(vit_attention_f32_kernel<96>, grid, dim3(256), 0, s, qkv, b, t, h, scale, out, attn); break;
+        case 128: hipLaunchKernelGGL(vit_attention_f32_kernel<128>, grid, dim3(256), 0, s, qkv, b, t, h, scale, out, attn); break;
+        default:
+            snf::set_error("snf_vit_attention_f32: head dim %d not in {32, 64, 96, 128}", dk);
+            return SNF_EUNSUPPORTED;
+    }
+    return snf::check_launch("vit_attention_f32_kernel");
+}
+
+int snf_vit_attention_mfma(const void* qkv_bf16, int b, int t, int h, int dk, float scale, void* out_bf16,
+                           snf_stream_t stream) {
+    SNF_REQUIRE(qkv_bf16 && out_bf16, "snf_vit_attention_mfma: null pointer");
+    SNF_REQUIRE(b >= 1 && t >= 1 && h >= 1, "snf_vit_attention_mfma: bad shape");
+    if (dk != 64 || t > 256 || b > 65535) {
+        snf::set_error("snf_vit_attention_mfma: unsupported shape dk=%d t=%d (need dk == 64, t <= 256)", dk, t);
+        return SNF_EUNSUPPORTED;
+    }
+    SNF_REQUIRE((reinterpret_cast<uintptr_t>(qkv_bf16) & 15) == 0, "snf_vit_attention_mfma: qkv must be 16-byte aligned");
+    hipStream_t s = snf::as_stream(stream);
+    const unsigned short* q = reinterpret_cast<const unsigned short*>(qkv_bf16);
+    unsigned short* o = reinterpret_cast<unsigned short*>(out_bf16);
+    const int nkb = (t + 31) / 32;
+    if (nkb <= 2) return launch_vit_mfma<2>(q, b, t, h, scale, o, s);
+    if (nkb <= 4) return launch_vit_mfma<4>(q, b, t, h, scale, o, s);
+    if (nkb <= 7) return launch_vit_mfma<7>(q, b, t, h, scale, o, s);
+    return launch_vit_mfma<8>(q, b, t, h, scale, o, s);
+}
+
+}  // extern "C"

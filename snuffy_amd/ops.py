@@ -269,3 +269,82 @@ def sparse_attn_fwd_mfma(q, vt, kp, n, h, scale=None, need_attn=False, need_lse=
     check(lib.snf_sparse_attn_fwd_mfma(_p(q), _p(vt), dt, ldv, _p(kp), n, k, h, dk, float(scale), _p(out), _p(attn),
                                        _p(lse), _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_mfma")
     return out, attn, lse
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# ViT extractor ops (K12-K14)
+# ----------------------------------------------------------------------------------------------------------------------
+def vit_patchify(img, patch, out_dtype=torch.float32):
+    """im2col of the patch-embedding conv: img [B, C, H, W] f32 -> [B * P, C * patch * patch]."""
+    img = _req(img, torch.float32, "img", 4)
+    b, c, h, w = img.shape
+    if h % patch or w % patch:
+        raise ValueError("image %dx%d is not a multiple of the patch size %d" % (h, w, patch))
+    cols = torch.empty(b * (h // patch) * (w // patch), c * patch * patch, dtype=out_dtype, device=img.device)
+    dt = DT_F32 if out_dtype == torch.float32 else DT_BF16
+    check(_ffi.load().snf_vit_patchify(_p(img), b, c, h, w, patch, _p(cols), dt, _stream()), "snf_vit_patchify")
+    return cols
+
+
+def vit_assemble_tokens(patch_emb, cls_token, pos_embed, b):
+    """[cls ; patches] + pos -> tokens [B * (P + 1), D] f32.  patch_emb [B * P, D] f32 or bf16."""
+    if patch_emb.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("patch_emb must be float32 or bfloat16")
+    patch_emb = _req(patch_emb, patch_emb.dtype, "patch_emb", 2)
+    d = patch_emb.shape[1]
+    p = patch_emb.shape[0] // b
+    cls_token = _req(cls_token.reshape(-1), torch.float32, "cls_token", 1)
+    pos_embed = _req(pos_embed.reshape(-1, d), torch.float32, "pos_embed", 2)
+    if pos_embed.shape[0] != p + 1:
+        raise ValueError("pos_embed has %d rows, need %d" % (pos_embed.shape[0], p + 1))
+    tokens = torch.empty(b * (p + 1), d, dtype=torch.float32, device=patch_emb.device)
+    dt = DT_F32 if patch_emb.dtype == torch.float32 else DT_BF16
+    check(_ffi.load().snf_vit_assemble_tokens(_p(patch_emb), dt, _p(cls_token), _p(pos_embed), b, p, d, _p(tokens),
+                                              _stream()), "snf_vit_assemble_tokens")
+    return tokens
+
+
+def vit_residual_ln_(x, add1=None, add2=None, scale2=1.0, gamma=None, beta=None, eps=1e-6, want_ln=True, want_x_bf16=False):
+    """x += add1 + scale2 * add2 in place (bf16 addends); returns (LayerNorm(x) bf16 or None, bf16 copy of x or None)."""
+    x = _req(x, torch.float32, "x", 2)
+    n, d = x.shape
+    for nm, t in (("add1", add1), ("add2", add2)):
+        if t is not None:
+            _req(t, torch.bfloat16, nm, 2)
+            if not t.is_contiguous() or t.shape != x.shape:
+                raise ValueError("%s must be a contiguous bf16 tensor of x's shape" % nm)
+    ln = torch.empty(n, d, dtype=torch.bfloat16, device=x.device) if want_ln else None
+    xb = torch.empty(n, d, dtype=torch.bfloat16, device=x.device) if want_x_bf16 else None
+    if want_ln:
+        gamma = _req(gamma, torch.float32, "gamma", 1)
+        beta = _req(beta, torch.float32, "beta", 1)
+    check(_ffi.load().snf_vit_residual_ln(_p(x), n, d, _p(add1), _p(add2), float(scale2), _p(gamma), _p(beta), float(eps),
+                                          _p(ln), _p(xb), _stream()), "snf_vit_residual_ln")
+    return ln, xb
+
+
+def vit_attention(qkv, b, t, heads, scale=None, need_attn=False):
+    """Multi-head self-attention on the qkv Linear output [B*T, 3*D].  fp32 -> exact kernel (+ optional attn [B,h,T,T]);
+    bf16 -> MFMA kernel (dk == 64, T <= 256)."""
+    d3 = qkv.shape[1]
+    d = d3 // 3
+    dk = d // heads
+    scale = dk ** -0.5 if scale is None else scale
+    lib = _ffi.load()
+    if qkv.dtype == torch.float32:
+        qkv = _req(qkv, torch.float32, "qkv", 2)
+        out = torch.empty(b * t, d, dtype=torch.float32, device=qkv.device)
+        attn = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device) if need_attn else None
+        check(lib.snf_vit_attention_f32(_p(qkv), b, t, heads, dk, float(scale), _p(out), _p(attn), _stream()),
+              "snf_vit_attention_f32")
+        return out, attn
+    qkv = _req(qkv, torch.bfloat16, "qkv", 2)
+    if need_attn:
+        raise ValueError("vit_attention: the MFMA kernel does not materialise attn; use the fp32 path")
+    out = torch.empty(b * t, d, dtype=torch.bfloat16, device=qkv.device)
+    check(lib.snf_vit_attention_mfma(_p(qkv), b, t, heads, dk, float(scale), _p(out), _stream()), "snf_vit_attention_mfma")
+    return out, None
+
+
+def vit_mfma_attention_supported(t, dk):
+    return dk == 64 and t <= 256

@@ -1,0 +1,364 @@
+"""MI355X-native ViT patch-embedding extractors (the L2 stage of the reference: compute_feats.py -> IClassifier ->
+VisionTransformer.forward).
+
+Mirrors the module API and state-dict keys of the reference's inference-time model files:
+  utils_ssls_cf/vision_transformer_with_adapter_dino_version.py   Mlp:51 Attention:70 Block:97 PatchEmbed:130
+                                                                  VisionTransformer:149 vit_tiny/small/base:258-276
+  utils_ssls_cf/vision_transformer_dino.py                        same without the adapter
+  utils_ssls_cf/adapter.py                                        Adapter:34-94
+  utils_ssls_cf/models_adapter_mae.py                             MaskedAutoencoderViT encoder:174-195
+(keys: cls_token, pos_embed, patch_embed.proj.*, blocks.{i}.{norm1,attn.qkv,attn.proj,norm2,mlp.fc1,mlp.fc2,
+ adaptmlp.down_proj,adaptmlp.up_proj}.*, norm.*).
+
+Inference only (parameters of the extractor are frozen in the reference, compute_feats.py:432-433).  Hand-written HIP:
+patchify, token assembly, LayerNorm, residual+LayerNorm fusion, GELU epilogue, multi-head self-attention (exact fp32 and
+bf16 MFMA).  The dense projections are plain library GEMMs.  ``configure(precision=...)``: "fp32" = reference-class
+numerics, "bf16" = bf16 GEMM / MFMA operands with an fp32 residual stream.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._ffi import SnuffyHipError
+
+
+class Adapter(nn.Module):
+    """scale * up(ReLU(down(x))) bottleneck adapter.  Reference utils_ssls_cf/adapter.py:34-94."""
+
+    def __init__(self, adapter_d_model, d_model=None, bottleneck=None, dropout=0.0, init_option="bert",
+                 adapter_scalar="1.0", adapter_layernorm_option="in"):
+        super().__init__()
+        self.n_embd = adapter_d_model if d_model is None else d_model
+        self.down_size = bottleneck
+        self.adapter_layernorm_option = adapter_layernorm_option
+        self.adapter_layer_norm_before = None
+        if adapter_layernorm_option in ("in", "out"):
+            self.adapter_layer_norm_before = nn.LayerNorm(self.n_embd)
+        if adapter_scalar == "learnable_scalar":
+            self.scale = nn.Parameter(torch.ones(1))
+        else:
+            self.scale = float(adapter_scalar)
+        self.down_proj = nn.Linear(self.n_embd, self.down_size)
+        self.non_linear_func = nn.ReLU()
+        self.up_proj = nn.Linear(self.down_size, self.n_embd)
+        self.dropout = dropout
+        if init_option == "bert":
+            raise NotImplementedError
+        elif init_option == "lora":
+            with torch.no_grad():
+                nn.init.kaiming_normal_(self.down_proj.weight, a=math.sqrt(5))
+                nn.init.zeros_(self.down_proj.bias)
+                nn.init.zeros_(self.up_proj.weight)
+                nn.init.zeros_(self.up_proj.bias)
+
+    def forward(self, x, add_residual=True, residual=None):
+        residual = x if residual is None else residual
+        if self.adapter_layernorm_option == 'in':
+            x = self.adapter_layer_norm_before(x)
+        up = self.up_proj(F.relu(self.down_proj(x))) * self.scale       # eval: the reference's dropout is inactive
+        if self.adapter_layernorm_option == 'out':
+            up = self.adapter_layer_norm_before(up)
+        return up + residual if add_residual else up
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        shp = x.shape
+        h = torch.mm(x.reshape(-1, shp[-1]).float(), self.fc1.weight.t())
+        ops.bias_act_(h, self.fc1.bias, "gelu")
+        return F.linear(h, self.fc2.weight, self.fc2.bias).view(*shp[:-1], -1)
+
+
+class Attention(nn.Module):
+    """Reference …dino_version.py:70-94: returns (x, attn)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = F.linear(x.reshape(B * N, C).float(), self.qkv.weight, self.qkv.bias)
+        o, attn = ops.vit_attention(qkv, B, N, self.num_heads, self.scale, need_attn=True)
+        return F.linear(o, self.proj.weight, self.proj.bias).view(B, N, C), attn
+
+
+class Block(nn.Module):
+    """x += Attn(LN1 x); x = x + MLP(LN2 x) [+ Adapter(x)].  Reference …dino_version.py:97-127 / vision_transformer_dino.py:96."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 adapter_ffn_layernorm_option="none", adapter_ffn_init_option="lora",
+                 adapter_ffn_scalar="0.1", adapter_ffn_num=64, d_model=768, adapter_d_model=768, use_adapter=True):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                              proj_drop=drop)
+        self.drop_path = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        if use_adapter:
+            self.adaptmlp = Adapter(bottleneck=adapter_ffn_num, dropout=0.1, adapter_d_model=adapter_d_model,
+                                    d_model=d_model, init_option=adapter_ffn_init_option,
+                                    adapter_scalar=adapter_ffn_scalar,
+                                    adapter_layernorm_option=adapter_ffn_layernorm_option)
+
+    def forward(self, x, return_attention=False):
+        B, N, C = x.shape
+        x2 = x.reshape(B * N, C).float().contiguous()
+        y, attn = self.attn(ops.layernorm_rows(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps).view(B, N, C))
+        if return_attention:
+            return attn
+        x = x + y
+        ad = self.adaptmlp(x, add_residual=False) if hasattr(self, "adaptmlp") else 0.0
+        xn = ops.layernorm_rows(x.reshape(B * N, C).contiguous(), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return x + self.mlp(xn).view(B, N, C) + ad
+
+
+class PatchEmbed(nn.Module):
+    """Image to patch embedding: Conv2d(in_chans, embed_dim, patch, patch) run as patchify + GEMM."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.num_patches = (img_size // patch_size) * (img_size // patch_size)
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def forward(self, x):
+        B = x.shape[0]
+        cols = ops.vit_patchify(x.float().contiguous(), self.patch_size)
+        w = self.proj.weight.reshape(self.proj.weight.shape[0], -1)
+        return F.linear(cols, w, self.proj.bias).view(B, -1, w.shape[0])
+
+
+class VisionTransformer(nn.Module):
+    """DINO ViT, optionally with adapters.  Reference …dino_version.py:149-256 (adapter) / vision_transformer_dino.py."""
+
+    def __init__(self, img_size=[224], patch_size=16, in_chans=3, num_classes=0, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0., norm_layer=nn.LayerNorm, adapter_ffn_layernorm_option="none",
+                 adapter_ffn_init_option="lora", adapter_ffn_scalar="0.1",
+                 adapter_ffn_num=64, adapter_d_model=768, use_adapter=True, pool="cls", **kwargs):
+        super().__init__()
+        self.num_features = self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.pool = pool                                   # "cls" (DINO) or "mean_patches" (MAE encoder)
+        self.precision = "fp32"
+        self.patch_embed = PatchEmbed(img_size=img_size[0] if isinstance(img_size, (list, tuple)) else img_size,
+                                      patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                  drop=drop_rate, attn_drop=attn_drop_rate, drop_path=0., norm_layer=norm_layer,
+                  adapter_ffn_layernorm_option=adapter_ffn_layernorm_option,
+                  adapter_ffn_init_option=adapter_ffn_init_option, adapter_ffn_scalar=adapter_ffn_scalar,
+                  adapter_ffn_num=adapter_ffn_num, d_model=adapter_d_model, adapter_d_model=adapter_d_model,
+                  use_adapter=use_adapter)
+            for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+        nn.init.trunc_normal_(self.cls_token, std=.02)
+        self._bf16_cache = None
+
+    def configure(self, precision="fp32"):
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
+        return self
+
+    # -- reference helper API ---------------------------------------------------------------------------------------
+    def interpolate_pos_encoding(self, x, w, h):
+        npatch = x.shape[1] - 1
+        N = self.pos_embed.shape[1] - 1
+        if npatch == N and w == h:
+            return self.pos_embed
+        class_pos_embed = self.pos_embed[:, 0]
+        patch_pos_embed = self.pos_embed[:, 1:]
+        dim = x.shape[-1]
+        w0 = w // self.patch_embed.patch_size + 0.1
+        h0 = h // self.patch_embed.patch_size + 0.1
+        patch_pos_embed = F.interpolate(
+            patch_pos_embed.reshape(1, int(math.sqrt(N)), int(math.sqrt(N)), dim).permute(0, 3, 1, 2),
+            scale_factor=(w0 / math.sqrt(N), h0 / math.sqrt(N)), mode='bicubic')
+        assert int(w0) == patch_pos_embed.shape[-2] and int(h0) == patch_pos_embed.shape[-1]
+        patch_pos_embed = patch_pos_embed.permute(0, 2, 3, 1).view(1, -1, dim)
+        return torch.cat((class_pos_embed.unsqueeze(0), patch_pos_embed), dim=1)
+
+    def prepare_tokens(self, x):
+        """[B, 3, H, W] -> tokens [B, T, D] (fp32): patch embedding, cls concat, + positional table."""
+        if not x.is_cuda:
+            raise SnuffyHipError("input must be a GPU tensor: snuffy_amd has no CPU fallback")
+        B, nc, w, h = x.shape
+        pe = self.patch_embed(x)                                                  # [B, P, D]
+        pos = self.interpolate_pos_encoding(torch.empty(1, pe.shape[1] + 1, pe.shape[2], device="meta"), w, h)
+        tok = ops.vit_assemble_tokens(pe.reshape(-1, pe.shape[2]).contiguous(), self.cls_token.detach(), pos.detach()[0], B)
+        return tok.view(B, pe.shape[1] + 1, pe.shape[2])
+
+    def get_last_selfattention(self, x):
+        x = self.prepare_tokens(x)
+        for i, blk in enumerate(self.blocks):
+            if i < len(self.blocks) - 1:
+                x = blk(x)
+            else:
+                return blk(x, return_attention=True)
+
+    def get_intermediate_layers(self, x, n=1):
+        x = self.prepare_tokens(x)
+        output = []
+        for i, blk in enumerate(self.blocks):
+            x = blk(x)
+            if len(self.blocks) - i <= n:
+                B, N, C = x.shape
+                output.append(ops.layernorm_rows(x.reshape(B * N, C).contiguous(), self.norm.weight, self.norm.bias,
+                                                 self.norm.eps).view(B, N, C))
+        return output
+
+    # -- forward -----------------------------------------------------------------------------------------------------
+    def _pool(self, x, B, T):
+        D = x.shape[-1]
+        xv = x.view(B, T, D)
+        if self.pool == "cls":
+            rows = xv[:, 0].contiguous()                                          # LN is per row: only the CLS rows matter
+        else:
+            rows = xv[:, 1:, :].mean(dim=1)                                       # models_adapter_mae.py:192
+        return ops.layernorm_rows(rows, self.norm.weight, self.norm.bias, self.norm.eps)
+
+    @torch.no_grad()
+    def forward(self, x):
+        if self.precision == "bf16":
+            return self._forward_bf16(x)
+        x = self.prepare_tokens(x)
+        for blk in self.blocks:
+            x = blk(x)
+        B, T, D = x.shape
+        return self._pool(x.reshape(B * T, D), B, T)
+
+    def _weights_bf16(self):
+        params = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._bf16_cache is not None and self._bf16_cache[0] == key:
+            return self._bf16_cache[1]
+        bf = torch.bfloat16
+        w = dict(pe_w=self.patch_embed.proj.weight.reshape(self.embed_dim, -1).to(bf),
+                 pe_b=self.patch_embed.proj.bias.to(bf), blocks=[])
+        for blk in self.blocks:
+            d = dict(qkv_w=blk.attn.qkv.weight.to(bf),
+                     qkv_b=(blk.attn.qkv.bias if blk.attn.qkv.bias is not None else
+                            torch.zeros(3 * self.embed_dim, device=blk.attn.qkv.weight.device)).to(bf),
+                     proj_w=blk.attn.proj.weight.to(bf), proj_b=blk.attn.proj.bias.to(bf),
+                     fc1_w=blk.mlp.fc1.weight.to(bf), fc2_w=blk.mlp.fc2.weight.to(bf), fc2_b=blk.mlp.fc2.bias.to(bf))
+            if hasattr(blk, "adaptmlp"):
+                d.update(dn_w=blk.adaptmlp.down_proj.weight.to(bf), dn_b=blk.adaptmlp.down_proj.bias.to(bf),
+                         up_w=blk.adaptmlp.up_proj.weight.to(bf), up_b=blk.adaptmlp.up_proj.bias.to(bf))
+            w["blocks"].append(d)
+        self._bf16_cache = (key, w)
+        return w
+
+    def _forward_bf16(self, x):
+        """bf16 GEMM / MFMA operands, fp32 residual stream, LayerNorm fused with the residual adds."""
+        if not x.is_cuda:
+            raise SnuffyHipError("input must be a GPU tensor: snuffy_amd has no CPU fallback")
+        B, nc, w_, h_ = x.shape
+        W = self._weights_bf16()
+        ps = self.patch_embed.patch_size
+        cols = ops.vit_patchify(x.float().contiguous(), ps, torch.bfloat16)
+        pe = torch.addmm(W["pe_b"], cols, W["pe_w"].t())                                       # [B*P, D] bf16
+        P = pe.shape[0] // B
+        T = P + 1
+        pos = self.interpolate_pos_encoding(torch.empty(1, T, self.embed_dim, device="meta"), w_, h_)
+        xt = ops.vit_assemble_tokens(pe, self.cls_token, pos[0], B)                              # [B*T, D] fp32
+        heads = self.num_heads
+        dk = self.embed_dim // heads
+        use_mfma = ops.vit_mfma_attention_supported(T, dk)
+        n1 = self.blocks[0].norm1
+        ln = ops.layernorm_rows(xt, n1.weight, n1.bias, n1.eps, out_dtype=torch.bfloat16)
+        for i, blk in enumerate(self.blocks):
+            wb = W["blocks"][i]
+            qkv = torch.addmm(wb["qkv_b"], ln, wb["qkv_w"].t())                                  # [B*T, 3D] bf16
+            if use_mfma:
+                o, _ = ops.vit_attention(qkv, B, T, heads, blk.attn.scale)
+            else:
+                o, _ = ops.vit_attention(qkv.float(), B, T, heads, blk.attn.scale)
+                o = o.to(torch.bfloat16)
+            y = torch.addmm(wb["proj_b"], o, wb["proj_w"].t())                                   # [B*T, D] bf16
+            has_ad = "dn_w" in wb
+            ln2, xb = ops.vit_residual_ln_(xt, add1=y, gamma=blk.norm2.weight, beta=blk.norm2.bias, eps=blk.norm2.eps,
+                                           want_ln=True, want_x_bf16=has_ad)                     # x += attn ; LN2(x)
+            hdn = torch.mm(ln2, wb["fc1_w"].t())
+            ops.bias_act_(hdn, blk.mlp.fc1.bias, "gelu")                                         # erf GELU (nn.GELU)
+            m = torch.addmm(wb["fc2_b"], hdn, wb["fc2_w"].t())
+            u, s2 = None, 1.0
+            if has_ad:
+                a = torch._addmm_activation(wb["dn_b"], xb, wb["dn_w"].t())                      # ReLU(down(x))
+                u = torch.addmm(wb["up_b"], a, wb["up_w"].t())
+                s2 = float(blk.adaptmlp.scale)
+            last = i == len(self.blocks) - 1
+            nxt = self.norm if last else self.blocks[i + 1].norm1
+            ln, _ = ops.vit_residual_ln_(xt, add1=m, add2=u, scale2=s2, gamma=nxt.weight, beta=nxt.bias, eps=nxt.eps,
+                                         want_ln=not last)                                       # x += mlp + s*adapter
+        return self._pool(xt, B, T)
+
+
+def vit_tiny(patch_size=16, **kwargs):
+    return VisionTransformer(patch_size=patch_size, embed_dim=192, depth=12, num_heads=3, mlp_ratio=4, qkv_bias=True,
+                             norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def vit_small(patch_size=16, **kwargs):
+    return VisionTransformer(patch_size=patch_size, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4, qkv_bias=True,
+                             norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def vit_base(patch_size=16, **kwargs):
+    return VisionTransformer(patch_size=patch_size, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
+                             norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def mae_adapter_encoder(img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.,
+                        norm_layer=partial(nn.LayerNorm, eps=1e-6), adapter_ffn_scalar="0.1", adapter_ffn_num=64,
+                        adapter_d_model=768, **kwargs):
+    """Encoder half of models_adapter_mae.MaskedAutoencoderViT (the part compute_feats.py runs): same keys, output
+    LN(mean of the patch tokens) (models_adapter_mae.py:174-195).  The decoder is training-only and out of scope."""
+    return VisionTransformer(img_size=[img_size], patch_size=patch_size, embed_dim=embed_dim, depth=depth,
+                             num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=True, norm_layer=norm_layer,
+                             adapter_ffn_scalar=adapter_ffn_scalar, adapter_ffn_num=adapter_ffn_num,
+                             adapter_d_model=adapter_d_model, pool="mean_patches", **kwargs)
+
+
+class IClassifier(nn.Module):
+    """feature_extractor + Linear, returns (feats, c).  Reference dsmil.py:39-50 (what compute_feats.py:442 builds)."""
+
+    def __init__(self, feature_extractor, feature_size, output_class):
+        super().__init__()
+        self.feature_extractor = feature_extractor
+        self.fc = nn.Linear(feature_size, output_class)
+
+    def forward(self, x):
+        feats = self.feature_extractor(x)
+        feats = feats.view(feats.shape[0], -1)
+        c = ops.critic(feats.float().contiguous(), self.fc.weight, self.fc.bias)
+        return feats, c

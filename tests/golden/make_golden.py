@@ -294,3 +294,69 @@ if __name__ == "__main__":
         run_f5()
     if "f6" in which:
         run_f6()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# F7 / F8: ViT patch-embedding extractors (compute_feats.py path), reference models imported unmodified
+# ----------------------------------------------------------------------------------------------------------------------
+def _randomize(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() == 1 and "norm" in name and name.endswith("weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            elif name in ("pos_embed", "decoder_pos_embed"):
+                continue                                    # keep the model's own (trunc-normal / sin-cos) table
+            else:
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+
+
+def run_f7_f8():
+    from functools import partial
+    import utils_ssls_cf.vision_transformer_with_adapter_dino_version as vit_adapter
+    import utils_ssls_cf.vision_transformer_dino as vit_plain
+    import utils_ssls_cf.models_adapter_mae as mae_adapter
+    ln = partial(torch.nn.LayerNorm, eps=1e-6)
+    cases = [
+        ("f7_dino_adapter_p16", lambda: vit_adapter.VisionTransformer(
+            patch_size=16, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4, qkv_bias=True, norm_layer=ln,
+            adapter_ffn_layernorm_option="none", adapter_ffn_init_option="lora", adapter_ffn_scalar="10",
+            adapter_ffn_num=8, adapter_d_model=128), dict(kind="dino_adapter", patch=16, dim=128, depth=2, heads=2, ffn=8, scalar=10.0)),
+        ("f7_dino_adapter_p32", lambda: vit_adapter.VisionTransformer(
+            patch_size=32, embed_dim=64, depth=1, num_heads=1, mlp_ratio=4, qkv_bias=True, norm_layer=ln,
+            adapter_ffn_layernorm_option="none", adapter_ffn_init_option="lora", adapter_ffn_scalar="0.1",
+            adapter_ffn_num=16, adapter_d_model=64), dict(kind="dino_adapter", patch=32, dim=64, depth=1, heads=1, ffn=16, scalar=0.1)),
+        ("f7_dino_plain_p16", lambda: vit_plain.VisionTransformer(
+            patch_size=16, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4, qkv_bias=True, norm_layer=ln),
+            dict(kind="dino", patch=16, dim=128, depth=2, heads=2, ffn=0, scalar=0.0)),
+        ("f8_mae_adapter_p16", lambda: mae_adapter.MaskedAutoencoderViT(
+            img_size=224, patch_size=16, embed_dim=128, depth=2, num_heads=2, decoder_embed_dim=32, decoder_depth=1,
+            decoder_num_heads=2, mlp_ratio=4, norm_layer=ln, adapter_ffn_scalar="1.0", adapter_ffn_num=8,
+            adapter_d_model=128), dict(kind="mae_adapter", patch=16, dim=128, depth=2, heads=2, ffn=8, scalar=1.0)),
+    ]
+    for i, (name, ctor, meta) in enumerate(cases):
+        torch.manual_seed(40 + i)
+        model = ctor().eval()
+        _randomize(model, 400 + i)
+        g = torch.Generator().manual_seed(4000 + i)
+        img_u8 = torch.randint(0, 256, (2, 3, 224, 224), generator=g, dtype=torch.uint8)   # what ToTensor() sees
+        imgs = img_u8.float() / 255.0
+        out = dict(imgs_u8=img_u8.numpy(), kind=np.array(meta["kind"]),
+                   cfg=np.array([meta["patch"], meta["dim"], meta["depth"], meta["heads"], meta["ffn"]], dtype=np.int64),
+                   scalar=np.float64(meta["scalar"]))
+        with torch.no_grad():
+            feats = model(imgs)
+            out["feats"] = feats.numpy()
+            if meta["kind"] != "mae_adapter":
+                tok = model.prepare_tokens(imgs)
+                out["tokens0"] = tok[:, ::13, :].numpy()                 # rows 0, 13, 26, ... of the token matrix
+                out["block0"] = model.blocks[0](tok)[:, ::13, :].numpy()
+                out["last_attn"] = model.get_last_selfattention(imgs)[:, :, ::29, :].numpy()
+        sd = {k: v for k, v in model.state_dict().items() if not k.startswith("decoder") and k != "mask_token"}
+        out.update({"sd." + k: v.detach().numpy().copy() for k, v in sd.items()})
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+        print(f"{name}: feats {tuple(feats.shape)} |feats|max={float(feats.abs().max()):.3f} params={sum(v.numel() for v in sd.values())}")
+
+
+if "f7" in (sys.argv[1:] or ["f7"]) and __name__ == "__main__":
+    run_f7_f8()

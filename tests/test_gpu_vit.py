@@ -1,0 +1,142 @@
+"""ViT extractor on the GPU: kernels vs the CPU oracle, models vs the golden vectors captured from the reference."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vit_oracle as vorc
+from tests.helpers import golden_files, load_case, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def ops():
+    from snuffy_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize("b,c,hw,ps", [(2, 3, 224, 16), (3, 3, 224, 32), (1, 3, 64, 8), (5, 1, 32, 16)])
+def test_patchify_exact(b, c, hw, ps):
+    g = torch.Generator().manual_seed(hw + ps)
+    img = torch.rand(b, c, hw, hw, generator=g)
+    gh = hw // ps
+    ref = img.reshape(b, c, gh, ps, gh, ps).permute(0, 2, 4, 1, 3, 5).reshape(b * gh * gh, c * ps * ps)
+    got = ops().vit_patchify(img.to(DEV), ps)
+    assert torch.equal(got.cpu(), ref)
+    gotb = ops().vit_patchify(img.to(DEV), ps, torch.bfloat16)
+    assert torch.equal(gotb.cpu(), ref.to(torch.bfloat16))
+    # and it is the conv: cols @ W^T + b == Conv2d
+    w, bias = torch.randn(24, c, ps, ps, generator=g), torch.randn(24, generator=g)
+    conv = F.conv2d(img, w, bias, stride=ps).flatten(2).transpose(1, 2).reshape(-1, 24)
+    assert (got.cpu() @ w.reshape(24, -1).t() + bias - conv).abs().max() < 1e-4
+
+
+def test_assemble_and_residual_ln():
+    g = torch.Generator().manual_seed(1)
+    B, P, D = 3, 49, 192
+    pe, cls, pos = torch.randn(B * P, D, generator=g), torch.randn(1, 1, D, generator=g), torch.randn(1, P + 1, D, generator=g)
+    ref = torch.cat((cls.expand(B, -1, -1), pe.view(B, P, D)), dim=1) + pos
+    got = ops().vit_assemble_tokens(pe.to(DEV), cls.to(DEV), pos[0].to(DEV), B)
+    assert torch.equal(got.cpu().view(B, P + 1, D), ref)
+    gotb = ops().vit_assemble_tokens(pe.to(DEV).to(torch.bfloat16), cls.to(DEV), pos[0].to(DEV), B)
+    refb = torch.cat((cls.expand(B, -1, -1), pe.to(torch.bfloat16).float().view(B, P, D)), dim=1) + pos
+    assert torch.equal(gotb.cpu().view(B, P + 1, D), refb)
+    for d in (64, 192, 384, 768):
+        n = 301
+        x = torch.randn(n, d, generator=g)
+        a1, a2 = torch.randn(n, d, generator=g).to(torch.bfloat16), torch.randn(n, d, generator=g).to(torch.bfloat16)
+        gam, bet = torch.randn(d, generator=g), torch.randn(d, generator=g)
+        xd = x.to(DEV)
+        ln, xb = ops().vit_residual_ln_(xd, a1.to(DEV), a2.to(DEV), 10.0, gam.to(DEV), bet.to(DEV), 1e-6, True, True)
+        xr = x + a1.float() + 10.0 * a2.float()
+        assert (xd.cpu() - xr).abs().max() < 1e-5
+        assert torch.equal(xb.cpu(), xd.cpu().to(torch.bfloat16))
+        lr = F.layer_norm(xr, (d,), gam, bet, 1e-6)
+        assert (ln.cpu().float() - lr).abs().max() < 3e-2 and rel_err(ln.cpu().float(), lr) < 1e-2
+        x2 = x.to(DEV)
+        ln2, _ = ops().vit_residual_ln_(x2, None, None, 1.0, gam.to(DEV), bet.to(DEV), 1e-6, True, False)
+        assert torch.equal(x2.cpu(), x)
+
+
+def ref_attention(qkv, b, t, h):
+    d = qkv.shape[1] // 3
+    dk = d // h
+    q, k, v = qkv.double().view(b, t, 3, h, dk).permute(2, 0, 3, 1, 4)
+    attn = ((q @ k.transpose(-2, -1)) * dk ** -0.5).softmax(-1)
+    return (attn @ v).transpose(1, 2).reshape(b * t, d), attn
+
+
+@pytest.mark.parametrize("b,t,h,dk", [(2, 197, 6, 64), (3, 50, 3, 64), (1, 1, 2, 32), (2, 300, 2, 64), (2, 65, 1, 128)])
+def test_vit_attention_exact(b, t, h, dk):
+    g = torch.Generator().manual_seed(t)
+    qkv = torch.randn(b * t, 3 * h * dk, generator=g)
+    o_ref, a_ref = ref_attention(qkv, b, t, h)
+    o, attn = ops().vit_attention(qkv.to(DEV), b, t, h, need_attn=True)
+    assert (attn.cpu().double() - a_ref).abs().max() < 1e-6
+    assert rel_err(o.cpu(), o_ref) < 1e-5
+
+
+@pytest.mark.parametrize("b,t,h", [(2, 197, 6), (3, 50, 3), (1, 1, 1), (2, 256, 2), (4, 100, 12), (2, 150, 2), (1, 33, 1)])
+def test_vit_attention_mfma(b, t, h):
+    g = torch.Generator().manual_seed(t + h)
+    qkv = (torch.randn(b * t, 3 * h * 64, generator=g) * 1.5).to(torch.bfloat16)
+    o_ref, _ = ref_attention(qkv.float(), b, t, h)            # same bf16-rounded operands: tight comparison
+    o, _ = ops().vit_attention(qkv.to(DEV), b, t, h)
+    assert o.dtype == torch.bfloat16
+    assert rel_err(o.cpu().float(), o_ref) < 1.5e-2           # P and O are rounded to bf16 (2^-8 relative)
+    o2, _ = ops().vit_attention(qkv.to(DEV), b, t, h)
+    assert torch.equal(o, o2)
+
+
+def build(z):
+    from snuffy_amd import vit
+    patch, dim, depth, heads, ffn = [int(v) for v in z["cfg"]]
+    kind, scale = str(z["kind"]), float(z["scalar"])
+    ln = partial(torch.nn.LayerNorm, eps=1e-6)
+    if kind == "mae_adapter":
+        return vit.mae_adapter_encoder(224, patch, dim, depth, heads, 4, ln, repr(scale), ffn, dim)
+    return vit.VisionTransformer(patch_size=patch, embed_dim=dim, depth=depth, num_heads=heads, mlp_ratio=4, qkv_bias=True,
+                                 norm_layer=ln, adapter_ffn_scalar=repr(scale), adapter_ffn_num=max(ffn, 1),
+                                 adapter_d_model=dim, use_adapter=(kind != "dino"))
+
+
+@pytest.mark.parametrize("path", golden_files("f7_") + golden_files("f8_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_vit_models_match_reference_goldens(path):
+    z, sd = load_case(path)
+    model = build(z)
+    assert sorted(model.state_dict().keys()) == sorted(sd.keys())
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    imgs = (torch.from_numpy(z["imgs_u8"]).float() / 255.0).to(DEV)
+    feats = model(imgs)
+    np.testing.assert_allclose(feats.cpu().numpy(), z["feats"], rtol=0, atol=1e-3)      # north-star fp32 tolerance
+    np.testing.assert_allclose(feats.cpu().numpy(), z["feats"], rtol=0, atol=5e-5)      # and reference-class in fact
+    if str(z["kind"]) != "mae_adapter":
+        with torch.no_grad():
+            tok = model.prepare_tokens(imgs)
+            np.testing.assert_allclose(tok[:, ::13, :].cpu().numpy(), z["tokens0"], rtol=0, atol=1e-5)
+            np.testing.assert_allclose(model.blocks[0](tok)[:, ::13, :].cpu().numpy(), z["block0"], rtol=0, atol=5e-5)
+            attn = model.get_last_selfattention(imgs)
+            np.testing.assert_allclose(attn[:, :, ::29, :].cpu().numpy(), z["last_attn"], rtol=0, atol=1e-5)
+    fb = model.configure("bf16")(imgs)
+    ref = torch.from_numpy(z["feats"])
+    assert rel_err(fb.cpu(), ref) < 2e-2, rel_err(fb.cpu(), ref)                       # bf16 path: 1e-2 per layer, depth <= 2
+
+
+def test_vit_small_shape_and_iclassifier():
+    from snuffy_amd import vit
+    torch.manual_seed(0)
+    model = vit.vit_small(patch_size=16, adapter_ffn_scalar="10", adapter_ffn_num=32, adapter_d_model=384)
+    emb = vit.IClassifier(model, 384, 2).to(DEV).eval()
+    x = torch.rand(4, 3, 224, 224, device=DEV)
+    with torch.no_grad():
+        feats, c = emb(x)
+        sd = {k: v.cpu() for k, v in model.state_dict().items()}
+        ref = vorc.vit_forward(x.cpu(), sd, 16, 12, 6, 10.0, "dino_adapter")
+    assert feats.shape == (4, 384) and c.shape == (4, 2)
+    assert (feats.cpu() - ref).abs().max() < 1e-3
+    fb = model.configure("bf16")(x)
+    assert rel_err(fb.cpu(), ref) < 5e-2
