@@ -1,4 +1,5 @@
 """ViT extractor on the GPU: kernels vs the CPU oracle, models vs the golden vectors captured from the reference."""
+import os
 from functools import partial
 
 import numpy as np
@@ -31,7 +32,7 @@ def test_patchify_exact(b, c, hw, ps):
     # and it is the conv: cols @ W^T + b == Conv2d
     w, bias = torch.randn(24, c, ps, ps, generator=g), torch.randn(24, generator=g)
     conv = F.conv2d(img, w, bias, stride=ps).flatten(2).transpose(1, 2).reshape(-1, 24)
-    assert (got.cpu() @ w.reshape(24, -1).t() + bias - conv).abs().max() < 1e-4
+    assert rel_err(got.cpu() @ w.reshape(24, -1).t() + bias, conv) < 1e-5
 
 
 def test_assemble_and_residual_ln():
@@ -140,3 +141,63 @@ def test_vit_small_shape_and_iclassifier():
     assert (feats.cpu() - ref).abs().max() < 1e-3
     fb = model.configure("bf16")(x)
     assert rel_err(fb.cpu(), ref) < 5e-2
+
+
+def test_compute_feats_end_to_end(tmp_path):
+    """Tile directory -> embedder -> CSV (%.4f) -> utils.get_bag_feats, the reference's file hand-off between stages."""
+    import argparse
+
+    import pandas as pd
+    from PIL import Image
+
+    from snuffy_amd import compute_feats as cf
+    from snuffy_amd import utils, vit
+    rng = np.random.RandomState(0)
+    bag_dir = tmp_path / "single" / "tumor" / "slide_001"
+    bag_dir.mkdir(parents=True)
+    for r in range(3):
+        for c in range(3):
+            Image.fromarray(rng.randint(0, 255, (256, 256, 3), dtype=np.uint8)).save(bag_dir / f"{r}_{c}-17.jpeg", quality=95)
+    args = argparse.Namespace(backbone="vit_tiny", embedder="DINO_adapter", patch_size=16, adapter_ffn_scalar="10",
+                              ffn_num=8, num_classes=1, batch_size=4, num_workers=0, transform=0, dataset="camelyon16",
+                              weights=None, precision="fp32")
+    torch.manual_seed(0)
+    backbone, nf = cf.get_embedder_backbone(args)
+    assert nf == 192 and not any(p.requires_grad for p in backbone.parameters())
+    embedder, _ = cf.get_embedder(args, backbone, nf)
+    labels = {os.path.join("tumor", "slide_001", f"{r}_{c}-17.jpeg"): int((r + c) % 2) for r in range(3) for c in range(3)}
+    cf.compute_feats(args, [str(bag_dir)], embedder, str(tmp_path / "out"), labels)
+    csv = tmp_path / "out" / "single" / "tumor" / "slide_001.csv"
+    df = pd.read_csv(csv)
+    assert df.shape == (9, 192 + 2) and list(df.columns[-2:]) == ["label", "position"]
+    body = open(csv).read().splitlines()[1].split(",")[:192]
+    assert all(len(v.split(".")[1]) == 4 for v in body)                        # '%.4f'
+    # the features are what the embedder gives for the same transformed tiles
+    files = sorted(str(p) for p in bag_dir.glob("*.jpeg"))
+    tf = cf.TileTransform(224)
+    x = torch.stack([tf({"input": Image.open(f), "label": 0, "position": None})["input"] for f in files]).to(DEV)
+    with torch.no_grad():
+        feats, _ = embedder(x)
+    np.testing.assert_allclose(df.iloc[:, :192].to_numpy(), feats.cpu().numpy(), atol=5.1e-5)
+    # and the MIL loader reads it back (rows shuffled, label / position split off)
+    a = argparse.Namespace(num_classes=1)
+    lab, f, fl, pos = utils.get_bag_feats(pd.Series([str(csv), 1]), a)
+    assert f.shape == (9, 192) and f.dtype == np.float32 and lab.tolist() == [1.0] and len(pos) == 9
+
+
+def test_positional_weight_loading_like_reference(tmp_path):
+    """compute_feats.py:477-480 maps checkpoint tensors to the embedder BY POSITION: our key order must be the reference's."""
+    import argparse
+
+    from snuffy_amd import compute_feats as cf
+    z, sd = load_case(golden_files("f7_dino_adapter_p16")[0])
+    ref_order = [k[3:] for k in z.files if k.startswith("sd.")]
+    model = build(z)
+    assert list(model.state_dict().keys()) == ref_order
+    # a DINO checkpoint: {'teacher': {'backbone.<key>': tensor}} in the same order
+    ckpt = {"teacher": {"backbone." + k: sd[k] for k in ref_order}}
+    torch.save(ckpt, tmp_path / "checkpoint.pth")
+    args = argparse.Namespace(embedder="DINO_adapter", weights=str(tmp_path / "checkpoint.pth"), num_classes=1)
+    emb, _ = cf.get_embedder(args, model, 128)
+    for k in ref_order:
+        assert torch.equal(emb.state_dict()["feature_extractor." + k].cpu(), sd[k])
