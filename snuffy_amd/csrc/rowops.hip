@@ -271,12 +271,27 @@ __global__ void slot_map_kernel(const int64_t* __restrict__ idx, int k, int64_t 
 // ---------------------------------------------------------------------------------------------------------------
 // K10 epilogue: h = act(h + bias)
 // ---------------------------------------------------------------------------------------------------------------
+// erf(x) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 -- fp32 round-off class): 5 FMAs + one exp + one rcp, branch
+// free, ~3x cheaper than libm's erff on the VALU (the GELU epilogue of a [N, 4D] hidden tensor is otherwise VALU-bound).
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
+    const float r = fmaf(-p, e, 1.0f);
+    return copysignf(r, x);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case SNF_ACT_RELU:
             return fmaxf(v, 0.f);
         case SNF_ACT_GELU:
-            return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
         case SNF_ACT_LEAKYRELU:
             return v > 0.f ? v : 0.01f * v;
         case SNF_ACT_SELU: {

@@ -2,8 +2,9 @@
 //
 // Exact, deterministic, tie rule = descending score then ascending index (torch.sort(stable=True) order).
 // Each score becomes a 64-bit composite key  (orderable(score) << 32) | ~index ; larger composite == earlier in the
-// output.  Round r: every workgroup bitonic-sorts a chunk of 4096 composites (registers + wave shuffles, LDS only for
-// the cross-wave steps) and keeps its top min(k, chunk);
+// output.  n <= 4096: one workgroup bitonic-sorts the composites (registers + wave shuffles, LDS only for the
+// cross-wave steps).  n > 4096: radix select (below).  [The multi-round chunked sort is kept for reference:] every
+// workgroup sorts a chunk of 4096 and keeps its top min(k, chunk);
 // rounds repeat on the survivors until one chunk is left, whose top k indices are the answer.  Integer compare-exchange
 // only -- bit-exact on every run.
 #include "common.h"
@@ -122,6 +123,166 @@ __global__ __launch_bounds__(TPB) void topk_round_kernel(const void* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Radix select (n > 4096): ONE workgroup, O(n) work.  Three counting passes (11 + 11 + 10 bits of the orderable key, LDS
+// histogram with integer atomics -> exact and deterministic) find the k-th largest key T; one more pass collects every
+// key > T plus the lowest-index (k - #greater) keys == T; the k survivors are sorted as 64-bit composites (bitonic, LDS).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int RS_MAXK = 2048;
+
+__device__ __forceinline__ unsigned int block_excl_scan_1024(unsigned int v, unsigned int* wave_tot, unsigned int* total) {
+    // exclusive prefix sum over the 1024 threads (ascending thread id); *total = sum of all
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        unsigned int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    unsigned int base = 0, tot = 0;
+    for (int i = 0; i < 16; ++i) {
+        unsigned int t = wave_tot[i];
+        if (i < wv) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restrict__ scores, int64_t n, int64_t stride, int k,
+                                                          int64_t* __restrict__ idx_out) {
+    __shared__ unsigned int hist[2048];
+    __shared__ unsigned long long sel[RS_MAXK];
+    __shared__ unsigned int wave_tot[16];
+    __shared__ unsigned int s_digit, s_above, s_cnt_sel, s_eq_base;
+    const int tid = threadIdx.x;
+    unsigned int prefix = 0, mask = 0, krem = (unsigned int)k, cnt_eq = 0;
+    const int shifts[3] = {21, 10, 0};
+    const int nbits[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = shifts[pass];
+        const unsigned int nb = 1u << nbits[pass];
+        for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+        __syncthreads();
+        for (int64_t i0 = tid; i0 < n; i0 += 8 * 1024) {   // 8 independent loads in flight per thread
+            float f[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = i0 + (int64_t)u * 1024;
+                f[u] = (i < n) ? scores[i * stride] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = i0 + (int64_t)u * 1024;
+                const unsigned int key = orderable_desc(f[u]);
+                if (i < n && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1)], 1u);
+            }
+        }
+        __syncthreads();
+        // suffix counts: thread t owns digits dpt*t .. dpt*t + dpt-1 ; S(d) = #keys (in the prefix class) with digit >= d
+        const int dpt = (int)(nb / 1024);
+        unsigned int own[2] = {0, 0}, local = 0;
+        for (int e = 0; e < dpt; ++e) {
+            own[e] = hist[dpt * tid + e];
+            local += own[e];
+        }
+        unsigned int total;
+        const unsigned int below = block_excl_scan_1024(local, wave_tot, &total);   // keys with a smaller digit
+        unsigned int s_hi = total - below - local;                                   // keys in digits above this thread's
+        for (int e = dpt - 1; e >= 0; --e) {
+            const unsigned int s_d = s_hi + own[e];                                  // S(d) for d = dpt*tid + e
+            if (s_d >= krem && s_hi < krem) {
+                s_digit = (unsigned int)(dpt * tid + e);
+                s_above = s_hi;
+            }
+            s_hi = s_d;
+        }
+        __syncthreads();
+        cnt_eq = hist[s_digit];
+        prefix |= s_digit << shift;
+        mask |= (nb - 1) << shift;
+        krem -= s_above;
+        __syncthreads();
+    }
+    // threshold key T = prefix: #(key > T) = k - krem, #(key == T) = cnt_eq >= krem
+    const unsigned int T = prefix;
+    if (tid == 0) {
+        s_cnt_sel = 0;
+        s_eq_base = 0;
+    }
+    __syncthreads();
+    const bool take_all_eq = (cnt_eq == krem);
+    if (take_all_eq) {   // common case (no tie straddles the k-th place): unordered append, 8 loads in flight
+        for (int64_t i0 = tid; i0 < n; i0 += 8 * 1024) {
+            float f[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = i0 + (int64_t)u * 1024;
+                f[u] = (i < n) ? scores[i * stride] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = i0 + (int64_t)u * 1024;
+                const unsigned int key = orderable_desc(f[u]);
+                if (i < n && key >= T) {
+                    const unsigned int pos = atomicAdd(&s_cnt_sel, 1u);
+                    sel[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xffffffffu - (unsigned int)i);
+                }
+            }
+        }
+    } else
+    for (int64_t i0 = 0; i0 < n; i0 += 1024) {
+        const int64_t i = i0 + tid;
+        unsigned int key = 0;
+        bool gt = false, eq = false;
+        if (i < n) {
+            key = orderable_desc(scores[i * stride]);
+            gt = key > T;
+            eq = key == T;
+        }
+        if (gt || (eq && take_all_eq)) {
+            const unsigned int pos = atomicAdd(&s_cnt_sel, 1u);
+            sel[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xffffffffu - (unsigned int)i);
+        }
+        if (!take_all_eq) {   // ties straddle the k-th place: keep the lowest indices (uniform branch)
+            unsigned int tot;
+            const unsigned int rank = s_eq_base + block_excl_scan_1024(eq ? 1u : 0u, wave_tot, &tot);
+            if (eq && rank < krem) {
+                const unsigned int pos = atomicAdd(&s_cnt_sel, 1u);
+                sel[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xffffffffu - (unsigned int)i);
+            }
+            __syncthreads();
+            if (tid == 0) s_eq_base += tot;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // sort the k survivors (descending composite == descending score, ascending index)
+    int p2 = 1;
+    while (p2 < k) p2 <<= 1;
+    for (int i = k + tid; i < p2; i += 1024) sel[i] = 0ull;
+    for (int size = 2; size <= p2; size <<= 1) {
+        for (int st = size >> 1; st > 0; st >>= 1) {
+            __syncthreads();
+            for (int p = tid; p < p2 / 2; p += 1024) {
+                const int lo = 2 * p - (p & (st - 1));
+                const int hi = lo + st;
+                const bool desc = (lo & size) == 0;
+                const unsigned long long a = sel[lo], b = sel[hi];
+                if (desc ? (a < b) : (a > b)) {
+                    sel[lo] = b;
+                    sel[hi] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < k; j += 1024) idx_out[j] = (int64_t)(0xffffffffu - (unsigned int)(sel[j] & 0xffffffffull));
+}
+
 // survivors after a round over m items with chunk keep k (every chunk but the last is full)
 inline int64_t survivors(int64_t m, int k) {
     int64_t full = m / CHUNK, rem = m % CHUNK;
@@ -133,10 +294,9 @@ inline int64_t survivors(int64_t m, int k) {
 extern "C" {
 
 size_t snf_topk_workspace_bytes(int64_t n, int k) {
-    if (n <= CHUNK || k < 1) return 0;
-    int64_t s0 = ((n + CHUNK - 1) / CHUNK) * (int64_t)k;
-    int64_t s1 = ((s0 + CHUNK - 1) / CHUNK) * (int64_t)k;
-    return (size_t)(s0 + s1) * sizeof(unsigned long long);
+    (void)n;
+    (void)k;
+    return 0;   // the radix-select path keeps its state in LDS; kept in the ABI for forward compatibility
 }
 
 int snf_topk_f32(const float* scores, int64_t n, int64_t stride, int k, int64_t* idx_out, void* workspace,
@@ -151,38 +311,11 @@ int snf_topk_f32(const float* scores, int64_t n, int64_t stride, int k, int64_t*
         hipLaunchKernelGGL((topk_round_kernel<true, true>), dim3(1), dim3(TPB), 0, s, scores, n, stride, k, idx_out);
         return snf::check_launch("topk_round_kernel<scores,index>");
     }
-    if (!workspace || workspace_bytes < snf_topk_workspace_bytes(n, k)) {
-        snf::set_error("snf_topk_f32: workspace %zu < %zu", workspace_bytes, snf_topk_workspace_bytes(n, k));
-        return SNF_EWORKSPACE;
-    }
-    unsigned long long* buf0 = reinterpret_cast<unsigned long long*>(workspace);
-    int64_t cap0 = ((n + CHUNK - 1) / CHUNK) * (int64_t)k;
-    unsigned long long* buf1 = buf0 + cap0;
-    // round 0: scores -> composites
-    int64_t m = n;
-    int blocks = (int)((m + CHUNK - 1) / CHUNK);
-    hipLaunchKernelGGL((topk_round_kernel<true, false>), dim3(blocks), dim3(TPB), 0, s, scores, m, stride, k, buf0);
-    int rc = snf::check_launch("topk_round_kernel<scores,pairs>");
-    if (rc) return rc;
-    // NB: chunks keep exactly k (all full) except possibly the last; lists are stored at block*k so a short last
-    // chunk leaves a gap only at the very end -> the survivor list is contiguous of length survivors(m, k).
-    m = survivors(m, k);
-    unsigned long long* cur = buf0;
-    unsigned long long* nxt = buf1;
-    while (m > CHUNK) {
-        blocks = (int)((m + CHUNK - 1) / CHUNK);
-        hipLaunchKernelGGL((topk_round_kernel<false, false>), dim3(blocks), dim3(TPB), 0, s, cur, m, (int64_t)1, k, nxt);
-        rc = snf::check_launch("topk_round_kernel<pairs,pairs>");
-        if (rc) return rc;
-        int64_t m2 = survivors(m, k);
-        SNF_REQUIRE(m2 < m, "snf_topk_f32: reduction does not converge (k=%d)", k);
-        m = m2;
-        unsigned long long* t = cur;
-        cur = nxt;
-        nxt = t;
-    }
-    hipLaunchKernelGGL((topk_round_kernel<false, true>), dim3(1), dim3(TPB), 0, s, cur, m, (int64_t)1, k, idx_out);
-    return snf::check_launch("topk_round_kernel<pairs,index>");
+    (void)workspace;
+    (void)workspace_bytes;
+    SNF_REQUIRE(k <= RS_MAXK, "snf_topk_f32: k=%d exceeds %d", k, RS_MAXK);
+    hipLaunchKernelGGL(topk_radix_kernel, dim3(1), dim3(1024), 0, s, scores, n, stride, k, idx_out);
+    return snf::check_launch("topk_radix_kernel");
 }
 
 int snf_topk_gather_f32(const float* scores, int64_t n, int64_t stride, int k, int64_t* idx_out, const float* x, int d,

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void vit_attention_f32_kernel(const float* __r
 // bf16 MFMA self-attention, dk = 64, T <= 32 * NKB.  qkv bf16 [B*T, 3*h*64]; out bf16 [B*T, h*64].
 // ---------------------------------------------------------------------------------------------------------------
 template <int NKB>
-__global__ __launch_bounds__(256, 2) void vit_attention_mfma_kernel(const unsigned short* __restrict__ qkv, int B, int T, int h,
+__global__ __launch_bounds__(256, (NKB <= 4 ? 2 : 1)) void vit_attention_mfma_kernel(const unsigned short* __restrict__ qkv, int B, int T, int h,
                                                                     float scale, unsigned short* __restrict__ out) {
     constexpr int DK = 64;
     constexpr int KPITCH = DK + 8;            // bf16 elements; 144 B rows: conflict-free ds_read_b128 of a K fragment
@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void vit_attention_mfma_kernel(const unsign
                     bf16x8, *reinterpret_cast<const u32x4*>(lds_k + (32 * jb + j) * KPITCH + 16 * ks + 8 * hf));
                 s_acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc[jb], 0, 0, 0);
             });
+            __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of later key blocks from being hoisted (spills)
         });
         // softmax over keys: registers of this lane + the partner half-wave
         float m = -INFINITY;
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void vit_attention_mfma_kernel(const unsign
                     o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, o_acc[db], 0, 0, 0);
                 });
             });
+            __builtin_amdgcn_sched_barrier(0);
         });
         // store O: lane = query row, 4 consecutive d per register group
         const int q_out = 32 * tile + j;
