@@ -248,22 +248,70 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
         }
     };
 
-    // pipeline fill: nothing pending -> P image and V fragments are zero, so the first interleaved GEMM2 adds 0
+    // Kp_a -> LDS as bf16 MFMA fragments: each wave owns fragments w, w+4, ...  Phase 1 issues every global load of the
+    // wave back to back (one latency, not one per fragment; padded keys re-read the last row), phase 2 converts and
+    // stores (padded keys zeroed; their probabilities are forced to 0 through the -inf accumulator init anyway).
+    constexpr int NF = (NKB * NKS + 3) / 4;
+    auto kp_issue = [&](int a, f32x4(&raw)[2 * NF]) __attribute__((always_inline)) {
+        static_for<0, NF>([&](auto i) __attribute__((always_inline)) {
+            int fr = w + 4 * i;
+            if (fr > NKB * NKS - 1) fr = NKB * NKS - 1;
+            const int jb = fr / NKS, kb = fr - jb * NKS;
+            int key = 32 * jb + j;
+            if (key > P.k - 1) key = P.k - 1;
+            const float* src = P.kp + (int64_t)key * P.ldq + a * DK + 16 * kb + 8 * hf;
+            raw[2 * i] = *reinterpret_cast<const f32x4*>(src);
+            raw[2 * i + 1] = *reinterpret_cast<const f32x4*>(src + 4);
+        });
+    };
+    auto kp_commit = [&](f32x4(&raw)[2 * NF]) __attribute__((always_inline)) {
+        static_for<0, NF>([&](auto i) __attribute__((always_inline)) {
+            const int fr = w + 4 * i;
+            if (fr < NKB * NKS) {
+                const int jb = fr / NKS;
+                f32x8 f = {raw[2 * i][0], raw[2 * i][1], raw[2 * i][2], raw[2 * i][3],
+                           raw[2 * i + 1][0], raw[2 * i + 1][1], raw[2 * i + 1][2], raw[2 * i + 1][3]};
+                u32x4 v = __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
+                if (32 * jb + j >= P.k) v = u32x4{0u, 0u, 0u, 0u};
+                lds_kp[fr * 64 + lane] = v;
+            }
+        });
+    };
+
+    // Prologue.  The cold-start latencies (kernarg, TLB, first HBM touch) are paid ONCE: the first tile's Q fragments and
+    // the first head's Kp rows are requested before anything else, the LDS / accumulator initialisation runs in their
+    // shadow, then Kp is converted into LDS.
+    int a = first_head, t = f_begin - first_head * P.tiles_per_head;   // (head, row tile) of the current work item
+    int cur_head = -1;
     {
+        f32x4 raw0[2 * NF];
+        if (f_begin < f_end) {
+            const QT* qp0 = q_ptr(a, t);
+            static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) { qf[kb] = load_frag(qp0 + 16 * kb); });
+            kp_issue(a, raw0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // pipeline fill: nothing pending -> P image and V fragments are zero, so the first interleaved GEMM2 adds 0
         const u32x4 z = {0u, 0u, 0u, 0u};
         for (int i = threadIdx.x; i < 4 * NKB * 2 * 64; i += 256) lds_p[i] = z;
 #pragma unroll
         for (int i = 0; i < 8; ++i) vf[i] = zero_frag();
-    }
-    int a = first_head, t = f_begin - first_head * P.tiles_per_head;   // (head, row tile) of the current work item
-    if (f_begin < f_end) {
-        const QT* qp0 = q_ptr(a, t);
-        static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) { qf[kb] = load_frag(qp0 + 16 * kb); });
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[ti][r] = 0.f;
+        stamp_abs(57);
+        __builtin_amdgcn_sched_barrier(0);
+        if (f_begin < f_end) {
+            kp_commit(raw0);
+            cur_head = a;
+        }
+        __syncthreads();
+        stamp_abs(61);
     }
     bool pending_tail = false;   // the pending tile (P published, GEMM2 not yet run) is the last tile of a bag
     bool published = false;      // a P image was written and its closing barrier has not been passed yet
     int pend_t = 0;
-    int cur_head = -1;
     for (int f = f_begin; f < f_end; ++f) {
         const int64_t row0 = (int64_t)t * TILE_ROWS;
         const int my_row0 = (int)row0 + 32 * w;
@@ -289,38 +337,15 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc_o[ti][r] = 0.f;
-            stamp_abs(57);
-            __syncthreads();  // everyone finished reading the previous head's Kp (and the zero-fill of lds_p is visible)
-            stamp_abs(58);
-            {   // Kp_a -> LDS as bf16 MFMA fragments: each wave owns fragments w, w+4, ...; all of its global loads are
-                // issued back to back (one latency, not one per fragment); padded keys re-read the last row and are
-                // zeroed by a select (their probabilities are forced to 0 through the -inf accumulator init anyway).
-                // (Keeping these fragments live across the main loop to prefetch them at kernel entry was measured:
-                // +56 registers of pressure cost 25 % in the loop -- do not.)
-                constexpr int NF = (NKB * NKS + 3) / 4;
-                bf16x8 kfr[NF];
-                static_for<0, NF>([&](auto i) __attribute__((always_inline)) {
-                    int fr = w + 4 * i;
-                    if (fr > NKB * NKS - 1) fr = NKB * NKS - 1;
-                    const int jb = fr / NKS, kb = fr - jb * NKS;
-                    int key = 32 * jb + j;
-                    if (key > P.k - 1) key = P.k - 1;
-                    kfr[i] = load_frag(P.kp + (int64_t)key * P.ldq + a * DK + 16 * kb + 8 * hf);
-                });
-                stamp_abs(59);
-                static_for<0, NF>([&](auto i) __attribute__((always_inline)) {
-                    const int fr = w + 4 * i;
-                    if (fr < NKB * NKS) {
-                        const int jb = fr / NKS;
-                        u32x4 v = __builtin_bit_cast(u32x4, kfr[i]);
-                        if (32 * jb + j >= P.k) v = u32x4{0u, 0u, 0u, 0u};
-                        lds_kp[fr * 64 + lane] = v;
-                    }
-                });
+            __syncthreads();  // everyone finished reading the previous head's Kp
+            {
+                f32x4 raw[2 * NF];
+                kp_issue(a, raw);
+                __builtin_amdgcn_sched_barrier(0);   // do not let the conversions pull the loads apart
+                kp_commit(raw);
             }
             __syncthreads();
             cur_head = a;
-            stamp_abs(61);
         }
 
         stamp(0);
