@@ -159,3 +159,37 @@ def test_module_level_api_matches_reference_call_sites():
     assert torch.equal(A, A2) and torch.equal(A, A3)
     with pytest.raises(IndexError):
         net(torch.cat([x, x]))                    # binary model: one bag per forward (as the reference)
+
+
+@pytest.mark.parametrize("path", golden_files("f6_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_f6_multiclass_golden(path):
+    """snuffy_multiclass (C = 2, B >= 1) against the reference goldens: per-class top-Lambda, unique, random share."""
+    import copy
+
+    from snuffy_amd import snuffy_multiclass as smc
+    z, sd = load_case(path)
+    B, N, D, h, lam, depth, seed = [int(v) for v in z["cfg"]]
+    r = float(z["r"])
+    attn = smc.MultiHeadedAttention(h, D)
+    ff = smc.PositionwiseFeedForward(D, D * 4, "relu")
+    net = smc.MILNet(smc.FCLayer(D, 2), smc.BClassifier(
+        smc.Encoder(smc.EncoderLayer(D, copy.deepcopy(attn), copy.deepcopy(ff), 2, 0.0, lam, r), depth), 2, D))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    x = torch.from_numpy(z["x"]).to(DEV)
+    for precision in ("fp32", "bf16"):
+        net.configure(precision=precision, return_attention=True)
+        np.random.seed(seed)
+        with torch.no_grad():
+            classes, logits, A = net(x)
+        tol = tol_for(precision, depth)
+        np.testing.assert_allclose(classes.cpu().numpy(), z["classes"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(logits.cpu().numpy(), z["logits"], rtol=0, atol=tol)
+        assert tuple(A.shape) == tuple(z["A"].shape)
+        np.testing.assert_allclose(A.cpu().numpy(), z["A"], rtol=0, atol=tol)
+        if int(z["n_rnd"]):
+            for l, layer in enumerate(net.b_classifier.encoder.layers):
+                _, rnd = layer.last_selection
+                got = rnd.cpu().numpy()
+                want = np.stack([z[f"rnd{l * B + i}"] for i in range(B)])      # one np.random.choice call per row
+                assert np.array_equal(got, want)
