@@ -13,6 +13,10 @@ OBJDIR = os.path.join(HERE, "build")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result"]
+# per-file extras.  The attention kernels never see NaN operands in their max-reductions; without this flag every fmaxf
+# costs two extra canonicalising v_max_f32 x,x,x (IEEE sNaN quieting) and the DPP move cannot fold into the max.
+# (-inf is still honoured: the padded-key masking relies on exp2(-inf) == 0.)
+EXTRA_FLAGS = {"sparse_attn_mfma.hip": ["-fno-honor-nans"], "vit.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc():
@@ -37,7 +41,7 @@ def _compile(src, force, hdr_mtime):
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
             and os.path.getmtime(obj) >= hdr_mtime):
         return obj, False
-    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -114,6 +114,19 @@ __device__ __forceinline__ bf16x8 load_frag(const unsigned short* p) {
     u32x4 v = *reinterpret_cast<const u32x4*>(p);
     return __builtin_bit_cast(bf16x8, v);
 }
+// S = Q Kp^T accumulates in ARCHITECTURAL VGPRs: the softmax reads S with the VALU, and the compiler's own choice for a
+// builtin MFMA result is the AGPR half of the file, which costs a v_accvgpr_read per element and -- with the O
+// accumulators already filling the AGPRs -- a storm of v_accvgpr_mov live-range splits (640 per tile, measured).
+// Inline asm with a tied "+v" accumulator keeps S where the VALU wants it.  hipcc does not model the instruction inside
+// an asm statement: the s_nop covers VALU-write -> MFMA-operand wait states, the caller parks before the first VALU read.
+__device__ __forceinline__ void mfma_vgpr(f32x16& acc, bf16x8 a, bf16x8 b) {
+    const u32x4 au = __builtin_bit_cast(u32x4, a), bu = __builtin_bit_cast(u32x4, b);
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(au), "v"(bu));
+}
+
+__device__ __forceinline__ void park_after_mfma(f32x16& x) { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" : "+v"(x)); }
+__device__ __forceinline__ void pin_vgpr(f32x16& x) { asm volatile("" : "+v"(x)); }
+
 // zero the elements of a fragment whose row index is >= valid (bit mask on the bf16 pairs: NaN-proof)
 __device__ __forceinline__ bf16x8 mask_frag(bf16x8 f, int valid) {
     u32x4 w = __builtin_bit_cast(u32x4, f);
@@ -377,12 +390,20 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
                     if constexpr (kb & 1)
-                        s_acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kb], kfb[jb], s_acc[jb], 0, 0, 0);
+                        mfma_vgpr(s_acc[jb], qf[kb], kfb[jb]);
                     else
-                        s_acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kb], kfa[jb], s_acc[jb], 0, 0, 0);
+                        mfma_vgpr(s_acc[jb], qf[kb], kfa[jb]);
                 });
             });
             __builtin_amdgcn_sched_barrier(0);
+            // MFMA result -> VALU read hazard of the asm MFMAs above (the compiler does not see them as MFMAs): park for
+            // the full pipeline depth once per tile; the "+v" operands pin every later read of S behind this point
+            static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
+                if constexpr (jb == 0)
+                    park_after_mfma(s_acc[jb]);
+                else
+                    pin_vgpr(s_acc[jb]);
+            });
         }
         stamp(1);
         if (published) {
