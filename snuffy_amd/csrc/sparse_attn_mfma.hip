@@ -124,6 +124,11 @@ __device__ __forceinline__ void mfma_vgpr(f32x16& acc, bf16x8 a, bf16x8 b) {
     asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(au), "v"(bu));
 }
 
+// first MFMA of an accumulation chain: C is the inline constant 0, D is write-only (early clobber: never overlaps A / B)
+__device__ __forceinline__ void mfma_vgpr_zero_c(f32x16& acc, bf16x8 a, bf16x8 b) {
+    const u32x4 au = __builtin_bit_cast(u32x4, a), bu = __builtin_bit_cast(u32x4, b);
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(au), "v"(bu));
+}
 __device__ __forceinline__ void park_after_mfma(f32x16& x) { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" : "+v"(x)); }
 __device__ __forceinline__ void pin_vgpr(f32x16& x) { asm volatile("" : "+v"(x)); }
 
@@ -366,36 +371,37 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
         //      the MFMAs of the current one issue
         f32x16 s_acc[NKB];
         {
-            // k-step outer, key block inner: consecutive MFMAs hit different accumulators (no dependent-issue stall).
-            // The NKB Kp fragments of step kb+1 are requested from LDS BEFORE the NKB MFMAs of step kb issue, so the
-            // LDS latency hides under ~NKB*32 cycles of matrix work; the sched_barrier fences pin that order (the
-            // scheduler otherwise sinks every read next to its use and the wave parks on lgkmcnt 56 times per tile).
-            bf16x8 kfa[NKB], kfb[NKB];
-            static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
-                kfa[jb] = __builtin_bit_cast(bf16x8, lds_kp[(jb * NKS) * 64 + lane]);
-                // padded keys (only possible in the last two blocks, see make_plan) start at -inf: exp() gives 0
-                const float init = (jb >= NKB - 2 && 32 * jb + j >= P.k) ? -INFINITY : 0.f;
+            // k-step outer, key block inner (m = kb * NKB + jb): consecutive MFMAs hit different accumulators, so there is
+            // no dependent-issue stall.  The asm MFMAs keep their program order, which lets a 4-deep ring of Kp fragments
+            // (16 VGPRs) stay exactly 4 MFMAs (~128 cycles) ahead of its consumer -- enough to cover the LDS latency.
+            constexpr int M1 = NKB * NKS;
+            constexpr int RING = 4;
+            bf16x8 kf[RING];
+            static_for<0, (M1 < RING ? M1 : RING)>([&](auto m_t) __attribute__((always_inline)) {
+                constexpr int m = decltype(m_t)::value;
+                kf[m] = __builtin_bit_cast(bf16x8, lds_kp[((m % NKB) * NKS + m / NKB) * 64 + lane]);
+            });
+            static_for<0, M1>([&](auto m_t) __attribute__((always_inline)) {
+                constexpr int m = decltype(m_t)::value;
+                constexpr int kb = m / NKB, jb = m % NKB;
+                if constexpr (kb == 0) {
+                    if constexpr (jb >= NKB - 2) {
+                        // padded keys (only possible in the last two blocks, see make_plan) start at -inf: exp() gives 0
+                        const float init = (32 * jb + j >= P.k) ? -INFINITY : 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s_acc[jb][r] = (jb >= NKB - 2) ? init : 0.f;
-            });
-            static_for<0, NKS>([&](auto kb_t) __attribute__((always_inline)) {
-                constexpr int kb = decltype(kb_t)::value;
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (kb + 1 < NKS) {
-                    static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
-                        bf16x8 nx = __builtin_bit_cast(bf16x8, lds_kp[(jb * NKS + kb + 1) * 64 + lane]);
-                        if constexpr (kb & 1) kfa[jb] = nx; else kfb[jb] = nx;
-                    });
+                        for (int r = 0; r < 16; ++r) s_acc[jb][r] = init;
+                        mfma_vgpr(s_acc[jb], qf[kb], kf[m % RING]);
+                    } else {
+                        mfma_vgpr_zero_c(s_acc[jb], qf[kb], kf[m % RING]);   // C = inline constant 0: no init moves
+                    }
+                } else {
+                    mfma_vgpr(s_acc[jb], qf[kb], kf[m % RING]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
-                    if constexpr (kb & 1)
-                        mfma_vgpr(s_acc[jb], qf[kb], kfb[jb]);
-                    else
-                        mfma_vgpr(s_acc[jb], qf[kb], kfa[jb]);
-                });
+                if constexpr (m + RING < M1) {
+                    constexpr int mn = m + RING;
+                    kf[m % RING] = __builtin_bit_cast(bf16x8, lds_kp[((mn % NKB) * NKS + mn / NKB) * 64 + lane]);
+                }
             });
-            __builtin_amdgcn_sched_barrier(0);
             // MFMA result -> VALU read hazard of the asm MFMAs above (the compiler does not see them as MFMAs): park for
             // the full pipeline depth once per tile; the "+v" operands pin every later read of S behind this point
             static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
