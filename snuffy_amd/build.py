@@ -16,7 +16,9 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
 # per-file extras.  The attention kernels never see NaN operands in their max-reductions; without this flag every fmaxf
 # costs two extra canonicalising v_max_f32 x,x,x (IEEE sNaN quieting) and the DPP move cannot fold into the max.
 # (-inf is still honoured: the padded-key masking relies on exp2(-inf) == 0.)
-EXTRA_FLAGS = {"sparse_attn_mfma.hip": ["-fno-honor-nans"], "vit.hip": ["-fno-honor-nans"]}
+# The SLP vectoriser is off for the attention kernel: it pairs the running softmax sums into v_pk_add_f32 and then needs
+# three v_mov per four probabilities to re-pair them for the explicit v_pk_mul / v_cvt_pk of the normalisation.
+EXTRA_FLAGS = {"sparse_attn_mfma.hip": ["-fno-honor-nans", "-fno-slp-vectorize"], "vit.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc():
@@ -42,6 +44,8 @@ def _compile(src, force, hdr_mtime):
             and os.path.getmtime(obj) >= hdr_mtime):
         return obj, False
     cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+    if os.environ.get("SNF_ATTN_DEV"):   # development: only the config-B attention variants (7 key blocks)
+        cmd.insert(1, "-DSNF_ATTN_DEV")
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -43,6 +43,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 constexpr int TILE_ROWS = 128;  // query rows per workgroup step (4 waves x 32)
+// row pitch (bytes) of the bf16 P image in LDS: 64 bytes per key block, an ODD number of 64-byte units (bank rule below)
+constexpr int p_row_bytes(int nkb) { return 64 * (nkb | 1); }
 
 struct AttnParams {
     const void* q;     // [n, ldq]  (ldq = h*dk)
@@ -143,24 +145,53 @@ __device__ __forceinline__ bf16x8 mask_frag(bf16x8 f, int valid) {
     return __builtin_bit_cast(bf16x8, w);
 }
 
-// AUX = the caller asked for the attention matrix and/or the row log-sum-exp (extra stores in the softmax loop).
+// One GEMM2 A operand (P^T fragment: key on the lane, 8 consecutive query rows in registers) out of the row-major P image:
+// two hardware transpose-reads.  ds_read_b64_tr_b16 semantics (probed on gfx950, tools/probes/tr16_probe.hip): every lane
+// supplies the address of its own 8-byte chunk; inside each group of 16 lanes the 16 chunks form a [4 rows][16 columns]
+// bf16 matrix (lane i = row i>>2, columns 4(i&3)..+3) and lane i receives column i.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ bf16x8 lds_read_p_frag(const unsigned char* p0, const unsigned char* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+// all-reduce across the two half-waves (lane l <-> lane l^32) on the VALU: v_permlane32_swap(x, x) = {x.lo, x.lo}, {x.hi, x.hi}
+__device__ __forceinline__ float xhalf_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// AUX = the caller asked for the attention matrix and/or the row log-sum-exp (extra stores after the softmax).
 //
 // Software pipeline of one wave (one wave per SIMD, so MFMA and VALU only overlap inside the wave's own stream):
-//   step t:   GEMM1(t)                                     MFMA   (Kp fragments double-buffered out of LDS)
+//   step t:   GEMM1(t)                                     MFMA   (Kp fragments through a 4-deep register ring out of LDS)
 //             softmax(t)  ||  GEMM2(t-1)                   VALU   ||  MFMA: the 8*NT MFMAs of the PREVIOUS tile are spread
-//                                                          over the 16 row iterations of the softmax
-//             barrier, publish P(t) in LDS, barrier
-//   loads:    one 16-byte fragment per softmax row (Q(t+1) on even rows, V(t) on odd rows, each into the register its
-//             last user just released): HBM requests stream continuously, a full step ahead of their use.
+//                                                          over the 2*NKB slices of the softmax by VALU weight
+//             barrier, publish P(t) in LDS, (barrier after the next GEMM1)
+//   loads:    one 16-byte fragment at a time between the slices (Q(t+1) during the max pass, V(t) as soon as the pending
+//             GEMM2 released the register): HBM requests stream continuously, a full step ahead of their use.
 template <int DK, int NKB, typename QT, bool AUX>
 __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) {
     constexpr int NKS = DK / 16;             // k-steps of GEMM1
     constexpr int NCB = DK / 32;             // 32-wide column blocks of the output
     constexpr int NT = (NKB * NCB + 3) / 4;  // output tiles owned by one wave
     constexpr int M2 = 8 * NT;               // GEMM2 MFMAs per tile and wave
+    constexpr int RS = p_row_bytes(NKB);     // row pitch of the P image
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4* lds_kp = reinterpret_cast<u32x4*>(smem);                    // [NKB][NKS][64]
-    u32x4* lds_p = lds_kp + NKB * NKS * 64;                            // [4 waves][NKB][2][64]
+    u32x4* lds_kp = reinterpret_cast<u32x4*>(smem);                    // [NKB][NKS][64] MFMA A fragments of Kp
+    unsigned char* lds_p = smem + NKB * NKS * 1024;                    // [128 rows][RS] bf16 probabilities, swizzled
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -169,17 +200,34 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     const QT* __restrict__ vt = reinterpret_cast<const QT*>(P.vt);
     const float c_exp = P.scale * 1.44269504088896340736f;
     const int cb = (NCB == 4) ? w : (w & (NCB - 1));
-    const int pj = pi_row(j);
     const int n32 = (int)P.n;
+    const bool attn_vec = AUX && (P.k & 3) == 0 && (reinterpret_cast<uintptr_t>(P.attn) & 15) == 0;
     int trace_it = 0;
     auto stamp = [&](int phase) __attribute__((always_inline)) {
         if (P.trace && blockIdx.x == 0 && lane == 0)
             P.trace[(trace_it * 8 + phase) * 4 + w] = __builtin_amdgcn_s_memtime();
     };
-    auto stamp_abs = [&](int slot) __attribute__((always_inline)) {  // slots 60..63 of the trace: kernel milestones
+    auto stamp_abs = [&](int slot) __attribute__((always_inline)) {  // slots 57, 60..63 of the trace: kernel milestones
         if (P.trace && blockIdx.x == 0 && lane == 0) P.trace[(slot * 8) * 4 + w] = __builtin_amdgcn_s_memtime();
     };
     stamp_abs(60);
+
+    // ---- P image addressing.  Row r of the tile lives at r * RS; the 8-byte chunk c (4 keys) of its 64-byte key-block
+    // segment is stored at chunk position c ^ ((r >> 1) & 7).  RS is an odd multiple of 64 bytes, so
+    //   * a ds_write_b64 group (16 lanes = 16 consecutive rows, same logical chunk) covers all 32 banks exactly once,
+    //   * a transpose-read group (32 lanes = 4 consecutive rows x 64 bytes) covers all 64 banks exactly once.
+    const int prow = 32 * w + j;                  // this lane's query row inside the tile (GEMM1 / softmax side)
+    const int pswz = (prow >> 1) & 7;
+    int waddr[4];                                 // byte offset of chunk (2*c4 + hf) of key block 0 in row prow
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) waddr[c4] = prow * RS + 8 * (((2 * c4) | hf) ^ pswz);
+    // reader (GEMM2 side): lane = group g (16 lanes) x i; rows 8*(g>>1) + 4*s + (i>>2), chunk 4*(g&1) + (i&3)
+    const int rg = lane >> 4, ri = lane & 15;
+    const int rr0 = 8 * (rg >> 1) + (ri >> 2), rr1 = rr0 + 4;
+    const int rch = 4 * (rg & 1) + (ri & 3);
+    // key block of output tile ti of this wave = ti * (4 / NCB) + w / NCB: the wave-dependent part goes into the base
+    const unsigned char* rbase0 = lds_p + rr0 * RS + 8 * (rch ^ ((rr0 >> 1) & 7)) + 64 * (w / NCB);
+    const unsigned char* rbase1 = lds_p + rr1 * RS + 8 * (rch ^ ((rr1 >> 1) & 7)) + 64 * (w / NCB);
 
     const int f_begin = blockIdx.x * P.tiles_per_wg;
     int f_end = f_begin + P.tiles_per_wg;
@@ -193,61 +241,38 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     // All loads are unconditional and in bounds: Q rows are clamped to n-1 (their probabilities are zeroed), V^T is
     // read up to round_up(n, 128) <= ldv (the tail is bit-masked before use).
     auto q_ptr = [&](int a, int t) __attribute__((always_inline)) -> const QT* {
-        const int64_t row0 = (int64_t)t * TILE_ROWS;
-        int64_t qrow = row0 + 32 * w + pj;
-        if (qrow > P.n - 1) qrow = P.n - 1;
-        return q + qrow * P.ldq + a * DK + 8 * hf;
+        int qrow = t * TILE_ROWS + prow;
+        if (qrow > n32 - 1) qrow = n32 - 1;
+        return q + (int64_t)qrow * P.ldq + a * DK + 8 * hf;
     };
     auto v_ptr = [&](int a, int t) __attribute__((always_inline)) -> const QT* {
         const int64_t row0 = (int64_t)t * TILE_ROWS;
         return vt + (int64_t)(a * DK + 32 * cb + j) * P.ldv + row0 + 8 * hf;
     };
-    auto tile_is_tail = [&](int t) __attribute__((always_inline)) -> bool {
-        return (int64_t)(t + 1) * TILE_ROWS > P.n;
-    };
-    // tail of a bag: zero the V rows past n (bit mask, so pad garbage / NaN never reaches the MFMA)
+    auto tile_is_tail = [&](int t) __attribute__((always_inline)) -> bool { return (t + 1) * TILE_ROWS > n32; };
+    // tail of a bag: zero the V rows past n (bit mask, so pad garbage / NaN never reaches the MFMA).  The empty volatile
+    // asm keeps this a real (wave-uniform) branch: if-converted it costs ~170 VALU instructions on EVERY tile.
     auto mask_v_tail = [&](int t) __attribute__((always_inline)) {
-        const int64_t row0 = (int64_t)t * TILE_ROWS;
+        asm volatile("; tail tile: mask V rows >= n");
+        const int row0 = t * TILE_ROWS;
         static_for<0, 8>([&](auto sk) __attribute__((always_inline)) {
-            const int64_t valid = P.n - (row0 + 32 * (sk >> 1) + 16 * (sk & 1) + 8 * hf);
-            vf[sk] = mask_frag(vf[sk], valid > 8 ? 8 : (valid < 0 ? 0 : (int)valid));
+            const int valid = n32 - (row0 + 16 * sk + 8 * hf);
+            vf[sk] = mask_frag(vf[sk], valid > 8 ? 8 : (valid < 0 ? 0 : valid));
         });
     };
-    // one GEMM2 MFMA of the pending tile: m = (s*2 + ks) * NT + ti
+    // one GEMM2 MFMA of the pending tile: m = sk * NT + ti  (sk = 16-row k-step of the tile, ti = output tile of the wave)
     auto gemm2_one = [&](auto m_tag) __attribute__((always_inline)) {
         constexpr int m = decltype(m_tag)::value;
         constexpr int sk = m / NT, ti = m % NT;
         const int t_idx = w + 4 * ti;  // tile = kb * NCB + cb ; cb == t_idx % NCB is constant per wave
         if (NT * 4 == NKB * NCB || t_idx < NKB * NCB) {
-            const int kb = t_idx / NCB;
-            bf16x8 pf = __builtin_bit_cast(bf16x8, lds_p[(((sk >> 1) * NKB + kb) * 2 + (sk & 1)) * 64 + lane]);
+            constexpr int off = sk * 16 * RS + ti * (4 / NCB) * 64;
+            const bf16x8 pf = lds_read_p_frag(rbase0 + off, rbase1 + off);
             acc_o[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vf[sk], acc_o[ti], 0, 0, 0);
         }
     };
-    auto gemm2_range = [&](auto lo_tag, auto hi_tag) __attribute__((always_inline)) {
-        constexpr int lo = decltype(lo_tag)::value, hi = decltype(hi_tag)::value;
-        if constexpr (lo < hi) {
-            gemm2_one(std::integral_constant<int, lo>{});
-            if constexpr (lo + 1 < hi) gemm2_one(std::integral_constant<int, lo + 1>{});
-            if constexpr (lo + 2 < hi) gemm2_one(std::integral_constant<int, lo + 2>{});
-            if constexpr (lo + 3 < hi) gemm2_one(std::integral_constant<int, lo + 3>{});
-            if constexpr (lo + 4 < hi) gemm2_one(std::integral_constant<int, lo + 4>{});
-            if constexpr (lo + 5 < hi) gemm2_one(std::integral_constant<int, lo + 5>{});
-            if constexpr (lo + 6 < hi) gemm2_one(std::integral_constant<int, lo + 6>{});
-            if constexpr (lo + 7 < hi) gemm2_one(std::integral_constant<int, lo + 7>{});
-            static_assert(hi - lo <= 8, "GEMM2 slice too long");
-        }
-    };
     auto gemm2_all = [&]() __attribute__((always_inline)) {
-        gemm2_range(std::integral_constant<int, 0>{}, std::integral_constant<int, (M2 >= 8 ? 8 : M2)>{});
-        if constexpr (M2 > 8) gemm2_range(std::integral_constant<int, 8>{}, std::integral_constant<int, (M2 >= 16 ? 16 : M2)>{});
-        if constexpr (M2 > 16) gemm2_range(std::integral_constant<int, 16>{}, std::integral_constant<int, (M2 >= 24 ? 24 : M2)>{});
-        if constexpr (M2 > 24) gemm2_range(std::integral_constant<int, 24>{}, std::integral_constant<int, (M2 >= 32 ? 32 : M2)>{});
-        if constexpr (M2 > 32) gemm2_range(std::integral_constant<int, 32>{}, std::integral_constant<int, (M2 >= 40 ? 40 : M2)>{});
-        if constexpr (M2 > 40) gemm2_range(std::integral_constant<int, 40>{}, std::integral_constant<int, (M2 >= 48 ? 48 : M2)>{});
-        if constexpr (M2 > 48) gemm2_range(std::integral_constant<int, 48>{}, std::integral_constant<int, (M2 >= 56 ? 56 : M2)>{});
-        if constexpr (M2 > 56) gemm2_range(std::integral_constant<int, 56>{}, std::integral_constant<int, M2>{});
-        static_assert(M2 <= 64, "GEMM2 too long");
+        static_for<0, M2>([&](auto m_tag) __attribute__((always_inline)) { gemm2_one(m_tag); });
     };
 
     auto flush = [&](int head) __attribute__((always_inline)) {
@@ -311,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
         __builtin_amdgcn_sched_barrier(0);
         // pipeline fill: nothing pending -> P image and V fragments are zero, so the first interleaved GEMM2 adds 0
         const u32x4 z = {0u, 0u, 0u, 0u};
-        for (int i = threadIdx.x; i < 4 * NKB * 2 * 64; i += 256) lds_p[i] = z;
+        for (int i = threadIdx.x; i < TILE_ROWS * RS / 16; i += 256) reinterpret_cast<u32x4*>(lds_p)[i] = z;
 #pragma unroll
         for (int i = 0; i < 8; ++i) vf[i] = zero_frag();
 #pragma unroll
@@ -331,8 +356,7 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     bool published = false;      // a P image was written and its closing barrier has not been passed yet
     int pend_t = 0;
     for (int f = f_begin; f < f_end; ++f) {
-        const int64_t row0 = (int64_t)t * TILE_ROWS;
-        const int my_row0 = (int)row0 + 32 * w;
+        const int row = t * TILE_ROWS + prow;   // this lane's query row
         int an = a, tn = t + 1;   // next work item
         if (tn == P.tiles_per_head) {
             tn = 0;
@@ -367,8 +391,8 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
         }
 
         stamp(0);
-        // ---- GEMM1: S[32 rows, 32*NKB keys] = Q Kp^T ; Kp fragments of the next key block are fetched from LDS while
-        //      the MFMAs of the current one issue
+        // ---- GEMM1 (swapped): S^T[key, row] = Kp Q^T.  A = Kp fragment (LDS), B = Q fragment: the C layout puts this
+        //      lane's ONE query row (column j) in registers -- 16 keys per block: key = 32 jb + (r&3) + 8 (r>>2) + 4 hf.
         f32x16 s_acc[NKB];
         {
             // k-step outer, key block inner (m = kb * NKB + jb): consecutive MFMAs hit different accumulators, so there is
@@ -385,17 +409,18 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
                 constexpr int m = decltype(m_t)::value;
                 constexpr int kb = m / NKB, jb = m % NKB;
                 if constexpr (kb == 0) {
-                    if constexpr (jb >= NKB - 2) {
-                        // padded keys (only possible in the last two blocks, see make_plan) start at -inf: exp() gives 0
-                        const float init = (32 * jb + j >= P.k) ? -INFINITY : 0.f;
+                    // padded keys (only possible in the last two blocks, see make_plan) start at -inf: exp() gives 0.
+                    // The test is wave-uniform; a full block takes the zero-C form (no init moves at all).
+                    if (jb >= NKB - 2 && P.k < 32 * jb + 32) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) s_acc[jb][r] = init;
-                        mfma_vgpr(s_acc[jb], qf[kb], kf[m % RING]);
+                        for (int r = 0; r < 16; ++r)
+                            s_acc[jb][r] = (32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hf >= P.k) ? -INFINITY : 0.f;
+                        mfma_vgpr(s_acc[jb], kf[m % RING], qf[kb]);
                     } else {
-                        mfma_vgpr_zero_c(s_acc[jb], qf[kb], kf[m % RING]);   // C = inline constant 0: no init moves
+                        mfma_vgpr_zero_c(s_acc[jb], kf[m % RING], qf[kb]);   // C = inline constant 0
                     }
                 } else {
-                    mfma_vgpr(s_acc[jb], qf[kb], kf[m % RING]);
+                    mfma_vgpr(s_acc[jb], kf[m % RING], qf[kb]);
                 }
                 if constexpr (m + RING < M1) {
                     constexpr int mn = m + RING;
@@ -414,74 +439,117 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
         stamp(1);
         if (published) {
             __syncthreads();   // closes the previous publish: placed AFTER GEMM1 so that the matrix work of this tile
-            published = false; // overlaps the other waves' bf16 conversion + LDS writes
+            published = false; // overlaps the other waves' LDS writes
         }
-        // Streaming loads, one 16-byte fragment per softmax row so HBM requests flow continuously instead of in one
-        // burst per step: Q(t+1) fragment kb goes out after row 2kb (qf is free since GEMM1), V(t) fragment sk after
-        // row 2sk+1 (the pending GEMM2 slices of rows <= 2sk+1 were the last users of vf[sk]).
         const bool has_next = f + 1 < f_end;
         const QT* qnext = q_ptr(has_next ? an : a, has_next ? tn : t);
         const QT* vcur = v_ptr(a, t);
         if (pending_tail) mask_v_tail(pend_t);
 
-        // ---- softmax over keys (lanes of a half-wave x NKB blocks), fp32, with GEMM2 of the pending tile interleaved
-        auto softmax_row = [&](auto r_tag) __attribute__((always_inline)) {
-            constexpr int r = decltype(r_tag)::value;
-            float m = s_acc[0][r];
-            static_for<1, NKB>([&](auto jb) __attribute__((always_inline)) { m = fmaxf(m, s_acc[jb][r]); });
-            m = half_allmax(m);
-            const float mc = m * c_exp;
-            float l = 0.f;
-            static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
-                float e = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r], c_exp, -mc));
-                s_acc[jb][r] = e;
-                l += e;
+        // ---- softmax over the keys of this lane's row: 16*NKB values in registers + the partner lane (l ^ 32), fp32.
+        // The pending GEMM2 is spread over 2*NKB slices in proportion to their VALU time: NT MFMAs under the max pass,
+        // the other 7*NT under the exp pass.  V fragment sk is re-loaded as soon as MFMA (sk+1)*NT - 1 has issued.
+        constexpr int MA = NT, MB = M2 - MA;
+        auto slice = [&](auto lo_t, auto hi_t) __attribute__((always_inline)) {
+            constexpr int lo = decltype(lo_t)::value, hi = decltype(hi_t)::value;
+            static_for<lo, hi>([&](auto m_tag) __attribute__((always_inline)) { gemm2_one(m_tag); });
+            static_for<lo / NT, hi / NT>([&](auto sk_t) __attribute__((always_inline)) {
+                constexpr int sk = decltype(sk_t)::value;
+                vf[sk] = load_frag(vcur + 16 * sk);
             });
-            l = half_allsum(l);
-            const int row = my_row0 + (r & 7) + 8 * hf + 16 * (r >> 3);
-            const bool rvalid = row < n32;
-            const float inv = rvalid ? __builtin_amdgcn_rcpf(l) : 0.f;
-            static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) { s_acc[jb][r] *= inv; });
-            if constexpr (AUX) {
-                if (P.lse && rvalid && j == 0) P.lse[(int64_t)a * P.n + row] = m * P.scale + __logf(l);
-                if (P.attn && rvalid) {
-                    float* arow = P.attn + ((int64_t)a * P.n + row) * P.k;
-                    static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
-                        const int key = 32 * jb + j;
-                        if (key < P.k) arow[key] = s_acc[jb][r];
-                    });
-                }
-            }
-            // slice r of the pending GEMM2
-            gemm2_range(std::integral_constant<int, (r * M2) / 16>{}, std::integral_constant<int, ((r + 1) * M2) / 16>{});
         };
-        static_for<0, 16>([&](auto r_tag) __attribute__((always_inline)) {
-            constexpr int r = decltype(r_tag)::value;
-            softmax_row(r_tag);
-            if constexpr ((r & 1) == 0) {
-                if constexpr (r / 2 < NKS) qf[r / 2] = load_frag(qnext + 16 * (r / 2));
-            } else {
-                constexpr int sk = r / 2;
-                vf[sk] = load_frag(vcur + 32 * (sk >> 1) + 16 * (sk & 1));
+        float mx0 = s_acc[0][0], mx1 = s_acc[0][1];
+        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
+            constexpr int jb = decltype(jb_t)::value;
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                mx0 = fmaxf(fmaxf(mx0, s_acc[jb][r]), s_acc[jb][r + 1]);
+                mx1 = fmaxf(fmaxf(mx1, s_acc[jb][r + 2]), s_acc[jb][r + 3]);
+            }
+            static_for<(jb * NKS) / NKB, ((jb + 1) * NKS) / NKB>([&](auto kb_t) __attribute__((always_inline)) {
+                constexpr int kb = decltype(kb_t)::value;
+                qf[kb] = load_frag(qnext + 16 * kb);
+            });
+            slice(std::integral_constant<int, (jb * MA) / NKB>{}, std::integral_constant<int, ((jb + 1) * MA) / NKB>{});
+        });
+        const float mrow = xhalf_max(fmaxf(mx0, mx1));
+        const float mc = mrow * c_exp;
+        float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+        f32x2 ev[NKB][8];   // exp values as register PAIRS: the normalisation below is one v_pk_mul_f32 + one v_cvt_pk per pair
+        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
+            constexpr int jb = decltype(jb_t)::value;
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r], c_exp, -mc));
+                const float e1 = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r + 1], c_exp, -mc));
+                const float e2 = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r + 2], c_exp, -mc));
+                const float e3 = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r + 3], c_exp, -mc));
+                ev[jb][r / 2] = f32x2{e0, e1};
+                ev[jb][r / 2 + 1] = f32x2{e2, e3};
+                l0 += e0;
+                l1 += e1;
+                l2 += e2;
+                l3 += e3;
+            }
+            slice(std::integral_constant<int, MA + (jb * MB) / NKB>{},
+                  std::integral_constant<int, MA + ((jb + 1) * MB) / NKB>{});
+        });
+        const float lrow = xhalf_sum((l0 + l1) + (l2 + l3));
+        const bool rvalid = row < n32;
+        const float inv = rvalid ? __builtin_amdgcn_rcpf(lrow) : 0.f;
+        if constexpr (AUX) {
+            if (P.lse && rvalid && hf == 0) P.lse[(int64_t)a * P.n + row] = mrow * P.scale + __logf(lrow);
+        }
+        if constexpr (AUX) {
+            // attention matrix: this lane owns 4 consecutive keys per (block, c4) of ONE row -> 16-byte stores
+            if (P.attn && rvalid) {
+                float* arow = P.attn + ((int64_t)a * P.n + row) * P.k + 4 * hf;
+                // keys this lane may store, relative to its first one.  Opaque to the optimiser on purpose: the bound is
+                // loop-invariant, and hoisting the 28..112 compare masks out of the tile loop spills ~240 SGPRs.
+                int klim = P.k - 4 * hf;
+                asm volatile("" : "+v"(klim));
+                static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
+                    constexpr int jb = decltype(jb_t)::value;
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const f32x2 p01 = ev[jb][2 * c4] * inv, p23 = ev[jb][2 * c4 + 1] * inv;
+                        constexpr int kb0 = 32 * jb;
+                        const int key0 = kb0 + 8 * c4;
+                        float* dst = arow + key0;
+                        if (attn_vec) {
+                            if (key0 < klim) *reinterpret_cast<f32x4*>(dst) = f32x4{p01[0], p01[1], p23[0], p23[1]};
+                        } else {
+                            if (key0 < klim) dst[0] = p01[0];
+                            if (key0 + 1 < klim) dst[1] = p01[1];
+                            if (key0 + 2 < klim) dst[2] = p23[0];
+                            if (key0 + 3 < klim) dst[3] = p23[1];
+                        }
+                    }
+                });
+            }
+        }
+        // normalise + convert before the barrier: the publish itself is then only the LDS stores
+        u32x2 pk[NKB][4];
+        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
+            constexpr int jb = decltype(jb_t)::value;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const f32x2 p01 = ev[jb][2 * c4] * inv, p23 = ev[jb][2 * c4 + 1] * inv;
+                pk[jb][c4] = u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(p01, bf16x2)),
+                                   __builtin_bit_cast(unsigned, __builtin_convertvector(p23, bf16x2))};
             }
         });
         pending_tail = tile_is_tail(t);
         pend_t = t;
         stamp(2);
 
-
-        // ---- publish P fragments (bf16) for the 4 waves
+        // ---- publish P (bf16, row-major image) for the 4 waves
         __syncthreads();  // every wave finished the GEMM2 reads of the previous image
         stamp(3);
-        static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
+        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
+            constexpr int jb = decltype(jb_t)::value;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                f32x8 pv;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pv[e] = s_acc[jb][8 * ks + e];
-                bf16x8 pb = __builtin_convertvector(pv, bf16x8);
-                lds_p[((w * NKB + jb) * 2 + ks) * 64 + lane] = __builtin_bit_cast(u32x4, pb);
-            }
+            for (int c4 = 0; c4 < 4; ++c4) *reinterpret_cast<u32x2*>(lds_p + waddr[c4] + jb * 64) = pk[jb][c4];
         });
         published = true;
         stamp(4);
@@ -498,6 +566,7 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     }
     stamp_abs(63);
 }
+
 
 // out[key, a*DK + col] = sum over the (workgroup, segment) partials of head a, ascending workgroup order
 template <int DK, int NKB>
@@ -576,7 +645,7 @@ inline bool make_plan(int64_t n, int k, int h, int dk, Plan* pl) {
 template <int DK, int NKB, typename QT, bool AUX>
 int launch_variant(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
     constexpr int NKS = DK / 16;
-    const size_t lds = (size_t)(NKB * NKS + 4 * NKB * 2) * 1024;
+    const size_t lds = (size_t)(NKB * NKS) * 1024 + (size_t)TILE_ROWS * p_row_bytes(NKB);
     static thread_local bool attr_set = false;
     auto kern = sparse_attn_mfma_kernel<DK, NKB, QT, AUX>;
     if (!attr_set) {
@@ -601,12 +670,15 @@ template <int DK, typename QT>
 int launch_nkb(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
     const bool aux = P.attn != nullptr || P.lse != nullptr;
     switch (pl.nkb) {
+#ifndef SNF_ATTN_DEV   // development builds instantiate the config-B shape only (the file takes minutes otherwise)
         case 1: return aux ? launch_variant<DK, 1, QT, true>(P, pl, out, s) : launch_variant<DK, 1, QT, false>(P, pl, out, s);
         case 2: return aux ? launch_variant<DK, 2, QT, true>(P, pl, out, s) : launch_variant<DK, 2, QT, false>(P, pl, out, s);
         case 4: return aux ? launch_variant<DK, 4, QT, true>(P, pl, out, s) : launch_variant<DK, 4, QT, false>(P, pl, out, s);
         case 6: return aux ? launch_variant<DK, 6, QT, true>(P, pl, out, s) : launch_variant<DK, 6, QT, false>(P, pl, out, s);
+        case 8: return aux ? launch_variant<DK, 8, QT, true>(P, pl, out, s) : launch_variant<DK, 8, QT, false>(P, pl, out, s);
+#endif
         case 7: return aux ? launch_variant<DK, 7, QT, true>(P, pl, out, s) : launch_variant<DK, 7, QT, false>(P, pl, out, s);
-        default: return aux ? launch_variant<DK, 8, QT, true>(P, pl, out, s) : launch_variant<DK, 8, QT, false>(P, pl, out, s);
+        default: snf::set_error("sparse_attn_mfma: key-block count %d not built", pl.nkb); return SNF_EUNSUPPORTED;
     }
 }
 
