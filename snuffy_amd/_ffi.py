@@ -8,7 +8,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsnuffy_hip.so")
+# SNUFFY_HIP_LIB: load another build of the same library (A/B timing of kernel variants, tools/ab.sh)
+LIB_PATH = os.environ.get("SNUFFY_HIP_LIB") or os.path.join(_HERE, "lib", "libsnuffy_hip.so")
 
 SNF_OK = 0
 SNF_EINVAL = -1

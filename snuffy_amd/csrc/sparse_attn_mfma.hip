@@ -121,9 +121,16 @@ __device__ __forceinline__ bf16x8 load_frag(const unsigned short* p) {
 // accumulators already filling the AGPRs -- a storm of v_accvgpr_mov live-range splits (640 per tile, measured).
 // Inline asm with a tied "+v" accumulator keeps S where the VALU wants it.  hipcc does not model the instruction inside
 // an asm statement: the s_nop covers VALU-write -> MFMA-operand wait states, the caller parks before the first VALU read.
+// NOP = the two wait states a 32x32 MFMA needs when (a) the previous instruction was an MFMA on the SAME accumulator
+// (back-to-back dependent issue) or (b) an operand may have been written by the VALU just before (f32 -> bf16
+// conversion, accumulator init).  "s_nop 1" is a full 8-cycle issue slot for a single wave, so it is only emitted then.
+template <bool NOP>
 __device__ __forceinline__ void mfma_vgpr(f32x16& acc, bf16x8 a, bf16x8 b) {
     const u32x4 au = __builtin_bit_cast(u32x4, a), bu = __builtin_bit_cast(u32x4, b);
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(au), "v"(bu));
+    if constexpr (NOP)
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(au), "v"(bu));
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(au), "v"(bu));
 }
 
 // first MFMA of an accumulation chain: C is the inline constant 0, D is write-only (early clobber: never overlaps A / B)
@@ -193,6 +200,11 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     u32x4* lds_kp = reinterpret_cast<u32x4*>(smem);                    // [NKB][NKS][64] MFMA A fragments of Kp
     unsigned char* lds_p = smem + NKB * NKS * 1024;                    // [128 rows][RS] bf16 probabilities, swizzled
 
+    // Every kernel argument is requested in the FIRST scalar-load batch: the compiler otherwise fetches k / partial / scale
+    // lazily, and each extra batch is one more cold round trip to the kernarg segment before the first HBM load can go out.
+    asm volatile("" ::"s"(P.q), "s"(P.vt), "s"(P.kp), "s"(P.n), "s"(P.ldq), "s"(P.ldv), "s"(P.k), "s"(P.scale),
+                 "s"(P.partial), "s"(P.tiles_per_head), "s"(P.tiles_per_wg), "s"(P.total_tiles), "s"(P.seg_count),
+                 "s"(P.trace));
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, hf = lane >> 5;
@@ -282,10 +294,14 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
         for (int ti = 0; ti < NT; ++ti) {
             const int t_idx = w + 4 * ti;
             if (t_idx < NKB * NCB) {
+                const int key0 = 32 * (t_idx / NCB);
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
-                    f32x4 v = {acc_o[ti][q4 * 4], acc_o[ti][q4 * 4 + 1], acc_o[ti][q4 * 4 + 2], acc_o[ti][q4 * 4 + 3]};
-                    *reinterpret_cast<f32x4*>(dst + ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4) = v;
+                    // registers 4 q4 .. 4 q4 + 3 hold keys key0 + 8 q4 + 4 hf + i: skip the quads that are padding only
+                    if (key0 + 8 * q4 < P.k) {
+                        f32x4 v = {acc_o[ti][q4 * 4], acc_o[ti][q4 * 4 + 1], acc_o[ti][q4 * 4 + 2], acc_o[ti][q4 * 4 + 3]};
+                        *reinterpret_cast<f32x4*>(dst + ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4) = v;
+                    }
                 }
             }
         }
@@ -331,12 +347,16 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
         if (f_begin < f_end) {
             const QT* qp0 = q_ptr(a, t);
             static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) { qf[kb] = load_frag(qp0 + 16 * kb); });
+            __builtin_amdgcn_sched_barrier(0);
+            stamp_abs(56);
             kp_issue(a, raw0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        stamp_abs(58);
         // pipeline fill: nothing pending -> P image and V fragments are zero, so the first interleaved GEMM2 adds 0
         const u32x4 z = {0u, 0u, 0u, 0u};
         for (int i = threadIdx.x; i < TILE_ROWS * RS / 16; i += 256) reinterpret_cast<u32x4*>(lds_p)[i] = z;
+        stamp_abs(59);
 #pragma unroll
         for (int i = 0; i < 8; ++i) vf[i] = zero_frag();
 #pragma unroll
@@ -415,12 +435,12 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
                             s_acc[jb][r] = (32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hf >= P.k) ? -INFINITY : 0.f;
-                        mfma_vgpr(s_acc[jb], kf[m % RING], qf[kb]);
+                        mfma_vgpr<true>(s_acc[jb], kf[m % RING], qf[kb]);
                     } else {
                         mfma_vgpr_zero_c(s_acc[jb], kf[m % RING], qf[kb]);   // C = inline constant 0
                     }
                 } else {
-                    mfma_vgpr(s_acc[jb], kf[m % RING], qf[kb]);
+                    mfma_vgpr<(NKB == 1) || std::is_same<QT, float>::value>(s_acc[jb], kf[m % RING], qf[kb]);
                 }
                 if constexpr (m + RING < M1) {
                     constexpr int mn = m + RING;
@@ -580,6 +600,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     if (unit >= TILES * 4) return;
     const int lane = threadIdx.x & 63;
     const int t_idx = unit >> 2, q4 = unit & 3;
+    if (32 * (t_idx / NCB) + 8 * q4 >= k) return;   // padding only: never written by the main kernel
     const int f_lo = a * tiles_per_head, f_hi = (a + 1) * tiles_per_head - 1;
     int b_lo = f_lo / tiles_per_wg, b_hi = f_hi / tiles_per_wg;
     if (b_hi > num_wg - 1) b_hi = num_wg - 1;
@@ -589,15 +610,18 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
         const int seg = a - (b * tiles_per_wg) / tiles_per_head;
         return partial + ((int64_t)b * seg_count + seg) * (int64_t)TILES * 1024 + off;
     };
-    int b = b_lo;
-    for (; b + 7 <= b_hi; b += 8) {  // 8 loads in flight; the summation order stays ascending in b (deterministic)
-        f32x4 v[8];
+    // 48 loads in flight (a whole head at the usual 43 contributing workgroups), tail included (a serial tail costs one full memory latency per leftover partial); the summation
+    // order stays ascending in b, so the result is bit-reproducible
+    for (int b = b_lo; b <= b_hi; b += 48) {
+        f32x4 v[48];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src_of(b + u));
+        for (int u = 0; u < 48; ++u) {
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (b + u <= b_hi) v[u] = *reinterpret_cast<const f32x4*>(src_of(b + u));
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+        for (int u = 0; u < 48; ++u) s += v[u];
     }
-    for (; b <= b_hi; ++b) s += *reinterpret_cast<const f32x4*>(src_of(b));
     const int kb = t_idx / NCB, cb = t_idx - kb * NCB;
     const int col = a * DK + 32 * cb + (lane & 31);
 #pragma unroll

@@ -26,9 +26,9 @@ ops.sparse_attn_fwd_mfma(q, vt, kp, N, h)
 torch.cuda.synchronize()
 lib.snf_debug_attn_trace(None)
 t = buf.cpu().view(64, 8, 4)
-pm = [int(t[sl, 0, 0]) for sl in (60, 57, 61)]
-print("prologue detail: entry -> loads issued + LDS/acc init %d | Kp landed, converted, stored, barrier %d"
-      % (pm[1] - pm[0], pm[2] - pm[1]))
+pm = [int(t[sl, 0, 0]) for sl in (60, 56, 58, 59, 57, 61)]
+print("prologue detail: entry -> Q loads issued %d | Kp loads issued %d | P image zeroed %d | accumulators zeroed %d | "
+      "Kp landed, converted, stored, barrier %d" % tuple(pm[i + 1] - pm[i] for i in range(5)))
 ms = [int(t[sl, 0, 0]) for sl in (60, 61, 62, 63)]
 print("kernel milestones (wave 0, s_memtime ticks): prologue(Kp->LDS) %d | main loop %d | drain+flush %d | total %d"
       % (ms[1] - ms[0], ms[2] - ms[1], ms[3] - ms[2], ms[3] - ms[0]))
