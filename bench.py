@@ -66,24 +66,23 @@ def kernel_rooflines(wl, precision, device):
     g = torch.Generator(device="cpu").manual_seed(7)
     dt = torch.bfloat16 if precision == "bf16" else torch.float32
     elt = 2 if precision == "bf16" else 4
-    n8 = ops.vt_leading_dim(N, elt)
     out = {}
     scores = torch.randn(N, generator=g).to(device)
     t_topk = timed(lambda: ops.topk(scores, K), 20)
     kp = torch.randn(K, D, generator=g).to(device)
     # rotate over several operand sets so the 256 MiB Infinity Cache cannot serve the re-reads
     nset = max(2, int(math.ceil(600e6 / (2 * N * D * elt))))
-    qs = [torch.randn(N, D, generator=g).to(device).to(dt) for _ in range(nset)]
-    vts = [torch.randn(D, n8, generator=g).to(device).to(dt) for _ in range(nset)]
+    # Q and V as the model produces them: the two column halves of one fused projection output [N, 2D]
+    qvs = [torch.randn(N, 2 * D, generator=g).to(device).to(dt) for _ in range(nset)]
     state = {"i": 0}
     if ops.mfma_attn_supported(K, dk):
         def attn():
             i = state["i"] = (state["i"] + 1) % nset
-            ops.sparse_attn_fwd_mfma(qs[i], vts[i], kp, N, h)
+            ops.sparse_attn_fwd_mfma(qvs[i][:, :D], qvs[i][:, D:], kp, N, h)
         kern = "sparse_attn_mfma_kernel+reduce_partials_kernel"
     else:
-        vs = [v[:, :N].t().float().contiguous() for v in vts]
-        qf = [q.float() for q in qs]
+        vs = [qv[:, D:].float().contiguous() for qv in qvs]
+        qf = [qv[:, :D].float().contiguous() for qv in qvs]
 
         def attn():
             i = state["i"] = (state["i"] + 1) % nset
@@ -105,7 +104,7 @@ def kernel_rooflines(wl, precision, device):
                                      unit="GB/s", frac=round(b_unit / (t_unit * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                      us_topk=round(t_topk * 1e3, 2), us_attn=round(t_attn * 1e3, 2),
                                      algorithmic_bytes=b_unit)
-    del qs, vts
+    del qvs
     return out
 
 

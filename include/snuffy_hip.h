@@ -129,18 +129,19 @@ int snf_ln_mean_head_f32(const float* z, int64_t n, int d, const void* add_bf16,
  *   log-sum-exp of the scaled scores (saved for backward).
  *
  *   snf_sparse_attn_fwd_f32 : exact fp32 arithmetic, any n/k/h/dk.  q, v [n, d]; kp [k, d].
- *   snf_sparse_attn_fwd_mfma: bf16 MFMA (fp32 accumulate), softmax in fp32.  q [n, d] row-major,
- *       vt = V TRANSPOSED [d, ldv] (ldv >= round_up(n, 128), multiple of 8; columns n..ldv-1 are read but
- *       bit-masked, any content is fine), both of dtype qv_dtype (f32 converted in registers, or bf16);
- *       kp [k, d] f32.  Supported: dk in {64, 128}, k <= 256.  Otherwise SNF_EUNSUPPORTED.
+ *   snf_sparse_attn_fwd_mfma: bf16 MFMA (fp32 accumulate), softmax in fp32.  q [n, ldq] and v [n, ldv] row-major
+ *       (ldq, ldv >= d in elements, rows 16-byte aligned: q and v may be the two column halves of ONE fused
+ *       projection output [n, 2d]), both of dtype qv_dtype (f32 converted in registers, or bf16); kp [k, d] f32.
+ *       Supported: dk == 64 with k <= 256, dk == 128 with k <= 224 (Kp + P + V images share the 160 KiB LDS).
+ *       Otherwise SNF_EUNSUPPORTED: the caller picks snf_sparse_attn_fwd_f32.
  *   workspace: deterministic cross-workgroup reduction of the [h, k, dk] accumulators.
  * --------------------------------------------------------------------------------------------------------- */
 size_t snf_sparse_attn_fwd_workspace_bytes(int64_t n, int k, int h, int dk, int mfma);
 int snf_sparse_attn_fwd_f32(const float* q, const float* kp, const float* v, int64_t n, int k, int h, int dk,
                             float scale, float* out, float* attn, float* lse, void* workspace,
                             size_t workspace_bytes, snf_stream_t stream);
-int snf_sparse_attn_fwd_mfma(const void* q, const void* vt, int qv_dtype, int64_t ldv, const float* kp, int64_t n,
-                             int k, int h, int dk, float scale, float* out, float* attn, float* lse,
+int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const float* kp,
+                             int64_t n, int k, int h, int dk, float scale, float* out, float* attn, float* lse,
                              void* workspace, size_t workspace_bytes, snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------

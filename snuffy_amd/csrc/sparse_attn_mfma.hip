@@ -47,10 +47,10 @@ constexpr int TILE_ROWS = 128;  // query rows per workgroup step (4 waves x 32)
 constexpr int p_row_bytes(int nkb) { return 64 * (nkb | 1); }
 
 struct AttnParams {
-    const void* q;     // [n, ldq]  (ldq = h*dk)
-    const void* vt;    // [h*dk, ldv]
+    const void* q;     // [n, ldq]   row-major, head a = columns a*dk .. (a+1)*dk
+    const void* v;     // [n, ldv]   row-major, same column layout
     const float* kp;   // [k, h*dk] f32
-    int64_t n, ldq, ldv;
+    int64_t n, ldq, ldv, ldkp;
     int k, h;
     float scale;
     float* attn;     // [h, n, k] or null
@@ -199,17 +199,18 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* lds_kp = reinterpret_cast<u32x4*>(smem);                    // [NKB][NKS][64] MFMA A fragments of Kp
     unsigned char* lds_p = smem + NKB * NKS * 1024;                    // [128 rows][RS] bf16 probabilities, swizzled
+    unsigned char* lds_v = lds_p + TILE_ROWS * RS;                     // [128 rows][DK] bf16 values of the pending tile
 
     // Every kernel argument is requested in the FIRST scalar-load batch: the compiler otherwise fetches k / partial / scale
     // lazily, and each extra batch is one more cold round trip to the kernarg segment before the first HBM load can go out.
-    asm volatile("" ::"s"(P.q), "s"(P.vt), "s"(P.kp), "s"(P.n), "s"(P.ldq), "s"(P.ldv), "s"(P.k), "s"(P.scale),
+    asm volatile("" ::"s"(P.q), "s"(P.v), "s"(P.kp), "s"(P.n), "s"(P.ldq), "s"(P.ldv), "s"(P.k), "s"(P.scale),
                  "s"(P.partial), "s"(P.tiles_per_head), "s"(P.tiles_per_wg), "s"(P.total_tiles), "s"(P.seg_count),
                  "s"(P.trace));
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, hf = lane >> 5;
     const QT* __restrict__ q = reinterpret_cast<const QT*>(P.q);
-    const QT* __restrict__ vt = reinterpret_cast<const QT*>(P.vt);
+    const QT* __restrict__ vg = reinterpret_cast<const QT*>(P.v);
     const float c_exp = P.scale * 1.44269504088896340736f;
     const int cb = (NCB == 4) ? w : (w & (NCB - 1));
     const int n32 = (int)P.n;
@@ -241,6 +242,22 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     const unsigned char* rbase0 = lds_p + rr0 * RS + 8 * (rch ^ ((rr0 >> 1) & 7)) + 64 * (w / NCB);
     const unsigned char* rbase1 = lds_p + rr1 * RS + 8 * (rch ^ ((rr1 >> 1) & 7)) + 64 * (w / NCB);
 
+    // ---- V image.  V arrives ROW-major (it comes out of the same GEMM as Q): each wave fetches 32 rows of the tile with
+    // fully coalesced 16-byte loads (one row = DK/8 chunks of 8 columns), parks them in registers for the rest of the step
+    // and stores them next to the P image at publish time; GEMM2 reads its B fragments (column on the lane, 8 consecutive
+    // rows in registers) back with the same hardware transpose-read as P.  Row pitch = 2*DK bytes, no padding: chunk c of
+    // row r sits at chunk position (c + 4 rot(r)) mod NCH, which spreads the 4 rows x 64 bytes of a transpose-read group
+    // over all 64 banks (rot = r & 3 for DK = 128, (r >> 1) & 1 for DK = 64: rows of 128 bytes already alternate halves).
+    constexpr int VRS = 2 * DK, NCH = DK / 8;     // row pitch (bytes), 16-byte chunks per row
+    constexpr int RPI = 64 / NCH, NVI = 32 / RPI; // rows per load instruction, load instructions per wave and tile
+    auto vrot = [](int r) __attribute__((always_inline)) -> int { return DK == 128 ? (r & 3) : ((r >> 1) & 1); };
+    const int vl_row = lane / NCH, vl_ch = lane % NCH;          // loader: row inside the instruction, chunk
+    const int vwaddr = (32 * w + vl_row) * VRS + 16 * ((vl_ch + 4 * vrot(vl_row)) & (NCH - 1));   // + i * RPI * VRS
+    const int vr0 = 8 * (rg >> 1) + (ri >> 2), vr1 = vr0 + 4;   // reader: rows of the two transpose-reads
+    const int vrc = 4 * cb + 2 * (rg & 1) + ((ri & 3) >> 1);     // chunk of this lane's 4 columns, + 8 * (ri & 1) bytes
+    const unsigned char* vbase0 = lds_v + vr0 * VRS + 16 * ((vrc + 4 * vrot(vr0)) & (NCH - 1)) + 8 * (ri & 1);
+    const unsigned char* vbase1 = lds_v + vr1 * VRS + 16 * ((vrc + 4 * vrot(vr1)) & (NCH - 1)) + 8 * (ri & 1);
+
     const int f_begin = blockIdx.x * P.tiles_per_wg;
     int f_end = f_begin + P.tiles_per_wg;
     if (f_end > P.total_tiles) f_end = P.total_tiles;
@@ -248,43 +265,57 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
 
     f32x16 acc_o[NT];
     bf16x8 qf[NKS];  // Q fragments of the tile about to enter GEMM1
-    bf16x8 vf[8];    // V fragments of the tile whose GEMM2 is pending (P already in LDS)
+    bf16x8 vld[NVI];  // this wave's 32 rows of V(t), in flight / parked until the publish
+    bf16x8 vfr[2];    // B fragments of the current and the next GEMM2 k-step (read one k-step ahead)
 
-    // All loads are unconditional and in bounds: Q rows are clamped to n-1 (their probabilities are zeroed), V^T is
-    // read up to round_up(n, 128) <= ldv (the tail is bit-masked before use).
-    auto q_ptr = [&](int a, int t) __attribute__((always_inline)) -> const QT* {
+    // All loads are unconditional and in bounds: Q and V rows are clamped to n-1; the probabilities of those rows are
+    // zeroed, so whatever (finite) row they re-read contributes nothing.  Element offsets are 32-bit (make_plan checks
+    // n * ld < 2^31) and row * ld is one v_mad_u32_u24: the pointer arithmetic of a tile is ~3 VALU per load, not ~11.
+    const int ldq32 = (int)P.ldq, ldv32 = (int)P.ldv;
+    auto q_off = [&](int a, int t) __attribute__((always_inline)) -> unsigned {
         int qrow = t * TILE_ROWS + prow;
         if (qrow > n32 - 1) qrow = n32 - 1;
-        return q + (int64_t)qrow * P.ldq + a * DK + 8 * hf;
+        return __umul24((unsigned)qrow, (unsigned)ldq32) + (a * DK + 8 * hf);
     };
-    auto v_ptr = [&](int a, int t) __attribute__((always_inline)) -> const QT* {
-        const int64_t row0 = (int64_t)t * TILE_ROWS;
-        return vt + (int64_t)(a * DK + 32 * cb + j) * P.ldv + row0 + 8 * hf;
+    auto v_off = [&](int a, int t, int i) __attribute__((always_inline)) -> unsigned {
+        int vrow = t * TILE_ROWS + 32 * w + RPI * i + vl_row;
+        if (vrow > n32 - 1) vrow = n32 - 1;
+        return __umul24((unsigned)vrow, (unsigned)ldv32) + (a * DK + 8 * vl_ch);
     };
-    auto tile_is_tail = [&](int t) __attribute__((always_inline)) -> bool { return (t + 1) * TILE_ROWS > n32; };
-    // tail of a bag: zero the V rows past n (bit mask, so pad garbage / NaN never reaches the MFMA).  The empty volatile
-    // asm keeps this a real (wave-uniform) branch: if-converted it costs ~170 VALU instructions on EVERY tile.
-    auto mask_v_tail = [&](int t) __attribute__((always_inline)) {
-        asm volatile("; tail tile: mask V rows >= n");
-        const int row0 = t * TILE_ROWS;
-        static_for<0, 8>([&](auto sk) __attribute__((always_inline)) {
-            const int valid = n32 - (row0 + 16 * sk + 8 * hf);
-            vf[sk] = mask_frag(vf[sk], valid > 8 ? 8 : (valid < 0 ? 0 : valid));
-        });
+    // GEMM2 of the pending tile, MFMA m = sk * NT + ti  (sk = 16-row k-step of the tile, ti = output tile of the wave):
+    // A = P^T fragment (key on the lane, 8 rows in registers), B = V fragment, both by transpose-read.  The P fragment of
+    // MFMA m + 3 is requested before MFMA m issues (4-slot ring: one wave per SIMD has nothing else to hide the LDS
+    // latency behind), the V fragment one whole k-step ahead.
+    bf16x8 pfr[4];
+    auto p_read = [&](auto m_tag) __attribute__((always_inline)) {
+        constexpr int m = decltype(m_tag)::value;
+        if constexpr (m < M2) {
+            constexpr int sk = m / NT, ti = m % NT;
+            constexpr int off = sk * 16 * RS + ti * (4 / NCB) * 64;
+            pfr[m % 4] = lds_read_p_frag(rbase0 + off, rbase1 + off);
+        }
     };
-    // one GEMM2 MFMA of the pending tile: m = sk * NT + ti  (sk = 16-row k-step of the tile, ti = output tile of the wave)
     auto gemm2_one = [&](auto m_tag) __attribute__((always_inline)) {
         constexpr int m = decltype(m_tag)::value;
         constexpr int sk = m / NT, ti = m % NT;
         const int t_idx = w + 4 * ti;  // tile = kb * NCB + cb ; cb == t_idx % NCB is constant per wave
-        if (NT * 4 == NKB * NCB || t_idx < NKB * NCB) {
-            constexpr int off = sk * 16 * RS + ti * (4 / NCB) * 64;
-            const bf16x8 pf = lds_read_p_frag(rbase0 + off, rbase1 + off);
-            acc_o[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vf[sk], acc_o[ti], 0, 0, 0);
+        if constexpr (m == 0) {
+            vfr[0] = lds_read_p_frag(vbase0, vbase1);
+            p_read(std::integral_constant<int, 0>{});
+            p_read(std::integral_constant<int, 1>{});
+            p_read(std::integral_constant<int, 2>{});
         }
+        p_read(std::integral_constant<int, m + 3>{});
+        if constexpr (ti == 0 && sk + 1 < 8)
+            vfr[(sk + 1) & 1] = lds_read_p_frag(vbase0 + (sk + 1) * 16 * VRS, vbase1 + (sk + 1) * 16 * VRS);
+        if (NT * 4 == NKB * NCB || t_idx < NKB * NCB)
+            acc_o[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pfr[m % 4], vfr[sk & 1], acc_o[ti], 0, 0, 0);
     };
     auto gemm2_all = [&]() __attribute__((always_inline)) {
-        static_for<0, M2>([&](auto m_tag) __attribute__((always_inline)) { gemm2_one(m_tag); });
+        static_for<0, M2>([&](auto m_tag) __attribute__((always_inline)) {
+            gemm2_one(m_tag);
+            __builtin_amdgcn_sched_barrier(0);
+        });
     };
 
     auto flush = [&](int head) __attribute__((always_inline)) {
@@ -318,7 +349,7 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
             const int jb = fr / NKS, kb = fr - jb * NKS;
             int key = 32 * jb + j;
             if (key > P.k - 1) key = P.k - 1;
-            const float* src = P.kp + (int64_t)key * P.ldq + a * DK + 16 * kb + 8 * hf;
+            const float* src = P.kp + (int64_t)key * P.ldkp + a * DK + 16 * kb + 8 * hf;
             raw[2 * i] = *reinterpret_cast<const f32x4*>(src);
             raw[2 * i + 1] = *reinterpret_cast<const f32x4*>(src + 4);
         });
@@ -345,7 +376,7 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     {
         f32x4 raw0[2 * NF];
         if (f_begin < f_end) {
-            const QT* qp0 = q_ptr(a, t);
+            const QT* qp0 = q + q_off(a, t);
             static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) { qf[kb] = load_frag(qp0 + 16 * kb); });
             __builtin_amdgcn_sched_barrier(0);
             stamp_abs(56);
@@ -355,10 +386,8 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
         stamp_abs(58);
         // pipeline fill: nothing pending -> P image and V fragments are zero, so the first interleaved GEMM2 adds 0
         const u32x4 z = {0u, 0u, 0u, 0u};
-        for (int i = threadIdx.x; i < TILE_ROWS * RS / 16; i += 256) reinterpret_cast<u32x4*>(lds_p)[i] = z;
+        for (int i = threadIdx.x; i < TILE_ROWS * (RS + VRS) / 16; i += 256) reinterpret_cast<u32x4*>(lds_p)[i] = z;
         stamp_abs(59);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) vf[i] = zero_frag();
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -372,9 +401,7 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
         __syncthreads();
         stamp_abs(61);
     }
-    bool pending_tail = false;   // the pending tile (P published, GEMM2 not yet run) is the last tile of a bag
     bool published = false;      // a P image was written and its closing barrier has not been passed yet
-    int pend_t = 0;
     for (int f = f_begin; f < f_end; ++f) {
         const int row = t * TILE_ROWS + prow;   // this lane's query row
         int an = a, tn = t + 1;   // next work item
@@ -388,19 +415,18 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
                 published = false;
             }
             if (cur_head >= 0) {  // drain the pending tile of the previous head, then flush its accumulators
-                if (pending_tail) mask_v_tail(pend_t);
-                pending_tail = false;
                 gemm2_all();
-#pragma unroll
-                for (int i = 0; i < 8; ++i) vf[i] = zero_frag();
                 flush(cur_head);
             }
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc_o[ti][r] = 0.f;
-            __syncthreads();  // everyone finished reading the previous head's Kp
+            __syncthreads();  // everyone finished reading the previous head's Kp and the drained P / V images
             {
+                // nothing is pending any more: the interleaved GEMM2 of the next step must add zero
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                for (int i = threadIdx.x; i < TILE_ROWS * VRS / 16; i += 256) reinterpret_cast<u32x4*>(lds_v)[i] = z;
                 f32x4 raw[2 * NF];
                 kp_issue(a, raw);
                 __builtin_amdgcn_sched_barrier(0);   // do not let the conversions pull the loads apart
@@ -462,65 +488,63 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
             published = false; // overlaps the other waves' LDS writes
         }
         const bool has_next = f + 1 < f_end;
-        const QT* qnext = q_ptr(has_next ? an : a, has_next ? tn : t);
-        const QT* vcur = v_ptr(a, t);
-        if (pending_tail) mask_v_tail(pend_t);
+        const QT* qnext = q + q_off(has_next ? an : a, has_next ? tn : t);
 
-        // ---- softmax over the keys of this lane's row: 16*NKB values in registers + the partner lane (l ^ 32), fp32.
-        // The pending GEMM2 is spread over 2*NKB slices in proportion to their VALU time: NT MFMAs under the max pass,
-        // the other 7*NT under the exp pass.  V fragment sk is re-loaded as soon as MFMA (sk+1)*NT - 1 has issued.
-        constexpr int MA = NT, MB = M2 - MA;
-        auto slice = [&](auto lo_t, auto hi_t) __attribute__((always_inline)) {
-            constexpr int lo = decltype(lo_t)::value, hi = decltype(hi_t)::value;
-            static_for<lo, hi>([&](auto m_tag) __attribute__((always_inline)) { gemm2_one(m_tag); });
-            static_for<lo / NT, hi / NT>([&](auto sk_t) __attribute__((always_inline)) {
-                constexpr int sk = decltype(sk_t)::value;
-                vf[sk] = load_frag(vcur + 16 * sk);
-            });
-        };
-        float mx0 = s_acc[0][0], mx1 = s_acc[0][1];
-        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
-            constexpr int jb = decltype(jb_t)::value;
-#pragma unroll
-            for (int r = 0; r < 16; r += 4) {
-                mx0 = fmaxf(fmaxf(mx0, s_acc[jb][r]), s_acc[jb][r + 1]);
-                mx1 = fmaxf(fmaxf(mx1, s_acc[jb][r + 2]), s_acc[jb][r + 3]);
-            }
-            static_for<(jb * NKS) / NKB, ((jb + 1) * NKS) / NKB>([&](auto kb_t) __attribute__((always_inline)) {
-                constexpr int kb = decltype(kb_t)::value;
-                qf[kb] = load_frag(qnext + 16 * kb);
-            });
-            slice(std::integral_constant<int, (jb * MA) / NKB>{}, std::integral_constant<int, ((jb + 1) * MA) / NKB>{});
-        });
-        const float mrow = xhalf_max(fmaxf(mx0, mx1));
-        const float mc = mrow * c_exp;
-        float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
-        f32x2 ev[NKB][8];   // exp values as register PAIRS: the normalisation below is one v_pk_mul_f32 + one v_cvt_pk per pair
-        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
-            constexpr int jb = decltype(jb_t)::value;
-#pragma unroll
-            for (int r = 0; r < 16; r += 4) {
-                const float e0 = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r], c_exp, -mc));
-                const float e1 = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r + 1], c_exp, -mc));
-                const float e2 = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r + 2], c_exp, -mc));
-                const float e3 = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r + 3], c_exp, -mc));
-                ev[jb][r / 2] = f32x2{e0, e1};
-                ev[jb][r / 2 + 1] = f32x2{e2, e3};
+        // ---- Phase 2: softmax over the keys of this lane's row (16*NKB values in registers + the partner lane l ^ 32,
+        // fp32) with the GEMM2 of the pending tile underneath.  Issue order is pinned slot by slot (one MFMA, its LDS
+        // prefetches, one HBM load, a chunk of softmax steps): left alone, the scheduler requests every P fragment right
+        // before its MFMA and the wave parks on lgkmcnt(0) 56 times per tile.
+        //   steps: 4 NKB max steps | finish max | 8 NKB exp steps (a register pair each) | row sum | 4 NKB normalise+convert
+        constexpr int S_FIN = 4 * NKB, S_EXP0 = S_FIN + 1, S_SUM = S_EXP0 + 8 * NKB, S_NRM0 = S_SUM + 1;
+        constexpr int S_END = S_NRM0 + 4 * NKB;
+        float mx0 = 0.f, mx1 = 0.f, mc = 0.f, mrow = 0.f, l0 = 0.f, l1 = 0.f, lrow = 0.f, inv = 0.f;
+        const bool rvalid = row < n32;
+        f32x2 ev[NKB][8];   // exp values as register PAIRS: the normalisation is one v_pk_mul_f32 + one v_cvt_pk per pair
+        u32x2 pk[NKB][4];
+        auto p2_step = [&](auto st_t) __attribute__((always_inline)) {
+            constexpr int st = decltype(st_t)::value;
+            if constexpr (st < S_FIN) {
+                constexpr int jb = st / 4, r = 4 * (st % 4);
+                if constexpr (st == 0) {
+                    mx0 = fmaxf(s_acc[0][0], s_acc[0][1]);
+                    mx1 = fmaxf(s_acc[0][2], s_acc[0][3]);
+                } else {
+                    mx0 = fmaxf(fmaxf(mx0, s_acc[jb][r]), s_acc[jb][r + 1]);
+                    mx1 = fmaxf(fmaxf(mx1, s_acc[jb][r + 2]), s_acc[jb][r + 3]);
+                }
+            } else if constexpr (st == S_FIN) {
+                mrow = xhalf_max(fmaxf(mx0, mx1));
+                mc = mrow * c_exp;
+            } else if constexpr (st < S_SUM) {
+                constexpr int e = st - S_EXP0, jb = e / 8, pr = e % 8;
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][2 * pr], c_exp, -mc));
+                const float e1 = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][2 * pr + 1], c_exp, -mc));
+                ev[jb][pr] = f32x2{e0, e1};
                 l0 += e0;
                 l1 += e1;
-                l2 += e2;
-                l3 += e3;
+            } else if constexpr (st == S_SUM) {
+                lrow = xhalf_sum(l0 + l1);
+                inv = rvalid ? __builtin_amdgcn_rcpf(lrow) : 0.f;
+            } else {
+                constexpr int u = st - S_NRM0, jb = u / 4, c4 = u % 4;
+                const f32x2 p01 = ev[jb][2 * c4] * inv, p23 = ev[jb][2 * c4 + 1] * inv;
+                pk[jb][c4] = u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(p01, bf16x2)),
+                                   __builtin_bit_cast(unsigned, __builtin_convertvector(p23, bf16x2))};
+                asm volatile("" : "+v"(pk[jb][c4]));   // keep the conversion under the MFMAs, not behind the barrier
             }
-            slice(std::integral_constant<int, MA + (jb * MB) / NKB>{},
-                  std::integral_constant<int, MA + ((jb + 1) * MB) / NKB>{});
+        };
+        constexpr int S_MFMA = AUX ? S_NRM0 : S_END;   // steps that run under the MFMAs
+        static_for<0, M2>([&](auto m_t) __attribute__((always_inline)) {
+            constexpr int m = decltype(m_t)::value;
+            gemm2_one(m_t);
+            if constexpr (m < NKS) qf[m] = load_frag(qnext + 16 * m);
+            if constexpr (m >= NKS && m < NKS + NVI) vld[m - NKS] = load_frag(vg + v_off(a, t, m - NKS));
+            static_for<(m * S_MFMA) / M2, ((m + 1) * S_MFMA) / M2>([&](auto st_t) __attribute__((always_inline)) { p2_step(st_t); });
+            __builtin_amdgcn_sched_barrier(0);
         });
-        const float lrow = xhalf_sum((l0 + l1) + (l2 + l3));
-        const bool rvalid = row < n32;
-        const float inv = rvalid ? __builtin_amdgcn_rcpf(lrow) : 0.f;
         if constexpr (AUX) {
+            // with the attention matrix / log-sum-exp outputs the normalised fp32 row is stored before it is converted
             if (P.lse && rvalid && hf == 0) P.lse[(int64_t)a * P.n + row] = mrow * P.scale + __logf(lrow);
-        }
-        if constexpr (AUX) {
             // attention matrix: this lane owns 4 consecutive keys per (block, c4) of ONE row -> 16-byte stores
             if (P.attn && rvalid) {
                 float* arow = P.attn + ((int64_t)a * P.n + row) * P.k + 4 * hf;
@@ -547,29 +571,21 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
                     }
                 });
             }
+            static_for<S_NRM0, S_END>([&](auto st_t) __attribute__((always_inline)) { p2_step(st_t); });
         }
-        // normalise + convert before the barrier: the publish itself is then only the LDS stores
-        u32x2 pk[NKB][4];
-        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
-            constexpr int jb = decltype(jb_t)::value;
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                const f32x2 p01 = ev[jb][2 * c4] * inv, p23 = ev[jb][2 * c4 + 1] * inv;
-                pk[jb][c4] = u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(p01, bf16x2)),
-                                   __builtin_bit_cast(unsigned, __builtin_convertvector(p23, bf16x2))};
-            }
-        });
-        pending_tail = tile_is_tail(t);
-        pend_t = t;
         stamp(2);
 
-        // ---- publish P (bf16, row-major image) for the 4 waves
+        // ---- publish P (bf16, row-major image) and this wave's rows of V for the 4 waves
         __syncthreads();  // every wave finished the GEMM2 reads of the previous image
         stamp(3);
         static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
             constexpr int jb = decltype(jb_t)::value;
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) *reinterpret_cast<u32x2*>(lds_p + waddr[c4] + jb * 64) = pk[jb][c4];
+        });
+        static_for<0, NVI>([&](auto i_t) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_t)::value;
+            *reinterpret_cast<u32x4*>(lds_v + vwaddr + i * RPI * VRS) = __builtin_bit_cast(u32x4, vld[i]);
         });
         published = true;
         stamp(4);
@@ -580,7 +596,6 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     stamp_abs(62);
     if (published) __syncthreads();
     if (cur_head >= 0) {
-        if (pending_tail) mask_v_tail(pend_t);
         gemm2_all();  // drain the last pending tile
         flush(cur_head);
     }
@@ -638,7 +653,7 @@ struct Plan {
 };
 
 inline bool make_plan(int64_t n, int k, int h, int dk, Plan* pl) {
-    if (!(dk == 64 || dk == 128) || k < 1 || k > 256) return false;
+    if (!(dk == 64 || dk == 128) || k < 1 || k > (dk == 128 ? 224 : 256)) return false;   // LDS: Kp + P + V images
     int nkb = (k + 31) / 32;
     // instantiated key-block counts
     const int opts[] = {1, 2, 4, 6, 7, 8};
@@ -649,7 +664,7 @@ inline bool make_plan(int64_t n, int k, int h, int dk, Plan* pl) {
             break;
         }
     if (!sel) return false;
-    if (n > 0x7fffff00ll) return false;   // 32-bit row arithmetic inside the kernel
+    if (n > 0xffff00ll) return false;   // 24-bit row x pitch products inside the kernel
     int64_t tph = (n + TILE_ROWS - 1) / TILE_ROWS;
     int64_t total = tph * h;
     if (total > 0x7fffffff) return false;
@@ -669,7 +684,7 @@ inline bool make_plan(int64_t n, int k, int h, int dk, Plan* pl) {
 template <int DK, int NKB, typename QT, bool AUX>
 int launch_variant(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
     constexpr int NKS = DK / 16;
-    const size_t lds = (size_t)(NKB * NKS) * 1024 + (size_t)TILE_ROWS * p_row_bytes(NKB);
+    const size_t lds = (size_t)(NKB * NKS) * 1024 + (size_t)TILE_ROWS * (p_row_bytes(NKB) + 2 * DK);
     static thread_local bool attr_set = false;
     auto kern = sparse_attn_mfma_kernel<DK, NKB, QT, AUX>;
     if (!attr_set) {
@@ -727,22 +742,31 @@ size_t snf_sparse_attn_fwd_workspace_bytes(int64_t n, int k, int h, int dk, int 
     return snf::generic_attn_workspace_bytes(n, k, h, dk);
 }
 
-int snf_sparse_attn_fwd_mfma(const void* q, const void* vt, int qv_dtype, int64_t ldv, const float* kp, int64_t n, int k,
-                             int h, int dk, float scale, float* out, float* attn, float* lse, void* workspace,
-                             size_t workspace_bytes, snf_stream_t stream) {
-    SNF_REQUIRE(q && vt && kp && out, "snf_sparse_attn_fwd_mfma: null pointer");
+int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const float* kp,
+                             int64_t n, int k, int h, int dk, float scale, float* out, float* attn, float* lse,
+                             void* workspace, size_t workspace_bytes, snf_stream_t stream) {
+    SNF_REQUIRE(q && v && kp && out, "snf_sparse_attn_fwd_mfma: null pointer");
     SNF_REQUIRE(n >= 1 && k >= 1 && h >= 1, "snf_sparse_attn_fwd_mfma: bad shape");
     SNF_REQUIRE(qv_dtype == SNF_DT_F32 || qv_dtype == SNF_DT_BF16, "snf_sparse_attn_fwd_mfma: bad dtype %d", qv_dtype);
     Plan pl;
     if (!make_plan(n, k, h, dk, &pl)) {
-        snf::set_error("snf_sparse_attn_fwd_mfma: unsupported shape k=%d dk=%d (need dk in {64,128}, k <= 256)", k, dk);
+        snf::set_error("snf_sparse_attn_fwd_mfma: unsupported shape k=%d dk=%d (need dk == 64 with k <= 256, or dk == 128 "
+                       "with k <= 224)", k, dk);
         return SNF_EUNSUPPORTED;
     }
-    SNF_REQUIRE(ldv >= ((n + 127) / 128) * 128 && (ldv % 8) == 0,
-                "snf_sparse_attn_fwd_mfma: ldv=%lld must be >= round_up(n, 128) and a multiple of 8", (long long)ldv);
-    SNF_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (reinterpret_cast<uintptr_t>(vt) & 15) == 0 &&
+    const int64_t d = (int64_t)h * dk;
+    if (ldq >= (1 << 24) || ldv >= (1 << 24) || n * (ldq > ldv ? ldq : ldv) >= 0x7fffffffll) {
+        snf::set_error("snf_sparse_attn_fwd_mfma: n * row pitch = %lld elements exceeds the 32-bit offsets of the kernel",
+                       (long long)(n * (ldq > ldv ? ldq : ldv)));
+        return SNF_EUNSUPPORTED;
+    }
+    const int align = qv_dtype == SNF_DT_BF16 ? 8 : 4;   // 16-byte rows
+    SNF_REQUIRE(ldq >= d && ldv >= d && (ldq % align) == 0 && (ldv % align) == 0,
+                "snf_sparse_attn_fwd_mfma: ldq=%lld / ldv=%lld must be >= h*dk and keep rows 16-byte aligned",
+                (long long)ldq, (long long)ldv);
+    SNF_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(kp) & 15) == 0,
-                "snf_sparse_attn_fwd_mfma: q / vt / kp must be 16-byte aligned");
+                "snf_sparse_attn_fwd_mfma: q / v / kp must be 16-byte aligned");
     const size_t need = mfma_workspace_bytes(pl, dk);
     if (!workspace || workspace_bytes < need) {
         snf::set_error("snf_sparse_attn_fwd_mfma: workspace %zu < %zu", workspace_bytes, need);
@@ -750,11 +774,12 @@ int snf_sparse_attn_fwd_mfma(const void* q, const void* vt, int qv_dtype, int64_
     }
     AttnParams P;
     P.q = q;
-    P.vt = vt;
+    P.v = v;
     P.kp = kp;
     P.n = n;
-    P.ldq = (int64_t)h * dk;
+    P.ldq = ldq;
     P.ldv = ldv;
+    P.ldkp = d;
     P.k = k;
     P.h = h;
     P.scale = scale;

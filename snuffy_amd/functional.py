@@ -5,8 +5,9 @@ Data layout in HBM for one bag (N patches, D features, K selected rows, F = mlp_
   c      [N]     fp32   critic scores
   S      [K]     int64  selected rows (top-Lambda ++ random)
   fp32 path : Xn [N, D] fp32, Q / V [N, D] fp32, hidden [N, F] fp32, z [N, D] fp32
-  bf16 path : xhat [ldv, D] bf16 (row-normalised x, affine folded into the GEMM weights; shared by the Q/V projection and,
-              after re-normalising the K patched rows in place, by the FFN), Q [N, D] bf16, V^T [D, ldv] bf16,
+  bf16 path : xhat [N, D] bf16 (row-normalised x, affine folded into the GEMM weights; shared by the Q/V projection and,
+              after re-normalising the K patched rows in place, by the FFN), [Q | V] [N, 2D] bf16 out of ONE fused
+              projection GEMM (the attention kernel takes the two halves in place through their row pitch),
               hidden [N, F] bf16, FFN out [N, D] bf16; the fp32 residual stream is re-assembled inside the final
               LayerNorm + mean + head kernel.
 """
@@ -177,8 +178,9 @@ def _folded(layer):
     with torch.no_grad():
         g0, b0, g1, b1 = n0.weight, n0.bias, n1.weight, n1.bias
         out = dict(
-            wq=(lq.weight * g0).to(torch.bfloat16), bq=(lq.weight @ b0 + lq.bias).to(torch.bfloat16),
-            wv=(lv.weight * g0).to(torch.bfloat16), bv=(lv.weight @ b0 + lv.bias).to(torch.bfloat16),
+            # Q and V projections as ONE GEMM over the shared normalised input: output [N, 2D] = [Q | V]
+            wqv=torch.cat([lq.weight * g0, lv.weight * g0]).to(torch.bfloat16).contiguous(),
+            bqv=torch.cat([lq.weight @ b0 + lq.bias, lv.weight @ b0 + lv.bias]).to(torch.bfloat16).contiguous(),
             w1=(ff.w_1.weight * g1).to(torch.bfloat16), b1=(ff.w_1.weight @ b1 + ff.w_1.bias).contiguous(),
             b1h=(ff.w_1.weight @ b1 + ff.w_1.bias).to(torch.bfloat16),
             w2=ff.w_2.weight.to(torch.bfloat16),
@@ -233,23 +235,22 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
     if n0.eps != n1.eps:
         raise NotImplementedError("bf16 path shares one normalisation between both sublayers: eps must match")
     fw = _folded(layer)
-    ldv = ops.vt_leading_dim(n, 2)
-    xhat = torch.empty(ldv, d, dtype=torch.bfloat16, device=x2.device)              # rows n..ldv-1: pad, never used
-    ops.layernorm_rows(x2, None, None, n0.eps, out=xhat[:n])
-    q = torch.addmm(fw["bq"], xhat[:n], fw["wq"].t())                               # [N, D]   bf16
-    vt = torch.addmm(fw["bv"].unsqueeze(1), fw["wv"], xhat.t())                     # [D, ldv] bf16  (V transposed)
+    xhat = torch.empty(n, d, dtype=torch.bfloat16, device=x2.device)
+    ops.layernorm_rows(x2, None, None, n0.eps, out=xhat)
+    qv = torch.addmm(fw["bqv"], xhat, fw["wqv"].t())                                # [N, 2D] bf16 = [Q | V], bias epilogue
+    q, v = qv[:, :d], qv[:, d:]                                                     # row-strided views, used in place
     if ops.mfma_attn_supported(k, d // h):
-        o, attn, _ = ops.sparse_attn_fwd_mfma(q, vt, kp, n, h, need_attn=need_attn)
+        o, attn, _ = ops.sparse_attn_fwd_mfma(q, v, kp, n, h, need_attn=need_attn)
     else:
-        o, attn, _ = ops.sparse_attn_fwd(q.float(), kp, vt[:, :n].t().float().contiguous(), h, need_attn=need_attn)
-    del q, vt
+        o, attn, _ = ops.sparse_attn_fwd(q.float(), kp, v.float(), h, need_attn=need_attn)
+    del q, v, qv
     delta = F.linear(o, lo.weight, lo.bias)
     x_sel = xs + delta
     ops.layernorm_rows(x_sel, None, None, n1.eps, out=xhat, out_row_idx=sel)        # re-normalise the K rows in place
     if ff.activation_name == "relu":
-        hid = torch._addmm_activation(fw["b1h"], xhat[:n], fw["w1"].t())            # GEMM + bias + ReLU epilogue
+        hid = torch._addmm_activation(fw["b1h"], xhat, fw["w1"].t())            # GEMM + bias + ReLU epilogue
     else:
-        hid = torch.mm(xhat[:n], fw["w1"].t())                                      # [N, F] bf16
+        hid = torch.mm(xhat, fw["w1"].t())                                          # [N, F] bf16
         ops.bias_act_(hid, fw["b1"], ff.activation_name)
     zb = torch.mm(hid, fw["w2"].t())                                                # [N, D] bf16
     del hid

@@ -209,17 +209,27 @@ def ln_mean_head(z, gamma, beta, eps, w_head, b_head, add_bf16=None, add_bias=No
 
 
 def mfma_attn_supported(k, dk):
-    return dk in (64, 128) and 1 <= k <= 256
+    """Shapes the MFMA attention kernel takes (Kp, P and V images share the 160 KiB LDS of a CU)."""
+    return (dk == 64 and 1 <= k <= 256) or (dk == 128 and 1 <= k <= 224)
 
 
-def vt_leading_dim(n, elt_bytes=2):
-    """Leading dimension (in elements) of the V^T [d, ldv] operand: >= round_up(n, 128) (the kernel reads whole 128-row
-    tiles) and NOT a multiple of 2 KiB in bytes -- a power-of-two pitch makes the 32 column rows one MFMA fragment load
-    touches land on the same HBM channel."""
-    ld = (n + 127) // 128 * 128
-    if (ld * elt_bytes) % 2048 == 0:
-        ld += 64
-    return ld
+def _rows16(t, name):
+    """[n, d] view whose rows are unit-stride and 16-byte aligned (e.g. one half of a fused projection output): the
+    kernels take a row pitch, so such views are used in place.  Anything else is made contiguous."""
+    t = _req_nc(t, name)
+    elt = t.element_size()
+    if t.stride(1) != 1 or (t.stride(0) * elt) % 16 or (t.data_ptr() % 16) or t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def _req_nc(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _ffi.SnuffyHipError(
+            "%s must be a GPU tensor: snuffy_amd runs on MI355X only (no CPU fallback)" % name)
+    if t.dim() != 2:
+        raise ValueError("%s must be 2-D, got shape %s" % (name, tuple(t.shape)))
+    return t
 
 
 def sparse_attn_fwd(q, kp, v, h, scale=None, need_attn=False, need_lse=False):
@@ -246,18 +256,20 @@ def sparse_attn_fwd(q, kp, v, h, scale=None, need_attn=False, need_lse=False):
     return out, attn, lse
 
 
-def sparse_attn_fwd_mfma(q, vt, kp, n, h, scale=None, need_attn=False, need_lse=False):
-    """bf16-MFMA sparse attention. q [n, d]; vt = V^T [d, ldv] (ldv >= n, multiple of 8), both f32 or both bf16;
-    kp [k, d] f32."""
-    if q.dtype not in (torch.float32, torch.bfloat16) or vt.dtype != q.dtype:
-        raise TypeError("sparse_attn_fwd_mfma: q and vt must both be float32 or both bfloat16")
-    q = _req(q, q.dtype, "q", 2)
-    vt = _req(vt, vt.dtype, "vt", 2)
+def sparse_attn_fwd_mfma(q, v, kp, n, h, scale=None, need_attn=False, need_lse=False):
+    """bf16-MFMA sparse attention.  q, v [n, d] row-major (both f32 or both bf16; row-strided views such as the two halves
+    of a fused [n, 2d] projection are taken in place); kp [k, d] f32."""
+    if q.dtype not in (torch.float32, torch.bfloat16) or v.dtype != q.dtype:
+        raise TypeError("sparse_attn_fwd_mfma: q and v must both be float32 or both bfloat16")
+    q = _rows16(q, "q")
+    v = _rows16(v, "v")
     kp = _req(kp, torch.float32, "kp", 2)
     d = q.shape[1]
+    if v.shape[1] != d or q.shape[0] < n or v.shape[0] < n:
+        raise ValueError("sparse_attn_fwd_mfma: q %s / v %s do not hold %d rows of width %d"
+                         % (tuple(q.shape), tuple(v.shape), n, d))
     k = kp.shape[0]
     dk = d // h
-    ldv = vt.shape[1]
     scale = 1.0 / math.sqrt(dk) if scale is None else scale
     lib = _ffi.load()
     out = torch.empty(k, d, dtype=torch.float32, device=q.device)
@@ -266,8 +278,8 @@ def sparse_attn_fwd_mfma(q, vt, kp, n, h, scale=None, need_attn=False, need_lse=
     wsb = lib.snf_sparse_attn_fwd_workspace_bytes(n, k, h, dk, 1)
     ws = _ws(wsb, q.device)
     dt = DT_F32 if q.dtype == torch.float32 else DT_BF16
-    check(lib.snf_sparse_attn_fwd_mfma(_p(q), _p(vt), dt, ldv, _p(kp), n, k, h, dk, float(scale), _p(out), _p(attn),
-                                       _p(lse), _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_mfma")
+    check(lib.snf_sparse_attn_fwd_mfma(_p(q), q.stride(0), _p(v), v.stride(0), dt, _p(kp), n, k, h, dk, float(scale),
+                                       _p(out), _p(attn), _p(lse), _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_mfma")
     return out, attn, lse
 
 

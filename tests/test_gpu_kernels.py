@@ -203,18 +203,16 @@ def bf16r(t):
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("n,k,h,dk", [(1, 1, 1, 64), (100, 31, 2, 64), (128, 32, 6, 64), (129, 33, 3, 128),
                                       (1000, 64, 6, 128), (4099, 100, 6, 64), (2500, 200, 6, 128), (3000, 224, 2, 128),
-                                      (777, 256, 6, 64), (1500, 250, 1, 128), (8192, 200, 6, 64), (640, 129, 4, 128)])
+                                      (777, 256, 6, 64), (1500, 224, 1, 128), (1500, 250, 1, 64), (8192, 200, 6, 64), (640, 129, 4, 128)])
 def test_sparse_attn_mfma(n, k, h, dk, dt):
     g = torch.Generator().manual_seed(n * 3 + k)
     d = h * dk
     q, kp, v = torch.randn(n, d, generator=g), torch.randn(k, d, generator=g), torch.randn(n, d, generator=g)
-    from snuffy_amd.ops import vt_leading_dim
-    n8 = vt_leading_dim(n, 4 if dt == "f32" else 2)
-    vt = torch.full((d, n8), float("nan"))          # poison the pad: it is read but must be masked before use
-    vt[:, :n] = v.t()
     tdt = torch.float32 if dt == "f32" else torch.bfloat16
-    o, attn, lse = ops().sparse_attn_fwd_mfma(q.to(DEV).to(tdt), vt.to(DEV).to(tdt), kp.to(DEV), n, h,
-                                              need_attn=True, need_lse=True)
+    # q and v as the two halves of one fused projection buffer [n, 2d] (row pitch 2d), as the model passes them
+    qv = torch.cat([q, v], dim=1).to(DEV).to(tdt)
+    qd, vd = qv[:, :d], qv[:, d:]
+    o, attn, lse = ops().sparse_attn_fwd_mfma(qd, vd, kp.to(DEV), n, h, need_attn=True, need_lse=True)
     # (a) against the exact oracle: bf16-class tolerance (north star: 1e-2)
     o_ref, p_ref = attn_ref(q, kp, v, h)
     assert (attn.cpu().double() - p_ref).abs().max() < 1e-2
@@ -227,10 +225,10 @@ def test_sparse_attn_mfma(n, k, h, dk, dt):
     assert (attn.sum(-1) - 1).abs().max() < 1e-4
     assert rel_err(o.cpu().view(k, h, dk).sum(0), bf16r(v).view(n, h, dk).sum(0)) < 5e-3
     # run-to-run determinism
-    o2, attn2, _ = ops().sparse_attn_fwd_mfma(q.to(DEV).to(tdt), vt.to(DEV).to(tdt), kp.to(DEV), n, h, need_attn=True)
+    o2, attn2, _ = ops().sparse_attn_fwd_mfma(q.to(DEV).to(tdt), v.to(DEV).to(tdt), kp.to(DEV), n, h, need_attn=True)  # contiguous
     assert torch.equal(o2, o) and torch.equal(attn2, attn)
     # without materialising A the output is the same
-    o3, a3, _ = ops().sparse_attn_fwd_mfma(q.to(DEV).to(tdt), vt.to(DEV).to(tdt), kp.to(DEV), n, h)
+    o3, a3, _ = ops().sparse_attn_fwd_mfma(qd, vd, kp.to(DEV), n, h)
     assert a3 is None and torch.equal(o3, o)
 
 
@@ -242,9 +240,7 @@ def test_sparse_attn_mfma_online_max_spike():
     q, kp, v = torch.randn(n, d, generator=g), torch.randn(k, d, generator=g), torch.randn(n, d, generator=g)
     q[7] *= 40.0
     kp[3] *= 25.0
-    vt = torch.zeros(d, ops().vt_leading_dim(n, 4))
-    vt[:, :n] = v.t()
-    o, attn, _ = ops().sparse_attn_fwd_mfma(q.to(DEV), vt.to(DEV), kp.to(DEV), n, h, need_attn=True)
+    o, attn, _ = ops().sparse_attn_fwd_mfma(q.to(DEV), v.to(DEV), kp.to(DEV), n, h, need_attn=True)
     assert torch.isfinite(o).all() and torch.isfinite(attn).all()
     o_r, p_r = attn_ref(bf16r(q), bf16r(kp), bf16r(v), h)
     assert (attn.cpu().double() - p_r).abs().max() < 5e-3
@@ -255,4 +251,7 @@ def test_mfma_rejects_unsupported_shapes():
     from snuffy_amd import SnuffyHipError
     q = torch.zeros(64, 96, device=DEV)
     with pytest.raises(SnuffyHipError):
-        ops().sparse_attn_fwd_mfma(q, torch.zeros(96, 128, device=DEV), torch.zeros(8, 96, device=DEV), 64, 2)  # dk=48
+        ops().sparse_attn_fwd_mfma(q, torch.zeros(64, 96, device=DEV), torch.zeros(8, 96, device=DEV), 64, 2)  # dk=48
+    q = torch.zeros(64, 256, device=DEV)
+    with pytest.raises(SnuffyHipError):   # dk = 128 holds at most 224 keys next to the P and V images in LDS
+        ops().sparse_attn_fwd_mfma(q, torch.zeros(64, 256, device=DEV), torch.zeros(225, 256, device=DEV), 64, 2)

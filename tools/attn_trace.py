@@ -15,8 +15,8 @@ lib.snf_debug_attn_trace.argtypes = [ctypes.c_void_p]
 lib.snf_debug_attn_trace.restype = None
 N, D, h, K = 32768, 768, 6, int(sys.argv[1]) if len(sys.argv) > 1 else 200
 g = torch.Generator().manual_seed(0)
-q = torch.randn(N, D, generator=g).to(dev).to(torch.bfloat16)
-vt = torch.randn(D, ops.vt_leading_dim(N, 2), generator=g).to(dev).to(torch.bfloat16)
+qv = torch.randn(N, 2 * D, generator=g).to(dev).to(torch.bfloat16)
+q, vt = qv[:, :D], qv[:, D:]
 kp = torch.randn(K, D, generator=g).to(dev)
 for _ in range(3):
     ops.sparse_attn_fwd_mfma(q, vt, kp, N, h)
