@@ -152,8 +152,21 @@ __device__ __forceinline__ unsigned int block_excl_scan_1024(unsigned int v, uns
     return base + incl - v;
 }
 
+// IPT > 0: n <= 1024 * IPT and every thread keeps its IPT keys in registers -- the scores are read from memory ONCE (all
+// loads in flight together) instead of once per counting pass plus once for the collection; one workgroup pays a full
+// memory latency per dependent read round, which is what this kernel's time is made of.  IPT == 0: streaming form, any n.
+template <int IPT>
 __global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restrict__ scores, int64_t n, int64_t stride, int k,
                                                           int64_t* __restrict__ idx_out) {
+    constexpr bool REG = IPT > 0;
+    unsigned int rkey[REG ? IPT : 1];
+    if constexpr (REG) {
+#pragma unroll
+        for (int u = 0; u < IPT; ++u) {
+            const int64_t i = threadIdx.x + (int64_t)u * 1024;
+            rkey[u] = (i < n) ? orderable_desc(scores[i * stride]) : 0u;
+        }
+    }
     __shared__ unsigned int hist[2048];
     __shared__ unsigned long long sel[RS_MAXK];
     __shared__ unsigned int wave_tot[16];
@@ -167,6 +180,13 @@ __global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restric
         const unsigned int nb = 1u << nbits[pass];
         for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
         __syncthreads();
+        if constexpr (REG) {
+#pragma unroll
+            for (int u = 0; u < IPT; ++u) {
+                const int64_t i = tid + (int64_t)u * 1024;
+                if (i < n && (rkey[u] & mask) == prefix) atomicAdd(&hist[(rkey[u] >> shift) & (nb - 1)], 1u);
+            }
+        } else
         for (int64_t i0 = tid; i0 < n; i0 += 8 * 1024) {   // 8 independent loads in flight per thread
             float f[8];
 #pragma unroll
@@ -215,7 +235,18 @@ __global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restric
     }
     __syncthreads();
     const bool take_all_eq = (cnt_eq == krem);
-    if (take_all_eq) {   // common case (no tie straddles the k-th place): unordered append, 8 loads in flight
+    if (take_all_eq && REG) {   // common case (no tie straddles the k-th place): unordered append straight from registers
+        if constexpr (REG) {
+#pragma unroll
+            for (int u = 0; u < IPT; ++u) {
+                const int64_t i = tid + (int64_t)u * 1024;
+                if (i < n && rkey[u] >= T) {
+                    const unsigned int pos = atomicAdd(&s_cnt_sel, 1u);
+                    sel[pos] = ((unsigned long long)rkey[u] << 32) | (unsigned long long)(0xffffffffu - (unsigned int)i);
+                }
+            }
+        }
+    } else     if (take_all_eq) {   // common case (no tie straddles the k-th place): unordered append, 8 loads in flight
         for (int64_t i0 = tid; i0 < n; i0 += 8 * 1024) {
             float f[8];
 #pragma unroll
@@ -260,7 +291,18 @@ __global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restric
         }
     }
     __syncthreads();
-    // sort the k survivors (descending composite == descending score, ascending index)
+    // order the k survivors (descending composite == descending score, ascending index)
+    if (k <= 512) {
+        // rank sort: the composites are distinct, so #(greater) IS the output position.  k broadcast LDS reads per thread and
+        // no further barrier -- the bitonic network below costs log2(k)^2 / 2 workgroup barriers (36 at k = 200).
+        if (tid < k) {
+            const unsigned long long mine = sel[tid];
+            int rank = 0;
+            for (int j2 = 0; j2 < k; ++j2) rank += (sel[j2] > mine) ? 1 : 0;
+            idx_out[rank] = (int64_t)(0xffffffffu - (unsigned int)(mine & 0xffffffffull));
+        }
+        return;
+    }
     int p2 = 1;
     while (p2 < k) p2 <<= 1;
     for (int i = k + tid; i < p2; i += 1024) sel[i] = 0ull;
@@ -314,7 +356,14 @@ int snf_topk_f32(const float* scores, int64_t n, int64_t stride, int k, int64_t*
     (void)workspace;
     (void)workspace_bytes;
     SNF_REQUIRE(k <= RS_MAXK, "snf_topk_f32: k=%d exceeds %d", k, RS_MAXK);
-    hipLaunchKernelGGL(topk_radix_kernel, dim3(1), dim3(1024), 0, s, scores, n, stride, k, idx_out);
+    if (n <= 1024 * 8)
+        hipLaunchKernelGGL(topk_radix_kernel<8>, dim3(1), dim3(1024), 0, s, scores, n, stride, k, idx_out);
+    else if (n <= 1024 * 32)
+        hipLaunchKernelGGL(topk_radix_kernel<32>, dim3(1), dim3(1024), 0, s, scores, n, stride, k, idx_out);
+    else if (n <= 1024 * 64)
+        hipLaunchKernelGGL(topk_radix_kernel<64>, dim3(1), dim3(1024), 0, s, scores, n, stride, k, idx_out);
+    else
+        hipLaunchKernelGGL(topk_radix_kernel<0>, dim3(1), dim3(1024), 0, s, scores, n, stride, k, idx_out);
     return snf::check_launch("topk_radix_kernel");
 }
 
