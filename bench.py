@@ -58,7 +58,7 @@ def timed(fn, iters, warmup=2):
     return e0.elapsed_time(e1) / iters
 
 
-def kernel_rooflines(wl, precision, device):
+def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
     """Live timing of the north-star kernels on synthetic operands of the workload's shape."""
     from snuffy_amd import ops
     N, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
@@ -94,8 +94,16 @@ def kernel_rooflines(wl, precision, device):
     b_attn = 2 * N * D * elt + K * D * 4 + K * D * 4
     b_topk = 4 * N + 8 * K
     b_gather = 2 * K * D * 4
+    # HBM-side bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE; tools/pmc_traffic.sh), recorded
+    # for exactly this workload under profiles/ -- counters cannot be collected inside a timed run
+    traffic = None
+    tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_attn_traffic_%s_%s.json"
+                         % (wl_name, precision))
+    if kern.startswith("sparse_attn_mfma") and os.path.exists(tfile):
+        with open(tfile) as f:
+            traffic = int(json.load(f)["total_bytes"])
     out["roofline"] = dict(bound="hbm", kernel=kern, achieved=round(b_attn / (t_attn * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS,
-                           unit="GB/s", frac=round(b_attn / (t_attn * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
+                           unit="GB/s", frac=round(b_attn / (t_attn * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic=traffic,
                            us_per_launch=round(t_attn * 1e3, 2), algorithmic_bytes=b_attn,
                            flops=4 * N * K * D, operand_dtype=precision)
     t_unit = t_attn + t_topk
@@ -219,7 +227,7 @@ def main():
                                                    / elapsed / 1e12, 2)},
         }
         if world == 1 and not args.no_roofline:
-            line.update(kernel_rooflines(wl, args.precision, device))
+            line.update(kernel_rooflines(wl, args.precision, device, args.workload))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(line), flush=True)
