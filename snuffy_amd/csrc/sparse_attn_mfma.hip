@@ -3,24 +3,22 @@
 //   per head a:   P_a = softmax_j(Q_a Kp_a^T * scale)  [n, k]      O_a = P_a^T V_a  [k, dk]        (snuffy.py:160-168)
 //
 // All n patches are queries, only the k selected rows are keys, and the probability matrix is used TRANSPOSED to pool
-// the values of all n patches into k output rows.  The contraction of the second product runs over the QUERY axis, so
-// the natural MFMA dataflow is the opposite of flash attention:
+// the values of all n patches into k output rows.  The contraction of the second product runs over the QUERY axis, the
+// opposite of flash attention:
 //
-//   GEMM1  S[q, key] = Q Kp^T    v_mfma_f32_32x32x16_bf16, A = Q fragment (global -> regs), B = Kp fragment (LDS).
-//          The C layout puts keys on lanes and 16 query rows in registers -- exactly the A-operand layout the second
-//          product needs (A[i = key][k = query]), so P never needs a transpose.
-//   softmax over keys = across the 32 lanes of a half-wave: DPP row rotations + one cross-row exchange, fp32.
-//   GEMM2  O[key, col] += P^T V   A = P fragment (bf16, via LDS so the 4 waves can share it), B = V fragment read
-//          straight from V^T [d, n] in HBM (8 consecutive query rows of one column = one 16-byte load).
+//   GEMM1  S^T[key, q] = Kp Q^T   v_mfma_f32_32x32x16_bf16, A = Kp fragment (bf16 image in LDS), B = Q fragment (HBM -> regs).
+//          Swapped on purpose: the C layout gives every lane ONE query row (16 keys per block in registers, the other 16
+//          in lane ^ 32), so the softmax over keys is register-local plus one v_permlane32_swap, fp32.
+//   publish  P (bf16) goes to LDS ROW-major, 4 keys per ds_write_b64, together with the wave's 32 rows of V (row-major from
+//          HBM, parked in registers during the step).  Chunk rotation by row keeps stores and reads conflict-free.
+//   GEMM2  O[key, col] += P^T V   needs both operands with 8 consecutive QUERY rows in a lane's registers, i.e. transposed
+//          with respect to how they were written: ds_read_b64_tr_b16 (hardware transpose-read) delivers exactly that.
 //
-// The row permutation pi() below is chosen so that the 8 query rows a lane holds in C registers 8ks..8ks+7 are 8
-// CONSECUTIVE bag rows -- that is what makes the V^T fragment a single contiguous load.
-//
-// Workgroup = 4 waves = 128 query rows per step of one head: wave w runs GEMM1 + softmax for rows 32w..32w+31 against
-// all keys, publishes its P fragments in LDS, then every wave accumulates its own share of the [k, dk] output tiles
-// over all 128 rows.  One workgroup per CU walks a contiguous range of (head, row-tile) work items; its accumulators
-// stay in registers until the head changes; partial tiles are written in fragment order and summed in a fixed order by
-// a second kernel (no float atomics -> bit-reproducible).
+// Workgroup = 4 waves (one per SIMD) = 128 query rows per step of one head: wave w runs GEMM1 + softmax for rows
+// 32w..32w+31 against all keys, publishes, then every wave accumulates its own share of the [k, dk] output tiles over
+// all 128 rows.  One workgroup per CU walks a contiguous range of (head, row-tile) work items; its accumulators stay in
+// registers until the head changes; partial tiles are written in fragment order and summed in a fixed order by a
+// second kernel (no float atomics -> bit-reproducible).
 //
 // HBM traffic per launch (algorithmic): read Q and V once (2*n*d*elt), Kp once per workgroup (L2), write partials.
 #include <math.h>
@@ -70,36 +68,6 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-__device__ __forceinline__ int pi_row(int i) {  // MFMA row slot -> row offset inside the wave's 32 rows
-    return (i & 3) | (((i >> 3) & 1) << 2) | (((i >> 2) & 1) << 3) | (i & 16);
-}
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
-}
-// v_permlane16_swap(x, x) returns {x.row0, x.row0, x.row2, x.row2} and {x.row1, x.row1, x.row3, x.row3}: combining the
-// two results reduces across the two 16-lane rows of each half-wave on the VALU (no LDS round trip like ds_bpermute).
-// all-reduce over the 32 lanes of a half-wave (lanes 0-31 and 32-63 independently)
-__device__ __forceinline__ float half_allmax(float v) {
-    v = fmaxf(v, dpp_mov<0x128>(v));  // row_ror:8
-    v = fmaxf(v, dpp_mov<0x124>(v));  // row_ror:4
-    v = fmaxf(v, dpp_mov<0x122>(v));  // row_ror:2
-    v = fmaxf(v, dpp_mov<0x121>(v));  // row_ror:1
-    const unsigned u = __float_as_uint(v);
-    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float half_allsum(float v) {
-    v += dpp_mov<0x128>(v);
-    v += dpp_mov<0x124>(v);
-    v += dpp_mov<0x122>(v);
-    v += dpp_mov<0x121>(v);
-    const unsigned u = __float_as_uint(v);
-    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
 __device__ __forceinline__ bf16x8 zero_frag() {
     u32x4 z = {0u, 0u, 0u, 0u};
     return __builtin_bit_cast(bf16x8, z);
@@ -140,17 +108,6 @@ __device__ __forceinline__ void mfma_vgpr_zero_c(f32x16& acc, bf16x8 a, bf16x8 b
 }
 __device__ __forceinline__ void park_after_mfma(f32x16& x) { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" : "+v"(x)); }
 __device__ __forceinline__ void pin_vgpr(f32x16& x) { asm volatile("" : "+v"(x)); }
-
-// zero the elements of a fragment whose row index is >= valid (bit mask on the bf16 pairs: NaN-proof)
-__device__ __forceinline__ bf16x8 mask_frag(bf16x8 f, int valid) {
-    u32x4 w = __builtin_bit_cast(u32x4, f);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const unsigned m = valid >= 2 * e + 2 ? 0xffffffffu : (valid == 2 * e + 1 ? 0x0000ffffu : 0u);
-        w[e] &= m;
-    }
-    return __builtin_bit_cast(bf16x8, w);
-}
 
 // One GEMM2 A operand (P^T fragment: key on the lane, 8 consecutive query rows in registers) out of the row-major P image:
 // two hardware transpose-reads.  ds_read_b64_tr_b16 semantics (probed on gfx950, tools/probes/tr16_probe.hip): every lane
