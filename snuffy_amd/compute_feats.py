@@ -130,8 +130,13 @@ def get_embedder(args, backbone, num_feats):
     return embedder, None
 
 
-def write_bag_csv(path, feats, labels=None, positions=None, camelyon16=False):
-    """One CSV per slide: D feature columns named 0..D-1 [+ label, position], '%.4f' (reference compute_feats.py:256-266)."""
+def write_bag_csv(path, feats, labels=None, positions=None, camelyon16=False, sidecar=False):
+    """One CSV per slide: D feature columns named 0..D-1 [+ label, position], '%.4f' (reference compute_feats.py:256-266).
+
+    ``sidecar=True`` also writes ``<path>.npz`` next to it: the SAME table as the loader would parse it from the text (the
+    CSV just written is read back once, so the float32 values are bit-identical to what ``utils.get_bag_feats`` gets from
+    the CSV -- '%.4f' rounding included).  A 30k x 768 slide is ~170 MB of text and seconds of parsing per epoch start;
+    the sidecar is 92 MB and loads at memory speed.  The CSV stays the interchange format."""
     import pandas as pd
     df = pd.DataFrame(np.asarray(feats, dtype=np.float32))
     if camelyon16:
@@ -139,6 +144,24 @@ def write_bag_csv(path, feats, labels=None, positions=None, camelyon16=False):
         df['position'] = positions if positions is not None else None
     os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
     df.to_csv(path, index=False, float_format='%.4f')
+    if sidecar:
+        write_bag_sidecar(path)
+
+
+def write_bag_sidecar(csv_path):
+    """Binary twin of an existing feature CSV (see write_bag_csv).  Returns the sidecar path."""
+    import pandas as pd
+    df = pd.read_csv(csv_path)
+    has = 'position' in df and 'label' in df
+    feats = (df.drop(columns=['label', 'position']) if has else df).to_numpy().astype('float32')
+    out = csv_path + '.npz'
+    tmp = out + '.tmp.npz'
+    if has:
+        np.savez(tmp, feats=feats, label=df['label'].to_numpy(), position=np.asarray(list(df['position']), dtype=object))
+    else:
+        np.savez(tmp, feats=feats)
+    os.replace(tmp, out)
+    return out
 
 
 def compute_feats(args, bags_list, embedder, save_path, patch_labels_dict=None):
@@ -162,4 +185,5 @@ def compute_feats(args, bags_list, embedder, save_path, patch_labels_dict=None):
         split_name, class_name, bag_name = bag_dir.rstrip(os.path.sep).split(os.path.sep)[-3:]
         has = patch_labels_dict is not None
         write_bag_csv(os.path.join(save_path, split_name, class_name, bag_name + '.csv'), torch.cat(feats).cpu().numpy(),
-                      labels if has else None, positions if has else None, camelyon16=(args.dataset == 'camelyon16'))
+                      labels if has else None, positions if has else None, camelyon16=(args.dataset == 'camelyon16'),
+                      sidecar=bool(getattr(args, 'binary_sidecar', 0)))

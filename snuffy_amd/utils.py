@@ -1,5 +1,7 @@
 """Host-side bag loader pieces of the hot path (reference utils.py:138-250, 469-507) plus the weight-init / optimizer
 registries train.py looks up (utils.py:69-135).  numpy / pandas only -- no GPU code here."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -43,23 +45,36 @@ def get_bag_feats(bag_row, args):
 
     Returns (label [num_classes] f32, feats [N, D] f32, feats_labels or None, positions or None); rows are shuffled with
     sklearn.utils.shuffle like the reference (global numpy RNG)."""
-    import pandas as pd
-    from sklearn.utils import shuffle
     path = bag_row.iloc[0] if hasattr(bag_row, "iloc") else bag_row[0]
     raw_label = bag_row.iloc[1] if hasattr(bag_row, "iloc") else bag_row[1]
     path = path.replace("datasets/Camelyon16", "embeddings/camelyon16/official/")
-    df = pd.read_csv(path)
-    has_patch_labels = 'position' in df and 'label' in df
-    df = shuffle(df).reset_index(drop=True)
-    feats = df.drop(columns=['label', 'position']) if has_patch_labels else df
-    feats = feats.to_numpy().astype('float32')
+    side = path + '.npz'
+    if os.path.exists(side) and os.path.getmtime(side) >= os.path.getmtime(path):
+        # binary twin written by compute_feats.write_bag_csv(sidecar=True): same parsed values, no text parsing.
+        # sklearn.utils.shuffle(df) draws ONE np.random.shuffle of arange(n) from the global RNG; so does this.
+        z = np.load(side, allow_pickle=True)
+        feats = z['feats']
+        idx = np.arange(feats.shape[0])
+        np.random.shuffle(idx)
+        feats = feats[idx]
+        has_patch_labels = 'label' in z.files and 'position' in z.files
+        feats_labels = z['label'][idx] if has_patch_labels else None
+        positions = list(z['position'][idx]) if has_patch_labels else None
+    else:
+        import pandas as pd
+        from sklearn.utils import shuffle
+        df = pd.read_csv(path)
+        has_patch_labels = 'position' in df and 'label' in df
+        df = shuffle(df).reset_index(drop=True)
+        feats = df.drop(columns=['label', 'position']) if has_patch_labels else df
+        feats = feats.to_numpy().astype('float32')
+        feats_labels = df['label'].to_numpy() if has_patch_labels else None
+        positions = list(df['position']) if has_patch_labels else None
     label = np.zeros(args.num_classes)
     if args.num_classes == 1:
         label[0] = raw_label
     elif int(raw_label) <= len(label) - 1:
         label[int(raw_label)] = 1
-    feats_labels = df['label'].to_numpy() if has_patch_labels else None
-    positions = list(df['position']) if has_patch_labels else None
     return label.astype('float32'), feats, feats_labels, positions
 
 

@@ -98,3 +98,48 @@ def test_forward_refuses_cpu_tensors():
     net = build_amd_milnet(64, 2, "relu", 10, 0.0, 1)
     with pytest.raises(SnuffyHipError):
         net(torch.zeros(1, 5, 64))
+
+
+@pytest.mark.parametrize("camelyon16", [False, True])
+def test_binary_sidecar_loads_exactly_what_the_csv_parses(tmp_path, camelyon16):
+    """the .npz twin of a feature CSV must give get_bag_feats the same rows in the same shuffled order, the
+    same '%.4f'-rounded float32 values, the same label / position columns, and leave the global numpy RNG in the same state."""
+    import types
+
+    import pandas as pd
+    from snuffy_amd import compute_feats, utils
+    rng = np.random.RandomState(3)
+    n, d = 257, 24
+    feats = (rng.randn(n, d) * 3).astype(np.float32)
+    feats[0, 0], feats[1, 1] = 0.00005, -1.23455          # half-way cases of the 4-decimal rounding
+    labels = rng.randint(0, 2, n).astype(np.float64) if camelyon16 else None
+    positions = ["(%d, %d)" % (i % 17, i // 17) for i in range(n)] if camelyon16 else None
+    csv = str(tmp_path / "slide_a.csv")
+    compute_feats.write_bag_csv(csv, feats, labels, positions, camelyon16=camelyon16, sidecar=True)
+    assert (tmp_path / "slide_a.csv.npz").exists()
+    args = types.SimpleNamespace(num_classes=1)
+    row = pd.Series([csv, 1])
+
+    np.random.seed(11)
+    lab_b, f_b, fl_b, pos_b = utils.get_bag_feats(row, args)          # binary twin
+    after_b = np.random.rand()
+    (tmp_path / "slide_a.csv.npz").unlink()
+    np.random.seed(11)
+    lab_c, f_c, fl_c, pos_c = utils.get_bag_feats(row, args)          # text path (the reference's)
+    after_c = np.random.rand()
+
+    assert f_b.dtype == np.float32 and f_b.shape == (n, d)
+    assert np.array_equal(f_b, f_c) and np.array_equal(lab_b, lab_c)
+    assert after_b == after_c
+    if camelyon16:
+        assert np.array_equal(fl_b, fl_c) and list(pos_b) == list(pos_c)
+    else:
+        assert fl_b is None and pos_b is None and fl_c is None and pos_c is None
+    # a CSV rewritten after its twin invalidates the twin (mtime rule)
+    compute_feats.write_bag_sidecar(csv)
+    import os
+    import time
+    os.utime(csv, (time.time() + 5, time.time() + 5))
+    np.random.seed(11)
+    _, f_d, _, _ = utils.get_bag_feats(row, args)
+    assert np.array_equal(f_d, f_c)
