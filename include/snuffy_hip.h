@@ -55,6 +55,11 @@ int snf_device_cu_count(void);
  * --------------------------------------------------------------------------------------------------------- */
 int snf_critic_f32(const float* x, int64_t n, int d, const float* w, const float* b, int c_out, float* scores,
                    float* colmax_val, int64_t* colmax_idx, snf_stream_t stream);
+/* K1 + K5 in one pass over the bag: the critic scores AND xhat [n, d] bf16 = (x - mean) * rstd, the affine-free LayerNorm
+ * of SublayerConnection 'attn' (snuffy.py:97,107) whose gamma/beta the bf16 path folds into the Q|V projection weights.
+ * Same arithmetic as snf_critic_f32 and snf_layernorm_rows_f32(gamma = beta = NULL, out_bf16): identical outputs. */
+int snf_critic_ln_f32(const float* x, int64_t n, int d, const float* w, const float* b, int c_out, float* scores,
+                      float eps, void* xhat_bf16, snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K2  top-k patch selector                    replaces torch.sort(c,1,descending=True)[:k], snuffy.py:128-130

@@ -29,6 +29,8 @@ SIGNATURES = {
     "snf_device_cu_count": (c_int, []),
     "snf_critic_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                c_void_p]),
+    "snf_critic_ln_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p,
+                                  c_void_p]),
     "snf_topk_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "snf_topk_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "snf_topk_gather_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,

@@ -85,12 +85,16 @@ __device__ __forceinline__ void store_row_bf16(unsigned short* __restrict__ row,
 // ---------------------------------------------------------------------------------------------------------------
 // K1 critic: scores[i, c] = x[i,:] . w[c,:] + b[c]          (FCLayer.forward, snuffy.py:39-41)
 // ---------------------------------------------------------------------------------------------------------------
-template <int VEC, int NV>
+// LN = also emit the row-normalised bf16 copy (x - mean) * rstd that the first encoder layer needs (its LayerNorm affine is
+// folded into the projection weights): the bag is read from HBM once for both, instead of once per kernel.
+template <int VEC, int NV, bool LN>
 __global__ __launch_bounds__(WG) void critic_kernel(const float* __restrict__ x, int64_t n, int d,
                                                     const float* __restrict__ w, const float* __restrict__ b,
-                                                    int c_out, float* __restrict__ scores) {
+                                                    int c_out, float* __restrict__ scores, float eps,
+                                                    unsigned short* __restrict__ xhat) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const float inv_d = 1.0f / (float)d;
     for (int64_t row = (int64_t)blockIdx.x * WAVES + wave; row < n; row += (int64_t)gridDim.x * WAVES) {
         float r[NV * VEC];
         load_row<VEC, NV>(x + row * d, d, lane, r);
@@ -102,6 +106,27 @@ __global__ __launch_bounds__(WG) void critic_kernel(const float* __restrict__ x,
             for (int i = 0; i < NV * VEC; ++i) acc = fmaf(r[i], wr[i], acc);
             acc = wave_sum(acc);
             if (lane == 0) scores[row * c_out + c] = acc + (b ? b[c] : 0.f);
+        }
+        if constexpr (LN) {   // same arithmetic, in the same order, as layernorm_rows_kernel without affine
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV * VEC; ++i) s1 += r[i];
+            const float mean = wave_sum(s1) * inv_d;
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) {
+                    int e = (i * 64 + lane) * VEC + t;
+                    float dv = (e < d) ? (r[i * VEC + t] - mean) : 0.f;
+                    s2 = fmaf(dv, dv, s2);
+                }
+            }
+            const float var = wave_sum(s2) * inv_d;
+            const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+            for (int i = 0; i < NV * VEC; ++i) r[i] = (r[i] - mean) * rstd;
+            store_row_bf16<VEC, NV>(xhat + row * d, d, lane, r);
         }
     }
 }
@@ -569,8 +594,8 @@ int snf_critic_f32(const float* x, int64_t n, int d, const float* w, const float
     RowCfg cfg;
     SNF_REQUIRE(pick_row_cfg(d, aligned16(x) && aligned16(w), &cfg), "snf_critic_f32: d=%d too wide (max 2048)", d);
     hipStream_t s = snf::as_stream(stream);
-    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((critic_kernel<VEC, NV>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w, b,
-                                              c_out, scores));
+    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((critic_kernel<VEC, NV, false>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w,
+                                              b, c_out, scores, 0.f, (unsigned short*)nullptr));
     int rc = snf::check_launch("critic_kernel");
     if (rc) return rc;
     if (colmax_val || colmax_idx) {
@@ -578,6 +603,19 @@ int snf_critic_f32(const float* x, int64_t n, int d, const float* w, const float
         rc = snf::check_launch("colmax_kernel");
     }
     return rc;
+}
+
+int snf_critic_ln_f32(const float* x, int64_t n, int d, const float* w, const float* b, int c_out, float* scores,
+                      float eps, void* xhat_bf16, snf_stream_t stream) {
+    SNF_REQUIRE(x && w && scores && xhat_bf16, "snf_critic_ln_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && d >= 1 && c_out >= 1, "snf_critic_ln_f32: bad shape n=%lld d=%d c=%d", (long long)n, d, c_out);
+    RowCfg cfg;
+    SNF_REQUIRE(pick_row_cfg(d, aligned16(x) && aligned16(w) && aligned16(xhat_bf16), &cfg),
+                "snf_critic_ln_f32: d=%d too wide (max 2048)", d);
+    hipStream_t s = snf::as_stream(stream);
+    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((critic_kernel<VEC, NV, true>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w,
+                                              b, c_out, scores, eps, reinterpret_cast<unsigned short*>(xhat_bf16)));
+    return snf::check_launch("critic_kernel<ln>");
 }
 
 int snf_layernorm_rows_f32(const float* x, int64_t n, int d, const int32_t* slot_map, const float* patch_rows,

@@ -66,6 +66,34 @@ def critic_scores(feats, w, b):
     return s.view(*lead, w.shape[0])
 
 
+# bf16 eval path: the critic pass can hand the first encoder layer its normalised input (one read of the bag instead of
+# two).  The hand-over is keyed on the bag's storage and version and consumed at most once.
+_xhat_offer = None
+
+
+def critic_scores_with_xhat(feats, w, b, eps):
+    """critic_scores() that also leaves xhat = (x - mean) * rstd (bf16) for encoder_layer()'s bf16 path."""
+    global _xhat_offer
+    lead = feats.shape[:-1]
+    f2 = feats.reshape(-1, feats.shape[-1])
+    if not f2.is_cuda:
+        raise SnuffyHipError("input must be a GPU tensor: snuffy_amd has no CPU fallback")
+    if f2.dtype != torch.float32 or not f2.is_contiguous():
+        _xhat_offer = None
+        return critic_scores(feats, w, b)             # a converted copy would not be the tensor the encoder sees
+    s, xhat = ops.critic_ln(f2, w, b, eps)
+    _xhat_offer = (f2.data_ptr(), tuple(f2.shape), f2._version, float(eps), xhat)
+    return s.view(*lead, w.shape[0])
+
+
+def _take_xhat(x2, eps):
+    global _xhat_offer
+    offer, _xhat_offer = _xhat_offer, None
+    if offer is not None and offer[:4] == (x2.data_ptr(), tuple(x2.shape), x2._version, float(eps)):
+        return offer[4]
+    return None
+
+
 def select_top(c1, big_lambda, top_share, n):
     k1 = min(math.ceil(big_lambda * top_share), n)          # python float arithmetic, snuffy.py:129
     if k1 < 1:
@@ -235,8 +263,10 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
     if n0.eps != n1.eps:
         raise NotImplementedError("bf16 path shares one normalisation between both sublayers: eps must match")
     fw = _folded(layer)
-    xhat = torch.empty(n, d, dtype=torch.bfloat16, device=x2.device)
-    ops.layernorm_rows(x2, None, None, n0.eps, out=xhat)
+    xhat = _take_xhat(x2, n0.eps)                                                   # left by the critic pass, if any
+    if xhat is None:
+        xhat = torch.empty(n, d, dtype=torch.bfloat16, device=x2.device)
+        ops.layernorm_rows(x2, None, None, n0.eps, out=xhat)
     qv = torch.addmm(fw["bqv"], xhat, fw["wqv"].t())                                # [N, 2D] bf16 = [Q | V], bias epilogue
     q, v = qv[:, :d], qv[:, d:]                                                     # row-strided views, used in place
     if ops.mfma_attn_supported(k, d // h):

@@ -56,6 +56,23 @@ def critic(x, w, b=None, want_max=False):
     return (scores, mv, mi) if want_max else scores
 
 
+def critic_ln(x, w, b, eps):
+    """One pass over the bag: (scores [n, c] f32, xhat [n, d] bf16 = affine-free LayerNorm of x).  See snf_critic_ln_f32."""
+    x = _req(x, torch.float32, "x", 2)
+    w = _req(w, torch.float32, "w", 2)
+    if b is not None:
+        b = _req(b, torch.float32, "b", 1)
+    n, d = x.shape
+    c = w.shape[0]
+    if w.shape[1] != d:
+        raise ValueError("critic_ln: w is %s but x has %d features" % (tuple(w.shape), d))
+    scores = torch.empty(n, c, dtype=torch.float32, device=x.device)
+    xhat = torch.empty(n, d, dtype=torch.bfloat16, device=x.device)
+    check(_ffi.load().snf_critic_ln_f32(_p(x), n, d, _p(w), _p(b), c, _p(scores), float(eps), _p(xhat), _stream()),
+          "snf_critic_ln_f32")
+    return scores, xhat
+
+
 def topk(scores, k, x=None):
     """Indices of the k largest scores, descending, ties by ascending index (snuffy.py:128-130).
 

@@ -255,6 +255,19 @@ class MILNet(nn.Module):
         return self
 
     def forward(self, x):
-        feats, classes = self.i_classifier(x)
+        feats, classes = self._critic(x)
         prediction_bag, A = self.b_classifier(feats, classes)
         return classes, prediction_bag, A
+
+    def _critic(self, x):
+        """i_classifier(x); in the bf16 inference path of a plain FCLayer critic the same pass over the bag also produces
+        the normalised input of the first encoder layer (snf_critic_ln_f32) -- identical values, one HBM read less."""
+        ic = self.i_classifier
+        cfg = getattr(self.b_classifier, "cfg", None)
+        if (type(ic) is FCLayer and cfg is not None and cfg.precision == "bf16" and not torch.is_grad_enabled()
+                and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 3 and x.shape[0] == 1
+                and len(self.b_classifier.encoder.layers) > 0):
+            lin = ic.fc[0]
+            eps = self.b_classifier.encoder.layers[0].sublayer[0].norm.eps
+            return x, SF.critic_scores_with_xhat(x, lin.weight, lin.bias, eps)
+        return ic(x)

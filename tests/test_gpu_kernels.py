@@ -255,3 +255,18 @@ def test_mfma_rejects_unsupported_shapes():
     q = torch.zeros(64, 256, device=DEV)
     with pytest.raises(SnuffyHipError):   # dk = 128 holds at most 224 keys next to the P and V images in LDS
         ops().sparse_attn_fwd_mfma(q, torch.zeros(64, 256, device=DEV), torch.zeros(225, 256, device=DEV), 64, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d,c", [(1, 64, 1), (1000, 166, 1), (4099, 384, 2), (513, 768, 1)])
+def test_critic_ln_equals_critic_plus_layernorm(n, d, c):
+    """The fused pass (snf_critic_ln_f32) must give bit-identical scores and bf16 xhat to the two separate kernels."""
+    g = torch.Generator().manual_seed(n + d)
+    x = (torch.randn(n, d, generator=g) * 2 + 0.3).to(DEV)
+    w = torch.randn(c, d, generator=g).to(DEV)
+    b = torch.randn(c, generator=g).to(DEV)
+    s_f, xhat_f = ops().critic_ln(x, w, b, 1e-5)
+    s_ref = ops().critic(x, w, b)
+    xhat_ref = ops().layernorm_rows(x, None, None, 1e-5, out_dtype=torch.bfloat16)
+    assert torch.equal(s_f, s_ref)
+    assert torch.equal(xhat_f.view(torch.int16), xhat_ref.view(torch.int16))

@@ -193,3 +193,27 @@ def test_f6_multiclass_golden(path):
                 got = rnd.cpu().numpy()
                 want = np.stack([z[f"rnd{l * B + i}"] for i in range(B)])      # one np.random.choice call per row
                 assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_fused_critic_layernorm_pass_changes_nothing():
+    """MILNet.forward in bf16 hands the encoder the xhat produced by the critic pass (snf_critic_ln_f32).  Calling the two
+    modules separately (the roi.py / reference call pattern) takes the unfused kernels: outputs must be bit-identical."""
+    D, h, N = 384, 6, 3000
+    net = synth_state(D, h, 1).to(DEV).eval().configure(precision="bf16", return_attention=True)
+    x = torch.randn(1, N, D, generator=torch.Generator().manual_seed(5)).to(DEV)
+    with torch.no_grad():
+        classes, logits, A = net(x)
+        feats, classes2 = net.i_classifier(x)
+        logits2, A2 = net.b_classifier(feats, classes2)
+    assert torch.equal(classes, classes2) and torch.equal(logits, logits2) and torch.equal(A, A2)
+    # a stale offer must never be consumed: change the bag in place between the critic pass and the encoder
+    from snuffy_amd import functional as SF
+    with torch.no_grad():
+        lin = net.i_classifier.fc[0]
+        eps = net.b_classifier.encoder.layers[0].sublayer[0].norm.eps
+        c3 = SF.critic_scores_with_xhat(x, lin.weight, lin.bias, eps)
+        x.mul_(2.0)                                           # bumps the version counter
+        logits3, _ = net.b_classifier(x, c3)
+        logits4, _ = net.b_classifier(x, c3)
+    assert torch.equal(logits3, logits4)
