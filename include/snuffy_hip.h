@@ -90,6 +90,10 @@ int snf_scatter_rows_f32(const float* x, int64_t n, int d, const int64_t* idx, i
 int snf_scatter_add_rows_f32(float* z, int64_t n, int d, const int64_t* idx, int k, const float* delta,
                              snf_stream_t stream);
 int snf_slot_map_i32(const int64_t* idx, int k, int64_t n, int32_t* map, snf_stream_t stream);
+/* K4 + slot map in one launch: xs[j] = x[idx[j]] and map[i] = j if idx[j] == i else -1 (k <= 2048, idx duplicate-free).
+ * Same results as snf_gather_rows_f32 + snf_slot_map_i32. */
+int snf_gather_slot_map_f32(const float* x, int64_t n, int d, const int64_t* idx, int k, float* xs, int32_t* map,
+                            snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K5  LayerNorm over rows, with the K9 scatter fused into the read

@@ -39,6 +39,7 @@ SIGNATURES = {
     "snf_scatter_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "snf_scatter_add_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "snf_slot_map_i32": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "snf_gather_slot_map_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "snf_layernorm_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "snf_bias_act": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p]),

@@ -293,6 +293,31 @@ __global__ void slot_map_kernel(const int64_t* __restrict__ idx, int k, int64_t 
     }
 }
 
+// gather + slot map in ONE launch (three ~5 us launches otherwise: fill, scatter of the slots, gather).  Workgroups
+// [0, k) copy the selected rows; the others build map[i] = j if idx[j] == i else -1 by searching the k indices held in LDS
+// (k <= 2048 broadcast reads per thread: cheaper than a launch, and no fill-then-scatter ordering between kernels).
+__global__ __launch_bounds__(WG) void gather_slot_map_kernel(const float* __restrict__ x, int64_t n, int d,
+                                                             const int64_t* __restrict__ idx, int k,
+                                                             float* __restrict__ xs, int32_t* __restrict__ map) {
+    if ((int)blockIdx.x < k) {
+        const int64_t src = idx[blockIdx.x];
+        if (src < 0 || src >= n) return;
+        const float* s = x + src * d;
+        float* o = xs + (int64_t)blockIdx.x * d;
+        for (int e = threadIdx.x; e < d; e += WG) o[e] = s[e];
+        return;
+    }
+    __shared__ int sel[2048];
+    for (int j = threadIdx.x; j < k; j += WG) sel[j] = (int)idx[j];
+    __syncthreads();
+    const int64_t i = ((int64_t)blockIdx.x - k) * WG + threadIdx.x;
+    if (i >= n) return;
+    int slot = -1;
+    const int me = (int)i;
+    for (int j = 0; j < k; ++j) slot = (sel[j] == me) ? j : slot;
+    map[i] = slot;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // K10 epilogue: h = act(h + bias)
 // ---------------------------------------------------------------------------------------------------------------
@@ -688,6 +713,17 @@ int snf_slot_map_i32(const int64_t* idx, int k, int64_t n, int32_t* map, snf_str
     if (rc || k == 0) return rc;
     hipLaunchKernelGGL(slot_map_kernel, dim3((k + 255) / 256), dim3(256), 0, s, idx, k, n, map);
     return snf::check_launch("slot_map_kernel");
+}
+
+int snf_gather_slot_map_f32(const float* x, int64_t n, int d, const int64_t* idx, int k, float* xs, int32_t* map,
+                            snf_stream_t stream) {
+    SNF_REQUIRE(x && map && (k == 0 || (idx && xs)), "snf_gather_slot_map_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && n < 0x7fffffffll && d >= 1 && k >= 0 && k <= 2048,
+                "snf_gather_slot_map_f32: bad shape n=%lld d=%d k=%d (k <= 2048)", (long long)n, d, k);
+    const int64_t grid = k + (n + WG - 1) / WG;
+    hipLaunchKernelGGL(gather_slot_map_kernel, dim3((unsigned)grid), dim3(WG), 0, snf::as_stream(stream), x, n, d, idx, k, xs,
+                       map);
+    return snf::check_launch("gather_slot_map_kernel");
 }
 
 int snf_bias_act(void* h, int dtype, int64_t n, int f, const float* bias, int act, snf_stream_t stream) {

@@ -238,7 +238,7 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
         ops.bias_act_(z, ff.w_2.bias, "none")
         return Parts(z), attn
 
-    xs = ops.gather_rows(x2, sel)                                                   # snuffy.py:131,145-147
+    xs, slot = ops.gather_slot_map(x2, sel)                                         # snuffy.py:131,145-147 (+ row -> slot map)
     kp = F.linear(xs, lk.weight, lk.bias)                                           # keys = RAW selected rows
     if precision == "fp32":
         xn = ops.layernorm_rows(x2, n0.weight, n0.bias, n0.eps)                     # snuffy.py:107
@@ -248,7 +248,6 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
         del q, v, xn
         delta = F.linear(o, lo.weight, lo.bias)                                     # snuffy.py:205
         x_sel = xs + delta                                                          # snuffy.py:108
-        slot = ops.slot_map(sel, n)
         yn = ops.layernorm_rows(x2, n1.weight, n1.bias, n1.eps, slot=slot, patch_rows=x_sel)  # LN(y), y never built
         hid = torch.mm(yn, ff.w_1.weight.t())
         del yn
@@ -284,5 +283,5 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
         ops.bias_act_(hid, fw["b1"], ff.activation_name)
     zb = torch.mm(hid, fw["w2"].t())                                                # [N, D] bf16
     del hid
-    parts = Parts(x2, add_bf16=zb, add_bias=ff.w_2.bias, slot=ops.slot_map(sel, n), delta=delta)
+    parts = Parts(x2, add_bf16=zb, add_bias=ff.w_2.bias, slot=slot, delta=delta)
     return parts, (attn.unsqueeze(0) if attn is not None else None)

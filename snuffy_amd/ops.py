@@ -113,6 +113,21 @@ def gather_rows(x, idx):
     return out
 
 
+def gather_slot_map(x, idx):
+    """(x[idx] [k, d], map [n] int32 with map[idx[j]] = j, -1 elsewhere) in one launch; idx must be duplicate-free."""
+    x = _req(x, torch.float32, "x", 2)
+    idx = _req(idx, torch.int64, "idx", 1)
+    n, d = x.shape
+    k = idx.shape[0]
+    if k > 2048:
+        return gather_rows(x, idx), slot_map(idx, n)
+    xs = torch.empty(k, d, dtype=torch.float32, device=x.device)
+    m = torch.empty(n, dtype=torch.int32, device=x.device)
+    check(_ffi.load().snf_gather_slot_map_f32(_p(x), n, d, _p(idx), k, _p(xs), _p(m), _stream()),
+          "snf_gather_slot_map_f32")
+    return xs, m
+
+
 def scatter_rows(x, idx, rows, inplace=False):
     """y = x.clone(); y[idx] = rows  (snuffy.py:154-155); in place when asked."""
     x = _req(x, torch.float32, "x", 2)

@@ -270,3 +270,15 @@ def test_critic_ln_equals_critic_plus_layernorm(n, d, c):
     xhat_ref = ops().layernorm_rows(x, None, None, 1e-5, out_dtype=torch.bfloat16)
     assert torch.equal(s_f, s_ref)
     assert torch.equal(xhat_f.view(torch.int16), xhat_ref.view(torch.int16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d,k", [(1, 64, 1), (1000, 166, 40), (32768, 768, 200), (5000, 384, 2048)])
+def test_gather_slot_map_equals_separate_kernels(n, d, k):
+    g = torch.Generator().manual_seed(n + k)
+    x = torch.randn(n, d, generator=g).to(DEV)
+    idx = torch.randperm(n, generator=g)[:k].to(DEV)
+    xs, m = ops().gather_slot_map(x, idx)
+    assert torch.equal(xs, ops().gather_rows(x, idx))
+    assert torch.equal(m, ops().slot_map(idx, n))
+    assert torch.equal(xs, x[idx])
