@@ -141,8 +141,10 @@ int snf_ln_mean_head_f32(const float* z, int64_t n, int d, const void* add_bf16,
  *   snf_sparse_attn_fwd_mfma: bf16 MFMA (fp32 accumulate), softmax in fp32.  q [n, ldq] and v [n, ldv] row-major
  *       (ldq, ldv >= d in elements, rows 16-byte aligned: q and v may be the two column halves of ONE fused
  *       projection output [n, 2d]), both of dtype qv_dtype (f32 converted in registers, or bf16); kp [k, d] f32.
- *       Supported: dk == 64 with k <= 256, dk == 128 with k <= 224 (Kp + P + V images share the 160 KiB LDS).
- *       Otherwise SNF_EUNSUPPORTED: the caller picks snf_sparse_attn_fwd_f32.
+ *       One launch holds 256 (dk == 64) / 224 (dk == 128) keys (Kp + P + V images share the 160 KiB LDS); more keys --
+ *       up to 8 such chunks, k <= 2048 / 1792 -- run as key chunks: a statistics launch per chunk (row max / sum) and a
+ *       full launch per chunk normalising with the statistics of all chunks, so the softmax stays exact.
+ *       Other dk / larger k: SNF_EUNSUPPORTED, the caller picks snf_sparse_attn_fwd_f32.
  *   workspace: deterministic cross-workgroup reduction of the [h, k, dk] accumulators.
  * --------------------------------------------------------------------------------------------------------- */
 size_t snf_sparse_attn_fwd_workspace_bytes(int64_t n, int k, int h, int dk, int mfma);

@@ -51,7 +51,13 @@ struct AttnParams {
     int64_t n, ldq, ldv, ldkp;
     int k, h;
     float scale;
-    float* attn;     // [h, n, k] or null
+    float* attn;     // [h, n, attn_ld] or null (already offset to this key chunk's first column)
+    int64_t attn_ld; // row pitch of attn (= total number of keys)
+    // key-chunked launches (more keys than one LDS image holds): per-chunk row statistics [n_chunks][h][n][2] =
+    // (row max * scale * log2 e, sum exp) written by sparse_attn_stats_kernel; null = single chunk, statistics computed here
+    const float* stats;
+    float* stats_out;
+    int n_chunks;
     float* lse;      // [h, n] or null
     float* partial;  // [num_wg * seg_count][tiles][16][64]
     int tiles_per_head, tiles_per_wg, total_tiles, seg_count;
@@ -146,7 +152,8 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 //             barrier, publish P(t) in LDS, (barrier after the next GEMM1)
 //   loads:    one 16-byte fragment at a time between the slices (Q(t+1) during the max pass, V(t) as soon as the pending
 //             GEMM2 released the register): HBM requests stream continuously, a full step ahead of their use.
-template <int DK, int NKB, typename QT, bool AUX>
+// EXT = key-chunked launch: the row statistics come from sparse_attn_stats_kernel (all chunks), not from this chunk's scores.
+template <int DK, int NKB, typename QT, bool AUX, bool EXT>
 __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) {
     constexpr int NKS = DK / 16;             // k-steps of GEMM1
     constexpr int NCB = DK / 32;             // 32-wide column blocks of the output
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     // lazily, and each extra batch is one more cold round trip to the kernarg segment before the first HBM load can go out.
     asm volatile("" ::"s"(P.q), "s"(P.v), "s"(P.kp), "s"(P.n), "s"(P.ldq), "s"(P.ldv), "s"(P.k), "s"(P.scale),
                  "s"(P.partial), "s"(P.tiles_per_head), "s"(P.tiles_per_wg), "s"(P.total_tiles), "s"(P.seg_count),
-                 "s"(P.trace));
+                 "s"(P.trace), "s"(P.stats), "s"(P.n_chunks), "s"(P.attn_ld));
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, hf = lane >> 5;
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     const float c_exp = P.scale * 1.44269504088896340736f;
     const int cb = (NCB == 4) ? w : (w & (NCB - 1));
     const int n32 = (int)P.n;
-    const bool attn_vec = AUX && (P.k & 3) == 0 && (reinterpret_cast<uintptr_t>(P.attn) & 15) == 0;
+    const bool attn_vec = AUX && (P.attn_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(P.attn) & 15) == 0;
     int trace_it = 0;
     auto stamp = [&](int phase) __attribute__((always_inline)) {
         if (P.trace && blockIdx.x == 0 && lane == 0)
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
         //   steps: 4 NKB max steps | finish max | 8 NKB exp steps (a register pair each) | row sum | 4 NKB normalise+convert
         constexpr int S_FIN = 4 * NKB, S_EXP0 = S_FIN + 1, S_SUM = S_EXP0 + 8 * NKB, S_NRM0 = S_SUM + 1;
         constexpr int S_END = S_NRM0 + 4 * NKB;
-        float mx0 = 0.f, mx1 = 0.f, mc = 0.f, mrow = 0.f, l0 = 0.f, l1 = 0.f, lrow = 0.f, inv = 0.f;
+        float mx0 = 0.f, mx1 = 0.f, mc = 0.f, l0 = 0.f, l1 = 0.f, lrow = 0.f, inv = 0.f;
         const bool rvalid = row < n32;
         f32x2 ev[NKB][8];   // exp values as register PAIRS: the normalisation is one v_pk_mul_f32 + one v_cvt_pk per pair
         u32x2 pk[NKB][4];
@@ -462,7 +469,8 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
             constexpr int st = decltype(st_t)::value;
             if constexpr (st < S_FIN) {
                 constexpr int jb = st / 4, r = 4 * (st % 4);
-                if constexpr (st == 0) {
+                if constexpr (EXT) {
+                } else if constexpr (st == 0) {
                     mx0 = fmaxf(s_acc[0][0], s_acc[0][1]);
                     mx1 = fmaxf(s_acc[0][2], s_acc[0][3]);
                 } else {
@@ -470,8 +478,19 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
                     mx1 = fmaxf(fmaxf(mx1, s_acc[jb][r + 2]), s_acc[jb][r + 3]);
                 }
             } else if constexpr (st == S_FIN) {
-                mrow = xhalf_max(fmaxf(mx0, mx1));
-                mc = mrow * c_exp;
+                if constexpr (EXT) {
+                    // key-chunked launch: the softmax runs over ALL chunks' keys -- combine their (max, sum) pairs
+                    const float* st0 = P.stats + ((int64_t)a * P.n + (rvalid ? row : 0)) * 2;
+                    const int64_t cs = (int64_t)P.h * P.n * 2;
+                    float m = st0[0];
+                    for (int c = 1; c < P.n_chunks; ++c) m = fmaxf(m, st0[c * cs]);
+                    float l = 0.f;
+                    for (int c = 0; c < P.n_chunks; ++c) l = fmaf(st0[c * cs + 1], __builtin_amdgcn_exp2f(st0[c * cs] - m), l);
+                    mc = m;
+                    lrow = l;
+                } else {
+                    mc = xhalf_max(fmaxf(mx0, mx1)) * c_exp;
+                }
             } else if constexpr (st < S_SUM) {
                 constexpr int e = st - S_EXP0, jb = e / 8, pr = e % 8;
                 const float e0 = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][2 * pr], c_exp, -mc));
@@ -480,7 +499,7 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
                 l0 += e0;
                 l1 += e1;
             } else if constexpr (st == S_SUM) {
-                lrow = xhalf_sum(l0 + l1);
+                if constexpr (!EXT) lrow = xhalf_sum(l0 + l1);
                 inv = rvalid ? __builtin_amdgcn_rcpf(lrow) : 0.f;
             } else {
                 constexpr int u = st - S_NRM0, jb = u / 4, c4 = u % 4;
@@ -501,10 +520,10 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
         });
         if constexpr (AUX) {
             // with the attention matrix / log-sum-exp outputs the normalised fp32 row is stored before it is converted
-            if (P.lse && rvalid && hf == 0) P.lse[(int64_t)a * P.n + row] = mrow * P.scale + __logf(lrow);
+            if (P.lse && rvalid && hf == 0) P.lse[(int64_t)a * P.n + row] = mc * 0.69314718055994530942f + __logf(lrow);
             // attention matrix: this lane owns 4 consecutive keys per (block, c4) of ONE row -> 16-byte stores
             if (P.attn && rvalid) {
-                float* arow = P.attn + ((int64_t)a * P.n + row) * P.k + 4 * hf;
+                float* arow = P.attn + ((int64_t)a * P.n + row) * P.attn_ld + 4 * hf;
                 // keys this lane may store, relative to its first one.  Opaque to the optimiser on purpose: the bound is
                 // loop-invariant, and hoisting the 28..112 compare masks out of the tile loop spills ~240 SGPRs.
                 int klim = P.k - 4 * hf;
@@ -559,6 +578,105 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
     stamp_abs(63);
 }
 
+
+// Row statistics of one key chunk (key-chunked launches, k above what one LDS image holds): the GEMM1 + max / exp / sum half
+// of the kernel above, nothing else.  stats_out[(a * n + row) * 2 + {0, 1}] = (row max * scale * log2 e, sum of exp).
+template <int DK, int NKB, typename QT>
+__global__ __launch_bounds__(256, 1) void sparse_attn_stats_kernel(AttnParams P) {
+    constexpr int NKS = DK / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* lds_kp = reinterpret_cast<u32x4*>(smem);                    // [NKB][NKS][64] MFMA A fragments of Kp
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, hf = lane >> 5;
+    const QT* __restrict__ q = reinterpret_cast<const QT*>(P.q);
+    const float c_exp = P.scale * 1.44269504088896340736f;
+    const int n32 = (int)P.n;
+    const int prow = 32 * w + j;
+    const int ldq32 = (int)P.ldq;
+    const int f_begin = blockIdx.x * P.tiles_per_wg;
+    int f_end = f_begin + P.tiles_per_wg;
+    if (f_end > P.total_tiles) f_end = P.total_tiles;
+    const int first_head = f_begin / P.tiles_per_head;
+    int a = first_head, t = f_begin - first_head * P.tiles_per_head;
+    int cur_head = -1;
+    constexpr int NF = (NKB * NKS + 3) / 4;
+    bf16x8 qf[NKS];
+    auto load_q = [&](int a_, int t_) __attribute__((always_inline)) {
+        int qrow = t_ * TILE_ROWS + prow;
+        if (qrow > n32 - 1) qrow = n32 - 1;
+        const QT* qp = q + __umul24((unsigned)qrow, (unsigned)ldq32) + (a_ * DK + 8 * hf);
+        static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) { qf[kb] = load_frag(qp + 16 * kb); });
+    };
+    if (f_begin < f_end) load_q(a, t);
+    for (int f = f_begin; f < f_end; ++f) {
+        const int row = t * TILE_ROWS + prow;
+        int an = a, tn = t + 1;
+        if (tn == P.tiles_per_head) {
+            tn = 0;
+            an = a + 1;
+        }
+        if (a != cur_head) {
+            __syncthreads();  // everyone finished reading the previous head's Kp
+            static_for<0, NF>([&](auto i) __attribute__((always_inline)) {
+                const int fr = w + 4 * i;
+                if (fr < NKB * NKS) {
+                    const int jb = fr / NKS, kb = fr - jb * NKS;
+                    int key = 32 * jb + j;
+                    const bool pad = key >= P.k;
+                    if (pad) key = P.k - 1;
+                    const float* src = P.kp + (int64_t)key * P.ldkp + a * DK + 16 * kb + 8 * hf;
+                    u32x4 v = __builtin_bit_cast(u32x4, load_frag(src));
+                    if (pad) v = u32x4{0u, 0u, 0u, 0u};
+                    lds_kp[fr * 64 + lane] = v;
+                }
+            });
+            __syncthreads();
+            cur_head = a;
+        }
+        f32x16 s_acc[NKB];
+        static_for<0, NKB * NKS>([&](auto m_t) __attribute__((always_inline)) {
+            constexpr int m = decltype(m_t)::value;
+            constexpr int kb = m / NKB, jb = m % NKB;
+            const bf16x8 kf = __builtin_bit_cast(bf16x8, lds_kp[(jb * NKS + kb) * 64 + lane]);
+            if constexpr (kb == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    s_acc[jb][r] = (32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hf >= P.k) ? -INFINITY : 0.f;
+            }
+            s_acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kb], s_acc[jb], 0, 0, 0);
+        });
+        const bool has_next = f + 1 < f_end;
+        if (has_next) load_q(an, tn);   // next tile's Q under this tile's softmax
+        float mx0 = s_acc[0][0], mx1 = s_acc[0][1];
+        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
+            constexpr int jb = decltype(jb_t)::value;
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                mx0 = fmaxf(fmaxf(mx0, s_acc[jb][r]), s_acc[jb][r + 1]);
+                mx1 = fmaxf(fmaxf(mx1, s_acc[jb][r + 2]), s_acc[jb][r + 3]);
+            }
+        });
+        const float mc = xhalf_max(fmaxf(mx0, mx1)) * c_exp;
+        float l0 = 0.f, l1 = 0.f;
+        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
+            constexpr int jb = decltype(jb_t)::value;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                l0 += __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r], c_exp, -mc));
+                l1 += __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r + 1], c_exp, -mc));
+            }
+        });
+        const float lrow = xhalf_sum(l0 + l1);
+        if (row < n32 && hf == 0) {
+            float* dst = P.stats_out + ((int64_t)a * P.n + row) * 2;
+            dst[0] = mc;
+            dst[1] = lrow;
+        }
+        a = an;
+        t = tn;
+    }
+}
 
 // out[key, a*DK + col] = sum over the (workgroup, segment) partials of head a, ascending workgroup order
 template <int DK, int NKB>
@@ -638,12 +756,12 @@ inline bool make_plan(int64_t n, int k, int h, int dk, Plan* pl) {
     return true;
 }
 
-template <int DK, int NKB, typename QT, bool AUX>
+template <int DK, int NKB, typename QT, bool AUX, bool EXT = false>
 int launch_variant(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
     constexpr int NKS = DK / 16;
     const size_t lds = (size_t)(NKB * NKS) * 1024 + (size_t)TILE_ROWS * (p_row_bytes(NKB) + 2 * DK);
     static thread_local bool attr_set = false;
-    auto kern = sparse_attn_mfma_kernel<DK, NKB, QT, AUX>;
+    auto kern = sparse_attn_mfma_kernel<DK, NKB, QT, AUX, EXT>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
@@ -662,24 +780,85 @@ int launch_variant(const AttnParams& P, const Plan& pl, float* out, hipStream_t 
     return snf::check_launch("reduce_partials_kernel");
 }
 
+#define SNF_ATTN_CASE(NB, EXT)                                                                     \
+    case NB:                                                                                       \
+        return aux ? launch_variant<DK, NB, QT, true, EXT>(P, pl, out, s) : launch_variant<DK, NB, QT, false, EXT>(P, pl, out, s);
 template <int DK, typename QT>
 int launch_nkb(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
     const bool aux = P.attn != nullptr || P.lse != nullptr;
+    if (P.stats) {   // key-chunked launch: chunk sizes are in (kmax/2, kmax] -> 4, 6, 7 or 8 key blocks
+        switch (pl.nkb) {
+#ifndef SNF_ATTN_DEV
+            SNF_ATTN_CASE(4, true)
+            SNF_ATTN_CASE(6, true)
+            SNF_ATTN_CASE(8, true)
+#endif
+            SNF_ATTN_CASE(7, true)
+            default: snf::set_error("sparse_attn_mfma: chunked key-block count %d not built", pl.nkb); return SNF_EUNSUPPORTED;
+        }
+    }
     switch (pl.nkb) {
 #ifndef SNF_ATTN_DEV   // development builds instantiate the config-B shape only (the file takes minutes otherwise)
-        case 1: return aux ? launch_variant<DK, 1, QT, true>(P, pl, out, s) : launch_variant<DK, 1, QT, false>(P, pl, out, s);
-        case 2: return aux ? launch_variant<DK, 2, QT, true>(P, pl, out, s) : launch_variant<DK, 2, QT, false>(P, pl, out, s);
-        case 4: return aux ? launch_variant<DK, 4, QT, true>(P, pl, out, s) : launch_variant<DK, 4, QT, false>(P, pl, out, s);
-        case 6: return aux ? launch_variant<DK, 6, QT, true>(P, pl, out, s) : launch_variant<DK, 6, QT, false>(P, pl, out, s);
-        case 8: return aux ? launch_variant<DK, 8, QT, true>(P, pl, out, s) : launch_variant<DK, 8, QT, false>(P, pl, out, s);
+        SNF_ATTN_CASE(1, false)
+        SNF_ATTN_CASE(2, false)
+        SNF_ATTN_CASE(4, false)
+        SNF_ATTN_CASE(6, false)
+        SNF_ATTN_CASE(8, false)
 #endif
-        case 7: return aux ? launch_variant<DK, 7, QT, true>(P, pl, out, s) : launch_variant<DK, 7, QT, false>(P, pl, out, s);
+        SNF_ATTN_CASE(7, false)
         default: snf::set_error("sparse_attn_mfma: key-block count %d not built", pl.nkb); return SNF_EUNSUPPORTED;
     }
 }
+#undef SNF_ATTN_CASE
 
 inline size_t mfma_workspace_bytes(const Plan& pl, int dk) {
     return (size_t)pl.num_wg * pl.seg_count * (size_t)(pl.nkb * (dk / 32)) * 1024 * sizeof(float);
+}
+
+template <int DK, int NKB, typename QT>
+int launch_stats_variant(const AttnParams& P, const Plan& pl, hipStream_t s) {
+    constexpr int NKS = DK / 16;
+    hipLaunchKernelGGL((sparse_attn_stats_kernel<DK, NKB, QT>), dim3(pl.num_wg), dim3(256), (size_t)(NKB * NKS) * 1024, s, P);
+    return snf::check_launch("sparse_attn_stats_kernel");
+}
+template <int DK, typename QT>
+int launch_stats(const AttnParams& P, const Plan& pl, hipStream_t s) {
+    switch (pl.nkb) {
+#ifndef SNF_ATTN_DEV
+        case 4: return launch_stats_variant<DK, 4, QT>(P, pl, s);
+        case 6: return launch_stats_variant<DK, 6, QT>(P, pl, s);
+        case 8: return launch_stats_variant<DK, 8, QT>(P, pl, s);
+#endif
+        case 7: return launch_stats_variant<DK, 7, QT>(P, pl, s);
+        default: snf::set_error("sparse_attn_stats: key-block count %d not built", pl.nkb); return SNF_EUNSUPPORTED;
+    }
+}
+
+// Key chunking: one launch holds at most KMAX keys (Kp + P + V images in 160 KiB of LDS).  More keys are split into
+// n_chunks near-equal chunks; every chunk gets a statistics launch (row max / sum over its keys) and then a full launch
+// that normalises with the statistics of ALL chunks -- the softmax stays exact, Q is read 2 n_chunks times and V n_chunks
+// times instead of once.
+constexpr int MAX_CHUNKS = 8;
+struct ChunkPlan {
+    int n_chunks, chunk_k;   // chunk c covers keys [c * chunk_k, min(k, (c + 1) * chunk_k))
+};
+inline bool make_chunks(int k, int dk, ChunkPlan* cp) {
+    if (!(dk == 64 || dk == 128) || k < 1) return false;
+    const int kmax = dk == 128 ? 224 : 256;
+    const int nc = (k + kmax - 1) / kmax;
+    if (nc > MAX_CHUNKS) return false;
+    cp->n_chunks = nc;
+    cp->chunk_k = (k + nc - 1) / nc;
+    return true;
+}
+// bytes of the partial-accumulator area (largest chunk) and of the statistics area behind it
+inline bool chunked_workspace(int64_t n, int k, int h, int dk, size_t* partial_bytes, size_t* stats_bytes) {
+    ChunkPlan cp;
+    Plan pl;
+    if (!make_chunks(k, dk, &cp) || !make_plan(n, cp.chunk_k, h, dk, &pl)) return false;
+    *partial_bytes = (mfma_workspace_bytes(pl, dk) + 255) / 256 * 256;
+    *stats_bytes = cp.n_chunks > 1 ? (size_t)cp.n_chunks * h * n * 2 * sizeof(float) : 0;
+    return true;
 }
 
 }  // namespace
@@ -692,9 +871,9 @@ void snf_debug_attn_trace(void* buf) { g_attn_trace = reinterpret_cast<unsigned 
 size_t snf_sparse_attn_fwd_workspace_bytes(int64_t n, int k, int h, int dk, int mfma) {
     if (n < 1 || k < 1 || h < 1 || dk < 1) return 0;
     if (mfma) {
-        Plan pl;
-        if (!make_plan(n, k, h, dk, &pl)) return 0;
-        return mfma_workspace_bytes(pl, dk);
+        size_t pb, sb;
+        if (!chunked_workspace(n, k, h, dk, &pb, &sb)) return 0;
+        return pb + sb;
     }
     return snf::generic_attn_workspace_bytes(n, k, h, dk);
 }
@@ -705,10 +884,11 @@ int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t 
     SNF_REQUIRE(q && v && kp && out, "snf_sparse_attn_fwd_mfma: null pointer");
     SNF_REQUIRE(n >= 1 && k >= 1 && h >= 1, "snf_sparse_attn_fwd_mfma: bad shape");
     SNF_REQUIRE(qv_dtype == SNF_DT_F32 || qv_dtype == SNF_DT_BF16, "snf_sparse_attn_fwd_mfma: bad dtype %d", qv_dtype);
-    Plan pl;
-    if (!make_plan(n, k, h, dk, &pl)) {
-        snf::set_error("snf_sparse_attn_fwd_mfma: unsupported shape k=%d dk=%d (need dk == 64 with k <= 256, or dk == 128 "
-                       "with k <= 224)", k, dk);
+    ChunkPlan cp;
+    size_t partial_bytes = 0, stats_bytes = 0;
+    if (!make_chunks(k, dk, &cp) || !chunked_workspace(n, k, h, dk, &partial_bytes, &stats_bytes)) {
+        snf::set_error("snf_sparse_attn_fwd_mfma: unsupported shape k=%d dk=%d (need dk in {64, 128} and k <= %d)", k, dk,
+                       MAX_CHUNKS * (dk == 128 ? 224 : 256));
         return SNF_EUNSUPPORTED;
     }
     const int64_t d = (int64_t)h * dk;
@@ -724,7 +904,7 @@ int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t 
     SNF_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(kp) & 15) == 0,
                 "snf_sparse_attn_fwd_mfma: q / v / kp must be 16-byte aligned");
-    const size_t need = mfma_workspace_bytes(pl, dk);
+    const size_t need = partial_bytes + stats_bytes;
     if (!workspace || workspace_bytes < need) {
         snf::set_error("snf_sparse_attn_fwd_mfma: workspace %zu < %zu", workspace_bytes, need);
         return SNF_EWORKSPACE;
@@ -732,29 +912,60 @@ int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t 
     AttnParams P;
     P.q = q;
     P.v = v;
-    P.kp = kp;
     P.n = n;
     P.ldq = ldq;
     P.ldv = ldv;
     P.ldkp = d;
-    P.k = k;
     P.h = h;
     P.scale = scale;
-    P.attn = attn;
-    P.lse = lse;
+    P.attn_ld = k;
     P.partial = reinterpret_cast<float*>(workspace);
-    P.tiles_per_head = pl.tiles_per_head;
-    P.tiles_per_wg = pl.tiles_per_wg;
-    P.total_tiles = pl.total_tiles;
-    P.seg_count = pl.seg_count;
     P.trace = g_attn_trace;
+    float* stats = cp.n_chunks > 1 ? reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + partial_bytes)
+                                   : nullptr;
+    P.n_chunks = cp.n_chunks;
     hipStream_t s = snf::as_stream(stream);
-    if (dk == 128) {
-        if (qv_dtype == SNF_DT_F32) return launch_nkb<128, float>(P, pl, out, s);
-        return launch_nkb<128, unsigned short>(P, pl, out, s);
+    auto plan_chunk = [&](int c, Plan* pl) -> int {   // keys of chunk c; fills the launch geometry
+        const int k0 = c * cp.chunk_k;
+        const int kc = (k - k0 < cp.chunk_k) ? k - k0 : cp.chunk_k;
+        make_plan(n, kc, h, dk, pl);
+        P.kp = kp + (int64_t)k0 * d;
+        P.k = kc;
+        P.tiles_per_head = pl->tiles_per_head;
+        P.tiles_per_wg = pl->tiles_per_wg;
+        P.total_tiles = pl->total_tiles;
+        P.seg_count = pl->seg_count;
+        return k0;
+    };
+    Plan pl;
+    if (stats) {   // pass 1: row statistics of every chunk
+        P.attn = nullptr;
+        P.lse = nullptr;
+        P.stats = nullptr;
+        for (int c = 0; c < cp.n_chunks; ++c) {
+            plan_chunk(c, &pl);
+            P.stats_out = stats + (size_t)c * h * n * 2;
+            int rc = dk == 128 ? (qv_dtype == SNF_DT_F32 ? launch_stats<128, float>(P, pl, s)
+                                                         : launch_stats<128, unsigned short>(P, pl, s))
+                               : (qv_dtype == SNF_DT_F32 ? launch_stats<64, float>(P, pl, s)
+                                                         : launch_stats<64, unsigned short>(P, pl, s));
+            if (rc) return rc;
+        }
     }
-    if (qv_dtype == SNF_DT_F32) return launch_nkb<64, float>(P, pl, out, s);
-    return launch_nkb<64, unsigned short>(P, pl, out, s);
+    P.stats = stats;
+    P.stats_out = nullptr;
+    for (int c = 0; c < cp.n_chunks; ++c) {
+        const int k0 = plan_chunk(c, &pl);
+        P.attn = attn ? attn + k0 : nullptr;
+        P.lse = c == 0 ? lse : nullptr;
+        float* out_c = out + (int64_t)k0 * d;
+        int rc = dk == 128 ? (qv_dtype == SNF_DT_F32 ? launch_nkb<128, float>(P, pl, out_c, s)
+                                                     : launch_nkb<128, unsigned short>(P, pl, out_c, s))
+                           : (qv_dtype == SNF_DT_F32 ? launch_nkb<64, float>(P, pl, out_c, s)
+                                                     : launch_nkb<64, unsigned short>(P, pl, out_c, s));
+        if (rc) return rc;
+    }
+    return SNF_OK;
 }
 
 }  // extern "C"

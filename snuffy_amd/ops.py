@@ -241,8 +241,9 @@ def ln_mean_head(z, gamma, beta, eps, w_head, b_head, add_bf16=None, add_bias=No
 
 
 def mfma_attn_supported(k, dk):
-    """Shapes the MFMA attention kernel takes (Kp, P and V images share the 160 KiB LDS of a CU)."""
-    return (dk == 64 and 1 <= k <= 256) or (dk == 128 and 1 <= k <= 224)
+    """Shapes the MFMA attention kernel takes.  One launch holds 256 (dk = 64) / 224 (dk = 128) keys next to the P and V
+    images in the 160 KiB LDS of a CU; up to 8 key chunks are run back to back with exact cross-chunk softmax statistics."""
+    return (dk == 64 and 1 <= k <= 8 * 256) or (dk == 128 and 1 <= k <= 8 * 224)
 
 
 def _rows16(t, name):

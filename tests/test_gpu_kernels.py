@@ -203,7 +203,8 @@ def bf16r(t):
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("n,k,h,dk", [(1, 1, 1, 64), (100, 31, 2, 64), (128, 32, 6, 64), (129, 33, 3, 128),
                                       (1000, 64, 6, 128), (4099, 100, 6, 64), (2500, 200, 6, 128), (3000, 224, 2, 128),
-                                      (777, 256, 6, 64), (1500, 224, 1, 128), (1500, 250, 1, 64), (8192, 200, 6, 64), (640, 129, 4, 128)])
+                                      (777, 256, 6, 64), (1500, 224, 1, 128), (1500, 250, 1, 64), (8192, 200, 6, 64), (640, 129, 4, 128),
+                                      (1500, 250, 1, 128), (3000, 512, 6, 128), (2000, 600, 2, 64), (700, 1792, 1, 128)])
 def test_sparse_attn_mfma(n, k, h, dk, dt):
     g = torch.Generator().manual_seed(n * 3 + k)
     d = h * dk
@@ -253,8 +254,8 @@ def test_mfma_rejects_unsupported_shapes():
     with pytest.raises(SnuffyHipError):
         ops().sparse_attn_fwd_mfma(q, torch.zeros(64, 96, device=DEV), torch.zeros(8, 96, device=DEV), 64, 2)  # dk=48
     q = torch.zeros(64, 256, device=DEV)
-    with pytest.raises(SnuffyHipError):   # dk = 128 holds at most 224 keys next to the P and V images in LDS
-        ops().sparse_attn_fwd_mfma(q, torch.zeros(64, 256, device=DEV), torch.zeros(225, 256, device=DEV), 64, 2)
+    with pytest.raises(SnuffyHipError):   # dk = 128: 8 key chunks of 224 at most
+        ops().sparse_attn_fwd_mfma(q, torch.zeros(64, 256, device=DEV), torch.zeros(1793, 256, device=DEV), 64, 2)
 
 
 @pytest.mark.gpu
