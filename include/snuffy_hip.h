@@ -156,6 +156,19 @@ int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t 
                              void* workspace, size_t workspace_bytes, snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * K7-bwd  sparse attention backward, exact fp32    replaces autograd through attention(), snuffy.py:160-168
+ *   p [h, n, k] = the probabilities the forward returned (attn);  mask [h, n, k] nullable = dropout keep-mask already
+ *   divided by (1 - p_drop) (the forward used p o mask);  dout [k, d] = gradient of the attention output.
+ *       dV = (P o M) dO        dS = P o (dP - rowsum(dP o P)) * scale,  dP = (V dO^T) o M
+ *       dQ = dS Kp             dKp = dS^T Q   (deterministic slice reduction, as the forward's P^T V)
+ *   dq, dv [n, d], dkp [k, d] f32.  workspace: snf_sparse_attn_bwd_workspace_bytes (holds dS [h, n, k]).
+ * --------------------------------------------------------------------------------------------------------- */
+size_t snf_sparse_attn_bwd_workspace_bytes(int64_t n, int k, int h, int dk);
+int snf_sparse_attn_bwd_f32(const float* q, const float* kp, const float* v, const float* p, const float* mask,
+                            const float* dout, int64_t n, int k, int h, int dk, float scale, float* dq, float* dkp,
+                            float* dv, void* workspace, size_t workspace_bytes, snf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * K12-K14  ViT patch-embedding extractor (compute_feats.py:239-247 -> IClassifier -> VisionTransformer.forward)
  *   reference model files: utils_ssls_cf/vision_transformer_with_adapter_dino_version.py (vd), vision_transformer_dino.py,
  *   adapter.py, models_adapter_mae.py.  Dense projections stay library GEMMs; these entry points are the rest.

@@ -74,16 +74,21 @@ class ScatterRowsFn(torch.autograd.Function):
 class SparseAttnFn(torch.autograd.Function):
     """O = dropout(softmax_K(Q Kp^T / sqrt(dk)))^T V per head (snuffy.py:160-168).
 
-    Forward: snf_sparse_attn_fwd_f32 (P materialised: the backward below needs it).  Backward: library bmm's.
+    Forward: snf_sparse_attn_fwd_f32 (P materialised: the backward needs it).  Backward: snf_sparse_attn_bwd_f32.
     """
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, q, kp, v, h, dropout_p):
+    def forward(ctx, q, kp, v, h, dropout_p, bf16_operands=False):
         n, d = q.shape
         k = kp.shape[0]
         dk = d // h
-        out, p, _ = ops.sparse_attn_fwd(q, kp, v, h, need_attn=True)
+        if bf16_operands and ops.mfma_attn_supported(k, dk):
+            # bf16-autocast training: the forward runs on the matrix cores (bf16 Q / V, fp32 softmax, P returned in fp32);
+            # the backward stays exact fp32 on the saved P
+            out, p, _ = ops.sparse_attn_fwd_mfma(q.to(torch.bfloat16), v.to(torch.bfloat16), kp, n, h, need_attn=True)
+        else:
+            out, p, _ = ops.sparse_attn_fwd(q, kp, v, h, need_attn=True)
         mask = None
         if dropout_p > 0.0:
             mask = (torch.rand_like(p) >= dropout_p).to(p.dtype) / (1.0 - dropout_p)
@@ -102,20 +107,9 @@ class SparseAttnFn(torch.autograd.Function):
         k = kp.shape[0]
         dk = d // h
         scale = 1.0 / math.sqrt(dk)
-        do = dout.reshape(k, h, dk).transpose(0, 1)               # [h, K, dk]
-        vh = v.view(n, h, dk).transpose(0, 1)                     # [h, N, dk]
-        qh = q.view(n, h, dk).transpose(0, 1)
-        kh = kp.view(k, h, dk).transpose(0, 1)
-        pd = p if mask is None else p * mask
-        dv = torch.bmm(pd, do)                                    # [h, N, dk]
-        dpd = torch.bmm(vh, do.transpose(1, 2))                   # [h, N, K]
-        dp = dpd if mask is None else dpd * mask
-        ds = p * (dp - (dp * p).sum(-1, keepdim=True))
-        ds.mul_(scale)
-        dq = torch.bmm(ds, kh)                                    # [h, N, dk]
-        dkp = torch.bmm(ds.transpose(1, 2), qh)                   # [h, K, dk]
-        return (dq.transpose(0, 1).reshape(n, d), dkp.transpose(0, 1).reshape(k, d),
-                dv.transpose(0, 1).reshape(n, d), None, None)
+        # K7-bwd on the HIP kernels (exact fp32): dS never leaves the workspace, P / dP are not re-materialised by bmm's
+        dq, dkp, dv = ops.sparse_attn_bwd(q, kp, v, p, dout.float().contiguous(), h, mask=mask, scale=scale)
+        return dq, dkp, dv, None, None, None
 
 
 def critic_train(feats2, w, b):
@@ -149,7 +143,7 @@ def _encoder_layer_train(x2, sel, layer, need_attn):
         kp = F.linear(xs, lk.weight, lk.bias)
         v = F.linear(xn, lv.weight, lv.bias)
         p_drop = mha.dropout.p if training else 0.0
-        o, p = SparseAttnFn.apply(q, kp, v, mha.h, p_drop)
+        o, p = SparseAttnFn.apply(q, kp, v, mha.h, p_drop, torch.is_autocast_enabled())
         delta = F.linear(o, lo.weight, lo.bias)                                 # snuffy.py:205
         if training and drop0.p > 0:
             delta = F.dropout(delta, drop0.p, True)

@@ -163,6 +163,172 @@ __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward (exact fp32).  With Pd = P o M (M = dropout keep-mask / (1 - p), or 1):
+//   dV_a  = Pd_a dO_a                [n, dk]
+//   dPd_a = V_a dO_a^T ; dP = dPd o M ; dS = P o (dP - rowsum(dP o P)) * scale      [n, k]
+//   dQ_a  = dS_a Kp_a                [n, dk]
+//   dKp_a = dS_a^T Q_a               [k, dk]   (contraction over the n rows: pt_v_kernel + reduce_slices on (dS, Q))
+// bwd_ds mirrors scores_softmax (16 rows of one head per workgroup, dO streamed through LDS in 64-key chunks, a lane owns
+// keys lane, lane+64, ...); bwd_dq_dv is an LDS-tiled fp32 GEMM pair over the key axis.
+// ---------------------------------------------------------------------------------------------------------------
+template <int KPL>
+__global__ __launch_bounds__(256) void bwd_ds_kernel(const float* __restrict__ v, const float* __restrict__ dout,
+                                                     const float* __restrict__ p /*[h,n,k]*/,
+                                                     const float* __restrict__ mask /*[h,n,k] nullable*/, int64_t n, int k,
+                                                     int h, int dk, float scale, float* __restrict__ ds /*[h,n,k]*/) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int dkp = (dk + 3) & ~3;
+    const int kpitch = dkp + 4;
+    float* lv = lds;                       // [16][dkp]   V rows of this workgroup
+    float* ldo = lds + ROWS_PER_WG * dkp;  // [64][kpitch] dO rows of the current key chunk
+    const int a = blockIdx.y;
+    const int d_model = h * dk;
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS_PER_WG;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < ROWS_PER_WG * dkp; e += 256) {
+        int r = e / dkp, d = e - r * dkp;
+        int64_t row = row0 + r;
+        lv[e] = (row < n && d < dk) ? v[row * d_model + a * dk + d] : 0.f;
+    }
+    float dp[4][KPL];
+#pragma unroll
+    for (int c = 0; c < KPL; ++c) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < KCHUNK * dkp; e += 256) {
+            int j = e / dkp, d = e - j * dkp;
+            int key = c * KCHUNK + j;
+            ldo[j * kpitch + d] = (key < k && d < dk) ? dout[(int64_t)key * d_model + a * dk + d] : 0.f;
+        }
+        __syncthreads();
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float4* kv4 = reinterpret_cast<const float4*>(ldo + lane * kpitch);
+        for (int d4 = 0; d4 < dkp / 4; ++d4) {
+            float4 kv = kv4[d4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float4 qv = reinterpret_cast<const float4*>(lv + (wave * 4 + r) * dkp)[d4];
+                acc[r] = fmaf(qv.x, kv.x, acc[r]);
+                acc[r] = fmaf(qv.y, kv.y, acc[r]);
+                acc[r] = fmaf(qv.z, kv.z, acc[r]);
+                acc[r] = fmaf(qv.w, kv.w, acc[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dp[r][c] = acc[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + wave * 4 + r;
+        if (row >= n) continue;   // wave-uniform
+        const int64_t base = ((int64_t)a * n + row) * k;
+        float pr[KPL];
+        float dsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+            const int key = c * KCHUNK + lane;
+            pr[c] = 0.f;
+            if (key < k) {
+                pr[c] = p[base + key];
+                if (mask) dp[r][c] *= mask[base + key];
+                dsum = fmaf(dp[r][c], pr[c], dsum);
+            }
+        }
+        dsum = wave_sum(dsum);
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+            const int key = c * KCHUNK + lane;
+            if (key < k) ds[base + key] = pr[c] * (dp[r][c] - dsum) * scale;
+        }
+    }
+}
+
+// dV tile and dQ tile of 64 rows x 64 columns of one head: acc_v += (P o M)[rows, keys] dO[keys, cols],
+// acc_q += dS[rows, keys] Kp[keys, cols]; keys in steps of 16 through LDS; 256 threads, 4x4 micro-tiles.
+__global__ __launch_bounds__(256) void bwd_dq_dv_kernel(const float* __restrict__ p, const float* __restrict__ mask,
+                                                        const float* __restrict__ ds, const float* __restrict__ dout,
+                                                        const float* __restrict__ kp, int64_t n, int k, int h, int dk,
+                                                        float* __restrict__ dq, float* __restrict__ dv) {
+    __shared__ float lp[16][64 + 4];    // [key][row]  Pd^T tile
+    __shared__ float lds_[16][64 + 4];  // [key][row]  dS^T tile
+    __shared__ float ldo[16][64 + 4];   // [key][col]
+    __shared__ float lkp[16][64 + 4];   // [key][col]
+    const int a = blockIdx.z;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const int d_model = h * dk;
+    const int tr = threadIdx.x & 15, tc = threadIdx.x >> 4;
+    float acc_v[4][4], acc_q[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc_v[i][j] = acc_q[i][j] = 0.f;
+    // loaders: P / dS tile [64 rows][16 keys] read along keys (contiguous), stored transposed; dO / Kp tile [16 keys][64 cols]
+    const int lrow = threadIdx.x >> 2;        // 0..63
+    const int lkey = (threadIdx.x & 3) * 4;   // 0,4,8,12
+    const int okey = threadIdx.x >> 4;        // 0..15
+    const int ocol = (threadIdx.x & 15) * 4;  // 0..60
+    for (int j0 = 0; j0 < k; j0 += 16) {
+        const int64_t row = r0 + lrow;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int key = j0 + lkey + t;
+            float pv = 0.f, sv = 0.f;
+            if (row < n && key < k) {
+                const int64_t e = ((int64_t)a * n + row) * k + key;
+                pv = p[e];
+                if (mask) pv *= mask[e];
+                sv = ds[e];
+            }
+            lp[lkey + t][lrow] = pv;
+            lds_[lkey + t][lrow] = sv;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int key = j0 + okey, col = c0 + ocol + t;
+            const bool ok = key < k && col < dk;
+            ldo[okey][ocol + t] = ok ? dout[(int64_t)key * d_model + a * dk + col] : 0.f;
+            lkp[okey][ocol + t] = ok ? kp[(int64_t)key * d_model + a * dk + col] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float pv[4], sv[4], ov[4], kv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pv[i] = lp[kk][tr * 4 + i];
+                sv[i] = lds_[kk][tr * 4 + i];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ov[j] = ldo[kk][tc * 4 + j];
+                kv[j] = lkp[kk][tc * 4 + j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc_v[i][j] = fmaf(pv[i], ov[j], acc_v[i][j]);
+                    acc_q[i][j] = fmaf(sv[i], kv[j], acc_q[i][j]);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t row = r0 + tr * 4 + i;
+        if (row >= n) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = c0 + tc * 4 + j;
+            if (col < dk) {
+                dv[row * d_model + a * dk + col] = acc_v[i][j];
+                dq[row * d_model + a * dk + col] = acc_q[i][j];
+            }
+        }
+    }
+}
+
 inline int generic_slices(int64_t n) {
     int64_t s = (n + 511) / 512;
     if (s > 64) s = 64;
@@ -181,6 +347,60 @@ size_t generic_attn_workspace_bytes(int64_t n, int k, int h, int dk) {
 }  // namespace snf
 
 extern "C" {
+
+size_t snf_sparse_attn_bwd_workspace_bytes(int64_t n, int k, int h, int dk) {
+    if (n < 1 || k < 1 || h < 1 || dk < 1) return 0;
+    return snf::generic_attn_workspace_bytes(n, k, h, dk);   // dS [h,n,k] + the dKp slice partials
+}
+
+int snf_sparse_attn_bwd_f32(const float* q, const float* kp, const float* v, const float* p, const float* mask,
+                            const float* dout, int64_t n, int k, int h, int dk, float scale, float* dq, float* dkp,
+                            float* dv, void* workspace, size_t workspace_bytes, snf_stream_t stream) {
+    SNF_REQUIRE(q && kp && v && p && dout && dq && dkp && dv, "snf_sparse_attn_bwd_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && k >= 1 && h >= 1 && dk >= 1, "snf_sparse_attn_bwd_f32: bad shape n=%lld k=%d h=%d dk=%d",
+                (long long)n, k, h, dk);
+    SNF_REQUIRE(k <= 2048 && dk <= 256 && h <= 65535, "snf_sparse_attn_bwd_f32: k=%d / dk=%d / h=%d out of range", k, dk, h);
+    const size_t need = snf::generic_attn_workspace_bytes(n, k, h, dk);
+    if (!workspace || workspace_bytes < need) {
+        snf::set_error("snf_sparse_attn_bwd_f32: workspace %zu < %zu", workspace_bytes, need);
+        return SNF_EWORKSPACE;
+    }
+    const size_t pbytes = ((size_t)h * (size_t)n * (size_t)k * sizeof(float) + 255) & ~(size_t)255;
+    float* ds = reinterpret_cast<float*>(workspace);
+    float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pbytes);
+    hipStream_t s = snf::as_stream(stream);
+    const int dk4 = (dk + 3) & ~3;
+    const size_t lds = (size_t)(ROWS_PER_WG * dk4 + KCHUNK * (dk4 + 4)) * sizeof(float);
+    dim3 grid1((unsigned)((n + ROWS_PER_WG - 1) / ROWS_PER_WG), (unsigned)h);
+    const int kpl = (k + 63) / 64;
+#define LAUNCH_DS(KPL) \
+    hipLaunchKernelGGL((bwd_ds_kernel<KPL>), grid1, dim3(256), lds, s, v, dout, p, mask, n, k, h, dk, scale, ds)
+    if (kpl <= 1) LAUNCH_DS(1);
+    else if (kpl <= 2) LAUNCH_DS(2);
+    else if (kpl <= 4) LAUNCH_DS(4);
+    else if (kpl <= 8) LAUNCH_DS(8);
+    else if (kpl <= 16) LAUNCH_DS(16);
+    else LAUNCH_DS(32);
+#undef LAUNCH_DS
+    int rc = snf::check_launch("bwd_ds_kernel");
+    if (rc) return rc;
+    dim3 grid2((unsigned)((n + 63) / 64), (unsigned)((dk + 63) / 64), (unsigned)h);
+    hipLaunchKernelGGL(bwd_dq_dv_kernel, grid2, dim3(256), 0, s, p, mask, ds, dout, kp, n, k, h, dk, dq, dv);
+    rc = snf::check_launch("bwd_dq_dv_kernel");
+    if (rc) return rc;
+    // dKp = dS^T Q: the forward's P^T V machinery on (dS, Q)
+    const int slices = generic_slices(n);
+    const int64_t rows_per_slice = (((n + slices - 1) / slices) + 15) & ~(int64_t)15;
+    dim3 grid3((unsigned)((k + 63) / 64), (unsigned)((dk + 63) / 64), (unsigned)(slices * h));
+    hipLaunchKernelGGL(pt_v_kernel, grid3, dim3(256), 0, s, ds, q, n, k, h, dk, rows_per_slice, partial);
+    rc = snf::check_launch("pt_v_kernel(dS, Q)");
+    if (rc) return rc;
+    const int64_t total = (int64_t)h * k * dk;
+    int rgrid = (int)((total + 255) / 256);
+    if (rgrid > 2048) rgrid = 2048;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3(rgrid), dim3(256), 0, s, partial, slices, k, h, dk, dkp);
+    return snf::check_launch("reduce_slices_kernel");
+}
 
 int snf_sparse_attn_fwd_f32(const float* q, const float* kp, const float* v, int64_t n, int k, int h, int dk, float scale,
                             float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,

@@ -240,6 +240,33 @@ def ln_mean_head(z, gamma, beta, eps, w_head, b_head, add_bf16=None, add_bias=No
     return logits, pooled, z_out
 
 
+def sparse_attn_bwd(q, kp, v, p, dout, h, mask=None, scale=None):
+    """Exact-fp32 backward of sparse_attn_fwd: (dq [n,d], dkp [k,d], dv [n,d]).  p [h,n,k] = forward probabilities,
+    mask (optional) = dropout keep-mask already divided by (1 - p_drop), dout [k, d]."""
+    q = _req(q, torch.float32, "q", 2)
+    kp = _req(kp, torch.float32, "kp", 2)
+    v = _req(v, torch.float32, "v", 2)
+    p = _req(p, torch.float32, "p", 3)
+    dout = _req(dout, torch.float32, "dout", 2)
+    if mask is not None:
+        mask = _req(mask, torch.float32, "mask", 3)
+    n, d = q.shape
+    k = kp.shape[0]
+    dk = d // h
+    if p.shape != (h, n, k) or dout.shape != (k, d) or (mask is not None and mask.shape != p.shape):
+        raise ValueError("sparse_attn_bwd: inconsistent shapes")
+    scale = 1.0 / math.sqrt(dk) if scale is None else scale
+    lib = _ffi.load()
+    dq = torch.empty_like(q)
+    dv = torch.empty_like(v)
+    dkp = torch.empty_like(kp)
+    wsb = lib.snf_sparse_attn_bwd_workspace_bytes(n, k, h, dk)
+    ws = _ws(wsb, q.device)
+    check(lib.snf_sparse_attn_bwd_f32(_p(q), _p(kp), _p(v), _p(p), _p(mask), _p(dout), n, k, h, dk, float(scale), _p(dq),
+                                      _p(dkp), _p(dv), _p(ws), wsb, _stream()), "snf_sparse_attn_bwd_f32")
+    return dq, dkp, dv
+
+
 def mfma_attn_supported(k, dk):
     """Shapes the MFMA attention kernel takes.  One launch holds 256 (dk = 64) / 224 (dk = 128) keys next to the P and V
     images in the 160 KiB LDS of a CU; up to 8 key chunks are run back to back with exact cross-chunk softmax statistics."""

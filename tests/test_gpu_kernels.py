@@ -283,3 +283,33 @@ def test_gather_slot_map_equals_separate_kernels(n, d, k):
     assert torch.equal(xs, ops().gather_rows(x, idx))
     assert torch.equal(m, ops().slot_map(idx, n))
     assert torch.equal(xs, x[idx])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k,h,dk,drop", [(1, 1, 1, 8, 0.0), (50, 7, 2, 16, 0.0), (1000, 200, 6, 64, 0.0), (777, 130, 3, 83, 0.0),
+                                           (2048, 200, 6, 128, 0.0), (300, 64, 2, 32, 0.3), (5000, 512, 2, 64, 0.0)])
+def test_sparse_attn_bwd_matches_autograd_reference(n, k, h, dk, drop):
+    """snf_sparse_attn_bwd_f32 against torch.autograd through the plain fp64 formulation of snuffy.py:160-168."""
+    g = torch.Generator().manual_seed(n + k + dk)
+    d = h * dk
+    q, kp, v = (torch.randn(s, d, generator=g) for s in (n, k, n))
+    dout = torch.randn(k, d, generator=g)
+    mask = None
+    if drop > 0:
+        mask = (torch.rand(h, n, k, generator=g) >= drop).float() / (1.0 - drop)
+    _, p, _ = ops().sparse_attn_fwd(q.to(DEV), kp.to(DEV), v.to(DEV), h, need_attn=True)
+    dq, dkp, dv = ops().sparse_attn_bwd(q.to(DEV), kp.to(DEV), v.to(DEV), p, dout.to(DEV), h,
+                                        mask=None if mask is None else mask.to(DEV))
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, kp, v))
+    qh, kh, vh = (t.view(-1, h, dk).transpose(0, 1) for t in (qd, kd, vd))
+    pr = torch.softmax(qh @ kh.transpose(1, 2) / dk ** 0.5, dim=-1)
+    if mask is not None:
+        pr = pr * mask.double()
+    o = (pr.transpose(1, 2) @ vh).transpose(0, 1).reshape(k, d)
+    o.backward(dout.double())
+    for got, ref, name in ((dq, qd.grad, "dq"), (dkp, kd.grad, "dkp"), (dv, vd.grad, "dv")):
+        assert rel_err(got.cpu(), ref) < 2e-5, name
+    # deterministic
+    dq2, dkp2, dv2 = ops().sparse_attn_bwd(q.to(DEV), kp.to(DEV), v.to(DEV), p, dout.to(DEV), h,
+                                           mask=None if mask is None else mask.to(DEV))
+    assert torch.equal(dq, dq2) and torch.equal(dkp, dkp2) and torch.equal(dv, dv2)
