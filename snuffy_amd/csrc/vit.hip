@@ -23,6 +23,8 @@ typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -240,15 +242,21 @@ __global__ __launch_bounds__(256) void vit_attention_f32_kernel(const float* __r
 // ---------------------------------------------------------------------------------------------------------------
 // bf16 MFMA self-attention, dk = 64, T <= 32 * NKB.  qkv bf16 [B*T, 3*h*64]; out bf16 [B*T, h*64].
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int VIT_ATTN_THREADS = 512;   // 8 waves: one 32-query tile each (T = 197 -> 7 tiles in one round)
 template <int NKB>
-__global__ __launch_bounds__(256, (NKB <= 4 ? 2 : 1)) void vit_attention_mfma_kernel(const unsigned short* __restrict__ qkv, int B, int T, int h,
-                                                                    float scale, unsigned short* __restrict__ out) {
+__global__ __launch_bounds__(VIT_ATTN_THREADS, 4) void vit_attention_mfma_kernel(const unsigned short* __restrict__ qkv, int B,
+                                                                                 int T, int h, float scale,
+                                                                                 unsigned short* __restrict__ out) {
     constexpr int DK = 64;
+    constexpr int NW = VIT_ATTN_THREADS / 64;   // waves per workgroup = query tiles in flight
     constexpr int KPITCH = DK + 8;            // bf16 elements; 144 B rows: conflict-free ds_read_b128 of a K fragment
-    constexpr int VPITCH = 32 * NKB + 12;     // bf16 elements; pitch/2 dwords == 2 (mod 4): conflict-free ds_read_b64
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned short* lds_k = reinterpret_cast<unsigned short*>(smem);                       // [32*NKB][KPITCH]
-    unsigned short* lds_vt = lds_k + 32 * NKB * KPITCH;                                     // [DK][VPITCH]
+    // V stays ROW-major in LDS ([key][64], 128-byte rows, 16-byte chunk c of row r at chunk position (c + 4*((r>>1)&1)) & 7):
+    // the A operand of O^T = V^T P^T (lane = d, 8 keys in registers) is read back with the hardware transpose-read
+    // ds_read_b64_tr_b16, so staging is one 16-byte store per chunk instead of eight 2-byte transposing stores.  The
+    // rotation spreads the 4 rows x 64 bytes a transpose-read group touches over all 64 banks.
+    unsigned char* lds_v = smem + 32 * NKB * KPITCH * 2;                                     // [32*NKB][128 B]
     const int a = blockIdx.x, b = blockIdx.y;
     const int D = h * DK;
     const int64_t base = (int64_t)b * T;
@@ -256,97 +264,133 @@ __global__ __launch_bounds__(256, (NKB <= 4 ? 2 : 1)) void vit_attention_mfma_ke
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, hf = lane >> 5;
 
-    // stage K (row-major) and V^T (transposed) of this (image, head); rows >= T are zero
-    for (int c = threadIdx.x; c < 32 * NKB * (DK / 8); c += 256) {
-        const int key = c >> 3, part = c & 7;
-        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-        if (key < T) {
-            const unsigned short* rowp = qkv + (base + key) * 3 * D + a * DK + part * 8;
-            kv = *reinterpret_cast<const u32x4*>(rowp + D);
-            vv = *reinterpret_cast<const u32x4*>(rowp + 2 * D);
-        }
-        *reinterpret_cast<u32x4*>(lds_k + key * KPITCH + part * 8) = kv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            lds_vt[(part * 8 + 2 * e) * VPITCH + key] = (unsigned short)(vv[e] & 0xffffu);
-            lds_vt[(part * 8 + 2 * e + 1) * VPITCH + key] = (unsigned short)(vv[e] >> 16);
-        }
-    }
-    __syncthreads();
-
-    const float c_exp = scale * 1.44269504088896340736f;
+    // this wave's first query tile is requested before anything else (B operand: lane = query, 8 consecutive dk per k-step)
     const int ntile = (T + 31) / 32;
-    for (int tile = w; tile < ntile; tile += 4) {
-        // Q fragments (B operand: lane = query, 8 consecutive dk per k-step)
+    bf16x8 qf[4];
+    auto load_q = [&](int tile) __attribute__((always_inline)) {
         int qrow = 32 * tile + j;
         if (qrow > T - 1) qrow = T - 1;
         const unsigned short* qp = qkv + (base + qrow) * 3 * D + a * DK + 8 * hf;
-        bf16x8 qf[4];
         static_for<0, 4>([&](auto ks) __attribute__((always_inline)) {
             qf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp + 16 * ks));
         });
-        // GEMM1: S^T[key, q] = K Q^T ; keys beyond T start at -inf
-        f32x16 s_acc[NKB];
-        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
-            constexpr int jb = decltype(jb_t)::value;
+    };
+    if (w < ntile) load_q(w);
+
+    // stage K and V of this (image, head): every global load of the thread is issued before the first LDS store (one
+    // memory latency for the whole tile, not one per chunk); rows >= T are zero
+    constexpr int NI = (32 * NKB * 8 + VIT_ATTN_THREADS - 1) / VIT_ATTN_THREADS;
+    {
+        u32x4 kst[NI], vst[NI];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = 32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                s_acc[jb][r] = (key >= T) ? -INFINITY : 0.f;
+        for (int i = 0; i < NI; ++i) {
+            const int c = threadIdx.x + VIT_ATTN_THREADS * i;
+            const int key = c >> 3, part = c & 7;
+            kst[i] = u32x4{0u, 0u, 0u, 0u};
+            vst[i] = u32x4{0u, 0u, 0u, 0u};
+            if (key < T) {
+                const unsigned short* rowp = qkv + (base + key) * 3 * D + a * DK + part * 8;
+                kst[i] = *reinterpret_cast<const u32x4*>(rowp + D);
+                vst[i] = *reinterpret_cast<const u32x4*>(rowp + 2 * D);
             }
-            static_for<0, 4>([&](auto ks) __attribute__((always_inline)) {
-                bf16x8 kf = __builtin_bit_cast(
-                    bf16x8, *reinterpret_cast<const u32x4*>(lds_k + (32 * jb + j) * KPITCH + 16 * ks + 8 * hf));
-                s_acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc[jb], 0, 0, 0);
-            });
-            __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of later key blocks from being hoisted (spills)
-        });
-        // softmax over keys: registers of this lane + the partner half-wave
-        float m = -INFINITY;
-        static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m = fmaxf(m, s_acc[jb][r]);
-        });
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        const float mc = m * c_exp;
-        float l = 0.f;
-        static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r], c_exp, -mc));
-                s_acc[jb][r] = e;
-                l += e;
+        for (int i = 0; i < NI; ++i) {
+            const int c = threadIdx.x + VIT_ATTN_THREADS * i;
+            const int key = c >> 3, part = c & 7;
+            if (key < 32 * NKB) {
+                *reinterpret_cast<u32x4*>(lds_k + key * KPITCH + part * 8) = kst[i];
+                *reinterpret_cast<u32x4*>(lds_v + key * 128 + 16 * ((part + 4 * ((key >> 1) & 1)) & 7)) = vst[i];
             }
-        });
-        l += __shfl_xor(l, 32, 64);
-        const float inv = __builtin_amdgcn_rcpf(l);
-        // GEMM2: O^T[d, q] = V^T P^T ; B operand = P^T fragments straight from the C registers
+        }
+    }
+    __syncthreads();
+    // transpose-read addressing of a V^T fragment (d block db, keys k_base ..): this lane's 16-lane group g covers
+    // d = 32 db + 16 (g & 1) + i, keys k_base + 4 (g >> 1) + {0..3} (first read) and the same + 8 (second)
+    const int tg = lane >> 4, ti = lane & 15;
+    const int vkey = 4 * (tg >> 1) + (ti >> 2);                 // the row this lane's chunk comes from
+    const int vch = 2 * (tg & 1) + ((ti & 3) >> 1);             // 16-byte chunk inside the 64-byte d block, + 4 db
+    const int vhalf = 8 * (ti & 1);
+    auto v_frag = [&](int k_base, int db) __attribute__((always_inline)) -> bf16x8 {
+        const int r0 = k_base + vkey, r1 = r0 + 8;
+        const unsigned char* p0 = lds_v + r0 * 128 + 16 * ((vch + 4 * db + 4 * ((r0 >> 1) & 1)) & 7) + vhalf;
+        const unsigned char* p1 = lds_v + r1 * 128 + 16 * ((vch + 4 * db + 4 * ((r1 >> 1) & 1)) & 7) + vhalf;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+        const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, vv);
+    };
+
+    const float c_exp = scale * 1.44269504088896340736f;
+    for (int tile = w; tile < ntile; tile += NW) {
+        if (tile != w) load_q(tile);
+        // Flash-style pass over the key blocks: S^T block = K_jb Q^T (keys in registers, this lane's query on the lane), online
+        // softmax with a running maximum, O^T += V^T P^T with P^T straight from the C registers.  ~100 registers per wave
+        // instead of 16*NKB + ... for the whole score row: two workgroups of eight waves stay resident per CU.
         f32x16 o_acc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             o_acc[0][r] = 0.f;
             o_acc[1][r] = 0.f;
         }
-        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
-            constexpr int jb = decltype(jb_t)::value;
+        float m_run = -INFINITY, l_lane = 0.f;   // running max (all-reduced over the two half-waves), lane-local sum
+#pragma unroll 1   // a rolled loop: unrolled, the per-block LDS addresses alone cost ~70 registers (two workgroups per CU need <= 128)
+        for (int jb = 0; jb < NKB; ++jb) {
+            f32x16 s_acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                s_acc[r] = (key >= T) ? -INFINITY : 0.f;
+            }
+            static_for<0, 4>([&](auto ks) __attribute__((always_inline)) {
+                bf16x8 kf = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const u32x4*>(lds_k + (32 * jb + j) * KPITCH + 16 * ks + 8 * hf));
+                s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc, 0, 0, 0);
+            });
+            float mb0 = fmaxf(s_acc[0], s_acc[1]), mb1 = fmaxf(s_acc[2], s_acc[3]);
+#pragma unroll
+            for (int r = 4; r < 16; r += 4) {
+                mb0 = fmaxf(fmaxf(mb0, s_acc[r]), s_acc[r + 1]);
+                mb1 = fmaxf(fmaxf(mb1, s_acc[r + 2]), s_acc[r + 3]);
+            }
+            float mb = fmaxf(mb0, mb1);
+            mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+            // block 0 always holds a valid key, so m_new is finite from the first block on
+            const float m_new = fmaxf(m_run, mb);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);   // exp2(-inf) = 0 on the first block
+            const float mc = m_new * c_exp;
+            m_run = m_new;
+            float lsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(s_acc[r], c_exp, -mc));
+                s_acc[r] = e;
+                lsum += e;
+            }
+            l_lane = fmaf(l_lane, alpha, lsum);
+            if (jb > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o_acc[0][r] *= alpha;
+                    o_acc[1][r] *= alpha;
+                }
+            }
             static_for<0, 2>([&](auto u_t) __attribute__((always_inline)) {
                 constexpr int u = decltype(u_t)::value;
                 f32x8 pv;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pv[e] = s_acc[jb][8 * u + e] * inv;
+                for (int e = 0; e < 8; ++e) pv[e] = s_acc[8 * u + e];
                 const bf16x8 pf = __builtin_convertvector(pv, bf16x8);
                 // this lane's 8 keys of the k-step: {16u + 4hf + 0..3} and {16u + 8 + 4hf + 0..3} of block jb
-                const int k0 = 32 * jb + 16 * u + 4 * hf;
-                static_for<0, 2>([&](auto db) __attribute__((always_inline)) {
-                    const unsigned short* vp = lds_vt + (32 * db + j) * VPITCH + k0;
-                    u32x2 lo = *reinterpret_cast<const u32x2*>(vp);
-                    u32x2 hi = *reinterpret_cast<const u32x2*>(vp + 8);
-                    u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
-                    o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, o_acc[db], 0, 0, 0);
+                static_for<0, 2>([&](auto db_t) __attribute__((always_inline)) {
+                    constexpr int db = decltype(db_t)::value;
+                    o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(32 * jb + 16 * u, db), pf, o_acc[db], 0, 0, 0);
                 });
             });
-            __builtin_amdgcn_sched_barrier(0);
-        });
+        }
+        const float l = l_lane + __shfl_xor(l_lane, 32, 64);
+        const float inv = __builtin_amdgcn_rcpf(l);
         // store O: lane = query row, 4 consecutive d per register group
         const int q_out = 32 * tile + j;
         if (q_out < T) {
@@ -355,8 +399,8 @@ __global__ __launch_bounds__(256, (NKB <= 4 ? 2 : 1)) void vit_attention_mfma_ke
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int d0 = 32 * db + 8 * g + 4 * hf;
-                    u32x2 o = {pack_bf16x2(o_acc[db][4 * g], o_acc[db][4 * g + 1]),
-                               pack_bf16x2(o_acc[db][4 * g + 2], o_acc[db][4 * g + 3])};
+                    u32x2 o = {pack_bf16x2(o_acc[db][4 * g] * inv, o_acc[db][4 * g + 1] * inv),
+                               pack_bf16x2(o_acc[db][4 * g + 2] * inv, o_acc[db][4 * g + 3] * inv)};
                     *reinterpret_cast<u32x2*>(op + d0) = o;
                 }
             });
@@ -366,7 +410,7 @@ __global__ __launch_bounds__(256, (NKB <= 4 ? 2 : 1)) void vit_attention_mfma_ke
 
 template <int NKB>
 int launch_vit_mfma(const unsigned short* qkv, int B, int T, int h, float scale, unsigned short* out, hipStream_t s) {
-    const size_t lds = (size_t)(32 * NKB * (64 + 8) + 64 * (32 * NKB + 12)) * sizeof(unsigned short);
+    const size_t lds = (size_t)(32 * NKB * (64 + 8)) * sizeof(unsigned short) + (size_t)32 * NKB * 128;
     static thread_local bool attr_set = false;
     auto kern = vit_attention_mfma_kernel<NKB>;
     if (!attr_set && lds > 48 * 1024) {
@@ -378,7 +422,7 @@ int launch_vit_mfma(const unsigned short* qkv, int B, int T, int h, float scale,
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(h, B), dim3(256), lds, s, qkv, B, T, h, scale, out);
+    hipLaunchKernelGGL(kern, dim3(h, B), dim3(VIT_ATTN_THREADS), lds, s, qkv, B, T, h, scale, out);
     return snf::check_launch("vit_attention_mfma_kernel");
 }
 
