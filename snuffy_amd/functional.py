@@ -278,6 +278,9 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
     ops.layernorm_rows(x_sel, None, None, n1.eps, out=xhat, out_row_idx=sel)        # re-normalise the K rows in place
     if ff.activation_name == "relu":
         hid = torch._addmm_activation(fw["b1h"], xhat, fw["w1"].t())            # GEMM + bias + ReLU epilogue
+    elif ff.activation_name == "gelu":
+        # GEMM + bias + GELU epilogue (tanh form: within 4.7e-4 of the erf form, far below the bf16 rounding of hid)
+        hid = torch._addmm_activation(fw["b1h"], xhat, fw["w1"].t(), use_gelu=True)
     else:
         hid = torch.mm(xhat, fw["w1"].t())                                          # [N, F] bf16
         ops.bias_act_(hid, fw["b1"], ff.activation_name)
