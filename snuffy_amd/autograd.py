@@ -83,28 +83,39 @@ class SparseAttnFn(torch.autograd.Function):
         n, d = q.shape
         k = kp.shape[0]
         dk = d // h
+        lse = None
         if bf16_operands and ops.mfma_attn_supported(k, dk):
-            # bf16-autocast training: the forward runs on the matrix cores (bf16 Q / V, fp32 softmax, P returned in fp32);
-            # the backward stays exact fp32 on the saved P
-            out, p, _ = ops.sparse_attn_fwd_mfma(q.to(torch.bfloat16), v.to(torch.bfloat16), kp, n, h, need_attn=True)
+            # bf16-autocast training: the forward runs on the matrix cores (bf16 Q / V, fp32 softmax, P returned in fp32)
+            q16, v16 = q.to(torch.bfloat16), v.to(torch.bfloat16)
+            fast_bwd = ops.mfma_attn_bwd_supported(k, dk)
+            out, p, lse = ops.sparse_attn_fwd_mfma(q16, v16, kp, n, h, need_attn=True, need_lse=fast_bwd)
+            if fast_bwd:
+                q, v = q16, v16          # the MFMA backward recomputes P from the bf16 operands and lse
         else:
             out, p, _ = ops.sparse_attn_fwd(q, kp, v, h, need_attn=True)
         mask = None
         if dropout_p > 0.0:
             mask = (torch.rand_like(p) >= dropout_p).to(p.dtype) / (1.0 - dropout_p)
-            vh = v.view(n, h, dk).transpose(0, 1)
+            vh = v.float().view(n, h, dk).transpose(0, 1)
             out = torch.bmm((p * mask).transpose(1, 2), vh).transpose(0, 1).reshape(k, d)
-        ctx.save_for_backward(q, kp, v, p, mask)
+        if lse is not None:
+            ctx.save_for_backward(q, kp, v, lse, mask)      # P itself is not kept for the backward
+        else:
+            ctx.save_for_backward(q, kp, v, p, mask)
+        ctx.fast_bwd = lse is not None
         ctx.h = h
         return out, p
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dout, _dp_unused):
-        q, kp, v, p, mask = ctx.saved_tensors
         h = ctx.h
+        if ctx.fast_bwd:
+            q, kp, v, lse, mask = ctx.saved_tensors
+            dq, dkp, dv = ops.sparse_attn_bwd_mfma(q, v, kp, dout.float().contiguous(), lse, h, mask=mask)
+            return dq, dkp, dv, None, None, None
+        q, kp, v, p, mask = ctx.saved_tensors
         n, d = q.shape
-        k = kp.shape[0]
         dk = d // h
         scale = 1.0 / math.sqrt(dk)
         # K7-bwd on the HIP kernels (exact fp32): dS never leaves the workspace, P / dP are not re-materialised by bmm's

@@ -402,6 +402,30 @@ int snf_sparse_attn_bwd_f32(const float* q, const float* kp, const float* v, con
     return snf::check_launch("reduce_slices_kernel");
 }
 
+int snf_sparse_attn_dkp_f32(const float* ds, const float* q, int64_t n, int k, int h, int dk, float* dkp, void* workspace,
+                            size_t workspace_bytes, snf_stream_t stream) {
+    SNF_REQUIRE(ds && q && dkp, "snf_sparse_attn_dkp_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && k >= 1 && h >= 1 && dk >= 1 && h <= 65535, "snf_sparse_attn_dkp_f32: bad shape");
+    const int slices = generic_slices(n);
+    const size_t need = (size_t)slices * h * (size_t)k * dk * sizeof(float);
+    if (!workspace || workspace_bytes < need) {
+        snf::set_error("snf_sparse_attn_dkp_f32: workspace %zu < %zu", workspace_bytes, need);
+        return SNF_EWORKSPACE;
+    }
+    float* partial = reinterpret_cast<float*>(workspace);
+    hipStream_t s = snf::as_stream(stream);
+    const int64_t rows_per_slice = (((n + slices - 1) / slices) + 15) & ~(int64_t)15;
+    dim3 grid((unsigned)((k + 63) / 64), (unsigned)((dk + 63) / 64), (unsigned)(slices * h));
+    hipLaunchKernelGGL(pt_v_kernel, grid, dim3(256), 0, s, ds, q, n, k, h, dk, rows_per_slice, partial);
+    int rc = snf::check_launch("pt_v_kernel(dS, Q)");
+    if (rc) return rc;
+    const int64_t total = (int64_t)h * k * dk;
+    int rgrid = (int)((total + 255) / 256);
+    if (rgrid > 2048) rgrid = 2048;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3(rgrid), dim3(256), 0, s, partial, slices, k, h, dk, dkp);
+    return snf::check_launch("reduce_slices_kernel");
+}
+
 int snf_sparse_attn_fwd_f32(const float* q, const float* kp, const float* v, int64_t n, int k, int h, int dk, float scale,
                             float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
                             snf_stream_t stream) {

@@ -267,6 +267,41 @@ def sparse_attn_bwd(q, kp, v, p, dout, h, mask=None, scale=None):
     return dq, dkp, dv
 
 
+def mfma_attn_bwd_supported(k, dk):
+    return dk == 128 and 1 <= k <= 224
+
+
+def sparse_attn_bwd_mfma(q, v, kp, dout, lse, h, mask=None, scale=None):
+    """MFMA backward (bf16 operands): (dq [n,d] f32, dkp [k,d] f32, dv [n,d] f32) from q, v (f32 or bf16, row-strided views
+    allowed), kp [k,d] f32, dout [k,d] f32 and the forward's lse [h,n].  mask: dropout keep-mask / (1 - p) or None."""
+    if q.dtype not in (torch.float32, torch.bfloat16) or v.dtype != q.dtype:
+        raise TypeError("sparse_attn_bwd_mfma: q and v must both be float32 or both bfloat16")
+    q = _rows16(q, "q")
+    v = _rows16(v, "v")
+    kp = _req(kp, torch.float32, "kp", 2)
+    dout = _req(dout, torch.float32, "dout", 2)
+    lse = _req(lse, torch.float32, "lse", 2)
+    if mask is not None:
+        mask = _req(mask, torch.float32, "mask", 3)
+    n, d = q.shape
+    k = kp.shape[0]
+    dk = d // h
+    scale = 1.0 / math.sqrt(dk) if scale is None else scale
+    lib = _ffi.load()
+    dq = torch.empty(n, d, dtype=torch.float32, device=q.device)
+    dv = torch.empty(n, d, dtype=torch.float32, device=q.device)
+    ds = torch.empty(h, n, k, dtype=torch.float32, device=q.device)
+    dt = DT_F32 if q.dtype == torch.float32 else DT_BF16
+    check(lib.snf_sparse_attn_bwd_mfma(_p(q), q.stride(0), _p(v), v.stride(0), dt, _p(kp), _p(dout), _p(lse), _p(mask), n, k,
+                                       h, dk, float(scale), _p(dq), _p(dv), _p(ds), _stream()), "snf_sparse_attn_bwd_mfma")
+    dkp = torch.empty(k, d, dtype=torch.float32, device=q.device)
+    wsb = lib.snf_sparse_attn_bwd_workspace_bytes(n, k, h, dk)
+    ws = _ws(wsb, q.device)
+    qf = q if q.dtype == torch.float32 and q.is_contiguous() else q.float().contiguous()
+    check(lib.snf_sparse_attn_dkp_f32(_p(ds), _p(qf), n, k, h, dk, _p(dkp), _p(ws), wsb, _stream()), "snf_sparse_attn_dkp_f32")
+    return dq, dkp, dv
+
+
 def mfma_attn_supported(k, dk):
     """Shapes the MFMA attention kernel takes.  One launch holds 256 (dk = 64) / 224 (dk = 128) keys next to the P and V
     images in the 160 KiB LDS of a CU; up to 8 key chunks are run back to back with exact cross-chunk softmax statistics."""

@@ -313,3 +313,49 @@ def test_sparse_attn_bwd_matches_autograd_reference(n, k, h, dk, drop):
     dq2, dkp2, dv2 = ops().sparse_attn_bwd(q.to(DEV), kp.to(DEV), v.to(DEV), p, dout.to(DEV), h,
                                            mask=None if mask is None else mask.to(DEV))
     assert torch.equal(dq, dq2) and torch.equal(dkp, dkp2) and torch.equal(dv, dv2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("n,k,h,drop", [(1, 1, 1, 0.0), (100, 31, 2, 0.0), (129, 33, 3, 0.0), (1000, 64, 6, 0.0),
+                                        (2500, 200, 6, 0.0), (3000, 224, 2, 0.0), (640, 129, 4, 0.25), (4099, 100, 1, 0.0)])
+def test_sparse_attn_bwd_mfma(n, k, h, drop, dt):
+    """MFMA backward (dk = 128) against fp64 autograd on the SAME bf16-rounded operands (layout slips show as O(1) errors)
+    and against the exact operands at bf16-class tolerance."""
+    dk = 128
+    g = torch.Generator().manual_seed(7 * n + k)
+    d = h * dk
+    q, kp, v = (torch.randn(s, d, generator=g) for s in (n, k, n))
+    dout = torch.randn(k, d, generator=g)
+    mask = None
+    if drop > 0:
+        mask = (torch.rand(h, n, k, generator=g) >= drop).float() / (1.0 - drop)
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    qv = torch.cat([q, v], dim=1).to(DEV).to(tdt)                      # row-strided halves, as the model passes them
+    qd_, vd_ = qv[:, :d], qv[:, d:]
+    _, _, lse = ops().sparse_attn_fwd_mfma(qd_, vd_, kp.to(DEV), n, h, need_lse=True)
+    dq, dkp, dv = ops().sparse_attn_bwd_mfma(qd_, vd_, kp.to(DEV), dout.to(DEV), lse, h,
+                                             mask=None if mask is None else mask.to(DEV))
+
+    def ref(qq, kk, vv, dd):
+        qd, kd, vd = (t.double().requires_grad_(True) for t in (qq, kk, vv))
+        qh, kh, vh = (t.view(-1, h, dk).transpose(0, 1) for t in (qd, kd, vd))
+        pr = torch.softmax(qh @ kh.transpose(1, 2) / dk ** 0.5, dim=-1)
+        if mask is not None:
+            pr = pr * mask.double()
+        o = (pr.transpose(1, 2) @ vh).transpose(0, 1).reshape(k, d)
+        o.backward(dd.double())
+        return qd.grad, kd.grad, vd.grad
+    # the kernel rounds q, v, kp, dout to bf16 and keeps P / dP / dS as bf16 MFMA operands: bf16-class tolerance
+    rq, rk, rv = ref(bf16r(q), bf16r(kp), bf16r(v), bf16r(dout))
+    def close(got, want, tol, name):   # relative to the gradient's own scale; a single key has dQ = dKp = 0 exactly
+        scale_ = max(float(want.abs().max()), 1e-3)
+        assert float((got.cpu().double() - want).abs().max()) < tol * 4 * scale_ or rel_err(got.cpu(), want) < tol, name
+    for got, want, name in ((dq, rq, "dq"), (dkp, rk, "dkp"), (dv, rv, "dv")):
+        close(got, want, 1.5e-2, name)
+    eq, ek, ev = ref(q, kp, v, dout)
+    for got, want, name in ((dq, eq, "dq"), (dkp, ek, "dkp"), (dv, ev, "dv")):
+        close(got, want, 2e-2, name)
+    dq2, dkp2, dv2 = ops().sparse_attn_bwd_mfma(qd_, vd_, kp.to(DEV), dout.to(DEV), lse, h,
+                                                mask=None if mask is None else mask.to(DEV))
+    assert torch.equal(dq, dq2) and torch.equal(dkp, dkp2) and torch.equal(dv, dv2)
