@@ -167,7 +167,7 @@ size_t snf_sparse_attn_bwd_workspace_bytes(int64_t n, int k, int h, int dk);
 int snf_sparse_attn_bwd_f32(const float* q, const float* kp, const float* v, const float* p, const float* mask,
                             const float* dout, int64_t n, int k, int h, int dk, float scale, float* dq, float* dkp,
                             float* dv, void* workspace, size_t workspace_bytes, snf_stream_t stream);
-/* Fast form of the backward for dk == 128, k <= 224 (bf16 MFMA operands, fp32 accumulate): P is recomputed from q, kp
+/* Fast form of the backward for dk == 128 with k <= 224 or dk == 64 with k <= 256 (bf16 MFMA operands, fp32 accumulate): P is recomputed from q, kp
  * and the forward's lse [h, n] (never read back), dQ / dV rows are owned by one wave (no reduction), dS [h, n, k] is
  * written out in fp32 -- the caller contracts it with q for dKp (snf_sparse_attn_dkp_f32).  q, v as in
  * snf_sparse_attn_fwd_mfma (row-strided views allowed); mask as in snf_sparse_attn_bwd_f32.  Other shapes:

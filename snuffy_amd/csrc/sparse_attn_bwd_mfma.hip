@@ -15,9 +15,8 @@
 //   dV^T = dO^T Pd^T   A = dO^T fragment (SAME image, hardware transpose-read),  B = Pd^T straight from the registers
 //   dQ^T = Kp^T dS^T   A = Kp^T fragment (SAME image, hardware transpose-read),  B = dS^T straight from the registers
 // so P, dP and dS never touch LDS, the waves of a workgroup never synchronise inside a head, and dV / dQ rows are owned by
-// one wave (no cross-workgroup reduction).  The Kp and dO images are row-major bf16 [key][dk] with 256-byte rows; 16-byte
-// chunk c of row r sits at position 4 * (((c >> 2) + (r & 3)) & 3) + ((c & 3) ^ ((r >> 2) & 3)), which makes BOTH access
-// patterns bank-conflict-free: the 16-lane groups of a ds_read_b128 (16 different rows) and the 32-lane groups of a
+// one wave (no cross-workgroup reduction).  The Kp and dO images are row-major bf16 [key][dk]; the 16-byte chunks of a row
+// are permuted by the row index (img_pos below), which makes BOTH access patterns bank-conflict-free: the 16-lane groups of a ds_read_b128 (16 different rows) and the 32-lane groups of a
 // ds_read_b64_tr_b16 (4 consecutive rows x 64 bytes).
 #include <math.h>
 #include <stdlib.h>
@@ -90,13 +89,20 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 __device__ __forceinline__ float lo_f(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi_f(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
-// chunk position inside a 256-byte image row (see the header)
-__device__ __forceinline__ int img_pos(int row, int c) { return 4 * (((c >> 2) + (row & 3)) & 3) + ((c & 3) ^ ((row >> 2) & 3)); }
+// chunk position inside an image row of 2*DK bytes (DK/8 chunks of 16 bytes = DK/32 blocks of 64 bytes): the block index is
+// rotated by the row (so the 4 consecutive rows x 64 bytes of a transpose-read group fall into 4 different 64-byte bank
+// quarters: r & 3 for 256-byte rows, (r >> 1) & 1 for 128-byte rows, whose rows already alternate halves), the chunk inside
+// the block is XOR-ed with (r >> 2) & 3 (so the 16 rows of a ds_read_b128 service group hit 16 different bank quads).
+template <int DK>
+__device__ __forceinline__ int img_pos(int row, int c) {
+    const int rot = DK == 128 ? (row & 3) : ((row >> 1) & 1);
+    return 4 * (((c >> 2) + rot) & (DK / 32 - 1)) + ((c & 3) ^ ((row >> 2) & 3));
+}
 
-template <int NKB, typename QT>
+template <int DK, int NKB, typename QT>
 __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams P) {
-    constexpr int DK = 128, NKS = DK / 16, NCB = DK / 32;
-    constexpr int IMG = 32 * NKB * 256;   // bytes of one image
+    constexpr int NKS = DK / 16, NCB = DK / 32, RP = 2 * DK, NCH = DK / 8;   // k-steps, column blocks, image row pitch, chunks
+    constexpr int IMG = 32 * NKB * RP;   // bytes of one image
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* img_kp = smem;
     unsigned char* img_do = smem + IMG;
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
     // A fragments with the KEY on the lane (S^T, dP^T): row 32 jb + j, 16-byte chunk 2 kb + hf
     int ra[NKS];
 #pragma unroll
-    for (int kb = 0; kb < NKS; ++kb) ra[kb] = j * 256 + 16 * img_pos(j, 2 * kb + hf);
+    for (int kb = 0; kb < NKS; ++kb) ra[kb] = j * RP + 16 * img_pos<DK>(j, 2 * kb + hf);
     // A fragments with the COLUMN on the lane (dV^T, dQ^T), by transpose-read: 16-lane group tg, lane ti in it;
     // rows k_base + 4 (tg >> 1) + (ti >> 2) (+8 for the second read), chunk 4 db + 2 (tg & 1) + ((ti & 3) >> 1), half ti & 1
     const int tg = lane >> 4, ti = lane & 15;
@@ -122,8 +128,8 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
     for (int db = 0; db < NCB; ++db) {
         const int r0 = 4 * (tg >> 1) + (ti >> 2), r1 = r0 + 8;
         const int c = 4 * db + 2 * (tg & 1) + ((ti & 3) >> 1);
-        rt0[db] = r0 * 256 + 16 * img_pos(r0, c) + 8 * (ti & 1);
-        rt1[db] = r1 * 256 + 16 * img_pos(r1, c) + 8 * (ti & 1);
+        rt0[db] = r0 * RP + 16 * img_pos<DK>(r0, c) + 8 * (ti & 1);
+        rt1[db] = r1 * RP + 16 * img_pos<DK>(r1, c) + 8 * (ti & 1);
     }
 
     const int f_begin = blockIdx.x * P.tiles_per_wg;
@@ -136,14 +142,14 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
         if (a != cur_head) {
             // Kp_a and dO_a -> LDS (bf16, row-major, swizzled): thread -> (row, chunk), a row's 512 bytes are read coalesced
             __syncthreads();
-            for (int ci = threadIdx.x; ci < 32 * NKB * 16; ci += 256) {
-                const int row = ci >> 4, c = ci & 15;
+            for (int ci = threadIdx.x; ci < 32 * NKB * NCH; ci += 256) {
+                const int row = ci / NCH, c = ci % NCH;
                 u32x4 vk = {0u, 0u, 0u, 0u}, vo = {0u, 0u, 0u, 0u};
                 if (row < P.k) {
                     vk = __builtin_bit_cast(u32x4, load_frag(P.kp + (int64_t)row * P.d + a * DK + 8 * c));
                     vo = __builtin_bit_cast(u32x4, load_frag(P.dout + (int64_t)row * P.d + a * DK + 8 * c));
                 }
-                const int off = row * 256 + 16 * img_pos(row, c);
+                const int off = row * RP + 16 * img_pos<DK>(row, c);
                 *reinterpret_cast<u32x4*>(img_kp + off) = vk;
                 *reinterpret_cast<u32x4*>(img_do + off) = vo;
             }
@@ -179,8 +185,8 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
             }
             static_for<0, NKS>([&](auto kb_t) __attribute__((always_inline)) {
                 constexpr int kb = decltype(kb_t)::value;
-                const bf16x8 ak = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img_kp + ra[kb] + jb * 32 * 256));
-                const bf16x8 ao = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img_do + ra[kb] + jb * 32 * 256));
+                const bf16x8 ak = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img_kp + ra[kb] + jb * 32 * RP));
+                const bf16x8 ao = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img_do + ra[kb] + jb * 32 * RP));
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qf[kb], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ao, vf[kb], dp, 0, 0, 0);
             });
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
                 constexpr int u = decltype(u_t)::value;
                 const u32x4 pb = {ppk[jb][4 * u], ppk[jb][4 * u + 1], ppk[jb][4 * u + 2], ppk[jb][4 * u + 3]};
                 const u32x4 sb = {dpk[jb][4 * u], dpk[jb][4 * u + 1], dpk[jb][4 * u + 2], dpk[jb][4 * u + 3]};
-                constexpr int koff = (32 * jb + 16 * u) * 256;
+                constexpr int koff = (32 * jb + 16 * u) * RP;
                 static_for<0, NCB>([&](auto db_t) __attribute__((always_inline)) {
                     constexpr int db = decltype(db_t)::value;
                     const bf16x8 ao = lds_tr_frag(img_do + rt0[db] + koff, img_do + rt1[db] + koff);
@@ -297,7 +303,7 @@ struct BwdPlan {
     int num_wg, tiles_per_head, tiles_per_wg, total_tiles, nkb;
 };
 inline bool make_bwd_plan(int64_t n, int k, int h, int dk, BwdPlan* pl) {
-    if (dk != 128 || k < 1 || k > 224 || n < 1 || n > 0x7fffff00ll) return false;
+    if (!((dk == 128 && k <= 224) || (dk == 64 && k <= 256)) || k < 1 || n < 1 || n > 0x7fffff00ll) return false;
     const int nkb = (k + 31) / 32;
     const int64_t tph = (n + TILE_ROWS - 1) / TILE_ROWS, total = tph * h;
     if (total > 0x7fffffff) return false;
@@ -309,11 +315,11 @@ inline bool make_bwd_plan(int64_t n, int k, int h, int dk, BwdPlan* pl) {
     return true;
 }
 
-template <int NKB, typename QT>
+template <int DK, int NKB, typename QT>
 int launch_bwd(const BwdParams& P, const BwdPlan& pl, hipStream_t s) {
-    const size_t lds = (size_t)2 * 32 * NKB * 256;
+    const size_t lds = (size_t)2 * 32 * NKB * 2 * DK;
     static thread_local bool attr_set = false;
-    auto kern = sparse_attn_bwd_mfma_kernel<NKB, QT>;
+    auto kern = sparse_attn_bwd_mfma_kernel<DK, NKB, QT>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess) {
@@ -326,16 +332,20 @@ int launch_bwd(const BwdParams& P, const BwdPlan& pl, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(pl.num_wg), dim3(256), lds, s, P);
     return snf::check_launch("sparse_attn_bwd_mfma_kernel");
 }
-template <typename QT>
+template <int DK, typename QT>
 int launch_bwd_nkb(const BwdParams& P, const BwdPlan& pl, hipStream_t s) {
     switch (pl.nkb) {
-        case 1: return launch_bwd<1, QT>(P, pl, s);
-        case 2: return launch_bwd<2, QT>(P, pl, s);
-        case 3: return launch_bwd<3, QT>(P, pl, s);
-        case 4: return launch_bwd<4, QT>(P, pl, s);
-        case 5: return launch_bwd<5, QT>(P, pl, s);
-        case 6: return launch_bwd<6, QT>(P, pl, s);
-        default: return launch_bwd<7, QT>(P, pl, s);
+        case 1: return launch_bwd<DK, 1, QT>(P, pl, s);
+        case 2: return launch_bwd<DK, 2, QT>(P, pl, s);
+        case 3: return launch_bwd<DK, 3, QT>(P, pl, s);
+        case 4: return launch_bwd<DK, 4, QT>(P, pl, s);
+        case 5: return launch_bwd<DK, 5, QT>(P, pl, s);
+        case 6: return launch_bwd<DK, 6, QT>(P, pl, s);
+        case 7: return launch_bwd<DK, 7, QT>(P, pl, s);
+        default:
+            if constexpr (DK == 64) return launch_bwd<DK, 8, QT>(P, pl, s);
+            snf::set_error("sparse_attn_bwd_mfma: key-block count %d not built", pl.nkb);
+            return SNF_EUNSUPPORTED;
     }
 }
 
@@ -350,7 +360,8 @@ int snf_sparse_attn_bwd_mfma(const void* q, int64_t ldq, const void* v, int64_t 
     SNF_REQUIRE(qv_dtype == SNF_DT_F32 || qv_dtype == SNF_DT_BF16, "snf_sparse_attn_bwd_mfma: bad dtype %d", qv_dtype);
     BwdPlan pl;
     if (!make_bwd_plan(n, k, h, dk, &pl)) {
-        snf::set_error("snf_sparse_attn_bwd_mfma: unsupported shape k=%d dk=%d (need dk == 128, k <= 224)", k, dk);
+        snf::set_error("snf_sparse_attn_bwd_mfma: unsupported shape k=%d dk=%d (need dk == 128 with k <= 224 or dk == 64 "
+                       "with k <= 256)", k, dk);
         return SNF_EUNSUPPORTED;
     }
     const int64_t d = (int64_t)h * dk;
@@ -382,8 +393,9 @@ int snf_sparse_attn_bwd_mfma(const void* q, int64_t ldq, const void* v, int64_t 
     P.tiles_per_wg = pl.tiles_per_wg;
     P.total_tiles = pl.total_tiles;
     hipStream_t s = snf::as_stream(stream);
-    if (qv_dtype == SNF_DT_F32) return launch_bwd_nkb<float>(P, pl, s);
-    return launch_bwd_nkb<unsigned short>(P, pl, s);
+    if (dk == 128)
+        return qv_dtype == SNF_DT_F32 ? launch_bwd_nkb<128, float>(P, pl, s) : launch_bwd_nkb<128, unsigned short>(P, pl, s);
+    return qv_dtype == SNF_DT_F32 ? launch_bwd_nkb<64, float>(P, pl, s) : launch_bwd_nkb<64, unsigned short>(P, pl, s);
 }
 
 }  // extern "C"

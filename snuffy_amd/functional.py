@@ -268,7 +268,7 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
         ops.layernorm_rows(x2, None, None, n0.eps, out=xhat)
     qv = torch.addmm(fw["bqv"], xhat, fw["wqv"].t())                                # [N, 2D] bf16 = [Q | V], bias epilogue
     q, v = qv[:, :d], qv[:, d:]                                                     # row-strided views, used in place
-    if ops.mfma_attn_supported(k, d // h):
+    if ops.mfma_attn_supported(k, d // h, n, qv.stride(0)):
         o, attn, _ = ops.sparse_attn_fwd_mfma(q, v, kp, n, h, need_attn=need_attn)
     else:
         o, attn, _ = ops.sparse_attn_fwd(q.float(), kp, v.float(), h, need_attn=need_attn)

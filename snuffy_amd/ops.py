@@ -268,7 +268,7 @@ def sparse_attn_bwd(q, kp, v, p, dout, h, mask=None, scale=None):
 
 
 def mfma_attn_bwd_supported(k, dk):
-    return dk == 128 and 1 <= k <= 224
+    return (dk == 128 and 1 <= k <= 224) or (dk == 64 and 1 <= k <= 256)
 
 
 def sparse_attn_bwd_mfma(q, v, kp, dout, lse, h, mask=None, scale=None):
@@ -302,10 +302,15 @@ def sparse_attn_bwd_mfma(q, v, kp, dout, lse, h, mask=None, scale=None):
     return dq, dkp, dv
 
 
-def mfma_attn_supported(k, dk):
+def mfma_attn_supported(k, dk, n=None, ld=None):
     """Shapes the MFMA attention kernel takes.  One launch holds 256 (dk = 64) / 224 (dk = 128) keys next to the P and V
-    images in the 160 KiB LDS of a CU; up to 8 key chunks are run back to back with exact cross-chunk softmax statistics."""
-    return (dk == 64 and 1 <= k <= 8 * 256) or (dk == 128 and 1 <= k <= 8 * 224)
+    images in the 160 KiB LDS of a CU; up to 8 key chunks are run back to back with exact cross-chunk softmax statistics.
+    n / ld (rows and row pitch of q, v) are optional: the kernel addresses rows with 32-bit element offsets."""
+    if not ((dk == 64 and 1 <= k <= 8 * 256) or (dk == 128 and 1 <= k <= 8 * 224)):
+        return False
+    if n is not None and (n > 0xffff00 or (ld is not None and (ld >= (1 << 24) or n * ld >= 0x7fffffff))):
+        return False
+    return True
 
 
 def _rows16(t, name):
