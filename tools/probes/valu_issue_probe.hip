@@ -59,11 +59,16 @@ __global__ void pkmul_ind4(unsigned long long* out, float seed) {
 
 #define RUN(NAME)                                                                          \
     {                                                                                      \
-        for (int it = 0; it < 3; ++it) NAME<<<1, 64>>>(d, 1.0f);                           \
-        hipDeviceSynchronize();                                                            \
-        unsigned long long h[3];                                                           \
-        hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);                                 \
-        printf("%-12s %6llu cycles / %4llu instr = %5.2f cyc/instr\n", #NAME, h[0], h[1], (double)h[0] / h[1]); \
+        double r[3];                                                                       \
+        const int cfg[3][2] = {{1, 64}, {1, 256}, {256, 256}};   /* one wave | one wave per SIMD | every CU busy */ \
+        for (int c = 0; c < 3; ++c) {                                                      \
+            for (int it = 0; it < 3; ++it) NAME<<<cfg[c][0], cfg[c][1]>>>(d, 1.0f);        \
+            hipDeviceSynchronize();                                                        \
+            unsigned long long h[3];                                                       \
+            hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);                             \
+            r[c] = (double)h[0] / h[1];                                                    \
+        }                                                                                  \
+        printf("%-12s cyc/instr: 1 wave %5.2f | 4 waves (1 per SIMD) %5.2f | 256 WG x 4 waves %5.2f\n", #NAME, r[0], r[1], r[2]); \
     }
 
 int main() {
