@@ -169,12 +169,13 @@ int snf_sparse_attn_bwd_f32(const float* q, const float* kp, const float* v, con
                             float* dv, void* workspace, size_t workspace_bytes, snf_stream_t stream);
 /* Fast form of the backward for dk == 128 with k <= 224 or dk == 64 with k <= 256 (bf16 MFMA operands, fp32 accumulate): P is recomputed from q, kp
  * and the forward's lse [h, n] (never read back), dQ / dV rows are owned by one wave (no reduction), dS [h, n, k] is
- * written out in fp32 -- the caller contracts it with q for dKp (snf_sparse_attn_dkp_f32).  q, v as in
+ * written out (ds_dtype f32, or bf16) -- the caller contracts it with q for dKp (snf_sparse_attn_dkp_f32 on f32, or a
+ * bf16 library batched GEMM).  q, v as in
  * snf_sparse_attn_fwd_mfma (row-strided views allowed); mask as in snf_sparse_attn_bwd_f32.  Other shapes:
  * SNF_EUNSUPPORTED, the caller uses snf_sparse_attn_bwd_f32. */
 int snf_sparse_attn_bwd_mfma(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const float* kp,
                              const float* dout, const float* lse, const float* mask, int64_t n, int k, int h, int dk,
-                             float scale, float* dq, float* dv, float* ds, snf_stream_t stream);
+                             float scale, float* dq, float* dv, void* ds, int ds_dtype, snf_stream_t stream);
 /* dKp [k, d] = dS^T Q per head (deterministic slice reduction); ds [h, n, k], q [n, d] f32.
  * workspace: snf_sparse_attn_bwd_workspace_bytes. */
 int snf_sparse_attn_dkp_f32(const float* ds, const float* q, int64_t n, int k, int h, int dk, float* dkp, void* workspace,

@@ -52,7 +52,8 @@ struct BwdParams {
     float scale;
     float* dq;  // [n, d]
     float* dv;  // [n, d]
-    float* ds;  // [h, n, k]
+    void* ds;   // [h, n, k] f32, or bf16 when ds_bf16 (the caller then contracts it with a bf16 library GEMM)
+    int ds_bf16;
     int tiles_per_head, tiles_per_wg, total_tiles;
 };
 
@@ -221,7 +222,8 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
         const float dtot = xhalf_sum(dsum);
 
         // dS = P o (dP - D) * scale: written out (fp32, for dKp) and kept as bf16 pairs for dQ; Pd = P o M for dV
-        float* dsrow = P.ds + ((int64_t)a * P.n + lrow) * P.k;
+        float* dsrow = reinterpret_cast<float*>(P.ds) + ((int64_t)a * P.n + lrow) * P.k;
+        unsigned short* dsrow16 = reinterpret_cast<unsigned short*>(P.ds) + ((int64_t)a * P.n + lrow) * P.k;
         const bool vec_ok = (P.k & 3) == 0;
         static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
             constexpr int jb = decltype(jb_t)::value;
@@ -235,8 +237,19 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dsv[e] = pv[e] * (gv[e] - dtot) * P.scale;
                 const int key0 = 32 * jb + 8 * c4 + 4 * hf;
+                const unsigned s01 = pack2(dsv[0], dsv[1]), s23 = pack2(dsv[2], dsv[3]);
                 if (rvalid) {
-                    if (vec_ok) {
+                    if (P.ds_bf16) {
+                        if (vec_ok) {
+                            if (key0 < P.k) *reinterpret_cast<uint2*>(dsrow16 + key0) = uint2{s01, s23};
+                        } else {
+                            const unsigned short hv[4] = {(unsigned short)(s01 & 0xffffu), (unsigned short)(s01 >> 16),
+                                                          (unsigned short)(s23 & 0xffffu), (unsigned short)(s23 >> 16)};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (key0 + e < P.k) dsrow16[key0 + e] = hv[e];
+                        }
+                    } else if (vec_ok) {
                         if (key0 < P.k) *reinterpret_cast<f32x4*>(dsrow + key0) = dsv;
                     } else {
 #pragma unroll
@@ -244,8 +257,8 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
                             if (key0 + e < P.k) dsrow[key0 + e] = dsv[e];
                     }
                 }
-                dpk[jb][2 * c4] = pack2(dsv[0], dsv[1]);
-                dpk[jb][2 * c4 + 1] = pack2(dsv[2], dsv[3]);
+                dpk[jb][2 * c4] = s01;
+                dpk[jb][2 * c4 + 1] = s23;
                 if (mrow) {
                     float mk[4];
 #pragma unroll
@@ -355,9 +368,10 @@ extern "C" {
 
 int snf_sparse_attn_bwd_mfma(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const float* kp,
                              const float* dout, const float* lse, const float* mask, int64_t n, int k, int h, int dk,
-                             float scale, float* dq, float* dv, float* ds, snf_stream_t stream) {
+                             float scale, float* dq, float* dv, void* ds, int ds_dtype, snf_stream_t stream) {
     SNF_REQUIRE(q && v && kp && dout && lse && dq && dv && ds, "snf_sparse_attn_bwd_mfma: null pointer");
     SNF_REQUIRE(qv_dtype == SNF_DT_F32 || qv_dtype == SNF_DT_BF16, "snf_sparse_attn_bwd_mfma: bad dtype %d", qv_dtype);
+    SNF_REQUIRE(ds_dtype == SNF_DT_F32 || ds_dtype == SNF_DT_BF16, "snf_sparse_attn_bwd_mfma: bad ds dtype %d", ds_dtype);
     BwdPlan pl;
     if (!make_bwd_plan(n, k, h, dk, &pl)) {
         snf::set_error("snf_sparse_attn_bwd_mfma: unsupported shape k=%d dk=%d (need dk == 128 with k <= 224 or dk == 64 "
@@ -389,6 +403,7 @@ int snf_sparse_attn_bwd_mfma(const void* q, int64_t ldq, const void* v, int64_t 
     P.dq = dq;
     P.dv = dv;
     P.ds = ds;
+    P.ds_bf16 = ds_dtype == SNF_DT_BF16;
     P.tiles_per_head = pl.tiles_per_head;
     P.tiles_per_wg = pl.tiles_per_wg;
     P.total_tiles = pl.total_tiles;
