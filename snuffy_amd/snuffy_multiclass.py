@@ -11,7 +11,8 @@ re-used from ``snuffy_amd.snuffy`` (same state-dict keys); only the selection di
   on the global numpy RNG, row after row); K = 2 * ref_dim.
 
 The per-class top-k runs on the exact HIP selector (strided column of c), the layer math on the same fused kernels as
-the binary model, one bag row at a time.  Inference path (eval) -- multiclass training stays on the list.
+the binary model, one bag row at a time.  Training goes through the same autograd functions as the binary model (every
+parameter gradient checked against autograd through the CPU oracle, tests/test_gpu_train.py).
 """
 import math
 
