@@ -26,6 +26,10 @@ WORKLOADS = {
     "cfgB": dict(N=32768, D=768, h=6, lam=200),    # BASELINE.json metric shape
     "cfgA": dict(N=8192, D=384, h=6, lam=200),
     "cfgC": dict(N=100000, D=768, h=6, lam=512),
+    # BASELINE.json configs[4] / SURVEY 8(d) Cfg5: CAMELYON16-scale synthetic set, 400 slides, lengths
+    # clip(round(lognormal(mu = ln 30000 - sigma^2/2, sigma = 0.5)), 1000, 100000), seed 0; sharded over the ranks (rank r takes
+    # bags r::W), resident in HBM.  N below is only the nominal length (roofline micro-benchmark shape).
+    "cam16": dict(N=30000, D=768, h=6, lam=200, bags=400),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0
@@ -174,9 +178,19 @@ def main():
     N, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
     net = build_net(D, h, lam, args.precision, device)
     # bags resident in HBM before the timed region; several distinct bags per rank, cycled
-    nbags = max(2, min(8, int(2.0e9 // (N * D * 4))))
-    g = torch.Generator().manual_seed(1234 + rank)
-    bags = [torch.randn(1, N, D, generator=g).to(device) for _ in range(nbags)]
+    if "bags" in wl:
+        import numpy as np
+        rs = np.random.RandomState(0)
+        sigma = 0.5
+        lens = np.clip(np.round(rs.lognormal(np.log(N) - sigma * sigma / 2, sigma, wl["bags"])), 1000, 100000).astype(int)
+        mine = lens[rank::world]                        # this rank's shard of the slide list (each rank times `steps` of them)
+        g = torch.Generator().manual_seed(1234 + rank)
+        bags = [torch.randn(1, int(n_i), D, generator=g).to(device) for n_i in mine]
+        nbags = len(bags)
+    else:
+        nbags = max(2, min(8, int(2.0e9 // (N * D * 4))))
+        g = torch.Generator().manual_seed(1234 + rank)
+        bags = [torch.randn(1, N, D, generator=g).to(device) for _ in range(nbags)]
     labels = [torch.tensor([float(i % 2)], device=device) for i in range(nbags)]
 
     if args.mode == "train":
