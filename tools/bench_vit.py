@@ -18,7 +18,12 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--precision", default="bf16")
 ap.add_argument("--arch", default="vit_small")
+ap.add_argument("--gemm-table", action="store_true", help="apply snuffy_amd/tuning/gemm_gfx950.csv (library GEMM selections)")
+ap.add_argument("--tune-gemms", default=None, metavar="CSV", help="tune unseen GEMM shapes online and record them in CSV")
 a = ap.parse_args()
+if a.gemm_table or a.tune_gemms:
+    from snuffy_amd.gemm_tuning import use_pretuned_gemms
+    use_pretuned_gemms(path=a.tune_gemms, tune_missing=bool(a.tune_gemms))
 dev = torch.device("cuda")
 torch.manual_seed(0)
 width = {"vit_small": 384, "vit_base": 768}[a.arch]
@@ -40,4 +45,5 @@ flops_img = 12 * (2 * T * width * 3 * width + 4 * T * T * width + 2 * T * width 
 print(json.dumps({"metric": "images/sec", "value": round(a.batch / dt, 1), "unit": "img/s", "arch": a.arch + "/16+adapter",
                   "batch": a.batch, "ms_per_batch": round(dt * 1e3, 2), "dtype": a.precision,
                   "model_tflops_per_s": round(flops_img * a.batch / dt / 1e12, 1),
-                  "mfma_frac_of_2.5PF": round(flops_img * a.batch / dt / 2.5e15, 4)}))
+                  "mfma_frac_of_2.5PF": round(flops_img * a.batch / dt / 2.5e15, 4),
+                  "gemm_table": bool(a.gemm_table or a.tune_gemms)}))
