@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--mode", default="eval", choices=["eval", "train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-table", action="store_true",
+                    help="apply snuffy_amd/tuning/gemm_gfx950.csv (library-GEMM selections; helps the training shapes, "
+                         "nothing measurable for the eval forward)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -173,6 +176,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # "nccl" == RCCL on ROCm
+
+    if args.gemm_table:
+        from snuffy_amd.gemm_tuning import use_pretuned_gemms
+        use_pretuned_gemms()
 
     wl = WORKLOADS[args.workload]
     N, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
