@@ -1,867 +1,17 @@
-// K7 (fast form): Snuffy's sparse attention on the CDNA4 matrix cores.
-//
-//   per head a:   P_a = softmax_j(Q_a Kp_a^T * scale)  [n, k]      O_a = P_a^T V_a  [k, dk]        (snuffy.py:160-168)
-//
-// All n patches are queries, only the k selected rows are keys, and the probability matrix is used TRANSPOSED to pool
-// the values of all n patches into k output rows.  The contraction of the second product runs over the QUERY axis, the
-// opposite of flash attention:
-//
-//   GEMM1  S^T[key, q] = Kp Q^T   v_mfma_f32_32x32x16_bf16, A = Kp fragment (bf16 image in LDS), B = Q fragment (HBM -> regs).
-//          Swapped on purpose: the C layout gives every lane ONE query row (16 keys per block in registers, the other 16
-//          in lane ^ 32), so the softmax over keys is register-local plus one v_permlane32_swap, fp32.
-//   publish  P (bf16) goes to LDS ROW-major, 4 keys per ds_write_b64, together with the wave's 32 rows of V (row-major from
-//          HBM, parked in registers during the step).  Chunk rotation by row keeps stores and reads conflict-free.
-//   GEMM2  O[key, col] += P^T V   needs both operands with 8 consecutive QUERY rows in a lane's registers, i.e. transposed
-//          with respect to how they were written: ds_read_b64_tr_b16 (hardware transpose-read) delivers exactly that.
-//
-// Workgroup = 4 waves (one per SIMD) = 128 query rows per step of one head: wave w runs GEMM1 + softmax for rows
-// 32w..32w+31 against all keys, publishes, then every wave accumulates its own share of the [k, dk] output tiles over
-// all 128 rows.  One workgroup per CU walks a contiguous range of (head, row-tile) work items; its accumulators stay in
-// registers until the head changes; partial tiles are written in fragment order and summed in a fixed order by a
-// second kernel (no float atomics -> bit-reproducible).
-//
-// HBM traffic per launch (algorithmic): read Q and V once (2*n*d*elt), Kp once per workgroup (L2), write partials.
-#include <math.h>
-#include <stdlib.h>
-
-#include <type_traits>
-
-#include "common.h"
-
-namespace snf {
-size_t generic_attn_workspace_bytes(int64_t n, int k, int h, int dk);
-}
+// K7 (fast form), translation unit 1: the dk = 128 kernel variants and the C entry points (see sparse_attn_mfma_impl.h).
+#include "sparse_attn_mfma_impl.h"
 
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(8))) float f32x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-
-constexpr int TILE_ROWS = 128;  // query rows per workgroup step (4 waves x 32)
-// row pitch (bytes) of the bf16 P image in LDS: 64 bytes per key block, an ODD number of 64-byte units (bank rule below)
-constexpr int p_row_bytes(int nkb) { return 64 * (nkb | 1); }
-
-struct AttnParams {
-    const void* q;     // [n, ldq]   row-major, head a = columns a*dk .. (a+1)*dk
-    const void* v;     // [n, ldv]   row-major, same column layout
-    const float* kp;   // [k, h*dk] f32
-    int64_t n, ldq, ldv, ldkp;
-    int k, h;
-    float scale;
-    float* attn;     // [h, n, attn_ld] or null (already offset to this key chunk's first column)
-    int64_t attn_ld; // row pitch of attn (= total number of keys)
-    // key-chunked launches (more keys than one LDS image holds): per-chunk row statistics [n_chunks][h][n][2] =
-    // (row max * scale * log2 e, sum exp) written by sparse_attn_stats_kernel; null = single chunk, statistics computed here
-    const float* stats;
-    float* stats_out;
-    int n_chunks;
-    float* lse;      // [h, n] or null
-    float* partial;  // [num_wg * seg_count][tiles][16][64]
-    int tiles_per_head, tiles_per_wg, total_tiles, seg_count;
-    unsigned long long* trace;  // debug: s_memtime stamps of workgroup 0 (tools/attn_trace.py), normally null
-};
-
-// compile-time loop: every index into the register-resident fragment arrays must be a constant, or the arrays go to
-// scratch (a "#pragma unroll" is only a hint and gives up on the larger variants)
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-__device__ __forceinline__ bf16x8 zero_frag() {
-    u32x4 z = {0u, 0u, 0u, 0u};
-    return __builtin_bit_cast(bf16x8, z);
-}
-
-// 8 consecutive elements -> bf16x8 (f32 source converted with v_cvt_pk_bf16_f32, round-to-nearest-even)
-__device__ __forceinline__ bf16x8 load_frag(const float* p) {
-    f32x4 lo = *reinterpret_cast<const f32x4*>(p);
-    f32x4 hi = *reinterpret_cast<const f32x4*>(p + 4);
-    f32x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_convertvector(v, bf16x8);
-}
-__device__ __forceinline__ bf16x8 load_frag(const unsigned short* p) {
-    u32x4 v = *reinterpret_cast<const u32x4*>(p);
-    return __builtin_bit_cast(bf16x8, v);
-}
-// S = Q Kp^T accumulates in ARCHITECTURAL VGPRs: the softmax reads S with the VALU, and the compiler's own choice for a
-// builtin MFMA result is the AGPR half of the file, which costs a v_accvgpr_read per element and -- with the O
-// accumulators already filling the AGPRs -- a storm of v_accvgpr_mov live-range splits (640 per tile, measured).
-// Inline asm with a tied "+v" accumulator keeps S where the VALU wants it.  hipcc does not model the instruction inside
-// an asm statement: the s_nop covers VALU-write -> MFMA-operand wait states, the caller parks before the first VALU read.
-// NOP = the two wait states a 32x32 MFMA needs when (a) the previous instruction was an MFMA on the SAME accumulator
-// (back-to-back dependent issue) or (b) an operand may have been written by the VALU just before (f32 -> bf16
-// conversion, accumulator init).  "s_nop 1" is a full 8-cycle issue slot for a single wave, so it is only emitted then.
-template <bool NOP>
-__device__ __forceinline__ void mfma_vgpr(f32x16& acc, bf16x8 a, bf16x8 b) {
-    const u32x4 au = __builtin_bit_cast(u32x4, a), bu = __builtin_bit_cast(u32x4, b);
-    if constexpr (NOP)
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(au), "v"(bu));
-    else
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(au), "v"(bu));
-}
-
-// first MFMA of an accumulation chain: C is the inline constant 0, D is write-only (early clobber: never overlaps A / B)
-__device__ __forceinline__ void mfma_vgpr_zero_c(f32x16& acc, bf16x8 a, bf16x8 b) {
-    const u32x4 au = __builtin_bit_cast(u32x4, a), bu = __builtin_bit_cast(u32x4, b);
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(au), "v"(bu));
-}
-__device__ __forceinline__ void park_after_mfma(f32x16& x) { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" : "+v"(x)); }
-__device__ __forceinline__ void pin_vgpr(f32x16& x) { asm volatile("" : "+v"(x)); }
-
-// One GEMM2 A operand (P^T fragment: key on the lane, 8 consecutive query rows in registers) out of the row-major P image:
-// two hardware transpose-reads.  ds_read_b64_tr_b16 semantics (probed on gfx950, tools/probes/tr16_probe.hip): every lane
-// supplies the address of its own 8-byte chunk; inside each group of 16 lanes the 16 chunks form a [4 rows][16 columns]
-// bf16 matrix (lane i = row i>>2, columns 4(i&3)..+3) and lane i receives column i.
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(8))) short s16x8;
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-__device__ __forceinline__ bf16x8 lds_read_p_frag(const unsigned char* p0, const unsigned char* p1) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
-    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-}
-// all-reduce across the two half-waves (lane l <-> lane l^32) on the VALU: v_permlane32_swap(x, x) = {x.lo, x.lo}, {x.hi, x.hi}
-__device__ __forceinline__ float xhalf_max(float v) {
-    const unsigned u = __float_as_uint(v);
-    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float xhalf_sum(float v) {
-    const unsigned u = __float_as_uint(v);
-    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-// AUX = the caller asked for the attention matrix and/or the row log-sum-exp (extra stores after the softmax).
-//
-// Software pipeline of one wave (one wave per SIMD, so MFMA and VALU only overlap inside the wave's own stream):
-//   step t:   GEMM1(t)                                     MFMA   (Kp fragments through a 4-deep register ring out of LDS)
-//             softmax(t)  ||  GEMM2(t-1)                   VALU   ||  MFMA: the 8*NT MFMAs of the PREVIOUS tile are spread
-//                                                          over the 2*NKB slices of the softmax by VALU weight
-//             barrier, publish P(t) in LDS, (barrier after the next GEMM1)
-//   loads:    one 16-byte fragment at a time between the slices (Q(t+1) during the max pass, V(t) as soon as the pending
-//             GEMM2 released the register): HBM requests stream continuously, a full step ahead of their use.
-// EXT = key-chunked launch: the row statistics come from sparse_attn_stats_kernel (all chunks), not from this chunk's scores.
-template <int DK, int NKB, typename QT, bool AUX, bool EXT>
-__global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) {
-    constexpr int NKS = DK / 16;             // k-steps of GEMM1
-    constexpr int NCB = DK / 32;             // 32-wide column blocks of the output
-    constexpr int NT = (NKB * NCB + 3) / 4;  // output tiles owned by one wave
-    constexpr int M2 = 8 * NT;               // GEMM2 MFMAs per tile and wave
-    constexpr int RS = p_row_bytes(NKB);     // row pitch of the P image
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4* lds_kp = reinterpret_cast<u32x4*>(smem);                    // [NKB][NKS][64] MFMA A fragments of Kp
-    unsigned char* lds_p = smem + NKB * NKS * 1024;                    // [128 rows][RS] bf16 probabilities, swizzled
-    unsigned char* lds_v = lds_p + TILE_ROWS * RS;                     // [128 rows][DK] bf16 values of the pending tile
-
-    // Every kernel argument is requested in the FIRST scalar-load batch: the compiler otherwise fetches k / partial / scale
-    // lazily, and each extra batch is one more cold round trip to the kernarg segment before the first HBM load can go out.
-    asm volatile("" ::"s"(P.q), "s"(P.v), "s"(P.kp), "s"(P.n), "s"(P.ldq), "s"(P.ldv), "s"(P.k), "s"(P.scale),
-                 "s"(P.partial), "s"(P.tiles_per_head), "s"(P.tiles_per_wg), "s"(P.total_tiles), "s"(P.seg_count),
-                 "s"(P.trace), "s"(P.stats), "s"(P.n_chunks), "s"(P.attn_ld));
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 31, hf = lane >> 5;
-    const QT* __restrict__ q = reinterpret_cast<const QT*>(P.q);
-    const QT* __restrict__ vg = reinterpret_cast<const QT*>(P.v);
-    const float c_exp = P.scale * 1.44269504088896340736f;
-    const int cb = (NCB == 4) ? w : (w & (NCB - 1));
-    const int n32 = (int)P.n;
-    const bool attn_vec = AUX && (P.attn_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(P.attn) & 15) == 0;
-    int trace_it = 0;
-    auto stamp = [&](int phase) __attribute__((always_inline)) {
-        if (P.trace && blockIdx.x == 0 && lane == 0)
-            P.trace[(trace_it * 8 + phase) * 4 + w] = __builtin_amdgcn_s_memtime();
-    };
-    auto stamp_abs = [&](int slot) __attribute__((always_inline)) {  // slots 57, 60..63 of the trace: kernel milestones
-        if (P.trace && blockIdx.x == 0 && lane == 0) P.trace[(slot * 8) * 4 + w] = __builtin_amdgcn_s_memtime();
-    };
-    stamp_abs(60);
-
-    // ---- P image addressing.  Row r of the tile lives at r * RS; the 8-byte chunk c (4 keys) of its 64-byte key-block
-    // segment is stored at chunk position c ^ ((r >> 1) & 7).  RS is an odd multiple of 64 bytes, so
-    //   * a ds_write_b64 group (16 lanes = 16 consecutive rows, same logical chunk) covers all 32 banks exactly once,
-    //   * a transpose-read group (32 lanes = 4 consecutive rows x 64 bytes) covers all 64 banks exactly once.
-    const int prow = 32 * w + j;                  // this lane's query row inside the tile (GEMM1 / softmax side)
-    const int pswz = (prow >> 1) & 7;
-    int waddr[4];                                 // byte offset of chunk (2*c4 + hf) of key block 0 in row prow
-#pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) waddr[c4] = prow * RS + 8 * (((2 * c4) | hf) ^ pswz);
-    // reader (GEMM2 side): lane = group g (16 lanes) x i; rows 8*(g>>1) + 4*s + (i>>2), chunk 4*(g&1) + (i&3)
-    const int rg = lane >> 4, ri = lane & 15;
-    const int rr0 = 8 * (rg >> 1) + (ri >> 2), rr1 = rr0 + 4;
-    const int rch = 4 * (rg & 1) + (ri & 3);
-    // key block of output tile ti of this wave = ti * (4 / NCB) + w / NCB: the wave-dependent part goes into the base
-    const unsigned char* rbase0 = lds_p + rr0 * RS + 8 * (rch ^ ((rr0 >> 1) & 7)) + 64 * (w / NCB);
-    const unsigned char* rbase1 = lds_p + rr1 * RS + 8 * (rch ^ ((rr1 >> 1) & 7)) + 64 * (w / NCB);
-
-    // ---- V image.  V arrives ROW-major (it comes out of the same GEMM as Q): each wave fetches 32 rows of the tile with
-    // fully coalesced 16-byte loads (one row = DK/8 chunks of 8 columns), parks them in registers for the rest of the step
-    // and stores them next to the P image at publish time; GEMM2 reads its B fragments (column on the lane, 8 consecutive
-    // rows in registers) back with the same hardware transpose-read as P.  Row pitch = 2*DK bytes, no padding: chunk c of
-    // row r sits at chunk position (c + 4 rot(r)) mod NCH, which spreads the 4 rows x 64 bytes of a transpose-read group
-    // over all 64 banks (rot = r & 3 for DK = 128, (r >> 1) & 1 for DK = 64: rows of 128 bytes already alternate halves).
-    constexpr int VRS = 2 * DK, NCH = DK / 8;     // row pitch (bytes), 16-byte chunks per row
-    constexpr int RPI = 64 / NCH, NVI = 32 / RPI; // rows per load instruction, load instructions per wave and tile
-    auto vrot = [](int r) __attribute__((always_inline)) -> int { return DK == 128 ? (r & 3) : ((r >> 1) & 1); };
-    const int vl_row = lane / NCH, vl_ch = lane % NCH;          // loader: row inside the instruction, chunk
-    const int vwaddr = (32 * w + vl_row) * VRS + 16 * ((vl_ch + 4 * vrot(vl_row)) & (NCH - 1));   // + i * RPI * VRS
-    const int vr0 = 8 * (rg >> 1) + (ri >> 2), vr1 = vr0 + 4;   // reader: rows of the two transpose-reads
-    const int vrc = 4 * cb + 2 * (rg & 1) + ((ri & 3) >> 1);     // chunk of this lane's 4 columns, + 8 * (ri & 1) bytes
-    const unsigned char* vbase0 = lds_v + vr0 * VRS + 16 * ((vrc + 4 * vrot(vr0)) & (NCH - 1)) + 8 * (ri & 1);
-    const unsigned char* vbase1 = lds_v + vr1 * VRS + 16 * ((vrc + 4 * vrot(vr1)) & (NCH - 1)) + 8 * (ri & 1);
-
-    const int f_begin = blockIdx.x * P.tiles_per_wg;
-    int f_end = f_begin + P.tiles_per_wg;
-    if (f_end > P.total_tiles) f_end = P.total_tiles;
-    const int first_head = f_begin / P.tiles_per_head;
-
-    f32x16 acc_o[NT];
-    bf16x8 qf[NKS];  // Q fragments of the tile about to enter GEMM1
-    bf16x8 vld[NVI];  // this wave's 32 rows of V(t), in flight / parked until the publish
-    bf16x8 vfr[2];    // B fragments of the current and the next GEMM2 k-step (read one k-step ahead)
-
-    // All loads are unconditional and in bounds: Q and V rows are clamped to n-1; the probabilities of those rows are
-    // zeroed, so whatever (finite) row they re-read contributes nothing.  Element offsets are 32-bit (make_plan checks
-    // n * ld < 2^31) and row * ld is one v_mad_u32_u24: the pointer arithmetic of a tile is ~3 VALU per load, not ~11.
-    const int ldq32 = (int)P.ldq, ldv32 = (int)P.ldv;
-    auto q_off = [&](int a, int t) __attribute__((always_inline)) -> unsigned {
-        int qrow = t * TILE_ROWS + prow;
-        if (qrow > n32 - 1) qrow = n32 - 1;
-        return __umul24((unsigned)qrow, (unsigned)ldq32) + (a * DK + 8 * hf);
-    };
-    auto v_off = [&](int a, int t, int i) __attribute__((always_inline)) -> unsigned {
-        int vrow = t * TILE_ROWS + 32 * w + RPI * i + vl_row;
-        if (vrow > n32 - 1) vrow = n32 - 1;
-        return __umul24((unsigned)vrow, (unsigned)ldv32) + (a * DK + 8 * vl_ch);
-    };
-    // GEMM2 of the pending tile, MFMA m = sk * NT + ti  (sk = 16-row k-step of the tile, ti = output tile of the wave):
-    // A = P^T fragment (key on the lane, 8 rows in registers), B = V fragment, both by transpose-read.  The P fragment of
-    // MFMA m + 3 is requested before MFMA m issues (4-slot ring: one wave per SIMD has nothing else to hide the LDS
-    // latency behind), the V fragment one whole k-step ahead.
-    bf16x8 pfr[4];
-    auto p_read = [&](auto m_tag) __attribute__((always_inline)) {
-        constexpr int m = decltype(m_tag)::value;
-        if constexpr (m < M2) {
-            constexpr int sk = m / NT, ti = m % NT;
-            constexpr int off = sk * 16 * RS + ti * (4 / NCB) * 64;
-            pfr[m % 4] = lds_read_p_frag(rbase0 + off, rbase1 + off);
-        }
-    };
-    auto gemm2_one = [&](auto m_tag) __attribute__((always_inline)) {
-        constexpr int m = decltype(m_tag)::value;
-        constexpr int sk = m / NT, ti = m % NT;
-        const int t_idx = w + 4 * ti;  // tile = kb * NCB + cb ; cb == t_idx % NCB is constant per wave
-        if constexpr (m == 0) {
-            vfr[0] = lds_read_p_frag(vbase0, vbase1);
-            p_read(std::integral_constant<int, 0>{});
-            p_read(std::integral_constant<int, 1>{});
-            p_read(std::integral_constant<int, 2>{});
-        }
-        p_read(std::integral_constant<int, m + 3>{});
-        if constexpr (ti == 0 && sk + 1 < 8)
-            vfr[(sk + 1) & 1] = lds_read_p_frag(vbase0 + (sk + 1) * 16 * VRS, vbase1 + (sk + 1) * 16 * VRS);
-        if (NT * 4 == NKB * NCB || t_idx < NKB * NCB)
-            acc_o[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pfr[m % 4], vfr[sk & 1], acc_o[ti], 0, 0, 0);
-    };
-    auto gemm2_all = [&]() __attribute__((always_inline)) {
-        static_for<0, M2>([&](auto m_tag) __attribute__((always_inline)) {
-            gemm2_one(m_tag);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-
-    auto flush = [&](int head) __attribute__((always_inline)) {
-        const int seg = head - first_head;
-        float* dst = P.partial + ((int64_t)blockIdx.x * P.seg_count + seg) * (int64_t)(NKB * NCB) * 1024;
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti) {
-            const int t_idx = w + 4 * ti;
-            if (t_idx < NKB * NCB) {
-                const int key0 = 32 * (t_idx / NCB);
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    // registers 4 q4 .. 4 q4 + 3 hold keys key0 + 8 q4 + 4 hf + i: skip the quads that are padding only
-                    if (key0 + 8 * q4 < P.k) {
-                        f32x4 v = {acc_o[ti][q4 * 4], acc_o[ti][q4 * 4 + 1], acc_o[ti][q4 * 4 + 2], acc_o[ti][q4 * 4 + 3]};
-                        *reinterpret_cast<f32x4*>(dst + ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4) = v;
-                    }
-                }
-            }
-        }
-    };
-
-    // Kp_a -> LDS as bf16 MFMA fragments: each wave owns fragments w, w+4, ...  Phase 1 issues every global load of the
-    // wave back to back (one latency, not one per fragment; padded keys re-read the last row), phase 2 converts and
-    // stores (padded keys zeroed; their probabilities are forced to 0 through the -inf accumulator init anyway).
-    constexpr int NF = (NKB * NKS + 3) / 4;
-    auto kp_issue = [&](int a, f32x4(&raw)[2 * NF]) __attribute__((always_inline)) {
-        static_for<0, NF>([&](auto i) __attribute__((always_inline)) {
-            int fr = w + 4 * i;
-            if (fr > NKB * NKS - 1) fr = NKB * NKS - 1;
-            const int jb = fr / NKS, kb = fr - jb * NKS;
-            int key = 32 * jb + j;
-            if (key > P.k - 1) key = P.k - 1;
-            const float* src = P.kp + (int64_t)key * P.ldkp + a * DK + 16 * kb + 8 * hf;
-            raw[2 * i] = *reinterpret_cast<const f32x4*>(src);
-            raw[2 * i + 1] = *reinterpret_cast<const f32x4*>(src + 4);
-        });
-    };
-    auto kp_commit = [&](f32x4(&raw)[2 * NF]) __attribute__((always_inline)) {
-        static_for<0, NF>([&](auto i) __attribute__((always_inline)) {
-            const int fr = w + 4 * i;
-            if (fr < NKB * NKS) {
-                const int jb = fr / NKS;
-                f32x8 f = {raw[2 * i][0], raw[2 * i][1], raw[2 * i][2], raw[2 * i][3],
-                           raw[2 * i + 1][0], raw[2 * i + 1][1], raw[2 * i + 1][2], raw[2 * i + 1][3]};
-                u32x4 v = __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
-                if (32 * jb + j >= P.k) v = u32x4{0u, 0u, 0u, 0u};
-                lds_kp[fr * 64 + lane] = v;
-            }
-        });
-    };
-
-    // Prologue.  The cold-start latencies (kernarg, TLB, first HBM touch) are paid ONCE: the first tile's Q fragments and
-    // the first head's Kp rows are requested before anything else, the LDS / accumulator initialisation runs in their
-    // shadow, then Kp is converted into LDS.
-    int a = first_head, t = f_begin - first_head * P.tiles_per_head;   // (head, row tile) of the current work item
-    int cur_head = -1;
-    {
-        f32x4 raw0[2 * NF];
-        if (f_begin < f_end) {
-            const QT* qp0 = q + q_off(a, t);
-            static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) { qf[kb] = load_frag(qp0 + 16 * kb); });
-            __builtin_amdgcn_sched_barrier(0);
-            stamp_abs(56);
-            kp_issue(a, raw0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        stamp_abs(58);
-        // pipeline fill: nothing pending -> P image and V fragments are zero, so the first interleaved GEMM2 adds 0
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        for (int i = threadIdx.x; i < TILE_ROWS * (RS + VRS) / 16; i += 256) reinterpret_cast<u32x4*>(lds_p)[i] = z;
-        stamp_abs(59);
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc_o[ti][r] = 0.f;
-        stamp_abs(57);
-        __builtin_amdgcn_sched_barrier(0);
-        if (f_begin < f_end) {
-            kp_commit(raw0);
-            cur_head = a;
-        }
-        __syncthreads();
-        stamp_abs(61);
-    }
-    bool published = false;      // a P image was written and its closing barrier has not been passed yet
-    for (int f = f_begin; f < f_end; ++f) {
-        const int row = t * TILE_ROWS + prow;   // this lane's query row
-        int an = a, tn = t + 1;   // next work item
-        if (tn == P.tiles_per_head) {
-            tn = 0;
-            an = a + 1;
-        }
-        if (a != cur_head) {
-            if (published) {
-                __syncthreads();   // P image of the pending tile is complete
-                published = false;
-            }
-            if (cur_head >= 0) {  // drain the pending tile of the previous head, then flush its accumulators
-                gemm2_all();
-                flush(cur_head);
-            }
-#pragma unroll
-            for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc_o[ti][r] = 0.f;
-            __syncthreads();  // everyone finished reading the previous head's Kp and the drained P / V images
-            {
-                // nothing is pending any more: the interleaved GEMM2 of the next step must add zero
-                const u32x4 z = {0u, 0u, 0u, 0u};
-                for (int i = threadIdx.x; i < TILE_ROWS * VRS / 16; i += 256) reinterpret_cast<u32x4*>(lds_v)[i] = z;
-                f32x4 raw[2 * NF];
-                kp_issue(a, raw);
-                __builtin_amdgcn_sched_barrier(0);   // do not let the conversions pull the loads apart
-                kp_commit(raw);
-            }
-            __syncthreads();
-            cur_head = a;
-        }
-
-        stamp(0);
-        // ---- GEMM1 (swapped): S^T[key, row] = Kp Q^T.  A = Kp fragment (LDS), B = Q fragment: the C layout puts this
-        //      lane's ONE query row (column j) in registers -- 16 keys per block: key = 32 jb + (r&3) + 8 (r>>2) + 4 hf.
-        f32x16 s_acc[NKB];
-        {
-            // k-step outer, key block inner (m = kb * NKB + jb): consecutive MFMAs hit different accumulators, so there is
-            // no dependent-issue stall.  The asm MFMAs keep their program order, which lets a 4-deep ring of Kp fragments
-            // (16 VGPRs) stay exactly 4 MFMAs (~128 cycles) ahead of its consumer -- enough to cover the LDS latency.
-            constexpr int M1 = NKB * NKS;
-            constexpr int RING = 4;
-            bf16x8 kf[RING];
-            static_for<0, (M1 < RING ? M1 : RING)>([&](auto m_t) __attribute__((always_inline)) {
-                constexpr int m = decltype(m_t)::value;
-                kf[m] = __builtin_bit_cast(bf16x8, lds_kp[((m % NKB) * NKS + m / NKB) * 64 + lane]);
-            });
-            static_for<0, M1>([&](auto m_t) __attribute__((always_inline)) {
-                constexpr int m = decltype(m_t)::value;
-                constexpr int kb = m / NKB, jb = m % NKB;
-                if constexpr (kb == 0) {
-                    // padded keys (only possible in the last two blocks, see make_plan) start at -inf: exp() gives 0.
-                    // The test is wave-uniform; a full block takes the zero-C form (no init moves at all).
-                    if (jb >= NKB - 2 && P.k < 32 * jb + 32) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            s_acc[jb][r] = (32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hf >= P.k) ? -INFINITY : 0.f;
-                        mfma_vgpr<true>(s_acc[jb], kf[m % RING], qf[kb]);
-                    } else {
-                        mfma_vgpr_zero_c(s_acc[jb], kf[m % RING], qf[kb]);   // C = inline constant 0
-                    }
-                } else {
-                    mfma_vgpr<(NKB == 1) || std::is_same<QT, float>::value>(s_acc[jb], kf[m % RING], qf[kb]);
-                }
-                if constexpr (m + RING < M1) {
-                    constexpr int mn = m + RING;
-                    kf[m % RING] = __builtin_bit_cast(bf16x8, lds_kp[((mn % NKB) * NKS + mn / NKB) * 64 + lane]);
-                }
-            });
-            // MFMA result -> VALU read hazard of the asm MFMAs above (the compiler does not see them as MFMAs): park for
-            // the full pipeline depth once per tile; the "+v" operands pin every later read of S behind this point
-            static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
-                if constexpr (jb == 0)
-                    park_after_mfma(s_acc[jb]);
-                else
-                    pin_vgpr(s_acc[jb]);
-            });
-        }
-        stamp(1);
-        if (published) {
-            __syncthreads();   // closes the previous publish: placed AFTER GEMM1 so that the matrix work of this tile
-            published = false; // overlaps the other waves' LDS writes
-        }
-        const bool has_next = f + 1 < f_end;
-        const QT* qnext = q + q_off(has_next ? an : a, has_next ? tn : t);
-
-        // ---- Phase 2: softmax over the keys of this lane's row (16*NKB values in registers + the partner lane l ^ 32,
-        // fp32) with the GEMM2 of the pending tile underneath.  Issue order is pinned slot by slot (one MFMA, its LDS
-        // prefetches, one HBM load, a chunk of softmax steps): left alone, the scheduler requests every P fragment right
-        // before its MFMA and the wave parks on lgkmcnt(0) 56 times per tile.
-        //   steps: 4 NKB max steps | finish max | 8 NKB exp steps (a register pair each) | row sum | 4 NKB normalise+convert
-        constexpr int S_FIN = 4 * NKB, S_EXP0 = S_FIN + 1, S_SUM = S_EXP0 + 8 * NKB, S_NRM0 = S_SUM + 1;
-        constexpr int S_END = S_NRM0 + 4 * NKB;
-        float mx0 = 0.f, mx1 = 0.f, mc = 0.f, l0 = 0.f, l1 = 0.f, lrow = 0.f, inv = 0.f;
-        const bool rvalid = row < n32;
-        f32x2 ev[NKB][8];   // exp values as register PAIRS: the normalisation is one v_pk_mul_f32 + one v_cvt_pk per pair
-        u32x2 pk[NKB][4];
-        auto p2_step = [&](auto st_t) __attribute__((always_inline)) {
-            constexpr int st = decltype(st_t)::value;
-            if constexpr (st < S_FIN) {
-                constexpr int jb = st / 4, r = 4 * (st % 4);
-                if constexpr (EXT) {
-                } else if constexpr (st == 0) {
-                    mx0 = fmaxf(s_acc[0][0], s_acc[0][1]);
-                    mx1 = fmaxf(s_acc[0][2], s_acc[0][3]);
-                } else {
-                    mx0 = fmaxf(fmaxf(mx0, s_acc[jb][r]), s_acc[jb][r + 1]);
-                    mx1 = fmaxf(fmaxf(mx1, s_acc[jb][r + 2]), s_acc[jb][r + 3]);
-                }
-            } else if constexpr (st == S_FIN) {
-                if constexpr (EXT) {
-                    // key-chunked launch: the softmax runs over ALL chunks' keys -- combine their (max, sum) pairs
-                    const float* st0 = P.stats + ((int64_t)a * P.n + (rvalid ? row : 0)) * 2;
-                    const int64_t cs = (int64_t)P.h * P.n * 2;
-                    float m = st0[0];
-                    for (int c = 1; c < P.n_chunks; ++c) m = fmaxf(m, st0[c * cs]);
-                    float l = 0.f;
-                    for (int c = 0; c < P.n_chunks; ++c) l = fmaf(st0[c * cs + 1], __builtin_amdgcn_exp2f(st0[c * cs] - m), l);
-                    mc = m;
-                    lrow = l;
-                } else {
-                    mc = xhalf_max(fmaxf(mx0, mx1)) * c_exp;
-                }
-            } else if constexpr (st < S_SUM) {
-                constexpr int e = st - S_EXP0, jb = e / 8, pr = e % 8;
-                const float e0 = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][2 * pr], c_exp, -mc));
-                const float e1 = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][2 * pr + 1], c_exp, -mc));
-                ev[jb][pr] = f32x2{e0, e1};
-                l0 += e0;
-                l1 += e1;
-            } else if constexpr (st == S_SUM) {
-                if constexpr (!EXT) lrow = xhalf_sum(l0 + l1);
-                inv = rvalid ? __builtin_amdgcn_rcpf(lrow) : 0.f;
-            } else {
-                constexpr int u = st - S_NRM0, jb = u / 4, c4 = u % 4;
-                const f32x2 p01 = ev[jb][2 * c4] * inv, p23 = ev[jb][2 * c4 + 1] * inv;
-                pk[jb][c4] = u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(p01, bf16x2)),
-                                   __builtin_bit_cast(unsigned, __builtin_convertvector(p23, bf16x2))};
-                asm volatile("" : "+v"(pk[jb][c4]));   // keep the conversion under the MFMAs, not behind the barrier
-            }
-        };
-        constexpr int S_MFMA = AUX ? S_NRM0 : S_END;   // steps that run under the MFMAs
-        static_for<0, M2>([&](auto m_t) __attribute__((always_inline)) {
-            constexpr int m = decltype(m_t)::value;
-            gemm2_one(m_t);
-            if constexpr (m < NKS) qf[m] = load_frag(qnext + 16 * m);
-            if constexpr (m >= NKS && m < NKS + NVI) vld[m - NKS] = load_frag(vg + v_off(a, t, m - NKS));
-            static_for<(m * S_MFMA) / M2, ((m + 1) * S_MFMA) / M2>([&](auto st_t) __attribute__((always_inline)) { p2_step(st_t); });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        if constexpr (AUX) {
-            // with the attention matrix / log-sum-exp outputs the normalised fp32 row is stored before it is converted
-            if (P.lse && rvalid && hf == 0) P.lse[(int64_t)a * P.n + row] = mc * 0.69314718055994530942f + __logf(lrow);
-            // attention matrix: this lane owns 4 consecutive keys per (block, c4) of ONE row -> 16-byte stores
-            if (P.attn && rvalid) {
-                float* arow = P.attn + ((int64_t)a * P.n + row) * P.attn_ld + 4 * hf;
-                // keys this lane may store, relative to its first one.  Opaque to the optimiser on purpose: the bound is
-                // loop-invariant, and hoisting the 28..112 compare masks out of the tile loop spills ~240 SGPRs.
-                int klim = P.k - 4 * hf;
-                asm volatile("" : "+v"(klim));
-                static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
-                    constexpr int jb = decltype(jb_t)::value;
-#pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        const f32x2 p01 = ev[jb][2 * c4] * inv, p23 = ev[jb][2 * c4 + 1] * inv;
-                        constexpr int kb0 = 32 * jb;
-                        const int key0 = kb0 + 8 * c4;
-                        float* dst = arow + key0;
-                        if (attn_vec) {
-                            if (key0 < klim) *reinterpret_cast<f32x4*>(dst) = f32x4{p01[0], p01[1], p23[0], p23[1]};
-                        } else {
-                            if (key0 < klim) dst[0] = p01[0];
-                            if (key0 + 1 < klim) dst[1] = p01[1];
-                            if (key0 + 2 < klim) dst[2] = p23[0];
-                            if (key0 + 3 < klim) dst[3] = p23[1];
-                        }
-                    }
-                });
-            }
-            static_for<S_NRM0, S_END>([&](auto st_t) __attribute__((always_inline)) { p2_step(st_t); });
-        }
-        stamp(2);
-
-        // ---- publish P (bf16, row-major image) and this wave's rows of V for the 4 waves
-        __syncthreads();  // every wave finished the GEMM2 reads of the previous image
-        stamp(3);
-        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
-            constexpr int jb = decltype(jb_t)::value;
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) *reinterpret_cast<u32x2*>(lds_p + waddr[c4] + jb * 64) = pk[jb][c4];
-        });
-        static_for<0, NVI>([&](auto i_t) __attribute__((always_inline)) {
-            constexpr int i = decltype(i_t)::value;
-            *reinterpret_cast<u32x4*>(lds_v + vwaddr + i * RPI * VRS) = __builtin_bit_cast(u32x4, vld[i]);
-        });
-        published = true;
-        stamp(4);
-        ++trace_it;
-        a = an;
-        t = tn;
-    }
-    stamp_abs(62);
-    if (published) __syncthreads();
-    if (cur_head >= 0) {
-        gemm2_all();  // drain the last pending tile
-        flush(cur_head);
-    }
-    stamp_abs(63);
-}
-
-
-// Row statistics of one key chunk (key-chunked launches, k above what one LDS image holds): the GEMM1 + max / exp / sum half
-// of the kernel above, nothing else.  stats_out[(a * n + row) * 2 + {0, 1}] = (row max * scale * log2 e, sum of exp).
-template <int DK, int NKB, typename QT>
-__global__ __launch_bounds__(256, 1) void sparse_attn_stats_kernel(AttnParams P) {
-    constexpr int NKS = DK / 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4* lds_kp = reinterpret_cast<u32x4*>(smem);                    // [NKB][NKS][64] MFMA A fragments of Kp
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 31, hf = lane >> 5;
-    const QT* __restrict__ q = reinterpret_cast<const QT*>(P.q);
-    const float c_exp = P.scale * 1.44269504088896340736f;
-    const int n32 = (int)P.n;
-    const int prow = 32 * w + j;
-    const int ldq32 = (int)P.ldq;
-    const int f_begin = blockIdx.x * P.tiles_per_wg;
-    int f_end = f_begin + P.tiles_per_wg;
-    if (f_end > P.total_tiles) f_end = P.total_tiles;
-    const int first_head = f_begin / P.tiles_per_head;
-    int a = first_head, t = f_begin - first_head * P.tiles_per_head;
-    int cur_head = -1;
-    constexpr int NF = (NKB * NKS + 3) / 4;
-    bf16x8 qf[NKS];
-    auto load_q = [&](int a_, int t_) __attribute__((always_inline)) {
-        int qrow = t_ * TILE_ROWS + prow;
-        if (qrow > n32 - 1) qrow = n32 - 1;
-        const QT* qp = q + __umul24((unsigned)qrow, (unsigned)ldq32) + (a_ * DK + 8 * hf);
-        static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) { qf[kb] = load_frag(qp + 16 * kb); });
-    };
-    if (f_begin < f_end) load_q(a, t);
-    for (int f = f_begin; f < f_end; ++f) {
-        const int row = t * TILE_ROWS + prow;
-        int an = a, tn = t + 1;
-        if (tn == P.tiles_per_head) {
-            tn = 0;
-            an = a + 1;
-        }
-        if (a != cur_head) {
-            __syncthreads();  // everyone finished reading the previous head's Kp
-            static_for<0, NF>([&](auto i) __attribute__((always_inline)) {
-                const int fr = w + 4 * i;
-                if (fr < NKB * NKS) {
-                    const int jb = fr / NKS, kb = fr - jb * NKS;
-                    int key = 32 * jb + j;
-                    const bool pad = key >= P.k;
-                    if (pad) key = P.k - 1;
-                    const float* src = P.kp + (int64_t)key * P.ldkp + a * DK + 16 * kb + 8 * hf;
-                    u32x4 v = __builtin_bit_cast(u32x4, load_frag(src));
-                    if (pad) v = u32x4{0u, 0u, 0u, 0u};
-                    lds_kp[fr * 64 + lane] = v;
-                }
-            });
-            __syncthreads();
-            cur_head = a;
-        }
-        f32x16 s_acc[NKB];
-        static_for<0, NKB * NKS>([&](auto m_t) __attribute__((always_inline)) {
-            constexpr int m = decltype(m_t)::value;
-            constexpr int kb = m / NKB, jb = m % NKB;
-            const bf16x8 kf = __builtin_bit_cast(bf16x8, lds_kp[(jb * NKS + kb) * 64 + lane]);
-            if constexpr (kb == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    s_acc[jb][r] = (32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hf >= P.k) ? -INFINITY : 0.f;
-            }
-            s_acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kb], s_acc[jb], 0, 0, 0);
-        });
-        const bool has_next = f + 1 < f_end;
-        if (has_next) load_q(an, tn);   // next tile's Q under this tile's softmax
-        float mx0 = s_acc[0][0], mx1 = s_acc[0][1];
-        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
-            constexpr int jb = decltype(jb_t)::value;
-#pragma unroll
-            for (int r = 0; r < 16; r += 4) {
-                mx0 = fmaxf(fmaxf(mx0, s_acc[jb][r]), s_acc[jb][r + 1]);
-                mx1 = fmaxf(fmaxf(mx1, s_acc[jb][r + 2]), s_acc[jb][r + 3]);
-            }
-        });
-        const float mc = xhalf_max(fmaxf(mx0, mx1)) * c_exp;
-        float l0 = 0.f, l1 = 0.f;
-        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
-            constexpr int jb = decltype(jb_t)::value;
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                l0 += __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r], c_exp, -mc));
-                l1 += __builtin_amdgcn_exp2f(fmaf(s_acc[jb][r + 1], c_exp, -mc));
-            }
-        });
-        const float lrow = xhalf_sum(l0 + l1);
-        if (row < n32 && hf == 0) {
-            float* dst = P.stats_out + ((int64_t)a * P.n + row) * 2;
-            dst[0] = mc;
-            dst[1] = lrow;
-        }
-        a = an;
-        t = tn;
-    }
-}
-
-// out[key, a*DK + col] = sum over the (workgroup, segment) partials of head a, ascending workgroup order
-template <int DK, int NKB>
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int num_wg, int seg_count,
-                                                              int tiles_per_head, int tiles_per_wg, int total_tiles,
-                                                              int k, int h, float* __restrict__ out) {
-    constexpr int NCB = DK / 32;
-    constexpr int TILES = NKB * NCB;
-    const int a = blockIdx.y;
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);  // (tile, q4)
-    if (unit >= TILES * 4) return;
-    const int lane = threadIdx.x & 63;
-    const int t_idx = unit >> 2, q4 = unit & 3;
-    if (32 * (t_idx / NCB) + 8 * q4 >= k) return;   // padding only: never written by the main kernel
-    const int f_lo = a * tiles_per_head, f_hi = (a + 1) * tiles_per_head - 1;
-    int b_lo = f_lo / tiles_per_wg, b_hi = f_hi / tiles_per_wg;
-    if (b_hi > num_wg - 1) b_hi = num_wg - 1;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    const int64_t off = ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4;
-    auto src_of = [&](int b) -> const float* {
-        const int seg = a - (b * tiles_per_wg) / tiles_per_head;
-        return partial + ((int64_t)b * seg_count + seg) * (int64_t)TILES * 1024 + off;
-    };
-    // 48 loads in flight (a whole head at the usual 43 contributing workgroups), tail included (a serial tail costs one full memory latency per leftover partial); the summation
-    // order stays ascending in b, so the result is bit-reproducible
-    for (int b = b_lo; b <= b_hi; b += 48) {
-        f32x4 v[48];
-#pragma unroll
-        for (int u = 0; u < 48; ++u) {
-            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (b + u <= b_hi) v[u] = *reinterpret_cast<const f32x4*>(src_of(b + u));
-        }
-#pragma unroll
-        for (int u = 0; u < 48; ++u) s += v[u];
-    }
-    const int kb = t_idx / NCB, cb = t_idx - kb * NCB;
-    const int col = a * DK + 32 * cb + (lane & 31);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int key = 32 * kb + i + 8 * q4 + 4 * (lane >> 5);
-        if (key < k) out[(int64_t)key * (h * DK) + col] = s[i];
-    }
-}
-
 unsigned long long* g_attn_trace = nullptr;  // debug hook, see snf_debug_attn_trace
-
-struct Plan {
-    int num_wg, tiles_per_head, tiles_per_wg, total_tiles, seg_count, nkb;
-};
-
-inline bool make_plan(int64_t n, int k, int h, int dk, Plan* pl) {
-    if (!(dk == 64 || dk == 128) || k < 1 || k > (dk == 128 ? 224 : 256)) return false;   // LDS: Kp + P + V images
-    int nkb = (k + 31) / 32;
-    // instantiated key-block counts
-    const int opts[] = {1, 2, 4, 6, 7, 8};
-    int sel = 0;
-    for (int o : opts)
-        if (o >= nkb) {
-            sel = o;
-            break;
-        }
-    if (!sel) return false;
-    if (n > 0xffff00ll) return false;   // 24-bit row x pitch products inside the kernel
-    int64_t tph = (n + TILE_ROWS - 1) / TILE_ROWS;
-    int64_t total = tph * h;
-    if (total > 0x7fffffff) return false;
-    int cus = snf::cu_count();
-    int64_t num_wg = total < cus ? total : cus;
-    int64_t tpw = (total + num_wg - 1) / num_wg;
-    num_wg = (total + tpw - 1) / tpw;
-    pl->num_wg = (int)num_wg;
-    pl->tiles_per_head = (int)tph;
-    pl->tiles_per_wg = (int)tpw;
-    pl->total_tiles = (int)total;
-    pl->seg_count = (int)((tpw + tph - 1) / tph + 1);
-    pl->nkb = sel;
-    return true;
-}
-
-template <int DK, int NKB, typename QT, bool AUX, bool EXT = false>
-int launch_variant(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
-    constexpr int NKS = DK / 16;
-    const size_t lds = (size_t)(NKB * NKS) * 1024 + (size_t)TILE_ROWS * (p_row_bytes(NKB) + 2 * DK);
-    static thread_local bool attr_set = false;
-    auto kern = sparse_attn_mfma_kernel<DK, NKB, QT, AUX, EXT>;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
-            snf::set_error("sparse_attn_mfma: cannot reserve %zu bytes of LDS", lds);
-            (void)hipGetLastError();
-            return SNF_ELAUNCH;
-        }
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(pl.num_wg), dim3(256), lds, s, P);
-    int rc = snf::check_launch("sparse_attn_mfma_kernel");
-    if (rc) return rc;
-    constexpr int TILES = NKB * (DK / 32);
-    hipLaunchKernelGGL((reduce_partials_kernel<DK, NKB>), dim3(TILES, P.h), dim3(256), 0, s, P.partial, pl.num_wg,
-                       pl.seg_count, pl.tiles_per_head, pl.tiles_per_wg, pl.total_tiles, P.k, P.h, out);
-    return snf::check_launch("reduce_partials_kernel");
-}
-
-#define SNF_ATTN_CASE(NB, EXT)                                                                     \
-    case NB:                                                                                       \
-        return aux ? launch_variant<DK, NB, QT, true, EXT>(P, pl, out, s) : launch_variant<DK, NB, QT, false, EXT>(P, pl, out, s);
-template <int DK, typename QT>
-int launch_nkb(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
-    const bool aux = P.attn != nullptr || P.lse != nullptr;
-    if (P.stats) {   // key-chunked launch: chunk sizes are in (kmax/2, kmax] -> 4, 6, 7 or 8 key blocks
-        switch (pl.nkb) {
-#ifndef SNF_ATTN_DEV
-            SNF_ATTN_CASE(4, true)
-            SNF_ATTN_CASE(6, true)
-            SNF_ATTN_CASE(8, true)
-#endif
-            SNF_ATTN_CASE(7, true)
-            default: snf::set_error("sparse_attn_mfma: chunked key-block count %d not built", pl.nkb); return SNF_EUNSUPPORTED;
-        }
-    }
-    switch (pl.nkb) {
-#ifndef SNF_ATTN_DEV   // development builds instantiate the config-B shape only (the file takes minutes otherwise)
-        SNF_ATTN_CASE(1, false)
-        SNF_ATTN_CASE(2, false)
-        SNF_ATTN_CASE(4, false)
-        SNF_ATTN_CASE(6, false)
-        SNF_ATTN_CASE(8, false)
-#endif
-        SNF_ATTN_CASE(7, false)
-        default: snf::set_error("sparse_attn_mfma: key-block count %d not built", pl.nkb); return SNF_EUNSUPPORTED;
-    }
-}
-#undef SNF_ATTN_CASE
-
-inline size_t mfma_workspace_bytes(const Plan& pl, int dk) {
-    return (size_t)pl.num_wg * pl.seg_count * (size_t)(pl.nkb * (dk / 32)) * 1024 * sizeof(float);
-}
-
-template <int DK, int NKB, typename QT>
-int launch_stats_variant(const AttnParams& P, const Plan& pl, hipStream_t s) {
-    constexpr int NKS = DK / 16;
-    hipLaunchKernelGGL((sparse_attn_stats_kernel<DK, NKB, QT>), dim3(pl.num_wg), dim3(256), (size_t)(NKB * NKS) * 1024, s, P);
-    return snf::check_launch("sparse_attn_stats_kernel");
-}
-template <int DK, typename QT>
-int launch_stats(const AttnParams& P, const Plan& pl, hipStream_t s) {
-    switch (pl.nkb) {
-#ifndef SNF_ATTN_DEV
-        case 4: return launch_stats_variant<DK, 4, QT>(P, pl, s);
-        case 6: return launch_stats_variant<DK, 6, QT>(P, pl, s);
-        case 8: return launch_stats_variant<DK, 8, QT>(P, pl, s);
-#endif
-        case 7: return launch_stats_variant<DK, 7, QT>(P, pl, s);
-        default: snf::set_error("sparse_attn_stats: key-block count %d not built", pl.nkb); return SNF_EUNSUPPORTED;
-    }
-}
-
-// Key chunking: one launch holds at most KMAX keys (Kp + P + V images in 160 KiB of LDS).  More keys are split into
-// n_chunks near-equal chunks; every chunk gets a statistics launch (row max / sum over its keys) and then a full launch
-// that normalises with the statistics of ALL chunks -- the softmax stays exact, Q is read 2 n_chunks times and V n_chunks
-// times instead of once.
-constexpr int MAX_CHUNKS = 8;
-struct ChunkPlan {
-    int n_chunks, chunk_k;   // chunk c covers keys [c * chunk_k, min(k, (c + 1) * chunk_k))
-};
-inline bool make_chunks(int k, int dk, ChunkPlan* cp) {
-    if (!(dk == 64 || dk == 128) || k < 1) return false;
-    const int kmax = dk == 128 ? 224 : 256;
-    const int nc = (k + kmax - 1) / kmax;
-    if (nc > MAX_CHUNKS) return false;
-    cp->n_chunks = nc;
-    cp->chunk_k = (k + nc - 1) / nc;
-    return true;
-}
-// bytes of the partial-accumulator area (largest chunk) and of the statistics area behind it
-inline bool chunked_workspace(int64_t n, int k, int h, int dk, size_t* partial_bytes, size_t* stats_bytes) {
-    ChunkPlan cp;
-    Plan pl;
-    if (!make_chunks(k, dk, &cp) || !make_plan(n, cp.chunk_k, h, dk, &pl)) return false;
-    *partial_bytes = (mfma_workspace_bytes(pl, dk) + 255) / 256 * 256;
-    *stats_bytes = cp.n_chunks > 1 ? (size_t)cp.n_chunks * h * n * 2 * sizeof(float) : 0;
-    return true;
-}
-
 }  // namespace
+
+namespace snf {
+int attn_launch_dk128(int qv_dtype, bool stats_pass, const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
+    if (stats_pass)
+        return qv_dtype == SNF_DT_F32 ? launch_stats<128, float>(P, pl, s) : launch_stats<128, unsigned short>(P, pl, s);
+    return qv_dtype == SNF_DT_F32 ? launch_nkb<128, float>(P, pl, out, s) : launch_nkb<128, unsigned short>(P, pl, out, s);
+}
+}  // namespace snf
 
 extern "C" {
 
@@ -945,10 +95,8 @@ int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t 
         for (int c = 0; c < cp.n_chunks; ++c) {
             plan_chunk(c, &pl);
             P.stats_out = stats + (size_t)c * h * n * 2;
-            int rc = dk == 128 ? (qv_dtype == SNF_DT_F32 ? launch_stats<128, float>(P, pl, s)
-                                                         : launch_stats<128, unsigned short>(P, pl, s))
-                               : (qv_dtype == SNF_DT_F32 ? launch_stats<64, float>(P, pl, s)
-                                                         : launch_stats<64, unsigned short>(P, pl, s));
+            int rc = dk == 128 ? snf::attn_launch_dk128(qv_dtype, true, P, pl, nullptr, s)
+                               : snf::attn_launch_dk64(qv_dtype, true, P, pl, nullptr, s);
             if (rc) return rc;
         }
     }
@@ -959,10 +107,8 @@ int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t 
         P.attn = attn ? attn + k0 : nullptr;
         P.lse = c == 0 ? lse : nullptr;
         float* out_c = out + (int64_t)k0 * d;
-        int rc = dk == 128 ? (qv_dtype == SNF_DT_F32 ? launch_nkb<128, float>(P, pl, out_c, s)
-                                                     : launch_nkb<128, unsigned short>(P, pl, out_c, s))
-                           : (qv_dtype == SNF_DT_F32 ? launch_nkb<64, float>(P, pl, out_c, s)
-                                                     : launch_nkb<64, unsigned short>(P, pl, out_c, s));
+        int rc = dk == 128 ? snf::attn_launch_dk128(qv_dtype, false, P, pl, out_c, s)
+                           : snf::attn_launch_dk64(qv_dtype, false, P, pl, out_c, s);
         if (rc) return rc;
     }
     return SNF_OK;
