@@ -157,20 +157,28 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 }
 
 // AUX = the caller asked for the attention matrix and/or the row log-sum-exp (extra stores after the softmax).
-//
-// Software pipeline of one wave (one wave per SIMD, so MFMA and VALU only overlap inside the wave's own stream):
-//   step t:   GEMM1(t)                                     MFMA   (Kp fragments through a 4-deep register ring out of LDS)
-//             softmax(t)  ||  GEMM2(t-1)                   VALU   ||  MFMA: the 8*NT MFMAs of the PREVIOUS tile are spread
-//                                                          over the 2*NKB slices of the softmax by VALU weight
-//             barrier, publish P(t) in LDS, (barrier after the next GEMM1)
-//   loads:    one 16-byte fragment at a time between the slices (Q(t+1) during the max pass, V(t) as soon as the pending
-//             GEMM2 released the register): HBM requests stream continuously, a full step ahead of their use.
 // EXT = key-chunked launch: the row statistics come from sparse_attn_stats_kernel (all chunks), not from this chunk's scores.
+//
+// Workgroup = 8 waves in two ROLES, one wave of each role per SIMD (waves w and w + 4 share a SIMD):
+//   softmax waves 0..3   Q loads, GEMM1 and the fp32 softmax of their 32 query rows, publish P (bf16) in LDS
+//   pooling waves 4..7   V loads and the V image, GEMM2 for their share of the [k, dk] output tiles, the accumulators,
+//                        the flush of the partial tiles
+// Why two roles: a single wave issues at most one instruction every 4-5 cycles (measured, tools/probes), and the softmax
+// is ~500 VALU instructions per 32 x 224 tile while GEMM2 is 56 MFMAs + 128 transpose-reads -- in one wave they only
+// interleave, on two waves of the same SIMD the VALU stream and the MFMA / LDS stream issue side by side.  The register
+// file splits accordingly: S (112 VGPRs) + Q fragments live only in the softmax waves, the output accumulators
+// (112 VGPRs) + V rows only in the pooling waves, so both fit the 256 registers of a two-waves-per-SIMD launch.
+//
+// One step (tile f = 128 query rows of one head), barriers B (images complete) and A (images free) shared by all 8 waves:
+//   softmax wave:  GEMM1(f)  B(f-1)  Q(f+1) loads, softmax(f)                A(f)  write P(f)
+//   pooling wave:  V(f) loads B(f-1) GEMM2(f-1) out of the P / V images      A(f)  write V(f)
+// B sits AFTER GEMM1 on purpose: the matrix pipe of the SIMD then runs GEMM1 and GEMM2 one after the other instead of
+// both at half speed, and GEMM2 overlaps the VALU-only softmax.
 template <int DK, int NKB, typename QT, bool AUX, bool EXT>
-__global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) {
+__global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
     constexpr int NKS = DK / 16;             // k-steps of GEMM1
     constexpr int NCB = DK / 32;             // 32-wide column blocks of the output
-    constexpr int NT = (NKB * NCB + 3) / 4;  // output tiles owned by one wave
+    constexpr int NT = (NKB * NCB + 3) / 4;  // output tiles owned by one pooling wave
     constexpr int M2 = 8 * NT;               // GEMM2 MFMAs per tile and wave
     constexpr int RS = p_row_bytes(NKB);     // row pitch of the P image
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -184,411 +192,434 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_mfma_kernel(AttnParams P) 
                  "s"(P.partial), "s"(P.tiles_per_head), "s"(P.tiles_per_wg), "s"(P.total_tiles), "s"(P.seg_count),
                  "s"(P.trace), "s"(P.stats), "s"(P.n_chunks), "s"(P.attn_ld));
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = w8 & 3;   // position inside the role = SIMD
     const int j = lane & 31, hf = lane >> 5;
-    const QT* __restrict__ q = reinterpret_cast<const QT*>(P.q);
-    const QT* __restrict__ vg = reinterpret_cast<const QT*>(P.v);
-    const float c_exp = P.scale * 1.44269504088896340736f;
-    const int cb = (NCB == 4) ? w : (w & (NCB - 1));
     const int n32 = (int)P.n;
-    const bool attn_vec = AUX && (P.attn_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(P.attn) & 15) == 0;
     int trace_it = 0;
+    // debug trace (tools/attn_trace.py): phases 0..4 are stamped by the softmax waves, 5..7 by the pooling waves
     auto stamp = [&](int phase) __attribute__((always_inline)) {
         if (P.trace && blockIdx.x == 0 && lane == 0)
             P.trace[(trace_it * 8 + phase) * 4 + w] = __builtin_amdgcn_s_memtime();
     };
-    auto stamp_abs = [&](int slot) __attribute__((always_inline)) {  // slots 57, 60..63 of the trace: kernel milestones
+    auto stamp_abs = [&](int slot) __attribute__((always_inline)) {  // slots 56..63 of the trace: kernel milestones
         if (P.trace && blockIdx.x == 0 && lane == 0) P.trace[(slot * 8) * 4 + w] = __builtin_amdgcn_s_memtime();
     };
-    stamp_abs(60);
-
-    // ---- P image addressing.  Row r of the tile lives at r * RS; the 8-byte chunk c (4 keys) of its 64-byte key-block
-    // segment is stored at chunk position c ^ ((r >> 1) & 7).  RS is an odd multiple of 64 bytes, so
-    //   * a ds_write_b64 group (16 lanes = 16 consecutive rows, same logical chunk) covers all 32 banks exactly once,
-    //   * a transpose-read group (32 lanes = 4 consecutive rows x 64 bytes) covers all 64 banks exactly once.
-    const int prow = 32 * w + j;                  // this lane's query row inside the tile (GEMM1 / softmax side)
-    const int pswz = (prow >> 1) & 7;
-    int waddr[4];                                 // byte offset of chunk (2*c4 + hf) of key block 0 in row prow
-#pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) waddr[c4] = prow * RS + 8 * (((2 * c4) | hf) ^ pswz);
-    // reader (GEMM2 side): lane = group g (16 lanes) x i; rows 8*(g>>1) + 4*s + (i>>2), chunk 4*(g&1) + (i&3)
-    const int rg = lane >> 4, ri = lane & 15;
-    const int rr0 = 8 * (rg >> 1) + (ri >> 2), rr1 = rr0 + 4;
-    const int rch = 4 * (rg & 1) + (ri & 3);
-    // key block of output tile ti of this wave = ti * (4 / NCB) + w / NCB: the wave-dependent part goes into the base
-    const unsigned char* rbase0 = lds_p + rr0 * RS + 8 * (rch ^ ((rr0 >> 1) & 7)) + 64 * (w / NCB);
-    const unsigned char* rbase1 = lds_p + rr1 * RS + 8 * (rch ^ ((rr1 >> 1) & 7)) + 64 * (w / NCB);
-
-    // ---- V image.  V arrives ROW-major (it comes out of the same GEMM as Q): each wave fetches 32 rows of the tile with
-    // fully coalesced 16-byte loads (one row = DK/8 chunks of 8 columns), parks them in registers for the rest of the step
-    // and stores them next to the P image at publish time; GEMM2 reads its B fragments (column on the lane, 8 consecutive
-    // rows in registers) back with the same hardware transpose-read as P.  Row pitch = 2*DK bytes, no padding: chunk c of
-    // row r sits at chunk position (c + 4 rot(r)) mod NCH, which spreads the 4 rows x 64 bytes of a transpose-read group
-    // over all 64 banks (rot = r & 3 for DK = 128, (r >> 1) & 1 for DK = 64: rows of 128 bytes already alternate halves).
-    constexpr int VRS = 2 * DK, NCH = DK / 8;     // row pitch (bytes), 16-byte chunks per row
-    constexpr int RPI = 64 / NCH, NVI = 32 / RPI; // rows per load instruction, load instructions per wave and tile
-    auto vrot = [](int r) __attribute__((always_inline)) -> int { return DK == 128 ? (r & 3) : ((r >> 1) & 1); };
-    const int vl_row = lane / NCH, vl_ch = lane % NCH;          // loader: row inside the instruction, chunk
-    const int vwaddr = (32 * w + vl_row) * VRS + 16 * ((vl_ch + 4 * vrot(vl_row)) & (NCH - 1));   // + i * RPI * VRS
-    const int vr0 = 8 * (rg >> 1) + (ri >> 2), vr1 = vr0 + 4;   // reader: rows of the two transpose-reads
-    const int vrc = 4 * cb + 2 * (rg & 1) + ((ri & 3) >> 1);     // chunk of this lane's 4 columns, + 8 * (ri & 1) bytes
-    const unsigned char* vbase0 = lds_v + vr0 * VRS + 16 * ((vrc + 4 * vrot(vr0)) & (NCH - 1)) + 8 * (ri & 1);
-    const unsigned char* vbase1 = lds_v + vr1 * VRS + 16 * ((vrc + 4 * vrot(vr1)) & (NCH - 1)) + 8 * (ri & 1);
 
     const int f_begin = blockIdx.x * P.tiles_per_wg;
     int f_end = f_begin + P.tiles_per_wg;
     if (f_end > P.total_tiles) f_end = P.total_tiles;
     const int first_head = f_begin / P.tiles_per_head;
-
-    f32x16 acc_o[NT];
-    bf16x8 qf[NKS];  // Q fragments of the tile about to enter GEMM1
-    bf16x8 vld[NVI];  // this wave's 32 rows of V(t), in flight / parked until the publish
-    bf16x8 vfr[2];    // B fragments of the current and the next GEMM2 k-step (read one k-step ahead)
+    int a = first_head, t = f_begin - first_head * P.tiles_per_head;   // (head, row tile) of the current work item
+    int cur_head = f_begin < f_end ? first_head : -1;                  // head whose Kp image / accumulators are live
+    bool published = false;   // P / V images written, their closing barrier B not passed yet (same value in both roles)
 
     // All loads are unconditional and in bounds: Q and V rows are clamped to n-1; the probabilities of those rows are
     // zeroed, so whatever (finite) row they re-read contributes nothing.  Element offsets are 32-bit (make_plan checks
     // n * ld < 2^31) and row * ld is one v_mad_u32_u24: the pointer arithmetic of a tile is ~3 VALU per load, not ~11.
-    const int ldq32 = (int)P.ldq, ldv32 = (int)P.ldv;
-    auto q_off = [&](int a, int t) __attribute__((always_inline)) -> unsigned {
-        int qrow = t * TILE_ROWS + prow;
-        if (qrow > n32 - 1) qrow = n32 - 1;
-        return __umul24((unsigned)qrow, (unsigned)ldq32) + (a * DK + 8 * hf);
-    };
-    auto v_off = [&](int a, int t, int i) __attribute__((always_inline)) -> unsigned {
-        int vrow = t * TILE_ROWS + 32 * w + RPI * i + vl_row;
-        if (vrow > n32 - 1) vrow = n32 - 1;
-        return __umul24((unsigned)vrow, (unsigned)ldv32) + (a * DK + 8 * vl_ch);
-    };
-    // GEMM2 of the pending tile, MFMA m = sk * NT + ti  (sk = 16-row k-step of the tile, ti = output tile of the wave):
-    // A = P^T fragment (key on the lane, 8 rows in registers), B = V fragment, both by transpose-read.  The P fragment of
-    // MFMA m + 3 is requested before MFMA m issues (4-slot ring: one wave per SIMD has nothing else to hide the LDS
-    // latency behind), the V fragment one whole k-step ahead.
-    bf16x8 pfr[4];
-    auto p_read = [&](auto m_tag) __attribute__((always_inline)) {
-        constexpr int m = decltype(m_tag)::value;
-        if constexpr (m < M2) {
-            constexpr int sk = m / NT, ti = m % NT;
-            constexpr int off = sk * 16 * RS + ti * (4 / NCB) * 64;
-            pfr[m % 4] = lds_read_p_frag(rbase0 + off, rbase1 + off);
-        }
-    };
-    auto gemm2_one = [&](auto m_tag) __attribute__((always_inline)) {
-        constexpr int m = decltype(m_tag)::value;
-        constexpr int sk = m / NT, ti = m % NT;
-        const int t_idx = w + 4 * ti;  // tile = kb * NCB + cb ; cb == t_idx % NCB is constant per wave
-        if constexpr (m == 0) {
-            vfr[0] = lds_read_p_frag(vbase0, vbase1);
-            p_read(std::integral_constant<int, 0>{});
-            p_read(std::integral_constant<int, 1>{});
-            p_read(std::integral_constant<int, 2>{});
-        }
-        p_read(std::integral_constant<int, m + 3>{});
-        if constexpr (ti == 0 && sk + 1 < 8)
-            vfr[(sk + 1) & 1] = lds_read_p_frag(vbase0 + (sk + 1) * 16 * VRS, vbase1 + (sk + 1) * 16 * VRS);
-        if (NT * 4 == NKB * NCB || t_idx < NKB * NCB)
-            acc_o[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pfr[m % 4], vfr[sk & 1], acc_o[ti], 0, 0, 0);
-    };
-    auto gemm2_all = [&]() __attribute__((always_inline)) {
-        static_for<0, M2>([&](auto m_tag) __attribute__((always_inline)) {
-            gemm2_one(m_tag);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
 
-    auto flush = [&](int head) __attribute__((always_inline)) {
-        const int seg = head - first_head;
-        float* dst = P.partial + ((int64_t)blockIdx.x * P.seg_count + seg) * (int64_t)(NKB * NCB) * 1024;
+    if (w8 < 4) {
+        // =========================================== softmax waves ===========================================
+        stamp_abs(60);
+        const QT* __restrict__ q = reinterpret_cast<const QT*>(P.q);
+        const float c_exp = P.scale * 1.44269504088896340736f;
+        const bool attn_vec = AUX && (P.attn_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(P.attn) & 15) == 0;
+        // ---- P image addressing.  Row r of the tile lives at r * RS; the 8-byte chunk c (4 keys) of its 64-byte key-block
+        // segment is stored at chunk position c ^ ((r >> 1) & 7).  RS is an odd multiple of 64 bytes, so
+        //   * a ds_write_b64 group (16 lanes = 16 consecutive rows, same logical chunk) covers all 32 banks exactly once,
+        //   * a transpose-read group (32 lanes = 4 consecutive rows x 64 bytes) covers all 64 banks exactly once.
+        const int prow = 32 * w + j;                  // this lane's query row inside the tile
+        const int pswz = (prow >> 1) & 7;
+        int waddr[4];                                 // byte offset of chunk (2*c4 + hf) of key block 0 in row prow
 #pragma unroll
-        for (int ti = 0; ti < NT; ++ti) {
-            const int t_idx = w + 4 * ti;
-            if (t_idx < NKB * NCB) {
-                const int key0 = 32 * (t_idx / NCB);
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    // registers 4 q4 .. 4 q4 + 3 hold keys key0 + 8 q4 + 4 hf + i: skip the quads that are padding only
-                    if (key0 + 8 * q4 < P.k) {
-                        f32x4 v = {acc_o[ti][q4 * 4], acc_o[ti][q4 * 4 + 1], acc_o[ti][q4 * 4 + 2], acc_o[ti][q4 * 4 + 3]};
-                        *reinterpret_cast<f32x4*>(dst + ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4) = v;
-                    }
+        for (int c4 = 0; c4 < 4; ++c4) waddr[c4] = prow * RS + 8 * (((2 * c4) | hf) ^ pswz);
+        const int ldq32 = (int)P.ldq;
+        auto q_off = [&](int a_, int t_) __attribute__((always_inline)) -> unsigned {
+            int qrow = t_ * TILE_ROWS + prow;
+            if (qrow > n32 - 1) qrow = n32 - 1;
+            return __umul24((unsigned)qrow, (unsigned)ldq32) + (a_ * DK + 8 * hf);
+        };
+        // Kp_a -> LDS as bf16 MFMA fragments: each softmax wave owns fragments w, w+4, ...  Phase 1 issues every global load
+        // of the wave back to back (one latency, not one per fragment; padded keys re-read the last row), phase 2 converts
+        // and stores (padded keys zeroed; their probabilities are forced to 0 through the -inf accumulator init anyway).
+        constexpr int NF = (NKB * NKS + 3) / 4;
+        auto kp_issue = [&](int a_, f32x4(&raw)[2 * NF]) __attribute__((always_inline)) {
+            // opaque copy of the lane's key index: the fragment addresses are loop-invariant, and hoisting NF 64-bit
+            // pointers out of the tile loop would hold 2 NF registers across the whole softmax for a once-per-head event
+            int jo = j;
+            asm volatile("" : "+v"(jo));
+            static_for<0, NF>([&](auto i) __attribute__((always_inline)) {
+                int fr = w + 4 * i;
+                if (fr > NKB * NKS - 1) fr = NKB * NKS - 1;
+                const int jb = fr / NKS, kb = fr - jb * NKS;
+                int key = 32 * jb + jo;
+                if (key > P.k - 1) key = P.k - 1;
+                const float* src = P.kp + (int64_t)key * P.ldkp + a_ * DK + 16 * kb + 8 * hf;
+                raw[2 * i] = *reinterpret_cast<const f32x4*>(src);
+                raw[2 * i + 1] = *reinterpret_cast<const f32x4*>(src + 4);
+            });
+        };
+        auto kp_commit = [&](f32x4(&raw)[2 * NF]) __attribute__((always_inline)) {
+            static_for<0, NF>([&](auto i) __attribute__((always_inline)) {
+                const int fr = w + 4 * i;
+                if (fr < NKB * NKS) {
+                    const int jb = fr / NKS;
+                    f32x8 f = {raw[2 * i][0], raw[2 * i][1], raw[2 * i][2], raw[2 * i][3],
+                               raw[2 * i + 1][0], raw[2 * i + 1][1], raw[2 * i + 1][2], raw[2 * i + 1][3]};
+                    u32x4 v = __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
+                    if (32 * jb + j >= P.k) v = u32x4{0u, 0u, 0u, 0u};
+                    lds_kp[fr * 64 + lane] = v;
                 }
-            }
-        }
-    };
+            });
+        };
 
-    // Kp_a -> LDS as bf16 MFMA fragments: each wave owns fragments w, w+4, ...  Phase 1 issues every global load of the
-    // wave back to back (one latency, not one per fragment; padded keys re-read the last row), phase 2 converts and
-    // stores (padded keys zeroed; their probabilities are forced to 0 through the -inf accumulator init anyway).
-    constexpr int NF = (NKB * NKS + 3) / 4;
-    auto kp_issue = [&](int a, f32x4(&raw)[2 * NF]) __attribute__((always_inline)) {
-        static_for<0, NF>([&](auto i) __attribute__((always_inline)) {
-            int fr = w + 4 * i;
-            if (fr > NKB * NKS - 1) fr = NKB * NKS - 1;
-            const int jb = fr / NKS, kb = fr - jb * NKS;
-            int key = 32 * jb + j;
-            if (key > P.k - 1) key = P.k - 1;
-            const float* src = P.kp + (int64_t)key * P.ldkp + a * DK + 16 * kb + 8 * hf;
-            raw[2 * i] = *reinterpret_cast<const f32x4*>(src);
-            raw[2 * i + 1] = *reinterpret_cast<const f32x4*>(src + 4);
-        });
-    };
-    auto kp_commit = [&](f32x4(&raw)[2 * NF]) __attribute__((always_inline)) {
-        static_for<0, NF>([&](auto i) __attribute__((always_inline)) {
-            const int fr = w + 4 * i;
-            if (fr < NKB * NKS) {
-                const int jb = fr / NKS;
-                f32x8 f = {raw[2 * i][0], raw[2 * i][1], raw[2 * i][2], raw[2 * i][3],
-                           raw[2 * i + 1][0], raw[2 * i + 1][1], raw[2 * i + 1][2], raw[2 * i + 1][3]};
-                u32x4 v = __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
-                if (32 * jb + j >= P.k) v = u32x4{0u, 0u, 0u, 0u};
-                lds_kp[fr * 64 + lane] = v;
-            }
-        });
-    };
-
-    // Prologue.  The cold-start latencies (kernarg, TLB, first HBM touch) are paid ONCE: the first tile's Q fragments and
-    // the first head's Kp rows are requested before anything else, the LDS / accumulator initialisation runs in their
-    // shadow, then Kp is converted into LDS.
-    int a = first_head, t = f_begin - first_head * P.tiles_per_head;   // (head, row tile) of the current work item
-    int cur_head = -1;
-    {
-        f32x4 raw0[2 * NF];
+        bf16x8 qf[NKS];  // Q fragments of the tile about to enter GEMM1
+        // Prologue.  The cold-start latencies (kernarg, TLB, first HBM touch) are paid ONCE: the first tile's Q fragments
+        // and the first head's Kp rows are requested before anything else.
         if (f_begin < f_end) {
+            f32x4 raw0[2 * NF];
             const QT* qp0 = q + q_off(a, t);
             static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) { qf[kb] = load_frag(qp0 + 16 * kb); });
             __builtin_amdgcn_sched_barrier(0);
             stamp_abs(56);
             kp_issue(a, raw0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        stamp_abs(58);
-        // pipeline fill: nothing pending -> P image and V fragments are zero, so the first interleaved GEMM2 adds 0
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        for (int i = threadIdx.x; i < TILE_ROWS * (RS + VRS) / 16; i += 256) reinterpret_cast<u32x4*>(lds_p)[i] = z;
-        stamp_abs(59);
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc_o[ti][r] = 0.f;
-        stamp_abs(57);
-        __builtin_amdgcn_sched_barrier(0);
-        if (f_begin < f_end) {
+            __builtin_amdgcn_sched_barrier(0);
+            stamp_abs(58);
             kp_commit(raw0);
-            cur_head = a;
         }
-        __syncthreads();
+        __syncthreads();   // K: the Kp image is complete
         stamp_abs(61);
-    }
-    bool published = false;      // a P image was written and its closing barrier has not been passed yet
-    for (int f = f_begin; f < f_end; ++f) {
-        const int row = t * TILE_ROWS + prow;   // this lane's query row
-        int an = a, tn = t + 1;   // next work item
-        if (tn == P.tiles_per_head) {
-            tn = 0;
-            an = a + 1;
-        }
-        if (a != cur_head) {
+        for (int f = f_begin; f < f_end; ++f) {
+            const int row = t * TILE_ROWS + prow;   // this lane's query row
+            int an = a, tn = t + 1;   // next work item
+            if (tn == P.tiles_per_head) {
+                tn = 0;
+                an = a + 1;
+            }
+            if (a != cur_head) {
+                // new head: every softmax wave passed A of the previous tile, so nobody reads the old Kp image any more
+                f32x4 raw[2 * NF];
+                kp_issue(a, raw);
+                __builtin_amdgcn_sched_barrier(0);   // do not let the conversions pull the loads apart
+                if (published) {
+                    __syncthreads();   // B: lets the pooling waves drain the previous head's last tile meanwhile
+                    published = false;
+                }
+                kp_commit(raw);
+                __syncthreads();   // K
+                cur_head = a;
+            }
+
+            stamp(0);
+            // ---- GEMM1 (swapped): S^T[key, row] = Kp Q^T.  A = Kp fragment (LDS), B = Q fragment: the C layout puts this
+            //      lane's ONE query row (column j) in registers -- 16 keys per block: key = 32 jb + (r&3) + 8 (r>>2) + 4 hf.
+            f32x16 s_acc[NKB];
+            {
+                // k-step outer, key block inner (m = kb * NKB + jb): consecutive MFMAs hit different accumulators, so there
+                // is no dependent-issue stall.  The asm MFMAs keep their program order, which lets a 4-deep ring of Kp
+                // fragments (16 VGPRs) stay exactly 4 MFMAs (~128 cycles) ahead of its consumer -- enough for the LDS latency.
+                constexpr int M1 = NKB * NKS;
+                constexpr int RING = 4;
+                bf16x8 kf[RING];
+                static_for<0, (M1 < RING ? M1 : RING)>([&](auto m_t) __attribute__((always_inline)) {
+                    constexpr int m = decltype(m_t)::value;
+                    kf[m] = __builtin_bit_cast(bf16x8, lds_kp[((m % NKB) * NKS + m / NKB) * 64 + lane]);
+                });
+                static_for<0, M1>([&](auto m_t) __attribute__((always_inline)) {
+                    constexpr int m = decltype(m_t)::value;
+                    constexpr int kb = m / NKB, jb = m % NKB;
+                    if constexpr (kb == 0) {
+                        // padded keys (only possible in the last two blocks, see make_plan) start at -inf: exp() gives 0.
+                        // The test is wave-uniform; a full block takes the zero-C form (no init moves at all).
+                        if (jb >= NKB - 2 && P.k < 32 * jb + 32) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                s_acc[jb][r] = (32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hf >= P.k) ? -INFINITY : 0.f;
+                            mfma_vgpr<true>(s_acc[jb], kf[m % RING], qf[kb]);
+                        } else {
+                            mfma_vgpr_zero_c(s_acc[jb], kf[m % RING], qf[kb]);   // C = inline constant 0
+                        }
+                    } else {
+                        mfma_vgpr<(NKB == 1) || std::is_same<QT, float>::value>(s_acc[jb], kf[m % RING], qf[kb]);
+                    }
+                    if constexpr (m + RING < M1) {
+                        constexpr int mn = m + RING;
+                        kf[m % RING] = __builtin_bit_cast(bf16x8, lds_kp[((mn % NKB) * NKS + mn / NKB) * 64 + lane]);
+                    }
+                });
+                // MFMA result -> VALU read hazard of the asm MFMAs above (the compiler does not see them as MFMAs): park
+                // for the full pipeline depth once per tile; the "+v" operands pin every later read of S behind this point
+                static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
+                    if constexpr (jb == 0)
+                        park_after_mfma(s_acc[jb]);
+                    else
+                        pin_vgpr(s_acc[jb]);
+                });
+            }
+            stamp(1);
             if (published) {
-                __syncthreads();   // P image of the pending tile is complete
+                __syncthreads();   // B: closes the previous publish -- from here the pooling waves run GEMM2(f-1)
                 published = false;
             }
-            if (cur_head >= 0) {  // drain the pending tile of the previous head, then flush its accumulators
-                gemm2_all();
-                flush(cur_head);
+            // next tile's Q: the fragment registers are free, the loads fly under the whole softmax
+            {
+                const bool has_next = f + 1 < f_end;
+                const QT* qnext = q + q_off(has_next ? an : a, has_next ? tn : t);
+                static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) { qf[kb] = load_frag(qnext + 16 * kb); });
             }
+
+            // ---- softmax over the keys of this lane's row: 16*NKB values in registers + the partner lane l ^ 32, fp32, IN
+            // PLACE in the S registers, two values per instruction wherever the ISA has a packed form (v_pk_fma / add / mul)
+            const bool rvalid = row < n32;
+            float mc, lrow = 0.f;
+            if constexpr (EXT) {
+                // key-chunked launch: the softmax runs over ALL chunks' keys -- combine their (max, sum) pairs
+                const float* st0 = P.stats + ((int64_t)a * P.n + (rvalid ? row : 0)) * 2;
+                const int64_t cs = (int64_t)P.h * P.n * 2;
+                float m = st0[0];
+                for (int c = 1; c < P.n_chunks; ++c) m = fmaxf(m, st0[c * cs]);
+                float l = 0.f;
+                for (int c = 0; c < P.n_chunks; ++c) l = fmaf(st0[c * cs + 1], __builtin_amdgcn_exp2f(st0[c * cs] - m), l);
+                mc = m;
+                lrow = l;
+            } else {
+                float mx0 = fmaxf(s_acc[0][0], s_acc[0][1]), mx1 = fmaxf(s_acc[0][2], s_acc[0][3]);
+                static_for<1, 4 * NKB>([&](auto st_t) __attribute__((always_inline)) {
+                    constexpr int st = decltype(st_t)::value;
+                    constexpr int jb = st / 4, r = 4 * (st % 4);
+                    mx0 = fmaxf(fmaxf(mx0, s_acc[jb][r]), s_acc[jb][r + 1]);
+                    mx1 = fmaxf(fmaxf(mx1, s_acc[jb][r + 2]), s_acc[jb][r + 3]);
+                });
+                mc = xhalf_max(fmaxf(mx0, mx1)) * c_exp;
+            }
+            {
+                const f32x2 c2 = {c_exp, c_exp}, nm2 = {-mc, -mc};
+                f32x2 l2 = {0.f, 0.f};
+                static_for<0, 8 * NKB>([&](auto e_t) __attribute__((always_inline)) {
+                    constexpr int e = decltype(e_t)::value;
+                    constexpr int jb = e / 8, pr = e % 8;
+                    const f32x2 sp = {s_acc[jb][2 * pr], s_acc[jb][2 * pr + 1]};
+                    const f32x2 ar = __builtin_elementwise_fma(sp, c2, nm2);
+                    const f32x2 ex = {__builtin_amdgcn_exp2f(ar[0]), __builtin_amdgcn_exp2f(ar[1])};
+                    l2 += ex;
+                    s_acc[jb][2 * pr] = ex[0];
+                    s_acc[jb][2 * pr + 1] = ex[1];
+                });
+                if constexpr (!EXT) lrow = xhalf_sum(l2[0] + l2[1]);
+            }
+            const float inv = rvalid ? __builtin_amdgcn_rcpf(lrow) : 0.f;
+            {
+                const f32x2 inv2 = {inv, inv};
+                static_for<0, 8 * NKB>([&](auto e_t) __attribute__((always_inline)) {
+                    constexpr int e = decltype(e_t)::value;
+                    constexpr int jb = e / 8, pr = e % 8;
+                    const f32x2 pp = f32x2{s_acc[jb][2 * pr], s_acc[jb][2 * pr + 1]} * inv2;
+                    s_acc[jb][2 * pr] = pp[0];
+                    s_acc[jb][2 * pr + 1] = pp[1];
+                });
+            }
+            if constexpr (AUX) {
+                // with the attention matrix / log-sum-exp outputs the normalised fp32 row is stored before it is converted
+                if (P.lse && rvalid && hf == 0) P.lse[(int64_t)a * P.n + row] = mc * 0.69314718055994530942f + __logf(lrow);
+                // attention matrix: this lane owns 4 consecutive keys per (block, c4) of ONE row -> 16-byte stores
+                if (P.attn && rvalid) {
+                    float* arow = P.attn + ((int64_t)a * P.n + row) * P.attn_ld + 4 * hf;
+                    // keys this lane may store, relative to its first one.  Opaque to the optimiser on purpose: the bound is
+                    // loop-invariant, and hoisting the 28..112 compare masks out of the tile loop spills ~240 SGPRs.
+                    int klim = P.k - 4 * hf;
+                    asm volatile("" : "+v"(klim));
+                    static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
+                        constexpr int jb = decltype(jb_t)::value;
+#pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4) {
+                            const f32x4 p4 = {s_acc[jb][4 * c4], s_acc[jb][4 * c4 + 1], s_acc[jb][4 * c4 + 2],
+                                              s_acc[jb][4 * c4 + 3]};
+                            constexpr int kb0 = 32 * jb;
+                            const int key0 = kb0 + 8 * c4;
+                            float* dst = arow + key0;
+                            if (attn_vec) {
+                                if (key0 < klim) *reinterpret_cast<f32x4*>(dst) = p4;
+                            } else {
+                                if (key0 < klim) dst[0] = p4[0];
+                                if (key0 + 1 < klim) dst[1] = p4[1];
+                                if (key0 + 2 < klim) dst[2] = p4[2];
+                                if (key0 + 3 < klim) dst[3] = p4[3];
+                            }
+                        }
+                    });
+                }
+            }
+            u32x2 pk[NKB][4];
+            static_for<0, 4 * NKB>([&](auto u_t) __attribute__((always_inline)) {
+                constexpr int u = decltype(u_t)::value;
+                constexpr int jb = u / 4, c4 = u % 4;
+                const f32x2 p01 = {s_acc[jb][4 * c4], s_acc[jb][4 * c4 + 1]}, p23 = {s_acc[jb][4 * c4 + 2], s_acc[jb][4 * c4 + 3]};
+                pk[jb][c4] = u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(p01, bf16x2)),
+                                   __builtin_bit_cast(unsigned, __builtin_convertvector(p23, bf16x2))};
+                asm volatile("" : "+v"(pk[jb][c4]));   // keep the conversion in front of the barrier, not behind it
+            });
+            stamp(2);
+
+            // ---- publish P (bf16, row-major image)
+            __syncthreads();  // A: every pooling wave finished the GEMM2 reads of the previous images
+            stamp(3);
+            static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
+                constexpr int jb = decltype(jb_t)::value;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) *reinterpret_cast<u32x2*>(lds_p + waddr[c4] + jb * 64) = pk[jb][c4];
+            });
+            published = true;
+            stamp(4);
+            ++trace_it;
+            a = an;
+            t = tn;
+        }
+        stamp_abs(62);
+        if (published) __syncthreads();   // B of the last tile
+    } else {
+        // =========================================== pooling waves ===========================================
+        const QT* __restrict__ vg = reinterpret_cast<const QT*>(P.v);
+        const int cb = (NCB == 4) ? w : (w & (NCB - 1));
+        // reader of the P image (GEMM2 A operand): lane = group g (16 lanes) x i; rows 8*(g>>1) + 4*s + (i>>2), chunk
+        // 4*(g&1) + (i&3)
+        const int rg = lane >> 4, ri = lane & 15;
+        const int rr0 = 8 * (rg >> 1) + (ri >> 2), rr1 = rr0 + 4;
+        const int rch = 4 * (rg & 1) + (ri & 3);
+        // key block of output tile ti of this wave = ti * (4 / NCB) + w / NCB: the wave-dependent part goes into the base
+        const unsigned char* rbase0 = lds_p + rr0 * RS + 8 * (rch ^ ((rr0 >> 1) & 7)) + 64 * (w / NCB);
+        const unsigned char* rbase1 = lds_p + rr1 * RS + 8 * (rch ^ ((rr1 >> 1) & 7)) + 64 * (w / NCB);
+
+        // ---- V image.  V arrives ROW-major (it comes out of the same GEMM as Q): each pooling wave fetches 32 rows of the
+        // tile with fully coalesced 16-byte loads (one row = DK/8 chunks of 8 columns), parks them in registers until the
+        // images are free and stores them next to the P image; GEMM2 reads its B fragments (column on the lane, 8
+        // consecutive rows in registers) back with the same hardware transpose-read as P.  Row pitch = 2*DK bytes, no
+        // padding: chunk c of row r sits at chunk position (c + 4 rot(r)) mod NCH, which spreads the 4 rows x 64 bytes of a
+        // transpose-read group over all 64 banks (rot = r & 3 for DK = 128, (r >> 1) & 1 for DK = 64: rows of 128 bytes
+        // already alternate halves).
+        constexpr int VRS = 2 * DK, NCH = DK / 8;     // row pitch (bytes), 16-byte chunks per row
+        constexpr int RPI = 64 / NCH, NVI = 32 / RPI; // rows per load instruction, load instructions per wave and tile
+        auto vrot = [](int r) __attribute__((always_inline)) -> int { return DK == 128 ? (r & 3) : ((r >> 1) & 1); };
+        const int vl_row = lane / NCH, vl_ch = lane % NCH;          // loader: row inside the instruction, chunk
+        const int vwaddr = (32 * w + vl_row) * VRS + 16 * ((vl_ch + 4 * vrot(vl_row)) & (NCH - 1));   // + i * RPI * VRS
+        const int vr0 = 8 * (rg >> 1) + (ri >> 2), vr1 = vr0 + 4;   // reader: rows of the two transpose-reads
+        const int vrc = 4 * cb + 2 * (rg & 1) + ((ri & 3) >> 1);     // chunk of this lane's 4 columns, + 8 * (ri & 1) bytes
+        const unsigned char* vbase0 = lds_v + vr0 * VRS + 16 * ((vrc + 4 * vrot(vr0)) & (NCH - 1)) + 8 * (ri & 1);
+        const unsigned char* vbase1 = lds_v + vr1 * VRS + 16 * ((vrc + 4 * vrot(vr1)) & (NCH - 1)) + 8 * (ri & 1);
+        const int ldv32 = (int)P.ldv;
+        auto v_off = [&](int a_, int t_, int i) __attribute__((always_inline)) -> unsigned {
+            int vrow = t_ * TILE_ROWS + 32 * w + RPI * i + vl_row;
+            if (vrow > n32 - 1) vrow = n32 - 1;
+            return __umul24((unsigned)vrow, (unsigned)ldv32) + (a_ * DK + 8 * vl_ch);
+        };
+
+        f32x16 acc_o[NT];
+        bf16x8 vld[NVI];  // this wave's 32 rows of V(f), in flight / parked until the images are free
+        bf16x8 vfr[2];    // B fragments of the current and the next GEMM2 k-step (read one k-step ahead)
+        // GEMM2 of the pending tile, MFMA m = sk * NT + ti  (sk = 16-row k-step of the tile, ti = output tile of the wave):
+        // A = P^T fragment (key on the lane, 8 rows in registers), B = V fragment, both by transpose-read.  The P fragment of
+        // MFMA m + 3 is requested before MFMA m issues (4-slot ring), the V fragment one whole k-step ahead.
+        bf16x8 pfr[4];
+        auto p_read = [&](auto m_tag) __attribute__((always_inline)) {
+            constexpr int m = decltype(m_tag)::value;
+            if constexpr (m < M2) {
+                constexpr int sk = m / NT, ti = m % NT;
+                constexpr int off = sk * 16 * RS + ti * (4 / NCB) * 64;
+                pfr[m % 4] = lds_read_p_frag(rbase0 + off, rbase1 + off);
+            }
+        };
+        auto gemm2_one = [&](auto m_tag) __attribute__((always_inline)) {
+            constexpr int m = decltype(m_tag)::value;
+            constexpr int sk = m / NT, ti = m % NT;
+            const int t_idx = w + 4 * ti;  // tile = kb * NCB + cb ; cb == t_idx % NCB is constant per wave
+            if constexpr (m == 0) {
+                vfr[0] = lds_read_p_frag(vbase0, vbase1);
+                p_read(std::integral_constant<int, 0>{});
+                p_read(std::integral_constant<int, 1>{});
+                p_read(std::integral_constant<int, 2>{});
+            }
+            p_read(std::integral_constant<int, m + 3>{});
+            if constexpr (ti == 0 && sk + 1 < 8)
+                vfr[(sk + 1) & 1] = lds_read_p_frag(vbase0 + (sk + 1) * 16 * VRS, vbase1 + (sk + 1) * 16 * VRS);
+            if (NT * 4 == NKB * NCB || t_idx < NKB * NCB)
+                acc_o[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pfr[m % 4], vfr[sk & 1], acc_o[ti], 0, 0, 0);
+        };
+        auto gemm2_all = [&]() __attribute__((always_inline)) {
+            static_for<0, M2>([&](auto m_tag) __attribute__((always_inline)) {
+                gemm2_one(m_tag);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        auto flush = [&](int head) __attribute__((always_inline)) {
+            const int seg = head - first_head;
+            float* dst = P.partial + ((int64_t)blockIdx.x * P.seg_count + seg) * (int64_t)(NKB * NCB) * 1024;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) {
+                const int t_idx = w + 4 * ti;
+                if (t_idx < NKB * NCB) {
+                    const int key0 = 32 * (t_idx / NCB);
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        // registers 4 q4 .. 4 q4 + 3 hold keys key0 + 8 q4 + 4 hf + i: skip the quads that are padding only
+                        if (key0 + 8 * q4 < P.k) {
+                            f32x4 v = {acc_o[ti][q4 * 4], acc_o[ti][q4 * 4 + 1], acc_o[ti][q4 * 4 + 2], acc_o[ti][q4 * 4 + 3]};
+                            *reinterpret_cast<f32x4*>(dst + ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4) = v;
+                        }
+                    }
+                }
+            }
+        };
+        auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc_o[ti][r] = 0.f;
-            __syncthreads();  // everyone finished reading the previous head's Kp and the drained P / V images
-            {
-                // nothing is pending any more: the interleaved GEMM2 of the next step must add zero
-                const u32x4 z = {0u, 0u, 0u, 0u};
-                for (int i = threadIdx.x; i < TILE_ROWS * VRS / 16; i += 256) reinterpret_cast<u32x4*>(lds_v)[i] = z;
-                f32x4 raw[2 * NF];
-                kp_issue(a, raw);
-                __builtin_amdgcn_sched_barrier(0);   // do not let the conversions pull the loads apart
-                kp_commit(raw);
-            }
-            __syncthreads();
-            cur_head = a;
-        }
-
-        stamp(0);
-        // ---- GEMM1 (swapped): S^T[key, row] = Kp Q^T.  A = Kp fragment (LDS), B = Q fragment: the C layout puts this
-        //      lane's ONE query row (column j) in registers -- 16 keys per block: key = 32 jb + (r&3) + 8 (r>>2) + 4 hf.
-        f32x16 s_acc[NKB];
-        {
-            // k-step outer, key block inner (m = kb * NKB + jb): consecutive MFMAs hit different accumulators, so there is
-            // no dependent-issue stall.  The asm MFMAs keep their program order, which lets a 4-deep ring of Kp fragments
-            // (16 VGPRs) stay exactly 4 MFMAs (~128 cycles) ahead of its consumer -- enough to cover the LDS latency.
-            constexpr int M1 = NKB * NKS;
-            constexpr int RING = 4;
-            bf16x8 kf[RING];
-            static_for<0, (M1 < RING ? M1 : RING)>([&](auto m_t) __attribute__((always_inline)) {
-                constexpr int m = decltype(m_t)::value;
-                kf[m] = __builtin_bit_cast(bf16x8, lds_kp[((m % NKB) * NKS + m / NKB) * 64 + lane]);
-            });
-            static_for<0, M1>([&](auto m_t) __attribute__((always_inline)) {
-                constexpr int m = decltype(m_t)::value;
-                constexpr int kb = m / NKB, jb = m % NKB;
-                if constexpr (kb == 0) {
-                    // padded keys (only possible in the last two blocks, see make_plan) start at -inf: exp() gives 0.
-                    // The test is wave-uniform; a full block takes the zero-C form (no init moves at all).
-                    if (jb >= NKB - 2 && P.k < 32 * jb + 32) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            s_acc[jb][r] = (32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hf >= P.k) ? -INFINITY : 0.f;
-                        mfma_vgpr<true>(s_acc[jb], kf[m % RING], qf[kb]);
-                    } else {
-                        mfma_vgpr_zero_c(s_acc[jb], kf[m % RING], qf[kb]);   // C = inline constant 0
-                    }
-                } else {
-                    mfma_vgpr<(NKB == 1) || std::is_same<QT, float>::value>(s_acc[jb], kf[m % RING], qf[kb]);
-                }
-                if constexpr (m + RING < M1) {
-                    constexpr int mn = m + RING;
-                    kf[m % RING] = __builtin_bit_cast(bf16x8, lds_kp[((mn % NKB) * NKS + mn / NKB) * 64 + lane]);
-                }
-            });
-            // MFMA result -> VALU read hazard of the asm MFMAs above (the compiler does not see them as MFMAs): park for
-            // the full pipeline depth once per tile; the "+v" operands pin every later read of S behind this point
-            static_for<0, NKB>([&](auto jb) __attribute__((always_inline)) {
-                if constexpr (jb == 0)
-                    park_after_mfma(s_acc[jb]);
-                else
-                    pin_vgpr(s_acc[jb]);
-            });
-        }
-        stamp(1);
-        if (published) {
-            __syncthreads();   // closes the previous publish: placed AFTER GEMM1 so that the matrix work of this tile
-            published = false; // overlaps the other waves' LDS writes
-        }
-        const bool has_next = f + 1 < f_end;
-        const QT* qnext = q + q_off(has_next ? an : a, has_next ? tn : t);
-
-        // ---- Phase 2: softmax over the keys of this lane's row (16*NKB values in registers + the partner lane l ^ 32,
-        // fp32) with the GEMM2 of the pending tile underneath.  Issue order is pinned slot by slot (one MFMA, its LDS
-        // prefetches, one HBM load, a chunk of softmax steps): left alone, the scheduler requests every P fragment right
-        // before its MFMA and the wave parks on lgkmcnt(0) 56 times per tile.
-        //   steps: 4 NKB max steps | finish max | 8 NKB exp steps (a register pair each) | row sum | 4 NKB normalise+convert
-        constexpr int S_FIN = 4 * NKB, S_EXP0 = S_FIN + 1, S_SUM = S_EXP0 + 8 * NKB, S_NRM0 = S_SUM + 1;
-        constexpr int S_END = S_NRM0 + 4 * NKB;
-        float mx0 = 0.f, mx1 = 0.f, mc = 0.f, l0 = 0.f, l1 = 0.f, lrow = 0.f, inv = 0.f;
-        const bool rvalid = row < n32;
-        f32x2 ev[NKB][8];   // exp values as register PAIRS: the normalisation is one v_pk_mul_f32 + one v_cvt_pk per pair
-        u32x2 pk[NKB][4];
-        auto p2_step = [&](auto st_t) __attribute__((always_inline)) {
-            constexpr int st = decltype(st_t)::value;
-            if constexpr (st < S_FIN) {
-                constexpr int jb = st / 4, r = 4 * (st % 4);
-                if constexpr (EXT) {
-                } else if constexpr (st == 0) {
-                    mx0 = fmaxf(s_acc[0][0], s_acc[0][1]);
-                    mx1 = fmaxf(s_acc[0][2], s_acc[0][3]);
-                } else {
-                    mx0 = fmaxf(fmaxf(mx0, s_acc[jb][r]), s_acc[jb][r + 1]);
-                    mx1 = fmaxf(fmaxf(mx1, s_acc[jb][r + 2]), s_acc[jb][r + 3]);
-                }
-            } else if constexpr (st == S_FIN) {
-                if constexpr (EXT) {
-                    // key-chunked launch: the softmax runs over ALL chunks' keys -- combine their (max, sum) pairs
-                    const float* st0 = P.stats + ((int64_t)a * P.n + (rvalid ? row : 0)) * 2;
-                    const int64_t cs = (int64_t)P.h * P.n * 2;
-                    float m = st0[0];
-                    for (int c = 1; c < P.n_chunks; ++c) m = fmaxf(m, st0[c * cs]);
-                    float l = 0.f;
-                    for (int c = 0; c < P.n_chunks; ++c) l = fmaf(st0[c * cs + 1], __builtin_amdgcn_exp2f(st0[c * cs] - m), l);
-                    mc = m;
-                    lrow = l;
-                } else {
-                    mc = xhalf_max(fmaxf(mx0, mx1)) * c_exp;
-                }
-            } else if constexpr (st < S_SUM) {
-                constexpr int e = st - S_EXP0, jb = e / 8, pr = e % 8;
-                const float e0 = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][2 * pr], c_exp, -mc));
-                const float e1 = __builtin_amdgcn_exp2f(fmaf(s_acc[jb][2 * pr + 1], c_exp, -mc));
-                ev[jb][pr] = f32x2{e0, e1};
-                l0 += e0;
-                l1 += e1;
-            } else if constexpr (st == S_SUM) {
-                if constexpr (!EXT) lrow = xhalf_sum(l0 + l1);
-                inv = rvalid ? __builtin_amdgcn_rcpf(lrow) : 0.f;
-            } else {
-                constexpr int u = st - S_NRM0, jb = u / 4, c4 = u % 4;
-                const f32x2 p01 = ev[jb][2 * c4] * inv, p23 = ev[jb][2 * c4 + 1] * inv;
-                pk[jb][c4] = u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(p01, bf16x2)),
-                                   __builtin_bit_cast(unsigned, __builtin_convertvector(p23, bf16x2))};
-                asm volatile("" : "+v"(pk[jb][c4]));   // keep the conversion under the MFMAs, not behind the barrier
-            }
         };
-        constexpr int S_MFMA = AUX ? S_NRM0 : S_END;   // steps that run under the MFMAs
-        static_for<0, M2>([&](auto m_t) __attribute__((always_inline)) {
-            constexpr int m = decltype(m_t)::value;
-            gemm2_one(m_t);
-            if constexpr (m < NKS) qf[m] = load_frag(qnext + 16 * m);
-            if constexpr (m >= NKS && m < NKS + NVI) vld[m - NKS] = load_frag(vg + v_off(a, t, m - NKS));
-            static_for<(m * S_MFMA) / M2, ((m + 1) * S_MFMA) / M2>([&](auto st_t) __attribute__((always_inline)) { p2_step(st_t); });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        if constexpr (AUX) {
-            // with the attention matrix / log-sum-exp outputs the normalised fp32 row is stored before it is converted
-            if (P.lse && rvalid && hf == 0) P.lse[(int64_t)a * P.n + row] = mc * 0.69314718055994530942f + __logf(lrow);
-            // attention matrix: this lane owns 4 consecutive keys per (block, c4) of ONE row -> 16-byte stores
-            if (P.attn && rvalid) {
-                float* arow = P.attn + ((int64_t)a * P.n + row) * P.attn_ld + 4 * hf;
-                // keys this lane may store, relative to its first one.  Opaque to the optimiser on purpose: the bound is
-                // loop-invariant, and hoisting the 28..112 compare masks out of the tile loop spills ~240 SGPRs.
-                int klim = P.k - 4 * hf;
-                asm volatile("" : "+v"(klim));
-                static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
-                    constexpr int jb = decltype(jb_t)::value;
-#pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        const f32x2 p01 = ev[jb][2 * c4] * inv, p23 = ev[jb][2 * c4 + 1] * inv;
-                        constexpr int kb0 = 32 * jb;
-                        const int key0 = kb0 + 8 * c4;
-                        float* dst = arow + key0;
-                        if (attn_vec) {
-                            if (key0 < klim) *reinterpret_cast<f32x4*>(dst) = f32x4{p01[0], p01[1], p23[0], p23[1]};
-                        } else {
-                            if (key0 < klim) dst[0] = p01[0];
-                            if (key0 + 1 < klim) dst[1] = p01[1];
-                            if (key0 + 2 < klim) dst[2] = p23[0];
-                            if (key0 + 3 < klim) dst[3] = p23[1];
-                        }
-                    }
-                });
-            }
-            static_for<S_NRM0, S_END>([&](auto st_t) __attribute__((always_inline)) { p2_step(st_t); });
-        }
-        stamp(2);
 
-        // ---- publish P (bf16, row-major image) and this wave's rows of V for the 4 waves
-        __syncthreads();  // every wave finished the GEMM2 reads of the previous image
-        stamp(3);
-        static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
-            constexpr int jb = decltype(jb_t)::value;
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) *reinterpret_cast<u32x2*>(lds_p + waddr[c4] + jb * 64) = pk[jb][c4];
-        });
-        static_for<0, NVI>([&](auto i_t) __attribute__((always_inline)) {
-            constexpr int i = decltype(i_t)::value;
-            *reinterpret_cast<u32x4*>(lds_v + vwaddr + i * RPI * VRS) = __builtin_bit_cast(u32x4, vld[i]);
-        });
-        published = true;
-        stamp(4);
-        ++trace_it;
-        a = an;
-        t = tn;
+        zero_acc();
+        __syncthreads();   // K (prologue)
+        for (int f = f_begin; f < f_end; ++f) {
+            int an = a, tn = t + 1;
+            if (tn == P.tiles_per_head) {
+                tn = 0;
+                an = a + 1;
+            }
+            // V(f): the registers are free (V(f-1) went into the image before B), the loads fly under GEMM2(f-1)
+            static_for<0, NVI>([&](auto i_t) __attribute__((always_inline)) {
+                constexpr int i = decltype(i_t)::value;
+                vld[i] = load_frag(vg + v_off(a, t, i));
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            if (published) {
+                __syncthreads();   // B: P(f-1) and V(f-1) are complete
+                published = false;
+                stamp(5);
+                gemm2_all();
+                stamp(6);
+            }
+            if (a != cur_head) {   // the tile just accumulated was the last one of its head
+                flush(cur_head);
+                zero_acc();
+                __syncthreads();   // K (the softmax waves replaced the Kp image)
+                cur_head = a;
+            }
+            __syncthreads();   // A: the images are free (all GEMM2 reads done, softmax(f) computed)
+            static_for<0, NVI>([&](auto i_t) __attribute__((always_inline)) {
+                constexpr int i = decltype(i_t)::value;
+                *reinterpret_cast<u32x4*>(lds_v + vwaddr + i * RPI * VRS) = __builtin_bit_cast(u32x4, vld[i]);
+            });
+            published = true;
+            stamp(7);
+            ++trace_it;
+            a = an;
+            t = tn;
+        }
+        if (published) {
+            __syncthreads();   // B of the last tile
+            gemm2_all();
+        }
+        if (cur_head >= 0) flush(cur_head);
+        stamp_abs(63);
     }
-    stamp_abs(62);
-    if (published) __syncthreads();
-    if (cur_head >= 0) {
-        gemm2_all();  // drain the last pending tile
-        flush(cur_head);
-    }
-    stamp_abs(63);
 }
 
 
@@ -781,7 +812,7 @@ int launch_variant(const AttnParams& P, const Plan& pl, float* out, hipStream_t 
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(pl.num_wg), dim3(256), lds, s, P);
+    hipLaunchKernelGGL(kern, dim3(pl.num_wg), dim3(512), lds, s, P);
     int rc = snf::check_launch("sparse_attn_mfma_kernel");
     if (rc) return rc;
     constexpr int TILES = NKB * (DK / 32);
