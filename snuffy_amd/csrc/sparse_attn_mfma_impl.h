@@ -197,7 +197,8 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
     const int j = lane & 31, hf = lane >> 5;
     const int n32 = (int)P.n;
     int trace_it = 0;
-    // debug trace (tools/attn_trace.py): phases 0..4 are stamped by the softmax waves, 5..7 by the pooling waves
+    // debug trace (tools/attn_trace.py): phases 0..4 are stamped by the softmax waves (step start, GEMM1 done, B passed,
+    // softmax done, A passed), 5..7 by the pooling waves (B passed, GEMM2 done, A passed)
     auto stamp = [&](int phase) __attribute__((always_inline)) {
         if (P.trace && blockIdx.x == 0 && lane == 0)
             P.trace[(trace_it * 8 + phase) * 4 + w] = __builtin_amdgcn_s_memtime();
@@ -221,6 +222,8 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
     if (w8 < 4) {
         // =========================================== softmax waves ===========================================
         stamp_abs(60);
+        // the softmax waves are the critical path of every step: they win every issue arbitration against their SIMD partner
+        __builtin_amdgcn_s_setprio(3);
         const QT* __restrict__ q = reinterpret_cast<const QT*>(P.q);
         const float c_exp = P.scale * 1.44269504088896340736f;
         const bool attn_vec = AUX && (P.attn_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(P.attn) & 15) == 0;
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
                 __syncthreads();   // B: closes the previous publish -- from here the pooling waves run GEMM2(f-1)
                 published = false;
             }
+            stamp(2);
             // next tile's Q: the fragment registers are free, the loads fly under the whole softmax
             {
                 const bool has_next = f + 1 < f_end;
@@ -408,68 +412,51 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
                 if constexpr (!EXT) lrow = xhalf_sum(l2[0] + l2[1]);
             }
             const float inv = rvalid ? __builtin_amdgcn_rcpf(lrow) : 0.f;
-            {
-                const f32x2 inv2 = {inv, inv};
-                static_for<0, 8 * NKB>([&](auto e_t) __attribute__((always_inline)) {
-                    constexpr int e = decltype(e_t)::value;
-                    constexpr int jb = e / 8, pr = e % 8;
-                    const f32x2 pp = f32x2{s_acc[jb][2 * pr], s_acc[jb][2 * pr + 1]} * inv2;
-                    s_acc[jb][2 * pr] = pp[0];
-                    s_acc[jb][2 * pr + 1] = pp[1];
-                });
-            }
-            if constexpr (AUX) {
-                // with the attention matrix / log-sum-exp outputs the normalised fp32 row is stored before it is converted
+            if constexpr (AUX)
                 if (P.lse && rvalid && hf == 0) P.lse[(int64_t)a * P.n + row] = mc * 0.69314718055994530942f + __logf(lrow);
-                // attention matrix: this lane owns 4 consecutive keys per (block, c4) of ONE row -> 16-byte stores
-                if (P.attn && rvalid) {
-                    float* arow = P.attn + ((int64_t)a * P.n + row) * P.attn_ld + 4 * hf;
-                    // keys this lane may store, relative to its first one.  Opaque to the optimiser on purpose: the bound is
-                    // loop-invariant, and hoisting the 28..112 compare masks out of the tile loop spills ~240 SGPRs.
-                    int klim = P.k - 4 * hf;
-                    asm volatile("" : "+v"(klim));
-                    static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
-                        constexpr int jb = decltype(jb_t)::value;
-#pragma unroll
-                        for (int c4 = 0; c4 < 4; ++c4) {
-                            const f32x4 p4 = {s_acc[jb][4 * c4], s_acc[jb][4 * c4 + 1], s_acc[jb][4 * c4 + 2],
-                                              s_acc[jb][4 * c4 + 3]};
-                            constexpr int kb0 = 32 * jb;
-                            const int key0 = kb0 + 8 * c4;
-                            float* dst = arow + key0;
-                            if (attn_vec) {
-                                if (key0 < klim) *reinterpret_cast<f32x4*>(dst) = p4;
-                            } else {
-                                if (key0 < klim) dst[0] = p4[0];
-                                if (key0 + 1 < klim) dst[1] = p4[1];
-                                if (key0 + 2 < klim) dst[2] = p4[2];
-                                if (key0 + 3 < klim) dst[3] = p4[3];
-                            }
-                        }
-                    });
-                }
-            }
-            u32x2 pk[NKB][4];
-            static_for<0, 4 * NKB>([&](auto u_t) __attribute__((always_inline)) {
-                constexpr int u = decltype(u_t)::value;
-                constexpr int jb = u / 4, c4 = u % 4;
-                const f32x2 p01 = {s_acc[jb][4 * c4], s_acc[jb][4 * c4 + 1]}, p23 = {s_acc[jb][4 * c4 + 2], s_acc[jb][4 * c4 + 3]};
-                pk[jb][c4] = u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(p01, bf16x2)),
-                                   __builtin_bit_cast(unsigned, __builtin_convertvector(p23, bf16x2))};
-                asm volatile("" : "+v"(pk[jb][c4]));   // keep the conversion in front of the barrier, not behind it
-            });
-            stamp(2);
-
-            // ---- publish P (bf16, row-major image)
-            __syncthreads();  // A: every pooling wave finished the GEMM2 reads of the previous images
             stamp(3);
+
+            // ---- A: every pooling wave finished the GEMM2 reads of the previous images (they got there long ago: GEMM2 is
+            // shorter than the passes above).  Normalise, convert and publish P block by block: the LDS stores drain under
+            // the VALU work of the next block instead of in a store-only tail.
+            __syncthreads();
+            stamp(4);
+            float* arow = nullptr;
+            int klim = 0;
+            if constexpr (AUX) {
+                // attention matrix: this lane owns 4 consecutive keys per (block, c4) of ONE row -> 16-byte stores
+                arow = P.attn + ((int64_t)a * P.n + row) * P.attn_ld + 4 * hf;
+                // keys this lane may store, relative to its first one.  Opaque to the optimiser on purpose: the bound is
+                // loop-invariant, and hoisting the 28..112 compare masks out of the tile loop spills ~240 SGPRs.
+                klim = (P.attn && rvalid) ? P.k - 4 * hf : 0;
+                asm volatile("" : "+v"(klim));
+            }
+            const f32x2 inv2 = {inv, inv};
             static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
                 constexpr int jb = decltype(jb_t)::value;
 #pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) *reinterpret_cast<u32x2*>(lds_p + waddr[c4] + jb * 64) = pk[jb][c4];
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const f32x2 p01 = f32x2{s_acc[jb][4 * c4], s_acc[jb][4 * c4 + 1]} * inv2;
+                    const f32x2 p23 = f32x2{s_acc[jb][4 * c4 + 2], s_acc[jb][4 * c4 + 3]} * inv2;
+                    if constexpr (AUX) {
+                        // the normalised fp32 row is stored before it is converted
+                        const int key0 = 32 * jb + 8 * c4;
+                        float* dst = arow + key0;
+                        if (attn_vec) {
+                            if (key0 < klim) *reinterpret_cast<f32x4*>(dst) = f32x4{p01[0], p01[1], p23[0], p23[1]};
+                        } else {
+                            if (key0 < klim) dst[0] = p01[0];
+                            if (key0 + 1 < klim) dst[1] = p01[1];
+                            if (key0 + 2 < klim) dst[2] = p23[0];
+                            if (key0 + 3 < klim) dst[3] = p23[1];
+                        }
+                    }
+                    const u32x2 pk = {__builtin_bit_cast(unsigned, __builtin_convertvector(p01, bf16x2)),
+                                      __builtin_bit_cast(unsigned, __builtin_convertvector(p23, bf16x2))};
+                    *reinterpret_cast<u32x2*>(lds_p + waddr[c4] + jb * 64) = pk;
+                }
             });
             published = true;
-            stamp(4);
             ++trace_it;
             a = an;
             t = tn;
@@ -603,12 +590,12 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
                 cur_head = a;
             }
             __syncthreads();   // A: the images are free (all GEMM2 reads done, softmax(f) computed)
+            stamp(7);
             static_for<0, NVI>([&](auto i_t) __attribute__((always_inline)) {
                 constexpr int i = decltype(i_t)::value;
                 *reinterpret_cast<u32x4*>(lds_v + vwaddr + i * RPI * VRS) = __builtin_bit_cast(u32x4, vld[i]);
             });
             published = true;
-            stamp(7);
             ++trace_it;
             a = an;
             t = tn;
@@ -824,6 +811,12 @@ int launch_variant(const AttnParams& P, const Plan& pl, float* out, hipStream_t 
 #define SNF_ATTN_CASE(NB, EXT)                                                                     \
     case NB:                                                                                       \
         return aux ? launch_variant<DK, NB, QT, true, EXT>(P, pl, out, s) : launch_variant<DK, NB, QT, false, EXT>(P, pl, out, s);
+// 8 key blocks (256 keys) only exist for dk = 64: with dk = 128 the three LDS images hold 224 keys at most
+#define SNF_ATTN_CASE8(EXT)                                                                        \
+    case 8:                                                                                        \
+        if constexpr (DK == 64)                                                                    \
+            return aux ? launch_variant<DK, 8, QT, true, EXT>(P, pl, out, s) : launch_variant<DK, 8, QT, false, EXT>(P, pl, out, s); \
+        break;
 template <int DK, typename QT>
 int launch_nkb(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
     const bool aux = P.attn != nullptr || P.lse != nullptr;
@@ -832,11 +825,13 @@ int launch_nkb(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
 #ifndef SNF_ATTN_DEV
             SNF_ATTN_CASE(4, true)
             SNF_ATTN_CASE(6, true)
-            SNF_ATTN_CASE(8, true)
+            SNF_ATTN_CASE8(true)
 #endif
             SNF_ATTN_CASE(7, true)
-            default: snf::set_error("sparse_attn_mfma: chunked key-block count %d not built", pl.nkb); return SNF_EUNSUPPORTED;
+            default: break;
         }
+        snf::set_error("sparse_attn_mfma: chunked key-block count %d not built", pl.nkb);
+        return SNF_EUNSUPPORTED;
     }
     switch (pl.nkb) {
 #ifndef SNF_ATTN_DEV   // development builds instantiate the config-B shape only (the file takes minutes otherwise)
@@ -844,13 +839,16 @@ int launch_nkb(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
         SNF_ATTN_CASE(2, false)
         SNF_ATTN_CASE(4, false)
         SNF_ATTN_CASE(6, false)
-        SNF_ATTN_CASE(8, false)
+        SNF_ATTN_CASE8(false)
 #endif
         SNF_ATTN_CASE(7, false)
-        default: snf::set_error("sparse_attn_mfma: key-block count %d not built", pl.nkb); return SNF_EUNSUPPORTED;
+        default: break;
     }
+    snf::set_error("sparse_attn_mfma: key-block count %d not built", pl.nkb);
+    return SNF_EUNSUPPORTED;
 }
 #undef SNF_ATTN_CASE
+#undef SNF_ATTN_CASE8
 
 inline size_t mfma_workspace_bytes(const Plan& pl, int dk) {
     return (size_t)pl.num_wg * pl.seg_count * (size_t)(pl.nkb * (dk / 32)) * 1024 * sizeof(float);
@@ -868,11 +866,15 @@ int launch_stats(const AttnParams& P, const Plan& pl, hipStream_t s) {
 #ifndef SNF_ATTN_DEV
         case 4: return launch_stats_variant<DK, 4, QT>(P, pl, s);
         case 6: return launch_stats_variant<DK, 6, QT>(P, pl, s);
-        case 8: return launch_stats_variant<DK, 8, QT>(P, pl, s);
+        case 8:
+            if constexpr (DK == 64) return launch_stats_variant<DK, 8, QT>(P, pl, s);
+            break;
 #endif
         case 7: return launch_stats_variant<DK, 7, QT>(P, pl, s);
-        default: snf::set_error("sparse_attn_stats: key-block count %d not built", pl.nkb); return SNF_EUNSUPPORTED;
+        default: break;
     }
+    snf::set_error("sparse_attn_stats: key-block count %d not built", pl.nkb);
+    return SNF_EUNSUPPORTED;
 }
 
 // Key chunking: one launch holds at most KMAX keys (Kp + P + V images in 160 KiB of LDS).  More keys are split into

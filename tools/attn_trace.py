@@ -26,12 +26,12 @@ ops.sparse_attn_fwd_mfma(q, vt, kp, N, h)
 torch.cuda.synchronize()
 lib.snf_debug_attn_trace(None)
 t = buf.cpu().view(64, 8, 4)
-pm = [int(t[sl, 0, 0]) for sl in (60, 56, 58, 59, 57, 61)]
-print("prologue detail: entry -> Q loads issued %d | Kp loads issued %d | P image zeroed %d | accumulators zeroed %d | "
-      "Kp landed, converted, stored, barrier %d" % tuple(pm[i + 1] - pm[i] for i in range(5)))
-ms = [int(t[sl, 0, 0]) for sl in (60, 61, 62, 63)]
-print("kernel milestones (wave 0, s_memtime ticks): prologue(Kp->LDS) %d | main loop %d | drain+flush %d | total %d"
-      % (ms[1] - ms[0], ms[2] - ms[1], ms[3] - ms[2], ms[3] - ms[0]))
+pm = [int(t[sl, 0, 0]) for sl in (60, 56, 58, 61)]
+print("prologue detail (softmax wave 0): entry -> Q loads issued %d | Kp loads issued %d | Kp landed, converted, stored, "
+      "barrier %d" % tuple(pm[i + 1] - pm[i] for i in range(3)))
+ms = [int(t[60, 0, 0]), int(t[61, 0, 0]), int(t[62, 0, 0]), int(t[63, 0, 0])]
+print("kernel milestones (s_memtime ticks): prologue(Kp->LDS) %d | main loop %d | last GEMM2 + flush (pooling wave 0) %d | "
+      "total %d" % (ms[1] - ms[0], ms[2] - ms[1], ms[3] - ms[2], ms[3] - ms[0]))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(10):
@@ -39,17 +39,16 @@ for _ in range(10):
 e1.record()
 torch.cuda.synchronize()
 print("event time per call (main + reduce kernels): %.1f us" % (e0.elapsed_time(e1) * 100))
-names = ["GEMM1", "softmax||GEMM2(+loads)", "wait barrier A", "publish P", "wait barrier B", "loop/top"]
-for it in range(3):
+# softmax waves stamp 0 step start, 1 GEMM1 done, 2 barrier B passed, 3 softmax done, 4 barrier A passed (next 0 = P written);
+# pooling waves stamp 5 barrier B passed, 6 GEMM2 done, 7 barrier A passed
+for it in range(4):
     if int(t[it, 0, 0]) == 0:
         break
-    row = []
-    for w in range(4):
-        st = [int(t[it, p, w]) for p in range(6)]
-        nxt = int(t[it + 1, 0, w]) if int(t[it + 1, 0, w]) else st[5]
-        d = [st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], nxt - st[5]]
-        row.append(d)
-    print(f"iter {it}:")
-    for p, nm in enumerate(names):
-        print(f"   {nm:26s} " + " ".join(f"w{w}:{row[w][p]:7d}" for w in range(4)))
-    print(f"   {'total':26s} " + " ".join(f"w{w}:{sum(row[w]):7d}" for w in range(4)))
+    print(f"step {it}:")
+    rows = {"softmax: GEMM1": (0, 1), "softmax: wait B": (1, 2), "softmax: Q loads + softmax": (2, 3), "softmax: wait A": (3, 4),
+            "pooling: GEMM2 (from B)": (5, 6), "pooling: wait A": (6, 7)}
+    for nm, (p0, p1) in rows.items():
+        print(f"   {nm:28s} " + " ".join(f"w{w}:{int(t[it, p1, w]) - int(t[it, p0, w]):7d}" for w in range(4)))
+    nxt = [int(t[it + 1, 0, w]) or int(t[62, 0, w]) for w in range(4)]
+    print(f"   {'softmax: write P (+loop)':28s} " + " ".join(f"w{w}:{nxt[w] - int(t[it, 4, w]):7d}" for w in range(4)))
+    print(f"   {'step total':28s} " + " ".join(f"w{w}:{nxt[w] - int(t[it, 0, w]):7d}" for w in range(4)))
