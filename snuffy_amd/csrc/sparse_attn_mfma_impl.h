@@ -219,6 +219,45 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
     // zeroed, so whatever (finite) row they re-read contributes nothing.  Element offsets are 32-bit (make_plan checks
     // n * ld < 2^31) and row * ld is one v_mad_u32_u24: the pointer arithmetic of a tile is ~3 VALU per load, not ~11.
 
+    // Kp_a -> LDS as bf16 MFMA fragments: wave wi of NW participating waves owns fragments wi, wi + NW, ...  (all 8 waves in
+    // the prologue, the 4 softmax waves at a head change -- the pooling waves are draining then).  Phase 1 issues every
+    // global load of the wave back to back (one latency, not one per fragment; padded keys re-read the last row), phase 2
+    // converts and stores (padded keys zeroed; their probabilities are forced to 0 through the -inf accumulator init anyway).
+    constexpr int NF = (NKB * NKS + 3) / 4;   // fragments per wave with 4 waves (sizes the staging registers)
+    auto kp_issue = [&](auto nw_t, int wi, int a_, f32x4(&raw)[2 * NF]) __attribute__((always_inline)) {
+        constexpr int NW = decltype(nw_t)::value;
+        // opaque copy of the lane's key index: the fragment addresses are loop-invariant, and hoisting NF 64-bit
+        // pointers out of the tile loop would hold 2 NF registers across the whole softmax for a once-per-head event
+        int jo = j;
+        asm volatile("" : "+v"(jo));
+        static_for<0, (NKB * NKS + NW - 1) / NW>([&](auto i) __attribute__((always_inline)) {
+            int fr = wi + NW * i;
+            if (fr > NKB * NKS - 1) fr = NKB * NKS - 1;
+            const int jb = fr / NKS, kb = fr - jb * NKS;
+            int key = 32 * jb + jo;
+            if (key > P.k - 1) key = P.k - 1;
+            const float* src = P.kp + (int64_t)key * P.ldkp + a_ * DK + 16 * kb + 8 * hf;
+            raw[2 * i] = *reinterpret_cast<const f32x4*>(src);
+            raw[2 * i + 1] = *reinterpret_cast<const f32x4*>(src + 4);
+        });
+    };
+    auto kp_commit = [&](auto nw_t, int wi, f32x4(&raw)[2 * NF]) __attribute__((always_inline)) {
+        constexpr int NW = decltype(nw_t)::value;
+        static_for<0, (NKB * NKS + NW - 1) / NW>([&](auto i) __attribute__((always_inline)) {
+            const int fr = wi + NW * i;
+            if (fr < NKB * NKS) {
+                const int jb = fr / NKS;
+                f32x8 f = {raw[2 * i][0], raw[2 * i][1], raw[2 * i][2], raw[2 * i][3],
+                           raw[2 * i + 1][0], raw[2 * i + 1][1], raw[2 * i + 1][2], raw[2 * i + 1][3]};
+                u32x4 v = __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
+                if (32 * jb + j >= P.k) v = u32x4{0u, 0u, 0u, 0u};
+                lds_kp[fr * 64 + lane] = v;
+            }
+        });
+    };
+    using W4 = std::integral_constant<int, 4>;
+    using W8 = std::integral_constant<int, 8>;
+
     if (w8 < 4) {
         // =========================================== softmax waves ===========================================
         stamp_abs(60);
@@ -242,40 +281,6 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
             if (qrow > n32 - 1) qrow = n32 - 1;
             return __umul24((unsigned)qrow, (unsigned)ldq32) + (a_ * DK + 8 * hf);
         };
-        // Kp_a -> LDS as bf16 MFMA fragments: each softmax wave owns fragments w, w+4, ...  Phase 1 issues every global load
-        // of the wave back to back (one latency, not one per fragment; padded keys re-read the last row), phase 2 converts
-        // and stores (padded keys zeroed; their probabilities are forced to 0 through the -inf accumulator init anyway).
-        constexpr int NF = (NKB * NKS + 3) / 4;
-        auto kp_issue = [&](int a_, f32x4(&raw)[2 * NF]) __attribute__((always_inline)) {
-            // opaque copy of the lane's key index: the fragment addresses are loop-invariant, and hoisting NF 64-bit
-            // pointers out of the tile loop would hold 2 NF registers across the whole softmax for a once-per-head event
-            int jo = j;
-            asm volatile("" : "+v"(jo));
-            static_for<0, NF>([&](auto i) __attribute__((always_inline)) {
-                int fr = w + 4 * i;
-                if (fr > NKB * NKS - 1) fr = NKB * NKS - 1;
-                const int jb = fr / NKS, kb = fr - jb * NKS;
-                int key = 32 * jb + jo;
-                if (key > P.k - 1) key = P.k - 1;
-                const float* src = P.kp + (int64_t)key * P.ldkp + a_ * DK + 16 * kb + 8 * hf;
-                raw[2 * i] = *reinterpret_cast<const f32x4*>(src);
-                raw[2 * i + 1] = *reinterpret_cast<const f32x4*>(src + 4);
-            });
-        };
-        auto kp_commit = [&](f32x4(&raw)[2 * NF]) __attribute__((always_inline)) {
-            static_for<0, NF>([&](auto i) __attribute__((always_inline)) {
-                const int fr = w + 4 * i;
-                if (fr < NKB * NKS) {
-                    const int jb = fr / NKS;
-                    f32x8 f = {raw[2 * i][0], raw[2 * i][1], raw[2 * i][2], raw[2 * i][3],
-                               raw[2 * i + 1][0], raw[2 * i + 1][1], raw[2 * i + 1][2], raw[2 * i + 1][3]};
-                    u32x4 v = __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
-                    if (32 * jb + j >= P.k) v = u32x4{0u, 0u, 0u, 0u};
-                    lds_kp[fr * 64 + lane] = v;
-                }
-            });
-        };
-
         bf16x8 qf[NKS];  // Q fragments of the tile about to enter GEMM1
         // Prologue.  The cold-start latencies (kernarg, TLB, first HBM touch) are paid ONCE: the first tile's Q fragments
         // and the first head's Kp rows are requested before anything else.
@@ -285,10 +290,10 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
             static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) { qf[kb] = load_frag(qp0 + 16 * kb); });
             __builtin_amdgcn_sched_barrier(0);
             stamp_abs(56);
-            kp_issue(a, raw0);
+            kp_issue(W8{}, w8, a, raw0);
             __builtin_amdgcn_sched_barrier(0);
             stamp_abs(58);
-            kp_commit(raw0);
+            kp_commit(W8{}, w8, raw0);
         }
         __syncthreads();   // K: the Kp image is complete
         stamp_abs(61);
@@ -302,13 +307,13 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
             if (a != cur_head) {
                 // new head: every softmax wave passed A of the previous tile, so nobody reads the old Kp image any more
                 f32x4 raw[2 * NF];
-                kp_issue(a, raw);
+                kp_issue(W4{}, w, a, raw);
                 __builtin_amdgcn_sched_barrier(0);   // do not let the conversions pull the loads apart
                 if (published) {
                     __syncthreads();   // B: lets the pooling waves drain the previous head's last tile meanwhile
                     published = false;
                 }
-                kp_commit(raw);
+                kp_commit(W4{}, w, raw);
                 __syncthreads();   // K
                 cur_head = a;
             }
@@ -387,28 +392,42 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
                 mc = m;
                 lrow = l;
             } else {
-                float mx0 = fmaxf(s_acc[0][0], s_acc[0][1]), mx1 = fmaxf(s_acc[0][2], s_acc[0][3]);
-                static_for<1, 4 * NKB>([&](auto st_t) __attribute__((always_inline)) {
+                // four independent v_max3 chains
+                float mx[4] = {fmaxf(s_acc[0][0], s_acc[0][1]), fmaxf(s_acc[0][2], s_acc[0][3]), fmaxf(s_acc[0][4], s_acc[0][5]),
+                               fmaxf(s_acc[0][6], s_acc[0][7])};
+                static_for<4, 8 * NKB>([&](auto st_t) __attribute__((always_inline)) {
                     constexpr int st = decltype(st_t)::value;
-                    constexpr int jb = st / 4, r = 4 * (st % 4);
-                    mx0 = fmaxf(fmaxf(mx0, s_acc[jb][r]), s_acc[jb][r + 1]);
-                    mx1 = fmaxf(fmaxf(mx1, s_acc[jb][r + 2]), s_acc[jb][r + 3]);
+                    constexpr int jb = st / 8, r = 2 * (st % 8);
+                    mx[st % 4] = fmaxf(fmaxf(mx[st % 4], s_acc[jb][r]), s_acc[jb][r + 1]);
                 });
-                mc = xhalf_max(fmaxf(mx0, mx1)) * c_exp;
+                mc = xhalf_max(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]))) * c_exp;
             }
             {
                 const f32x2 c2 = {c_exp, c_exp}, nm2 = {-mc, -mc};
                 f32x2 l2 = {0.f, 0.f};
+                // software pipeline: the exponent of pair e + 2 is computed before the exps of pair e issue, and the running
+                // sum takes pair e - 1 -- no instruction sits right behind the one that feeds it
+                constexpr int AHEAD = 2;
+                f32x2 ar[AHEAD + 1];
+                static_for<0, AHEAD>([&](auto e_t) __attribute__((always_inline)) {
+                    constexpr int e = decltype(e_t)::value;
+                    ar[e] = __builtin_elementwise_fma(f32x2{s_acc[e / 8][2 * (e % 8)], s_acc[e / 8][2 * (e % 8) + 1]}, c2, nm2);
+                });
                 static_for<0, 8 * NKB>([&](auto e_t) __attribute__((always_inline)) {
                     constexpr int e = decltype(e_t)::value;
                     constexpr int jb = e / 8, pr = e % 8;
-                    const f32x2 sp = {s_acc[jb][2 * pr], s_acc[jb][2 * pr + 1]};
-                    const f32x2 ar = __builtin_elementwise_fma(sp, c2, nm2);
-                    const f32x2 ex = {__builtin_amdgcn_exp2f(ar[0]), __builtin_amdgcn_exp2f(ar[1])};
-                    l2 += ex;
-                    s_acc[jb][2 * pr] = ex[0];
-                    s_acc[jb][2 * pr + 1] = ex[1];
+                    if constexpr (e + AHEAD < 8 * NKB) {
+                        constexpr int en = e + AHEAD;
+                        ar[en % (AHEAD + 1)] = __builtin_elementwise_fma(
+                            f32x2{s_acc[en / 8][2 * (en % 8)], s_acc[en / 8][2 * (en % 8) + 1]}, c2, nm2);
+                    }
+                    if constexpr (e > 0)
+                        l2 += f32x2{s_acc[(e - 1) / 8][2 * ((e - 1) % 8)], s_acc[(e - 1) / 8][2 * ((e - 1) % 8) + 1]};
+                    s_acc[jb][2 * pr] = __builtin_amdgcn_exp2f(ar[e % (AHEAD + 1)][0]);
+                    s_acc[jb][2 * pr + 1] = __builtin_amdgcn_exp2f(ar[e % (AHEAD + 1)][1]);
+                    __builtin_amdgcn_sched_barrier(0);
                 });
+                l2 += f32x2{s_acc[NKB - 1][14], s_acc[NKB - 1][15]};
                 if constexpr (!EXT) lrow = xhalf_sum(l2[0] + l2[1]);
             }
             const float inv = rvalid ? __builtin_amdgcn_rcpf(lrow) : 0.f;
@@ -562,7 +581,15 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
                 for (int r = 0; r < 16; ++r) acc_o[ti][r] = 0.f;
         };
 
-        zero_acc();
+        if (f_begin < f_end) {   // the pooling waves fetch their half of the first head's Kp fragments
+            f32x4 raw0[2 * NF];
+            kp_issue(W8{}, w8, a, raw0);
+            __builtin_amdgcn_sched_barrier(0);
+            zero_acc();
+            kp_commit(W8{}, w8, raw0);
+        } else {
+            zero_acc();
+        }
         __syncthreads();   // K (prologue)
         for (int f = f_begin; f < f_end; ++f) {
             int an = a, tn = t + 1;
