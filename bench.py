@@ -74,6 +74,7 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
     scores = torch.randn(N, generator=g).to(device)
     t_topk = timed(lambda: ops.topk(scores, K), 20)
     kp = torch.randn(K, D, generator=g).to(device)
+    kp_in = kp.to(dt)   # the bf16 path hands the kernel a bf16 Kp (output of the bf16 key projection), as the model does
     # rotate over several operand sets so the 256 MiB Infinity Cache cannot serve the re-reads
     nset = max(2, int(math.ceil(600e6 / (2 * N * D * elt))))
     # Q and V as the model produces them: the two column halves of one fused projection output [N, 2D]
@@ -82,7 +83,7 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
     if ops.mfma_attn_supported(K, dk):
         def attn():
             i = state["i"] = (state["i"] + 1) % nset
-            ops.sparse_attn_fwd_mfma(qvs[i][:, :D], qvs[i][:, D:], kp, N, h)
+            ops.sparse_attn_fwd_mfma(qvs[i][:, :D], qvs[i][:, D:], kp_in, N, h)
         kern = "sparse_attn_mfma_kernel+reduce_partials_kernel"
     else:
         vs = [qv[:, D:].float().contiguous() for qv in qvs]
@@ -95,7 +96,7 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
         elt = 4
     t_attn = timed(attn, 20, warmup=3)
     # algorithmic bytes: read Q and V once, read Kp, write O;  top-k: read N scores, write K indices
-    b_attn = 2 * N * D * elt + K * D * 4 + K * D * 4
+    b_attn = 2 * N * D * elt + K * D * elt + K * D * 4
     b_topk = 4 * N + 8 * K
     b_gather = 2 * K * D * 4
     # HBM-side bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE; tools/pmc_traffic.sh), recorded

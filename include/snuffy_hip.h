@@ -91,9 +91,10 @@ int snf_scatter_add_rows_f32(float* z, int64_t n, int d, const int64_t* idx, int
                              snf_stream_t stream);
 int snf_slot_map_i32(const int64_t* idx, int k, int64_t n, int32_t* map, snf_stream_t stream);
 /* K4 + slot map in one launch: xs[j] = x[idx[j]] and map[i] = j if idx[j] == i else -1 (k <= 2048, idx duplicate-free).
- * Same results as snf_gather_rows_f32 + snf_slot_map_i32. */
+ * Same results as snf_gather_rows_f32 + snf_slot_map_i32.  xs_bf16 (nullable): a second copy of xs rounded to bf16
+ * [k, d] -- the operand of the bf16 key projection that feeds snf_sparse_attn_fwd_mfma. */
 int snf_gather_slot_map_f32(const float* x, int64_t n, int d, const int64_t* idx, int k, float* xs, int32_t* map,
-                            snf_stream_t stream);
+                            void* xs_bf16, snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K5  LayerNorm over rows, with the K9 scatter fused into the read
@@ -140,7 +141,8 @@ int snf_ln_mean_head_f32(const float* z, int64_t n, int d, const void* add_bf16,
  *   snf_sparse_attn_fwd_f32 : exact fp32 arithmetic, any n/k/h/dk.  q, v [n, d]; kp [k, d].
  *   snf_sparse_attn_fwd_mfma: bf16 MFMA (fp32 accumulate), softmax in fp32.  q [n, ldq] and v [n, ldv] row-major
  *       (ldq, ldv >= d in elements, rows 16-byte aligned: q and v may be the two column halves of ONE fused
- *       projection output [n, 2d]), both of dtype qv_dtype (f32 converted in registers, or bf16); kp [k, d] f32.
+ *       projection output [n, 2d]), both of dtype qv_dtype (f32 converted in registers, or bf16); kp [k, d] of
+ *       dtype kp_dtype: bf16 is read as it is, f32 is rounded to bf16 into the workspace first (one small launch).
  *       One launch holds 256 (dk == 64) / 224 (dk == 128) keys (Kp + P + V images share the 160 KiB LDS); more keys --
  *       up to 8 such chunks, k <= 2048 / 1792 -- run as key chunks: a statistics launch per chunk (row max / sum) and a
  *       full launch per chunk normalising with the statistics of all chunks, so the softmax stays exact.
@@ -151,9 +153,9 @@ size_t snf_sparse_attn_fwd_workspace_bytes(int64_t n, int k, int h, int dk, int 
 int snf_sparse_attn_fwd_f32(const float* q, const float* kp, const float* v, int64_t n, int k, int h, int dk,
                             float scale, float* out, float* attn, float* lse, void* workspace,
                             size_t workspace_bytes, snf_stream_t stream);
-int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const float* kp,
-                             int64_t n, int k, int h, int dk, float scale, float* out, float* attn, float* lse,
-                             void* workspace, size_t workspace_bytes, snf_stream_t stream);
+int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const void* kp,
+                             int kp_dtype, int64_t n, int k, int h, int dk, float scale, float* out, float* attn,
+                             float* lse, void* workspace, size_t workspace_bytes, snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K7-bwd  sparse attention backward, exact fp32    replaces autograd through attention(), snuffy.py:160-168

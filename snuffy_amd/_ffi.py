@@ -39,7 +39,7 @@ SIGNATURES = {
     "snf_scatter_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "snf_scatter_add_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "snf_slot_map_i32": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p]),
-    "snf_gather_slot_map_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "snf_gather_slot_map_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "snf_layernorm_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "snf_bias_act": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p]),
@@ -57,7 +57,7 @@ SIGNATURES = {
                                          c_int64, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "snf_sparse_attn_dkp_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
                                         c_void_p]),
-    "snf_sparse_attn_fwd_mfma": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int,
+    "snf_sparse_attn_fwd_mfma": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int,
                                          c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "snf_vit_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "snf_vit_assemble_tokens": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -298,13 +298,18 @@ __global__ void slot_map_kernel(const int64_t* __restrict__ idx, int k, int64_t 
 // (k <= 2048 broadcast reads per thread: cheaper than a launch, and no fill-then-scatter ordering between kernels).
 __global__ __launch_bounds__(WG) void gather_slot_map_kernel(const float* __restrict__ x, int64_t n, int d,
                                                              const int64_t* __restrict__ idx, int k,
-                                                             float* __restrict__ xs, int32_t* __restrict__ map) {
+                                                             float* __restrict__ xs, int32_t* __restrict__ map,
+                                                             __bf16* __restrict__ xs16) {
     if ((int)blockIdx.x < k) {
         const int64_t src = idx[blockIdx.x];
         if (src < 0 || src >= n) return;
         const float* s = x + src * d;
         float* o = xs + (int64_t)blockIdx.x * d;
-        for (int e = threadIdx.x; e < d; e += WG) o[e] = s[e];
+        for (int e = threadIdx.x; e < d; e += WG) {
+            const float val = s[e];
+            o[e] = val;
+            if (xs16) xs16[(int64_t)blockIdx.x * d + e] = (__bf16)val;   // round to nearest even
+        }
         return;
     }
     __shared__ int sel[2048];
@@ -716,13 +721,13 @@ int snf_slot_map_i32(const int64_t* idx, int k, int64_t n, int32_t* map, snf_str
 }
 
 int snf_gather_slot_map_f32(const float* x, int64_t n, int d, const int64_t* idx, int k, float* xs, int32_t* map,
-                            snf_stream_t stream) {
+                            void* xs_bf16, snf_stream_t stream) {
     SNF_REQUIRE(x && map && (k == 0 || (idx && xs)), "snf_gather_slot_map_f32: null pointer");
     SNF_REQUIRE(n >= 1 && n < 0x7fffffffll && d >= 1 && k >= 0 && k <= 2048,
                 "snf_gather_slot_map_f32: bad shape n=%lld d=%d k=%d (k <= 2048)", (long long)n, d, k);
     const int64_t grid = k + (n + WG - 1) / WG;
     hipLaunchKernelGGL(gather_slot_map_kernel, dim3((unsigned)grid), dim3(WG), 0, snf::as_stream(stream), x, n, d, idx, k, xs,
-                       map);
+                       map, reinterpret_cast<__bf16*>(xs_bf16));
     return snf::check_launch("gather_slot_map_kernel");
 }
 

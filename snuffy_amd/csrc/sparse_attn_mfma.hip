@@ -23,17 +23,18 @@ size_t snf_sparse_attn_fwd_workspace_bytes(int64_t n, int k, int h, int dk, int 
     if (mfma) {
         size_t pb, sb;
         if (!chunked_workspace(n, k, h, dk, &pb, &sb)) return 0;
-        return pb + sb;
+        return pb + sb + kp_staging_bytes(k, h, dk);   // partial tiles | chunk statistics | bf16 copy of an f32 Kp
     }
     return snf::generic_attn_workspace_bytes(n, k, h, dk);
 }
 
-int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const float* kp,
-                             int64_t n, int k, int h, int dk, float scale, float* out, float* attn, float* lse,
-                             void* workspace, size_t workspace_bytes, snf_stream_t stream) {
+int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const void* kp,
+                             int kp_dtype, int64_t n, int k, int h, int dk, float scale, float* out, float* attn,
+                             float* lse, void* workspace, size_t workspace_bytes, snf_stream_t stream) {
     SNF_REQUIRE(q && v && kp && out, "snf_sparse_attn_fwd_mfma: null pointer");
     SNF_REQUIRE(n >= 1 && k >= 1 && h >= 1, "snf_sparse_attn_fwd_mfma: bad shape");
     SNF_REQUIRE(qv_dtype == SNF_DT_F32 || qv_dtype == SNF_DT_BF16, "snf_sparse_attn_fwd_mfma: bad dtype %d", qv_dtype);
+    SNF_REQUIRE(kp_dtype == SNF_DT_F32 || kp_dtype == SNF_DT_BF16, "snf_sparse_attn_fwd_mfma: bad kp dtype %d", kp_dtype);
     ChunkPlan cp;
     size_t partial_bytes = 0, stats_bytes = 0;
     if (!make_chunks(k, dk, &cp) || !chunked_workspace(n, k, h, dk, &partial_bytes, &stats_bytes)) {
@@ -54,7 +55,7 @@ int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t 
     SNF_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(kp) & 15) == 0,
                 "snf_sparse_attn_fwd_mfma: q / v / kp must be 16-byte aligned");
-    const size_t need = partial_bytes + stats_bytes;
+    const size_t need = partial_bytes + stats_bytes + (kp_dtype == SNF_DT_F32 ? kp_staging_bytes(k, h, dk) : 0);
     if (!workspace || workspace_bytes < need) {
         snf::set_error("snf_sparse_attn_fwd_mfma: workspace %zu < %zu", workspace_bytes, need);
         return SNF_EWORKSPACE;
@@ -75,11 +76,24 @@ int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t 
                                    : nullptr;
     P.n_chunks = cp.n_chunks;
     hipStream_t s = snf::as_stream(stream);
+    // the kernels read Kp as bf16 (half the bytes of the cold prologue burst every workgroup starts with); an f32 Kp is
+    // rounded once here, to the same values the kernels used to produce in flight
+    const unsigned short* kp16 = reinterpret_cast<const unsigned short*>(kp);
+    if (kp_dtype == SNF_DT_F32) {
+        unsigned short* stage = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(workspace) + partial_bytes +
+                                                                  stats_bytes);
+        const int64_t groups = (int64_t)k * d / 8;
+        hipLaunchKernelGGL(kp_to_bf16_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(kp), stage, groups);
+        int rc = snf::check_launch("kp_to_bf16_kernel");
+        if (rc) return rc;
+        kp16 = stage;
+    }
     auto plan_chunk = [&](int c, Plan* pl) -> int {   // keys of chunk c; fills the launch geometry
         const int k0 = c * cp.chunk_k;
         const int kc = (k - k0 < cp.chunk_k) ? k - k0 : cp.chunk_k;
         make_plan(n, kc, h, dk, pl);
-        P.kp = kp + (int64_t)k0 * d;
+        P.kp = kp16 + (int64_t)k0 * d;
         P.k = kc;
         P.tiles_per_head = pl->tiles_per_head;
         P.tiles_per_wg = pl->tiles_per_wg;

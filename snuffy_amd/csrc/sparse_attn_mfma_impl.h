@@ -40,7 +40,7 @@ namespace snf_attn {
 struct AttnParams {
     const void* q;     // [n, ldq]   row-major, head a = columns a*dk .. (a+1)*dk
     const void* v;     // [n, ldv]   row-major, same column layout
-    const float* kp;   // [k, h*dk] f32
+    const unsigned short* kp;   // [k, ldkp] bf16 (the entry point converts an f32 Kp into the workspace first)
     int64_t n, ldq, ldv, ldkp;
     int k, h;
     float scale;
@@ -222,9 +222,9 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
     // Kp_a -> LDS as bf16 MFMA fragments: wave wi of NW participating waves owns fragments wi, wi + NW, ...  (all 8 waves in
     // the prologue, the 4 softmax waves at a head change -- the pooling waves are draining then).  Phase 1 issues every
     // global load of the wave back to back (one latency, not one per fragment; padded keys re-read the last row), phase 2
-    // converts and stores (padded keys zeroed; their probabilities are forced to 0 through the -inf accumulator init anyway).
+    // stores (padded keys zeroed; their probabilities are forced to 0 through the -inf accumulator init anyway).
     constexpr int NF = (NKB * NKS + 3) / 4;   // fragments per wave with 4 waves (sizes the staging registers)
-    auto kp_issue = [&](auto nw_t, int wi, int a_, f32x4(&raw)[2 * NF]) __attribute__((always_inline)) {
+    auto kp_issue = [&](auto nw_t, int wi, int a_, u32x4(&raw)[NF]) __attribute__((always_inline)) {
         constexpr int NW = decltype(nw_t)::value;
         // opaque copy of the lane's key index: the fragment addresses are loop-invariant, and hoisting NF 64-bit
         // pointers out of the tile loop would hold 2 NF registers across the whole softmax for a once-per-head event
@@ -236,20 +236,16 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
             const int jb = fr / NKS, kb = fr - jb * NKS;
             int key = 32 * jb + jo;
             if (key > P.k - 1) key = P.k - 1;
-            const float* src = P.kp + (int64_t)key * P.ldkp + a_ * DK + 16 * kb + 8 * hf;
-            raw[2 * i] = *reinterpret_cast<const f32x4*>(src);
-            raw[2 * i + 1] = *reinterpret_cast<const f32x4*>(src + 4);
+            raw[i] = *reinterpret_cast<const u32x4*>(P.kp + (int64_t)key * P.ldkp + a_ * DK + 16 * kb + 8 * hf);
         });
     };
-    auto kp_commit = [&](auto nw_t, int wi, f32x4(&raw)[2 * NF]) __attribute__((always_inline)) {
+    auto kp_commit = [&](auto nw_t, int wi, u32x4(&raw)[NF]) __attribute__((always_inline)) {
         constexpr int NW = decltype(nw_t)::value;
         static_for<0, (NKB * NKS + NW - 1) / NW>([&](auto i) __attribute__((always_inline)) {
             const int fr = wi + NW * i;
             if (fr < NKB * NKS) {
                 const int jb = fr / NKS;
-                f32x8 f = {raw[2 * i][0], raw[2 * i][1], raw[2 * i][2], raw[2 * i][3],
-                           raw[2 * i + 1][0], raw[2 * i + 1][1], raw[2 * i + 1][2], raw[2 * i + 1][3]};
-                u32x4 v = __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
+                u32x4 v = raw[i];
                 if (32 * jb + j >= P.k) v = u32x4{0u, 0u, 0u, 0u};
                 lds_kp[fr * 64 + lane] = v;
             }
@@ -285,7 +281,7 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
         // Prologue.  The cold-start latencies (kernarg, TLB, first HBM touch) are paid ONCE: the first tile's Q fragments
         // and the first head's Kp rows are requested before anything else.
         if (f_begin < f_end) {
-            f32x4 raw0[2 * NF];
+            u32x4 raw0[NF];
             const QT* qp0 = q + q_off(a, t);
             static_for<0, NKS>([&](auto kb) __attribute__((always_inline)) { qf[kb] = load_frag(qp0 + 16 * kb); });
             __builtin_amdgcn_sched_barrier(0);
@@ -306,7 +302,7 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
             }
             if (a != cur_head) {
                 // new head: every softmax wave passed A of the previous tile, so nobody reads the old Kp image any more
-                f32x4 raw[2 * NF];
+                u32x4 raw[NF];
                 kp_issue(W4{}, w, a, raw);
                 __builtin_amdgcn_sched_barrier(0);   // do not let the conversions pull the loads apart
                 if (published) {
@@ -582,7 +578,7 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
         };
 
         if (f_begin < f_end) {   // the pooling waves fetch their half of the first head's Kp fragments
-            f32x4 raw0[2 * NF];
+            u32x4 raw0[NF];
             kp_issue(W8{}, w8, a, raw0);
             __builtin_amdgcn_sched_barrier(0);
             zero_acc();
@@ -683,8 +679,7 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_stats_kernel(AttnParams P)
                     int key = 32 * jb + j;
                     const bool pad = key >= P.k;
                     if (pad) key = P.k - 1;
-                    const float* src = P.kp + (int64_t)key * P.ldkp + a * DK + 16 * kb + 8 * hf;
-                    u32x4 v = __builtin_bit_cast(u32x4, load_frag(src));
+                    u32x4 v = *reinterpret_cast<const u32x4*>(P.kp + (int64_t)key * P.ldkp + a * DK + 16 * kb + 8 * hf);
                     if (pad) v = u32x4{0u, 0u, 0u, 0u};
                     lds_kp[fr * 64 + lane] = v;
                 }
@@ -908,6 +903,15 @@ int launch_stats(const AttnParams& P, const Plan& pl, hipStream_t s) {
 // n_chunks near-equal chunks; every chunk gets a statistics launch (row max / sum over its keys) and then a full launch
 // that normalises with the statistics of ALL chunks -- the softmax stays exact, Q is read 2 n_chunks times and V n_chunks
 // times instead of once.
+// f32 Kp -> bf16 (round to nearest even), 8 elements per thread
+__global__ __launch_bounds__(256) void kp_to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                        int64_t groups) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= groups) return;
+    *reinterpret_cast<u32x4*>(dst + g * 8) = __builtin_bit_cast(u32x4, load_frag(src + g * 8));
+}
+inline size_t kp_staging_bytes(int k, int h, int dk) { return ((size_t)k * h * dk * 2 + 255) / 256 * 256; }
+
 constexpr int MAX_CHUNKS = 8;
 struct ChunkPlan {
     int n_chunks, chunk_k;   // chunk c covers keys [c * chunk_k, min(k, (c + 1) * chunk_k))

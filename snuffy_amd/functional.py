@@ -198,7 +198,7 @@ def _folded(layer):
     lq, lk, lv, lo = layer.self_attn.linears
     ff = layer.feed_forward
     plist = [n0.weight, n0.bias, n1.weight, n1.bias, lq.weight, lq.bias, lv.weight, lv.bias, ff.w_1.weight,
-             ff.w_1.bias, ff.w_2.weight]
+             ff.w_1.bias, ff.w_2.weight, lk.weight, lk.bias]
     key = tuple((p.data_ptr(), p._version) for p in plist)
     ent = _fold_cache.get(id(layer))
     if ent is not None and ent[0] == key:
@@ -212,6 +212,8 @@ def _folded(layer):
             w1=(ff.w_1.weight * g1).to(torch.bfloat16), b1=(ff.w_1.weight @ b1 + ff.w_1.bias).contiguous(),
             b1h=(ff.w_1.weight @ b1 + ff.w_1.bias).to(torch.bfloat16),
             w2=ff.w_2.weight.to(torch.bfloat16),
+            # key projection of the K raw selected rows (snuffy.py:190), bf16 operands like Q and V
+            wk=lk.weight.to(torch.bfloat16).contiguous(), bk=lk.bias.to(torch.bfloat16).contiguous(),
         )
     _fold_cache[id(layer)] = (key, out)
     return out
@@ -238,9 +240,9 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
         ops.bias_act_(z, ff.w_2.bias, "none")
         return Parts(z), attn
 
-    xs, slot = ops.gather_slot_map(x2, sel)                                         # snuffy.py:131,145-147 (+ row -> slot map)
-    kp = F.linear(xs, lk.weight, lk.bias)                                           # keys = RAW selected rows
     if precision == "fp32":
+        xs, slot = ops.gather_slot_map(x2, sel)                                     # snuffy.py:131,145-147 (+ row -> slot map)
+        kp = F.linear(xs, lk.weight, lk.bias)                                       # keys = RAW selected rows
         xn = ops.layernorm_rows(x2, n0.weight, n0.bias, n0.eps)                     # snuffy.py:107
         q = F.linear(xn, lq.weight, lq.bias)
         v = F.linear(xn, lv.weight, lv.bias)
@@ -269,8 +271,14 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
     qv = torch.addmm(fw["bqv"], xhat, fw["wqv"].t())                                # [N, 2D] bf16 = [Q | V], bias epilogue
     q, v = qv[:, :d], qv[:, d:]                                                     # row-strided views, used in place
     if ops.mfma_attn_supported(k, d // h, n, qv.stride(0)):
+        # keys = RAW selected rows: the gather also leaves them in bf16, the projection runs like Q | V (bf16 operands,
+        # fp32 accumulate, bf16 out) and the attention kernel reads Kp as it is
+        xs, slot, xs16 = ops.gather_slot_map(x2, sel, bf16_copy=True)               # snuffy.py:131,145-147 (+ row -> slot map)
+        kp = torch.addmm(fw["bk"], xs16, fw["wk"].t())
         o, attn, _ = ops.sparse_attn_fwd_mfma(q, v, kp, n, h, need_attn=need_attn)
     else:
+        xs, slot = ops.gather_slot_map(x2, sel)
+        kp = F.linear(xs, lk.weight, lk.bias)
         o, attn, _ = ops.sparse_attn_fwd(q.float(), kp, v.float(), h, need_attn=need_attn)
     del q, v, qv
     delta = F.linear(o, lo.weight, lo.bias)

@@ -113,19 +113,22 @@ def gather_rows(x, idx):
     return out
 
 
-def gather_slot_map(x, idx):
-    """(x[idx] [k, d], map [n] int32 with map[idx[j]] = j, -1 elsewhere) in one launch; idx must be duplicate-free."""
+def gather_slot_map(x, idx, bf16_copy=False):
+    """(x[idx] [k, d], map [n] int32 with map[idx[j]] = j, -1 elsewhere) in one launch; idx must be duplicate-free.
+    bf16_copy: also return x[idx] rounded to bf16 (third element) -- the operand of the bf16 key projection."""
     x = _req(x, torch.float32, "x", 2)
     idx = _req(idx, torch.int64, "idx", 1)
     n, d = x.shape
     k = idx.shape[0]
     if k > 2048:
-        return gather_rows(x, idx), slot_map(idx, n)
+        xs = gather_rows(x, idx)
+        return (xs, slot_map(idx, n), xs.to(torch.bfloat16)) if bf16_copy else (xs, slot_map(idx, n))
     xs = torch.empty(k, d, dtype=torch.float32, device=x.device)
     m = torch.empty(n, dtype=torch.int32, device=x.device)
-    check(_ffi.load().snf_gather_slot_map_f32(_p(x), n, d, _p(idx), k, _p(xs), _p(m), _stream()),
+    xs16 = torch.empty(k, d, dtype=torch.bfloat16, device=x.device) if bf16_copy else None
+    check(_ffi.load().snf_gather_slot_map_f32(_p(x), n, d, _p(idx), k, _p(xs), _p(m), _p(xs16), _stream()),
           "snf_gather_slot_map_f32")
-    return xs, m
+    return (xs, m, xs16) if bf16_copy else (xs, m)
 
 
 def scatter_rows(x, idx, rows, inplace=False):
@@ -366,13 +369,18 @@ def sparse_attn_fwd(q, kp, v, h, scale=None, need_attn=False, need_lse=False):
 
 def sparse_attn_fwd_mfma(q, v, kp, n, h, scale=None, need_attn=False, need_lse=False):
     """bf16-MFMA sparse attention.  q, v [n, d] row-major (both f32 or both bf16; row-strided views such as the two halves
-    of a fused [n, 2d] projection are taken in place); kp [k, d] f32."""
+    of a fused [n, 2d] projection are taken in place); kp [k, d] f32 or bf16 (f32 is rounded to bf16 by the library, one
+    extra small launch)."""
     if q.dtype not in (torch.float32, torch.bfloat16) or v.dtype != q.dtype:
         raise TypeError("sparse_attn_fwd_mfma: q and v must both be float32 or both bfloat16")
     q = _rows16(q, "q")
     v = _rows16(v, "v")
-    kp = _req(kp, torch.float32, "kp", 2)
+    if kp.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("sparse_attn_fwd_mfma: kp must be float32 or bfloat16")
+    kp = _req(kp, kp.dtype, "kp", 2)
     d = q.shape[1]
+    if kp.shape[1] != d:
+        raise ValueError("sparse_attn_fwd_mfma: kp %s does not match the width %d of q" % (tuple(kp.shape), d))
     if v.shape[1] != d or q.shape[0] < n or v.shape[0] < n:
         raise ValueError("sparse_attn_fwd_mfma: q %s / v %s do not hold %d rows of width %d"
                          % (tuple(q.shape), tuple(v.shape), n, d))
@@ -386,7 +394,8 @@ def sparse_attn_fwd_mfma(q, v, kp, n, h, scale=None, need_attn=False, need_lse=F
     wsb = lib.snf_sparse_attn_fwd_workspace_bytes(n, k, h, dk, 1)
     ws = _ws(wsb, q.device)
     dt = DT_F32 if q.dtype == torch.float32 else DT_BF16
-    check(lib.snf_sparse_attn_fwd_mfma(_p(q), q.stride(0), _p(v), v.stride(0), dt, _p(kp), n, k, h, dk, float(scale),
+    kdt = DT_F32 if kp.dtype == torch.float32 else DT_BF16
+    check(lib.snf_sparse_attn_fwd_mfma(_p(q), q.stride(0), _p(v), v.stride(0), dt, _p(kp), kdt, n, k, h, dk, float(scale),
                                        _p(out), _p(attn), _p(lse), _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_mfma")
     return out, attn, lse
 

@@ -231,6 +231,10 @@ def test_sparse_attn_mfma(n, k, h, dk, dt):
     # without materialising A the output is the same
     o3, a3, _ = ops().sparse_attn_fwd_mfma(qd, vd, kp.to(DEV), n, h)
     assert a3 is None and torch.equal(o3, o)
+    # a bf16 Kp (what the model's bf16 key projection hands over) is read as it is: same bits as the library's own
+    # round-to-nearest-even of the f32 Kp
+    o4, a4, _ = ops().sparse_attn_fwd_mfma(qd, vd, kp.to(DEV).to(torch.bfloat16), n, h, need_attn=True)
+    assert torch.equal(o4, o) and torch.equal(a4, attn)
 
 
 def test_sparse_attn_mfma_online_max_spike():
@@ -283,6 +287,9 @@ def test_gather_slot_map_equals_separate_kernels(n, d, k):
     assert torch.equal(xs, ops().gather_rows(x, idx))
     assert torch.equal(m, ops().slot_map(idx, n))
     assert torch.equal(xs, x[idx])
+    xs2, m2, xs16 = ops().gather_slot_map(x, idx, bf16_copy=True)       # + the bf16 copy for the bf16 key projection
+    assert torch.equal(xs2, xs) and torch.equal(m2, m)
+    assert torch.equal(xs16.view(torch.int16), xs.to(torch.bfloat16).view(torch.int16))
 
 
 @pytest.mark.gpu

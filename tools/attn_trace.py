@@ -17,7 +17,7 @@ N, D, h, K = 32768, 768, 6, int(sys.argv[1]) if len(sys.argv) > 1 else 200
 g = torch.Generator().manual_seed(0)
 qv = torch.randn(N, 2 * D, generator=g).to(dev).to(torch.bfloat16)
 q, vt = qv[:, :D], qv[:, D:]
-kp = torch.randn(K, D, generator=g).to(dev)
+kp = torch.randn(K, D, generator=g).to(dev).to(torch.bfloat16)
 for _ in range(3):
     ops.sparse_attn_fwd_mfma(q, vt, kp, N, h)
 buf = torch.zeros(64 * 8 * 4, dtype=torch.int64, device=dev)

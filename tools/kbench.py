@@ -24,12 +24,13 @@ def attn(wlname="cfgB", dts=("bf16", "f32"), iters=30, K=None, nset=4, N=None):
         elt = 2 if dt == "bf16" else 4
         qvs = [torch.randn(N, 2 * D, generator=g).to(dev).to(tdt) for _ in range(nset)]   # fused projection output
         st = {"i": 0}
+        kpi = kp.to(tdt)   # bf16 runs hand over a bf16 Kp, as the model's bf16 path does
 
         def f():
             st["i"] = (st["i"] + 1) % nset
-            ops.sparse_attn_fwd_mfma(qvs[st["i"]][:, :D], qvs[st["i"]][:, D:], kp, N, h)
+            ops.sparse_attn_fwd_mfma(qvs[st["i"]][:, :D], qvs[st["i"]][:, D:], kpi, N, h)
         t = timed(f, iters, warmup=3)
-        b = 2 * N * D * elt + 2 * K * D * 4
+        b = 2 * N * D * elt + K * D * (elt + 4)
         print(f"attn_mfma {wlname} N={N} K={K} nset={nset} {dt}: {t*1e3:8.1f} us  {b/t/1e6:8.1f} GB/s algorithmic  ({b/t/1e6/8000*100:.1f}% of 8 TB/s)"
               f"  {4*N*K*D/t/1e9:.1f} TFLOP/s")
         del qvs

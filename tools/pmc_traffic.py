@@ -21,7 +21,7 @@ g = torch.Generator().manual_seed(5)
 nset = 4
 xs = [torch.randn(N, D, generator=g).to(dev) for _ in range(nset)]
 qvs = [torch.randn(N, 2 * D, generator=g).to(dev).to(torch.bfloat16) for _ in range(nset)]
-kp = torch.randn(K, D, generator=g).to(dev)
+kp = torch.randn(K, D, generator=g).to(dev).to(torch.bfloat16)   # as the model's bf16 path passes it
 w = torch.randn(1, D, generator=g).to(dev)
 b = torch.zeros(1, device=dev)
 outs = [torch.empty(N, D, device=dev) for _ in range(nset)]
@@ -33,4 +33,4 @@ for it in range(12):
     ops.sparse_attn_fwd_mfma(qvs[i][:, :D], qvs[i][:, D:], kp, N, h)
 torch.cuda.synchronize()
 print("known bytes: critic read %d, fill write %d, attention algorithmic %d (Q,V bf16 + Kp + O)"
-      % (N * D * 4, N * D * 4, 2 * N * D * 2 + 2 * K * D * 4))
+      % (N * D * 4, N * D * 4, 2 * N * D * 2 + K * D * (2 + 4)))
