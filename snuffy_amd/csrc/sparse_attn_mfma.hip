@@ -3,6 +3,7 @@
 
 namespace {
 unsigned long long* g_attn_trace = nullptr;  // debug hook, see snf_debug_attn_trace
+int g_attn_trace_wg = 0;
 }  // namespace
 
 namespace snf {
@@ -17,6 +18,7 @@ extern "C" {
 
 // debug only (not part of the public header): device buffer of >= 64*8*4 u64 receiving s_memtime stamps of workgroup 0
 void snf_debug_attn_trace(void* buf) { g_attn_trace = reinterpret_cast<unsigned long long*>(buf); }
+void snf_debug_attn_trace_wg(int wg) { g_attn_trace_wg = wg; }
 
 size_t snf_sparse_attn_fwd_workspace_bytes(int64_t n, int k, int h, int dk, int mfma) {
     if (n < 1 || k < 1 || h < 1 || dk < 1) return 0;
@@ -72,6 +74,7 @@ int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t 
     P.attn_ld = k;
     P.partial = reinterpret_cast<float*>(workspace);
     P.trace = g_attn_trace;
+    P.trace_wg = g_attn_trace_wg;
     float* stats = cp.n_chunks > 1 ? reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + partial_bytes)
                                    : nullptr;
     P.n_chunks = cp.n_chunks;

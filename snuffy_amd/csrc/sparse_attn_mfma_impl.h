@@ -54,7 +54,8 @@ struct AttnParams {
     float* lse;      // [h, n] or null
     float* partial;  // [num_wg * seg_count][tiles][16][64]
     int tiles_per_head, tiles_per_wg, total_tiles, seg_count;
-    unsigned long long* trace;  // debug: s_memtime stamps of workgroup 0 (tools/attn_trace.py), normally null
+    unsigned long long* trace;  // debug: s_memtime stamps of workgroup trace_wg (tools/attn_trace.py), normally null
+    int trace_wg;
 };
 struct Plan {
     int num_wg, tiles_per_head, tiles_per_wg, total_tiles, seg_count, nkb;
@@ -200,11 +201,11 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
     // debug trace (tools/attn_trace.py): phases 0..4 are stamped by the softmax waves (step start, GEMM1 done, B passed,
     // softmax done, A passed), 5..7 by the pooling waves (B passed, GEMM2 done, A passed)
     auto stamp = [&](int phase) __attribute__((always_inline)) {
-        if (P.trace && blockIdx.x == 0 && lane == 0)
+        if (P.trace && (int)blockIdx.x == P.trace_wg && lane == 0)
             P.trace[(trace_it * 8 + phase) * 4 + w] = __builtin_amdgcn_s_memtime();
     };
     auto stamp_abs = [&](int slot) __attribute__((always_inline)) {  // slots 56..63 of the trace: kernel milestones
-        if (P.trace && blockIdx.x == 0 && lane == 0) P.trace[(slot * 8) * 4 + w] = __builtin_amdgcn_s_memtime();
+        if (P.trace && (int)blockIdx.x == P.trace_wg && lane == 0) P.trace[(slot * 8) * 4 + w] = __builtin_amdgcn_s_memtime();
     };
 
     const int f_begin = blockIdx.x * P.tiles_per_wg;
@@ -219,8 +220,7 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
     // zeroed, so whatever (finite) row they re-read contributes nothing.  Element offsets are 32-bit (make_plan checks
     // n * ld < 2^31) and row * ld is one v_mad_u32_u24: the pointer arithmetic of a tile is ~3 VALU per load, not ~11.
 
-    // Kp_a -> LDS as bf16 MFMA fragments: wave wi of NW participating waves owns fragments wi, wi + NW, ...  (all 8 waves in
-    // the prologue, the 4 softmax waves at a head change -- the pooling waves are draining then).  Phase 1 issues every
+    // Kp_a -> LDS as bf16 MFMA fragments: wave wi of NW participating waves owns fragments wi, wi + NW, ...  Phase 1 issues every
     // global load of the wave back to back (one latency, not one per fragment; padded keys re-read the last row), phase 2
     // stores (padded keys zeroed; their probabilities are forced to 0 through the -inf accumulator init anyway).
     constexpr int NF = (NKB * NKS + 3) / 4;   // fragments per wave with 4 waves (sizes the staging registers)
@@ -301,15 +301,16 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
                 an = a + 1;
             }
             if (a != cur_head) {
-                // new head: every softmax wave passed A of the previous tile, so nobody reads the old Kp image any more
+                // new head: every softmax wave passed A of the previous tile, so nobody reads the old Kp image any more.
+                // All 8 waves fetch fragments (the pooling waves request theirs before they drain the last tile)
                 u32x4 raw[NF];
-                kp_issue(W4{}, w, a, raw);
+                kp_issue(W8{}, w8, a, raw);
                 __builtin_amdgcn_sched_barrier(0);   // do not let the conversions pull the loads apart
                 if (published) {
                     __syncthreads();   // B: lets the pooling waves drain the previous head's last tile meanwhile
                     published = false;
                 }
-                kp_commit(W4{}, w, raw);
+                kp_commit(W8{}, w8, raw);
                 __syncthreads();   // K
                 cur_head = a;
             }
@@ -598,6 +599,8 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
                 constexpr int i = decltype(i_t)::value;
                 vld[i] = load_frag(vg + v_off(a, t, i));
             });
+            u32x4 kraw[NF];
+            if (a != cur_head) kp_issue(W8{}, w8, a, kraw);   // new head: this wave's share of its Kp, in flight under the drain
             __builtin_amdgcn_sched_barrier(0);
             if (published) {
                 __syncthreads();   // B: P(f-1) and V(f-1) are complete
@@ -607,9 +610,12 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
                 stamp(6);
             }
             if (a != cur_head) {   // the tile just accumulated was the last one of its head
+                kp_commit(W8{}, w8, kraw);
+                // K first (the Kp image is replaced, the softmax waves go on with GEMM1 / softmax of the new head), THEN the
+                // flush: the partial tiles drain to HBM beside the softmax waves' work instead of in front of it
+                __syncthreads();
                 flush(cur_head);
                 zero_acc();
-                __syncthreads();   // K (the softmax waves replaced the Kp image)
                 cur_head = a;
             }
             __syncthreads();   // A: the images are free (all GEMM2 reads done, softmax(f) computed)

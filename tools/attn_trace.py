@@ -14,6 +14,10 @@ lib = _ffi.load()
 lib.snf_debug_attn_trace.argtypes = [ctypes.c_void_p]
 lib.snf_debug_attn_trace.restype = None
 N, D, h, K = 32768, 768, 6, int(sys.argv[1]) if len(sys.argv) > 1 else 200
+WG = int(sys.argv[2]) if len(sys.argv) > 2 else 0     # traced workgroup (42 = first one that straddles two heads)
+lib.snf_debug_attn_trace_wg.argtypes = [ctypes.c_int]
+lib.snf_debug_attn_trace_wg.restype = None
+lib.snf_debug_attn_trace_wg(WG)
 g = torch.Generator().manual_seed(0)
 qv = torch.randn(N, 2 * D, generator=g).to(dev).to(torch.bfloat16)
 q, vt = qv[:, :D], qv[:, D:]
@@ -41,7 +45,7 @@ torch.cuda.synchronize()
 print("event time per call (main + reduce kernels): %.1f us" % (e0.elapsed_time(e1) * 100))
 # softmax waves stamp 0 step start, 1 GEMM1 done, 2 barrier B passed, 3 softmax done, 4 barrier A passed (next 0 = P written);
 # pooling waves stamp 5 barrier B passed, 6 GEMM2 done, 7 barrier A passed
-for it in range(4):
+for it in range(7):
     if int(t[it, 0, 0]) == 0:
         break
     print(f"step {it}:")
