@@ -40,7 +40,7 @@ for name in ("sparse_attn_mfma_kernel", "reduce_partials_kernel"):
     out[name] = {"read_bytes": round(rb), "write_bytes": round(wb)}
     print("%-28s read %8.2f MB  write %8.2f MB per launch" % (name, rb / 1e6, wb / 1e6))
 tot = sum(v["read_bytes"] + v["write_bytes"] for v in out.values())
-alg = 2 * N * D * 2 + 2 * K * D * 4
+alg = 2 * N * D * 2 + K * D * (2 + 4)   # Q, V bf16 + Kp bf16 in, O f32 out
 print("attention total HBM-side traffic %.1f MB per launch vs %.1f MB algorithmic (x%.2f)" % (tot / 1e6, alg / 1e6, tot / alg))
 out["total_bytes"] = tot
 out["algorithmic_bytes"] = alg
