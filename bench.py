@@ -248,7 +248,7 @@ def main():
                        "model_tflops_per_s": round(flops_fwd * (3 if args.mode == "train" else 1) * world * args.steps
                                                    / elapsed / 1e12, 2)},
         }
-        if world == 1 and not args.no_roofline:
+        if not args.no_roofline:   # rank 0 only, after the timed region (the other ranks wait at the closing barrier)
             line.update(kernel_rooflines(wl, args.precision, device, args.workload))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl)

@@ -17,13 +17,14 @@
 //   GEMM2  O[key, col] += P^T V   needs both operands with 8 consecutive QUERY rows in a lane's registers, i.e. transposed
 //          with respect to how they were written: ds_read_b64_tr_b16 (hardware transpose-read) delivers exactly that.
 //
-// Workgroup = 4 waves (one per SIMD) = 128 query rows per step of one head: wave w runs GEMM1 + softmax for rows
-// 32w..32w+31 against all keys, publishes, then every wave accumulates its own share of the [k, dk] output tiles over
-// all 128 rows.  One workgroup per CU walks a contiguous range of (head, row-tile) work items; its accumulators stay in
-// registers until the head changes; partial tiles are written in fragment order and summed in a fixed order by a
-// second kernel (no float atomics -> bit-reproducible).
+// Workgroup = 8 waves in two roles = 128 query rows per step of one head: the softmax waves 0..3 run GEMM1 + softmax for
+// rows 32w..32w+31 against all keys and publish P, the pooling waves 4..7 (one on each softmax wave's SIMD) publish V and
+// accumulate their share of the [k, dk] output tiles over all 128 rows (details at the kernel).  One workgroup per CU
+// walks a contiguous range of (head, row-tile) work items; the accumulators stay in registers until the head changes;
+// partial tiles are written in fragment order and summed in a fixed order by a second kernel (no float atomics ->
+// bit-reproducible).
 //
-// HBM traffic per launch (algorithmic): read Q and V once (2*n*d*elt), Kp once per workgroup (L2), write partials.
+// HBM traffic per launch (algorithmic): read Q and V once (2*n*d*elt), Kp (bf16) once per workgroup (L2), write partials.
 #include <math.h>
 #include <stdlib.h>
 
