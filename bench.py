@@ -107,16 +107,23 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
     if kern.startswith("sparse_attn_mfma") and os.path.exists(tfile):
         with open(tfile) as f:
             traffic = int(json.load(f)["total_bytes"])
+    # `achieved` / `frac` price the launch at the bytes it has to move at ITS operand width (bf16 Q, V, Kp here).  SURVEY
+    # section 8(d) prices the same unit at the reference's fp32 tensors (8ND + 8KD; with the selector 8ND + 4N + 16KD + 8K):
+    # that figure is reported next to it as survey_8d_* -- same time, twice the bytes on the bf16 path.
+    b_attn_8d = 8 * N * D + 8 * K * D
+    b_unit_8d = 8 * N * D + 4 * N + 16 * K * D + 8 * K
     out["roofline"] = dict(bound="hbm", kernel=kern, achieved=round(b_attn / (t_attn * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS,
                            unit="GB/s", frac=round(b_attn / (t_attn * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic=traffic,
                            us_per_launch=round(t_attn * 1e3, 2), algorithmic_bytes=b_attn,
-                           flops=4 * N * K * D, operand_dtype=precision)
+                           flops=4 * N * K * D, operand_dtype=precision, survey_8d_bytes=b_attn_8d,
+                           survey_8d_frac=round(b_attn_8d / (t_attn * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
     t_unit = t_attn + t_topk
     b_unit = b_attn + b_topk + b_gather
     out["roofline_topk_attn"] = dict(bound="hbm", achieved=round(b_unit / (t_unit * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS,
                                      unit="GB/s", frac=round(b_unit / (t_unit * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                      us_topk=round(t_topk * 1e3, 2), us_attn=round(t_attn * 1e3, 2),
-                                     algorithmic_bytes=b_unit)
+                                     algorithmic_bytes=b_unit, survey_8d_bytes=b_unit_8d,
+                                     survey_8d_frac=round(b_unit_8d / (t_unit * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
     del qvs
     return out
 
