@@ -129,6 +129,13 @@ __global__ __launch_bounds__(TPB) void topk_round_kernel(const void* __restrict_
 // key > T plus the lowest-index (k - #greater) keys == T; the k survivors are sorted as 64-bit composites (bitonic, LDS).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int RS_MAXK = 2048;
+// debug: phase stamps of thread 0 (tools/topk_trace.py); compiled in only with -DSNF_TOPK_TRACE
+#ifdef SNF_TOPK_TRACE
+__device__ unsigned long long g_topk_trace[16];
+#define TSTAMP(ix) do { if (threadIdx.x == 0) g_topk_trace[ix] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP(ix) do { } while (0)
+#endif
 
 __device__ __forceinline__ unsigned int block_excl_scan_1024(unsigned int v, unsigned int* wave_tot, unsigned int* total) {
     // exclusive prefix sum over the 1024 threads (ascending thread id); *total = sum of all
@@ -159,15 +166,50 @@ template <int IPT>
 __global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restrict__ scores, int64_t n, int64_t stride, int k,
                                                           int64_t* __restrict__ idx_out) {
     constexpr bool REG = IPT > 0;
+    // Register form: slots past n hold the key 0, which no score maps to (the smallest orderable key, -inf, is 0x007fffff)
+    // and which sits alone in digit 0 of the first pass -- it can never be selected (k <= n), never matches a later prefix
+    // and never passes the final threshold, so the per-key loops below carry no bounds test.
+    TSTAMP(0);
+    // slot u of thread t holds score index 4 (t + 1024 (u / 4)) + u % 4 with vector loads, t + 1024 u otherwise
+    const bool vec = REG && stride == 1 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0;
+    auto slot_index = [&](int u) __attribute__((always_inline)) -> unsigned int {
+        return vec ? 4u * ((unsigned int)threadIdx.x + 1024u * (unsigned int)(u >> 2)) + (unsigned int)(u & 3)
+                   : (unsigned int)threadIdx.x + 1024u * (unsigned int)u;
+    };
     unsigned int rkey[REG ? IPT : 1];
     if constexpr (REG) {
+        if (vec) {   // uniform: 16-byte loads, 4 consecutive scores per slot group (one CU pulls dword loads at ~11 B/clk)
 #pragma unroll
-        for (int u = 0; u < IPT; ++u) {
-            const int64_t i = threadIdx.x + (int64_t)u * 1024;
-            rkey[u] = (i < n) ? orderable_desc(scores[i * stride]) : 0u;
+            for (int g4 = 0; g4 < IPT / 4; ++g4) {
+                const int base = 4 * ((int)threadIdx.x + 1024 * g4);
+                if (base + 3 < n) {
+                    const float4 f = *reinterpret_cast<const float4*>(scores + base);
+                    rkey[4 * g4] = orderable_desc(f.x);
+                    rkey[4 * g4 + 1] = orderable_desc(f.y);
+                    rkey[4 * g4 + 2] = orderable_desc(f.z);
+                    rkey[4 * g4 + 3] = orderable_desc(f.w);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rkey[4 * g4 + e] = (base + e < n) ? orderable_desc(scores[base + e]) : 0u;
+                }
+            }
+        } else if (stride == 1) {   // uniform: unit-stride scores need no 64-bit index multiply per load
+#pragma unroll
+            for (int u = 0; u < IPT; ++u) {
+                const int i = (int)threadIdx.x + u * 1024;
+                rkey[u] = (i < n) ? orderable_desc(scores[i]) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < IPT; ++u) {
+                const int64_t i = threadIdx.x + (int64_t)u * 1024;
+                rkey[u] = (i < n) ? orderable_desc(scores[i * stride]) : 0u;
+            }
         }
     }
-    __shared__ unsigned int hist[2048];
+    // first pass: 4 replicas interleaved per digit (word 4 d + lane % 4; 8 replicas measured slower) -- real scores crowd into a few dozen of the 2048
+    // (sign, exponent, 2 mantissa bits) bins, and lanes adding to the SAME word serialise; later passes use words 0..2047
+    __shared__ __attribute__((aligned(16))) unsigned int hist[REG ? 4 * 2048 : 2048];
     __shared__ unsigned long long sel[RS_MAXK];
     __shared__ unsigned int wave_tot[16];
     __shared__ unsigned int s_digit, s_above, s_cnt_sel, s_eq_base;
@@ -175,16 +217,31 @@ __global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restric
     unsigned int prefix = 0, mask = 0, krem = (unsigned int)k, cnt_eq = 0;
     const int shifts[3] = {21, 10, 0};
     const int nbits[3] = {11, 11, 10};
+#ifdef SNF_TOPK_TRACE
+    if constexpr (REG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+    TSTAMP(1);
     for (int pass = 0; pass < 3; ++pass) {
+        TSTAMP(2 + 2 * pass);
         const int shift = shifts[pass];
         const unsigned int nb = 1u << nbits[pass];
-        for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+        for (int i = tid; i < ((REG && pass == 0) ? 4 * 2048 : 2048); i += 1024) hist[i] = 0;
         __syncthreads();
         if constexpr (REG) {
+            if (pass == 0) {   // no prefix yet: every key counts (the padding keys land in digit 0, below every score)
+                const unsigned int rep = (unsigned int)tid & 3u;
 #pragma unroll
-            for (int u = 0; u < IPT; ++u) {
-                const int64_t i = tid + (int64_t)u * 1024;
-                if (i < n && (rkey[u] & mask) == prefix) atomicAdd(&hist[(rkey[u] >> shift) & (nb - 1)], 1u);
+                for (int u = 0; u < IPT; ++u) atomicAdd(&hist[((rkey[u] >> 21) << 2) | rep], 1u);
+                __syncthreads();
+                // fold the replicas: thread t owns digits 2t, 2t+1 (two 16-byte reads), result back in words 0..2047
+                const uint4 a = *reinterpret_cast<const uint4*>(&hist[8 * tid]), b = *reinterpret_cast<const uint4*>(&hist[8 * tid + 4]);
+                __syncthreads();
+                hist[2 * tid] = a.x + a.y + a.z + a.w;
+                hist[2 * tid + 1] = b.x + b.y + b.z + b.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < IPT; ++u)
+                    if ((rkey[u] & mask) == prefix) atomicAdd(&hist[(rkey[u] >> shift) & (nb - 1)], 1u);
             }
         } else
         for (int64_t i0 = tid; i0 < n; i0 += 8 * 1024) {   // 8 independent loads in flight per thread
@@ -202,6 +259,7 @@ __global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restric
             }
         }
         __syncthreads();
+        TSTAMP(3 + 2 * pass);
         // suffix counts: thread t owns digits dpt*t .. dpt*t + dpt-1 ; S(d) = #keys (in the prefix class) with digit >= d
         const int dpt = (int)(nb / 1024);
         unsigned int own[2] = {0, 0}, local = 0;
@@ -227,6 +285,7 @@ __global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restric
         krem -= s_above;
         __syncthreads();
     }
+    TSTAMP(8);
     // threshold key T = prefix: #(key > T) = k - krem, #(key == T) = cnt_eq >= krem
     const unsigned int T = prefix;
     if (tid == 0) {
@@ -239,10 +298,9 @@ __global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restric
         if constexpr (REG) {
 #pragma unroll
             for (int u = 0; u < IPT; ++u) {
-                const int64_t i = tid + (int64_t)u * 1024;
-                if (i < n && rkey[u] >= T) {
+                if (rkey[u] >= T) {
                     const unsigned int pos = atomicAdd(&s_cnt_sel, 1u);
-                    sel[pos] = ((unsigned long long)rkey[u] << 32) | (unsigned long long)(0xffffffffu - (unsigned int)i);
+                    sel[pos] = ((unsigned long long)rkey[u] << 32) | (unsigned long long)(0xffffffffu - slot_index(u));
                 }
             }
         }
@@ -291,16 +349,25 @@ __global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restric
         }
     }
     __syncthreads();
+    TSTAMP(9);
     // order the k survivors (descending composite == descending score, ascending index)
     if (k <= 512) {
         // rank sort: the composites are distinct, so #(greater) IS the output position.  k broadcast LDS reads per thread and
         // no further barrier -- the bitonic network below costs log2(k)^2 / 2 workgroup barriers (36 at k = 200).
-        if (tid < k) {
-            const unsigned long long mine = sel[tid];
-            int rank = 0;
-            for (int j2 = 0; j2 < k; ++j2) rank += (sel[j2] > mine) ? 1 : 0;
-            idx_out[rank] = (int64_t)(0xffffffffu - (unsigned int)(mine & 0xffffffffull));
+        // `parts` adjacent lanes share one survivor (k * parts <= 1024): each counts over a strided quarter of the list, four
+        // independent LDS reads per trip (one dependent read per trip is a full LDS latency each), then a lane-group sum
+        const int parts = k <= 128 ? 8 : (k <= 256 ? 4 : 2);
+        const int cand = tid / parts, part = tid % parts;
+        const unsigned long long mine = cand < k ? sel[cand] : ~0ull;
+        int rank = 0, j2 = part;
+        for (; j2 + 3 * parts < k; j2 += 4 * parts) {
+            const unsigned long long v0 = sel[j2], v1 = sel[j2 + parts], v2 = sel[j2 + 2 * parts], v3 = sel[j2 + 3 * parts];
+            rank += (v0 > mine) + (v1 > mine) + (v2 > mine) + (v3 > mine);
         }
+        for (; j2 < k; j2 += parts) rank += (sel[j2] > mine) ? 1 : 0;
+        for (int o = 1; o < parts; o <<= 1) rank += __shfl_xor(rank, o, 64);
+        if (cand < k && part == 0) idx_out[rank] = (int64_t)(0xffffffffu - (unsigned int)(mine & 0xffffffffull));
+        TSTAMP(10);
         return;
     }
     int p2 = 1;
@@ -334,6 +401,10 @@ inline int64_t survivors(int64_t m, int k) {
 }  // namespace
 
 extern "C" {
+
+#ifdef SNF_TOPK_TRACE
+void snf_debug_topk_trace(unsigned long long* host16) { (void)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_topk_trace), 16 * sizeof(unsigned long long)); }
+#endif
 
 size_t snf_topk_workspace_bytes(int64_t n, int k) {
     (void)n;
