@@ -237,6 +237,29 @@ def test_sparse_attn_mfma(n, k, h, dk, dt):
     assert torch.equal(o4, o) and torch.equal(a4, attn)
 
 
+@pytest.mark.parametrize("n,k,h,dk,dt", [(40000, 200, 6, 128, "bf16"), (40000, 300, 6, 128, "bf16"), (70000, 256, 6, 64, "f32"),
+                                         (33000, 224, 3, 128, "f32")])
+def test_sparse_attn_mfma_workgroups_straddle_heads(n, k, h, dk, dt):
+    """More row tiles than compute units: every workgroup walks several (head, tile) items and some cross a head boundary
+    (Kp refetched by all 8 waves, partial tiles flushed mid-loop) -- with the attention / lse outputs and, for k = 300, the
+    key-chunked variant.  Checked against the oracle fed with the same bf16-rounded operands and through the
+    size-independent checksums."""
+    g = torch.Generator().manual_seed(n + k)
+    d = h * dk
+    q, kp, v = torch.randn(n, d, generator=g), torch.randn(k, d, generator=g), torch.randn(n, d, generator=g)
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    qv = torch.cat([q, v], dim=1).to(DEV).to(tdt)
+    qd, vd = qv[:, :d], qv[:, d:]
+    o, attn, lse = ops().sparse_attn_fwd_mfma(qd, vd, kp.to(DEV), n, h, need_attn=True, need_lse=True)
+    o_r, p_r = attn_ref(bf16r(q), bf16r(kp), bf16r(v), h)
+    assert (attn.cpu().double() - p_r).abs().max() < 2e-5 + 2e-3 * float(p_r.max())
+    assert rel_err(o.cpu(), o_r) < 3e-3
+    assert (attn.sum(-1) - 1).abs().max() < 1e-4
+    assert rel_err(o.cpu().view(k, h, dk).sum(0), bf16r(v).view(n, h, dk).sum(0)) < 5e-3
+    o2, a2, _ = ops().sparse_attn_fwd_mfma(qd, vd, kp.to(DEV).to(torch.bfloat16), n, h)      # no attention output, bf16 Kp
+    assert a2 is None and torch.equal(o2, o)
+
+
 def test_sparse_attn_mfma_online_max_spike():
     """A key row that dominates one query (score >> others) must not overflow or lose the other rows."""
     n, k, h, dk = 512, 200, 6, 128
