@@ -1,18 +1,15 @@
 // K2: top-k patch selector (replaces torch.sort(c, 1, descending=True)[:k], snuffy.py:128-130).
 //
 // Exact, deterministic, tie rule = descending score then ascending index (torch.sort(stable=True) order).
-// Each score becomes a 64-bit composite key  (orderable(score) << 32) | ~index ; larger composite == earlier in the
-// output.  n <= 4096: one workgroup bitonic-sorts the composites (registers + wave shuffles, LDS only for the
-// cross-wave steps).  n > 4096: radix select (below).  [The multi-round chunked sort is kept for reference:] every
-// workgroup sorts a chunk of 4096 and keeps its top min(k, chunk);
-// rounds repeat on the survivors until one chunk is left, whose top k indices are the answer.  Integer compare-exchange
-// only -- bit-exact on every run.
+// Each score becomes a 32-bit orderable key; larger key == earlier in the output, equal keys by ascending index.  One
+// workgroup radix-selects the k-th largest key (below) and rank-sorts the k survivors as 64-bit composites
+// (orderable(score) << 32) | ~index.  Integer compares and integer LDS atomics only -- bit-exact on every run.
+// (History: a multi-round chunked bitonic sort, 60 us at n = 32768, then a register/shuffle bitonic network for n <= 4096
+// -- 29 us at any size, against 11 us for the radix select -- both gone.)
 #include "common.h"
 
 namespace {
 
-constexpr int CHUNK = 4096;
-constexpr int TPB = 1024;
 
 __device__ __forceinline__ unsigned int orderable_desc(float f) {
     unsigned int u = __float_as_uint(f);
@@ -21,110 +18,8 @@ __device__ __forceinline__ unsigned int orderable_desc(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// Bitonic sort (descending) of CHUNK = 4 * TPB 64-bit keys, 4 consecutive keys per thread held in REGISTERS:
-//   partner distance 1, 2        -> inside the thread
-//   partner distance 4 .. 128    -> another lane of the same wave (64-bit shuffle, no barrier)
-//   partner distance >= 256      -> another wave: through LDS (10 of the 78 network steps)
-// Element i of the chunk lives in thread i / 4, slot i % 4.
-__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
-    unsigned int lo = (unsigned int)v, hi = (unsigned int)(v >> 32);
-    lo = __shfl_xor(lo, mask, 64);
-    hi = __shfl_xor(hi, mask, 64);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-__device__ __forceinline__ void cmpx(unsigned long long& mine, unsigned long long other, bool take_max) {
-    const bool other_gt = other > mine;
-    mine = (other_gt == take_max) ? other : mine;
-}
-
-__device__ __forceinline__ void bitonic_sort_desc_regs(unsigned long long (&v)[4], unsigned long long* s) {
-    const int tid = threadIdx.x;
-    for (int size = 2; size <= CHUNK; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            if (stride >= 256) {
-                __syncthreads();
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s[4 * tid + e] = v[e];
-                __syncthreads();
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = 4 * tid + e;
-                    const bool lower = (i & stride) == 0, desc = (i & size) == 0;
-                    cmpx(v[e], s[i ^ stride], lower == desc);
-                }
-            } else if (stride >= 4) {
-                const int lm = stride >> 2;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = 4 * tid + e;
-                    const bool lower = (i & stride) == 0, desc = (i & size) == 0;
-                    cmpx(v[e], shfl_xor_u64(v[e], lm), lower == desc);
-                }
-            } else {
-                const bool desc = ((4 * tid) & size) == 0;  // size >= 2: all 4 slots of a thread share it unless size < 8
-                if (stride == 2) {
-                    const bool d0 = ((4 * tid + 0) & size) == 0, d1 = ((4 * tid + 1) & size) == 0;
-                    unsigned long long a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
-                    cmpx(v[0], a2, d0);        // slot 0 is the lower element of the pair (0,2)
-                    cmpx(v[2], a0, !d0);
-                    cmpx(v[1], a3, d1);
-                    cmpx(v[3], a1, !d1);
-                } else {
-                    const bool d0 = ((4 * tid + 0) & size) == 0, d2 = ((4 * tid + 2) & size) == 0;
-                    unsigned long long a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
-                    cmpx(v[0], a1, d0);
-                    cmpx(v[1], a0, !d0);
-                    cmpx(v[2], a3, d2);
-                    cmpx(v[3], a2, !d2);
-                }
-                (void)desc;
-            }
-        }
-    }
-}
-
-// FROM_SCORES: src is float scores (stride elements apart), else src is a composite list of length m.
-// TO_INDEX   : write int64 indices (final round), else write composites.
-template <bool FROM_SCORES, bool TO_INDEX>
-__global__ __launch_bounds__(TPB) void topk_round_kernel(const void* __restrict__ src, int64_t m, int64_t stride, int k,
-                                                        void* __restrict__ dst) {
-    __shared__ unsigned long long s[CHUNK];
-    const int64_t base = (int64_t)blockIdx.x * CHUNK;
-    unsigned long long v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int li = 4 * threadIdx.x + e;
-        const int64_t gi = base + li;
-        unsigned long long key = 0ull;  // below every real composite (index part of a real key is never ~0 here)
-        if (gi < m) {
-            if (FROM_SCORES) {
-                float f = reinterpret_cast<const float*>(src)[gi * stride];
-                key = ((unsigned long long)orderable_desc(f) << 32) | (unsigned long long)(0xffffffffu - (unsigned int)gi);
-            } else {
-                key = reinterpret_cast<const unsigned long long*>(src)[gi];
-            }
-        }
-        v[e] = key;
-    }
-    bitonic_sort_desc_regs(v, s);
-    int64_t remain = m - base;
-    int cnt = (int)(remain < CHUNK ? remain : CHUNK);
-    int keep = cnt < k ? cnt : k;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int li = 4 * threadIdx.x + e;
-        if (li < keep) {
-            if (TO_INDEX)
-                reinterpret_cast<int64_t*>(dst)[li] = (int64_t)(0xffffffffu - (unsigned int)(v[e] & 0xffffffffull));
-            else
-                reinterpret_cast<unsigned long long*>(dst)[(int64_t)blockIdx.x * k + li] = v[e];
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// Radix select (n > 4096): ONE workgroup, O(n) work.  Three counting passes (11 + 11 + 10 bits of the orderable key, LDS
+// Radix select: ONE workgroup, O(n) work.  Three counting passes (11 + 11 + 10 bits of the orderable key, LDS
 // histogram with integer atomics -> exact and deterministic) find the k-th largest key T; one more pass collects every
 // key > T plus the lowest-index (k - #greater) keys == T; the k survivors are sorted as 64-bit composites (bitonic, LDS).
 // ---------------------------------------------------------------------------------------------------------------
@@ -392,12 +287,6 @@ __global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restric
     for (int j = tid; j < k; j += 1024) idx_out[j] = (int64_t)(0xffffffffu - (unsigned int)(sel[j] & 0xffffffffull));
 }
 
-// survivors after a round over m items with chunk keep k (every chunk but the last is full)
-inline int64_t survivors(int64_t m, int k) {
-    int64_t full = m / CHUNK, rem = m % CHUNK;
-    return full * (int64_t)(k < CHUNK ? k : CHUNK) + (rem < k ? rem : k);
-}
-
 }  // namespace
 
 extern "C" {
@@ -420,10 +309,6 @@ int snf_topk_f32(const float* scores, int64_t n, int64_t stride, int k, int64_t*
     SNF_REQUIRE(k <= SNF_TOPK_MAX_K, "snf_topk_f32: k=%d exceeds SNF_TOPK_MAX_K=%d", k, SNF_TOPK_MAX_K);
     SNF_REQUIRE(n < 0xffffffffll, "snf_topk_f32: n too large");
     hipStream_t s = snf::as_stream(stream);
-    if (n <= CHUNK) {
-        hipLaunchKernelGGL((topk_round_kernel<true, true>), dim3(1), dim3(TPB), 0, s, scores, n, stride, k, idx_out);
-        return snf::check_launch("topk_round_kernel<scores,index>");
-    }
     (void)workspace;
     (void)workspace_bytes;
     SNF_REQUIRE(k <= RS_MAXK, "snf_topk_f32: k=%d exceeds %d", k, RS_MAXK);
