@@ -167,6 +167,9 @@ def main():
     ap.add_argument("--mode", default="eval", choices=["eval", "train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the eval forward from HIP graphs (MILNet.configure(graph_max_patches=...)): same kernels, "
+                         "no per-launch host work -- +50 %% and more for bags of <= 8k patches, nothing for config B on a fast host")
     ap.add_argument("--gemm-table", action="store_true",
                     help="apply snuffy_amd/tuning/gemm_gfx950.csv (library-GEMM selections; helps the training shapes, "
                          "nothing measurable for the eval forward)")
@@ -216,6 +219,12 @@ def main():
             stepper.step(bags[i % nbags], labels[i % nbags])
     else:
         net.eval()
+        if args.graph:
+            net.configure(graph_max_patches=1 << 20)
+            with torch.no_grad():   # untimed set-up: large bags bind a graph to their buffer on the second sighting
+                for _ in range(2):
+                    for b in bags:
+                        net(b)
 
         def step(i):
             with torch.no_grad():
@@ -252,6 +261,7 @@ def main():
                                    % (args.workload, "train step (fwd+bwd+AdamW+all-reduce)" if args.mode == "train" else
                                       "eval forward", N, D, h, lam, K),
                        "parallelism": "bag-parallel x%d" % world, "bags_resident_per_rank": nbags,
+                       "launch": "hip graph replay" if (args.graph and args.mode == "eval") else "eager",
                        "model_tflops_per_s": round(flops_fwd * (3 if args.mode == "train" else 1) * world * args.steps
                                                    / elapsed / 1e12, 2)},
         }

@@ -250,14 +250,81 @@ class MILNet(nn.Module):
         self.i_classifier = i_classifier
         self.b_classifier = b_classifier
 
-    def configure(self, precision=None, return_attention=None):
+    def configure(self, precision=None, return_attention=None, graph_max_patches=None):
+        """graph_max_patches (opt-in, default off): inference forwards of bags with at most that many patches are captured
+        into HIP graphs and replayed -- a bag is ~25 kernel launches, ~0.24 ms of host-side issue, more than the GPU time of
+        a bag of <= 8k patches and, on a slow host, of larger ones.  Same kernels, bit-identical results.  Small bags
+        (<= 32 MB) are captured once per shape behind a static input buffer; larger ones are bound to their own buffer the
+        second time the same tensor comes in (a dataset resident in HBM), so nothing is copied.  Only for the
+        deterministic selection (random_patch_share == 0: the random share draws from numpy on the host), outside autograd."""
         self.b_classifier.configure(precision, return_attention)
+        if graph_max_patches is not None:
+            self._graph_max_patches = int(graph_max_patches)
+            self._graphs, self._graph_seen, self._graph_pool = {}, set(), None
         return self
 
     def forward(self, x):
+        if self._graph_ok(x):
+            return self._forward_graph(x)
+        return self._forward_eager(x)
+
+    def _forward_eager(self, x):
         feats, classes = self._critic(x)
         prediction_bag, A = self.b_classifier(feats, classes)
         return classes, prediction_bag, A
+
+    _GRAPH_SHAPES = 64            # captured graphs kept per model (oldest dropped first); they share one memory pool
+    _GRAPH_COPY_BYTES = 32 << 20  # bags up to this size go through a static input buffer (one copy per forward)
+
+    def _graph_ok(self, x):
+        lim = getattr(self, "_graph_max_patches", 0)
+        if lim <= 0 or self.training or torch.is_grad_enabled():
+            return False
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 3 and x.shape[0] == 1 and x.dtype == torch.float32
+                and x.is_contiguous() and 0 < x.shape[1] <= lim and type(self.i_classifier) is FCLayer):
+            return False
+        if self.b_classifier.cfg.return_attention and x.numel() * 4 > self._GRAPH_COPY_BYTES:
+            return False   # the [1, h, N, K] attention tensor would be cloned out of the graph's pool on every forward
+        return all(getattr(l, "random_patch_share", 1) == 0 for l in self.b_classifier.encoder.layers)
+
+    def _forward_graph(self, x):
+        cfg = self.b_classifier.cfg
+        small = x.numel() * 4 <= self._GRAPH_COPY_BYTES
+        key = (tuple(x.shape), x.device, cfg.precision, cfg.return_attention) + (() if small else (x.data_ptr(),))
+        ent = self._graphs.get(key)
+        if ent is None:
+            if not small and key not in self._graph_seen:   # bind a graph to a large buffer only once it comes back
+                if len(self._graph_seen) > 8192:
+                    self._graph_seen.clear()
+                self._graph_seen.add(key)
+                return self._forward_eager(x)
+            try:
+                static_x = torch.empty_like(x).copy_(x) if small else x
+                cur = torch.cuda.current_stream()
+                side = torch.cuda.Stream()
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):   # warm-up off the capture: kernel attributes, library handles, weight folds
+                    for _ in range(2):
+                        self._forward_eager(static_x)
+                cur.wait_stream(side)
+                if self._graph_pool is None:
+                    self._graph_pool = torch.cuda.graph_pool_handle()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, pool=self._graph_pool):
+                    out = self._forward_eager(static_x)
+            except Exception:   # capture not possible here: stay on the eager path for good
+                self._graph_max_patches = 0
+                torch.cuda.synchronize()
+                return self._forward_eager(x)
+            if len(self._graphs) >= self._GRAPH_SHAPES:
+                self._graphs.pop(next(iter(self._graphs)))
+            ent = self._graphs[key] = (graph, static_x, out)
+        graph, static_x, out = ent
+        if small:
+            static_x.copy_(x)
+        graph.replay()
+        # the graphs share one pool: the outputs are only valid until the next replay, so hand out copies
+        return tuple(o.clone() if isinstance(o, torch.Tensor) else o for o in out)
 
     def _critic(self, x):
         """i_classifier(x); in the bf16 inference path of a plain FCLayer critic the same pass over the bag also produces

@@ -217,3 +217,41 @@ def test_fused_critic_layernorm_pass_changes_nothing():
         logits3, _ = net.b_classifier(x, c3)
         logits4, _ = net.b_classifier(x, c3)
     assert torch.equal(logits3, logits4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_graph_replay_equals_eager(precision):
+    """MILNet.configure(graph_max_patches=...): HIP-graph replay of the inference forward is the same kernels on the same
+    data -- bit-identical outputs; small bags share one graph per shape (static input buffer), a large bag gets its own
+    graph the second time the same tensor comes in; the random patch share (host RNG) keeps the eager path."""
+    import torch
+    from tests.helpers import build_amd_milnet
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    net = build_amd_milnet(384, 6, "relu", 200, 0.0, 1).to(dev).eval().configure(precision=precision, return_attention=False)
+    g = torch.Generator().manual_seed(3)
+    small = [torch.randn(1, n, 384, generator=g).to(dev) for n in (700, 700, 3000, 700)]
+    large = torch.randn(1, 30000, 384, generator=g).to(dev)          # 46 MB: bound to its buffer, no copy
+    with torch.no_grad():
+        ref_s = [net(b) for b in small]
+        ref_l = net(large)
+        net.configure(graph_max_patches=100000)
+        for _ in range(3):
+            for b, r in zip(small, ref_s):
+                out = net(b)
+                assert torch.equal(out[0], r[0]) and torch.equal(out[1], r[1]) and out[2] is None
+            out = net(large)
+            assert torch.equal(out[0], ref_l[0]) and torch.equal(out[1], ref_l[1])
+        assert len(net._graphs) == 3                                  # 700, 3000 (by shape) and the large buffer
+        large.mul_(0.5)                                               # same buffer, new contents: the graph reads it live
+        net.configure(graph_max_patches=0)
+        ref2 = net(large)
+        net.configure(graph_max_patches=100000)
+        net(large)
+        out = net(large)
+        assert torch.equal(out[1], ref2[1])
+    rnd = build_amd_milnet(384, 6, "relu", 200, 0.5, 1).to(dev).eval().configure(precision=precision, graph_max_patches=100000)
+    with torch.no_grad():
+        rnd(small[0])
+    assert len(rnd._graphs) == 0
