@@ -273,7 +273,7 @@ class MILNet(nn.Module):
         prediction_bag, A = self.b_classifier(feats, classes)
         return classes, prediction_bag, A
 
-    _GRAPH_SHAPES = 64            # captured graphs kept per model (oldest dropped first); they share one memory pool
+    _GRAPH_SHAPES = 1024          # captured graphs kept per model (oldest dropped first); they share one memory pool
     _GRAPH_COPY_BYTES = 32 << 20  # bags up to this size go through a static input buffer (one copy per forward)
 
     def _graph_ok(self, x):
