@@ -310,7 +310,8 @@ class MILNet(nn.Module):
                 if self._graph_pool is None:
                     self._graph_pool = torch.cuda.graph_pool_handle()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, pool=self._graph_pool):
+                # thread_local: a helper thread of the process (e.g. the RCCL watchdog) may touch the runtime meanwhile
+                with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
                     out = self._forward_eager(static_x)
             except Exception:   # capture not possible here: stay on the eager path for good
                 self._graph_max_patches = 0
