@@ -152,7 +152,16 @@ def cpu_baseline(wl, budget_s=25.0):
             el = time.perf_counter() - t0
             if el > budget_s or n >= 20:
                 break
-    return dict(value=round(n / el, 4), unit="slides/s", cores=cores, kind="port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return dict(value=round(n / el, 4), unit="slides/s", cores=cores, kind="port", cpu_model=cpu_model,
                 sample="%d eval forwards of one synthetic bag N=%d D=%d (oracle/snuffy_oracle.py, torch-CPU fp32, %d threads)"
                        % (n, N, D, cores))
 
