@@ -95,10 +95,28 @@ __global__ __launch_bounds__(WG) void critic_kernel(const float* __restrict__ x,
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const float inv_d = 1.0f / (float)d;
-    for (int64_t row = (int64_t)blockIdx.x * WAVES + wave; row < n; row += (int64_t)gridDim.x * WAVES) {
+    // class-0 weights stay in registers (the usual critic has ONE output), and the next row of x is requested before the
+    // current one is reduced: the pass is bound by one HBM round trip per row and wave, not by bytes
+    float w0[NV * VEC];
+    load_row<VEC, NV>(w, d, lane, w0);
+    const float b0 = b ? b[0] : 0.f;
+    const int64_t rstride = (int64_t)gridDim.x * WAVES;
+    float nx[NV * VEC];
+    int64_t row = (int64_t)blockIdx.x * WAVES + wave;
+    if (row < n) load_row<VEC, NV>(x + row * d, d, lane, nx);
+    for (; row < n; row += rstride) {
         float r[NV * VEC];
-        load_row<VEC, NV>(x + row * d, d, lane, r);
-        for (int c = 0; c < c_out; ++c) {
+#pragma unroll
+        for (int i = 0; i < NV * VEC; ++i) r[i] = nx[i];
+        if (row + rstride < n) load_row<VEC, NV>(x + (row + rstride) * d, d, lane, nx);   // wave-uniform
+        {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV * VEC; ++i) acc = fmaf(r[i], w0[i], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) scores[row * c_out] = acc + b0;
+        }
+        for (int c = 1; c < c_out; ++c) {
             float wr[NV * VEC];
             load_row<VEC, NV>(w + (int64_t)c * d, d, lane, wr);
             float acc = 0.f;
@@ -454,10 +472,44 @@ __global__ __launch_bounds__(WG) void ln_colsum_kernel(const float* __restrict__
     float bias_r[NV * VEC];
     if (add_bias) load_row<VEC, NV>(add_bias, d, lane, bias_r);
     const float inv_d = 1.0f / (float)d;
-    for (int64_t row = (int64_t)blockIdx.x * WAVES + wave; row < n; row += (int64_t)gridDim.x * WAVES) {
+    // The pass is latency-bound (PMC: waves parked on vmcnt 79 % of their cycles, one row = one HBM round trip per trip):
+    // the NEXT row's loads (f32 base + raw bf16 addend) are issued before the current row is reduced, so every wave keeps
+    // two rows in flight.  Rows are consumed in the same order as before -> bit-identical sums.
+    const int64_t rstride = (int64_t)gridDim.x * WAVES;
+    float nz[NV * VEC];     // prefetched base row
+    uint2 nb[NV];           // prefetched raw bf16 addend (VEC == 4 only)
+    auto issue = [&](int64_t row) __attribute__((always_inline)) {
+        load_row<VEC, NV>(z + row * d, d, lane, nz);
+        if constexpr (VEC == 4) {
+            if (add_bf16) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int e = (i * 64 + lane) * 4;
+                    nb[i] = (e < d) ? *reinterpret_cast<const uint2*>(add_bf16 + row * d + e) : make_uint2(0u, 0u);
+                }
+            }
+        }
+    };
+    int64_t row = (int64_t)blockIdx.x * WAVES + wave;
+    if (row < n) issue(row);
+    for (; row < n; row += rstride) {
         float r[NV * VEC];
-        load_row<VEC, NV>(z + row * d, d, lane, r);
-        if (add_bf16) add_row_bf16<VEC, NV>(add_bf16 + row * d, d, lane, r);
+#pragma unroll
+        for (int i = 0; i < NV * VEC; ++i) r[i] = nz[i];
+        if constexpr (VEC == 4) {
+            if (add_bf16) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    r[i * 4 + 0] += __uint_as_float(nb[i].x << 16);
+                    r[i * 4 + 1] += __uint_as_float(nb[i].x & 0xffff0000u);
+                    r[i * 4 + 2] += __uint_as_float(nb[i].y << 16);
+                    r[i * 4 + 3] += __uint_as_float(nb[i].y & 0xffff0000u);
+                }
+            }
+        } else {
+            if (add_bf16) add_row_bf16<VEC, NV>(add_bf16 + row * d, d, lane, r);
+        }
+        if (row + rstride < n) issue(row + rstride);   // wave-uniform
         if (add_bias) {
 #pragma unroll
             for (int i = 0; i < NV * VEC; ++i) r[i] += bias_r[i];
