@@ -244,6 +244,14 @@ def test_graph_replay_equals_eager(precision):
             out = net(large)
             assert torch.equal(out[0], ref_l[0]) and torch.equal(out[1], ref_l[1])
         assert len(net._graphs) == 3                                  # 700, 3000 (by shape) and the large buffer
+        # the graphs share one memory pool, so what forward() hands out are copies: they survive later replays
+        large2 = torch.randn(1, 31000, 384, generator=g).to(dev)
+        held = net(large)
+        for _ in range(2):
+            net(large2)
+            for b in small:
+                net(b)
+        assert torch.equal(held[0], ref_l[0]) and torch.equal(held[1], ref_l[1])
         large.mul_(0.5)                                               # same buffer, new contents: the graph reads it live
         net.configure(graph_max_patches=0)
         ref2 = net(large)
