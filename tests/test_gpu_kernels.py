@@ -204,7 +204,8 @@ def bf16r(t):
 @pytest.mark.parametrize("n,k,h,dk", [(1, 1, 1, 64), (100, 31, 2, 64), (128, 32, 6, 64), (129, 33, 3, 128),
                                       (1000, 64, 6, 128), (4099, 100, 6, 64), (2500, 200, 6, 128), (3000, 224, 2, 128),
                                       (777, 256, 6, 64), (1500, 224, 1, 128), (1500, 250, 1, 64), (8192, 200, 6, 64), (640, 129, 4, 128),
-                                      (1500, 250, 1, 128), (3000, 512, 6, 128), (2000, 600, 2, 64), (700, 1792, 1, 128)])
+                                      (1500, 250, 1, 128), (3000, 512, 6, 128), (2000, 600, 2, 64), (700, 1792, 1, 128),
+                                      (300, 7, 12, 64), (897, 65, 1, 128), (127, 1, 4, 128), (2049, 193, 5, 64)])
 def test_sparse_attn_mfma(n, k, h, dk, dt):
     g = torch.Generator().manual_seed(n * 3 + k)
     d = h * dk
