@@ -287,7 +287,20 @@ class MILNet(nn.Module):
             return False   # the [1, h, N, K] attention tensor would be cloned out of the graph's pool on every forward
         return all(getattr(l, "random_patch_share", 1) == 0 for l in self.b_classifier.encoder.layers)
 
+    def _weights_signature(self):
+        """Changes whenever a parameter is written in place (optimizer step, load_state_dict) or replaced (.to(), .half())."""
+        plist = getattr(self, "_graph_params", None)
+        if plist is None or len(plist) != sum(1 for _ in self.parameters()):
+            plist = self._graph_params = list(self.parameters())
+        return tuple(p._version for p in plist), tuple(p.data_ptr() for p in plist[:2])
+
     def _forward_graph(self, x):
+        # a captured graph has the folded bf16 weights of its capture baked in: new weights -> new graphs
+        sig = self._weights_signature()
+        if sig != getattr(self, "_graph_sig", None):
+            self._graphs.clear()
+            self._graph_seen.clear()
+            self._graph_sig = sig
         cfg = self.b_classifier.cfg
         small = x.numel() * 4 <= self._GRAPH_COPY_BYTES
         key = (tuple(x.shape), x.device, cfg.precision, cfg.return_attention) + (() if small else (x.data_ptr(),))

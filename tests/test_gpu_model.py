@@ -259,6 +259,16 @@ def test_graph_replay_equals_eager(precision):
         net(large)
         out = net(large)
         assert torch.equal(out[1], ref2[1])
+    # new weights invalidate the captured graphs (they hold the folded bf16 copies of the old ones)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.mul_(1.01)
+        net.configure(graph_max_patches=0)
+        ref3 = net(small[0])
+        net.configure(graph_max_patches=100000)
+        net(small[0])
+        out = net(small[0])
+        assert torch.equal(out[1], ref3[1]) and torch.equal(out[0], ref3[0])
     rnd = build_amd_milnet(384, 6, "relu", 200, 0.5, 1).to(dev).eval().configure(precision=precision, graph_max_patches=100000)
     with torch.no_grad():
         rnd(small[0])
