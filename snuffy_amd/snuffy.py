@@ -288,11 +288,13 @@ class MILNet(nn.Module):
         return all(getattr(l, "random_patch_share", 1) == 0 for l in self.b_classifier.encoder.layers)
 
     def _weights_signature(self):
-        """Changes whenever a parameter is written in place (optimizer step, load_state_dict) or replaced (.to(), .half())."""
+        """Changes whenever a parameter is written in place (optimizer step, load_state_dict) or replaced (.to(), .half()),
+        or a selection knob of a layer is reassigned."""
         plist = getattr(self, "_graph_params", None)
         if plist is None or len(plist) != sum(1 for _ in self.parameters()):
             plist = self._graph_params = list(self.parameters())
-        return tuple(p._version for p in plist), tuple(p.data_ptr() for p in plist[:2])
+        knobs = tuple((l.big_lambda, l.random_patch_share) for l in self.b_classifier.encoder.layers)
+        return tuple(p._version for p in plist), tuple(p.data_ptr() for p in plist[:2]), knobs
 
     def _forward_graph(self, x):
         # a captured graph has the folded bf16 weights of its capture baked in: new weights -> new graphs
