@@ -80,7 +80,7 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
     # Q and V as the model produces them: the two column halves of one fused projection output [N, 2D]
     qvs = [torch.randn(N, 2 * D, generator=g).to(device).to(dt) for _ in range(nset)]
     state = {"i": 0}
-    if ops.mfma_attn_supported(K, dk):
+    if precision == "bf16" and ops.mfma_attn_supported(K, dk):   # what functional.encoder_layer dispatches for this precision
         def attn():
             i = state["i"] = (state["i"] + 1) % nset
             ops.sparse_attn_fwd_mfma(qvs[i][:, :D], qvs[i][:, D:], kp_in, N, h)
@@ -102,11 +102,14 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
     # HBM-side bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE; tools/pmc_traffic.sh), recorded
     # for exactly this workload under profiles/ -- counters cannot be collected inside a timed run
     traffic = None
-    tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_attn_traffic_%s_%s.json"
-                         % (wl_name, precision))
-    if kern.startswith("sparse_attn_mfma") and os.path.exists(tfile):
-        with open(tfile) as f:
-            traffic = int(json.load(f)["total_bytes"])
+    import glob
+    tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                           "r*_attn_traffic_%s_%s.json" % (wl_name, precision))))
+    if tfiles:   # newest round's PMC record for this workload / precision
+        with open(tfiles[-1]) as f:
+            rec = json.load(f)
+        if rec.get("kernel", kern) == kern:
+            traffic = int(rec["total_bytes"])
     # `achieved` / `frac` price the launch at the bytes it has to move at ITS operand width (bf16 Q, V, Kp here).  SURVEY
     # section 8(d) prices the same unit at the reference's fp32 tensors (8ND + 8KD; with the selector 8ND + 4N + 16KD + 8K):
     # that figure is reported next to it as survey_8d_* -- same time, twice the bytes on the bf16 path.
@@ -129,7 +132,9 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
 
 
 def cpu_baseline(wl, budget_s=25.0):
-    """The CPU oracle (a torch-CPU port of the reference's op sequence) timed on this host's cores."""
+    """The CPU oracle (a torch-CPU port of the reference's op sequence; it materialises A like the reference) timed on this
+    host's cores.  More threads is not faster on a many-core host (round 1: 0.79 slides/s on 128 threads vs 1.7 on 8): the
+    thread count is swept and the best is reported with its count."""
     from oracle import snuffy_oracle as orc          # cpu_baseline leg: the only place bench.py touches oracle/
     N, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
     cores = os.cpu_count() or 1
@@ -138,20 +143,26 @@ def cpu_baseline(wl, budget_s=25.0):
         cores = psutil.cpu_count(logical=False) or cores
     except Exception:
         pass
-    torch.set_num_threads(cores)
     net = build_net(D, h, lam, "fp32", "cpu")
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
     x = torch.randn(N, D, generator=torch.Generator().manual_seed(1234))
+    sweep = sorted({t for t in (8, 16, 32, 64, 128, cores) if t <= cores} or {cores})
+    per = budget_s / len(sweep)
+    rates, total_n, t_all = {}, 0, time.perf_counter()
     with torch.no_grad():
-        orc.milnet_forward(x, sd, h, "relu", lam, 0.0, 1)           # warm-up
-        t0 = time.perf_counter()
-        n = 0
-        while True:
-            orc.milnet_forward(x, sd, h, "relu", lam, 0.0, 1)
-            n += 1
-            el = time.perf_counter() - t0
-            if el > budget_s or n >= 20:
-                break
+        for thr in sweep:
+            torch.set_num_threads(thr)
+            orc.milnet_forward(x, sd, h, "relu", lam, 0.0, 1)           # warm-up at this thread count
+            t0, n = time.perf_counter(), 0
+            while True:
+                orc.milnet_forward(x, sd, h, "relu", lam, 0.0, 1)
+                n += 1
+                el = time.perf_counter() - t0
+                if el > per * 0.7 or n >= 8:
+                    break
+            rates[thr] = n / el
+            total_n += n + 1
+    best = max(rates, key=rates.get)
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -161,9 +172,11 @@ def cpu_baseline(wl, budget_s=25.0):
                     break
     except OSError:
         pass
-    return dict(value=round(n / el, 4), unit="slides/s", cores=cores, kind="port", cpu_model=cpu_model,
-                sample="%d eval forwards of one synthetic bag N=%d D=%d (oracle/snuffy_oracle.py, torch-CPU fp32, %d threads)"
-                       % (n, N, D, cores))
+    return dict(value=round(rates[best], 4), unit="slides/s", cores=best, kind="port", cpu_model=cpu_model,
+                physical_cores=cores, thread_sweep={str(k): round(v, 4) for k, v in rates.items()},
+                sample="%d eval forwards (A materialised, as the reference does) of one synthetic bag N=%d D=%d in %.0f s: "
+                       "oracle/snuffy_oracle.py, torch-CPU fp32, threads swept over %s, best = %d threads"
+                       % (total_n, N, D, time.perf_counter() - t_all, sweep, best))
 
 
 def main():
@@ -181,6 +194,9 @@ def main():
                          "(MILNet.configure(graph_max_patches=...)).  Same kernels and bit-identical results either way; the "
                          "replay removes ~0.24 ms of host-side issue per bag: +50 %% and more for bags of <= 8k patches, "
                          "within 1 %% for config B on a fast host, +15 %% on a slow one")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="time only --precision (default: the other precision and the A-materialising forward are timed as "
+                         "well and reported as value_f32 / value_bf16 / value_with_attention_output)")
     ap.add_argument("--gemm-table", action="store_true",
                     help="apply snuffy_amd/tuning/gemm_gfx950.csv (library-GEMM selections; helps the training shapes, "
                          "nothing measurable for the eval forward)")
@@ -205,7 +221,6 @@ def main():
 
     wl = WORKLOADS[args.workload]
     N, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
-    net = build_net(D, h, lam, args.precision, device)
     # bags resident in HBM before the timed region; several distinct bags per rank, cycled
     if "bags" in wl:
         import numpy as np
@@ -222,72 +237,115 @@ def main():
         bags = [torch.randn(1, N, D, generator=g).to(device) for _ in range(nbags)]
     labels = [torch.tensor([float(i % 2)], device=device) for i in range(nbags)]
 
-    if args.mode == "train":
-        from snuffy_amd.train import BagParallelStepper
-        stepper = BagParallelStepper(net, world_size=world, dist=dist, device=device, precision=args.precision)
+    def measure(precision, return_attention=False, steps=None, warmup=None, use_graph=None):
+        """Times `steps` steps of one configuration (barrier + synchronize on both sides, max over ranks).
+        Returns (elapsed seconds, per-rank seconds, launch mode)."""
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
+        use_graph = args.graph if use_graph is None else use_graph
+        net = build_net(D, h, lam, precision, device)
+        net.configure(return_attention=return_attention)
+        launch = "eager"
+        if args.mode == "train":
+            from snuffy_amd.train import BagParallelStepper
+            stepper = BagParallelStepper(net, world_size=world, dist=dist, device=device, precision=precision)
 
-        def step(i):
-            stepper.step(bags[i % nbags], labels[i % nbags])
-    else:
-        net.eval()
-        if args.graph:
-            with torch.no_grad():   # untimed set-up: large bags bind a graph to their buffer on the second sighting
-                ref = net(bags[0])                       # eager reference of one bag
-                net.configure(graph_max_patches=1 << 20)
-                try:
-                    for _ in range(2):
-                        for b in bags:
-                            net(b)
-                    out = net(bags[0])
-                    same = torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
-                except Exception:
-                    same = False
-                if not same or not getattr(net, "_graphs", None):   # replay unavailable here: every kernel issued from Python
-                    net.configure(graph_max_patches=0)
-                    args.graph = False
-            torch.cuda.synchronize()
+            def step(i):
+                stepper.step(bags[i % nbags], labels[i % nbags])
+        else:
+            net.eval()
+            if use_graph:
+                with torch.no_grad():   # untimed set-up: large bags bind a graph to their buffer on the second sighting
+                    ref = net(bags[0])                       # eager reference of one bag
+                    net.configure(graph_max_patches=1 << 20)
+                    try:
+                        for _ in range(2):
+                            for b in bags:
+                                net(b)
+                        out = net(bags[0])
+                        same = torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+                    except Exception:
+                        same = False
+                    if not same or not getattr(net, "_graphs", None):   # replay unavailable: kernels issued from Python
+                        net.configure(graph_max_patches=0)
+                    else:
+                        launch = "hip graph replay"
+                torch.cuda.synchronize()
 
-        def step(i):
-            with torch.no_grad():
-                net(bags[i % nbags])
+            def step(i):
+                with torch.no_grad():
+                    net(bags[i % nbags])
 
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        torch.cuda.synchronize()
+        mine_s = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        per_rank = [mine_s]
+        if dist is not None:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            allr = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(allr, torch.tensor([mine_s], device=device, dtype=torch.float64))
+            per_rank = [float(v.item()) for v in allr]
+        del net
+        return elapsed, per_rank, launch
+
+    elapsed, per_rank, launch = measure(args.precision)            # the headline leg: EXACTLY args.steps timed steps
+    extra = {}
+    if not args.headline_only:
+        # the reference's own arithmetic (fp32) next to the bf16 headline (or the other way round), same bags, same loop
+        other = "fp32" if args.precision == "bf16" else "bf16"
+        steps_o = args.steps if args.mode == "eval" else max(3, args.steps // 3)
+        e2, _, l2 = measure(other, steps=steps_o, warmup=min(args.warmup, 3))
+        extra[other] = dict(elapsed=e2, steps=steps_o, launch=l2)
+        if args.mode == "eval":
+            # the reference's MILNet.forward always materialises A [1, h, N, K] (157 MB at config B); the trainer discards it
+            # (train.py:830) and so does the headline -- this is the same forward with A written out
+            e3, _, l3 = measure(args.precision, return_attention=True, warmup=min(args.warmup, 3))
+            extra["with_A"] = dict(elapsed=e3, steps=args.steps, launch=l3)
 
     if rank == 0:
         K = min(lam, N)
         flops_fwd = 20 * N * D * D + 4 * N * K * D + 4 * K * D * D
+        dt_name = {"bf16": "bf16", "fp32": "f32"}
         line = {
             "metric": "slides/sec", "value": round(world * args.steps / elapsed, 3), "unit": "slides/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dt_name[args.precision], "data": "synthetic",
             "config": {"workload": "%s: MILNet %s, 1 bag/step/rank, N=%d patches D=%d h=%d Lambda=%d (K=%d) depth=1 relu mlp x4"
                                    % (args.workload, "train step (fwd+bwd+AdamW+all-reduce)" if args.mode == "train" else
                                       "eval forward", N, D, h, lam, K),
                        "parallelism": "bag-parallel x%d" % world, "bags_resident_per_rank": nbags,
-                       "launch": "hip graph replay" if (args.graph and args.mode == "eval") else "eager",
+                       "launch": launch, "rccl_ranks": world if dist is not None else 0,
+                       "per_rank_slides_per_s": [round(args.steps / t, 2) for t in per_rank],
                        "model_tflops_per_s": round(flops_fwd * (3 if args.mode == "train" else 1) * world * args.steps
                                                    / elapsed / 1e12, 2)},
         }
+        for key, rec in extra.items():
+            if key == "with_A":
+                line["value_with_attention_output"] = round(world * rec["steps"] / rec["elapsed"], 3)
+            else:
+                line["value_" + dt_name[key]] = round(world * rec["steps"] / rec["elapsed"], 3)
+                line["ms_per_step_" + dt_name[key]] = round(rec["elapsed"] / rec["steps"] * 1e3, 4)
         if not args.no_roofline:   # rank 0 only, after the timed region (the other ranks wait at the closing barrier)
             line.update(kernel_rooflines(wl, args.precision, device, args.workload))
+            if not args.headline_only:
+                other = "fp32" if args.precision == "bf16" else "bf16"
+                for k, v in kernel_rooflines(wl, other, device, args.workload).items():
+                    line[k + "_" + dt_name[other]] = v
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(line), flush=True)

@@ -65,13 +65,13 @@ int snf_critic_ln_f32(const float* x, int64_t n, int d, const float* w, const fl
  * K2  top-k patch selector                    replaces torch.sort(c,1,descending=True)[:k], snuffy.py:128-130
  *   scores: n values at stride `stride` (elements).  idx_out [k] int64: the k largest, in descending score
  *   order, ties by ascending index (== torch.sort(stable=True, descending=True)[:k]); -0.0 == +0.0; NaN sorts
- *   first like torch.  Requires 1 <= k <= n, k <= SNF_TOPK_MAX_K.  Chunked bitonic sort of 64-bit (score,index)
- *   composites in LDS, repeated on the survivors (integer compare-exchange only: bit-exact on every run).
+ *   first like torch.  Requires 1 <= k <= n, k <= SNF_TOPK_MAX_K.  One-workgroup radix select on the orderable 32-bit keys (three counting
+ *   passes over register-resident keys, LDS integer atomics) + rank sort of the survivors: exact, deterministic.
  * K4  fused gather  xs[j,:] = x[idx[j],:]      replaces index_select/cat, snuffy.py:131,145-147,103-106
  *   snf_topk_gather_f32 = selector then gather in one call (x, xs nullable -> selector only).
  * --------------------------------------------------------------------------------------------------------- */
 #define SNF_TOPK_MAX_K 2048
-size_t snf_topk_workspace_bytes(int64_t n, int k); /* 0 when n <= 4096 */
+size_t snf_topk_workspace_bytes(int64_t n, int k); /* bytes the selector needs for this shape (may be 0) */
 int snf_topk_f32(const float* scores, int64_t n, int64_t stride, int k, int64_t* idx_out, void* workspace,
                  size_t workspace_bytes, snf_stream_t stream);
 int snf_topk_gather_f32(const float* scores, int64_t n, int64_t stride, int k, int64_t* idx_out, const float* x,

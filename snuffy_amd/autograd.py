@@ -1,9 +1,9 @@
 """Training path of the Snuffy aggregator (loss.backward() of reference train.py:259).
 
-Round-1 status: the FORWARD of every custom op runs on the hand-written HIP kernels; the BACKWARD of those
-ops is composed from library GPU ops (torch.bmm / elementwise) inside ``torch.autograd.Function`` -- the hand-written
-backward kernels (K7-bwd: recompute P, stream dQ/dV, reduce dKp) are the next item.  Dense projections are library GEMMs
-with torch's own autograd.  Everything stays on the GPU; nothing here touches the CPU oracle.
+The FORWARD of every custom op runs on the hand-written HIP kernels.  The attention BACKWARD is hand-written too
+(snf_sparse_attn_bwd_f32 exact, snf_sparse_attn_bwd_mfma on the matrix cores: P recomputed from the saved log-sum-exp, dQ /
+dV streamed, dKp reduced); the LayerNorm backward and the dense projections are library GPU ops inside / next to the
+``torch.autograd.Function``s below.  Everything stays on the GPU; nothing here touches the CPU oracle.
 
 Semantics follow the reference in train mode:
   * attention dropout p = MultiHeadedAttention.dropout.p (0.1 -- train.py:866-869 never overrides it) on P, snuffy.py:166-167

@@ -66,29 +66,31 @@ def critic_scores(feats, w, b):
     return s.view(*lead, w.shape[0])
 
 
+def _needs_grad(*tensors):
+    """True when autograd has to see this op: grad mode on and some input / parameter asks for a gradient."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
 # bf16 eval path: the critic pass can hand the first encoder layer its normalised input (one read of the bag instead of
-# two).  The hand-over is keyed on the bag's storage and version and consumed at most once.
-_xhat_offer = None
-
-
-def critic_scores_with_xhat(feats, w, b, eps):
-    """critic_scores() that also leaves xhat = (x - mean) * rstd (bf16) for encoder_layer()'s bf16 path."""
-    global _xhat_offer
+# two).  The hand-over lives on the receiving layer object, is keyed on the bag's storage and version and is consumed at
+# most once.
+def critic_scores_with_xhat(feats, w, b, eps, layer):
+    """critic_scores() that also leaves xhat = (x - mean) * rstd (bf16) on `layer` for encoder_layer()'s bf16 path."""
     lead = feats.shape[:-1]
     f2 = feats.reshape(-1, feats.shape[-1])
     if not f2.is_cuda:
         raise SnuffyHipError("input must be a GPU tensor: snuffy_amd has no CPU fallback")
     if f2.dtype != torch.float32 or not f2.is_contiguous():
-        _xhat_offer = None
+        layer._xhat_offer = None
         return critic_scores(feats, w, b)             # a converted copy would not be the tensor the encoder sees
     s, xhat = ops.critic_ln(f2, w, b, eps)
-    _xhat_offer = (f2.data_ptr(), tuple(f2.shape), f2._version, float(eps), xhat)
+    layer._xhat_offer = (f2.data_ptr(), tuple(f2.shape), f2._version, float(eps), xhat)
     return s.view(*lead, w.shape[0])
 
 
-def _take_xhat(x2, eps):
-    global _xhat_offer
-    offer, _xhat_offer = _xhat_offer, None
+def _take_xhat(layer, x2, eps):
+    offer = getattr(layer, "_xhat_offer", None)
+    layer._xhat_offer = None
     if offer is not None and offer[:4] == (x2.data_ptr(), tuple(x2.shape), x2._version, float(eps)):
         return offer[4]
     return None
@@ -106,6 +108,9 @@ def gather(x2, idx):
 
 
 def layer_norm(x2, norm):
+    if _needs_grad(x2, norm.weight, norm.bias):
+        from . import autograd as SA
+        return SA.LayerNormRowsFn.apply(x2, norm.weight, norm.bias, norm.eps)
     return ops.layernorm_rows(x2, norm.weight, norm.bias, norm.eps)
 
 
@@ -116,10 +121,12 @@ def act_name(ff):
 # ----------------------------------------------------------------------------------------------------------------------
 # attention building blocks (API-fidelity entry points)
 # ----------------------------------------------------------------------------------------------------------------------
+def _drop_p(dropout):
+    return float(dropout.p) if dropout is not None and getattr(dropout, "training", False) else 0.0
+
+
 def attention_4d(query, key, value, dropout=None):
-    """attention() of snuffy.py:160-168 on [1, h, N, dk] tensors."""
-    if dropout is not None and getattr(dropout, "training", False) and getattr(dropout, "p", 0.0) > 0:
-        raise NotImplementedError("attention dropout inside the fused kernel is not implemented yet")
+    """attention() of snuffy.py:160-168 on [1, h, N, dk] tensors (dropout: an nn.Dropout module, active in train mode)."""
     b, h, n, dk = query.shape
     if b != 1:
         raise IndexError("single bag only")
@@ -127,23 +134,39 @@ def attention_4d(query, key, value, dropout=None):
     q2 = query[0].transpose(0, 1).reshape(n, h * dk).contiguous()
     k2 = key[0].transpose(0, 1).reshape(k, h * dk).contiguous()
     v2 = value[0].transpose(0, 1).reshape(n, h * dk).contiguous()
-    out, attn, _ = ops.sparse_attn_fwd(q2, k2, v2, h, need_attn=True)
+    p_drop = _drop_p(dropout)
+    if p_drop > 0.0 or _needs_grad(query, key, value):
+        from . import autograd as SA
+        out, attn = SA.SparseAttnFn.apply(q2, k2, v2, h, p_drop, False)
+    else:
+        out, attn, _ = ops.sparse_attn_fwd(q2, k2, v2, h, need_attn=True)
     return out.view(k, h, dk).transpose(0, 1).unsqueeze(0), attn.unsqueeze(0)
 
 
 def mha_forward(mha, q_in, key_in, v_in, need_attn, precision):
-    """MultiHeadedAttention.forward (snuffy.py:183-205) on 2-D inputs; fp32 projections, exact attention kernel."""
+    """MultiHeadedAttention.forward (snuffy.py:183-205) on 2-D inputs; fp32 projections, exact attention kernel.  With grad
+    mode on (or the module in train mode: its dropout is active) the call goes through the autograd functions."""
     lq, lk, lv, lo = mha.linears
     q = F.linear(q_in, lq.weight, lq.bias)
     kp = F.linear(key_in, lk.weight, lk.bias)
     v = F.linear(v_in, lv.weight, lv.bias)
-    o, attn, _ = ops.sparse_attn_fwd(q, kp, v, mha.h, need_attn=need_attn)
+    p_drop = _drop_p(mha.dropout)
+    if p_drop > 0.0 or _needs_grad(q, kp, v):
+        from . import autograd as SA
+        o, attn = SA.SparseAttnFn.apply(q, kp, v, mha.h, p_drop, False)
+    else:
+        o, attn, _ = ops.sparse_attn_fwd(q, kp, v, mha.h, need_attn=need_attn)
     out = F.linear(o, lo.weight, lo.bias)
     return out, (attn.unsqueeze(0) if attn is not None else None)
 
 
 def ffn_forward(ff, x2, precision):
-    """PositionwiseFeedForward.forward (snuffy.py:224-225), eval semantics."""
+    """PositionwiseFeedForward.forward (snuffy.py:224-225); autograd / dropout semantics as the reference's module."""
+    p_drop = _drop_p(ff.dropout)
+    if p_drop > 0.0 or _needs_grad(x2, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias):
+        from . import autograd as SA
+        hid = SA._ACT[ff.activation_name](F.linear(x2, ff.w_1.weight, ff.w_1.bias))
+        return F.linear(ff.dropout(hid), ff.w_2.weight, ff.w_2.bias)
     hid = torch.mm(x2, ff.w_1.weight.t())
     ops.bias_act_(hid, ff.w_1.bias, ff.activation_name)
     return F.linear(hid, ff.w_2.weight, ff.w_2.bias)
@@ -186,21 +209,21 @@ def head(parts, norm, linear):
     return logits
 
 
-_fold_cache = {}
-
-
 def _folded(layer):
-    """bf16 path: LayerNorm affine folded into the following projection, cached until a parameter changes.
+    """bf16 path: LayerNorm affine folded into the following projection, cached ON THE LAYER until a parameter changes.
 
     LN(x) W^T + b = xhat (W * gamma)^T + (W beta + b)   with xhat = (x - mean) * rstd.
+    The cache key is (id, storage pointer, version counter) of every folded parameter: optimizer steps, load_state_dict and
+    parameter replacement refresh it.  An edit through ``p.data`` does not bump the version counter -- call
+    ``invalidate_folded(layer)`` (or ``MILNet.invalidate()``) after such an edit.
     """
     n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
     lq, lk, lv, lo = layer.self_attn.linears
     ff = layer.feed_forward
     plist = [n0.weight, n0.bias, n1.weight, n1.bias, lq.weight, lq.bias, lv.weight, lv.bias, ff.w_1.weight,
              ff.w_1.bias, ff.w_2.weight, lk.weight, lk.bias]
-    key = tuple((p.data_ptr(), p._version) for p in plist)
-    ent = _fold_cache.get(id(layer))
+    key = tuple((id(p), p.data_ptr(), p._version) for p in plist)
+    ent = getattr(layer, "_fold", None)
     if ent is not None and ent[0] == key:
         return ent[1]
     with torch.no_grad():
@@ -215,14 +238,20 @@ def _folded(layer):
             # key projection of the K raw selected rows (snuffy.py:190), bf16 operands like Q and V
             wk=lk.weight.to(torch.bfloat16).contiguous(), bk=lk.bias.to(torch.bfloat16).contiguous(),
         )
-    _fold_cache[id(layer)] = (key, out)
+    layer._fold = (key, out)
     return out
+
+
+def invalidate_folded(layer):
+    """Drop the layer's folded bf16 weights and any pending critic hand-over (after editing parameters through .data)."""
+    layer._fold = None
+    layer._xhat_offer = None
 
 
 def encoder_layer(x2, sel, layer, need_attn, precision):
     """EncoderLayer.forward (snuffy.py:126-157) for x2 [N, D] and selected rows sel [K].  Returns (Parts, A)."""
-    if torch.is_grad_enabled() and any(p.requires_grad for p in layer.parameters()):
-        from . import autograd as SA  # training path (custom backward kernels)
+    if torch.is_grad_enabled() and (x2.requires_grad or any(p.requires_grad for p in layer.parameters())):
+        from . import autograd as SA  # training path (custom backward kernels); also when only the input asks for a gradient
         return SA.encoder_layer_train(x2, sel, layer, need_attn, precision)
     n, d = x2.shape
     mha, ff = layer.self_attn, layer.feed_forward
@@ -264,7 +293,7 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
     if n0.eps != n1.eps:
         raise NotImplementedError("bf16 path shares one normalisation between both sublayers: eps must match")
     fw = _folded(layer)
-    xhat = _take_xhat(x2, n0.eps)                                                   # left by the critic pass, if any
+    xhat = _take_xhat(layer, x2, n0.eps)                                                 # left by the critic pass, if any
     if xhat is None:
         xhat = torch.empty(n, d, dtype=torch.bfloat16, device=x2.device)
         ops.layernorm_rows(x2, None, None, n0.eps, out=xhat)

@@ -27,10 +27,19 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _on_current_device(t, name):
+    """Kernels launch on torch's current stream of the CURRENT device: a tensor living on another GPU would be addressed from
+    the wrong device -- refuse loudly (wrap the call in ``torch.cuda.device(t.device)`` or call ``torch.cuda.set_device``)."""
+    if t.device.index != torch.cuda.current_device():
+        raise _ffi.SnuffyHipError("%s lives on %s but the current device is cuda:%d: select the tensor's device first "
+                                  "(torch.cuda.set_device / torch.cuda.device)" % (name, t.device, torch.cuda.current_device()))
+
+
 def _req(t, dtype, name, dim=None):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _ffi.SnuffyHipError(
             "%s must be a GPU tensor: snuffy_amd runs on MI355X only (no CPU fallback)" % name)
+    _on_current_device(t, name)
     if t.dtype != dtype:
         raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
     if dim is not None and t.dim() != dim:
@@ -345,6 +354,7 @@ def _req_nc(t, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _ffi.SnuffyHipError(
             "%s must be a GPU tensor: snuffy_amd runs on MI355X only (no CPU fallback)" % name)
+    _on_current_device(t, name)
     if t.dim() != 2:
         raise ValueError("%s must be 2-D, got shape %s" % (name, tuple(t.shape)))
     return t

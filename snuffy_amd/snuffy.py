@@ -285,16 +285,40 @@ class MILNet(nn.Module):
             return False
         if self.b_classifier.cfg.return_attention and x.numel() * 4 > self._GRAPH_COPY_BYTES:
             return False   # the [1, h, N, K] attention tensor would be cloned out of the graph's pool on every forward
-        return all(getattr(l, "random_patch_share", 1) == 0 for l in self.b_classifier.encoder.layers)
+        # only the binary model's deterministic selection can be captured (the multiclass layer and the random share
+        # synchronise with the host)
+        return all(type(l) is EncoderLayer and l.random_patch_share == 0 for l in self.b_classifier.encoder.layers)
 
     def _weights_signature(self):
-        """Changes whenever a parameter is written in place (optimizer step, load_state_dict) or replaced (.to(), .half()),
-        or a selection knob of a layer is reassigned."""
-        plist = getattr(self, "_graph_params", None)
-        if plist is None or len(plist) != sum(1 for _ in self.parameters()):
-            plist = self._graph_params = list(self.parameters())
+        """Changes whenever a parameter is written in place (optimizer step, load_state_dict), replaced (.to(), .half(),
+        load_state_dict(assign=True), module.weight = ...) or a selection knob of a layer is reassigned.  Not seen: edits
+        through ``p.data`` (they do not bump the version counter) -- call ``invalidate()`` after those."""
+        plist = list(self.parameters())
         knobs = tuple((l.big_lambda, l.random_patch_share) for l in self.b_classifier.encoder.layers)
-        return tuple(p._version for p in plist), tuple(p.data_ptr() for p in plist[:2]), knobs
+        return tuple((id(p), p.data_ptr(), p._version) for p in plist), knobs
+
+    def invalidate(self):
+        """Forget everything derived from the current weights: captured graphs and the folded bf16 weights of every layer."""
+        if getattr(self, "_graph_max_patches", 0):
+            self._graphs.clear()
+            self._graph_seen.clear()
+            self._graph_sig = None
+        for layer in self.b_classifier.encoder.layers:
+            SF.invalidate_folded(layer)
+        return self
+
+    _GRAPH_STATE = ("_graphs", "_graph_seen", "_graph_pool", "_graph_sig")
+
+    def __deepcopy__(self, memo):
+        """Captured HIP graphs belong to this instance's buffers: a copy starts without them."""
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in self._GRAPH_STATE:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        if getattr(self, "_graph_max_patches", 0):
+            new._graphs, new._graph_seen, new._graph_pool = {}, set(), None
+        return new
 
     def _forward_graph(self, x):
         # a captured graph has the folded bf16 weights of its capture baked in: new weights -> new graphs
@@ -328,7 +352,11 @@ class MILNet(nn.Module):
                 # thread_local: a helper thread of the process (e.g. the RCCL watchdog) may touch the runtime meanwhile
                 with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
                     out = self._forward_eager(static_x)
-            except Exception:   # capture not possible here: stay on the eager path for good
+            except Exception as exc:   # capture not possible here: stay on the eager path for good, and say so once
+                import warnings
+                warnings.warn("snuffy_amd: HIP-graph capture of the inference forward failed (%s: %s); graph replay is "
+                              "disabled for this model, every kernel is issued from Python" % (type(exc).__name__, exc),
+                              RuntimeWarning, stacklevel=2)
                 self._graph_max_patches = 0
                 torch.cuda.synchronize()
                 return self._forward_eager(x)
@@ -352,5 +380,5 @@ class MILNet(nn.Module):
                 and len(self.b_classifier.encoder.layers) > 0):
             lin = ic.fc[0]
             eps = self.b_classifier.encoder.layers[0].sublayer[0].norm.eps
-            return x, SF.critic_scores_with_xhat(x, lin.weight, lin.bias, eps)
+            return x, SF.critic_scores_with_xhat(x, lin.weight, lin.bias, eps, self.b_classifier.encoder.layers[0])
         return ic(x)

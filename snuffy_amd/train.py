@@ -24,8 +24,9 @@ import torch
 import torch.nn as nn
 from torch import optim
 
-from . import snuffy
-from .utils import OPTIMIZERS, WEIGHT_INITS, compute_pos_weight, dropout_patches
+from . import snuffy, snuffy_multiclass
+from .utils import (OPTIMIZERS, WEIGHT_INITS, compute_pos_weight, dropout_patches, dropout_patches_device,
+                    multi_label_roc)
 
 MIL_DATASETS = ('musk1', 'musk2', 'elephant', 'fox', 'tiger')
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
@@ -104,17 +105,65 @@ class FlatGradAllReduce:
             off += n
 
 
+class CosineWarmupScheduler(torch.optim.lr_scheduler.LambdaLR):
+    """Linear warm-up then cosine decay of the learning-rate factor.  The reference takes this class from the third-party
+    package lightly (requirements.txt: lightly==1.4.8, train.py:19,189-194), which is not vendored; restated from that
+    release's published rule: factor = (epoch + 1) / warmup while epoch < warmup, afterwards
+    end - (end - 1) * (cos(pi * step / (max_steps - 1)) + 1) / 2 with step = epoch - warmup, max_steps = max - warmup,
+    end = 0.001 (parity unpinned: no fixture of the package's output exists here)."""
+
+    def __init__(self, optimizer, warmup_epochs, max_epochs, last_epoch=-1, end_value=0.001):
+        self.warmup_epochs, self.max_epochs, self.end_value = warmup_epochs, max_epochs, end_value
+        super().__init__(optimizer, lr_lambda=self.scale_lr, last_epoch=last_epoch)
+
+    def scale_lr(self, epoch):
+        if epoch < self.warmup_epochs:
+            return (epoch + 1) / self.warmup_epochs
+        step, max_steps = epoch - self.warmup_epochs, self.max_epochs - self.warmup_epochs
+        if max_steps <= 1 or step >= max_steps:
+            return self.end_value
+        return self.end_value - (self.end_value - 1.0) * (np.cos(np.pi * step / (max_steps - 1)) + 1) / 2
+
+
 class Trainer:
     def __init__(self, args, dist=None, rank=0, world_size=1):
         self.args = args
         self.dist, self.rank, self.world_size = dist, rank, world_size
         self.milnet = self._get_milnet()
         self._load_init_weights()
+        self._sync_replicas()
         self._criterion_is_set = False
         self.criterion = self._get_criterion()
         self.optimizer = self._get_optimizer()
         self.scheduler = self._get_scheduler()
         self._grad_sync = FlatGradAllReduce(self._trainable(), dist, world_size)
+
+    def _sync_replicas(self):
+        """world_size > 1: every replica starts from rank 0's weights (the ranks may have been seeded differently)."""
+        if self.dist is None or self.world_size <= 1:
+            return
+        with torch.no_grad():
+            for t in self._replicated_tensors():
+                self.dist.broadcast(t, src=0)
+
+    def _replicated_tensors(self):
+        return [p.data for p in self.milnet.parameters()] + [b.data for b in self.milnet.buffers()]
+
+    def _epoch_order(self, num_bags, cur_epoch):
+        """Bag visiting order of one epoch.  One process: sklearn.utils.shuffle on the global numpy RNG, as the reference
+        (train.py:231-236).  Several ranks: the per-bag draws (dropout_patches, the random patch share) depend on each rank's
+        own bags, so the global RNG streams diverge after the first step; the order therefore comes from rank 0 (same draw on
+        the global RNG there) and is broadcast -- every bag of the epoch is visited exactly once across the ranks."""
+        from sklearn.utils import shuffle
+        if self.dist is None or self.world_size <= 1:
+            return shuffle(np.arange(num_bags))
+        order = torch.zeros(num_bags, dtype=torch.int64)
+        if self.rank == 0:
+            order = torch.from_numpy(np.ascontiguousarray(shuffle(np.arange(num_bags))).astype(np.int64))
+        dev = device if self.dist.get_backend() == "nccl" else torch.device("cpu")
+        order = order.to(dev)
+        self.dist.broadcast(order, src=0)
+        return order.cpu().numpy()
 
     # -- hooks (reference names) --------------------------------------------------------------------------------------
     def _get_milnet(self) -> nn.Module:
@@ -139,6 +188,10 @@ class Trainer:
         if self.args.scheduler == 'cosine':
             return torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=self.args.num_epochs,
                                                               eta_min=self.args.eta_min)
+        if self.args.scheduler == 'cosinewarmup':                                # train.py:189-194
+            return CosineWarmupScheduler(self.optimizer, warmup_epochs=int(self.args.num_epochs / 20),
+                                         max_epochs=self.args.num_epochs)
+        print('Scheduler set to None')
         return None
 
     def _load_init_weights(self):
@@ -174,10 +227,9 @@ class Trainer:
 
         feats entries are [N_i, D] numpy arrays (as utils.load_data returns them) or [1, N_i, D] device tensors
         (utils.stage_bags).  Bags are visited in a seeded shuffle; rank r takes positions r::world_size."""
-        from sklearn.utils import shuffle
         self.milnet.train()
         labels, feats = data[0], data[1]
-        order = shuffle(np.arange(len(labels)))                                 # consumes the global numpy RNG once
+        order = self._epoch_order(len(labels), cur_epoch)                       # consumes the global numpy RNG once
         if not self._criterion_is_set:
             pw = torch.tensor(compute_pos_weight(labels), device=device, dtype=torch.float32)
             self.criterion = nn.BCEWithLogitsLoss(pw)
@@ -193,6 +245,9 @@ class Trainer:
                 if self.args.l2normed_embeddings == 1:
                     f = f / np.linalg.norm(f, axis=1, keepdims=True)
                 f = dropout_patches(f, self.args.dropout_patch)
+            else:
+                # resident bag: the SAME two draws on the global numpy RNG, the row gather on the device
+                f = dropout_patches_device(f, self.args.dropout_patch)
             bag_feats = self._bag_to_device(f)
             bag_label = torch.as_tensor(np.asarray(labels[i], dtype=np.float32).reshape(1, -1), device=device)
             bag_prediction, loss, _ = self._run_model(bag_feats, bag_label)
@@ -203,33 +258,86 @@ class Trainer:
             seen.append(i)
         total = torch.stack(losses).sum().item()                                # ONE device->host read per epoch
         preds = torch.stack([p.reshape(-1) for p in preds]).cpu().numpy()
-        return {'epoch_train_loss': total / max(1, len(losses)), 'predictions': preds,
-                'labels': np.array([labels[i] for i in seen])}
+        lab = np.array([labels[i] for i in seen])
+        res = {'epoch_train_loss': total / max(1, len(losses)), 'predictions': preds, 'labels': lab, 'visited': seen}
+        res.update(self._epoch_metrics(lab, preds, 'epoch_train'))
+        return res
+
+    def _calc_metrics(self, labels, predictions, predefined_thresholds_optimal=None):
+        """accuracy / AUC / optimal thresholds of one epoch (reference train.py:475-506)."""
+        assert len(labels) == len(predictions), \
+            f"Number of predictions ({len(predictions)}) and labels ({len(labels)}) do not match"
+        num_bags = len(labels)
+        labels = np.array(labels)
+        predictions = np.array(predictions)
+        auc_scores, _, thresholds_optimal = multi_label_roc(labels, predictions, self.args.num_classes)
+        if predefined_thresholds_optimal is not None:
+            thresholds_optimal = predefined_thresholds_optimal
+        if self.args.num_classes == 1:
+            # the reference holds one scalar per bag here (np.squeeze of [n, 1] labels): [n, 1] predictions are taken as well
+            predictions = (predictions >= thresholds_optimal[0]).astype(predictions.dtype).reshape(num_bags)
+            labels = labels.reshape(num_bags)
+        else:
+            predictions = predictions.copy()
+            for i in range(self.args.num_classes):
+                predictions[:, i] = (predictions[:, i] >= thresholds_optimal[i]).astype(predictions.dtype)
+        bag_score = sum(bool(np.array_equal(labels[i], predictions[i])) for i in range(num_bags))
+        return bag_score / num_bags, auc_scores, thresholds_optimal
+
+    def _epoch_metrics(self, lab, preds, prefix):
+        lab = np.asarray(lab).reshape(len(preds), -1)
+        try:
+            if all(len(np.unique(lab[:, c])) > 1 for c in range(lab.shape[1])):
+                acc, aucs, thr = self._calc_metrics(lab, np.asarray(preds, dtype=np.float64).reshape(lab.shape))
+                return {prefix + '_accuracy': acc, prefix + '_aucs': aucs, prefix + '_thresholds_optimal': thr}
+        except ImportError:
+            pass
+        return {}
 
     @torch.no_grad()
-    def valid(self, data):
-        """Per-bag evaluation loop (reference train.py:295-360): returns mean loss, predictions, labels (+ AUC)."""
+    def valid(self, data, predefined_thresholds_optimal=None):
+        """Per-bag evaluation loop (reference train.py:295-360): mean loss, predictions, labels, accuracy / AUCs / optimal
+        thresholds.  world_size > 1: rank r evaluates bags r::world_size, ONE all_gather of the (loss, prediction) rows
+        (SURVEY 8e); every rank returns the full result in the original bag order."""
         self.milnet.eval()
         labels, feats = data[0], data[1]
+        num_bags = len(labels)
+        mine = list(range(self.rank, num_bags, self.world_size))
         losses, preds = [], []
-        for i in range(len(labels)):
+        for i in mine:
             f = feats[i]
             if not torch.is_tensor(f) and self.args.l2normed_embeddings == 1:
                 f = f / np.linalg.norm(f, axis=1, keepdims=True)
             bag_feats = self._bag_to_device(f)
             bag_label = torch.as_tensor(np.asarray(labels[i], dtype=np.float32).reshape(1, -1), device=device)
             bag_prediction, loss, _ = self._run_model(bag_feats, bag_label)
-            losses.append(loss)
-            preds.append(bag_prediction.reshape(-1))
-        preds = torch.stack(preds).cpu().numpy()
-        lab = np.array(labels).reshape(len(labels), -1)
-        res = {'epoch_valid_loss': torch.stack(losses).mean().item(), 'predictions': preds, 'labels': lab}
-        try:
-            from sklearn.metrics import roc_auc_score
-            if len(np.unique(lab[:, 0])) > 1:
-                res['epoch_valid_aucs'] = [float(roc_auc_score(lab[:, c], preds[:, c])) for c in range(lab.shape[1])]
-        except Exception:
-            pass
+            losses.append(loss.reshape(1).float())
+            preds.append(bag_prediction.reshape(-1).float())
+        ncls = int(np.asarray(labels[0]).size)
+        rows = torch.cat([torch.cat(losses).view(-1, 1), torch.stack(preds)], dim=1) if mine else \
+            torch.zeros(0, 1 + ncls, device=device)
+        if self.dist is not None and self.world_size > 1:
+            per = (num_bags + self.world_size - 1) // self.world_size
+            pad = torch.zeros(per, rows.shape[1], device=rows.device, dtype=rows.dtype)
+            pad[:rows.shape[0]] = rows
+            if self.dist.get_backend() != "nccl":
+                pad = pad.cpu()
+            gathered = [torch.empty_like(pad) for _ in range(self.world_size)]
+            self.dist.all_gather(gathered, pad)
+            full = torch.zeros(num_bags, rows.shape[1], dtype=rows.dtype)
+            for r in range(self.world_size):
+                idx = list(range(r, num_bags, self.world_size))
+                full[idx] = gathered[r][:len(idx)].cpu()
+            rows = full
+        rows = rows.cpu().numpy()
+        preds = rows[:, 1:]
+        lab = np.array(labels).reshape(num_bags, -1)
+        res = {'epoch_valid_loss': float(rows[:, 0].mean()), 'predictions': preds, 'labels': lab}
+        if predefined_thresholds_optimal is not None:
+            acc, aucs, thr = self._calc_metrics(lab, preds.astype(np.float64), predefined_thresholds_optimal)
+            res.update({'epoch_valid_accuracy': acc, 'epoch_valid_aucs': aucs, 'epoch_valid_thresholds_optimal': thr})
+        else:
+            res.update(self._epoch_metrics(lab, preds, 'epoch_valid'))
         return res
 
 
@@ -249,6 +357,9 @@ class SmallWeightTrainer(Trainer):
     def _trainable(self):
         extra = [self.single_weight_parameter] if self.single_weight_parameter.requires_grad else []
         return extra + list(self.milnet.parameters())
+
+    def _replicated_tensors(self):
+        return [self.single_weight_parameter.data] + super()._replicated_tensors()
 
     def _get_optimizer(self) -> optim.Optimizer:
         try:
@@ -279,6 +390,12 @@ class SmallWeightTrainer(Trainer):
         return f'Single_Weight__sa{self.args.soft_average}'
 
 
+# per-tensor initialisers of the _get_milnet hooks (train.py:892-899)
+_INIT_FUNCS = {'trunc_normal': nn.init.trunc_normal_, 'kaiming_uniform': nn.init.kaiming_uniform_,
+               'kaiming_normal': nn.init.kaiming_normal_, 'xavier_uniform': nn.init.xavier_uniform_,
+               'xavier_normal': nn.init.xavier_normal_, 'orthogonal': nn.init.orthogonal_}
+
+
 class Snuffy(SmallWeightTrainer):
     def _get_milnet(self) -> nn.Module:
         """Same construction + init order as reference train.py:861-911."""
@@ -293,12 +410,9 @@ class Snuffy(SmallWeightTrainer):
                                                a.random_patch_share), a.depth),
             a.num_classes, a.feats_size).to(device)
         milnet = snuffy.MILNet(i_classifier, b_classifier).to(device)
-        registry = {'trunc_normal': nn.init.trunc_normal_, 'kaiming_uniform': nn.init.kaiming_uniform_,
-                    'kaiming_normal': nn.init.kaiming_normal_, 'xavier_uniform': nn.init.xavier_uniform_,
-                    'xavier_normal': nn.init.xavier_normal_, 'orthogonal': nn.init.orthogonal_}
         names = a.weight_init__weight_init_i__weight_init_b
         for init_name, module_name in [(names[1], 'i_classifier'), (names[2], 'b_classifier')]:
-            fn = registry.get(init_name)
+            fn = _INIT_FUNCS.get(init_name)
             for name, p in milnet.named_parameters():
                 if p.dim() > 1 and name.split(".")[0] == module_name:
                     fn(p)
@@ -313,7 +427,38 @@ class Snuffy(SmallWeightTrainer):
         return f'Snuffy_k{self.args.big_lambda}_sa{self.args.soft_average}_depth{self.args.depth}'
 
 
-ARCH_REGISTRY = {'snuffy': Snuffy}
+class SnuffyMulticlass(SmallWeightTrainer):
+    def _get_milnet(self) -> nn.Module:
+        """Same construction + init order as reference train.py:922-972 (multi-class / batched model)."""
+        a = self.args
+        smc = snuffy_multiclass
+        i_classifier = smc.FCLayer(in_size=a.feats_size, out_size=a.num_classes).to(device)
+        c = copy.deepcopy
+        attn = smc.MultiHeadedAttention(a.num_heads, a.feats_size).to(device)
+        ff = smc.PositionwiseFeedForward(a.feats_size, a.feats_size * a.mlp_multiplier, a.activation).to(device)
+        b_classifier = smc.BClassifier(
+            smc.Encoder(smc.EncoderLayer(a.feats_size, c(attn), c(ff), a.num_classes, a.encoder_dropout, a.big_lambda,
+                                         a.random_patch_share), a.depth),
+            a.num_classes, a.feats_size).to(device)
+        milnet = smc.MILNet(i_classifier, b_classifier).to(device)
+        names = a.weight_init__weight_init_i__weight_init_b
+        for init_name, module_name in [(names[1], 'i_classifier'), (names[2], 'b_classifier')]:
+            fn = _INIT_FUNCS.get(init_name)
+            for name, p in milnet.named_parameters():
+                if p.dim() > 1 and name.split(".")[0] == module_name:
+                    fn(p)
+        milnet.b_classifier.configure(precision=getattr(a, 'precision', 'fp32'), return_attention=False)
+        return milnet
+
+    def _run_model(self, bag_feats, bag_label):
+        bag_prediction, loss, ins_prediction = super()._run_model(bag_feats, bag_label)
+        return bag_prediction, loss, torch.sigmoid(ins_prediction.view(-1, 1))
+
+    def __str__(self):
+        return f'Snuffy_Multiclass_k{self.args.big_lambda}_sa{self.args.soft_average}_depth{self.args.depth}'
+
+
+ARCH_REGISTRY = {'snuffy': Snuffy, 'snuffy_multiclass': SnuffyMulticlass}
 
 
 class BagParallelStepper:

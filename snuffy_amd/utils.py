@@ -40,6 +40,53 @@ def dropout_patches(feats, p):
     return np.concatenate((sampled, np.take(sampled, pad_idx, axis=0)), axis=0)
 
 
+def dropout_patches_device(feats, p):
+    """dropout_patches for a bag already resident in HBM ([1, N, D] or [N, D] device tensor): the same two draws on the
+    global numpy RNG as the host version (so the RNG stream and the resulting row order are identical), one device gather."""
+    x = feats[0] if feats.dim() == 3 else feats
+    n = x.shape[0]
+    idx = np.random.choice(np.arange(n), int(n * (1 - p)), replace=False)
+    pad_idx = np.random.choice(np.arange(idx.shape[0]), int(n * p), replace=False)
+    rows = np.concatenate((idx, idx[pad_idx]))
+    out = x.index_select(0, torch.from_numpy(rows.astype(np.int64)).to(x.device))
+    return out.unsqueeze(0) if feats.dim() == 3 else out
+
+
+def optimal_thresh(fpr, tpr, thresholds, p=0):
+    """Threshold minimising (fpr - tpr) (reference utils.py:291-294)."""
+    loss = (fpr - tpr) - p * tpr / (fpr + tpr + 1)
+    idx = np.argmin(loss, axis=0)
+    return fpr[idx], tpr[idx], thresholds[idx]
+
+
+def multi_label_roc(labels, predictions, num_classes, for_feats=False):
+    """Per-class AUC, ROC thresholds and the optimal threshold (reference utils.py:253-276)."""
+    from sklearn.metrics import roc_auc_score, roc_curve
+    thresholds, thresholds_optimal, aucs = [], [], []
+    if len(predictions.shape) == 1 and not for_feats:
+        predictions = predictions[:, None]
+    for c in range(num_classes):
+        label = labels if for_feats else labels[:, c]
+        prediction = predictions if for_feats else predictions[:, c]
+        fpr, tpr, threshold = roc_curve(label, prediction, pos_label=1)
+        _, _, threshold_optimal = optimal_thresh(fpr, tpr, threshold)
+        aucs.append(roc_auc_score(label, prediction))
+        thresholds.append(threshold)
+        thresholds_optimal.append(threshold_optimal)
+    return aucs, thresholds, thresholds_optimal
+
+
+def five_scores(bag_labels, bag_predictions):
+    """(accuracy at the optimal threshold, AUC) of one class (reference utils.py:279-288)."""
+    from sklearn.metrics import roc_auc_score, roc_curve
+    fpr, tpr, threshold = roc_curve(bag_labels, bag_predictions, pos_label=1)
+    _, _, threshold_optimal = optimal_thresh(fpr, tpr, threshold)
+    auc_value = roc_auc_score(bag_labels, bag_predictions)
+    hard = (np.array(bag_predictions) >= threshold_optimal).astype(int)
+    accuracy = 1 - np.count_nonzero(np.array(bag_labels).astype(int) - hard) / len(bag_labels)
+    return accuracy, auc_value
+
+
 def get_bag_feats(bag_row, args):
     """One bag from its feature CSV (reference utils.py:138-183).  bag_row = (csv_path, label).
 
@@ -95,6 +142,46 @@ def load_data(bags_df, args):
     if not have:
         flabels, positions = None, None
     return labels, feats, flabels, positions, names
+
+
+def convert_dsmil_mil_dataset_format_to_our_format(bag_ins_list, args):
+    """[[bag_label, [instance vectors ...]], ...] -> (labels, feats, None, None) (reference utils.py:425-451): labels clipped to
+    {0, 1} as float arrays of shape [1], feats = the first feats_size columns of the stacked instances."""
+    all_labels, all_feats = [], []
+    for bag_label, bag_vector in bag_ins_list:
+        all_labels.append(np.expand_dims(np.array(int(np.clip(bag_label, 0, 1)), dtype=float), axis=0))
+        all_feats.append(np.stack(bag_vector)[:, 0:args.feats_size])
+    return all_labels, all_feats, None, None
+
+
+def cross_validation_set(bag_ins_list, num_folds, current_fold, valid_ratio):
+    """Fold split of the classical MIL datasets (reference utils.py:454-466): chunks of len // num_folds bags (a remainder
+    becomes an extra chunk), the current chunk is the test split, the rest is cut into train | valid."""
+    import itertools
+    from copy import deepcopy
+    csv_list = deepcopy(bag_ins_list)
+    n = int(len(csv_list) / num_folds)
+    chunked = [csv_list[i:i + n] for i in range(0, len(csv_list), n)]
+    test_list = chunked.pop(current_fold)
+    train_valid_list = list(itertools.chain.from_iterable(chunked))
+    cut = int(len(train_valid_list) * (1 - valid_ratio))
+    return train_valid_list[0:cut], train_valid_list[cut:], test_list
+
+
+MIL_DATASET_FILES = {'musk1': ('Musk', 'musk1norm'), 'musk2': ('Musk', 'musk2norm'), 'elephant': ('Elephant', 'data_100x100'),
+                     'fox': ('Fox', 'data_100x100'), 'tiger': ('Tiger', 'data_100x100')}
+
+
+def load_mil_data(args, mil_datasets_base_path='./datasets/mil_dataset'):
+    """(train, valid, test) tuples of the classical MIL benchmarks -- MUSK1/2, Elephant, Fox, Tiger -- from the pickled
+    bag list '<name>_<folds>folds_<ratio>split.pkl' (reference utils.py:469-496; BASELINE config 1 = MUSK bags)."""
+    import pickle
+    folder, stem = MIL_DATASET_FILES[args.dataset]
+    fname = f'{stem}_{args.cv_num_folds}folds_{args.cv_valid_ratio}split.pkl'
+    with open(os.path.join(mil_datasets_base_path, folder, fname), 'rb') as f:
+        bag_ins_list = pickle.load(f)
+    tr, va, te = cross_validation_set(bag_ins_list, args.cv_num_folds, args.cv_current_fold, args.cv_valid_ratio)
+    return tuple(convert_dsmil_mil_dataset_format_to_our_format(part, args) for part in (tr, va, te))
 
 
 def compute_pos_weight(labels):

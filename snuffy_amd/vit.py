@@ -46,14 +46,17 @@ class Adapter(nn.Module):
         self.non_linear_func = nn.ReLU()
         self.up_proj = nn.Linear(self.down_size, self.n_embd)
         self.dropout = dropout
-        if init_option == "bert":
-            raise NotImplementedError
-        elif init_option == "lora":
-            with torch.no_grad():
-                nn.init.kaiming_normal_(self.down_proj.weight, a=math.sqrt(5))
-                nn.init.zeros_(self.down_proj.bias)
-                nn.init.zeros_(self.up_proj.weight)
-                nn.init.zeros_(self.up_proj.bias)
+        if init_option == "lora":
+            self._init_lora()
+        elif init_option == "bert":
+            raise NotImplementedError("init_option='bert' is not implemented (neither is it in the reference, adapter.py:63)")
+
+    @torch.no_grad()
+    def _init_lora(self):
+        """LoRA-style start: random down-projection, ZERO up-projection -> the adapter starts as the identity branch."""
+        nn.init.kaiming_normal_(self.down_proj.weight, a=math.sqrt(5))
+        for t in (self.down_proj.bias, self.up_proj.weight, self.up_proj.bias):
+            t.zero_()
 
     def forward(self, x, add_residual=True, residual=None):
         residual = x if residual is None else residual
@@ -192,21 +195,21 @@ class VisionTransformer(nn.Module):
 
     # -- reference helper API ---------------------------------------------------------------------------------------
     def interpolate_pos_encoding(self, x, w, h):
-        npatch = x.shape[1] - 1
-        N = self.pos_embed.shape[1] - 1
-        if npatch == N and w == h:
-            return self.pos_embed
-        class_pos_embed = self.pos_embed[:, 0]
-        patch_pos_embed = self.pos_embed[:, 1:]
-        dim = x.shape[-1]
-        w0 = w // self.patch_embed.patch_size + 0.1
-        h0 = h // self.patch_embed.patch_size + 0.1
-        patch_pos_embed = F.interpolate(
-            patch_pos_embed.reshape(1, int(math.sqrt(N)), int(math.sqrt(N)), dim).permute(0, 3, 1, 2),
-            scale_factor=(w0 / math.sqrt(N), h0 / math.sqrt(N)), mode='bicubic')
-        assert int(w0) == patch_pos_embed.shape[-2] and int(h0) == patch_pos_embed.shape[-1]
-        patch_pos_embed = patch_pos_embed.permute(0, 2, 3, 1).view(1, -1, dim)
-        return torch.cat((class_pos_embed.unsqueeze(0), patch_pos_embed), dim=1)
+        """Positional table for a w x h pixel input (reference ...dino_version.py:196-216): the stored table at the training
+        resolution; otherwise its patch rows resampled bicubically on the sqrt(N) grid (the reference's +0.1 guard against
+        floor rounding of the scale factor included), class row untouched."""
+        table = self.pos_embed
+        n_train = table.shape[1] - 1
+        if x.shape[1] - 1 == n_train and w == h:
+            return table
+        side = int(math.sqrt(n_train))
+        ps = self.patch_embed.patch_size
+        gw, gh = w // ps, h // ps
+        grid = table[:, 1:].reshape(1, side, side, table.shape[-1]).permute(0, 3, 1, 2)
+        grid = F.interpolate(grid, scale_factor=((gw + 0.1) / math.sqrt(n_train), (gh + 0.1) / math.sqrt(n_train)),
+                             mode='bicubic')
+        assert tuple(grid.shape[-2:]) == (gw, gh)
+        return torch.cat((table[:, :1], grid.permute(0, 2, 3, 1).reshape(1, gw * gh, table.shape[-1])), dim=1)
 
     def prepare_tokens(self, x):
         """[B, 3, H, W] -> tokens [B, T, D] (fp32): patch embedding, cls concat, + positional table."""
@@ -219,23 +222,25 @@ class VisionTransformer(nn.Module):
         return tok.view(B, pe.shape[1] + 1, pe.shape[2])
 
     def get_last_selfattention(self, x):
-        x = self.prepare_tokens(x)
-        for i, blk in enumerate(self.blocks):
-            if i < len(self.blocks) - 1:
-                x = blk(x)
-            else:
-                return blk(x, return_attention=True)
+        """Attention probabilities [B, h, T, T] of the LAST block (reference ...dino_version.py:238-245)."""
+        tokens = self.prepare_tokens(x)
+        *body, last = self.blocks
+        for blk in body:
+            tokens = blk(tokens)
+        return last(tokens, return_attention=True)
 
     def get_intermediate_layers(self, x, n=1):
-        x = self.prepare_tokens(x)
-        output = []
+        """Normalised token maps of the last n blocks (reference ...dino_version.py:247-255)."""
+        tokens = self.prepare_tokens(x)
+        first_kept = len(self.blocks) - n
+        kept = []
         for i, blk in enumerate(self.blocks):
-            x = blk(x)
-            if len(self.blocks) - i <= n:
-                B, N, C = x.shape
-                output.append(ops.layernorm_rows(x.reshape(B * N, C).contiguous(), self.norm.weight, self.norm.bias,
-                                                 self.norm.eps).view(B, N, C))
-        return output
+            tokens = blk(tokens)
+            if i >= first_kept:
+                B, T, C = tokens.shape
+                kept.append(ops.layernorm_rows(tokens.reshape(B * T, C).contiguous(), self.norm.weight, self.norm.bias,
+                                               self.norm.eps).view(B, T, C))
+        return kept
 
     # -- forward -----------------------------------------------------------------------------------------------------
     def _pool(self, x, B, T):
@@ -340,15 +345,39 @@ def vit_base(patch_size=16, **kwargs):
                              norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
 
 
+def get_2d_sincos_pos_embed(embed_dim, grid_size, cls_token=False):
+    """Fixed 2-D sine-cosine positional table of the MAE encoder, [grid*grid (+1), embed_dim] float64 (reference
+    utils_ssls_cf/pos_embed.py:21-66).  Column layout: [sin(x w) | cos(x w) | sin(y w) | cos(y w)] with D/4 frequencies
+    w_i = 10000^(-i / (D/4)), x = column and y = row of the patch; an all-zero first row stands for the class token."""
+    import numpy as np
+    if embed_dim % 4:
+        raise AssertionError("embed_dim must be divisible by 4")
+    quarter = embed_dim // 4
+    freq = 1.0 / 10000 ** (np.arange(quarter, dtype=np.float64) / quarter)
+    ys, xs = np.divmod(np.arange(grid_size * grid_size), grid_size)           # row-major patch order
+    ax = np.outer(xs.astype(np.float32), freq)
+    ay = np.outer(ys.astype(np.float32), freq)
+    table = np.concatenate([np.sin(ax), np.cos(ax), np.sin(ay), np.cos(ay)], axis=1)
+    if cls_token:
+        table = np.concatenate([np.zeros((1, embed_dim)), table], axis=0)
+    return table
+
+
 def mae_adapter_encoder(img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.,
                         norm_layer=partial(nn.LayerNorm, eps=1e-6), adapter_ffn_scalar="0.1", adapter_ffn_num=64,
                         adapter_d_model=768, **kwargs):
     """Encoder half of models_adapter_mae.MaskedAutoencoderViT (the part compute_feats.py runs): same keys, output
     LN(mean of the patch tokens) (models_adapter_mae.py:174-195).  The decoder is training-only and out of scope."""
-    return VisionTransformer(img_size=[img_size], patch_size=patch_size, embed_dim=embed_dim, depth=depth,
-                             num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=True, norm_layer=norm_layer,
-                             adapter_ffn_scalar=adapter_ffn_scalar, adapter_ffn_num=adapter_ffn_num,
-                             adapter_d_model=adapter_d_model, pool="mean_patches", **kwargs)
+    model = VisionTransformer(img_size=[img_size], patch_size=patch_size, embed_dim=embed_dim, depth=depth,
+                              num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=True, norm_layer=norm_layer,
+                              adapter_ffn_scalar=adapter_ffn_scalar, adapter_ffn_num=adapter_ffn_num,
+                              adapter_d_model=adapter_d_model, pool="mean_patches", **kwargs)
+    # the MAE encoder's positional table is the fixed sin-cos one (models_adapter_mae.py:89-92), frozen
+    table = get_2d_sincos_pos_embed(embed_dim, int(model.patch_embed.num_patches ** .5), cls_token=True)
+    with torch.no_grad():
+        model.pos_embed.copy_(torch.from_numpy(table).float().unsqueeze(0))
+    model.pos_embed.requires_grad = False
+    return model
 
 
 class IClassifier(nn.Module):

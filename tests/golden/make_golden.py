@@ -254,6 +254,60 @@ def run_f5():
     print("F5 done")
 
 
+def musk_like_bags(seed=7, n_bags=92, d_file=24):
+    """Synthetic stand-in for the MUSK pickle (the real file is not in the reference repo): 92 bags of 2..40 instances, labels
+    in {-1, 0, 1, 2} (the loader clips to {0, 1}), d_file columns of which feats_size are used
+    (MUSK itself has 166 feature columns; the fixture keeps 20 of 24 to stay small)."""
+    g = np.random.RandomState(seed)
+    bags = []
+    for _ in range(n_bags):
+        n = int(g.randint(2, 41))
+        lab = int(g.choice([-1, 0, 1, 2]))
+        bags.append([lab, [g.randn(d_file).astype(np.float32) for _ in range(n)]])
+    return bags
+
+
+def run_f9():
+    """F9 host-side loader / metrics / positional table of the hot path's callers: load_mil_data (utils.py:425-496),
+    multi_label_roc / optimal_thresh / five_scores (utils.py:253-294), get_2d_sincos_pos_embed (pos_embed.py:21-66)."""
+    import pickle
+    import tempfile
+    import argparse
+    from utils_ssls_cf.pos_embed import get_2d_sincos_pos_embed
+    out = {}
+    bags = musk_like_bags()
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "Musk"))
+        for folds, ratio, cur in [(10, 0.2, 3), (5, 0.1, 0)]:
+            args = argparse.Namespace(dataset="musk1", cv_num_folds=folds, cv_valid_ratio=ratio, cv_current_fold=cur,
+                                      feats_size=20)
+            with open(os.path.join(td, "Musk", f"musk1norm_{folds}folds_{ratio}split.pkl"), "wb") as f:
+                pickle.dump(bags, f)
+            parts = ref_utils.load_mil_data(args, td)
+            tag = f"mil_{folds}_{cur}"
+            for name, (labels, feats, a, b) in zip(("train", "valid", "test"), parts):
+                assert a is None and b is None
+                out[f"{tag}.{name}.labels"] = np.stack(labels)
+                out[f"{tag}.{name}.lens"] = np.array([f.shape[0] for f in feats], dtype=np.int64)
+                out[f"{tag}.{name}.feats"] = np.concatenate(feats, axis=0)
+    g = np.random.RandomState(3)
+    labels = (g.rand(60, 2) > 0.5).astype(np.float64)
+    preds = np.clip(labels * 0.3 + g.rand(60, 2) * 0.7, 0, 1)
+    aucs, thr, thr_opt = ref_utils.multi_label_roc(labels, preds, 2)
+    out["roc.labels"], out["roc.preds"] = labels, preds
+    out["roc.aucs"], out["roc.thr_opt"] = np.array(aucs), np.array(thr_opt)
+    out["roc.thr0"], out["roc.thr1"] = thr[0], thr[1]
+    aucs1, _, thr1 = ref_utils.multi_label_roc(labels[:, :1], preds[:, 0], 1)
+    out["roc1.aucs"], out["roc1.thr_opt"] = np.array(aucs1), np.array(thr1)
+    aucsf, _, thrf = ref_utils.multi_label_roc(labels[:, 1], preds[:, 1], 1, for_feats=True)
+    out["rocf.aucs"], out["rocf.thr_opt"] = np.array(aucsf), np.array(thrf)
+    out["five"] = np.array(ref_utils.five_scores(labels[:, 0], preds[:, 0]))
+    for d, gs in [(64, 4), (128, 7)]:
+        out[f"sincos_{d}_{gs}"] = get_2d_sincos_pos_embed(d, gs, cls_token=True)
+    np.savez_compressed(os.path.join(HERE, "f9_host.npz"), **out)
+    print("F9 done", {k: v.shape for k, v in out.items() if k.startswith("mil_10")})
+
+
 def run_f6():
     for name, B, N, D, h, lam, r, depth, seed in [
         ("mc_b1_n100", 1, 100, 64, 4, 10, 0.0, 1, 31),
@@ -283,7 +337,7 @@ def run_f6():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f9"]
     if "f1" in which:
         run_f1()
     if "f2" in which:
@@ -294,6 +348,8 @@ if __name__ == "__main__":
         run_f5()
     if "f6" in which:
         run_f6()
+    if "f9" in which:
+        run_f9()
 
 
 # ----------------------------------------------------------------------------------------------------------------------

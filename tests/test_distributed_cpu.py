@@ -81,3 +81,86 @@ def test_world1_is_a_no_op():
     FlatGradAllReduce(model.parameters(), None, 1)()
     for a, p in zip(before, model.parameters()):
         assert torch.equal(a, p.grad)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the trainer's epoch loop under world_size 2 (gloo): bag partition, replica sync, sharded validation
+# ----------------------------------------------------------------------------------------------------------------------
+class _TinyMIL(torch.nn.Module):
+    """CPU stand-in with MILNet's return convention (ins [1, N, 1], logits [1, 1], A): the product model has no CPU path;
+    what is under test here is the model-agnostic Trainer loop."""
+
+    def __init__(self):
+        super().__init__()
+        self.i_classifier = torch.nn.Linear(6, 1)
+        self.b_classifier = torch.nn.Linear(6, 1)
+
+    def forward(self, x):
+        return self.i_classifier(x), self.b_classifier(x.mean(dim=1)), None
+
+
+def _toy_bags(n_bags=11):
+    import numpy as np
+    g = np.random.RandomState(0)
+    labels = [np.array([float(i % 2)], dtype=np.float32) for i in range(n_bags)]
+    feats = [g.randn(int(g.randint(3, 30)), 6).astype(np.float32) + labels[i][0] for i in range(n_bags)]
+    return labels, feats, None, None
+
+
+def _trainer_worker(rank, world, port, out):
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from snuffy_amd import train as T
+    T.device = torch.device("cpu")
+
+    class Tiny(T.SmallWeightTrainer):
+        def _get_milnet(self):
+            return _TinyMIL()
+
+    args = T.get_args_parser().parse_args(["--optimizer", "adamw", "--num_epochs", "4", "--lr", "1e-2", "--dropout_patch",
+                                           "0.1", "--soft_average", "1"])
+    args.weight_init__weight_init_i__weight_init_b = [None, None, None]
+    torch.manual_seed(100 + rank)            # replicas are built from DIFFERENT seeds: the trainer must sync them
+    np.random.seed(7 + rank)                 # and the global numpy RNGs differ from the start
+    tr = Tiny(args, dist=dist, rank=rank, world_size=world)
+    data = _toy_bags()
+    visited = []
+    for epoch in (1, 2, 3):
+        visited.append(list(tr.train(data, epoch)["visited"]))
+    res = tr.valid(data)
+    out[rank] = dict(visited=visited, weights=[p.detach().clone() for p in tr.milnet.parameters()],
+                     w=tr.single_weight_parameter.detach().clone(), preds=res["predictions"], loss=res["epoch_valid_loss"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_epoch_partition_replica_sync_and_sharded_valid_world2():
+    import numpy as np
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_trainer_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    n_bags = 11
+    for e in range(3):
+        seen = out[0]["visited"][e] + out[1]["visited"][e]
+        assert len(out[0]["visited"][e]) == len(out[1]["visited"][e]) == (n_bags + 1) // 2
+        assert set(seen) == set(range(n_bags))                         # every bag of the epoch, across the ranks
+        assert len(seen) - len(set(seen)) == (world - n_bags % world) % world   # only the wrap-around pad repeats
+    for a, b in zip(out[0]["weights"], out[1]["weights"]):             # replicas identical after three epochs
+        assert torch.equal(a, b)
+    assert torch.equal(out[0]["w"], out[1]["w"])
+    # sharded validation: both ranks hold the full, ordered result; it equals a single-process pass with the same weights
+    assert np.array_equal(out[0]["preds"], out[1]["preds"]) and out[0]["loss"] == out[1]["loss"]
+    model = _TinyMIL()
+    with torch.no_grad():
+        for p, w in zip(model.parameters(), out[0]["weights"]):
+            p.copy_(w)
+        labels, feats, _, _ = _toy_bags()
+        w = out[0]["w"]
+        ref = []
+        for f in feats:
+            ins, logit, _ = model(torch.from_numpy(f).unsqueeze(0))
+            ref.append(float((1 - w) * torch.sigmoid(ins.max()) + w * torch.sigmoid(logit.squeeze())))
+    assert np.allclose(out[0]["preds"][:, 0], np.array(ref), atol=1e-6)

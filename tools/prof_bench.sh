@@ -2,7 +2,7 @@
 # rocprofv3 kernel stats of one bench.py configuration.  usage: bash tools/prof_bench.sh <outname> [bench args...]
 ROOT=$(pwd); NAME=$1; shift
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$NAME -o p -- python $ROOT/bench.py --no-cpu-baseline --no-roofline "$@" > $ROOT/gpurun_out/prof_$NAME.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$NAME -o p -- python $ROOT/bench.py --no-cpu-baseline --no-roofline --headline-only "$@" > $ROOT/gpurun_out/prof_$NAME.log 2>&1
 python - <<PY
 import csv,glob
 for f in glob.glob("$ROOT/gpurun_out/prof_$NAME/**/p_kernel_stats.csv", recursive=True):
