@@ -184,6 +184,19 @@ int snf_sparse_attn_dkp_f32(const float* ds, const float* q, int64_t n, int k, i
                             size_t workspace_bytes, snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * K6 / K10 / K13  dense projection on the matrix cores      replaces nn.Linear (+ activation):
+ *     snuffy.py:187-190 (Q | V and key projections), snuffy.py:224-225 (w_1 + activation, w_2),
+ *     utils_ssls_cf/vision_transformer_with_adapter_dino_version.py:51-67 (Mlp), :82-94 (qkv / proj), :141-146 (patch embed)
+ *   C[m, n] = act(A[m, k] W[n, k]^T + bias[n])   A, W bf16 row-major with row pitches lda / ldw (elements), bias f32 [n]
+ *   (nullable), act = SNF_ACT_* (GELU = erf form, as nn.GELU), C bf16 or f32 (out_dtype = SNF_DT_*), row pitch ldc.
+ *   Hand-written v_mfma_f32_16x16x32_bf16 kernel, fp32 accumulate; 256 x 256 or 256 x 128 output tiles (tile_n = 256 / 128,
+ *   anything else = chosen from the shape).  Domain: k % 64 == 0, n % 16 == 0, rows 16-byte aligned, m * lda and
+ *   n * ldw < 2^31; outside it SNF_EUNSUPPORTED (the caller keeps its library GEMM).
+ * --------------------------------------------------------------------------------------------------------- */
+int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t m, int n, int k,
+                  int act, void* c, int64_t ldc, int out_dtype, int tile_n, snf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * K12-K14  ViT patch-embedding extractor (compute_feats.py:239-247 -> IClassifier -> VisionTransformer.forward)
  *   reference model files: utils_ssls_cf/vision_transformer_with_adapter_dino_version.py (vd), vision_transformer_dino.py,
  *   adapter.py, models_adapter_mae.py.  Dense projections stay library GEMMs; these entry points are the rest.

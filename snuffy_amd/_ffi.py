@@ -59,6 +59,8 @@ SIGNATURES = {
                                         c_void_p]),
     "snf_sparse_attn_fwd_mfma": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int,
                                          c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "snf_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
+                              c_int, c_int, c_void_p]),
     "snf_vit_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "snf_vit_assemble_tokens": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "snf_vit_residual_ln": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_float,

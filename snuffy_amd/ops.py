@@ -417,6 +417,39 @@ def sparse_attn_fwd_mfma(q, v, kp, n, h, scale=None, need_attn=False, need_lse=F
     return out, attn, lse
 
 
+def gemm_supported(m, n, k, lda=None, ldw=None):
+    """Shapes snf_gemm_bf16 takes (see include/snuffy_hip.h)."""
+    lda = k if lda is None else lda
+    ldw = k if ldw is None else ldw
+    return (m >= 1 and k >= 64 and k % 64 == 0 and n >= 16 and n % 16 == 0 and lda % 8 == 0 and ldw % 8 == 0
+            and m * lda < 0x7fffffff and n * ldw < 0x7fffffff)
+
+
+def gemm_bf16(a, w, bias=None, act="none", out_dtype=torch.bfloat16, out=None, tile_n=0):
+    """act(a @ w.T + bias) on the hand-written MFMA kernel.  a [m, k] bf16 (row-strided views allowed), w [n, k] bf16 (the
+    nn.Linear layout), bias [n] f32 or None, act in relu | gelu (erf) | leakyrelu | selu | none -> [m, n] bf16 or f32."""
+    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
+        raise TypeError("gemm_bf16: a and w must be bfloat16")
+    a = _rows16(a, "a")
+    w = _rows16(w, "w")
+    m, k = a.shape
+    n = w.shape[0]
+    if w.shape[1] != k:
+        raise ValueError("gemm_bf16: a is %s but w is %s" % (tuple(a.shape), tuple(w.shape)))
+    if bias is not None:
+        bias = _req(bias, torch.float32, "bias", 1)
+        if bias.shape[0] != n:
+            raise ValueError("gemm_bf16: bias has %d entries for %d columns" % (bias.shape[0], n))
+    if out is None:
+        out = torch.empty(m, n, dtype=out_dtype, device=a.device)
+    elif out.shape != (m, n) or out.stride(1) != 1 or out.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("gemm_bf16: bad out buffer")
+    odt = DT_F32 if out.dtype == torch.float32 else DT_BF16
+    check(_ffi.load().snf_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), m, n, k, ACT_CODES[act], _p(out),
+                                    out.stride(0), odt, int(tile_n), _stream()), "snf_gemm_bf16")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # ViT extractor ops (K12-K14)
 # ----------------------------------------------------------------------------------------------------------------------

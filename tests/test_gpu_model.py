@@ -212,7 +212,7 @@ def test_fused_critic_layernorm_pass_changes_nothing():
     with torch.no_grad():
         lin = net.i_classifier.fc[0]
         eps = net.b_classifier.encoder.layers[0].sublayer[0].norm.eps
-        c3 = SF.critic_scores_with_xhat(x, lin.weight, lin.bias, eps)
+        c3 = SF.critic_scores_with_xhat(x, lin.weight, lin.bias, eps, net.b_classifier.encoder.layers[0])
         x.mul_(2.0)                                           # bumps the version counter
         logits3, _ = net.b_classifier(x, c3)
         logits4, _ = net.b_classifier(x, c3)
