@@ -190,7 +190,7 @@ int snf_sparse_attn_dkp_f32(const float* ds, const float* q, int64_t n, int k, i
  *   C[m, n] = act(A[m, k] W[n, k]^T + bias[n])   A, W bf16 row-major with row pitches lda / ldw (elements), bias f32 [n]
  *   (nullable), act = SNF_ACT_* (GELU = erf form, as nn.GELU), C bf16 or f32 (out_dtype = SNF_DT_*), row pitch ldc.
  *   Hand-written v_mfma_f32_16x16x32_bf16 kernel, fp32 accumulate; 256 x 256 or 256 x 128 output tiles (tile_n = 256 / 128,
- *   anything else = chosen from the shape).  Domain: k % 64 == 0, n % 16 == 0, rows 16-byte aligned, m * lda and
+ *   anything else = chosen from the shape).  Domain: k % 32 == 0, k >= 64, n % 8 == 0, rows 16-byte aligned, m * lda and
  *   n * ldw < 2^31; outside it SNF_EUNSUPPORTED (the caller keeps its library GEMM).
  * --------------------------------------------------------------------------------------------------------- */
 int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t m, int n, int k,

@@ -1,27 +1,32 @@
-// K5 / K10 / K12-K14: the dense projections of the hot path on the CDNA4 matrix cores.
+// K6 / K10 / K12-K14: the dense projections of the hot path on the CDNA4 matrix cores.
 //
 //   C[M, N] = act(A[M, K] * W[N, K]^T + bias[N])       bf16 operands, fp32 accumulate, bf16 (or fp32) out
 //
-// replaces nn.Linear of snuffy.py:187-190 (Q | V projection), snuffy.py:224-225 (w_1 + activation, w_2) and the ViT
-// Linear / Conv2d-as-GEMM layers (utils_ssls_cf/vision_transformer_with_adapter_dino_version.py:51-67, 82-94, 141-146).
-// Both operands are K-major (A row-major, W as nn.Linear stores it), so the same LDS image serves both.
+// replaces nn.Linear of snuffy.py:187-190 (Q | V and key projections), snuffy.py:224-225 (w_1 + activation, w_2) and the
+// ViT Linear / Conv2d-as-GEMM layers (utils_ssls_cf/vision_transformer_with_adapter_dino_version.py:51-67, 82-94, 141-146).
+// Both operands are K-major (A row-major, W as nn.Linear stores it), so one LDS image format serves both.
 //
-// Structure (one 256 x BN output tile per workgroup, BN = 256 or 128, 8 waves = 2 (M) x 4 (N), K step 64):
-//   * HBM -> LDS by LDS-DMA (global_load_lds, 16 B per lane) in HALF-TILES of 128 rows x 64 k = 16 KiB, one half-tile per
-//     phase, two K tiles of LDS (128 KiB).  The destination of an LDS-DMA is lane-linear, so the bank swizzle is applied
-//     to the SOURCE address: lane i of a piece fetches the 16-byte chunk that belongs at position i of the image.
-//   * image: row r of a half-tile is 128 contiguous bytes (8 chunks of 8 k); chunk q sits at slot q ^ sw(r).  For the
-//     operand whose fragment rows are consecutive (A) sw = (r >> 1) & 7; for W the wave reads rows 16 g + 4 ni + r'
-//     (see the epilogue) and sw = ((r >> 1) & 1) | (((r >> 4) & 3) << 1): every ds_read_b128 lane group then covers the
-//     16 slots of a 256-byte bank row exactly once (conflict-free, derivation in DESIGN.md).
-//   * MFMA v_mfma_f32_16x16x32_bf16 with the operands SWAPPED (W fragment as srcA, A fragment as srcB): the accumulator
-//     of a lane then holds 4 consecutive OUTPUT COLUMNS of one output row; with the W rows of fragment ni, slot 4 g + r'
-//     chosen as column 16 g + 4 ni + r' a lane owns 16 consecutive columns of a row -> two 16-byte stores per row.
-//   * schedule: the K tile is cut into 4 phases (one quadrant of the wave's 128 x 64 output each, 16 MFMAs); a phase is
-//     {LDS reads of the quadrant's new fragments, LDS-DMA of one future half-tile, s_barrier, 16 MFMAs, s_barrier}.  The two
-//     wave groups (wr = 0 / 1, one wave of each per SIMD) run ONE BARRIER APART, so one wave of a SIMD issues its MFMA
-//     cluster while the other reads LDS and issues DMA.  The DMA runs two half-tiles ahead: the only wait in the loop is
-//     one counted s_waitcnt vmcnt(4) per K tile (never 0), placed one phase before the first read of the tile it retires.
+// Structure.  Persistent workgroups (one per CU, 8 waves = 2 (M) x 4 (N)) walk a stream of 256 x BN output tiles
+// (BN = 256 or 128); a tile is a sequence of 32-deep K STEPS; the steps of consecutive tiles form one stream.
+//   * HBM -> LDS by LDS-DMA (global_load_lds, 16 B per lane) into a ring of FOUR step buffers (A 256 x 32 + W BN x 32 bf16
+//     each, 128 KiB in all).  The DMA runs two steps ahead of the reads -- across tile boundaries, so the first steps of the
+//     next tile land while the current tile's epilogue stores drain; the only wait in the stream is one counted
+//     s_waitcnt vmcnt(n) per step (never 0 inside a tile), placed one step before the first read of the data it retires.
+//   * The destination of an LDS-DMA is lane-linear, so the bank swizzle is applied to the SOURCE address: a piece is
+//     16 rows x 64 bytes, lane l lands at row l >> 2, slot l & 3 and fetches chunk slot ^ f(row).  f = (-(row >> 2)) & 3
+//     for A (fragment rows consecutive) and (-(row >> 3)) & 3 for W (fragment rows 8 g + r, below): every ds_read_b128
+//     lane group then covers the 16 slots of a 256-byte bank row exactly once (conflict-free; derivation in DESIGN.md).
+//   * MFMA v_mfma_f32_16x16x32_bf16 with the operands SWAPPED (W fragment as srcA, A fragment as srcB): a lane's accumulator
+//     holds 4 consecutive OUTPUT COLUMNS of one row.  W fragment ni, slot 4 g + r is column 8 g + 4 (ni & 1) + r + 32 (ni >> 1)
+//     of the wave's 64: a lane owns 2 x 8 consecutive columns of a row, the 4 lanes of a row 2 x 64 contiguous bytes
+//     -> 16-byte stores that fill 64-byte segments.
+//   * Schedule: a step is {LDS reads of its 8 + NI fragments, LDS-DMA of the step two ahead, s_barrier, 8 NI MFMAs, s_barrier}.
+//     The two wave groups (wr = 0 / 1, one wave of each per SIMD) run ONE BARRIER APART: one wave of a SIMD issues its MFMA
+//     burst (32 MFMAs = 512 matrix-pipe cycles at BN = 256) while the other reads LDS, issues DMA and -- at a tile boundary
+//     -- converts and stores its accumulators.  WAR safety of the ring is by construction: a buffer is re-staged two steps
+//     after its last read was issued (two barrier pairs in between, the reads are consumed by MFMAs one pair earlier).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -45,23 +50,20 @@ struct GemmParams {
     int m, n, k;
     int act;
     int tiles_m, tiles_n;
+    unsigned long long* trace;   // dev builds only (SNF_GEMM_TRACE), else null
 };
 
-constexpr int BM = 256, BK = 64;
-constexpr int HT_BYTES = 128 * BK * 2;   // one half-tile: 128 rows x 64 k bf16 = 16 KiB
+constexpr int BM = 256, BKS = 32;
+// ring of step buffers and LDS-DMA distance in steps.  A deeper ring (5 buffers = all 160 KiB, 3 steps ahead) measured the
+// same on every shape: the stream is bound by the L2 -> LDS fill rate (~7 TB/s over the chip), not by its latency.
+constexpr int NBUF = 4, AHEAD = 2;
+constexpr int ROWB = BKS * 2;            // bytes of one row of a step image
+constexpr int A_BYTES = BM * ROWB;       // 16 KiB
 
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
+// two f32 -> packed bf16x2 (v_cvt_pk_bf16_f32: round to nearest even, NaN kept)
+__device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi) {
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
-
-__device__ __forceinline__ int sw_a(int r) { return (r >> 1) & 7; }
-// W rows of fragment ni, slot 4 g + r' are 16 g + 4 ni + r' (BN = 256, GS = 4) or 8 g + 4 ni + r' (BN = 128, GS = 3)
-template <int GS>
-__device__ __forceinline__ int sw_w(int r) { return ((r >> 1) & 1) | (((r >> GS) & 3) << 1); }
 
 // erf, Abramowitz & Stegun 7.1.26 (|err| <= 1.5e-7), branch-free
 __device__ __forceinline__ float erf_as(float x) {
@@ -72,13 +74,7 @@ __device__ __forceinline__ float erf_as(float x) {
     p = fmaf(p, t, -0.284496736f);
     p = fmaf(p, t, 0.254829592f);
     const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
-    const float r = fmaf(-p * t, e, 1.0f);
-    return copysignf(r, x);
-}
-
-// two f32 -> packed bf16x2 (v_cvt_pk_bf16_f32: round to nearest even, NaN kept)
-__device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi) {
-    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+    return copysignf(fmaf(-p * t, e, 1.0f), x);
 }
 
 template <int ACT>
@@ -93,278 +89,254 @@ __device__ __forceinline__ float activate(float v) {
     return v;
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
 // NI = 16-column W fragments per wave: 4 -> BN = 256, 2 -> BN = 128.  OUT_F32: fp32 output instead of bf16.
 template <int NI, int ACT, bool OUT_F32>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
     constexpr int BN = 64 * NI;
-    constexpr int NHT_W = BN / 128;               // W half-tiles per K tile (2 or 1)
-    constexpr int NHT = 2 + NHT_W;                // half-tiles per K tile
-    constexpr int NPH = (NI == 4) ? 4 : 2;        // phases per K tile
-    constexpr int KT_BYTES = NHT * HT_BYTES;
-    constexpr int GS = (NI == 4) ? 4 : 3;        // log2 of the column-group pitch of the W fragment rows
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 K tiles][NHT half-tiles][16 KiB]
+    constexpr int W_BYTES = BN * ROWB;
+    constexpr int STEP_BYTES = A_BYTES + W_BYTES;
+    constexpr int WP = NI / 2;                 // W pieces (16 rows each) staged by one wave per step
+    constexpr int GL = 2 + WP;                 // LDS-DMA instructions per wave and step
+    constexpr int NC = 4 * NI;                 // output columns per lane
+    constexpr int NST = OUT_F32 ? NC / 4 : NC / 8;   // store instructions per lane and 16-row block
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NBUF][A image | W image]
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wid >> 2, wc = wid & 3;
+    const int ns = P.k / BKS;                  // steps per tile (>= 2)
 
-    // XCD-aware tile order: workgroup b runs on XCD b % 8; give every XCD a contiguous range of logical tiles, and walk
-    // the tiles of one A row panel first, so the panel is fetched from HBM once per XCD and W stays in that XCD's L2
-    const int nwg = P.tiles_m * P.tiles_n;
-    int tile;
+    // ---- persistent tile stream, XCD-aware: workgroup b runs on XCD b % 8; every XCD owns a contiguous range of logical
+    // tiles and its workgroups take consecutive tiles of it (column tiles of one A row panel first), so a panel is fetched
+    // from HBM once per XCD and W stays in that XCD's L2
+    const int ntiles = P.tiles_m * P.tiles_n;
+    const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int t_lo, t_hi;
     {
-        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        const int q = ntiles >> 3, r = ntiles & 7;
+        t_lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        t_hi = t_lo + q + (xcd < r ? 1 : 0);
     }
-    const int tile_m = tile / P.tiles_n, tile_n = tile - tile_m * P.tiles_n;
-    const int nt = P.k / BK;
+    int tile = t_lo + wg_in_xcd;
+    if (tile >= t_hi) return;   // whole workgroup: no barrier has been executed yet
 
-    // ---- LDS-DMA source offsets (elements), two 1-KiB pieces per wave and half-tile: piece p = 2 wid + j covers rows
-    //      8 p .. 8 p + 7; lane i lands at byte 16 i of the piece = row 8 p + (i >> 3), slot i & 7
-    int goff[NHT][2];
-    {
-        const int slot = lane & 7;
-#pragma unroll
-        for (int ht = 0; ht < NHT; ++ht)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = (2 * wid + j) * 8 + (lane >> 3);
-                if (ht < 2) {
-                    int grow = tile_m * BM + ht * 128 + row;
-                    if (grow > P.m - 1) grow = P.m - 1;
-                    goff[ht][j] = grow * (int)P.lda + ((slot ^ sw_a(row)) << 3);
-                } else {
-                    int grow = tile_n * BN + (ht - 2) * 128 + row;
-                    if (grow > P.n - 1) grow = P.n - 1;
-                    goff[ht][j] = grow * (int)P.ldw + ((slot ^ sw_w<GS>(row)) << 3);
-                }
-            }
-    }
-    // this lane's output columns and their bias (requested first, used in the epilogue: the latency hides under the loop)
-    const int n0 = tile_n * BN + (NI == 4 ? 64 : 32) * wc + (NI == 4 ? 16 : 8) * (lane >> 4);   // first column of this lane
-    constexpr int NC = 4 * NI;                                                                 // columns per lane
-    const bool col_ok = n0 + NC <= P.n;
-    f32x4 bv4[NC / 4];
-#pragma unroll
-    for (int c4 = 0; c4 < NC / 4; ++c4) bv4[c4] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (P.bias && col_ok) {
-#pragma unroll
-        for (int c4 = 0; c4 < NC / 4; ++c4) bv4[c4] = *reinterpret_cast<const f32x4*>(P.bias + n0 + 4 * c4);
-    }
-    auto stage = [&](auto ht_t, int u, int buf) __attribute__((always_inline)) {
-        constexpr int ht = decltype(ht_t)::value;
-        const unsigned short* base = ht < 2 ? P.a : P.w;
+    // ---- LDS-DMA source offsets (elements) of a tile: piece p covers rows 16 p .. 16 p + 15 of an image; lane l lands at
+    //      row 16 p + (l >> 2), slot l & 3.  Wave wid stages A pieces 2 wid, 2 wid + 1 and W pieces WP wid ..
+    struct Src {
+        int a[2], w[WP];
+    };
+    auto tile_src = [&](int tl) __attribute__((always_inline)) -> Src {
+        Src s;
+        const int tm = tl / P.tiles_n, tn = tl - tm * P.tiles_n;
+        const int slot = lane & 3;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            unsigned char* dst = smem + buf * KT_BYTES + ht * HT_BYTES + (2 * wid + j) * 1024;
-            __builtin_amdgcn_global_load_lds((glb_void*)(base + goff[ht][j] + u * BK), (lds_void*)dst, 16, 0, 0);
+            const int row = (2 * wid + j) * 16 + (lane >> 2);
+            int grow = tm * BM + row;
+            if (grow > P.m - 1) grow = P.m - 1;
+            s.a[j] = grow * (int)P.lda + ((slot ^ ((-(row >> 2)) & 3)) << 3);
+        }
+#pragma unroll
+        for (int j = 0; j < WP; ++j) {
+            const int row = (WP * wid + j) * 16 + (lane >> 2);
+            int grow = tn * BN + row;
+            if (grow > P.n - 1) grow = P.n - 1;
+            s.w[j] = grow * (int)P.ldw + ((slot ^ ((-(row >> 3)) & 3)) << 3);
+        }
+        return s;
+    };
+    auto stage = [&](const Src& s, int kstep, int buf) __attribute__((always_inline)) {
+        unsigned char* base = smem + buf * STEP_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void*)(P.a + s.a[j] + kstep * BKS), (lds_void*)(base + (2 * wid + j) * 1024), 16, 0,
+                                             0);
+#pragma unroll
+        for (int j = 0; j < WP; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void*)(P.w + s.w[j] + kstep * BKS),
+                                             (lds_void*)(base + A_BYTES + (WP * wid + j) * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment read offsets (bytes inside a step buffer)
+    const int fi = lane & 15, fg = lane >> 4;
+    const int fsw = (fg ^ ((-(fi >> 2)) & 3)) << 4;                           // same swizzle term for both operands
+    const int xoff = (128 * wr + fi) * ROWB + fsw;                            // + mi * 1024
+    const int woff = A_BYTES + ((NI == 4 ? 64 : 32) * wc + 8 * (fi >> 2) + (fi & 3)) * ROWB + fsw;   // + (4 (ni & 1) + 32 (ni >> 1)) * 64
+
+    f32x4 acc[8][NI];
+    bf16x8 xf[8], wf[NI];
+    f32x4 bv4[NC / 4];   // bias of this lane's columns (hand-counted asm loads in the last step of a tile)
+#pragma unroll
+    for (int c4 = 0; c4 < NC / 4; ++c4) bv4[c4] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#ifdef SNF_GEMM_TRACE   // dev build (tools/gemm_trace.py): workgroup 0 stamps s_memtime around its barriers
+    int trace_n = 0;
+    auto stamp = [&]() __attribute__((always_inline)) {
+        if (P.trace && blockIdx.x == 0 && lane == 0 && (wid == 0 || wid == 4) && trace_n < 160)
+            P.trace[(wid >> 2) * 160 + trace_n++] = __builtin_amdgcn_s_memtime();
+    };
+#else
+    auto stamp = [&]() __attribute__((always_inline)) {};
+#endif
+    auto barrier = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        stamp();
+        __builtin_amdgcn_s_barrier();
+        stamp();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto read_frags = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char* base = smem + buf * STEP_BYTES;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+            wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + woff + (4 * (ni & 1) + 32 * (ni >> 1)) * ROWB));
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) xf[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + xoff + mi * 1024));
+    };
+    auto mma = [&](auto first_t) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_t)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+#ifdef SNF_GEMM_NOMFMA   // timing ablation: operands kept alive, no matrix work
+                if constexpr (FIRST) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+                asm volatile("" : "+v"(acc[mi][ni]) : "v"(wf[ni]), "v"(xf[mi]));
+#else
+                // first step of a tile: C is the constant 0 (no accumulator clearing pass between tiles)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[mi][ni],
+                                                                      0, 0, 0);
+#endif
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // hand-counted bias loads: older than every LDS-DMA issued after them, so the step's own counted wait retires them.
+    // Column groups past N (partial column tile) are never stored; they read a valid address.
+    auto load_bias = [&](int tl) __attribute__((always_inline)) {
+        if (P.bias) {
+            const int tn = tl % P.tiles_n;
+            const int n0 = tn * BN + (NI == 4 ? 64 : 32) * wc + 8 * fg;
+            const float* bp0 = P.bias + (n0 + 8 <= P.n ? n0 : 0);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv4[0]) : "v"(bp0) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(bv4[1]) : "v"(bp0) : "memory");
+            if constexpr (NI == 4) {
+                const float* bp1 = P.bias + (n0 + 40 <= P.n ? n0 + 32 : 0);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv4[2]) : "v"(bp1) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(bv4[3]) : "v"(bp1) : "memory");
+            }
+        }
+    };
+    // names the bias registers in a (free) asm statement placed behind the counted wait that retired their loads
+    auto bias_landed = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int c4 = 0; c4 < NC / 4; ++c4) asm volatile("" : "+v"(bv4[c4]));
+    };
+
+    // epilogue of one tile: lane owns rows 16 mi + fi and columns n0 + {0..7} (+ 32 + {0..7} at BN = 256)
+    auto epilogue = [&](int tl, auto full_t) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_t)::value;
+        const int tm = tl / P.tiles_n, tn = tl - tm * P.tiles_n;
+        const int n0 = tn * BN + (NI == 4 ? 64 : 32) * wc + 8 * fg;
+        const int row0 = tm * BM + 128 * wr + fi;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int row = row0 + 16 * mi;
+#pragma unroll
+            for (int h = 0; h < NI / 2; ++h) {   // 8-column group: ni = 2 h, 2 h + 1
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = activate<ACT>(acc[mi][2 * h + (e >> 2)][e & 3] + bv4[2 * h + (e >> 2)][e & 3]);
+                const int col = n0 + 32 * h;
+                const bool ok = FULL || (row < P.m && col + 8 <= P.n);
+                if constexpr (OUT_F32) {
+                    float* dst = reinterpret_cast<float*>(P.c) + (int64_t)row * P.ldc + col;
+                    if (ok) {
+                        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    }
+                } else {
+                    unsigned short* dst = reinterpret_cast<unsigned short*>(P.c) + (int64_t)row * P.ldc + col;
+                    const u32x4 pk = {cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
+                    if (ok) *reinterpret_cast<u32x4*>(dst) = pk;
+                }
+            }
         }
     };
 
-    // ---- fragment read offsets (bytes inside a half-tile), k half kk = 0 / 1
-    const int fi = lane & 15, fg = lane >> 4;
-    int xoff[2], woff[2];
+    // ---- stream prologue: steps 0 .. AHEAD - 1 of the first tile (ns >= AHEAD)
+    Src cur = tile_src(tile);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        xoff[kk] = fi * 128 + (((4 * kk + fg) ^ sw_a(fi)) << 4);                                   // + mi * 2048
-        const int wrow = (NI == 4 ? 64 * (wc & 1) : 32 * wc) + (1 << GS) * (fi >> 2) + (fi & 3);   // + 4 ni
-        woff[kk] = wrow * 128 + (((4 * kk + fg) ^ sw_w<GS>(wrow)) << 4);                           // + ni * 512
-    }
-    const int a_ht = wr;                               // this wave's A half-tile
-    const int w_ht = 2 + (NI == 4 ? (wc >> 1) : 0);    // and W half-tile
-
-    f32x4 acc[8][NI];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 xf[4][2];          // A fragments of the current 64-row half of the wave's rows
-    bf16x8 wf[NI][2];         // W fragments (all of the wave's columns stay in registers over the K tile)
-
-    auto lds_frag = [&](const unsigned char* p) __attribute__((always_inline)) -> bf16x8 {
-#ifdef SNF_GEMM_NOLDS   // timing ablation (tools/gemm_variants.sh): no LDS reads
-        u32x4 z = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, (unsigned)(uintptr_t)p};
-        asm volatile("" : "+v"(z));
-        return __builtin_bit_cast(bf16x8, z);
-#else
-        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
-#endif
-    };
-    auto read_x = [&](int buf, auto ah_t) __attribute__((always_inline)) {
-        constexpr int ah = decltype(ah_t)::value;
-        const unsigned char* base = smem + buf * KT_BYTES + a_ht * HT_BYTES;
-#pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) xf[m4][kk] = lds_frag(base + xoff[kk] + (4 * ah + m4) * 2048);
-    };
-    auto read_w = [&](int buf, auto lo_t, auto cnt_t) __attribute__((always_inline)) {
-        constexpr int lo = decltype(lo_t)::value, cnt = decltype(cnt_t)::value;
-        const unsigned char* base = smem + buf * KT_BYTES + w_ht * HT_BYTES;
-#pragma unroll
-        for (int n2 = 0; n2 < cnt; ++n2)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) wf[lo + n2][kk] = lds_frag(base + woff[kk] + (lo + n2) * 512);
-    };
-    auto mma = [&](auto ah_t, auto lo_t, auto cnt_t) __attribute__((always_inline)) {
-        constexpr int ah = decltype(ah_t)::value, lo = decltype(lo_t)::value, cnt = decltype(cnt_t)::value;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int m4 = 0; m4 < 4; ++m4)
-#pragma unroll
-                for (int n2 = 0; n2 < cnt; ++n2)
-#ifdef SNF_GEMM_NOMFMA   // timing ablation: operands kept alive, no matrix work
-                    asm volatile("" : "+v"(acc[4 * ah + m4][lo + n2]) : "v"(wf[lo + n2][kk]), "v"(xf[m4][kk]));
-#else
-                    acc[4 * ah + m4][lo + n2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[lo + n2][kk], xf[m4][kk],
-                                                                                       acc[4 * ah + m4][lo + n2], 0, 0, 0);
-#endif
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // end of a phase's load part: this wave's LDS reads have returned (so the slot may be re-staged one phase later),
-    // then the workgroup barrier that hands the matrix pipe over
-    auto load_done = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto mma_done = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-
-    // ---- prologue: K tile 0 complete, the W half-tiles of K tile 1 in flight
-    static_for<0, NHT_W>([&](auto h) __attribute__((always_inline)) { stage(std::integral_constant<int, 2 + decltype(h)::value>{}, 0, 0); });
-    stage(I0{}, 0, 0);
-    stage(I1{}, 0, 0);
-    if (nt > 1) {
-        static_for<0, NHT_W>([&](auto h) __attribute__((always_inline)) { stage(std::integral_constant<int, 2 + decltype(h)::value>{}, 1, 1); });
-        if constexpr (NHT_W == 2)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    for (int i = 0; i < AHEAD; ++i) stage(cur, i, i);
+    wait_vmcnt<(AHEAD - 1) * GL>();   // step 0 has landed, the others stay in flight
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (wr == 1) __builtin_amdgcn_s_barrier();   // the second wave group runs one barrier behind the first
 
-    auto ktile = [&](int t, auto buf_t) __attribute__((always_inline)) {
-        constexpr int buf = decltype(buf_t)::value;
-#ifdef SNF_GEMM_NOSTAGE   // timing ablation: no LDS-DMA inside the loop
-        const bool nxt = false, nxt2 = false;
-#else
-        const bool nxt = t + 1 < nt, nxt2 = t + 2 < nt;
-#endif
-        if constexpr (NI == 4) {
-            // P0: quadrant (rows 0..63, columns 0..31)
-            read_w(buf, I0{}, I2{});
-            read_x(buf, I0{});
-            if (nxt) stage(I0{}, t + 1, buf ^ 1);
-            load_done();
-            mma(I0{}, I0{}, I2{});
-            mma_done();
-            // P1: (rows 0..63, columns 32..63)
-            read_w(buf, I2{}, I2{});
-            if (nxt) stage(I1{}, t + 1, buf ^ 1);
-            load_done();
-            mma(I0{}, I2{}, I2{});
-            mma_done();
-            // P2: (rows 64..127, columns 32..63); the W half-tiles of this K tile are dead: re-stage them for t + 2
-            read_x(buf, I1{});
-            if (nxt2) stage(I2{}, t + 2, buf);
-            load_done();
-            mma(I1{}, I2{}, I2{});
-            mma_done();
-            // P3: (rows 64..127, columns 0..31), no LDS reads
-            if (nxt2) {
-                stage(I3{}, t + 2, buf);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // K tile t + 1 has landed; W(t + 2) stays in flight
+    int rb = 0, sb = AHEAD;        // ring slots of the step being read and of the step being staged (global step mod NBUF)
+    bool after_epilogue = false;   // stores of the previous tile may still be in flight (they count in vmcnt)
+    while (true) {
+        const int next = tile + wgs_per_xcd;
+        const bool has_next = next < t_hi;
+        const Src nxt = tile_src(has_next ? next : tile);
+        const bool full = (tile / P.tiles_n + 1) * BM <= P.m && (tile % P.tiles_n + 1) * BN <= P.n;
+        for (int s = 0; s < ns; ++s) {
+            // ---- load part of step s
+            read_frags(rb);
+            if (s == ns - 1) load_bias(tile);
+            // queue of this wave, oldest first: stage(+1) .. stage(+AHEAD-1) [, the previous tile's stores], then the
+            // stage(+AHEAD) issued here.  The counted wait retires stage(+1) and everything older; at the end of the stream
+            // the queue is shorter by the stages that no longer exist.
+            const bool in_tile = s + AHEAD < ns;
+            const int exist = has_next ? AHEAD : (ns - 1 - s < AHEAD ? ns - 1 - s : AHEAD);   // steps after this one, capped
+            if (in_tile)
+                stage(cur, s + AHEAD, sb);
+            else if (has_next)
+                stage(nxt, s + AHEAD - ns, sb);
+            if (exist == AHEAD) {
+                if (after_epilogue)
+                    wait_vmcnt<(AHEAD - 1) * GL + 8 * NST>();
+                else
+                    wait_vmcnt<(AHEAD - 1) * GL>();
+            } else if (AHEAD == 3 && exist == 2) {
+                wait_vmcnt<GL>();
             } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wait_vmcnt<0>();
             }
-            load_done();
-            mma(I1{}, I0{}, I2{});
-            mma_done();
-        } else {
-            // BN = 128: two phases per K tile (rows 0..63 / 64..127 x all 32 columns of the wave)
-            read_w(buf, I0{}, I2{});
-            read_x(buf, I0{});
-            if (nxt) {
-                stage(I0{}, t + 1, buf ^ 1);
-                stage(I1{}, t + 1, buf ^ 1);
-            }
-            load_done();
-            mma(I0{}, I0{}, I2{});
-            mma_done();
-            read_x(buf, I1{});
-            if (nxt2) {
-                stage(I2{}, t + 2, buf);
-                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // K tile t + 1 has landed; W(t + 2) stays in flight
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            load_done();
-            mma(I1{}, I0{}, I2{});
-            mma_done();
+            after_epilogue = false;
+            rb = rb == NBUF - 1 ? 0 : rb + 1;
+            sb = sb == NBUF - 1 ? 0 : sb + 1;
+            barrier();
+            // ---- MFMA part
+            if (s == 0)
+                mma(std::true_type{});
+            else
+                mma(std::false_type{});
+            barrier();
         }
-    };
-    for (int t = 0; t < nt; t += 2) {
-        ktile(t, I0{});
-        if (t + 1 < nt) ktile(t + 1, I1{});
+        bias_landed();
+        if (full) {
+            epilogue(tile, std::true_type{});
+            after_epilogue = true;     // exactly 8 NST stores issued by this wave
+        } else {
+            epilogue(tile, std::false_type{});
+            wait_vmcnt<0>();           // predicated stores: their count is not known statically
+        }
+        if (!has_next) break;
+        tile = next;
+        cur = nxt;
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();   // barrier counts of the two wave groups match again
-
-    // ---- epilogue: lane owns rows 16 mi + fi and NC consecutive columns from n0: acc[mi][ni][r] = C[row][n0 + 4 ni + r]
-    float bv[NC];
-#pragma unroll
-    for (int c4 = 0; c4 < NC / 4; ++c4) {
-        asm volatile("" : "+v"(bv4[c4]));   // one unconditional wait for the bias here, none inside the row blocks below
-        bv[4 * c4] = bv4[c4][0], bv[4 * c4 + 1] = bv4[c4][1], bv[4 * c4 + 2] = bv4[c4][2], bv[4 * c4 + 3] = bv4[c4][3];
-    }
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-        const int row = tile_m * BM + 128 * wr + 16 * mi + fi;
-        if (row < P.m && col_ok) {
-            float v[NC];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[4 * ni + r] = activate<ACT>(acc[mi][ni][r] + bv[4 * ni + r]);
-            if constexpr (OUT_F32) {
-                float* dst = reinterpret_cast<float*>(P.c) + (int64_t)row * P.ldc + n0;
-#pragma unroll
-                for (int c4 = 0; c4 < NC / 4; ++c4)
-                    *reinterpret_cast<f32x4*>(dst + 4 * c4) = f32x4{v[4 * c4], v[4 * c4 + 1], v[4 * c4 + 2], v[4 * c4 + 3]};
-            } else {
-                unsigned short* dst = reinterpret_cast<unsigned short*>(P.c) + (int64_t)row * P.ldc + n0;
-#pragma unroll
-                for (int c8 = 0; c8 < NC / 8; ++c8) {
-                    const u32x4 pk = {cvt_pk_bf16(v[8 * c8], v[8 * c8 + 1]), cvt_pk_bf16(v[8 * c8 + 2], v[8 * c8 + 3]),
-                                      cvt_pk_bf16(v[8 * c8 + 4], v[8 * c8 + 5]), cvt_pk_bf16(v[8 * c8 + 6], v[8 * c8 + 7])};
-#ifdef SNF_GEMM_NOSTORE   // timing ablation: epilogue arithmetic without the stores
-                    asm volatile("" ::"v"(pk), "v"(dst));
-#else
-                    *reinterpret_cast<u32x4*>(dst + 8 * c8) = pk;
-#endif
-                }
-            }
-        }
-    }
 }
 
 template <int NI, int ACT, bool OUT_F32>
 int launch(const GemmParams& P, hipStream_t s) {
-    constexpr int lds = 2 * (2 + NI / 2) * HT_BYTES;
+    constexpr int lds = NBUF * (A_BYTES + 64 * NI * ROWB);
     static thread_local bool attr_set = false;
     auto kern = gemm_bf16_kernel<NI, ACT, OUT_F32>;
     if (!attr_set) {
@@ -376,7 +348,12 @@ int launch(const GemmParams& P, hipStream_t s) {
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(P.tiles_m * P.tiles_n), dim3(512), lds, s, P);
+    const int ntiles = P.tiles_m * P.tiles_n;
+    int grid = snf::cu_count() & ~7;          // one persistent workgroup per CU, a multiple of the 8 XCDs
+    if (grid < 8) grid = 8;
+    const int per_xcd = (ntiles + 7) / 8;     // no XCD holds more tiles than this
+    if (per_xcd * 8 < grid) grid = per_xcd * 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, P);
     return snf::check_launch("gemm_bf16_kernel");
 }
 
@@ -399,11 +376,11 @@ extern "C" int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t 
     SNF_REQUIRE(m >= 1 && n >= 1 && k >= 1, "snf_gemm_bf16: bad shape m=%lld n=%d k=%d", (long long)m, n, k);
     SNF_REQUIRE(act >= SNF_ACT_RELU && act <= SNF_ACT_NONE, "snf_gemm_bf16: bad activation code %d", act);
     SNF_REQUIRE(out_dtype == SNF_DT_F32 || out_dtype == SNF_DT_BF16, "snf_gemm_bf16: bad output dtype %d", out_dtype);
-    if (k % BK || n % 16 || lda % 8 || ldw % 8 || ldc % (out_dtype == SNF_DT_F32 ? 4 : 8) || lda < k || ldw < k || ldc < n ||
-        (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(c)) % 16 ||
+    if (k % BKS || k < AHEAD * BKS || n % 8 || lda % 8 || ldw % 8 || ldc % (out_dtype == SNF_DT_F32 ? 4 : 8) || lda < k || ldw < k ||
+        ldc < n || (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(c)) % 16 ||
         (bias && reinterpret_cast<uintptr_t>(bias) % 16) || m * lda >= 0x7fffffffll || (int64_t)n * ldw >= 0x7fffffffll) {
         snf::set_error("snf_gemm_bf16: shape m=%lld n=%d k=%d (lda %lld ldw %lld ldc %lld) outside the kernel's domain "
-                       "(k %% 64, n %% 16, 16-byte aligned rows, 31-bit element offsets)",
+                       "(k %% 32, k >= 64, n %% 8, 16-byte aligned rows, 31-bit element offsets)",
                        (long long)m, n, k, (long long)lda, (long long)ldw, (long long)ldc);
         return SNF_EUNSUPPORTED;
     }
@@ -422,6 +399,10 @@ extern "C" int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t 
     P.m = (int)m, P.n = n, P.k = k, P.act = act;
     P.tiles_m = (int)((m + BM - 1) / BM);
     P.tiles_n = (n + tile_n - 1) / tile_n;
+    P.trace = nullptr;
+#ifdef SNF_GEMM_TRACE
+    if (const char* e = getenv("SNF_GEMM_TRACE_PTR")) P.trace = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
+#endif
     hipStream_t s = snf::as_stream(stream);
     if (tile_n == 256) return out_dtype == SNF_DT_F32 ? launch_act<4, true>(P, s) : launch_act<4, false>(P, s);
     return out_dtype == SNF_DT_F32 ? launch_act<2, true>(P, s) : launch_act<2, false>(P, s);

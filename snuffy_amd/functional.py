@@ -232,6 +232,7 @@ def _folded(layer):
             # Q and V projections as ONE GEMM over the shared normalised input: output [N, 2D] = [Q | V]
             wqv=torch.cat([lq.weight * g0, lv.weight * g0]).to(torch.bfloat16).contiguous(),
             bqv=torch.cat([lq.weight @ b0 + lq.bias, lv.weight @ b0 + lv.bias]).to(torch.bfloat16).contiguous(),
+            bqv_f=torch.cat([lq.weight @ b0 + lq.bias, lv.weight @ b0 + lv.bias]).float().contiguous(),
             w1=(ff.w_1.weight * g1).to(torch.bfloat16), b1=(ff.w_1.weight @ b1 + ff.w_1.bias).contiguous(),
             b1h=(ff.w_1.weight @ b1 + ff.w_1.bias).to(torch.bfloat16),
             w2=ff.w_2.weight.to(torch.bfloat16),
@@ -297,7 +298,7 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
     if xhat is None:
         xhat = torch.empty(n, d, dtype=torch.bfloat16, device=x2.device)
         ops.layernorm_rows(x2, None, None, n0.eps, out=xhat)
-    qv = torch.addmm(fw["bqv"], xhat, fw["wqv"].t())                                # [N, 2D] bf16 = [Q | V], bias epilogue
+    qv = ops.linear_bf16(xhat, fw["wqv"], fw["bqv_f"], fw["bqv"])                   # [N, 2D] bf16 = [Q | V], bias epilogue
     q, v = qv[:, :d], qv[:, d:]                                                     # row-strided views, used in place
     if ops.mfma_attn_supported(k, d // h, n, qv.stride(0)):
         # keys = RAW selected rows: the gather also leaves them in bf16, the projection runs like Q | V (bf16 operands,
@@ -313,15 +314,10 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
     delta = F.linear(o, lo.weight, lo.bias)
     x_sel = xs + delta
     ops.layernorm_rows(x_sel, None, None, n1.eps, out=xhat, out_row_idx=sel)        # re-normalise the K rows in place
-    if ff.activation_name == "relu":
-        hid = torch._addmm_activation(fw["b1h"], xhat, fw["w1"].t())            # GEMM + bias + ReLU epilogue
-    elif ff.activation_name == "gelu":
-        # GEMM + bias + GELU epilogue (tanh form: within 4.7e-4 of the erf form, far below the bf16 rounding of hid)
-        hid = torch._addmm_activation(fw["b1h"], xhat, fw["w1"].t(), use_gelu=True)
-    else:
-        hid = torch.mm(xhat, fw["w1"].t())                                          # [N, F] bf16
-        ops.bias_act_(hid, fw["b1"], ff.activation_name)
-    zb = torch.mm(hid, fw["w2"].t())                                                # [N, D] bf16
+    # W1 + bias + activation in the GEMM epilogue: [N, F] bf16.  GELU is the reference's erf form (nn.GELU(), snuffy.py:218) --
+    # the library's fused epilogue only has the tanh form, so gelu / leakyrelu / selu always run on the native kernel
+    hid = ops.linear_bf16(xhat, fw["w1"], fw["b1"], fw["b1h"], ff.activation_name)
+    zb = ops.linear_bf16(hid, fw["w2"])                                             # [N, D] bf16
     del hid
     parts = Parts(x2, add_bf16=zb, add_bias=ff.w_2.bias, slot=slot, delta=delta)
     return parts, (attn.unsqueeze(0) if attn is not None else None)

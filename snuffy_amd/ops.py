@@ -421,8 +421,38 @@ def gemm_supported(m, n, k, lda=None, ldw=None):
     """Shapes snf_gemm_bf16 takes (see include/snuffy_hip.h)."""
     lda = k if lda is None else lda
     ldw = k if ldw is None else ldw
-    return (m >= 1 and k >= 64 and k % 64 == 0 and n >= 16 and n % 16 == 0 and lda % 8 == 0 and ldw % 8 == 0
+    return (m >= 1 and k >= 64 and k % 32 == 0 and n >= 8 and n % 8 == 0 and lda % 8 == 0 and ldw % 8 == 0
             and m * lda < 0x7fffffff and n * ldw < 0x7fffffff)
+
+
+def gemm_prefers_native(m, n, k):
+    """Shape policy measured on MI355X (tools/gemm_bench.py, profiles/r02_gemm_bench.txt): the hand-written kernel wins where
+    the K loop is short (k <= 512: ViT qkv / proj / fc1, bags of <= 8k patches: 1.2 - 1.5x the library); at k >= 768 with
+    large m * n both are bound by the L2 -> LDS fill rate and the library's main loop is ~20 % ahead."""
+    return gemm_supported(m, n, k) and (k <= 512 or (k <= 768 and m * n <= (16 << 20)))
+
+
+def linear_bf16(a, w, bias_f32=None, bias_bf16=None, act="none", prefer_native=None):
+    """act(a @ w.T + bias) -> bf16, on the hand-written MFMA kernel or the library GEMM by the shape policy above.  The
+    activations the library cannot fuse exactly (erf GELU, leaky ReLU, SELU) always take the native kernel when the shape is
+    in its domain."""
+    m, k = a.shape
+    n = w.shape[0]
+    native = gemm_prefers_native(m, n, k) if prefer_native is None else (prefer_native and gemm_supported(m, n, k))
+    if act in ("gelu", "leakyrelu", "selu") and gemm_supported(m, n, k):
+        native = True
+    if native:
+        if bias_f32 is None and bias_bf16 is not None:
+            bias_f32 = bias_bf16.float()
+        return gemm_bf16(a, w, bias_f32, act)
+    if bias_bf16 is None and bias_f32 is not None:
+        bias_bf16 = bias_f32.to(torch.bfloat16)
+    if act == "relu" and bias_bf16 is not None:
+        return torch._addmm_activation(bias_bf16, a, w.t())
+    out = torch.addmm(bias_bf16, a, w.t()) if bias_bf16 is not None else torch.mm(a, w.t())
+    if act != "none":
+        bias_act_(out, None, act)
+    return out
 
 
 def gemm_bf16(a, w, bias=None, act="none", out_dtype=torch.bfloat16, out=None, tile_n=0):

@@ -268,15 +268,16 @@ class VisionTransformer(nn.Module):
         if self._bf16_cache is not None and self._bf16_cache[0] == key:
             return self._bf16_cache[1]
         bf = torch.bfloat16
-        w = dict(pe_w=self.patch_embed.proj.weight.reshape(self.embed_dim, -1).to(bf),
-                 pe_b=self.patch_embed.proj.bias.to(bf), blocks=[])
+        f32 = torch.float32
+        w = dict(pe_w=self.patch_embed.proj.weight.reshape(self.embed_dim, -1).to(bf).contiguous(),
+                 pe_b=self.patch_embed.proj.bias.to(bf), pe_bf=self.patch_embed.proj.bias.to(f32), blocks=[])
         for blk in self.blocks:
-            d = dict(qkv_w=blk.attn.qkv.weight.to(bf),
-                     qkv_b=(blk.attn.qkv.bias if blk.attn.qkv.bias is not None else
-                            torch.zeros(3 * self.embed_dim, device=blk.attn.qkv.weight.device)).to(bf),
-                     proj_w=blk.attn.proj.weight.to(bf), proj_b=blk.attn.proj.bias.to(bf),
-                     fc1_w=blk.mlp.fc1.weight.to(bf), fc1_b=blk.mlp.fc1.bias.to(bf), fc2_w=blk.mlp.fc2.weight.to(bf),
-                     fc2_b=blk.mlp.fc2.bias.to(bf))
+            qkv_bias = (blk.attn.qkv.bias if blk.attn.qkv.bias is not None else
+                        torch.zeros(3 * self.embed_dim, device=blk.attn.qkv.weight.device))
+            d = dict(qkv_w=blk.attn.qkv.weight.to(bf), qkv_b=qkv_bias.to(bf), qkv_bf=qkv_bias.to(f32),
+                     proj_w=blk.attn.proj.weight.to(bf), proj_b=blk.attn.proj.bias.to(bf), proj_bf=blk.attn.proj.bias.to(f32),
+                     fc1_w=blk.mlp.fc1.weight.to(bf), fc1_b=blk.mlp.fc1.bias.to(bf), fc1_bf=blk.mlp.fc1.bias.to(f32),
+                     fc2_w=blk.mlp.fc2.weight.to(bf), fc2_b=blk.mlp.fc2.bias.to(bf), fc2_bf=blk.mlp.fc2.bias.to(f32))
             if hasattr(blk, "adaptmlp"):
                 d.update(dn_w=blk.adaptmlp.down_proj.weight.to(bf), dn_b=blk.adaptmlp.down_proj.bias.to(bf),
                          up_w=blk.adaptmlp.up_proj.weight.to(bf), up_b=blk.adaptmlp.up_proj.bias.to(bf))
@@ -292,7 +293,8 @@ class VisionTransformer(nn.Module):
         W = self._weights_bf16()
         ps = self.patch_embed.patch_size
         cols = ops.vit_patchify(x.float().contiguous(), ps, torch.bfloat16)
-        pe = torch.addmm(W["pe_b"], cols, W["pe_w"].t())                                       # [B*P, D] bf16
+        # patch embedding = im2col rows x conv weight on the hand-written MFMA kernel                 [B*P, D] bf16
+        pe = ops.linear_bf16(cols, W["pe_w"], W["pe_bf"], W["pe_b"], prefer_native=True)
         P = pe.shape[0] // B
         T = P + 1
         pos = self.interpolate_pos_encoding(torch.empty(1, T, self.embed_dim, device="meta"), w_, h_)
@@ -304,20 +306,20 @@ class VisionTransformer(nn.Module):
         ln = ops.layernorm_rows(xt, n1.weight, n1.bias, n1.eps, out_dtype=torch.bfloat16)
         for i, blk in enumerate(self.blocks):
             wb = W["blocks"][i]
-            qkv = torch.addmm(wb["qkv_b"], ln, wb["qkv_w"].t())                                  # [B*T, 3D] bf16
+            qkv = ops.linear_bf16(ln, wb["qkv_w"], wb["qkv_bf"], wb["qkv_b"])                    # [B*T, 3D] bf16
             if use_mfma:
                 o, _ = ops.vit_attention(qkv, B, T, heads, blk.attn.scale)
             else:
                 o, _ = ops.vit_attention(qkv.float(), B, T, heads, blk.attn.scale)
                 o = o.to(torch.bfloat16)
-            y = torch.addmm(wb["proj_b"], o, wb["proj_w"].t())                                   # [B*T, D] bf16
+            y = ops.linear_bf16(o, wb["proj_w"], wb["proj_bf"], wb["proj_b"])                    # [B*T, D] bf16
             has_ad = "dn_w" in wb
             ln2, xb = ops.vit_residual_ln_(xt, add1=y, gamma=blk.norm2.weight, beta=blk.norm2.bias, eps=blk.norm2.eps,
                                            want_ln=True, want_x_bf16=has_ad)                     # x += attn ; LN2(x)
-            # bias + GELU in the GEMM epilogue (tanh form: within 4.7e-4 of nn.GELU's erf, well under the bf16 rounding of
-            # the hidden activations; one rounding instead of two, and no extra pass over the [B*T, 4D] tensor)
-            hdn = torch._addmm_activation(wb["fc1_b"], ln2, wb["fc1_w"].t(), use_gelu=True)
-            m = torch.addmm(wb["fc2_b"], hdn, wb["fc2_w"].t())
+            # bias + GELU (erf form, as nn.GELU) in the epilogue of the hand-written GEMM: one rounding, no extra pass over the
+            # [B*T, 4D] tensor
+            hdn = ops.linear_bf16(ln2, wb["fc1_w"], wb["fc1_bf"], wb["fc1_b"], "gelu")
+            m = ops.linear_bf16(hdn, wb["fc2_w"], wb["fc2_bf"], wb["fc2_b"])
             u, s2 = None, 1.0
             if has_ad:
                 a = torch._addmm_activation(wb["dn_b"], xb, wb["dn_w"].t())                      # ReLU(down(x))

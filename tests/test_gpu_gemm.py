@@ -36,8 +36,9 @@ def run_case(m, n, k, act, tile_n, out_dtype, bias=True, seed=0, lda=None):
 
 
 @pytest.mark.parametrize("tile_n", [256, 128])
-@pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 512, 128), (300, 256, 192), (1000, 384, 768), (257, 1152, 384),
-                                   (4096, 1536, 768), (777, 768, 3072), (1, 128, 64), (255, 16, 64), (640, 48, 128)])
+@pytest.mark.parametrize("m,n,k", [(256, 256, 96), (512, 512, 128), (300, 256, 192), (1000, 384, 768), (257, 1152, 384),
+                                   (4096, 1536, 768), (777, 768, 3072), (1, 128, 96), (255, 16, 160), (640, 48, 128), (513, 264, 96),
+                                   (70000, 256, 96)])
 def test_gemm_shapes(m, n, k, tile_n):
     run_case(m, n, k, "none", tile_n, torch.float32, seed=m + n + k)
     run_case(m, n, k, "none", tile_n, torch.bfloat16, seed=m + n + k + 1)
@@ -57,8 +58,8 @@ def test_gemm_strided_views_and_determinism():
     out2 = run_case(700, 256, 128, "relu", 256, torch.bfloat16, seed=9, lda=384)
     assert torch.equal(out1, out2)
     g = torch.Generator().manual_seed(1)
-    a = torch.randn(512, 64, generator=g).to(torch.bfloat16).to(DEV)
-    w = torch.randn(256, 64, generator=g).to(torch.bfloat16).to(DEV)
+    a = torch.randn(512, 128, generator=g).to(torch.bfloat16).to(DEV)
+    w = torch.randn(256, 128, generator=g).to(torch.bfloat16).to(DEV)
     wide = torch.zeros(512, 512, dtype=torch.bfloat16, device=DEV)
     ops.gemm_bf16(a, w, None, "none", out=wide[:, 256:])
     assert torch.equal(wide[:, 256:], ops.gemm_bf16(a, w)) and float(wide[:, :256].abs().max()) == 0.0
@@ -81,9 +82,9 @@ def test_gemm_config_b_shapes_match_library():
 def test_gemm_rejects_unsupported_shapes():
     from snuffy_amd import ops
     from snuffy_amd._ffi import SnuffyHipError
-    a = torch.zeros(64, 96, dtype=torch.bfloat16, device=DEV)
-    w = torch.zeros(32, 96, dtype=torch.bfloat16, device=DEV)
-    assert not ops.gemm_supported(64, 32, 96)
+    a = torch.zeros(64, 48, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(32, 48, dtype=torch.bfloat16, device=DEV)
+    assert not ops.gemm_supported(64, 32, 48) and ops.gemm_supported(64, 32, 96)
     with pytest.raises(SnuffyHipError):
         ops.gemm_bf16(a, w)
     with pytest.raises(SnuffyHipError):
