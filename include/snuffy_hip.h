@@ -157,6 +157,17 @@ int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t 
                              int kp_dtype, int64_t n, int k, int h, int dk, float scale, float* out, float* attn,
                              float* lse, void* workspace, size_t workspace_bytes, snf_stream_t stream);
 
+/* K7, fp32-class on the matrix cores: q, v, kp fp32; every operand split into hi + lo bf16 halves and every product taken as
+ * three bf16 MFMAs (ah bh + ah bl + al bh, fp32 accumulate); softmax / normalisation fp32.  Same outputs as
+ * snf_sparse_attn_fwd_f32 to ~3e-6 on P, 1e-5 on O (the reference's own arithmetic class, north-star bound 1e-3), ~10x its speed.
+ * q [n, ldq], v [n, ldv] row-major (row pitches in elements, 16-byte aligned rows: column halves of a fused projection are
+ * taken in place); dk in {64, 128}, k <= 256 / 224 keys -- other shapes SNF_EUNSUPPORTED (the caller keeps the exact kernel).
+ * workspace: snf_sparse_attn_fwd_x3_workspace_bytes (deterministic cross-workgroup reduction, as the bf16 kernel). */
+size_t snf_sparse_attn_fwd_x3_workspace_bytes(int64_t n, int k, int h, int dk);
+int snf_sparse_attn_fwd_x3(const float* q, int64_t ldq, const float* v, int64_t ldv, const float* kp, int64_t n, int k, int h,
+                           int dk, float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
+                           snf_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * K7-bwd  sparse attention backward, exact fp32    replaces autograd through attention(), snuffy.py:160-168
  *   p [h, n, k] = the probabilities the forward returned (attn);  mask [h, n, k] nullable = dropout keep-mask already

@@ -59,6 +59,9 @@ SIGNATURES = {
                                         c_void_p]),
     "snf_sparse_attn_fwd_mfma": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int,
                                          c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "snf_sparse_attn_fwd_x3_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "snf_sparse_attn_fwd_x3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_float,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "snf_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
                               c_int, c_int, c_void_p]),
     "snf_vit_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

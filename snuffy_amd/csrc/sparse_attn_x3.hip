@@ -1,0 +1,507 @@
+// K7 (fp32-class form on the matrix cores): Snuffy's sparse attention with SPLIT-bf16 operands.
+//
+//   per head a:   P_a = softmax_j(Q_a Kp_a^T * scale)  [n, k]      O_a = P_a^T V_a  [k, dk]        (snuffy.py:160-168)
+//
+// The reference computes this in fp32.  gfx950 has no fast fp32 matrix path (v_mfma_f32_32x32x2_f32 runs at the vector
+// rate, 1/16 of bf16), so every fp32 operand x is split into x = hi + lo with hi = bf16(x), lo = bf16(x - hi), and every
+// product a b is taken as  ah bh + ah bl + al bh  -- three bf16 MFMAs with fp32 accumulate; the dropped term al bl is
+// 2^-17 relative (fp32-class: measured <= 3.5e-6 on P and <= 1e-5 of its scale on O against the fp64 oracle on nine shapes,
+// tests/test_gpu_kernels.py; the exact vector-ALU kernel gives 4e-7 / 9e-7, the bf16 kernel 5e-3).
+// Softmax, the normalisation and all accumulation are fp32; P is split after the normalisation.
+//
+// The hi + lo images do not fit the two-role kernel's LDS budget (Kp alone is 112 KiB at 224 keys x 128), so this kernel is
+// organised differently: one workgroup (8 waves) per CU walks (head, 32-ROW tile) items and all 8 waves cooperate on a tile:
+//   stage   Q and V rows of the tile: fp32 from HBM one step ahead (registers), split and written as MFMA-shaped images
+//   GEMM1   wave w owns key block w (32 keys): S^T[key, row] = Kp Q^T, 3 MFMAs per 16-deep k-step, operands from LDS
+//   softmax every lane holds 16 keys of ONE row (C layout of the swapped product) -> block-local max / exp / sum, one
+//           (max, sum) pair per wave and row through LDS, combined exactly (as the key-chunked launches of the bf16 kernel)
+//   GEMM2   O[key, col] += P^T V over the tile's 32 rows: 28 output tiles of 32 x 32 spread over the 8 waves, both operands
+//           by hardware transpose-read (ds_read_b64_tr_b16) out of row-major images, 3 MFMAs per 16-row k-step
+// Four workgroup barriers per tile.  Accumulators stay in registers until the head changes; partial tiles are written in
+// fragment order and summed in ascending workgroup order by a second kernel (no float atomics: bit-reproducible).
+// LDS at dk = 128, 224 keys: Kp hi+lo 112 KiB | Q (later P) hi+lo 28 KiB | V hi+lo 16 KiB | row statistics 2 KiB = 158 KiB.
+#include <math.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+struct X3Params {
+    const float* q;    // [n, ldq]
+    const float* v;    // [n, ldv]
+    const float* kp;   // [k, ldkp]
+    int64_t n, ldq, ldv, ldkp;
+    int k, h;
+    float scale;
+    float* attn;       // [h, n, k] or null
+    float* lse;        // [h, n] or null
+    float* partial;    // [num_wg * seg_count][tiles][4][64][4]
+    int tiles_per_head, tiles_per_wg, total_tiles, seg_count;
+};
+
+constexpr int TROWS = 32;   // query rows per step
+constexpr int p_row_bytes(int nkb) { return 64 * (nkb | 1); }   // odd multiple of 64 B (bank rule of the transpose-read)
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// x (8 fp32) -> hi = bf16(x), lo = bf16(x - hi)
+__device__ __forceinline__ void split8(const f32x8 x, u32x4& hi, u32x4& lo) {
+    const bf16x8 h = __builtin_convertvector(x, bf16x8);
+    const f32x8 r = x - __builtin_convertvector(h, f32x8);
+    hi = __builtin_bit_cast(u32x4, h);
+    lo = __builtin_bit_cast(u32x4, __builtin_convertvector(r, bf16x8));
+}
+__device__ __forceinline__ f32x8 load8(const float* p) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigned char* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ float xhalf_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+template <int DK, int NKB, bool AUX>
+__global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
+    constexpr int NKS = DK / 16;               // k-steps of GEMM1
+    constexpr int NCB = DK / 32;               // 32-wide column blocks of the output
+    constexpr int TILES = NKB * NCB;
+    constexpr int NT = (TILES + 7) / 8;        // output tiles owned by one wave
+    constexpr int RS = p_row_bytes(NKB);       // row pitch of a P image
+    constexpr int VRS = 2 * DK, NCH = DK / 8;  // row pitch of a V image, 16-byte chunks per row
+    constexpr int KP_BYTES = NKB * NKS * 1024;
+    constexpr int Q_BYTES = NKS * 1024, PI_BYTES = TROWS * RS;
+    constexpr int QP_BYTES = (Q_BYTES > PI_BYTES ? Q_BYTES : PI_BYTES);
+    constexpr int V_BYTES = TROWS * VRS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* lds_kph = reinterpret_cast<u32x4*>(smem);                       // [NKB][NKS][64] A fragments of Kp, hi
+    u32x4* lds_kpl = reinterpret_cast<u32x4*>(smem + KP_BYTES);            // lo
+    unsigned char* lds_qp = smem + 2 * KP_BYTES;                           // Q fragments hi | lo, later the P images hi | lo
+    u32x4* lds_qh = reinterpret_cast<u32x4*>(lds_qp);
+    u32x4* lds_ql = reinterpret_cast<u32x4*>(lds_qp + QP_BYTES);
+    unsigned char* lds_ph = lds_qp;
+    unsigned char* lds_pl = lds_qp + QP_BYTES;
+    unsigned char* lds_vh = lds_qp + 2 * QP_BYTES;                         // [32 rows][VRS] row-major, chunk-rotated
+    unsigned char* lds_vl = lds_vh + V_BYTES;
+    f32x2* lds_st = reinterpret_cast<f32x2*>(lds_vl + V_BYTES);            // [8 waves][32 rows] (max * c, sum)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, hf = lane >> 5;
+    const int n32 = (int)P.n;
+    const float c_exp = P.scale * 1.44269504088896340736f;
+
+    const int f_begin = blockIdx.x * P.tiles_per_wg;
+    int f_end = f_begin + P.tiles_per_wg;
+    if (f_end > P.total_tiles) f_end = P.total_tiles;
+    if (f_begin >= f_end) return;
+    const int first_head = f_begin / P.tiles_per_head;
+    int a = first_head, t = f_begin - first_head * P.tiles_per_head;
+    int cur_head = -1;
+
+    // ---- staging of one tile's Q and V rows: piece p of Q = B fragment (kb = p >> 6, lane' = p & 63: row lane' & 31,
+    //      8 k from 16 kb + 8 (lane' >> 5)); piece p of V = 8 columns (chunk p % NCH) of row p / NCH
+    constexpr int NQ = NKS * 64, NV = TROWS * NCH;         // 512 + 512 pieces at dk = 128, 256 + 256 at dk = 64
+    constexpr bool ONE_EACH = (NQ == 512);                  // dk = 128: every thread stages one Q and one V piece
+    f32x8 qpre, vpre;                                       // the next tile's pieces, in flight during the current tile
+    auto fetch = [&](int a_, int t_) __attribute__((always_inline)) {
+        const bool do_q = ONE_EACH || tid < NQ;
+        const int p = ONE_EACH ? tid : (tid < NQ ? tid : tid - NQ);
+        if (do_q) {
+            const int kb = p >> 6, lp = p & 63;
+            int row = t_ * TROWS + (lp & 31);
+            if (row > n32 - 1) row = n32 - 1;
+            qpre = load8(P.q + (int64_t)row * P.ldq + a_ * DK + 16 * kb + 8 * (lp >> 5));
+        }
+        if (ONE_EACH || !do_q) {
+            int row = t_ * TROWS + p / NCH;
+            if (row > n32 - 1) row = n32 - 1;
+            vpre = load8(P.v + (int64_t)row * P.ldv + a_ * DK + 8 * (p % NCH));
+        }
+    };
+    auto vrot = [](int r) __attribute__((always_inline)) -> int { return DK == 128 ? (r & 3) : ((r >> 1) & 1); };
+    auto commit = [&]() __attribute__((always_inline)) {
+        const bool do_q = ONE_EACH || tid < NQ;
+        const int p = ONE_EACH ? tid : (tid < NQ ? tid : tid - NQ);
+        u32x4 hi, lo;
+        if (do_q) {
+            split8(qpre, hi, lo);
+            lds_qh[p] = hi;
+            lds_ql[p] = lo;
+        }
+        if (ONE_EACH || !do_q) {
+            split8(vpre, hi, lo);
+            const int row = p / NCH, ch = p % NCH;
+            const int off = row * VRS + 16 * ((ch + 4 * vrot(row)) & (NCH - 1));
+            *reinterpret_cast<u32x4*>(lds_vh + off) = hi;
+            *reinterpret_cast<u32x4*>(lds_vl + off) = lo;
+        }
+    };
+    auto load_kp = [&](int a_) __attribute__((always_inline)) {
+        for (int fr = w; fr < NKB * NKS; fr += 8) {
+            const int jb = fr / NKS, kb = fr - jb * NKS;
+            int key = 32 * jb + j;
+            const bool pad = key >= P.k;
+            if (pad) key = P.k - 1;
+            u32x4 hi, lo;
+            split8(load8(P.kp + (int64_t)key * P.ldkp + a_ * DK + 16 * kb + 8 * hf), hi, lo);
+            if (pad) hi = lo = u32x4{0u, 0u, 0u, 0u};
+            lds_kph[fr * 64 + lane] = hi;
+            lds_kpl[fr * 64 + lane] = lo;
+        }
+    };
+
+    // ---- GEMM2 addressing (as in sparse_attn_mfma_impl.h): reader lane = group g (16 lanes) x i
+    const int rg = lane >> 4, ri = lane & 15;
+    const int rr0 = 8 * (rg >> 1) + (ri >> 2), rr1 = rr0 + 4;
+    const int rch = 4 * (rg & 1) + (ri & 3);
+    const int cb = w & (NCB - 1);                                     // column block of every tile of this wave
+    const int kb0 = w / NCB;                                          // key block of tile ti: kb0 + ti * (8 / NCB)
+    const int poff0 = rr0 * RS + 8 * (rch ^ ((rr0 >> 1) & 7)) + 64 * kb0;
+    const int poff1 = rr1 * RS + 8 * (rch ^ ((rr1 >> 1) & 7)) + 64 * kb0;
+    const int vrc = 4 * cb + 2 * (rg & 1) + ((ri & 3) >> 1);
+    const int voff0 = rr0 * VRS + 16 * ((vrc + 4 * vrot(rr0)) & (NCH - 1)) + 8 * (ri & 1);
+    const int voff1 = rr1 * VRS + 16 * ((vrc + 4 * vrot(rr1)) & (NCH - 1)) + 8 * (ri & 1);
+    // P image writer (softmax): row j, 4 keys per 8-byte chunk; chunk (2 c4 + hf) of key block w at position ^ ((j >> 1) & 7)
+    int waddr[4];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) waddr[c4] = j * RS + 64 * w + 8 * (((2 * c4) | hf) ^ ((j >> 1) & 7));
+
+    f32x16 acc_o[NT];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[ti][r] = 0.f;
+    };
+    auto flush = [&](int head) __attribute__((always_inline)) {
+        const int seg = head - first_head;
+        float* dst = P.partial + ((int64_t)blockIdx.x * P.seg_count + seg) * (int64_t)TILES * 1024;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            const int t_idx = w + 8 * ti;
+            if (t_idx < TILES) {
+                const int key0 = 32 * (t_idx / NCB);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    if (key0 + 8 * q4 < P.k) {
+                        const f32x4 v4 = {acc_o[ti][q4 * 4], acc_o[ti][q4 * 4 + 1], acc_o[ti][q4 * 4 + 2], acc_o[ti][q4 * 4 + 3]};
+                        *reinterpret_cast<f32x4*>(dst + ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4) = v4;
+                    }
+            }
+        }
+    };
+
+    zero_acc();
+    fetch(a, t);
+    const bool attn_vec = AUX && (P.k & 3) == 0 && (reinterpret_cast<uintptr_t>(P.attn) & 15) == 0;
+    for (int f = f_begin; f < f_end; ++f) {
+        int an = a, tn = t + 1;
+        if (tn == P.tiles_per_head) {
+            tn = 0;
+            an = a + 1;
+        }
+        if (a != cur_head) {
+            // new head: everybody is past the previous tile's GEMM2 (closing barrier below), the Kp images are free
+            if (cur_head >= 0) {
+                flush(cur_head);
+                zero_acc();
+            }
+            load_kp(a);
+            cur_head = a;
+        }
+        commit();                                // this tile's Q / V images (fetched one tile ago)
+        if (f + 1 < f_end) fetch(an, tn);        // next tile's rows fly under this tile's work
+        __syncthreads();                         // B1: images complete
+
+        // ---- GEMM1 (swapped): S^T[key, row] for key block w; lane = (row j, half hf): keys 32 w + (r&3) + 8 (r>>2) + 4 hf
+        f32x16 s;
+        float mw = -INFINITY, lw = 0.f;
+        const int row = t * TROWS + j;
+        const bool rvalid = row < n32;
+        if (w < NKB) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < NKS; ++kb) {
+                const bf16x8 kh = __builtin_bit_cast(bf16x8, lds_kph[(w * NKS + kb) * 64 + lane]);
+                const bf16x8 kl = __builtin_bit_cast(bf16x8, lds_kpl[(w * NKS + kb) * 64 + lane]);
+                const bf16x8 qh = __builtin_bit_cast(bf16x8, lds_qh[kb * 64 + lane]);
+                const bf16x8 ql = __builtin_bit_cast(bf16x8, lds_ql[kb * 64 + lane]);
+                s = mfma(kl, qh, s);
+                s = mfma(kh, ql, s);
+                s = mfma(kh, qh, s);
+            }
+            // block-local softmax statistics (padded keys -> -inf)
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                s[r] = key < P.k ? s[r] * c_exp : -INFINITY;
+                mx = fmaxf(mx, s[r]);
+            }
+            mw = xhalf_max(mx);
+            const float mref = mw == -INFINITY ? 0.f : mw;   // a block of padding only (k far below the built capacity): all zeros
+            float l = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = __builtin_amdgcn_exp2f(s[r] - mref);
+                l += s[r];
+            }
+            lw = xhalf_sum(l);
+            if (hf == 0) lds_st[w * 32 + j] = f32x2{mw, lw};
+        }
+        __syncthreads();                         // B2: statistics published, every wave is done with the Q images
+
+        // ---- exact combination over the key blocks, normalisation, publish P = hi + lo
+        if (w < NKB) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int b = 0; b < NKB; ++b) m = fmaxf(m, lds_st[b * 32 + j][0]);
+            float l = 0.f;
+#pragma unroll
+            for (int b = 0; b < NKB; ++b) {
+                const f32x2 st = lds_st[b * 32 + j];
+                l = fmaf(st[1], __builtin_amdgcn_exp2f(st[0] - m), l);
+            }
+            const float fscale = rvalid ? __builtin_amdgcn_exp2f(mw - m) / l : 0.f;
+            if constexpr (AUX)
+                if (P.lse && rvalid && hf == 0 && w == 0) P.lse[(int64_t)a * P.n + row] = (m + __log2f(l)) * 0.69314718055994530942f;
+            float* arow = nullptr;
+            if constexpr (AUX) arow = P.attn ? P.attn + ((int64_t)a * P.n + row) * P.k + 32 * w + 4 * hf : nullptr;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const f32x4 p4 = {s[4 * c4] * fscale, s[4 * c4 + 1] * fscale, s[4 * c4 + 2] * fscale, s[4 * c4 + 3] * fscale};
+                if constexpr (AUX) {
+                    if (arow && rvalid) {
+                        const int key0 = 32 * w + 8 * c4 + 4 * hf;
+                        if (attn_vec && key0 + 4 <= P.k) {
+                            *reinterpret_cast<f32x4*>(arow + 8 * c4) = p4;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (key0 + e < P.k) arow[8 * c4 + e] = p4[e];
+                        }
+                    }
+                }
+                const bf16x2 h01 = __builtin_convertvector(f32x2{p4[0], p4[1]}, bf16x2);
+                const bf16x2 h23 = __builtin_convertvector(f32x2{p4[2], p4[3]}, bf16x2);
+                const f32x2 r01 = f32x2{p4[0], p4[1]} - __builtin_convertvector(h01, f32x2);
+                const f32x2 r23 = f32x2{p4[2], p4[3]} - __builtin_convertvector(h23, f32x2);
+                *reinterpret_cast<u32x2*>(lds_ph + waddr[c4]) = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+                *reinterpret_cast<u32x2*>(lds_pl + waddr[c4]) =
+                    u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2)),
+                          __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2))};
+            }
+        }
+        __syncthreads();                         // B3: P images complete
+
+        // ---- GEMM2: O[key, col] += P^T V over the 32 rows of the tile (two 16-row k-steps, 3 MFMAs each)
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk) {
+            const bf16x8 vh = tr_frag(lds_vh + voff0 + sk * 16 * VRS, lds_vh + voff1 + sk * 16 * VRS);
+            const bf16x8 vl = tr_frag(lds_vl + voff0 + sk * 16 * VRS, lds_vl + voff1 + sk * 16 * VRS);
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) {
+                if (TILES % 8 == 0 || w + 8 * ti < TILES) {
+                    const int off = sk * 16 * RS + ti * (8 / NCB) * 64;
+                    const bf16x8 ph = tr_frag(lds_ph + poff0 + off, lds_ph + poff1 + off);
+                    const bf16x8 pl = tr_frag(lds_pl + poff0 + off, lds_pl + poff1 + off);
+                    acc_o[ti] = mfma(pl, vh, acc_o[ti]);
+                    acc_o[ti] = mfma(ph, vl, acc_o[ti]);
+                    acc_o[ti] = mfma(ph, vh, acc_o[ti]);
+                }
+            }
+        }
+        __syncthreads();                         // B4: images free
+        a = an;
+        t = tn;
+    }
+    flush(cur_head);
+}
+
+// out[key, a*DK + col] = sum over the (workgroup, segment) partials of head a, ascending workgroup order
+template <int DK, int NKB>
+__global__ __launch_bounds__(256) void x3_reduce_kernel(const float* __restrict__ partial, int num_wg, int seg_count,
+                                                        int tiles_per_head, int tiles_per_wg, int k, int h, float* __restrict__ out) {
+    constexpr int NCB = DK / 32, TILES = NKB * NCB;
+    const int a = blockIdx.y;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);   // (tile, q4)
+    if (unit >= TILES * 4) return;
+    const int lane = threadIdx.x & 63;
+    const int t_idx = unit >> 2, q4 = unit & 3;
+    if (32 * (t_idx / NCB) + 8 * q4 >= k) return;
+    const int f_lo = a * tiles_per_head, f_hi = (a + 1) * tiles_per_head - 1;
+    const int b_lo = f_lo / tiles_per_wg;
+    int b_hi = f_hi / tiles_per_wg;
+    if (b_hi > num_wg - 1) b_hi = num_wg - 1;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const int64_t off = ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4;
+    for (int b = b_lo; b <= b_hi; b += 16) {
+        f32x4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (b + u <= b_hi) {
+                const int seg = a - ((b + u) * tiles_per_wg) / tiles_per_head;
+                v[u] = *reinterpret_cast<const f32x4*>(partial + ((int64_t)(b + u) * seg_count + seg) * (int64_t)TILES * 1024 + off);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    const int kb = t_idx / NCB, cbk = t_idx - kb * NCB;
+    const int col = a * DK + 32 * cbk + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int key = 32 * kb + i + 8 * q4 + 4 * (lane >> 5);
+        if (key < k) out[(int64_t)key * (h * DK) + col] = s[i];
+    }
+}
+
+struct X3Plan {
+    int num_wg, tiles_per_head, tiles_per_wg, total_tiles, seg_count, nkb;
+};
+bool x3_plan(int64_t n, int k, int h, int dk, X3Plan* pl) {
+    if (!(dk == 64 || dk == 128) || k < 1 || k > (dk == 128 ? 224 : 256) || n < 1) return false;
+    const int need = (k + 31) / 32;
+    const int opts[] = {2, 4, 7, 8};
+    int sel = 0;
+    for (int o : opts)
+        if (o >= need && !(o == 8 && dk == 128)) {
+            sel = o;
+            break;
+        }
+    if (!sel) return false;
+    const int64_t tph = (n + TROWS - 1) / TROWS, total = tph * h;
+    if (total > 0x7fffffff) return false;
+    const int cus = snf::cu_count();
+    int64_t num_wg = total < cus ? total : cus;
+    const int64_t tpw = (total + num_wg - 1) / num_wg;
+    num_wg = (total + tpw - 1) / tpw;
+    pl->num_wg = (int)num_wg;
+    pl->tiles_per_head = (int)tph;
+    pl->tiles_per_wg = (int)tpw;
+    pl->total_tiles = (int)total;
+    pl->seg_count = (int)((tpw + tph - 1) / tph + 1);
+    pl->nkb = sel;
+    return true;
+}
+size_t x3_workspace(const X3Plan& pl, int dk) { return (size_t)pl.num_wg * pl.seg_count * (size_t)(pl.nkb * (dk / 32)) * 1024 * sizeof(float); }
+
+template <int DK, int NKB, bool AUX>
+int x3_launch(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s) {
+    constexpr int NKS = DK / 16;
+    constexpr int q_bytes = NKS * 1024, p_bytes = TROWS * p_row_bytes(NKB);
+    constexpr int lds = 2 * NKB * NKS * 1024 + 2 * (q_bytes > p_bytes ? q_bytes : p_bytes) + 2 * TROWS * 2 * DK + 8 * 32 * 8;
+    static thread_local bool attr_set = false;
+    auto kern = sparse_attn_x3_kernel<DK, NKB, AUX>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            snf::set_error("sparse_attn_x3: cannot reserve %d bytes of LDS", lds);
+            (void)hipGetLastError();
+            return SNF_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(pl.num_wg), dim3(512), lds, s, P);
+    int rc = snf::check_launch("sparse_attn_x3_kernel");
+    if (rc) return rc;
+    constexpr int TILES = NKB * (DK / 32);
+    hipLaunchKernelGGL((x3_reduce_kernel<DK, NKB>), dim3(TILES, P.h), dim3(256), 0, s, P.partial, pl.num_wg, pl.seg_count,
+                       pl.tiles_per_head, pl.tiles_per_wg, P.k, P.h, out);
+    return snf::check_launch("x3_reduce_kernel");
+}
+template <int DK>
+int x3_dispatch(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s) {
+    const bool aux = P.attn != nullptr || P.lse != nullptr;
+#define X3_CASE(NB) \
+    case NB: return aux ? x3_launch<DK, NB, true>(P, pl, out, s) : x3_launch<DK, NB, false>(P, pl, out, s);
+    switch (pl.nkb) {
+        X3_CASE(2)
+        X3_CASE(4)
+        X3_CASE(7)
+        case 8:
+            if constexpr (DK == 64) return aux ? x3_launch<DK, 8, true>(P, pl, out, s) : x3_launch<DK, 8, false>(P, pl, out, s);
+            break;
+        default: break;
+    }
+#undef X3_CASE
+    snf::set_error("sparse_attn_x3: key-block count %d not built", pl.nkb);
+    return SNF_EUNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t snf_sparse_attn_fwd_x3_workspace_bytes(int64_t n, int k, int h, int dk) {
+    X3Plan pl;
+    if (h < 1 || !x3_plan(n, k, h, dk, &pl)) return 0;
+    return x3_workspace(pl, dk);
+}
+
+int snf_sparse_attn_fwd_x3(const float* q, int64_t ldq, const float* v, int64_t ldv, const float* kp, int64_t n, int k, int h,
+                           int dk, float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
+                           snf_stream_t stream) {
+    SNF_REQUIRE(q && v && kp && out, "snf_sparse_attn_fwd_x3: null pointer");
+    SNF_REQUIRE(n >= 1 && k >= 1 && h >= 1, "snf_sparse_attn_fwd_x3: bad shape");
+    X3Plan pl;
+    if (!x3_plan(n, k, h, dk, &pl)) {
+        snf::set_error("snf_sparse_attn_fwd_x3: unsupported shape k=%d dk=%d (dk in {64, 128}, k <= 256 / 224)", k, dk);
+        return SNF_EUNSUPPORTED;
+    }
+    const int64_t d = (int64_t)h * dk;
+    SNF_REQUIRE(ldq >= d && ldv >= d && (ldq % 4) == 0 && (ldv % 4) == 0, "snf_sparse_attn_fwd_x3: ldq=%lld / ldv=%lld must be >= "
+                "h*dk and keep rows 16-byte aligned", (long long)ldq, (long long)ldv);
+    SNF_REQUIRE(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(kp)) & 15) == 0,
+                "snf_sparse_attn_fwd_x3: q / v / kp must be 16-byte aligned");
+    const size_t need = x3_workspace(pl, dk);
+    if (!workspace || workspace_bytes < need) {
+        snf::set_error("snf_sparse_attn_fwd_x3: workspace %zu < %zu", workspace_bytes, need);
+        return SNF_EWORKSPACE;
+    }
+    X3Params P;
+    P.q = q, P.v = v, P.kp = kp;
+    P.n = n, P.ldq = ldq, P.ldv = ldv, P.ldkp = d;
+    P.k = k, P.h = h, P.scale = scale;
+    P.attn = attn, P.lse = lse;
+    P.partial = reinterpret_cast<float*>(workspace);
+    P.tiles_per_head = pl.tiles_per_head, P.tiles_per_wg = pl.tiles_per_wg, P.total_tiles = pl.total_tiles;
+    P.seg_count = pl.seg_count;
+    hipStream_t s = snf::as_stream(stream);
+    return dk == 128 ? x3_dispatch<128>(P, pl, out, s) : x3_dispatch<64>(P, pl, out, s);
+}
+
+}  // extern "C"

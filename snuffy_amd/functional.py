@@ -20,6 +20,9 @@ from . import ops
 from ._ffi import SnuffyHipError
 
 ACTIVATIONS = ("relu", "gelu", "leakyrelu", "selu")      # reference snuffy.py:215-220
+# attention kernel of the fp32 path: "x3" = split-bf16 x 3 on the matrix cores (fp32-class, ~1e-6 from the exact kernel) where
+# the shape allows, "exact" = fp32 FMA on the vector ALUs for every shape
+FP32_ATTENTION = "x3"
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -276,7 +279,10 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
         xn = ops.layernorm_rows(x2, n0.weight, n0.bias, n0.eps)                     # snuffy.py:107
         q = F.linear(xn, lq.weight, lq.bias)
         v = F.linear(xn, lv.weight, lv.bias)
-        o, attn, _ = ops.sparse_attn_fwd(q, kp, v, h, need_attn=need_attn)           # snuffy.py:160-168
+        if FP32_ATTENTION == "x3" and ops.x3_attn_supported(k, d // h):
+            o, attn, _ = ops.sparse_attn_fwd_x3(q, v, kp, h, need_attn=need_attn)    # snuffy.py:160-168, fp32-class on MFMA
+        else:
+            o, attn, _ = ops.sparse_attn_fwd(q, kp, v, h, need_attn=need_attn)       # exact fp32 on the vector ALUs
         del q, v, xn
         delta = F.linear(o, lo.weight, lo.bias)                                     # snuffy.py:205
         x_sel = xs + delta                                                          # snuffy.py:108

@@ -384,6 +384,37 @@ def sparse_attn_fwd(q, kp, v, h, scale=None, need_attn=False, need_lse=False):
     return out, attn, lse
 
 
+def x3_attn_supported(k, dk):
+    """Shapes of the fp32-class (split-bf16 x 3) MFMA attention kernel."""
+    return (dk == 128 and 1 <= k <= 224) or (dk == 64 and 1 <= k <= 256)
+
+
+def sparse_attn_fwd_x3(q, v, kp, h, scale=None, need_attn=False, need_lse=False):
+    """fp32-class sparse attention on the matrix cores (snf_sparse_attn_fwd_x3): q, v [n, d] f32 (row-strided views allowed),
+    kp [k, d] f32 -> (out [k, d], attn [h, n, k] or None, lse [h, n] or None)."""
+    if q.dtype != torch.float32 or v.dtype != torch.float32:
+        raise TypeError("sparse_attn_fwd_x3: q and v must be float32")
+    q = _rows16(q, "q")
+    v = _rows16(v, "v")
+    kp = _req(kp, torch.float32, "kp", 2)
+    n, d = q.shape
+    k = kp.shape[0]
+    if d % h or kp.shape[1] != d or v.shape != q.shape:
+        raise ValueError("sparse_attn_fwd_x3: inconsistent shapes q %s v %s kp %s h %d" % (tuple(q.shape), tuple(v.shape),
+                                                                                            tuple(kp.shape), h))
+    dk = d // h
+    scale = 1.0 / math.sqrt(dk) if scale is None else scale
+    lib = _ffi.load()
+    out = torch.empty(k, d, dtype=torch.float32, device=q.device)
+    attn = torch.empty(h, n, k, dtype=torch.float32, device=q.device) if need_attn else None
+    lse = torch.empty(h, n, dtype=torch.float32, device=q.device) if need_lse else None
+    wsb = lib.snf_sparse_attn_fwd_x3_workspace_bytes(n, k, h, dk)
+    ws = _ws(wsb, q.device)
+    check(lib.snf_sparse_attn_fwd_x3(_p(q), q.stride(0), _p(v), v.stride(0), _p(kp), n, k, h, dk, float(scale), _p(out), _p(attn),
+                                     _p(lse), _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_x3")
+    return out, attn, lse
+
+
 def sparse_attn_fwd_mfma(q, v, kp, n, h, scale=None, need_attn=False, need_lse=False):
     """bf16-MFMA sparse attention.  q, v [n, d] row-major (both f32 or both bf16; row-strided views such as the two halves
     of a fused [n, 2d] projection are taken in place); kp [k, d] f32 or bf16 (f32 is rounded to bf16 by the library, one

@@ -36,6 +36,30 @@ def attn(wlname="cfgB", dts=("bf16", "f32"), iters=30, K=None, nset=4, N=None):
         del qvs
 
 
+def attn_x3(wlname="cfgB", iters=20, nset=3):
+    wl = WORKLOADS[wlname]
+    N, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
+    K = min(lam, 224)
+    g = torch.Generator().manual_seed(1)
+    kp = torch.randn(K, D, generator=g).to(dev)
+    qvs = [torch.randn(N, 2 * D, generator=g).to(dev) for _ in range(nset)]
+    st = {"i": 0}
+
+    def f():
+        st["i"] = (st["i"] + 1) % nset
+        ops.sparse_attn_fwd_x3(qvs[st["i"]][:, :D], qvs[st["i"]][:, D:], kp, h)
+
+    def fe():
+        st["i"] = (st["i"] + 1) % nset
+        ops.sparse_attn_fwd(qvs[st["i"]][:, :D].contiguous(), kp, qvs[st["i"]][:, D:].contiguous(), h)
+    t = timed(f, iters, warmup=3)
+    b = 2 * N * D * 4 + 2 * K * D * 4
+    print(f"attn_x3 {wlname} N={N} K={K} f32 operands: {t*1e3:8.1f} us  {b/t/1e6:8.1f} GB/s algorithmic ({b/t/1e6/8000*100:.1f}% of 8 TB/s)"
+          f"  {4*N*K*D/t/1e9:.1f} TFLOP/s useful ({3*4*N*K*D/t/1e9:.1f} issued)")
+    t = timed(fe, 5, warmup=1)
+    print(f"attn exact (vector ALU) {wlname}: {t*1e3:8.1f} us")
+
+
 def topk():
     g = torch.Generator().manual_seed(2)
     for n, k in [(8192, 200), (32768, 200), (100000, 512)]:
@@ -79,6 +103,9 @@ if __name__ == "__main__":
     if what in ("attn", "all"):
         attn("cfgB")
         attn("cfgA", dts=("bf16",))
+    if what in ("x3", "all"):
+        attn_x3("cfgB")
+        attn_x3("cfgA")
     if what in ("topk", "all"):
         topk()
     if what in ("rows", "all"):
