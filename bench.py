@@ -85,6 +85,15 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
             i = state["i"] = (state["i"] + 1) % nset
             ops.sparse_attn_fwd_mfma(qvs[i][:, :D], qvs[i][:, D:], kp_in, N, h)
         kern = "sparse_attn_mfma_kernel+reduce_partials_kernel"
+    elif precision == "fp32" and ops.x3_attn_supported(K, dk):   # the fp32 path's kernel: split-bf16 x 3 on the matrix cores
+        vs = [qv[:, D:].float().contiguous() for qv in qvs]
+        qf = [qv[:, :D].float().contiguous() for qv in qvs]
+
+        def attn():
+            i = state["i"] = (state["i"] + 1) % nset
+            ops.sparse_attn_fwd_x3(qf[i], vs[i], kp, h)
+        kern = "sparse_attn_x3_kernel+x3_reduce_kernel"
+        elt = 4
     else:
         vs = [qv[:, D:].float().contiguous() for qv in qvs]
         qf = [qv[:, :D].float().contiguous() for qv in qvs]
@@ -118,7 +127,7 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
     out["roofline"] = dict(bound="hbm", kernel=kern, achieved=round(b_attn / (t_attn * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS,
                            unit="GB/s", frac=round(b_attn / (t_attn * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic=traffic,
                            us_per_launch=round(t_attn * 1e3, 2), algorithmic_bytes=b_attn,
-                           flops=4 * N * K * D, operand_dtype=precision, survey_8d_bytes=b_attn_8d,
+                           flops=4 * N * K * D * (3 if kern.startswith("sparse_attn_x3") else 1), operand_dtype=precision, survey_8d_bytes=b_attn_8d,
                            survey_8d_frac=round(b_attn_8d / (t_attn * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
     t_unit = t_attn + t_topk
     b_unit = b_attn + b_topk + b_gather

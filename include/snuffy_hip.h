@@ -157,6 +157,24 @@ int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t 
                              int kp_dtype, int64_t n, int k, int h, int dk, float scale, float* out, float* attn,
                              float* lse, void* workspace, size_t workspace_bytes, snf_stream_t stream);
 
+/* Attention dropout (training; nn.Dropout(p = 0.1) on p_attn, snuffy.py:166-167,173).  The keep-mask is a pure function of
+ * (seed, offset, head, row, key) -- Philox4x32-10, one call per 4 consecutive keys of a row (csrc/philox.h; host restatement
+ * oracle/philox_ref.py) -- regenerated in registers by the forward and the backward kernel, never stored:
+ *   forward : the normalised probabilities are multiplied by the mask (0 or 1 / (1 - p)) before they are pooled; `out` and the
+ *             returned `attn` are those of the dropped P, as in the reference.  Needs lse (or attn) requested.
+ *   backward: pass mask == NULL and the forward's (dropout_p, seed, offset).
+ * snf_dropout_mask_f32 writes the same mask as a tensor [h, n, k] (exact-fp32 training path, tests). */
+int snf_sparse_attn_fwd_mfma_dropout(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const void* kp,
+                                     int kp_dtype, int64_t n, int k, int h, int dk, float scale, float* out, float* attn,
+                                     float* lse, float dropout_p, uint64_t seed, uint64_t offset, void* workspace,
+                                     size_t workspace_bytes, snf_stream_t stream);
+int snf_sparse_attn_bwd_mfma_dropout(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const float* kp,
+                                     const float* dout, const float* lse, const float* mask, float dropout_p, uint64_t seed,
+                                     uint64_t offset, int64_t n, int k, int h, int dk, float scale, float* dq, float* dv,
+                                     void* ds, int ds_dtype, snf_stream_t stream);
+int snf_dropout_mask_f32(float dropout_p, uint64_t seed, uint64_t offset, int h, int64_t n, int k, float* mask,
+                         snf_stream_t stream);
+
 /* K7, fp32-class on the matrix cores: q, v, kp fp32; every operand split into hi + lo bf16 halves and every product taken as
  * three bf16 MFMAs (ah bh + ah bl + al bh, fp32 accumulate); softmax / normalisation fp32.  Same outputs as
  * snf_sparse_attn_fwd_f32 to ~3e-6 on P, 1e-5 on O (the reference's own arithmetic class, north-star bound 1e-3), ~10x its speed.

@@ -5,7 +5,7 @@ infrastructure and is never imported from here.)
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SNUFFY_HIP_LIB: load another build of the same library (A/B timing of kernel variants, tools/ab.sh)
@@ -62,6 +62,13 @@ SIGNATURES = {
     "snf_sparse_attn_fwd_x3_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "snf_sparse_attn_fwd_x3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "snf_sparse_attn_fwd_mfma_dropout": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int,
+                                                 c_int, c_float, c_void_p, c_void_p, c_void_p, c_float, c_uint64, c_uint64,
+                                                 c_void_p, c_size_t, c_void_p]),
+    "snf_sparse_attn_bwd_mfma_dropout": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 c_float, c_uint64, c_uint64, c_int64, c_int, c_int, c_int, c_float, c_void_p,
+                                                 c_void_p, c_void_p, c_int, c_void_p]),
+    "snf_dropout_mask_f32": (c_int, [c_float, c_uint64, c_uint64, c_int, c_int64, c_int, c_void_p, c_void_p]),
     "snf_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
                               c_int, c_int, c_void_p]),
     "snf_vit_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

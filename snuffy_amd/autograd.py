@@ -71,56 +71,65 @@ class ScatterRowsFn(torch.autograd.Function):
         return dx, None, drows
 
 
+def draw_dropout_state():
+    """(seed, offset) of one dropout mask: the seed of torch's default CPU generator and a 62-bit offset drawn from it --
+    reproducible under torch.manual_seed, no device synchronisation."""
+    return int(torch.initial_seed()), int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
 class SparseAttnFn(torch.autograd.Function):
     """O = dropout(softmax_K(Q Kp^T / sqrt(dk)))^T V per head (snuffy.py:160-168).
 
-    Forward: snf_sparse_attn_fwd_f32 (P materialised: the backward needs it).  Backward: snf_sparse_attn_bwd_f32.
-    """
+    bf16-autocast training (dk = 128 / 64, K within one LDS image): forward AND backward on the MFMA kernels; the dropout
+    mask is regenerated in registers from (seed, offset) in both (csrc/philox.h) -- no [h, N, K] tensor is stored for it and
+    the forward's O is the kernel's own.  Otherwise: fp32-class forward (split-bf16 x 3 on the matrix cores where the shape
+    allows, else the exact vector-ALU kernel) with P materialised for the exact backward kernel snf_sparse_attn_bwd_f32; the
+    mask is the same Philox stream written out as a tensor.  Returns (O, P): P is the dropped P in train mode, as the
+    reference's attention() returns it."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, q, kp, v, h, dropout_p, bf16_operands=False):
+    def forward(ctx, q, kp, v, h, dropout_p, bf16_operands=False, want_p=True):
         n, d = q.shape
         k = kp.shape[0]
         dk = d // h
-        lse = None
-        if bf16_operands and ops.mfma_attn_supported(k, dk):
-            # bf16-autocast training: the forward runs on the matrix cores (bf16 Q / V, fp32 softmax, P returned in fp32)
+        drop = (float(dropout_p),) + draw_dropout_state() if dropout_p > 0.0 else None
+        ctx.h, ctx.drop = h, drop
+        ctx.fast_bwd = bool(bf16_operands and ops.mfma_attn_supported(k, dk) and ops.mfma_attn_bwd_supported(k, dk))
+        if ctx.fast_bwd:
             q16, v16 = q.to(torch.bfloat16), v.to(torch.bfloat16)
-            fast_bwd = ops.mfma_attn_bwd_supported(k, dk)
-            out, p, lse = ops.sparse_attn_fwd_mfma(q16, v16, kp, n, h, need_attn=True, need_lse=fast_bwd)
-            if fast_bwd:
-                q, v = q16, v16          # the MFMA backward recomputes P from the bf16 operands and lse
+            out, p, lse = ops.sparse_attn_fwd_mfma(q16, v16, kp, n, h, need_attn=want_p, need_lse=True, dropout=drop)
+            ctx.save_for_backward(q16, kp, v16, lse)        # P is recomputed from lse, the mask from (seed, offset)
+            return out, p
+        if bf16_operands and ops.mfma_attn_supported(k, dk):
+            out, p, _ = ops.sparse_attn_fwd_mfma(q.to(torch.bfloat16), v.to(torch.bfloat16), kp, n, h, need_attn=True)
+        elif ops.x3_attn_supported(k, dk):
+            out, p, _ = ops.sparse_attn_fwd_x3(q, v, kp, h, need_attn=True)
         else:
             out, p, _ = ops.sparse_attn_fwd(q, kp, v, h, need_attn=True)
         mask = None
-        if dropout_p > 0.0:
-            mask = (torch.rand_like(p) >= dropout_p).to(p.dtype) / (1.0 - dropout_p)
+        if drop is not None:
+            mask = ops.dropout_mask(h, n, k, drop[0], drop[1], drop[2], q.device)
             vh = v.float().view(n, h, dk).transpose(0, 1)
             out = torch.bmm((p * mask).transpose(1, 2), vh).transpose(0, 1).reshape(k, d)
-        if lse is not None:
-            ctx.save_for_backward(q, kp, v, lse, mask)      # P itself is not kept for the backward
-        else:
-            ctx.save_for_backward(q, kp, v, p, mask)
-        ctx.fast_bwd = lse is not None
-        ctx.h = h
-        return out, p
+        ctx.save_for_backward(q, kp, v, p, mask)
+        return out, (p * mask if mask is not None else p)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dout, _dp_unused):
         h = ctx.h
         if ctx.fast_bwd:
-            q, kp, v, lse, mask = ctx.saved_tensors
-            dq, dkp, dv = ops.sparse_attn_bwd_mfma(q, v, kp, dout.float().contiguous(), lse, h, mask=mask)
-            return dq, dkp, dv, None, None, None
+            q, kp, v, lse = ctx.saved_tensors
+            dq, dkp, dv = ops.sparse_attn_bwd_mfma(q, v, kp, dout.float().contiguous(), lse, h, dropout=ctx.drop)
+            return dq, dkp, dv, None, None, None, None
         q, kp, v, p, mask = ctx.saved_tensors
         n, d = q.shape
         dk = d // h
         scale = 1.0 / math.sqrt(dk)
         # K7-bwd on the HIP kernels (exact fp32): dS never leaves the workspace, P / dP are not re-materialised by bmm's
         dq, dkp, dv = ops.sparse_attn_bwd(q, kp, v, p, dout.float().contiguous(), h, mask=mask, scale=scale)
-        return dq, dkp, dv, None, None, None
+        return dq, dkp, dv, None, None, None, None
 
 
 def critic_train(feats2, w, b):
@@ -154,13 +163,13 @@ def _encoder_layer_train(x2, sel, layer, need_attn):
         kp = F.linear(xs, lk.weight, lk.bias)
         v = F.linear(xn, lv.weight, lv.bias)
         p_drop = mha.dropout.p if training else 0.0
-        o, p = SparseAttnFn.apply(q, kp, v, mha.h, p_drop, torch.is_autocast_enabled())
+        o, p = SparseAttnFn.apply(q, kp, v, mha.h, p_drop, torch.is_autocast_enabled(), need_attn)
         delta = F.linear(o, lo.weight, lo.bias)                                 # snuffy.py:205
         if training and drop0.p > 0:
             delta = F.dropout(delta, drop0.p, True)
         x_sel = xs + delta.float()                                              # snuffy.py:108
         y = ScatterRowsFn.apply(x2, sel, x_sel)                                 # snuffy.py:154-155
-        attn = p.detach().unsqueeze(0) if need_attn else None
+        attn = p.detach().unsqueeze(0) if (need_attn and p is not None) else None
     yn = LayerNormRowsFn.apply(y, n1.weight, n1.bias, n1.eps)
     hid = _ACT[ff.activation_name](F.linear(yn, ff.w_1.weight, ff.w_1.bias))    # snuffy.py:224-225
     if training and ff.dropout.p > 0:

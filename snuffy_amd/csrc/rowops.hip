@@ -7,6 +7,7 @@
 #include <math.h>
 
 #include "common.h"
+#include "philox.h"
 
 namespace {
 
@@ -667,6 +668,22 @@ inline int row_grid(int64_t n) {
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void dropout_mask_kernel(snf::DropoutState st, int h, int64_t n, int k, float* __restrict__ mask,
+                                                           int64_t groups) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= groups) return;
+    const int kg = (k + 3) >> 2;
+    const int64_t rowi = g / kg;                      // a * n + row
+    const int key0 = (int)(g - rowi * kg) * 4;
+    snf::philox_f4 m = {1.f, 1.f, 1.f, 1.f};
+    if (st.thresh) m = snf::dropout_mask4(st, (int)(rowi / n), n, rowi % n, k, key0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (key0 + e < k) mask[rowi * k + key0 + e] = m[e];
+}
+}  // namespace
+
 extern "C" {
 
 int snf_critic_f32(const float* x, int64_t n, int d, const float* w, const float* b, int c_out, float* scores,
@@ -847,6 +864,19 @@ int snf_ln_mean_head_f32(const float* z, int64_t n, int d, const void* add_bf16,
     hipLaunchKernelGGL(head_gemv_kernel, dim3(c_out), dim3(256), 0, s, partial2, n, d, gamma, beta, w_head, b_head, pooled,
                        logits);
     return snf::check_launch("head_gemv_kernel");
+}
+
+// The dropout keep-mask of the attention kernels as a tensor: mask[a, row, key] = 0 or 1 / (1 - p) (philox.h).  For the exact
+// fp32 training path (which materialises P anyway) and for tests; the MFMA kernels never store it.
+int snf_dropout_mask_f32(float dropout_p, uint64_t seed, uint64_t offset, int h, int64_t n, int k, float* mask,
+                         snf_stream_t stream) {
+    SNF_REQUIRE(mask && h >= 1 && n >= 1 && k >= 1, "snf_dropout_mask_f32: bad arguments");
+    SNF_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "snf_dropout_mask_f32: dropout_p=%f outside [0, 1)", dropout_p);
+    const snf::DropoutState st = snf::make_dropout(dropout_p, seed, offset);
+    const int64_t groups = (int64_t)h * n * ((k + 3) >> 2);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, snf::as_stream(stream), st, h, n, k,
+                       mask, groups);
+    return snf::check_launch("dropout_mask_kernel");
 }
 
 }  // extern "C"

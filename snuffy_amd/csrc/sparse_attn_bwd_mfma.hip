@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "philox.h"
 
 namespace {
 
@@ -55,6 +56,7 @@ struct BwdParams {
     void* ds;   // [h, n, k] f32, or bf16 when ds_bf16 (the caller then contracts it with a bf16 library GEMM)
     int ds_bf16;
     int tiles_per_head, tiles_per_wg, total_tiles;
+    snf::DropoutState drop;   // mask regenerated in registers when thresh != 0 (and mask == null): same stream as the forward
 };
 
 template <int I, int N, typename F>
@@ -199,6 +201,9 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
                     const int key0 = 32 * jb + 8 * c4 + 4 * hf;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) mk[e] = (key0 + e < P.k) ? mrow[key0 + e] : 0.f;
+                } else if (P.drop.thresh) {
+                    const snf::philox_f4 m4 = snf::dropout_mask4(P.drop, a, P.n, lrow, P.k, 32 * jb + 8 * c4 + 4 * hf);
+                    mk = f32x4{m4[0], m4[1], m4[2], m4[3]};
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -265,6 +270,10 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
                     for (int e = 0; e < 4; ++e) mk[e] = (key0 + e < P.k) ? mrow[key0 + e] : 0.f;
                     ppk[jb][2 * c4] = pack2(pv[0] * mk[0], pv[1] * mk[1]);
                     ppk[jb][2 * c4 + 1] = pack2(pv[2] * mk[2], pv[3] * mk[3]);
+                } else if (P.drop.thresh) {   // the mask is regenerated (second use): 4 keys per Philox call
+                    const snf::philox_f4 m4 = snf::dropout_mask4(P.drop, a, P.n, lrow, P.k, key0);
+                    ppk[jb][2 * c4] = pack2(pv[0] * m4[0], pv[1] * m4[1]);
+                    ppk[jb][2 * c4 + 1] = pack2(pv[2] * m4[2], pv[3] * m4[3]);
                 }
             }
         });
@@ -369,7 +378,17 @@ extern "C" {
 int snf_sparse_attn_bwd_mfma(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const float* kp,
                              const float* dout, const float* lse, const float* mask, int64_t n, int k, int h, int dk,
                              float scale, float* dq, float* dv, void* ds, int ds_dtype, snf_stream_t stream) {
+    return snf_sparse_attn_bwd_mfma_dropout(q, ldq, v, ldv, qv_dtype, kp, dout, lse, mask, 0.f, 0, 0, n, k, h, dk, scale, dq, dv, ds,
+                                            ds_dtype, stream);
+}
+
+int snf_sparse_attn_bwd_mfma_dropout(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const float* kp,
+                                     const float* dout, const float* lse, const float* mask, float dropout_p, uint64_t seed,
+                                     uint64_t offset, int64_t n, int k, int h, int dk, float scale, float* dq, float* dv,
+                                     void* ds, int ds_dtype, snf_stream_t stream) {
     SNF_REQUIRE(q && v && kp && dout && lse && dq && dv && ds, "snf_sparse_attn_bwd_mfma: null pointer");
+    SNF_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "snf_sparse_attn_bwd_mfma: dropout_p=%f outside [0, 1)", dropout_p);
+    SNF_REQUIRE(!(mask && dropout_p > 0.f), "snf_sparse_attn_bwd_mfma: pass a mask tensor OR (dropout_p, seed, offset), not both");
     SNF_REQUIRE(qv_dtype == SNF_DT_F32 || qv_dtype == SNF_DT_BF16, "snf_sparse_attn_bwd_mfma: bad dtype %d", qv_dtype);
     SNF_REQUIRE(ds_dtype == SNF_DT_F32 || ds_dtype == SNF_DT_BF16, "snf_sparse_attn_bwd_mfma: bad ds dtype %d", ds_dtype);
     BwdPlan pl;
@@ -393,6 +412,7 @@ int snf_sparse_attn_bwd_mfma(const void* q, int64_t ldq, const void* v, int64_t 
     P.dout = dout;
     P.lse = lse;
     P.mask = mask;
+    P.drop = snf::make_dropout(dropout_p, seed, offset);
     P.n = n;
     P.ldq = ldq;
     P.ldv = ldv;

@@ -33,7 +33,18 @@ size_t snf_sparse_attn_fwd_workspace_bytes(int64_t n, int k, int h, int dk, int 
 int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const void* kp,
                              int kp_dtype, int64_t n, int k, int h, int dk, float scale, float* out, float* attn,
                              float* lse, void* workspace, size_t workspace_bytes, snf_stream_t stream) {
+    return snf_sparse_attn_fwd_mfma_dropout(q, ldq, v, ldv, qv_dtype, kp, kp_dtype, n, k, h, dk, scale, out, attn, lse, 0.f, 0, 0,
+                                            workspace, workspace_bytes, stream);
+}
+
+int snf_sparse_attn_fwd_mfma_dropout(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const void* kp,
+                                     int kp_dtype, int64_t n, int k, int h, int dk, float scale, float* out, float* attn,
+                                     float* lse, float dropout_p, uint64_t seed, uint64_t offset, void* workspace,
+                                     size_t workspace_bytes, snf_stream_t stream) {
     SNF_REQUIRE(q && v && kp && out, "snf_sparse_attn_fwd_mfma: null pointer");
+    SNF_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "snf_sparse_attn_fwd_mfma: dropout_p=%f outside [0, 1)", dropout_p);
+    SNF_REQUIRE(!(dropout_p > 0.f) || attn || lse, "snf_sparse_attn_fwd_mfma: dropout needs the lse (or attn) output -- "
+                "the backward regenerates the mask and recomputes P from lse");
     SNF_REQUIRE(n >= 1 && k >= 1 && h >= 1, "snf_sparse_attn_fwd_mfma: bad shape");
     SNF_REQUIRE(qv_dtype == SNF_DT_F32 || qv_dtype == SNF_DT_BF16, "snf_sparse_attn_fwd_mfma: bad dtype %d", qv_dtype);
     SNF_REQUIRE(kp_dtype == SNF_DT_F32 || kp_dtype == SNF_DT_BF16, "snf_sparse_attn_fwd_mfma: bad kp dtype %d", kp_dtype);
@@ -75,6 +86,7 @@ int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t 
     P.partial = reinterpret_cast<float*>(workspace);
     P.trace = g_attn_trace;
     P.trace_wg = g_attn_trace_wg;
+    P.drop = snf::make_dropout(dropout_p, seed, offset);
     float* stats = cp.n_chunks > 1 ? reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + partial_bytes)
                                    : nullptr;
     P.n_chunks = cp.n_chunks;

@@ -31,6 +31,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "philox.h"
 
 namespace snf {
 size_t generic_attn_workspace_bytes(int64_t n, int k, int h, int dk);
@@ -57,6 +58,10 @@ struct AttnParams {
     int tiles_per_head, tiles_per_wg, total_tiles, seg_count;
     unsigned long long* trace;  // debug: s_memtime stamps of workgroup trace_wg (tools/attn_trace.py), normally null
     int trace_wg;
+    // attention dropout (training, snuffy.py:166-167): the keep-mask is regenerated from (seed, offset, a, row, key) in
+    // registers (philox.h) and applied to the normalised probabilities before they are published -- O and the returned A
+    // are those of the dropped P, as in the reference.  thresh == 0: off.  Only the AUX variants look at it.
+    snf::DropoutState drop;
 };
 struct Plan {
     int num_wg, tiles_per_head, tiles_per_wg, total_tiles, seg_count, nkb;
@@ -453,8 +458,15 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
                 constexpr int jb = decltype(jb_t)::value;
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4) {
-                    const f32x2 p01 = f32x2{s_acc[jb][4 * c4], s_acc[jb][4 * c4 + 1]} * inv2;
-                    const f32x2 p23 = f32x2{s_acc[jb][4 * c4 + 2], s_acc[jb][4 * c4 + 3]} * inv2;
+                    f32x2 p01 = f32x2{s_acc[jb][4 * c4], s_acc[jb][4 * c4 + 1]} * inv2;
+                    f32x2 p23 = f32x2{s_acc[jb][4 * c4 + 2], s_acc[jb][4 * c4 + 3]} * inv2;
+                    if constexpr (AUX) {
+                        if (P.drop.thresh) {   // training: drop probabilities (wave-uniform branch, never taken in inference)
+                            const snf::philox_f4 mk = snf::dropout_mask4(P.drop, a, P.n, row, (int)P.attn_ld, 32 * jb + 8 * c4 + 4 * hf);
+                            p01 *= f32x2{mk[0], mk[1]};
+                            p23 *= f32x2{mk[2], mk[3]};
+                        }
+                    }
                     if constexpr (AUX) {
                         // the normalised fp32 row is stored before it is converted
                         const int key0 = 32 * jb + 8 * c4;

@@ -302,7 +302,10 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
             if constexpr (AUX) arow = P.attn ? P.attn + ((int64_t)a * P.n + row) * P.k + 32 * w + 4 * hf : nullptr;
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
-                const f32x4 p4 = {s[4 * c4] * fscale, s[4 * c4 + 1] * fscale, s[4 * c4 + 2] * fscale, s[4 * c4 + 3] * fscale};
+                f32x4 p4 = {s[4 * c4] * fscale, s[4 * c4 + 1] * fscale, s[4 * c4 + 2] * fscale, s[4 * c4 + 3] * fscale};
+                // P is ROUNDED to fp32 here in every variant: without this the compiler contracts the product into the
+                // subtraction of the split below (fma) in the variants that do not store A, and their O differs in the last bits
+                asm volatile("" : "+v"(p4));
                 if constexpr (AUX) {
                     if (arow && rvalid) {
                         const int key0 = 32 * w + 8 * c4 + 4 * hf;

@@ -290,7 +290,7 @@ def mfma_attn_bwd_supported(k, dk):
     return (dk == 128 and 1 <= k <= 224) or (dk == 64 and 1 <= k <= 256)
 
 
-def sparse_attn_bwd_mfma(q, v, kp, dout, lse, h, mask=None, scale=None):
+def sparse_attn_bwd_mfma(q, v, kp, dout, lse, h, mask=None, scale=None, dropout=None):
     """MFMA backward (bf16 operands): (dq [n,d] f32, dkp [k,d] f32, dv [n,d] f32) from q, v (f32 or bf16, row-strided views
     allowed), kp [k,d] f32, dout [k,d] f32 and the forward's lse [h,n].  mask: dropout keep-mask / (1 - p) or None."""
     if q.dtype not in (torch.float32, torch.bfloat16) or v.dtype != q.dtype:
@@ -314,8 +314,10 @@ def sparse_attn_bwd_mfma(q, v, kp, dout, lse, h, mask=None, scale=None):
     bf16 = q.dtype == torch.bfloat16
     ds = torch.empty(h, n, k, dtype=torch.bfloat16 if bf16 else torch.float32, device=q.device)
     dt = DT_F32 if q.dtype == torch.float32 else DT_BF16
-    check(lib.snf_sparse_attn_bwd_mfma(_p(q), q.stride(0), _p(v), v.stride(0), dt, _p(kp), _p(dout), _p(lse), _p(mask), n, k,
-                                       h, dk, float(scale), _p(dq), _p(dv), _p(ds), DT_BF16 if bf16 else DT_F32, _stream()),
+    pdrop, seed, offset = dropout if dropout is not None else (0.0, 0, 0)
+    check(lib.snf_sparse_attn_bwd_mfma_dropout(_p(q), q.stride(0), _p(v), v.stride(0), dt, _p(kp), _p(dout), _p(lse), _p(mask),
+                                               float(pdrop), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), n, k, h, dk,
+                                               float(scale), _p(dq), _p(dv), _p(ds), DT_BF16 if bf16 else DT_F32, _stream()),
           "snf_sparse_attn_bwd_mfma")
     if bf16:
         qh = q.view(n, h, dk).transpose(0, 1)                       # [h, n, dk] (strided view)
@@ -415,7 +417,16 @@ def sparse_attn_fwd_x3(q, v, kp, h, scale=None, need_attn=False, need_lse=False)
     return out, attn, lse
 
 
-def sparse_attn_fwd_mfma(q, v, kp, n, h, scale=None, need_attn=False, need_lse=False):
+def dropout_mask(h, n, k, p, seed, offset, device):
+    """The attention kernels' dropout mask as a tensor [h, n, k] f32 (0 or 1 / (1 - p)) -- see snf_dropout_mask_f32."""
+    m = torch.empty(h, n, k, dtype=torch.float32, device=device)
+    with torch.cuda.device(m.device):
+        check(_ffi.load().snf_dropout_mask_f32(float(p), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), h, n, k, _p(m),
+                                               _stream()), "snf_dropout_mask_f32")
+    return m
+
+
+def sparse_attn_fwd_mfma(q, v, kp, n, h, scale=None, need_attn=False, need_lse=False, dropout=None):
     """bf16-MFMA sparse attention.  q, v [n, d] row-major (both f32 or both bf16; row-strided views such as the two halves
     of a fused [n, 2d] projection are taken in place); kp [k, d] f32 or bf16 (f32 is rounded to bf16 by the library, one
     extra small launch)."""
@@ -443,8 +454,10 @@ def sparse_attn_fwd_mfma(q, v, kp, n, h, scale=None, need_attn=False, need_lse=F
     ws = _ws(wsb, q.device)
     dt = DT_F32 if q.dtype == torch.float32 else DT_BF16
     kdt = DT_F32 if kp.dtype == torch.float32 else DT_BF16
-    check(lib.snf_sparse_attn_fwd_mfma(_p(q), q.stride(0), _p(v), v.stride(0), dt, _p(kp), kdt, n, k, h, dk, float(scale),
-                                       _p(out), _p(attn), _p(lse), _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_mfma")
+    pdrop, seed, offset = dropout if dropout is not None else (0.0, 0, 0)
+    check(lib.snf_sparse_attn_fwd_mfma_dropout(_p(q), q.stride(0), _p(v), v.stride(0), dt, _p(kp), kdt, n, k, h, dk, float(scale),
+                                               _p(out), _p(attn), _p(lse), float(pdrop), int(seed) & (2 ** 64 - 1),
+                                               int(offset) & (2 ** 64 - 1), _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_mfma")
     return out, attn, lse
 
 
