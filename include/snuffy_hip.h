@@ -254,6 +254,20 @@ int snf_vit_attention_f32(const float* qkv, int b, int t, int h, int dk, float s
 int snf_vit_attention_mfma(const void* qkv_bf16, int b, int t, int h, int dk, float scale, void* out_bf16,
                            snf_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Tile preprocessing for the extractor, batched on the device     replaces the per-tile CPU transforms of
+ *     compute_feats.py:104-152,173-177: Resize(224) (PIL bilinear + antialiasing), ToTensor (/ 255), NormalizeImage
+ *   img_u8 [b, h, w, c] uint8 (decoded tiles, channels last, c <= 4).  The resize is Pillow's 8-bit resampler: horizontal
+ *   then vertical pass with the integer coefficient tables computed by the caller (snuffy_amd/tiles.py restates Pillow's
+ *   precompute_coeffs / normalize_coeffs_8bpc): hbounds [ow][2] = (first input column, count), hcoef [ow][hks]; vbounds /
+ *   vcoef likewise for rows (device int32 arrays).  mean / std: HOST arrays of c floats (used when normalize != 0).
+ *   Outputs, either nullable: out_f32 [b, c, oh, ow]; cols_bf16 [b * (oh/patch) * (ow/patch), c * patch * patch] = the
+ *   patch-embedding GEMM operand (column order (c, i, j)).  Bit-exact against PIL + torch on the same tiles.
+ * --------------------------------------------------------------------------------------------------------- */
+int snf_tile_preprocess_u8(const void* img_u8, int b, int h, int w, int c, int oh, int ow, const int* hbounds, const int* hcoef,
+                           int hks, const int* vbounds, const int* vcoef, int vks, int normalize, const float* mean,
+                           const float* std_, float* out_f32, void* cols_bf16, int patch, snf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,8 @@ SIGNATURES = {
                                                  c_float, c_uint64, c_uint64, c_int64, c_int, c_int, c_int, c_float, c_void_p,
                                                  c_void_p, c_void_p, c_int, c_void_p]),
     "snf_dropout_mask_f32": (c_int, [c_float, c_uint64, c_uint64, c_int, c_int64, c_int, c_void_p, c_void_p]),
+    "snf_tile_preprocess_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                       c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "snf_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
                               c_int, c_int, c_void_p]),
     "snf_vit_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -69,10 +69,33 @@ class TileTransform:
         return {**sample, 'input': t, 'label': torch.tensor(label)}
 
 
+class DecodeOnly:
+    """Host half of the batched preprocessing: decode the tile to RGB uint8 [H, W, 3] and stop -- Resize(224),
+    ToTensor and the normalisation run on the GPU for the whole batch (snuffy_amd.tiles.preprocess_tiles, bit-identical to
+    TileTransform).  The uint8 tile is a quarter of the bytes of the fp32 tensor on the PCIe link as well."""
+
+    def __call__(self, sample):
+        img = sample['input'].convert('RGB')
+        t = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())
+        label = sample['label']
+        assert isinstance(label, int), f"A sample label should be of type int, but {type(label)} received."
+        return {**sample, 'input': t, 'label': torch.tensor(label)}
+
+
+def device_preprocess(args):
+    """Batched on-device tile preprocessing is the default for the ViT backbones; --device_preprocess 0 keeps the reference's
+    per-tile PIL path on the DataLoader workers."""
+    is_vit = args.backbone in VIT_BACKBONES or args.backbone == 'vitbasetimm'
+    return is_vit and int(getattr(args, 'device_preprocess', 1)) == 1
+
+
 def bag_dataset(args, patches, patch_labels_dict=None):
     """(DataLoader, number of tiles) for one slide directory (reference compute_feats.py:155-197)."""
     is_vit = args.backbone in VIT_BACKBONES or args.backbone == 'vitbasetimm'
-    tf = TileTransform(224 if is_vit else None, normalize=(getattr(args, 'transform', 0) == 1))
+    if device_preprocess(args):
+        tf = DecodeOnly()
+    else:
+        tf = TileTransform(224 if is_vit else None, normalize=(getattr(args, 'transform', 0) == 1))
     ds = BagDataset(files_list=patches, transform=tf, patch_labels_dict=patch_labels_dict)
     return DataLoader(ds, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers, drop_last=False), len(ds)
 
@@ -179,8 +202,15 @@ def compute_feats(args, bags_list, embedder, save_path, patch_labels_dict=None):
         loader, _ = bag_dataset(args, patches, patch_labels_dict)
         feats, labels, positions = [], [], []
         with torch.no_grad():
+            on_device = device_preprocess(args)
             for batch in loader:
-                f, _ = embedder(batch['input'].float().to(device, non_blocking=True))
+                if on_device:   # uint8 tiles up, one kernel: Resize(224) + / 255 (+ ImageNet normalisation)
+                    from .tiles import preprocess_tiles
+                    x = preprocess_tiles(batch['input'].to(device, non_blocking=True), 224,
+                                         normalize=(getattr(args, 'transform', 0) == 1))
+                else:
+                    x = batch['input'].float().to(device, non_blocking=True)
+                f, _ = embedder(x)
                 feats.append(f)
                 labels.extend(np.atleast_1d(batch['label'].squeeze().tolist()).tolist())
                 positions.extend(batch['position'])

@@ -308,6 +308,39 @@ def run_f9():
     print("F9 done", {k: v.shape for k, v in out.items() if k.startswith("mil_10")})
 
 
+def run_f10():
+    """F10 tile preprocessing (compute_feats.py:104-152,173-177).  torchvision is not importable here; its Resize(224) on a PIL
+    image is PIL's own Image.resize(size, BILINEAR) (torchvision/transforms/_functional_pil.py), ToTensor is uint8 / 255 in fp32
+    and NormalizeImage is (t - mean) / std per channel: captured with PIL + torch on seeded uint8 tiles."""
+    from PIL import Image
+    rs = np.random.RandomState(10)
+    out = {}
+    mean = torch.tensor((0.485, 0.456, 0.406)).view(3, 1, 1)
+    std = torch.tensor((0.229, 0.224, 0.225)).view(3, 1, 1)
+    for name, (h, w) in [("t256", (256, 256)), ("t96x80", (96, 80)), ("t40x70", (40, 70))]:
+        # smooth image + noise: exercises the rounding of the fixed-point accumulation on non-trivial gradients
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([(np.sin(xx / 7.0 + c) + np.cos(yy / 5.0 - c)) * 60 + 128 for c in range(3)], axis=-1)
+        img = np.clip(base + rs.randint(-40, 41, (h, w, 3)), 0, 255).astype(np.uint8)
+        size = 224 if name == "t256" else 32
+        if (w <= h and w == size) or (h <= w and h == size):
+            oh, ow = h, w
+        elif w < h:
+            oh, ow = int(size * h / w), size
+        else:
+            oh, ow = size, int(size * w / h)
+        res = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+        t = torch.from_numpy(res.copy()).permute(2, 0, 1).float().div(255.0)
+        out[name + ".img"] = img
+        out[name + ".size"] = np.int64(size)
+        out[name + ".resized_u8"] = res
+        out[name + ".tensor"] = t.numpy() if name != "t256" else t[:, ::7, ::5].numpy()       # subsampled: keeps the file small
+        tn = (t - mean) / std
+        out[name + ".normalized"] = tn.numpy() if name != "t256" else tn[:, ::7, ::5].numpy()
+    np.savez_compressed(os.path.join(HERE, "f10_tiles.npz"), **out)
+    print("F10 done", {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.ndim})
+
+
 def run_f6():
     for name, B, N, D, h, lam, r, depth, seed in [
         ("mc_b1_n100", 1, 100, 64, 4, 10, 0.0, 1, 31),
@@ -337,7 +370,7 @@ def run_f6():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f9"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f9", "f10"]
     if "f1" in which:
         run_f1()
     if "f2" in which:
@@ -350,6 +383,8 @@ if __name__ == "__main__":
         run_f6()
     if "f9" in which:
         run_f9()
+    if "f10" in which:
+        run_f10()
 
 
 # ----------------------------------------------------------------------------------------------------------------------

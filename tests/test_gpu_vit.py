@@ -201,3 +201,59 @@ def test_positional_weight_loading_like_reference(tmp_path):
     emb, _ = cf.get_embedder(args, model, 128)
     for k in ref_order:
         assert torch.equal(emb.state_dict()["feature_extractor." + k].cpu(), sd[k])
+
+
+def test_tile_preprocess_kernel_bit_exact_vs_pil_fixtures():
+    """snf_tile_preprocess_u8 (Resize + ToTensor + NormalizeImage for a batch of uint8 tiles in one launch) against the PIL /
+    torch fixtures: the fp32 tensor bit for bit, the bf16 patch-embedding operand = patchify of that tensor."""
+    from snuffy_amd import ops as o
+    from snuffy_amd.tiles import preprocess_tiles
+    z = np.load(golden_files("f10_")[0])
+    for name in ("t256", "t96x80", "t40x70"):
+        size = int(z[name + ".size"])
+        img = torch.from_numpy(z[name + ".img"]).to(DEV)
+        batch = torch.stack([img, img.flip(0), img.flip(1)])                      # three tiles, one launch
+        for normalize, key in ((False, ".tensor"), (True, ".normalized")):
+            out = preprocess_tiles(batch, size, normalize=normalize)
+            got = out[0].cpu().numpy()
+            want = z[name + key]
+            if name == "t256":
+                got = got[:, ::7, ::5]
+            assert np.array_equal(got, want), (name, normalize)
+        u8 = (preprocess_tiles(batch, size)[0] * 255.0).round().to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+        assert np.array_equal(u8, z[name + ".resized_u8"])
+    # the GEMM-operand output: same values as patchify of the fp32 output, for the whole batch
+    img = torch.from_numpy(z["t256.img"]).to(DEV)
+    batch = torch.stack([img, img.flip(0)])
+    f32, cols = preprocess_tiles(batch, 224, normalize=True, want="both", patch=16)
+    assert torch.equal(cols, o.vit_patchify(f32, 16, torch.bfloat16))
+    with pytest.raises(Exception):
+        preprocess_tiles(batch.cpu(), 224)
+
+
+def test_compute_feats_device_preprocess_equals_pil_path(tmp_path):
+    """compute_feats with the batched on-device preprocessing (default) writes the same CSV as with the reference's per-tile
+    PIL transforms (--device_preprocess 0): the two pipelines feed the embedder identical tensors."""
+    import argparse
+
+    import pandas as pd
+    from PIL import Image
+
+    from snuffy_amd import compute_feats as cf
+    rng = np.random.RandomState(1)
+    bag_dir = tmp_path / "single" / "normal" / "slide_007"
+    bag_dir.mkdir(parents=True)
+    for r in range(2):
+        for c in range(3):
+            Image.fromarray(rng.randint(0, 255, (256, 256, 3), dtype=np.uint8)).save(bag_dir / f"{r}_{c}.jpeg", quality=90)
+    outs = {}
+    for mode in (1, 0):
+        args = argparse.Namespace(backbone="vit_tiny", embedder="DINO_adapter", patch_size=16, adapter_ffn_scalar="10",
+                                  ffn_num=8, num_classes=1, batch_size=4, num_workers=0, transform=1, dataset="tcga",
+                                  weights=None, precision="fp32", device_preprocess=mode)
+        torch.manual_seed(0)
+        backbone, nf = cf.get_embedder_backbone(args)
+        embedder, _ = cf.get_embedder(args, backbone, nf)
+        cf.compute_feats(args, [str(bag_dir)], embedder, str(tmp_path / f"out{mode}"))
+        outs[mode] = pd.read_csv(tmp_path / f"out{mode}" / "single" / "normal" / "slide_007.csv").to_numpy()
+    assert outs[1].shape == (6, 192) and np.array_equal(outs[0], outs[1])

@@ -123,3 +123,43 @@ def test_arch_registry_and_parser():
     assert set(train.ARCH_REGISTRY) == {"snuffy", "snuffy_multiclass"}
     a = train.get_args_parser().parse_args(["--scheduler", "cosinewarmup"])
     assert a.scheduler == "cosinewarmup" and a.big_lambda == 200 and a.betas == [0.5, 0.9]
+
+
+def test_pil_resampler_tables_reproduce_pil_fixtures():
+    """snuffy_amd.tiles.resample_coeffs (Pillow's 8-bit bilinear resampler restated) applied in numpy == the PIL-resized
+    fixtures, byte for byte -- the tables are what the HIP kernel consumes (reference compute_feats.py:173-177: Resize(224))."""
+    from snuffy_amd.tiles import PRECISION_BITS, resample_coeffs, resize_target
+    z = np.load(golden_files("f10_")[0])
+    for name in ("t256", "t96x80", "t40x70"):
+        img, want = z[name + ".img"], z[name + ".resized_u8"]
+        h, w, _ = img.shape
+        oh, ow = resize_target(h, w, int(z[name + ".size"]))
+        assert (oh, ow) == want.shape[:2]
+        hb, hc, _ = resample_coeffs(w, ow)
+        vb, vc, _ = resample_coeffs(h, oh)
+        tmp = np.zeros((h, ow, 3), dtype=np.uint8)
+        for ox in range(ow):
+            x0, n = hb[ox]
+            acc = (img[:, x0:x0 + n, :].astype(np.int64) * hc[ox, :n].astype(np.int64)[None, :, None]).sum(1)
+            tmp[:, ox, :] = np.clip((acc + (1 << (PRECISION_BITS - 1))) >> PRECISION_BITS, 0, 255)
+        out = np.zeros((oh, ow, 3), dtype=np.uint8)
+        for oy in range(oh):
+            y0, n = vb[oy]
+            acc = (tmp[y0:y0 + n].astype(np.int64) * vc[oy, :n].astype(np.int64)[:, None, None]).sum(0)
+            out[oy] = np.clip((acc + (1 << (PRECISION_BITS - 1))) >> PRECISION_BITS, 0, 255)
+        assert np.array_equal(out, want), name
+    assert resize_target(224, 224, 224) == (224, 224) and resize_target(256, 256, 224) == (224, 224)
+    assert resize_target(300, 260, 224) == (258, 224) and resize_target(200, 333, 224) == (224, 372)
+
+
+def test_tile_transform_matches_pil_fixtures():
+    """The PIL path kept for --device_preprocess 0 (compute_feats.TileTransform) against the same fixtures."""
+    from PIL import Image
+
+    from snuffy_amd.compute_feats import TileTransform
+    z = np.load(golden_files("f10_")[0])
+    for name in ("t96x80", "t40x70"):
+        size = int(z[name + ".size"])
+        for normalize, key in ((False, ".tensor"), (True, ".normalized")):
+            out = TileTransform(size, normalize)({"input": Image.fromarray(z[name + ".img"]), "label": 0, "position": None})
+            assert np.array_equal(out["input"].numpy(), z[name + key]), (name, normalize)
