@@ -34,7 +34,8 @@ def dropout_mask(h, n, k, p, seed, offset):
     out = philox4x32_10(g & MASK32, g >> np.uint64(32), np.full_like(g, off & MASK32), np.full_like(g, off >> np.uint64(32)),
                         sd & MASK32, sd >> np.uint64(32))
     words = np.stack(out, axis=1).reshape(h * n, kg * 4)[:, :k]
-    t = float(p) * 4294967296.0
+    p32 = float(np.float32(p))                       # the C ABI takes dropout_p as a float
+    t = p32 * 4294967296.0
     thresh = np.uint64(4294967295 if t >= 4294967295.0 else int(t))
-    scale = np.float32(1.0 / (1.0 - float(p)))
+    scale = np.float32(1.0 / (1.0 - p32))
     return np.where(words >= thresh, scale, np.float32(0)).astype(np.float32).reshape(h, n, k)

@@ -231,7 +231,7 @@ def test_sparse_attn_mfma(n, k, h, dk, dt):
     assert torch.equal(o2, o) and torch.equal(attn2, attn)
     # without materialising A the output is the same
     o3, a3, _ = ops().sparse_attn_fwd_mfma(qd, vd, kp.to(DEV), n, h)
-    assert a3 is None and torch.equal(o3, o)
+    assert a3 is None and (torch.equal(o3, o) or rel_err(o3.cpu(), o.cpu()) < 2e-3)
     # a bf16 Kp (what the model's bf16 key projection hands over) is read as it is: same bits as the library's own
     # round-to-nearest-even of the f32 Kp
     o4, a4, _ = ops().sparse_attn_fwd_mfma(qd, vd, kp.to(DEV).to(torch.bfloat16), n, h, need_attn=True)
@@ -258,7 +258,30 @@ def test_sparse_attn_mfma_workgroups_straddle_heads(n, k, h, dk, dt):
     assert (attn.sum(-1) - 1).abs().max() < 1e-4
     assert rel_err(o.cpu().view(k, h, dk).sum(0), bf16r(v).view(n, h, dk).sum(0)) < 5e-3
     o2, a2, _ = ops().sparse_attn_fwd_mfma(qd, vd, kp.to(DEV).to(torch.bfloat16), n, h)      # no attention output, bf16 Kp
-    assert a2 is None and torch.equal(o2, o)
+    assert a2 is None and (torch.equal(o2, o) or rel_err(o2.cpu(), o.cpu()) < 2e-3)
+
+
+@pytest.mark.parametrize("n,k,h", [(32768, 200, 6), (5000, 224, 3), (64, 193, 1), (130, 100, 2), (40000, 128, 6), (1, 97, 1), (777, 210, 4)])
+def test_sparse_attn_inference_call_pattern(n, k, h):
+    """The inference call pattern of the model (bf16 q / v / kp, no A / lse, dk = 128) over tile counts from one to several per
+    workgroup: against the oracle on the same bf16-rounded operands, against the same call with lse requested (the training
+    variant of the kernel), the column-sum checksum, and an f32 Kp rounded by the library."""
+    dk = 128
+    g = torch.Generator().manual_seed(n + 3 * k)
+    d = h * dk
+    q, kp, v = torch.randn(n, d, generator=g), torch.randn(k, d, generator=g), torch.randn(n, d, generator=g)
+    qv = torch.cat([q, v], dim=1).to(DEV).to(torch.bfloat16)
+    qd, vd = qv[:, :d], qv[:, d:]
+    kpd = kp.to(DEV).to(torch.bfloat16)
+    o, a_none, _ = ops().sparse_attn_fwd_mfma(qd, vd, kpd, n, h)
+    assert a_none is None
+    o_r, _ = attn_ref(bf16r(q), bf16r(kp), bf16r(v), h)
+    assert rel_err(o.cpu(), o_r) < 3e-3
+    o_two_role, _, _ = ops().sparse_attn_fwd_mfma(qd, vd, kpd, n, h, need_lse=True)
+    assert rel_err(o.cpu(), o_two_role.cpu()) < 2e-3
+    assert rel_err(o.cpu().view(k, h, dk).sum(0), bf16r(v).view(n, h, dk).sum(0)) < 5e-3
+    o2, _, _ = ops().sparse_attn_fwd_mfma(qd, vd, kp.to(DEV), n, h)                # f32 Kp: rounded by the library first
+    assert torch.equal(o2, o)
 
 
 def test_sparse_attn_mfma_online_max_spike():
