@@ -21,6 +21,8 @@ g = torch.Generator().manual_seed(5)
 nset = 4
 xs = [torch.randn(N, D, generator=g).to(dev) for _ in range(nset)]
 qvs = [torch.randn(N, 2 * D, generator=g).to(dev).to(torch.bfloat16) for _ in range(nset)]
+qvf = [torch.randn(N, 2 * D, generator=g).to(dev) for _ in range(2)]       # fp32 operands of the fp32-class (x3) kernel
+kpf = torch.randn(K, D, generator=g).to(dev)
 kp = torch.randn(K, D, generator=g).to(dev).to(torch.bfloat16)   # as the model's bf16 path passes it
 w = torch.randn(1, D, generator=g).to(dev)
 b = torch.zeros(1, device=dev)
@@ -31,6 +33,7 @@ for it in range(12):
     ops.critic(xs[i], w, b)                                   # calibration read : N*D*4 bytes
     outs[i].fill_(1.0)                                        # calibration write: N*D*4 bytes
     ops.sparse_attn_fwd_mfma(qvs[i][:, :D], qvs[i][:, D:], kp, N, h)
+    ops.sparse_attn_fwd_x3(qvf[it % 2][:, :D], qvf[it % 2][:, D:], kpf, h)
 torch.cuda.synchronize()
 print("known bytes: critic read %d, fill write %d, attention algorithmic %d (Q,V bf16 + Kp + O)"
       % (N * D * 4, N * D * 4, 2 * N * D * 2 + K * D * (2 + 4)))

@@ -46,5 +46,20 @@ out["total_bytes"] = tot
 out["algorithmic_bytes"] = alg
 out["workload"] = "cfgB N=32768 D=768 h=6 K=200 bf16 operands"
 out["fetch_bytes_per_unit"], out["write_bytes_per_unit"] = fr, fw
+out["kernel"] = "sparse_attn_mfma_kernel+reduce_partials_kernel"
 if len(sys.argv) > 2:
     json.dump(out, open(sys.argv[2], "w"), indent=1)
+# the fp32-class kernel (split-bf16 x 3): fp32 Q, V, Kp in, O out
+if pick(fetch, "sparse_attn_x3_kernel") is not None:
+    o3 = {}
+    for name in ("sparse_attn_x3_kernel", "x3_reduce_kernel"):
+        rb, wb = pick(fetch, name) * fr, pick(write, name) * fw
+        o3[name] = {"read_bytes": round(rb), "write_bytes": round(wb)}
+        print("%-28s read %8.2f MB  write %8.2f MB per launch" % (name, rb / 1e6, wb / 1e6))
+    tot3 = sum(v["read_bytes"] + v["write_bytes"] for v in o3.values())
+    alg3 = 2 * N * D * 4 + 2 * K * D * 4
+    print("x3 attention total HBM-side traffic %.1f MB per launch vs %.1f MB algorithmic (x%.2f)" % (tot3 / 1e6, alg3 / 1e6, tot3 / alg3))
+    o3.update(total_bytes=tot3, algorithmic_bytes=alg3, workload="cfgB N=32768 D=768 h=6 K=200 fp32 operands",
+              kernel="sparse_attn_x3_kernel+x3_reduce_kernel", fetch_bytes_per_unit=fr, write_bytes_per_unit=fw)
+    if len(sys.argv) > 3:
+        json.dump(o3, open(sys.argv[3], "w"), indent=1)
