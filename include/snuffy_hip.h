@@ -41,6 +41,7 @@ typedef void* snf_stream_t; /* hipStream_t */
 /* element types of q / v^T operands of the MFMA attention kernel */
 #define SNF_DT_F32 0
 #define SNF_DT_BF16 1
+#define SNF_DT_BF16_SPLIT3 2 /* [hi | hi | lo] bf16 image of an fp32 value (snf_gemm_bf16 output, snf_layernorm_rows_split3_f32) */
 
 const char* snf_version(void);
 const char* snf_last_error(void);
@@ -107,6 +108,11 @@ int snf_gather_slot_map_f32(const float* x, int64_t n, int d, const int64_t* idx
 int snf_layernorm_rows_f32(const float* x, int64_t n, int d, const int32_t* slot_map, const float* patch_rows,
                            const float* gamma, const float* beta, float eps, float* out_f32, void* out_bf16,
                            float* mean, float* rstd, const int64_t* out_row_idx, snf_stream_t stream);
+/* Same rows, written as the split image out_bf16 [n, 3 d] = [hi | hi | lo] (hi = bf16(v), lo = bf16(v - hi)): the A operand
+ * of the fp32-class projection  v W^T ~ hi Wh^T + hi Wl^T + lo Wh^T  run as ONE bf16 GEMM over the tripled K axis against
+ * W3 = [Wh | Wl | Wh] (snf_gemm_bf16; products to 2^-17 relative, fp32 accumulate). */
+int snf_layernorm_rows_split3_f32(const float* x, int64_t n, int d, const int32_t* slot_map, const float* patch_rows,
+                                  const float* gamma, const float* beta, float eps, void* out_bf16, snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K10 epilogue  h = act(h + bias) in place     replaces activation(w_1(x)) of snuffy.py:224-225
@@ -221,6 +227,8 @@ int snf_sparse_attn_dkp_f32(const float* ds, const float* q, int64_t n, int k, i
  *   Hand-written v_mfma_f32_16x16x32_bf16 kernel, fp32 accumulate; 256 x 256 or 256 x 128 output tiles (tile_n = 256 / 128,
  *   anything else = chosen from the shape).  Domain: k % 32 == 0, k >= 64, n % 8 == 0, rows 16-byte aligned, m * lda and
  *   n * ldw < 2^31; outside it SNF_EUNSUPPORTED (the caller keeps its library GEMM).
+ *   out_dtype = SNF_DT_BF16_SPLIT3: C is the bf16 image [hi | hi | lo] of the fp32 result, [m, 3 n] (ldc >= 3 n) -- the
+ *   hidden activations of the fp32-class FFN go from the first GEMM to the second without an fp32 round trip.
  * --------------------------------------------------------------------------------------------------------- */
 int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t m, int n, int k,
                   int act, void* c, int64_t ldc, int out_dtype, int tile_n, snf_stream_t stream);

@@ -20,6 +20,7 @@ SNF_EWORKSPACE = -4
 ACT_CODES = {"relu": 0, "gelu": 1, "leakyrelu": 2, "selu": 3, "none": 4}
 DT_F32 = 0
 DT_BF16 = 1
+DT_BF16_SPLIT3 = 2
 TOPK_MAX_K = 2048
 
 # name -> (restype, argtypes); mirrors include/snuffy_hip.h one to one
@@ -42,6 +43,8 @@ SIGNATURES = {
     "snf_gather_slot_map_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "snf_layernorm_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "snf_layernorm_rows_split3_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                              c_void_p, c_void_p]),
     "snf_bias_act": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "snf_ln_mean_head_workspace_bytes": (c_size_t, [c_int]),
     "snf_ln_mean_head_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

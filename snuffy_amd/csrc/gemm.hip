@@ -94,8 +94,9 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
-// NI = 16-column W fragments per wave: 4 -> BN = 256, 2 -> BN = 128.  OUT_F32: fp32 output instead of bf16.
-template <int NI, int ACT, bool OUT_F32>
+// NI = 16-column W fragments per wave: 4 -> BN = 256, 2 -> BN = 128.  OUT: 0 = bf16 output, 1 = fp32, 2 = the bf16 image
+// [hi | hi | lo] of the fp32 result (3 n columns, lo = bf16(v - hi)): the A operand of a following split-bf16 x3 GEMM.
+template <int NI, int ACT, int OUT>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
     constexpr int BN = 64 * NI;
     constexpr int W_BYTES = BN * ROWB;
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
     constexpr int WP = NI / 2;                 // W pieces (16 rows each) staged by one wave per step
     constexpr int GL = 2 + WP;                 // LDS-DMA instructions per wave and step
     constexpr int NC = 4 * NI;                 // output columns per lane
-    constexpr int NST = OUT_F32 ? NC / 4 : NC / 8;   // store instructions per lane and 16-row block
+    constexpr bool OUT_F32 = OUT == 1;
+    constexpr int NST = OUT == 1 ? NC / 4 : OUT == 2 ? 3 * NC / 8 : NC / 8;   // store instructions per lane and 16-row block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NBUF][A image | W image]
 
     const int lane = threadIdx.x & 63;
@@ -264,6 +266,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                     unsigned short* dst = reinterpret_cast<unsigned short*>(P.c) + (int64_t)row * P.ldc + col;
                     const u32x4 pk = {cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
                     if (ok) *reinterpret_cast<u32x4*>(dst) = pk;
+                    if constexpr (OUT == 2) {
+                        float lo[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            lo[e] = v[e] - __uint_as_float((e & 1) ? (pk[e >> 1] & 0xffff0000u) : (pk[e >> 1] << 16));
+                        const u32x4 pl = {cvt_pk_bf16(lo[0], lo[1]), cvt_pk_bf16(lo[2], lo[3]), cvt_pk_bf16(lo[4], lo[5]), cvt_pk_bf16(lo[6], lo[7])};
+                        if (ok) {
+                            *reinterpret_cast<u32x4*>(dst + P.n) = pk;
+                            *reinterpret_cast<u32x4*>(dst + 2 * (int64_t)P.n) = pl;
+                        }
+                    }
                 }
             }
         }
@@ -334,11 +347,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
     if (wr == 0) __builtin_amdgcn_s_barrier();   // barrier counts of the two wave groups match again
 }
 
-template <int NI, int ACT, bool OUT_F32>
+template <int NI, int ACT, int OUT>
 int launch(const GemmParams& P, hipStream_t s) {
     constexpr int lds = NBUF * (A_BYTES + 64 * NI * ROWB);
     static thread_local bool attr_set = false;
-    auto kern = gemm_bf16_kernel<NI, ACT, OUT_F32>;
+    auto kern = gemm_bf16_kernel<NI, ACT, OUT>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
             hipSuccess) {
@@ -357,14 +370,14 @@ int launch(const GemmParams& P, hipStream_t s) {
     return snf::check_launch("gemm_bf16_kernel");
 }
 
-template <int NI, bool OUT_F32>
+template <int NI, int OUT>
 int launch_act(const GemmParams& P, hipStream_t s) {
     switch (P.act) {
-        case SNF_ACT_RELU: return launch<NI, SNF_ACT_RELU, OUT_F32>(P, s);
-        case SNF_ACT_GELU: return launch<NI, SNF_ACT_GELU, OUT_F32>(P, s);
-        case SNF_ACT_LEAKYRELU: return launch<NI, SNF_ACT_LEAKYRELU, OUT_F32>(P, s);
-        case SNF_ACT_SELU: return launch<NI, SNF_ACT_SELU, OUT_F32>(P, s);
-        default: return launch<NI, SNF_ACT_NONE, OUT_F32>(P, s);
+        case SNF_ACT_RELU: return launch<NI, SNF_ACT_RELU, OUT>(P, s);
+        case SNF_ACT_GELU: return launch<NI, SNF_ACT_GELU, OUT>(P, s);
+        case SNF_ACT_LEAKYRELU: return launch<NI, SNF_ACT_LEAKYRELU, OUT>(P, s);
+        case SNF_ACT_SELU: return launch<NI, SNF_ACT_SELU, OUT>(P, s);
+        default: return launch<NI, SNF_ACT_NONE, OUT>(P, s);
     }
 }
 
@@ -375,9 +388,10 @@ extern "C" int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t 
     SNF_REQUIRE(a && w && c, "snf_gemm_bf16: null pointer");
     SNF_REQUIRE(m >= 1 && n >= 1 && k >= 1, "snf_gemm_bf16: bad shape m=%lld n=%d k=%d", (long long)m, n, k);
     SNF_REQUIRE(act >= SNF_ACT_RELU && act <= SNF_ACT_NONE, "snf_gemm_bf16: bad activation code %d", act);
-    SNF_REQUIRE(out_dtype == SNF_DT_F32 || out_dtype == SNF_DT_BF16, "snf_gemm_bf16: bad output dtype %d", out_dtype);
+    SNF_REQUIRE(out_dtype == SNF_DT_F32 || out_dtype == SNF_DT_BF16 || out_dtype == SNF_DT_BF16_SPLIT3,
+                "snf_gemm_bf16: bad output dtype %d", out_dtype);
     if (k % BKS || k < AHEAD * BKS || n % 8 || lda % 8 || ldw % 8 || ldc % (out_dtype == SNF_DT_F32 ? 4 : 8) || lda < k || ldw < k ||
-        ldc < n || (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(c)) % 16 ||
+        ldc < (out_dtype == SNF_DT_BF16_SPLIT3 ? 3 * (int64_t)n : n) || (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(c)) % 16 ||
         (bias && reinterpret_cast<uintptr_t>(bias) % 16) || m * lda >= 0x7fffffffll || (int64_t)n * ldw >= 0x7fffffffll) {
         snf::set_error("snf_gemm_bf16: shape m=%lld n=%d k=%d (lda %lld ldw %lld ldc %lld) outside the kernel's domain "
                        "(k %% 32, k >= 64, n %% 8, 16-byte aligned rows, 31-bit element offsets)",
@@ -404,6 +418,7 @@ extern "C" int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t 
     if (const char* e = getenv("SNF_GEMM_TRACE_PTR")) P.trace = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
 #endif
     hipStream_t s = snf::as_stream(stream);
-    if (tile_n == 256) return out_dtype == SNF_DT_F32 ? launch_act<4, true>(P, s) : launch_act<4, false>(P, s);
-    return out_dtype == SNF_DT_F32 ? launch_act<2, true>(P, s) : launch_act<2, false>(P, s);
+    if (out_dtype == SNF_DT_BF16_SPLIT3) return tile_n == 256 ? launch_act<4, 2>(P, s) : launch_act<2, 2>(P, s);
+    if (tile_n == 256) return out_dtype == SNF_DT_F32 ? launch_act<4, 1>(P, s) : launch_act<4, 0>(P, s);
+    return out_dtype == SNF_DT_F32 ? launch_act<2, 1>(P, s) : launch_act<2, 0>(P, s);
 }

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(WG) void layernorm_rows_kernel(const float* __restr
                                                             float* __restrict__ out_f32,
                                                             unsigned short* __restrict__ out_bf16,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            const int64_t* __restrict__ out_row_idx) {
+                                                            const int64_t* __restrict__ out_row_idx, int split3) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     float g[NV * VEC], bt[NV * VEC];
@@ -250,7 +250,17 @@ __global__ __launch_bounds__(WG) void layernorm_rows_kernel(const float* __restr
         }
         const int64_t orow = out_row_idx ? out_row_idx[row] : row;
         if (out_f32) store_row_f32<VEC, NV>(out_f32 + orow * d, d, lane, r);
-        if (out_bf16) store_row_bf16<VEC, NV>(out_bf16 + orow * d, d, lane, r);
+        if (out_bf16 && !split3) store_row_bf16<VEC, NV>(out_bf16 + orow * d, d, lane, r);
+        if (out_bf16 && split3) {
+            // [hi | hi | lo] image of the row (3 d bf16): the A operand of a split-bf16 x3 GEMM (gemm.hip, header comment)
+            float lo[NV * VEC];
+#pragma unroll
+            for (int i = 0; i < NV * VEC; ++i) lo[i] = r[i] - bf16_bits_to_f32(f32_to_bf16_bits(r[i]));
+            unsigned short* o3 = out_bf16 + orow * 3 * d;
+            store_row_bf16<VEC, NV>(o3, d, lane, r);
+            store_row_bf16<VEC, NV>(o3 + d, d, lane, r);
+            store_row_bf16<VEC, NV>(o3 + 2 * d, d, lane, lo);
+        }
         if (lane == 0) {
             if (mean_out) mean_out[orow] = mean;
             if (rstd_out) rstd_out[orow] = rstd;
@@ -730,8 +740,25 @@ int snf_layernorm_rows_f32(const float* x, int64_t n, int d, const int32_t* slot
     hipStream_t s = snf::as_stream(stream);
     SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((layernorm_rows_kernel<VEC, NV>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d,
                                               slot_map, patch_rows, gamma, beta, eps, out_f32,
-                                              reinterpret_cast<unsigned short*>(out_bf16), mean, rstd, out_row_idx));
+                                              reinterpret_cast<unsigned short*>(out_bf16), mean, rstd, out_row_idx, 0));
     return snf::check_launch("layernorm_rows_kernel");
+}
+
+int snf_layernorm_rows_split3_f32(const float* x, int64_t n, int d, const int32_t* slot_map, const float* patch_rows,
+                                  const float* gamma, const float* beta, float eps, void* out_bf16, snf_stream_t stream) {
+    SNF_REQUIRE(x && out_bf16, "snf_layernorm_rows_split3_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && d >= 1, "snf_layernorm_rows_split3_f32: bad shape");
+    SNF_REQUIRE(!slot_map || patch_rows, "snf_layernorm_rows_split3_f32: slot_map without patch_rows");
+    bool al = aligned16(x) && (!patch_rows || aligned16(patch_rows)) && (!gamma || aligned16(gamma)) &&
+              (!beta || aligned16(beta)) && aligned16(out_bf16);
+    RowCfg cfg;
+    SNF_REQUIRE(pick_row_cfg(d, al, &cfg), "snf_layernorm_rows_split3_f32: d=%d too wide (max 2048)", d);
+    hipStream_t s = snf::as_stream(stream);
+    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((layernorm_rows_kernel<VEC, NV>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d,
+                                              slot_map, patch_rows, gamma, beta, eps, (float*)nullptr,
+                                              reinterpret_cast<unsigned short*>(out_bf16), (float*)nullptr, (float*)nullptr,
+                                              (const int64_t*)nullptr, 1));
+    return snf::check_launch("layernorm_rows_kernel<split3>");
 }
 
 int snf_gather_rows_f32(const float* x, int64_t n, int d, const int64_t* idx, int k, float* out, snf_stream_t stream) {

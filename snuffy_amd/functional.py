@@ -23,6 +23,9 @@ ACTIVATIONS = ("relu", "gelu", "leakyrelu", "selu")      # reference snuffy.py:2
 # attention kernel of the fp32 path: "x3" = split-bf16 x 3 on the matrix cores (fp32-class, ~1e-6 from the exact kernel) where
 # the shape allows, "exact" = fp32 FMA on the vector ALUs for every shape
 FP32_ATTENTION = "x3"
+# fp32 path, the [N, .] projections: "x3" = split-bf16 products on the hand-written MFMA GEMM (fp32-class: logits within
+# ~1e-5 of the exact path), "library" = fp32 library GEMMs.
+FP32_GEMM = "x3"
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -246,9 +249,31 @@ def _folded(layer):
     return out
 
 
+def _split_weights(layer):
+    """fp32 path on the matrix cores: every projection weight as its split image [Wh | Wl | Wh] (ops.split3_weight), cached
+    on the layer like the bf16 fold (same key rule)."""
+    lq, lk, lv, lo = layer.self_attn.linears
+    ff = layer.feed_forward
+    plist = [lq.weight, lq.bias, lv.weight, lv.bias, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias]
+    key = tuple((id(p), p.data_ptr(), p._version) for p in plist)
+    ent = getattr(layer, "_fold3", None)
+    if ent is not None and ent[0] == key:
+        return ent[1]
+    with torch.no_grad():
+        out = dict(
+            wqv=ops.split3_weight(torch.cat([lq.weight, lv.weight])),                  # [2D, 3D]: output [Q | V]
+            bqv=torch.cat([lq.bias, lv.bias]).float().contiguous(),
+            w1=ops.split3_weight(ff.w_1.weight), b1=ff.w_1.bias.detach().float().contiguous(),
+            w2=ops.split3_weight(ff.w_2.weight), b2=ff.w_2.bias.detach().float().contiguous(),
+        )
+    layer._fold3 = (key, out)
+    return out
+
+
 def invalidate_folded(layer):
     """Drop the layer's folded bf16 weights and any pending critic hand-over (after editing parameters through .data)."""
     layer._fold = None
+    layer._fold3 = None
     layer._xhat_offer = None
 
 
@@ -272,6 +297,34 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
         z = torch.addmm(x2, hid, ff.w_2.weight.t())
         ops.bias_act_(z, ff.w_2.bias, "none")
         return Parts(z), attn
+
+    if precision == "fp32" and FP32_GEMM == "x3" and ops.gemm_supported(n, d, 3 * ff.w_2.weight.shape[1]) \
+            and ops.gemm_supported(n, 2 * d, 3 * d):
+        # fp32-class arithmetic on the matrix cores: every [N, .] projection is ONE bf16 GEMM over a tripled K axis
+        # (activations [hi | hi | lo], weights [Wh | Wl | Wh]; products to ~2^-17, fp32 accumulate) -- the fp32 library
+        # GEMMs these replace were 85 % of a config-B bag (profiles/r02_bench_cfgB_fp32_kernel_stats.csv)
+        fw = _split_weights(layer)
+        xs, slot = ops.gather_slot_map(x2, sel)                                     # snuffy.py:131,145-147 (+ row -> slot map)
+        kp = F.linear(xs, lk.weight, lk.bias)                                       # keys = RAW selected rows (K rows: fp32)
+        xn3 = ops.layernorm_rows_split3(x2, n0.weight, n0.bias, n0.eps)             # snuffy.py:107
+        qv = ops.gemm_bf16(xn3, fw["wqv"], fw["bqv"], out_dtype=torch.float32)      # [N, 2D] f32 = [Q | V]
+        del xn3
+        q, v = qv[:, :d], qv[:, d:]
+        if FP32_ATTENTION == "x3" and ops.x3_attn_supported(k, d // h):
+            o, attn, _ = ops.sparse_attn_fwd_x3(q, v, kp, h, need_attn=need_attn)    # snuffy.py:160-168
+        else:
+            o, attn, _ = ops.sparse_attn_fwd(q.contiguous(), kp, v.contiguous(), h, need_attn=need_attn)
+        del q, v, qv
+        delta = F.linear(o, lo.weight, lo.bias)                                     # snuffy.py:205
+        x_sel = xs + delta                                                          # snuffy.py:108
+        yn3 = ops.layernorm_rows_split3(x2, n1.weight, n1.bias, n1.eps, slot=slot, patch_rows=x_sel)   # LN(y), y never built
+        hid3 = ops.gemm_bf16(yn3, fw["w1"], fw["b1"], ff.activation_name, split3=True)   # snuffy.py:224-225, [N, 3F] image
+        del yn3
+        z = ops.gemm_bf16(hid3, fw["w2"], fw["b2"], out_dtype=torch.float32)
+        del hid3
+        z.add_(x2)
+        ops.scatter_add_rows_(z, sel, delta)                                        # rows S: x -> x_sel (snuffy.py:155)
+        return Parts(z), (attn.unsqueeze(0) if attn is not None else None)
 
     if precision == "fp32":
         xs, slot = ops.gather_slot_map(x2, sel)                                     # snuffy.py:131,145-147 (+ row -> slot map)

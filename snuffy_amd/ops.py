@@ -9,7 +9,7 @@ import math
 import torch
 
 from . import _ffi
-from ._ffi import ACT_CODES, DT_BF16, DT_F32, check
+from ._ffi import ACT_CODES, DT_BF16, DT_BF16_SPLIT3, DT_F32, check
 
 
 def _p(t):
@@ -499,9 +499,10 @@ def linear_bf16(a, w, bias_f32=None, bias_bf16=None, act="none", prefer_native=N
     return out
 
 
-def gemm_bf16(a, w, bias=None, act="none", out_dtype=torch.bfloat16, out=None, tile_n=0):
+def gemm_bf16(a, w, bias=None, act="none", out_dtype=torch.bfloat16, out=None, tile_n=0, split3=False):
     """act(a @ w.T + bias) on the hand-written MFMA kernel.  a [m, k] bf16 (row-strided views allowed), w [n, k] bf16 (the
-    nn.Linear layout), bias [n] f32 or None, act in relu | gelu (erf) | leakyrelu | selu | none -> [m, n] bf16 or f32."""
+    nn.Linear layout), bias [n] f32 or None, act in relu | gelu (erf) | leakyrelu | selu | none -> [m, n] bf16 or f32.
+    split3: the result leaves as its bf16 image [hi | hi | lo], [m, 3 n] (operand of a following x3 GEMM)."""
     if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
         raise TypeError("gemm_bf16: a and w must be bfloat16")
     a = _rows16(a, "a")
@@ -514,13 +515,58 @@ def gemm_bf16(a, w, bias=None, act="none", out_dtype=torch.bfloat16, out=None, t
         bias = _req(bias, torch.float32, "bias", 1)
         if bias.shape[0] != n:
             raise ValueError("gemm_bf16: bias has %d entries for %d columns" % (bias.shape[0], n))
-    if out is None:
-        out = torch.empty(m, n, dtype=out_dtype, device=a.device)
-    elif out.shape != (m, n) or out.stride(1) != 1 or out.dtype not in (torch.bfloat16, torch.float32):
-        raise ValueError("gemm_bf16: bad out buffer")
-    odt = DT_F32 if out.dtype == torch.float32 else DT_BF16
+    if split3:
+        if out is None:
+            out = torch.empty(m, 3 * n, dtype=torch.bfloat16, device=a.device)
+        elif out.shape != (m, 3 * n) or out.stride(1) != 1 or out.dtype != torch.bfloat16:
+            raise ValueError("gemm_bf16: bad out buffer for the split image")
+        odt = DT_BF16_SPLIT3
+    else:
+        if out is None:
+            out = torch.empty(m, n, dtype=out_dtype, device=a.device)
+        elif out.shape != (m, n) or out.stride(1) != 1 or out.dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("gemm_bf16: bad out buffer")
+        odt = DT_F32 if out.dtype == torch.float32 else DT_BF16
     check(_ffi.load().snf_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), m, n, k, ACT_CODES[act], _p(out),
                                     out.stride(0), odt, int(tile_n), _stream()), "snf_gemm_bf16")
+    return out
+
+
+def split3_weight(w):
+    """W [n, k] f32 -> W3 [n, 3 k] bf16 = [Wh | Wl | Wh]: with an activation image [hi | hi | lo] (layernorm_rows_split3,
+    gemm_bf16(split3=True)) one bf16 GEMM over the tripled K axis computes hi Wh^T + hi Wl^T + lo Wh^T, i.e. the fp32
+    product to ~2^-17 relative per term with fp32 accumulation."""
+    w = w.detach().float()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo, hi], dim=1).contiguous()
+
+
+def split3_rows(x):
+    """x [m, k] f32 -> [m, 3 k] bf16 = [hi | hi | lo] with torch ops (small operands: the K selected rows)."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, hi, lo], dim=1).contiguous()
+
+
+def gemm_x3_supported(m, n, k):
+    return gemm_supported(m, n, 3 * k) and m * 3 * k < 2 ** 31 and n * 3 * k < 2 ** 31
+
+
+def layernorm_rows_split3(x, gamma, beta, eps=1e-5, slot=None, patch_rows=None):
+    """LayerNorm over rows (as layernorm_rows) written as the split bf16 image [n, 3 d]."""
+    x = _req(x, torch.float32, "x", 2)
+    n, d = x.shape
+    if gamma is not None:
+        gamma = _req(gamma, torch.float32, "gamma", 1)
+    if beta is not None:
+        beta = _req(beta, torch.float32, "beta", 1)
+    if slot is not None:
+        slot = _req(slot, torch.int32, "slot", 1)
+        patch_rows = _req(patch_rows, torch.float32, "patch_rows", 2)
+    out = torch.empty(n, 3 * d, dtype=torch.bfloat16, device=x.device)
+    check(_ffi.load().snf_layernorm_rows_split3_f32(_p(x), n, d, _p(slot), _p(patch_rows), _p(gamma), _p(beta), float(eps),
+                                                    _p(out), _stream()), "snf_layernorm_rows_split3_f32")
     return out
 
 

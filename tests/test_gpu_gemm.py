@@ -89,3 +89,80 @@ def test_gemm_rejects_unsupported_shapes():
         ops.gemm_bf16(a, w)
     with pytest.raises(SnuffyHipError):
         ops.gemm_bf16(a.cpu(), w.cpu())
+
+
+# ---- fp32-class projections: split-bf16 x3 over a tripled K axis ---------------------------------------------------------
+def _split_host(x):
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+@pytest.mark.parametrize("n,d", [(700, 384), (513, 768), (64, 96), (1000, 100)])
+def test_layernorm_rows_split3_is_the_split_of_the_fp32_rows(n, d):
+    """snf_layernorm_rows_split3_f32 == [hi | hi | lo] of snf_layernorm_rows_f32's fp32 output, bit for bit (incl. patch rows)."""
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(n + d)
+    x = (torch.randn(n, d, generator=g) * 3 + 1).to(DEV)
+    gam, bet = torch.randn(d, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
+    slot = torch.full((n,), -1, dtype=torch.int32)
+    slot[[3, n // 2, n - 1]] = torch.tensor([0, 1, 2], dtype=torch.int32)
+    patch = torch.randn(3, d, generator=g).to(DEV)
+    for kw in ({}, {"slot": slot.to(DEV), "patch_rows": patch}):
+        ref = ops.layernorm_rows(x, gam, bet, 1e-5, **kw)
+        got = ops.layernorm_rows_split3(x, gam, bet, 1e-5, **kw)
+        hi, lo = _split_host(ref)
+        assert got.shape == (n, 3 * d) and got.dtype == torch.bfloat16
+        assert torch.equal(got[:, :d], hi) and torch.equal(got[:, d:2 * d], hi) and torch.equal(got[:, 2 * d:], lo)
+
+
+@pytest.mark.parametrize("m,n,k,act", [(1000, 768, 384, "none"), (4096, 1536, 768, "none"), (777, 3072, 768, "relu"),
+                                       (900, 768, 3072, "none"), (300, 512, 96, "gelu")])
+def test_gemm_x3_is_fp32_class(m, n, k, act):
+    """[hi | hi | lo] x [Wh | Wl | Wh] on the bf16 MFMA kernel against an fp64 contraction of the fp32 operands: error of the
+    order of 2^-17 per product (measured <= 4e-6 relative to the result scale), 500x below a plain bf16 GEMM's."""
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(m + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g)
+    ref = ref_act(a.double() @ w.double().t() + b.double(), act)
+    a3 = ops.split3_rows(a.to(DEV))
+    w3 = ops.split3_weight(w.to(DEV))
+    assert a3.shape == (m, 3 * k) and w3.shape == (n, 3 * k)
+    out = ops.gemm_bf16(a3, w3, b.to(DEV), act, torch.float32)
+    scale = max(1.0, ref.abs().max().item())
+    err = (out.cpu().double() - ref).abs().max().item() / scale
+    assert err <= 8e-6, (m, n, k, act, err)
+    # the split image of the result straight from the epilogue == the split of the fp32 output, bit for bit
+    img = ops.gemm_bf16(a3, w3, b.to(DEV), act, split3=True)
+    hi, lo = _split_host(out)
+    assert img.shape == (m, 3 * n)
+    assert torch.equal(img[:, :n], hi) and torch.equal(img[:, n:2 * n], hi)
+    if act == "gelu":   # the erf polynomial may round differently in the two kernel variants: hi + lo reproduces the value
+        assert ((img[:, :n].float() + img[:, 2 * n:].float()) - out).abs().max().item() <= 2.0 ** -15 * scale
+    else:
+        assert torch.equal(img[:, 2 * n:], lo)
+    img128 = ops.gemm_bf16(a3, w3, b.to(DEV), act, split3=True, tile_n=128)
+    out128 = ops.gemm_bf16(a3, w3, b.to(DEV), act, torch.float32, tile_n=128)
+    hi, lo = _split_host(out128)
+    assert torch.equal(img128[:, :n], hi) and (act == "gelu" or torch.equal(img128[:, 2 * n:], lo))
+
+
+def test_fp32_path_x3_projections_against_library_projections(monkeypatch):
+    """One encoder layer of the fp32 path at config-A size: split-bf16 x3 projections vs the fp32 library GEMMs."""
+    from snuffy_amd import functional as SF
+    torch.manual_seed(0)
+    n, d = 8192, 384
+    from tests.helpers import build_amd_milnet
+    net = build_amd_milnet(d, 6, "gelu", 200, 0.0, 2).to(DEV).eval()
+    net.configure(precision="fp32")
+    x = torch.randn(1, n, d, device=DEV) * 0.7
+    with torch.no_grad():
+        monkeypatch.setattr(SF, "FP32_GEMM", "x3")
+        c3, l3, a3 = net(x)
+        monkeypatch.setattr(SF, "FP32_GEMM", "library")
+        c0, l0, a0 = net(x)
+    assert torch.equal(c3, c0)
+    assert (l3 - l0).abs().max().item() <= 2e-5 * max(1.0, l0.abs().max().item())
+    assert (a3 - a0).abs().max().item() <= 2e-5
