@@ -324,6 +324,17 @@ def main():
             # (train.py:830) and so does the headline -- this is the same forward with A written out
             e3, _, l3 = measure(args.precision, return_attention=True, warmup=min(args.warmup, 3))
             extra["with_A"] = dict(elapsed=e3, steps=args.steps, launch=l3)
+            # the fp32 leg runs its projections as split-bf16 x3 products on the matrix cores (fp32-class: ~2^-17 per product,
+            # fp32 accumulate); this is the same forward with plain fp32 library GEMMs instead
+            from snuffy_amd import functional as SF
+            keep = SF.FP32_GEMM
+            SF.FP32_GEMM = "library"
+            try:
+                steps_l = max(5, args.steps // 2)
+                e4, _, l4 = measure("fp32", steps=steps_l, warmup=min(args.warmup, 3))
+            finally:
+                SF.FP32_GEMM = keep
+            extra["f32_library_gemm"] = dict(elapsed=e4, steps=steps_l, launch=l4)
 
     if rank == 0:
         K = min(lam, N)
@@ -346,9 +357,16 @@ def main():
         for key, rec in extra.items():
             if key == "with_A":
                 line["value_with_attention_output"] = round(world * rec["steps"] / rec["elapsed"], 3)
+            elif key == "f32_library_gemm":
+                line["value_f32_library_gemm"] = round(world * rec["steps"] / rec["elapsed"], 3)
             else:
                 line["value_" + dt_name[key]] = round(world * rec["steps"] / rec["elapsed"], 3)
                 line["ms_per_step_" + dt_name[key]] = round(rec["elapsed"] / rec["steps"] * 1e3, 4)
+        line["arithmetic"] = {
+            "bf16": "bf16 MFMA operands, fp32 accumulate / softmax / LayerNorm / residual (north_star's 1e-2 class)",
+            "f32": "fp32 tensors; products as split-bf16 x3 on the MFMA units (2^-17 per product, fp32 accumulate), "
+                   "logits within 1e-5 of plain fp32 (north_star's 1e-3 class); value_f32_library_gemm = the same forward "
+                   "with fp32 library GEMMs"}
         if not args.no_roofline:   # rank 0 only, after the timed region (the other ranks wait at the closing barrier)
             line.update(kernel_rooflines(wl, args.precision, device, args.workload))
             if not args.headline_only:

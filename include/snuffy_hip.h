@@ -111,6 +111,16 @@ int snf_layernorm_rows_f32(const float* x, int64_t n, int d, const int32_t* slot
 /* Same rows, written as the split image out_bf16 [n, 3 d] = [hi | hi | lo] (hi = bf16(v), lo = bf16(v - hi)): the A operand
  * of the fp32-class projection  v W^T ~ hi Wh^T + hi Wl^T + lo Wh^T  run as ONE bf16 GEMM over the tripled K axis against
  * W3 = [Wh | Wl | Wh] (snf_gemm_bf16; products to 2^-17 relative, fp32 accumulate). */
+/* Backward of the same LayerNorm (loss.backward() of train.py:259 through snuffy.py:86,97,107,110); statistics are recomputed
+ * from x, nothing is saved by the forward:
+ *   dxhat = dy * gamma;  dx = residual + rstd * (dxhat - mean_d(dxhat) - xhat * mean_d(dxhat * xhat))
+ *   dy [n, d] f32 or bf16 (dy_dtype) with row pitch dy_stride; dy_stride = 0 broadcasts ONE row (the mean-pooled head).
+ *   gamma, residual, dx, dx_bf16, partials nullable.  partials [snf_layernorm_bwd_blocks(n), 2, d] f32: per-workgroup
+ *   (sum dy * xhat, sum dy) in a fixed order -- dgamma / dbeta are their sums over the first axis. */
+int snf_layernorm_bwd_blocks(int64_t n);
+int snf_layernorm_rows_bwd_f32(const float* x, int64_t n, int d, const void* dy, int dy_dtype, int64_t dy_stride,
+                               const float* gamma, float eps, const float* residual, float* dx, void* dx_bf16,
+                               float* partials, snf_stream_t stream);
 int snf_layernorm_rows_split3_f32(const float* x, int64_t n, int d, const int32_t* slot_map, const float* patch_rows,
                                   const float* gamma, const float* beta, float eps, void* out_bf16, snf_stream_t stream);
 
@@ -213,6 +223,12 @@ int snf_sparse_attn_bwd_f32(const float* q, const float* kp, const float* v, con
 int snf_sparse_attn_bwd_mfma(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const float* kp,
                              const float* dout, const float* lse, const float* mask, int64_t n, int k, int h, int dk,
                              float scale, float* dq, float* dv, void* ds, int ds_dtype, snf_stream_t stream);
+/* Same kernel with the gradients written where the caller wants them: dq / dv f32 or bf16 (dqv_dtype) with row pitch ldd
+ * (elements) -- e.g. the two column halves of ONE [n, 2 d] bf16 buffer, the operand of the fused Q|V weight-gradient GEMM. */
+int snf_sparse_attn_bwd_mfma_ex(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const float* kp,
+                                const float* dout, const float* lse, const float* mask, float dropout_p, uint64_t seed,
+                                uint64_t offset, int64_t n, int k, int h, int dk, float scale, void* dq, void* dv, int64_t ldd,
+                                int dqv_dtype, void* ds, int ds_dtype, snf_stream_t stream);
 /* dKp [k, d] = dS^T Q per head (deterministic slice reduction); ds [h, n, k], q [n, d] f32.
  * workspace: snf_sparse_attn_bwd_workspace_bytes. */
 int snf_sparse_attn_dkp_f32(const float* ds, const float* q, int64_t n, int k, int h, int dk, float* dkp, void* workspace,

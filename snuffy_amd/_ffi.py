@@ -43,6 +43,9 @@ SIGNATURES = {
     "snf_gather_slot_map_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "snf_layernorm_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "snf_layernorm_bwd_blocks": (c_int, [c_int64]),
+    "snf_layernorm_rows_bwd_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_void_p, c_float, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p]),
     "snf_layernorm_rows_split3_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                               c_void_p, c_void_p]),
     "snf_bias_act": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p]),
@@ -71,6 +74,9 @@ SIGNATURES = {
     "snf_sparse_attn_bwd_mfma_dropout": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  c_float, c_uint64, c_uint64, c_int64, c_int, c_int, c_int, c_float, c_void_p,
                                                  c_void_p, c_void_p, c_int, c_void_p]),
+    "snf_sparse_attn_bwd_mfma_ex": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_float, c_uint64, c_uint64, c_int64, c_int, c_int, c_int, c_float, c_void_p,
+                                            c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "snf_dropout_mask_f32": (c_int, [c_float, c_uint64, c_uint64, c_int, c_int64, c_int, c_void_p, c_void_p]),
     "snf_tile_preprocess_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                        c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

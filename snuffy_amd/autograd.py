@@ -17,6 +17,10 @@ import torch.nn.functional as F
 
 from . import ops
 
+# bf16 training: the first encoder layer as one hand-ordered forward / backward chain (EncoderLayer0Bf16Fn) instead of the generic
+# autograd graph; False keeps the generic chain everywhere (tests compare the two)
+FUSED_BF16_TRAINING = True
+
 _ACT = {
     "relu": F.relu,
     "gelu": F.gelu,
@@ -26,29 +30,48 @@ _ACT = {
 
 
 class LayerNormRowsFn(torch.autograd.Function):
-    """y = LayerNorm(x) * gamma + beta (forward: snf_layernorm_rows_f32, statistics saved for backward)."""
+    """y = LayerNorm(x) * gamma + beta (forward: snf_layernorm_rows_f32; backward: snf_layernorm_rows_bwd_f32, one pass that
+    recomputes the statistics from x and leaves per-workgroup partial sums for dgamma / dbeta)."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, gamma, beta, eps):
-        y, mean, rstd = ops.layernorm_rows(x, gamma, beta, eps, want_stats=True)
-        ctx.save_for_backward(x, gamma, mean, rstd)
+        y = ops.layernorm_rows(x, gamma, beta, eps)
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
         return y
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
-        x, gamma, mean, rstd = ctx.saved_tensors
-        xhat = (x - mean.unsqueeze(1)) * rstd.unsqueeze(1)
-        dgamma = (dy * xhat).sum(0)
-        dbeta = dy.sum(0)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dxhat = dy * gamma
-            m1 = dxhat.mean(1, keepdim=True)
-            m2 = (dxhat * xhat).mean(1, keepdim=True)
-            dx = (dxhat - m1 - xhat * m2) * rstd.unsqueeze(1)
+        x, gamma = ctx.saved_tensors
+        dx, _, dgamma, dbeta = ops.layernorm_rows_bwd(x, dy.float(), gamma, ctx.eps, want_dx=ctx.needs_input_grad[0])
         return dx, dgamma, dbeta, None
+
+
+class HeadFn(torch.autograd.Function):
+    """logits = Linear(mean_n LayerNorm(z)) (snuffy.py:86,71): forward on the fused column-reduction kernels
+    (snf_ln_mean_head_f32); backward in ONE pass over z -- every row receives the same gradient row d pooled / N, which
+    snf_layernorm_rows_bwd_f32 broadcasts."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, z, gamma, beta, w, b, eps):
+        logits, pooled, _ = ops.ln_mean_head(z, gamma, beta, eps, w, b)
+        ctx.save_for_backward(z, gamma, w, pooled)
+        ctx.eps, ctx.has_bias = eps, b is not None
+        return logits
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dlogits):
+        z, gamma, w, pooled = ctx.saved_tensors
+        dlogits = dlogits.float().reshape(-1)
+        dpooled = dlogits @ w                                   # [D]
+        dw = torch.outer(dlogits, pooled)
+        dy_row = (dpooled / z.shape[0]).contiguous()            # d loss / d LN(z)_i, identical for every row i
+        dz, _, dgamma, dbeta = ops.layernorm_rows_bwd(z, dy_row, gamma, ctx.eps, want_dx=ctx.needs_input_grad[0])
+        return dz, dgamma, dbeta, dw, (dlogits if ctx.has_bias else None), None
 
 
 class ScatterRowsFn(torch.autograd.Function):
@@ -132,6 +155,131 @@ class SparseAttnFn(torch.autograd.Function):
         return dq, dkp, dv, None, None, None, None
 
 
+def _tn_mm(a, b, chunks=8):
+    """a^T b for a [n, p], b [n, q] bf16 -> [p, q] f32: the weight-gradient contraction over the bag axis.  The output is small
+    (p q <= 2.4 M) and the contraction long (n = bag size), so the library's one-tile-per-workgroup kernels leave most CUs idle
+    (36 tiles of 256 x 256 at config B: 311 us); split over `chunks` row blocks as ONE batched GEMM plus an fp32 sum of the
+    partials (180-190 us, profiles/r02_tn_gemm.txt)."""
+    n = a.shape[0]
+    m = (n // chunks) * chunks
+    if n < 4096 or m == 0:
+        return torch.mm(a.t(), b).float()
+    av = a[:m].view(chunks, m // chunks, a.shape[1]).transpose(1, 2)
+    out = torch.bmm(av, b[:m].view(chunks, m // chunks, b.shape[1])).sum(0, dtype=torch.float32)
+    if m < n:
+        out += torch.mm(a[m:].t(), b[m:]).float()
+    return out
+
+
+class EncoderLayer0Bf16Fn(torch.autograd.Function):
+    """EncoderLayer.forward + backward (snuffy.py:126-157) for the FIRST layer of a bf16 training step, as one hand-ordered
+    chain: the bag x is data there (no gradient), so nothing upstream of the K selected rows needs d/dx and the backward
+    collapses to the weight gradients plus the K-row chain through the attention output.
+
+    Forward = the inference pipeline of functional.encoder_layer (LayerNorm affine folded into the projection weights,
+    one normalised bf16 copy of the bag, fused Q|V projection, MFMA attention with in-kernel dropout, FFN with the
+    activation in the GEMM epilogue).  Backward: dz -> FFN weight gradients (three [N, .] GEMMs) -> the K selected rows
+    through LayerNorm 1 / the output projection -> MFMA attention backward -> Q|V weight gradients; the folded-weight
+    gradients are unfolded into (W, b, gamma, beta) at the end.  Replaces ~150 autograd nodes (casts, adds, reductions:
+    2.6 ms of a 5.4 ms step at config B) by 9 large kernels and a handful of [K, D] / [4D, D] ones."""
+
+    @staticmethod
+    def forward(ctx, x2, sel, layer, need_attn, g0, b0, g1, b1, wq, bq, wk, bk, wv, bv, wo, bo, w1, bb1, w2, bb2):
+        from . import functional as SF
+        n, d = x2.shape
+        mha = layer.self_attn
+        h = mha.h
+        eps = layer.sublayer[0].norm.eps
+        fw = SF._folded(layer)
+        xhat = torch.empty(n, d, dtype=torch.bfloat16, device=x2.device)
+        ops.layernorm_rows(x2, None, None, eps, out=xhat)
+        qv = ops.linear_bf16(xhat, fw["wqv"], fw["bqv_f"], fw["bqv"])
+        q, v = qv[:, :d], qv[:, d:]
+        xs, slot, xs16 = ops.gather_slot_map(x2, sel, bf16_copy=True)
+        kp = torch.addmm(fw["bk"], xs16, fw["wk"].t()).float()
+        p_drop = mha.dropout.p if layer.training else 0.0
+        drop = (float(p_drop),) + draw_dropout_state() if p_drop > 0.0 else None
+        o, attn, lse = ops.sparse_attn_fwd_mfma(q, v, kp, n, h, need_attn=need_attn, need_lse=True, dropout=drop)
+        delta = torch.addmm(bo, o, wo.t())
+        x_sel = xs + delta
+        xhat0_sel = xhat.index_select(0, sel)
+        ops.layernorm_rows(x_sel, None, None, eps, out=xhat, out_row_idx=sel)
+        hid = ops.linear_bf16(xhat, fw["w1"], fw["b1"], fw["b1h"], "relu")
+        zb = ops.linear_bf16(hid, fw["w2"])
+        z = SF.materialize(SF.Parts(x2, add_bf16=zb, add_bias=bb2, slot=slot, delta=delta))
+        ctx.save_for_backward(sel, xhat0_sel, qv, kp, lse, o, xs, x_sel, hid, g0, b0, g1, b1, wq, wk, wv, wo, w1,
+                              fw["w1"], fw["w2"])
+        ctx.xhat = xhat          # rows S are swapped in place during backward (and swapped back): kept outside the version check
+        ctx.h, ctx.eps, ctx.drop = h, eps, drop
+        ctx.mark_non_differentiable(*([attn] if attn is not None else []))
+        return z, attn
+
+    @staticmethod
+    def backward(ctx, dz, _dattn):
+        (sel, xhat0_sel, qv, kp, lse, o, xs, x_sel, hid, g0, b0, g1, b1, wq, wk, wv, wo, w1, w1f, w2f) = ctx.saved_tensors
+        xhat = ctx.xhat
+        n, d = xhat.shape
+        h, eps = ctx.h, ctx.eps
+        f32 = torch.float32
+        dz = dz.float()
+        dz16 = dz.to(torch.bfloat16)
+        # ---- FFN: z = y + act(xhat1 W1'^T + b1') W2^T + b2                                                (snuffy.py:224-225)
+        db2 = dz.sum(0)
+        dw2 = _tn_mm(dz16, hid)                                                      # [D, F]
+        dhid = torch.ops.aten.threshold_backward(torch.mm(dz16, w2f), hid, 0)        # [N, F] bf16, ReLU mask from the output
+        db1f = dhid.sum(0, dtype=f32)
+        dw1f = _tn_mm(dhid, xhat)                                                    # [F, D] gradient of the FOLDED weight
+        # ---- the K selected rows: y[S] = x_sel = xs + o Wo^T + bo; every other row of y is data             (snuffy.py:108,152-155)
+        dyn_s = torch.mm(dhid.index_select(0, sel).float(), w1f.float())             # d loss / d xhat1[S]
+        mu = x_sel.mean(1, keepdim=True)
+        xc = x_sel - mu
+        rstd = torch.rsqrt((xc * xc).mean(1, keepdim=True) + eps)
+        xh = xc * rstd
+        dy_s = dz.index_select(0, sel) + rstd * (dyn_s - dyn_s.mean(1, keepdim=True) - xh * (dyn_s * xh).mean(1, keepdim=True))
+        dbo = dy_s.sum(0)
+        dwo = dy_s.t() @ o
+        do = dy_s @ wo
+        # ---- attention                                                                                     (snuffy.py:160-168)
+        q, v = qv[:, :d], qv[:, d:]
+        dq, dkp, dv = ops.sparse_attn_bwd_mfma(q, v, kp, do.contiguous(), lse, h, dropout=ctx.drop, fused_bf16_grads=True)
+        dqv = dq._base                                                                # [N, 2D] bf16 = [dQ | dV]
+        del dq, dv
+        xhat1_sel = xhat.index_select(0, sel)
+        xhat.index_copy_(0, sel, xhat0_sel)                                           # back to LayerNorm 0's rows
+        dwqvf = _tn_mm(dqv, xhat)                                                     # [2D, D] folded
+        xhat.index_copy_(0, sel, xhat1_sel)                                           # (a second backward sees the same state)
+        dbqvf = dqv.sum(0, dtype=f32)
+        dwk = dkp.t() @ xs
+        dbk = dkp.sum(0)
+        # ---- unfold  W' = W * gamma,  b' = W beta + b
+        dwqf, dwvf = dwqvf[:d], dwqvf[d:]
+        dbq, dbv = dbqvf[:d], dbqvf[d:]
+        dg0 = (dwqf * wq).sum(0) + (dwvf * wv).sum(0)
+        db0 = dbq @ wq + dbv @ wv
+        dg1 = (dw1f * w1).sum(0)
+        db1 = db1f @ w1
+        dwq = dwqf * g0 + torch.outer(dbq, b0)
+        dwv = dwvf * g0 + torch.outer(dbv, b0)
+        dw1 = dw1f * g1 + torch.outer(db1f, b1)
+        return (None, None, None, None, dg0, db0, dg1, db1, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dw1, db1f, dw2, db2)
+
+
+def fused_layer0_ok(x2, sel, layer, precision):
+    """Shapes / settings EncoderLayer0Bf16Fn covers; everything else keeps the generic autograd chain below."""
+    if precision != "bf16" or x2.requires_grad or sel.numel() == 0 or not FUSED_BF16_TRAINING:
+        return False
+    mha, ff = layer.self_attn, layer.feed_forward
+    n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
+    if ff.activation_name != "relu" or n0.eps != n1.eps:
+        return False
+    if layer.training and (layer.sublayer[0].dropout.p > 0 or layer.sublayer[1].dropout.p > 0 or ff.dropout.p > 0):
+        return False
+    n, d = x2.shape
+    k, dk = sel.numel(), d // mha.h
+    return (ops.mfma_attn_supported(k, dk, n, 2 * d) and k <= (224 if dk == 128 else 256) and ops.mfma_attn_bwd_supported(k, dk)
+            and all(p.requires_grad for p in layer.parameters()))
+
+
 def critic_train(feats2, w, b):
     """Critic scores with autograd (library GEMV); the selection itself uses them detached."""
     return F.linear(feats2, w, b)
@@ -140,6 +288,14 @@ def critic_train(feats2, w, b):
 def encoder_layer_train(x2, sel, layer, need_attn, precision):
     """Differentiable EncoderLayer.forward (snuffy.py:126-157).  Returns (functional.Parts, A)."""
     from .functional import Parts
+    if fused_layer0_ok(x2, sel, layer, precision):
+        n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
+        lq, lk, lv, lo = layer.self_attn.linears
+        ff = layer.feed_forward
+        z, attn = EncoderLayer0Bf16Fn.apply(x2, sel, layer, bool(need_attn), n0.weight, n0.bias, n1.weight, n1.bias, lq.weight,
+                                            lq.bias, lk.weight, lk.bias, lv.weight, lv.bias, lo.weight, lo.bias,
+                                            ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias)
+        return Parts(z), (attn.unsqueeze(0) if attn is not None else None)
     # precision "bf16": the dense projections run under torch.autocast (bf16 operands, fp32 accumulate, fp32 master
     # weights); LayerNorm, softmax / attention and the residual stream stay fp32.
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(precision == "bf16")):
@@ -183,5 +339,4 @@ def _encoder_layer_train(x2, sel, layer, need_attn):
 
 def head_train(z, norm, linear):
     """logits = Linear(mean_n LayerNorm(z)) with autograd (snuffy.py:86,71)."""
-    zn = LayerNormRowsFn.apply(z, norm.weight, norm.bias, norm.eps)
-    return F.linear(zn.mean(dim=0), linear.weight, linear.bias)
+    return HeadFn.apply(z, norm.weight, norm.bias, linear.weight, linear.bias, norm.eps)

@@ -269,6 +269,113 @@ __global__ __launch_bounds__(WG) void layernorm_rows_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// LayerNorm backward over rows (autograd through SublayerConnection.norm / Encoder.norm, snuffy.py:86,97,107,110)
+//   xhat = (x - mean) * rstd (recomputed from x);  dxhat = dy * gamma
+//   dx = res + rstd * (dxhat - mean_d(dxhat) - xhat * mean_d(dxhat * xhat))
+//   partials[block] = (sum_rows dy * xhat, sum_rows dy): the caller sums them over blocks for dgamma / dbeta.
+// dy_stride = 0 broadcasts ONE gradient row to every row (the mean-pooled head: d logits / d LN(z)_i is the same for all i).
+// ---------------------------------------------------------------------------------------------------------------
+template <int VEC, int NV>
+__device__ __forceinline__ void load_row_bf16(const unsigned short* __restrict__ row, int d, int lane, float (&r)[NV * VEC]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int e = (i * 64 + lane) * VEC;
+        if constexpr (VEC == 4) {
+            uint2 t = make_uint2(0u, 0u);
+            if (e < d) t = *reinterpret_cast<const uint2*>(row + e);
+            r[i * 4 + 0] = __uint_as_float(t.x << 16);
+            r[i * 4 + 1] = __uint_as_float(t.x & 0xffff0000u);
+            r[i * 4 + 2] = __uint_as_float(t.y << 16);
+            r[i * 4 + 3] = __uint_as_float(t.y & 0xffff0000u);
+        } else {
+            r[i] = (e < d) ? bf16_bits_to_f32(row[e]) : 0.f;
+        }
+    }
+}
+
+template <int VEC, int NV>
+__global__ __launch_bounds__(WG) void ln_bwd_rows_kernel(const float* __restrict__ x, int64_t n, int d,
+                                                         const void* __restrict__ dy, int dy_bf16, int64_t dy_stride,
+                                                         const float* __restrict__ gamma, float eps,
+                                                         const float* __restrict__ res, float* __restrict__ dx,
+                                                         unsigned short* __restrict__ dx_bf16,
+                                                         float* __restrict__ partials) {
+    constexpr int R = NV * VEC;
+    __shared__ float red[WAVES][2][R * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float g[R], gy[R], sg[R], sb[R];
+    if (gamma) load_row<VEC, NV>(gamma, d, lane, g);
+#pragma unroll
+    for (int i = 0; i < R; ++i) sg[i] = 0.f, sb[i] = 0.f;
+    const float inv_d = 1.0f / (float)d;
+    for (int64_t row = (int64_t)blockIdx.x * WAVES + wave; row < n; row += (int64_t)gridDim.x * WAVES) {
+        float r[R];
+        load_row<VEC, NV>(x + row * d, d, lane, r);
+        if (dy_bf16)
+            load_row_bf16<VEC, NV>(reinterpret_cast<const unsigned short*>(dy) + row * dy_stride, d, lane, gy);
+        else
+            load_row<VEC, NV>(reinterpret_cast<const float*>(dy) + row * dy_stride, d, lane, gy);
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < R; ++i) s1 += r[i];
+        const float mean = wave_sum(s1) * inv_d;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) {
+                int e = (i * 64 + lane) * VEC + t;
+                float dv = (e < d) ? (r[i * VEC + t] - mean) : 0.f;
+                r[i * VEC + t] = dv;
+                s2 = fmaf(dv, dv, s2);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) * inv_d + eps);
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            r[i] *= rstd;                       // xhat (0 past d)
+            sg[i] = fmaf(gy[i], r[i], sg[i]);
+            sb[i] += gy[i];
+            if (gamma) gy[i] *= g[i];           // dxhat (0 past d: dy loads are zero-filled)
+            m1 += gy[i];
+            m2 = fmaf(gy[i], r[i], m2);
+        }
+        m1 = wave_sum(m1) * inv_d;
+        m2 = wave_sum(m2) * inv_d;
+        if (dx || dx_bf16) {
+            float o[R];
+            if (res) load_row<VEC, NV>(res + row * d, d, lane, o);
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const float v = rstd * (gy[i] - m1 - r[i] * m2);
+                o[i] = res ? o[i] + v : v;
+            }
+            if (dx) store_row_f32<VEC, NV>(dx + row * d, d, lane, o);
+            if (dx_bf16) store_row_bf16<VEC, NV>(dx_bf16 + row * d, d, lane, o);
+        }
+    }
+    if (!partials) return;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) {
+            red[wave][0][(i * 64 + lane) * VEC + t] = sg[i * VEC + t];
+            red[wave][1][(i * 64 + lane) * VEC + t] = sb[i * VEC + t];
+        }
+    __syncthreads();
+    float* out = partials + (int64_t)blockIdx.x * 2 * d;
+    for (int e = threadIdx.x; e < 2 * d; e += WG) {
+        const int which = e >= d, c = which ? e - d : e;
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) a += red[w][which][c];
+        out[e] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // gather / scatter of the K selected rows
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void gather_rows_kernel(const float* __restrict__ x, int64_t n, int d,
@@ -759,6 +866,26 @@ int snf_layernorm_rows_split3_f32(const float* x, int64_t n, int d, const int32_
                                               reinterpret_cast<unsigned short*>(out_bf16), (float*)nullptr, (float*)nullptr,
                                               (const int64_t*)nullptr, 1));
     return snf::check_launch("layernorm_rows_kernel<split3>");
+}
+
+int snf_layernorm_bwd_blocks(int64_t n) { return row_grid(n); }
+
+int snf_layernorm_rows_bwd_f32(const float* x, int64_t n, int d, const void* dy, int dy_dtype, int64_t dy_stride,
+                               const float* gamma, float eps, const float* residual, float* dx, void* dx_bf16,
+                               float* partials, snf_stream_t stream) {
+    SNF_REQUIRE(x && dy, "snf_layernorm_rows_bwd_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && d >= 1, "snf_layernorm_rows_bwd_f32: bad shape");
+    SNF_REQUIRE(dy_dtype == SNF_DT_F32 || dy_dtype == SNF_DT_BF16, "snf_layernorm_rows_bwd_f32: bad dy dtype %d", dy_dtype);
+    SNF_REQUIRE(dy_stride == 0 || dy_stride >= d, "snf_layernorm_rows_bwd_f32: bad dy row pitch");
+    bool al = aligned16(x) && aligned16(dy) && (!gamma || aligned16(gamma)) && (!residual || aligned16(residual)) &&
+              (!dx || aligned16(dx)) && (!dx_bf16 || aligned16(dx_bf16)) && dy_stride % 4 == 0;
+    RowCfg cfg;
+    SNF_REQUIRE(pick_row_cfg(d, al, &cfg), "snf_layernorm_rows_bwd_f32: d=%d too wide (max 2048)", d);
+    hipStream_t s = snf::as_stream(stream);
+    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((ln_bwd_rows_kernel<VEC, NV>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, dy,
+                                              dy_dtype == SNF_DT_BF16 ? 1 : 0, dy_stride, gamma, eps, residual, dx,
+                                              reinterpret_cast<unsigned short*>(dx_bf16), partials));
+    return snf::check_launch("ln_bwd_rows_kernel");
 }
 
 int snf_gather_rows_f32(const float* x, int64_t n, int d, const int64_t* idx, int k, float* out, snf_stream_t stream) {

@@ -51,8 +51,10 @@ struct BwdParams {
     int64_t n, ldq, ldv, d;
     int k, h;
     float scale;
-    float* dq;  // [n, d]
-    float* dv;  // [n, d]
+    void* dq;   // [n, ldd] f32 or bf16 (dqv_bf16)
+    void* dv;   // [n, ldd]
+    int64_t ldd;
+    int dqv_bf16;
     void* ds;   // [h, n, k] f32, or bf16 when ds_bf16 (the caller then contracts it with a bf16 library GEMM)
     int ds_bf16;
     int tiles_per_head, tiles_per_wg, total_tiles;
@@ -301,9 +303,9 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
             });
         });
         // C layout of X^T[col, row]: lane = row, registers = columns 32 db + (r & 3) + 8 (r >> 2) + 4 hf -> 16-byte stores
-        if (rvalid) {
-            float* dvp = P.dv + (int64_t)row * P.d + a * DK + 4 * hf;
-            float* dqp = P.dq + (int64_t)row * P.d + a * DK + 4 * hf;
+        if (rvalid && !P.dqv_bf16) {
+            float* dvp = reinterpret_cast<float*>(P.dv) + (int64_t)row * P.ldd + a * DK + 4 * hf;
+            float* dqp = reinterpret_cast<float*>(P.dq) + (int64_t)row * P.ldd + a * DK + 4 * hf;
 #pragma unroll
             for (int db = 0; db < NCB; ++db)
 #pragma unroll
@@ -312,6 +314,22 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
                         f32x4{acc_v[db][4 * g], acc_v[db][4 * g + 1], acc_v[db][4 * g + 2], acc_v[db][4 * g + 3]};
                     *reinterpret_cast<f32x4*>(dqp + 32 * db + 8 * g) =
                         f32x4{acc_q[db][4 * g], acc_q[db][4 * g + 1], acc_q[db][4 * g + 2], acc_q[db][4 * g + 3]};
+                }
+        }
+        if (rvalid && P.dqv_bf16) {   // gradients leave as bf16 (operands of the weight-gradient GEMMs), 8-byte stores
+            unsigned short* dvp = reinterpret_cast<unsigned short*>(P.dv) + (int64_t)row * P.ldd + a * DK + 4 * hf;
+            unsigned short* dqp = reinterpret_cast<unsigned short*>(P.dq) + (int64_t)row * P.ldd + a * DK + 4 * hf;
+#pragma unroll
+            for (int db = 0; db < NCB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 pv, pq;
+                    pv.x = pack_bf16x2(acc_v[db][4 * g], acc_v[db][4 * g + 1]);
+                    pv.y = pack_bf16x2(acc_v[db][4 * g + 2], acc_v[db][4 * g + 3]);
+                    pq.x = pack_bf16x2(acc_q[db][4 * g], acc_q[db][4 * g + 1]);
+                    pq.y = pack_bf16x2(acc_q[db][4 * g + 2], acc_q[db][4 * g + 3]);
+                    *reinterpret_cast<uint2*>(dvp + 32 * db + 8 * g) = pv;
+                    *reinterpret_cast<uint2*>(dqp + 32 * db + 8 * g) = pq;
                 }
         }
         if (++t == P.tiles_per_head) {
@@ -386,7 +404,18 @@ int snf_sparse_attn_bwd_mfma_dropout(const void* q, int64_t ldq, const void* v, 
                                      const float* dout, const float* lse, const float* mask, float dropout_p, uint64_t seed,
                                      uint64_t offset, int64_t n, int k, int h, int dk, float scale, float* dq, float* dv,
                                      void* ds, int ds_dtype, snf_stream_t stream) {
+    return snf_sparse_attn_bwd_mfma_ex(q, ldq, v, ldv, qv_dtype, kp, dout, lse, mask, dropout_p, seed, offset, n, k, h, dk, scale,
+                                       dq, dv, (int64_t)h * dk, SNF_DT_F32, ds, ds_dtype, stream);
+}
+
+int snf_sparse_attn_bwd_mfma_ex(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const float* kp,
+                                const float* dout, const float* lse, const float* mask, float dropout_p, uint64_t seed,
+                                uint64_t offset, int64_t n, int k, int h, int dk, float scale, void* dq, void* dv, int64_t ldd,
+                                int dqv_dtype, void* ds, int ds_dtype, snf_stream_t stream) {
     SNF_REQUIRE(q && v && kp && dout && lse && dq && dv && ds, "snf_sparse_attn_bwd_mfma: null pointer");
+    SNF_REQUIRE(dqv_dtype == SNF_DT_F32 || dqv_dtype == SNF_DT_BF16, "snf_sparse_attn_bwd_mfma: bad dq / dv dtype %d", dqv_dtype);
+    SNF_REQUIRE(ldd >= (int64_t)h * dk && ldd % (dqv_dtype == SNF_DT_BF16 ? 8 : 4) == 0,
+                "snf_sparse_attn_bwd_mfma: ldd=%lld must be >= h*dk and keep rows 16-byte aligned", (long long)ldd);
     SNF_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "snf_sparse_attn_bwd_mfma: dropout_p=%f outside [0, 1)", dropout_p);
     SNF_REQUIRE(!(mask && dropout_p > 0.f), "snf_sparse_attn_bwd_mfma: pass a mask tensor OR (dropout_p, seed, offset), not both");
     SNF_REQUIRE(qv_dtype == SNF_DT_F32 || qv_dtype == SNF_DT_BF16, "snf_sparse_attn_bwd_mfma: bad dtype %d", qv_dtype);
@@ -422,6 +451,8 @@ int snf_sparse_attn_bwd_mfma_dropout(const void* q, int64_t ldq, const void* v, 
     P.scale = scale;
     P.dq = dq;
     P.dv = dv;
+    P.ldd = ldd;
+    P.dqv_bf16 = dqv_dtype == SNF_DT_BF16;
     P.ds = ds;
     P.ds_bf16 = ds_dtype == SNF_DT_BF16;
     P.tiles_per_head = pl.tiles_per_head;

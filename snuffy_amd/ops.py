@@ -214,6 +214,41 @@ def layernorm_rows(x, gamma=None, beta=None, eps=1e-5, slot=None, patch_rows=Non
     return (out, mean, rstd) if want_stats else out
 
 
+def layernorm_rows_bwd(x, dy, gamma=None, eps=1e-5, residual=None, want_dx=True, want_dx_bf16=False, want_param_grads=True):
+    """Backward of layernorm_rows (snf_layernorm_rows_bwd_f32): x [n, d] f32 (the forward's input), dy [n, d] f32 / bf16 or
+    ONE row [d] broadcast to all rows.  Returns (dx f32 or None, dx bf16 or None, dgamma_unscaled [d], dbeta [d]) where
+    dgamma_unscaled = sum_rows dy * xhat and dbeta = sum_rows dy (None when not asked for)."""
+    x = _req(x, torch.float32, "x", 2)
+    n, d = x.shape
+    if dy.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("layernorm_rows_bwd: dy must be float32 or bfloat16")
+    if dy.dim() == 1:
+        dy = _req(dy, dy.dtype, "dy", 1)
+        stride = 0
+        if dy.shape[0] != d:
+            raise ValueError("layernorm_rows_bwd: broadcast dy has %d entries, need %d" % (dy.shape[0], d))
+    else:
+        dy = _rows16(dy, "dy")
+        if dy.shape != x.shape:
+            raise ValueError("layernorm_rows_bwd: dy shape %s does not match x %s" % (tuple(dy.shape), tuple(x.shape)))
+        stride = dy.stride(0)
+    if gamma is not None:
+        gamma = _req(gamma, torch.float32, "gamma", 1)
+    if residual is not None:
+        residual = _req(residual, torch.float32, "residual", 2)
+    lib = _ffi.load()
+    dx = torch.empty_like(x) if want_dx else None
+    dxb = torch.empty(n, d, dtype=torch.bfloat16, device=x.device) if want_dx_bf16 else None
+    part = torch.empty(lib.snf_layernorm_bwd_blocks(n), 2, d, dtype=torch.float32, device=x.device) if want_param_grads else None
+    check(lib.snf_layernorm_rows_bwd_f32(_p(x), n, d, _p(dy), DT_F32 if dy.dtype == torch.float32 else DT_BF16, stride,
+                                         _p(gamma), float(eps), _p(residual), _p(dx), _p(dxb), _p(part), _stream()),
+          "snf_layernorm_rows_bwd_f32")
+    if part is None:
+        return dx, dxb, None, None
+    sums = part.sum(0)
+    return dx, dxb, sums[0], sums[1]
+
+
 def bias_act_(h, bias, act):
     """h = act(h + bias) in place (snuffy.py:224-225)."""
     if not h.is_cuda or not h.is_contiguous() or h.dim() != 2:
@@ -290,9 +325,10 @@ def mfma_attn_bwd_supported(k, dk):
     return (dk == 128 and 1 <= k <= 224) or (dk == 64 and 1 <= k <= 256)
 
 
-def sparse_attn_bwd_mfma(q, v, kp, dout, lse, h, mask=None, scale=None, dropout=None):
+def sparse_attn_bwd_mfma(q, v, kp, dout, lse, h, mask=None, scale=None, dropout=None, fused_bf16_grads=False):
     """MFMA backward (bf16 operands): (dq [n,d] f32, dkp [k,d] f32, dv [n,d] f32) from q, v (f32 or bf16, row-strided views
-    allowed), kp [k,d] f32, dout [k,d] f32 and the forward's lse [h,n].  mask: dropout keep-mask / (1 - p) or None."""
+    allowed), kp [k,d] f32, dout [k,d] f32 and the forward's lse [h,n].  mask: dropout keep-mask / (1 - p) or None.
+    fused_bf16_grads: dq and dv are the two column halves of ONE bf16 buffer [n, 2 d] (returned as views of it)."""
     if q.dtype not in (torch.float32, torch.bfloat16) or v.dtype != q.dtype:
         raise TypeError("sparse_attn_bwd_mfma: q and v must both be float32 or both bfloat16")
     q = _rows16(q, "q")
@@ -307,17 +343,22 @@ def sparse_attn_bwd_mfma(q, v, kp, dout, lse, h, mask=None, scale=None, dropout=
     dk = d // h
     scale = 1.0 / math.sqrt(dk) if scale is None else scale
     lib = _ffi.load()
-    dq = torch.empty(n, d, dtype=torch.float32, device=q.device)
-    dv = torch.empty(n, d, dtype=torch.float32, device=q.device)
+    if fused_bf16_grads:
+        dqv = torch.empty(n, 2 * d, dtype=torch.bfloat16, device=q.device)
+        dq, dv, ldd, gdt = dqv[:, :d], dqv[:, d:], 2 * d, DT_BF16
+    else:
+        dq = torch.empty(n, d, dtype=torch.float32, device=q.device)
+        dv = torch.empty(n, d, dtype=torch.float32, device=q.device)
+        ldd, gdt = d, DT_F32
     # bf16 operands: dS is written as bf16 and dKp = dS^T Q is one batched bf16 library GEMM (fp32 accumulate) -- half the
     # dS traffic and ~40 us instead of ~310 us for the fp32 slice kernel; f32 operands keep the fp32 route
     bf16 = q.dtype == torch.bfloat16
     ds = torch.empty(h, n, k, dtype=torch.bfloat16 if bf16 else torch.float32, device=q.device)
     dt = DT_F32 if q.dtype == torch.float32 else DT_BF16
     pdrop, seed, offset = dropout if dropout is not None else (0.0, 0, 0)
-    check(lib.snf_sparse_attn_bwd_mfma_dropout(_p(q), q.stride(0), _p(v), v.stride(0), dt, _p(kp), _p(dout), _p(lse), _p(mask),
-                                               float(pdrop), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), n, k, h, dk,
-                                               float(scale), _p(dq), _p(dv), _p(ds), DT_BF16 if bf16 else DT_F32, _stream()),
+    check(lib.snf_sparse_attn_bwd_mfma_ex(_p(q), q.stride(0), _p(v), v.stride(0), dt, _p(kp), _p(dout), _p(lse), _p(mask),
+                                          float(pdrop), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), n, k, h, dk,
+                                          float(scale), _p(dq), _p(dv), ldd, gdt, _p(ds), DT_BF16 if bf16 else DT_F32, _stream()),
           "snf_sparse_attn_bwd_mfma")
     if bf16:
         qh = q.view(n, h, dk).transpose(0, 1)                       # [h, n, dk] (strided view)

@@ -459,6 +459,11 @@ def test_sparse_attn_bwd_mfma(n, k, h, drop, dt, dk):
     dq2, dkp2, dv2 = ops().sparse_attn_bwd_mfma(qd_, vd_, kp.to(DEV), dout.to(DEV), lse, h,
                                                 mask=None if mask is None else mask.to(DEV))
     assert torch.equal(dq, dq2) and torch.equal(dkp, dkp2) and torch.equal(dv, dv2)
+    # gradients written as bf16 into the two halves of one [n, 2 d] buffer == the fp32 outputs rounded once
+    dq3, dkp3, dv3 = ops().sparse_attn_bwd_mfma(qd_, vd_, kp.to(DEV), dout.to(DEV), lse, h,
+                                                mask=None if mask is None else mask.to(DEV), fused_bf16_grads=True)
+    assert dq3._base is dv3._base and dq3._base.shape == (n, 2 * h * dk) and dq3.dtype == torch.bfloat16
+    assert torch.equal(dq3, dq.to(torch.bfloat16)) and torch.equal(dv3, dv.to(torch.bfloat16)) and torch.equal(dkp3, dkp)
 
 
 # ---------------------------------------------------------------- attention dropout: mask regenerated in the kernels

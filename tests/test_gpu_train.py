@@ -169,3 +169,109 @@ def test_multiclass_gradients_match_oracle_autograd():
         assert float((p.grad.cpu() - g_ref).abs().max()) / denom < 2e-3, name
         checked += 1
     assert checked >= 20
+
+
+def _ln_reference(x, dy, gamma, eps, residual):
+    x = x.double().requires_grad_(True)
+    g = gamma.double().requires_grad_(True)
+    b = torch.zeros_like(g).requires_grad_(True)
+    y = torch.nn.functional.layer_norm(x, (x.shape[1],), g, b, eps)
+    y.backward(dy.double().expand_as(y))
+    dx = x.grad + (residual.double() if residual is not None else 0)
+    return dx, g.grad, b.grad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d", [(1000, 768), (333, 384), (4096, 64), (77, 100), (5000, 1536)])
+def test_layernorm_rows_bwd_kernel(n, d):
+    """snf_layernorm_rows_bwd_f32 vs fp64 autograd: per-row dy (f32 / bf16), ONE broadcast row, residual, dgamma / dbeta."""
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(n + d)
+    x = (torch.randn(n, d, generator=g) * 2 + 0.5).to(DEV)
+    gamma = (1 + 0.3 * torch.randn(d, generator=g)).to(DEV)
+    dy = torch.randn(n, d, generator=g).to(DEV)
+    res = torch.randn(n, d, generator=g).to(DEV)
+    for dyv, resv, tol in ((dy, None, 2e-5), (dy, res, 2e-5), (dy.to(torch.bfloat16), None, 2e-5), (dy[0].contiguous(), res, 2e-5)):
+        dx, dxb, dgam, dbet = ops.layernorm_rows_bwd(x, dyv, gamma, 1e-5, residual=resv, want_dx_bf16=True)
+        rdx, rg, rb = _ln_reference(x, dyv.float() if dyv.dim() == 2 else dyv.float().unsqueeze(0), gamma, 1e-5, resv)
+        scale = rdx.abs().max().item()
+        assert (dx.double() - rdx).abs().max().item() <= tol * scale
+        assert torch.equal(dxb, dx.to(torch.bfloat16))
+        assert (dgam.double() - rg).abs().max().item() <= 1e-4 * max(1.0, rg.abs().max().item())
+        assert (dbet.double() - rb).abs().max().item() <= 1e-4 * max(1.0, rb.abs().max().item())
+    # no gamma, no partial sums
+    dx, _, a, b = ops.layernorm_rows_bwd(x, dy, None, 1e-5, want_param_grads=False)
+    rdx, _, _ = _ln_reference(x, dy, torch.ones(d, device=DEV), 1e-5, None)
+    assert a is None and b is None and (dx.double() - rdx).abs().max().item() <= 2e-5 * rdx.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_head_function_gradients():
+    """HeadFn (Linear(mean_n LayerNorm(z)), snuffy.py:86,71) vs fp64 autograd: dz, dgamma, dbeta, dW, db."""
+    from snuffy_amd import autograd as SA
+    torch.manual_seed(3)
+    n, d, c = 3000, 384, 2
+    z = (torch.randn(n, d, device=DEV) * 1.5).requires_grad_(True)
+    norm = torch.nn.LayerNorm(d).to(DEV)
+    lin = torch.nn.Linear(d, c).to(DEV)
+    with torch.no_grad():
+        norm.weight.add_(0.3 * torch.randn(d, device=DEV))
+        norm.bias.add_(0.2 * torch.randn(d, device=DEV))
+    w_out = torch.tensor([1.5, -0.7], device=DEV)
+    (SA.head_train(z, norm, lin) * w_out).sum().backward()
+    got = [z.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()]
+    zd = z.detach().double().requires_grad_(True)
+    nd, ld = torch.nn.LayerNorm(d).to(DEV).double(), torch.nn.Linear(d, c).to(DEV).double()
+    nd.load_state_dict({k: v.double() for k, v in norm.state_dict().items()})
+    ld.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+    (ld(nd(zd).mean(0)) * w_out.double()).sum().backward()
+    want = [zd.grad, nd.weight.grad, nd.bias.grad, ld.weight.grad, ld.bias.grad]
+    for a, b in zip(got, want):
+        assert (a.double() - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-30), (a.shape,)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d,h,lam", [(700, 256, 4, 50), (3000, 384, 6, 200), (2048, 768, 6, 200)])
+def test_fused_bf16_layer0_training_matches_generic_and_fp32(n, d, h, lam, monkeypatch):
+    """EncoderLayer0Bf16Fn (hand-ordered forward / backward of the first layer, bf16) against the generic autograd chain of
+    the same precision and against the fp32 training path: every parameter gradient, eval mode and train mode (the
+    in-kernel dropout mask is a function of (seed, offset), so both bf16 chains see the same mask)."""
+    from snuffy_amd import autograd as SA
+    torch.manual_seed(n)
+    ref = build_amd_milnet(d, h, "relu", lam, 0.0, 1)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.add_(0.3 * torch.randn(d))
+                m.bias.add_(0.2 * torch.randn(d))
+            if isinstance(m, torch.nn.Linear) and m.bias is not None:
+                m.bias.add_(0.1 * torch.randn_like(m.bias))
+    sd = ref.state_dict()
+    x = torch.randn(1, n, d, device=DEV)
+    for train_mode in (False, True):
+        grads, outs = {}, {}
+        for tag, precision, fused in (("fp32", "fp32", True), ("generic", "bf16", False), ("fused", "bf16", True)):
+            if train_mode and tag == "fp32":
+                continue                           # the fp32 chain draws its mask for a materialised P: same stream, other layout
+            monkeypatch.setattr(SA, "FUSED_BF16_TRAINING", fused)
+            net = build_amd_milnet(d, h, "relu", lam, 0.0, 1)
+            net.load_state_dict(sd, strict=True)
+            net = net.to(DEV).configure(precision=precision, return_attention=False)
+            net.train(train_mode)
+            torch.manual_seed(11)
+            ins, logits, _ = net(x)
+            (logits.sum() * 3 + ins.max()).backward()
+            grads[tag] = {k: p.grad.float().clone() for k, p in net.named_parameters()}
+            outs[tag] = logits.detach().clone()
+        base = "generic"
+        assert (outs["fused"] - outs[base]).abs().max().item() <= 2e-2 * max(1.0, outs[base].abs().max().item())
+        for k in grads["fused"]:
+            if k.endswith("self_attn.linears.1.bias"):
+                continue                           # mathematically zero gradient
+            a = grads["fused"][k].double()
+            for other, bound in (("generic", 0.08), ("fp32", 0.1)):
+                if other not in grads:
+                    continue
+                b = grads[other][k].double()
+                rel = float((a - b).norm() / b.norm().clamp_min(1e-12))
+                assert rel < bound, (train_mode, k, other, rel)
