@@ -67,6 +67,12 @@ def get_args_parser():
 # ----------------------------------------------------------------------------------------------------------------------
 # bag-parallel gradient exchange (new)
 # ----------------------------------------------------------------------------------------------------------------------
+def _fused_step(params):
+    """Adam / AdamW as ONE kernel over all parameters (torch's fused implementation: the same update rule as the default
+    multi-tensor one, ~50 us instead of ~150 us for the 7 M parameters of a D = 768 model) when they live on the GPU."""
+    return {"fused": True} if all(p.is_cuda and p.is_floating_point() for p in params) else {}
+
+
 class FlatGradAllReduce:
     """One flat fp32 buffer over all trainable parameters; ONE all-reduce (sum, then / world) per optimizer step.
 
@@ -182,7 +188,7 @@ class Trainer:
         except KeyError:
             raise Exception(f'Optimizer not found. Given: {self.args.optimizer}, Have: {OPTIMIZERS.keys()}')
         return cls(params=self.milnet.parameters(), lr=self.args.lr, betas=(self.args.betas[0], self.args.betas[1]),
-                   weight_decay=self.args.weight_decay)
+                   weight_decay=self.args.weight_decay, **_fused_step(self.milnet.parameters()))
 
     def _get_scheduler(self):
         if self.args.scheduler == 'cosine':
@@ -369,7 +375,8 @@ class SmallWeightTrainer(Trainer):
         return cls(params=[{'params': self.single_weight_parameter,
                             'lr': self.args.lr * self.args.single_weight__lr_multiplier},
                            {'params': self.milnet.parameters()}],
-                   lr=self.args.lr, betas=(self.args.betas[0], self.args.betas[1]), weight_decay=self.args.weight_decay)
+                   lr=self.args.lr, betas=(self.args.betas[0], self.args.betas[1]), weight_decay=self.args.weight_decay,
+                   **_fused_step([self.single_weight_parameter] + list(self.milnet.parameters())))
 
     def _run_model(self, bag_feats, bag_label):
         ins_prediction, bag_prediction, _ = self.milnet(bag_feats)
@@ -470,7 +477,8 @@ class BagParallelStepper:
         self.milnet.configure(precision=precision, return_attention=False)
         self.w = torch.tensor(0.5, device=device)
         self.criterion = nn.BCEWithLogitsLoss()
-        self.optimizer = torch.optim.AdamW(self.milnet.parameters(), lr=lr, betas=betas, weight_decay=weight_decay)
+        self.optimizer = torch.optim.AdamW(self.milnet.parameters(), lr=lr, betas=betas, weight_decay=weight_decay,
+                                           **_fused_step(self.milnet.parameters()))
         self.sync = FlatGradAllReduce(self.milnet.parameters(), dist, world_size)
 
     def step(self, bag, label):
@@ -481,5 +489,5 @@ class BagParallelStepper:
         loss.backward()
         self.sync()
         self.optimizer.step()
-        self.optimizer.zero_grad(set_to_none=False)
+        self.optimizer.zero_grad()           # set_to_none: the next backward assigns the gradients, no fill + add per parameter
         return loss.detach()
