@@ -186,7 +186,7 @@ def test_bag_parallel_stepper_equals_trainer_step_world1():
     shuffle(np.arange(1))                           # the epoch order consumed one draw first
     xp = dropout_patches_device(x, 0.0)
     st.optimizer = type(tr.optimizer)(params=[{"params": twin.parameters()}], lr=args.lr, betas=tuple(args.betas),
-                                      weight_decay=args.weight_decay)
+                                      weight_decay=args.weight_decay, fused=True)   # as the trainer builds it on the GPU
     st.step(xp, torch.tensor([1.0], device=DEV))
     for (k, a), (_, b) in zip(tr.milnet.named_parameters(), twin.named_parameters()):
         assert torch.equal(a, b), k
