@@ -104,8 +104,13 @@ __device__ __forceinline__ int img_pos(int row, int c) {
     return 4 * (((c >> 2) + rot) & (DK / 32 - 1)) + ((c & 3) ^ ((row >> 2) & 3));
 }
 
-template <int DK, int NKB, typename QT>
+// MODE 0: every option at run time (mask tensor, fp32 dS, K not a multiple of 4).  MODE 1 / 2: the training path's shape --
+// bf16 dS, K % 4 == 0, no mask tensor -- without (1) / with (2) the in-register Philox mask.  The fast modes drop the per-store
+// predicates of full key blocks, compare against K only in the last block, and (2) generate the mask ONCE: a dropped key is
+// remembered in the sign bit of its bf16 probability (P >= 0), so the second use costs a max instead of ten Philox rounds.
+template <int DK, int NKB, typename QT, int MODE>
 __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams P) {
+    constexpr bool FAST = MODE != 0;
     constexpr int NKS = DK / 16, NCB = DK / 32, RP = 2 * DK, NCH = DK / 8;   // k-steps, column blocks, image row pitch, chunks
     constexpr int IMG = 32 * NKB * RP;   // bytes of one image
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -177,6 +182,8 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
         // rows past the bag end get P = 0 (exp2(-inf))
         const float lse2 = rvalid ? P.lse[(int64_t)a * P.n + row] * 1.44269504088896340736f : INFINITY;
         const float* mrow = P.mask ? P.mask + ((int64_t)a * P.n + lrow) * P.k : nullptr;
+        int kk = P.k;
+        asm volatile("" : "+s"(kk));
 
         unsigned ppk[NKB][8], dpk[NKB][8];   // Pd (= P o M) and dP (o M), later dS, as bf16 pairs: [block][pair of registers]
         float dsum = 0.f;
@@ -185,7 +192,12 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = (32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hf >= P.k) ? -INFINITY : 0.f;   // padded keys: P = 0
+                // padded keys: P = 0.  Only the last block can hold any; kk is opaque so that the compare masks are not hoisted
+                // out of the tile loop (16 NKB SGPR pairs: that was 225 spilled SGPRs)
+                if (!FAST || jb == NKB - 1)
+                    s[r] = (32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hf >= kk) ? -INFINITY : 0.f;
+                else
+                    s[r] = 0.f;
                 dp[r] = 0.f;
             }
             static_for<0, NKS>([&](auto kb_t) __attribute__((always_inline)) {
@@ -199,11 +211,16 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
             for (int c4 = 0; c4 < 4; ++c4) {
                 float pv[4], gv[4];
                 f32x4 mk = {1.f, 1.f, 1.f, 1.f};
-                if (mrow) {
-                    const int key0 = 32 * jb + 8 * c4 + 4 * hf;
+                if constexpr (MODE == 0) {
+                    if (mrow) {
+                        const int key0 = 32 * jb + 8 * c4 + 4 * hf;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) mk[e] = (key0 + e < P.k) ? mrow[key0 + e] : 0.f;
-                } else if (P.drop.thresh) {
+                        for (int e = 0; e < 4; ++e) mk[e] = (key0 + e < P.k) ? mrow[key0 + e] : 0.f;
+                    } else if (P.drop.thresh) {
+                        const snf::philox_f4 m4 = snf::dropout_mask4(P.drop, a, P.n, lrow, P.k, 32 * jb + 8 * c4 + 4 * hf);
+                        mk = f32x4{m4[0], m4[1], m4[2], m4[3]};
+                    }
+                } else if constexpr (MODE == 2) {
                     const snf::philox_f4 m4 = snf::dropout_mask4(P.drop, a, P.n, lrow, P.k, 32 * jb + 8 * c4 + 4 * hf);
                     mk = f32x4{m4[0], m4[1], m4[2], m4[3]};
                 }
@@ -211,6 +228,7 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
                 for (int e = 0; e < 4; ++e) {
                     pv[e] = __builtin_amdgcn_exp2f(fmaf(s[4 * c4 + e], c_exp, -lse2));
                     gv[e] = dp[4 * c4 + e] * mk[e];          // dP = dPd o M
+                    if constexpr (MODE == 2) pv[e] = mk[e] == 0.f ? -pv[e] : pv[e];   // dropped: remembered in the sign
                 }
                 // ppk holds P (un-masked: dS = P o (dP - D)); the masked Pd for dV is rebuilt from it below when a mask exists
                 const unsigned p01 = pack2(pv[0], pv[1]), p23 = pack2(pv[2], pv[3]);
@@ -225,12 +243,43 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
                 dsum = fmaf(lo_f(p23), lo_f(g23), dsum);
                 dsum = fmaf(hi_f(p23), hi_f(g23), dsum);
             }
+            // keep the key blocks apart: interleaved, the scheduler holds every block's 32 accumulator registers live at once
+            // (512 registers + 190 spilled before this fence, profiles/history/r02_attn_bwd_resources.txt)
+            __builtin_amdgcn_sched_barrier(0);
         });
         const float dtot = xhalf_sum(dsum);
 
         // dS = P o (dP - D) * scale: written out (fp32, for dKp) and kept as bf16 pairs for dQ; Pd = P o M for dV
         float* dsrow = reinterpret_cast<float*>(P.ds) + ((int64_t)a * P.n + lrow) * P.k;
         unsigned short* dsrow16 = reinterpret_cast<unsigned short*>(P.ds) + ((int64_t)a * P.n + lrow) * P.k;
+        if constexpr (FAST) {
+            // rows past the bag end skip the whole pass (their registers feed accumulators that are never stored)
+            if (rvalid) {
+                static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
+                    constexpr int jb = decltype(jb_t)::value;
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const unsigned p01 = ppk[jb][2 * c4], p23 = ppk[jb][2 * c4 + 1];
+                        const unsigned g01 = dpk[jb][2 * c4], g23 = dpk[jb][2 * c4 + 1];
+                        const float pv[4] = {lo_f(p01), hi_f(p01), lo_f(p23), hi_f(p23)};
+                        const float gv[4] = {lo_f(g01), hi_f(g01), lo_f(g23), hi_f(g23)};
+                        f32x4 dsv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dsv[e] = fabsf(pv[e]) * (gv[e] - dtot) * P.scale;
+                        const int key0 = 32 * jb + 8 * c4 + 4 * hf;
+                        const unsigned s01 = pack2(dsv[0], dsv[1]), s23 = pack2(dsv[2], dsv[3]);
+                        if (jb < NKB - 1 || key0 < kk) *reinterpret_cast<uint2*>(dsrow16 + key0) = uint2{s01, s23};
+                        dpk[jb][2 * c4] = s01;
+                        dpk[jb][2 * c4 + 1] = s23;
+                        if constexpr (MODE == 2) {   // Pd = P o M: kept keys scaled, dropped keys (negative sign) -> 0
+                            ppk[jb][2 * c4] = pack2(fmaxf(pv[0], 0.f) * P.drop.scale, fmaxf(pv[1], 0.f) * P.drop.scale);
+                            ppk[jb][2 * c4 + 1] = pack2(fmaxf(pv[2], 0.f) * P.drop.scale, fmaxf(pv[3], 0.f) * P.drop.scale);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+        } else {
         const bool vec_ok = (P.k & 3) == 0;
         static_for<0, NKB>([&](auto jb_t) __attribute__((always_inline)) {
             constexpr int jb = decltype(jb_t)::value;
@@ -278,7 +327,9 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_bwd_mfma_kernel(BwdParams 
                     ppk[jb][2 * c4 + 1] = pack2(pv[2] * m4[2], pv[3] * m4[3]);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         });
+        }
 
         // dV^T[col, row] += dO^T Pd^T ;  dQ^T[col, row] += Kp^T dS^T : k-step = 16 keys (registers 8u .. 8u+7 of block jb)
         f32x16 acc_v[NCB], acc_q[NCB];
@@ -355,11 +406,11 @@ inline bool make_bwd_plan(int64_t n, int k, int h, int dk, BwdPlan* pl) {
     return true;
 }
 
-template <int DK, int NKB, typename QT>
-int launch_bwd(const BwdParams& P, const BwdPlan& pl, hipStream_t s) {
+template <int DK, int NKB, typename QT, int MODE>
+int launch_bwd_mode(const BwdParams& P, const BwdPlan& pl, hipStream_t s) {
     const size_t lds = (size_t)2 * 32 * NKB * 2 * DK;
     static thread_local bool attr_set = false;
-    auto kern = sparse_attn_bwd_mfma_kernel<DK, NKB, QT>;
+    auto kern = sparse_attn_bwd_mfma_kernel<DK, NKB, QT, MODE>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess) {
@@ -371,6 +422,14 @@ int launch_bwd(const BwdParams& P, const BwdPlan& pl, hipStream_t s) {
     }
     hipLaunchKernelGGL(kern, dim3(pl.num_wg), dim3(256), lds, s, P);
     return snf::check_launch("sparse_attn_bwd_mfma_kernel");
+}
+template <int DK, int NKB, typename QT>
+int launch_bwd(const BwdParams& P, const BwdPlan& pl, hipStream_t s) {
+    if constexpr (std::is_same<QT, unsigned short>::value) {   // the training path: bf16 operands, bf16 dS, K % 4 == 0
+        if (P.ds_bf16 && !P.mask && (P.k & 3) == 0)
+            return P.drop.thresh ? launch_bwd_mode<DK, NKB, QT, 2>(P, pl, s) : launch_bwd_mode<DK, NKB, QT, 1>(P, pl, s);
+    }
+    return launch_bwd_mode<DK, NKB, QT, 0>(P, pl, s);
 }
 template <int DK, typename QT>
 int launch_bwd_nkb(const BwdParams& P, const BwdPlan& pl, hipStream_t s) {
