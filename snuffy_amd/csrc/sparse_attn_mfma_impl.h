@@ -752,15 +752,16 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_stats_kernel(AttnParams P)
 
 // out[key, a*DK + col] = sum over the (workgroup, segment) partials of head a, ascending workgroup order
 template <int DK, int NKB>
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int num_wg, int seg_count,
+__global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __restrict__ partial, int num_wg, int seg_count,
                                                               int tiles_per_head, int tiles_per_wg, int total_tiles,
                                                               int k, int h, float* __restrict__ out) {
     constexpr int NCB = DK / 32;
     constexpr int TILES = NKB * NCB;
     const int a = blockIdx.y;
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);  // (tile, q4)
-    if (unit >= TILES * 4) return;
-    const int lane = threadIdx.x & 63;
+    // one wave per workgroup: 4 TILES h small workgroups (672 at config B) spread over all CUs; as 168 workgroups of 4 waves
+    // the pass left a third of the chip idle
+    const int unit = blockIdx.x;  // (tile, q4)
+    const int lane = threadIdx.x;
     const int t_idx = unit >> 2, q4 = unit & 3;
     if (32 * (t_idx / NCB) + 8 * q4 >= k) return;   // padding only: never written by the main kernel
     const int f_lo = a * tiles_per_head, f_hi = (a + 1) * tiles_per_head - 1;
@@ -844,7 +845,7 @@ int launch_variant(const AttnParams& P, const Plan& pl, float* out, hipStream_t 
     int rc = snf::check_launch("sparse_attn_mfma_kernel");
     if (rc) return rc;
     constexpr int TILES = NKB * (DK / 32);
-    hipLaunchKernelGGL((reduce_partials_kernel<DK, NKB>), dim3(TILES, P.h), dim3(256), 0, s, P.partial, pl.num_wg,
+    hipLaunchKernelGGL((reduce_partials_kernel<DK, NKB>), dim3(TILES * 4, P.h), dim3(64), 0, s, P.partial, pl.num_wg,
                        pl.seg_count, pl.tiles_per_head, pl.tiles_per_wg, pl.total_tiles, P.k, P.h, out);
     return snf::check_launch("reduce_partials_kernel");
 }

@@ -356,13 +356,12 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
 
 // out[key, a*DK + col] = sum over the (workgroup, segment) partials of head a, ascending workgroup order
 template <int DK, int NKB>
-__global__ __launch_bounds__(256) void x3_reduce_kernel(const float* __restrict__ partial, int num_wg, int seg_count,
+__global__ __launch_bounds__(64) void x3_reduce_kernel(const float* __restrict__ partial, int num_wg, int seg_count,
                                                         int tiles_per_head, int tiles_per_wg, int k, int h, float* __restrict__ out) {
     constexpr int NCB = DK / 32, TILES = NKB * NCB;
     const int a = blockIdx.y;
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);   // (tile, q4)
-    if (unit >= TILES * 4) return;
-    const int lane = threadIdx.x & 63;
+    const int unit = blockIdx.x;   // (tile, q4): one wave per workgroup, so that the 4 TILES h units spread over all CUs
+    const int lane = threadIdx.x;
     const int t_idx = unit >> 2, q4 = unit & 3;
     if (32 * (t_idx / NCB) + 8 * q4 >= k) return;
     const int f_lo = a * tiles_per_head, f_hi = (a + 1) * tiles_per_head - 1;
@@ -442,7 +441,7 @@ int x3_launch(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s) {
     int rc = snf::check_launch("sparse_attn_x3_kernel");
     if (rc) return rc;
     constexpr int TILES = NKB * (DK / 32);
-    hipLaunchKernelGGL((x3_reduce_kernel<DK, NKB>), dim3(TILES, P.h), dim3(256), 0, s, P.partial, pl.num_wg, pl.seg_count,
+    hipLaunchKernelGGL((x3_reduce_kernel<DK, NKB>), dim3(TILES * 4, P.h), dim3(64), 0, s, P.partial, pl.num_wg, pl.seg_count,
                        pl.tiles_per_head, pl.tiles_per_wg, P.k, P.h, out);
     return snf::check_launch("x3_reduce_kernel");
 }
