@@ -195,7 +195,9 @@ int snf_dropout_mask_f32(float dropout_p, uint64_t seed, uint64_t offset, int h,
  * three bf16 MFMAs (ah bh + ah bl + al bh, fp32 accumulate); softmax / normalisation fp32.  Same outputs as
  * snf_sparse_attn_fwd_f32 to ~3e-6 on P, 1e-5 on O (the reference's own arithmetic class, north-star bound 1e-3), ~10x its speed.
  * q [n, ldq], v [n, ldv] row-major (row pitches in elements, 16-byte aligned rows: column halves of a fused projection are
- * taken in place); dk in {64, 128}, k <= 256 / 224 keys -- other shapes SNF_EUNSUPPORTED (the caller keeps the exact kernel).
+ * taken in place); dk in {64, 128}; 256 / 224 keys fit one launch, more keys (up to 8 x 256 / 8 x 224) run as key chunks: a
+ * statistics pass per chunk (row max / sum), then the chunks' main passes with the softmax exact over all keys -- other shapes
+ * SNF_EUNSUPPORTED (the caller keeps the exact kernel).
  * workspace: snf_sparse_attn_fwd_x3_workspace_bytes (deterministic cross-workgroup reduction, as the bf16 kernel). */
 size_t snf_sparse_attn_fwd_x3_workspace_bytes(int64_t n, int k, int h, int dk);
 int snf_sparse_attn_fwd_x3(const float* q, int64_t ldq, const float* v, int64_t ldv, const float* kp, int64_t n, int k, int h,

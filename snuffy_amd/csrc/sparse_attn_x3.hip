@@ -47,8 +47,13 @@ struct X3Params {
     int64_t n, ldq, ldv, ldkp;
     int k, h;
     float scale;
-    float* attn;       // [h, n, k] or null
+    float* attn;       // [h, n, attn_ld] (already offset to this launch's first key) or null
+    int64_t attn_ld;
     float* lse;        // [h, n] or null
+    // key-chunked launches (k above one LDS image): stats [nchunks][h][n] of (max * c, sum) pairs.  MODE 1 writes chunk
+    // `chunk`'s pair per row; MODE 2 reads all chunks' pairs instead of combining its own (softmax exact over all keys)
+    f32x2* stats;
+    int nchunks, chunk;
     float* partial;    // [num_wg * seg_count][tiles][4][64][4]
     int tiles_per_head, tiles_per_wg, total_tiles, seg_count;
 };
@@ -92,7 +97,9 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 }
 __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
-template <int DK, int NKB, bool AUX>
+// MODE 0: one launch covers all keys.  MODE 1: statistics pass of one key chunk (GEMM1 + max / sum, nothing else).
+// MODE 2: main pass of one key chunk with the row statistics of ALL chunks taken from P.stats.
+template <int DK, int NKB, bool AUX, int MODE>
 __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
     constexpr int NKS = DK / 16;               // k-steps of GEMM1
     constexpr int NCB = DK / 32;               // 32-wide column blocks of the output
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
             if (row > n32 - 1) row = n32 - 1;
             qpre = load8(P.q + (int64_t)row * P.ldq + a_ * DK + 16 * kb + 8 * (lp >> 5));
         }
-        if (ONE_EACH || !do_q) {
+        if (MODE != 1 && (ONE_EACH || !do_q)) {
             int row = t_ * TROWS + p / NCH;
             if (row > n32 - 1) row = n32 - 1;
             vpre = load8(P.v + (int64_t)row * P.ldv + a_ * DK + 8 * (p % NCH));
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
             lds_qh[p] = hi;
             lds_ql[p] = lo;
         }
-        if (ONE_EACH || !do_q) {
+        if (MODE != 1 && (ONE_EACH || !do_q)) {
             split8(vpre, hi, lo);
             const int row = p / NCH, ch = p % NCH;
             const int off = row * VRS + 16 * ((ch + 4 * vrot(row)) & (NCH - 1));
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
 
     zero_acc();
     fetch(a, t);
-    const bool attn_vec = AUX && (P.k & 3) == 0 && (reinterpret_cast<uintptr_t>(P.attn) & 15) == 0;
+    const bool attn_vec = AUX && (P.attn_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(P.attn) & 15) == 0;
     for (int f = f_begin; f < f_end; ++f) {
         int an = a, tn = t + 1;
         if (tn == P.tiles_per_head) {
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
         }
         if (a != cur_head) {
             // new head: everybody is past the previous tile's GEMM2 (closing barrier below), the Kp images are free
-            if (cur_head >= 0) {
+            if (MODE != 1 && cur_head >= 0) {
                 flush(cur_head);
                 zero_acc();
             }
@@ -284,22 +291,49 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
         }
         __syncthreads();                         // B2: statistics published, every wave is done with the Q images
 
+        if constexpr (MODE == 1) {
+            // statistics pass: this chunk's (max, sum) per row, then on to the next tile
+            if (w == 0 && hf == 0 && rvalid) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int b = 0; b < NKB; ++b) m = fmaxf(m, lds_st[b * 32 + j][0]);
+                float l = 0.f;
+#pragma unroll
+                for (int b = 0; b < NKB; ++b) {
+                    const f32x2 st = lds_st[b * 32 + j];
+                    if (st[0] != -INFINITY) l = fmaf(st[1], __builtin_amdgcn_exp2f(st[0] - m), l);
+                }
+                P.stats[((int64_t)P.chunk * P.h + a) * P.n + row] = f32x2{m, l};
+            }
+            __syncthreads();                     // the statistics slots and the Q images are free
+            a = an;
+            t = tn;
+            continue;
+        }
         // ---- exact combination over the key blocks, normalisation, publish P = hi + lo
         if (w < NKB) {
-            float m = -INFINITY;
+            float m = -INFINITY, l = 0.f;
+            if constexpr (MODE == 2) {
+                const int64_t so = (int64_t)a * P.n + (rvalid ? row : n32 - 1);
+                for (int c = 0; c < P.nchunks; ++c) m = fmaxf(m, P.stats[(int64_t)c * P.h * P.n + so][0]);
+                for (int c = 0; c < P.nchunks; ++c) {
+                    const f32x2 st = P.stats[(int64_t)c * P.h * P.n + so];
+                    if (st[0] != -INFINITY) l = fmaf(st[1], __builtin_amdgcn_exp2f(st[0] - m), l);
+                }
+            } else {
 #pragma unroll
-            for (int b = 0; b < NKB; ++b) m = fmaxf(m, lds_st[b * 32 + j][0]);
-            float l = 0.f;
+                for (int b = 0; b < NKB; ++b) m = fmaxf(m, lds_st[b * 32 + j][0]);
 #pragma unroll
-            for (int b = 0; b < NKB; ++b) {
-                const f32x2 st = lds_st[b * 32 + j];
-                l = fmaf(st[1], __builtin_amdgcn_exp2f(st[0] - m), l);
+                for (int b = 0; b < NKB; ++b) {
+                    const f32x2 st = lds_st[b * 32 + j];
+                    l = fmaf(st[1], __builtin_amdgcn_exp2f(st[0] - m), l);
+                }
             }
             const float fscale = rvalid ? __builtin_amdgcn_exp2f(mw - m) / l : 0.f;
             if constexpr (AUX)
                 if (P.lse && rvalid && hf == 0 && w == 0) P.lse[(int64_t)a * P.n + row] = (m + __log2f(l)) * 0.69314718055994530942f;
             float* arow = nullptr;
-            if constexpr (AUX) arow = P.attn ? P.attn + ((int64_t)a * P.n + row) * P.k + 32 * w + 4 * hf : nullptr;
+            if constexpr (AUX) arow = P.attn ? P.attn + ((int64_t)a * P.n + row) * P.attn_ld + 32 * w + 4 * hf : nullptr;
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
                 f32x4 p4 = {s[4 * c4] * fscale, s[4 * c4 + 1] * fscale, s[4 * c4 + 2] * fscale, s[4 * c4 + 3] * fscale};
@@ -351,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
         a = an;
         t = tn;
     }
-    flush(cur_head);
+    if constexpr (MODE != 1) flush(cur_head);
 }
 
 // out[key, a*DK + col] = sum over the (workgroup, segment) partials of head a, ascending workgroup order
@@ -422,13 +456,13 @@ bool x3_plan(int64_t n, int k, int h, int dk, X3Plan* pl) {
 }
 size_t x3_workspace(const X3Plan& pl, int dk) { return (size_t)pl.num_wg * pl.seg_count * (size_t)(pl.nkb * (dk / 32)) * 1024 * sizeof(float); }
 
-template <int DK, int NKB, bool AUX>
+template <int DK, int NKB, bool AUX, int MODE>
 int x3_launch(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s) {
     constexpr int NKS = DK / 16;
     constexpr int q_bytes = NKS * 1024, p_bytes = TROWS * p_row_bytes(NKB);
     constexpr int lds = 2 * NKB * NKS * 1024 + 2 * (q_bytes > p_bytes ? q_bytes : p_bytes) + 2 * TROWS * 2 * DK + 8 * 32 * 8;
     static thread_local bool attr_set = false;
-    auto kern = sparse_attn_x3_kernel<DK, NKB, AUX>;
+    auto kern = sparse_attn_x3_kernel<DK, NKB, AUX, MODE>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             snf::set_error("sparse_attn_x3: cannot reserve %d bytes of LDS", lds);
@@ -439,29 +473,44 @@ int x3_launch(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s) {
     }
     hipLaunchKernelGGL(kern, dim3(pl.num_wg), dim3(512), lds, s, P);
     int rc = snf::check_launch("sparse_attn_x3_kernel");
-    if (rc) return rc;
+    if (rc || MODE == 1) return rc;
     constexpr int TILES = NKB * (DK / 32);
     hipLaunchKernelGGL((x3_reduce_kernel<DK, NKB>), dim3(TILES * 4, P.h), dim3(64), 0, s, P.partial, pl.num_wg, pl.seg_count,
                        pl.tiles_per_head, pl.tiles_per_wg, P.k, P.h, out);
     return snf::check_launch("x3_reduce_kernel");
 }
-template <int DK>
-int x3_dispatch(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s) {
+template <int DK, int NB>
+int x3_modes(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s, int mode) {
     const bool aux = P.attn != nullptr || P.lse != nullptr;
-#define X3_CASE(NB) \
-    case NB: return aux ? x3_launch<DK, NB, true>(P, pl, out, s) : x3_launch<DK, NB, false>(P, pl, out, s);
+    if (mode == 1) return x3_launch<DK, NB, false, 1>(P, pl, out, s);
+    if (mode == 2) return aux ? x3_launch<DK, NB, true, 2>(P, pl, out, s) : x3_launch<DK, NB, false, 2>(P, pl, out, s);
+    return aux ? x3_launch<DK, NB, true, 0>(P, pl, out, s) : x3_launch<DK, NB, false, 0>(P, pl, out, s);
+}
+template <int DK>
+int x3_dispatch(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s, int mode) {
     switch (pl.nkb) {
-        X3_CASE(2)
-        X3_CASE(4)
-        X3_CASE(7)
+        case 2: return x3_modes<DK, 2>(P, pl, out, s, mode);
+        case 4: return x3_modes<DK, 4>(P, pl, out, s, mode);
+        case 7: return x3_modes<DK, 7>(P, pl, out, s, mode);
         case 8:
-            if constexpr (DK == 64) return aux ? x3_launch<DK, 8, true>(P, pl, out, s) : x3_launch<DK, 8, false>(P, pl, out, s);
+            if constexpr (DK == 64) return x3_modes<DK, 8>(P, pl, out, s, mode);
             break;
         default: break;
     }
-#undef X3_CASE
     snf::set_error("sparse_attn_x3: key-block count %d not built", pl.nkb);
     return SNF_EUNSUPPORTED;
+}
+
+// keys per launch: one LDS image holds kmax keys; more keys run as up to 8 chunks of equal size (a multiple of 4)
+struct X3Chunks {
+    int count, size;
+};
+bool x3_chunks(int k, int dk, X3Chunks* c) {
+    const int kmax = dk == 128 ? 224 : 256;
+    if (!(dk == 64 || dk == 128) || k < 1 || k > 8 * kmax) return false;
+    c->count = (k + kmax - 1) / kmax;
+    c->size = c->count == 1 ? k : ((k + c->count - 1) / c->count + 3) & ~3;
+    return c->size <= kmax;
 }
 
 }  // namespace
@@ -470,8 +519,10 @@ extern "C" {
 
 size_t snf_sparse_attn_fwd_x3_workspace_bytes(int64_t n, int k, int h, int dk) {
     X3Plan pl;
-    if (h < 1 || !x3_plan(n, k, h, dk, &pl)) return 0;
-    return x3_workspace(pl, dk);
+    X3Chunks ch;
+    if (h < 1 || !x3_chunks(k, dk, &ch) || !x3_plan(n, ch.size, h, dk, &pl)) return 0;
+    const size_t stats = ch.count > 1 ? (size_t)ch.count * h * n * sizeof(f32x2) : 0;
+    return x3_workspace(pl, dk) + stats;
 }
 
 int snf_sparse_attn_fwd_x3(const float* q, int64_t ldq, const float* v, int64_t ldv, const float* kp, int64_t n, int k, int h,
@@ -480,8 +531,9 @@ int snf_sparse_attn_fwd_x3(const float* q, int64_t ldq, const float* v, int64_t 
     SNF_REQUIRE(q && v && kp && out, "snf_sparse_attn_fwd_x3: null pointer");
     SNF_REQUIRE(n >= 1 && k >= 1 && h >= 1, "snf_sparse_attn_fwd_x3: bad shape");
     X3Plan pl;
-    if (!x3_plan(n, k, h, dk, &pl)) {
-        snf::set_error("snf_sparse_attn_fwd_x3: unsupported shape k=%d dk=%d (dk in {64, 128}, k <= 256 / 224)", k, dk);
+    X3Chunks ch;
+    if (!x3_chunks(k, dk, &ch) || !x3_plan(n, ch.size, h, dk, &pl)) {
+        snf::set_error("snf_sparse_attn_fwd_x3: unsupported shape k=%d dk=%d (dk in {64, 128}, k <= 8 x 256 / 8 x 224)", k, dk);
         return SNF_EUNSUPPORTED;
     }
     const int64_t d = (int64_t)h * dk;
@@ -489,7 +541,8 @@ int snf_sparse_attn_fwd_x3(const float* q, int64_t ldq, const float* v, int64_t 
                 "h*dk and keep rows 16-byte aligned", (long long)ldq, (long long)ldv);
     SNF_REQUIRE(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(kp)) & 15) == 0,
                 "snf_sparse_attn_fwd_x3: q / v / kp must be 16-byte aligned");
-    const size_t need = x3_workspace(pl, dk);
+    const size_t part_bytes = x3_workspace(pl, dk);
+    const size_t need = part_bytes + (ch.count > 1 ? (size_t)ch.count * h * n * sizeof(f32x2) : 0);
     if (!workspace || workspace_bytes < need) {
         snf::set_error("snf_sparse_attn_fwd_x3: workspace %zu < %zu", workspace_bytes, need);
         return SNF_EWORKSPACE;
@@ -498,12 +551,28 @@ int snf_sparse_attn_fwd_x3(const float* q, int64_t ldq, const float* v, int64_t 
     P.q = q, P.v = v, P.kp = kp;
     P.n = n, P.ldq = ldq, P.ldv = ldv, P.ldkp = d;
     P.k = k, P.h = h, P.scale = scale;
-    P.attn = attn, P.lse = lse;
+    P.attn = attn, P.attn_ld = k, P.lse = lse;
     P.partial = reinterpret_cast<float*>(workspace);
+    P.stats = reinterpret_cast<f32x2*>(reinterpret_cast<unsigned char*>(workspace) + part_bytes);
+    P.nchunks = ch.count, P.chunk = 0;
     P.tiles_per_head = pl.tiles_per_head, P.tiles_per_wg = pl.tiles_per_wg, P.total_tiles = pl.total_tiles;
     P.seg_count = pl.seg_count;
     hipStream_t s = snf::as_stream(stream);
-    return dk == 128 ? x3_dispatch<128>(P, pl, out, s) : x3_dispatch<64>(P, pl, out, s);
+    if (ch.count == 1) return dk == 128 ? x3_dispatch<128>(P, pl, out, s, 0) : x3_dispatch<64>(P, pl, out, s, 0);
+    // key chunks: statistics of every chunk first, then the chunks' main passes with the softmax exact over all keys
+    for (int pass = 1; pass <= 2; ++pass)
+        for (int c = 0; c < ch.count; ++c) {
+            const int k0 = c * ch.size, kc = k - k0 < ch.size ? k - k0 : ch.size;
+            X3Params C = P;
+            C.kp = kp + (int64_t)k0 * d;
+            C.k = kc, C.chunk = c;
+            C.attn = (pass == 2 && attn) ? attn + k0 : nullptr;
+            C.lse = (pass == 2 && c == 0) ? lse : nullptr;
+            int rc = dk == 128 ? x3_dispatch<128>(C, pl, out + (int64_t)k0 * d, s, pass)
+                               : x3_dispatch<64>(C, pl, out + (int64_t)k0 * d, s, pass);
+            if (rc) return rc;
+        }
+    return SNF_OK;
 }
 
 }  // extern "C"

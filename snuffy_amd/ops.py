@@ -428,8 +428,9 @@ def sparse_attn_fwd(q, kp, v, h, scale=None, need_attn=False, need_lse=False):
 
 
 def x3_attn_supported(k, dk):
-    """Shapes of the fp32-class (split-bf16 x 3) MFMA attention kernel."""
-    return (dk == 128 and 1 <= k <= 224) or (dk == 64 and 1 <= k <= 256)
+    """Shapes of the fp32-class (split-bf16 x 3) MFMA attention kernel: 224 (dk = 128) / 256 (dk = 64) keys per launch, up to 8
+    key chunks with exact cross-chunk softmax statistics."""
+    return (dk == 128 and 1 <= k <= 8 * 224) or (dk == 64 and 1 <= k <= 8 * 256)
 
 
 def sparse_attn_fwd_x3(q, v, kp, h, scale=None, need_attn=False, need_lse=False):

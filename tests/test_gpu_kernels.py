@@ -300,7 +300,9 @@ def test_sparse_attn_mfma_online_max_spike():
 
 
 @pytest.mark.parametrize("n,k,h,dk", [(1000, 200, 6, 128), (4097, 224, 3, 128), (33, 7, 2, 128), (1, 1, 1, 64), (700, 256, 6, 64),
-                                      (2500, 150, 6, 64), (5000, 100, 2, 128), (31, 40, 4, 64), (300, 33, 1, 128)])
+                                      (2500, 150, 6, 64), (5000, 100, 2, 128), (31, 40, 4, 64), (300, 33, 1, 128),
+                                      # more keys than one LDS image: key chunks with exact cross-chunk statistics
+                                      (3000, 512, 6, 128), (700, 225, 2, 128), (1500, 601, 3, 64), (257, 1790, 1, 128), (100, 2048, 2, 64)])
 def test_sparse_attn_x3_fp32_class(n, k, h, dk):
     """snf_sparse_attn_fwd_x3 (split-bf16 x 3 on the matrix cores) against the fp64 oracle on the UNROUNDED operands: the
     reference's own arithmetic class (fp32), not the bf16 one.  Measured: P <= 3.5e-6, O <= 1e-5 of its scale (the exact
@@ -313,13 +315,13 @@ def test_sparse_attn_x3_fp32_class(n, k, h, dk):
     o, attn, lse = ops().sparse_attn_fwd_x3(qv[:, :d], qv[:, d:], kp.to(DEV), h, need_attn=True, need_lse=True)
     o_ref, p_ref = attn_ref(q, kp, v, h)
     assert (attn.cpu().double() - p_ref).abs().max() < 6e-6
-    assert rel_err(o.cpu(), o_ref) < 2e-5
+    assert rel_err(o.cpu(), o_ref) < (2e-5 if k <= 256 else 4e-5)      # few rows under many keys: O is a short sum of small P
     s_ref = (q.double().view(n, h, dk).transpose(0, 1) @ kp.double().view(k, h, dk).transpose(0, 1).transpose(1, 2)) / dk ** 0.5
     assert (lse.cpu().double() - torch.logsumexp(s_ref, dim=-1)).abs().max() < 3e-5
     assert (attn.sum(-1) - 1).abs().max() < 1e-5
     # same answer as the exact vector-ALU kernel to fp32 rounding, bit-identical run to run, and without the A / lse outputs
     o_ex, a_ex, _ = ops().sparse_attn_fwd(q.to(DEV), kp.to(DEV), v.to(DEV), h, need_attn=True)
-    assert (attn - a_ex).abs().max() < 6e-6 and rel_err(o.cpu(), o_ex.cpu()) < 2e-5
+    assert (attn - a_ex).abs().max() < 6e-6 and rel_err(o.cpu(), o_ex.cpu()) < (2e-5 if k <= 256 else 4e-5)
     o2, a2, _ = ops().sparse_attn_fwd_x3(q.to(DEV), v.to(DEV), kp.to(DEV), h)
     assert a2 is None and torch.equal(o2, o)
 
@@ -342,7 +344,7 @@ def test_sparse_attn_x3_config_b_walks_heads_and_spike():
     assert rel_err(o.cpu(), o_ref) < 1e-3
     from snuffy_amd import SnuffyHipError
     with pytest.raises(SnuffyHipError):
-        ops().sparse_attn_fwd_x3(q.to(DEV), v.to(DEV), torch.zeros(225, d, device=DEV), h)       # more keys than one LDS image
+        ops().sparse_attn_fwd_x3(q.to(DEV), v.to(DEV), torch.zeros(8 * 224 + 1, d, device=DEV), h)   # more than 8 key chunks
 
 
 def test_mfma_rejects_unsupported_shapes():
