@@ -191,8 +191,10 @@ class EncoderLayer0Bf16Fn(torch.autograd.Function):
         h = mha.h
         eps = layer.sublayer[0].norm.eps
         fw = SF._folded(layer)
-        xhat = torch.empty(n, d, dtype=torch.bfloat16, device=x2.device)
-        ops.layernorm_rows(x2, None, None, eps, out=xhat)
+        xhat = SF._take_xhat(layer, x2, eps)                                           # left by the critic pass, if any
+        if xhat is None:
+            xhat = torch.empty(n, d, dtype=torch.bfloat16, device=x2.device)
+            ops.layernorm_rows(x2, None, None, eps, out=xhat)
         qv = ops.linear_bf16(xhat, fw["wqv"], fw["bqv_f"], fw["bqv"])
         q, v = qv[:, :d], qv[:, d:]
         xs, slot, xs16 = ops.gather_slot_map(x2, sel, bf16_copy=True)
@@ -230,7 +232,7 @@ class EncoderLayer0Bf16Fn(torch.autograd.Function):
         db1f = dhid.sum(0, dtype=f32)
         dw1f = _tn_mm(dhid, xhat)                                                    # [F, D] gradient of the FOLDED weight
         # ---- the K selected rows: y[S] = x_sel = xs + o Wo^T + bo; every other row of y is data             (snuffy.py:108,152-155)
-        dyn_s = torch.mm(dhid.index_select(0, sel).float(), w1f.float())             # d loss / d xhat1[S]
+        dyn_s = torch.mm(dhid.index_select(0, sel), w1f, out_dtype=f32)              # d loss / d xhat1[S] (bf16 operands as they are)
         mu = x_sel.mean(1, keepdim=True)
         xc = x_sel - mu
         rstd = torch.rsqrt((xc * xc).mean(1, keepdim=True) + eps)
@@ -264,25 +266,59 @@ class EncoderLayer0Bf16Fn(torch.autograd.Function):
         return (None, None, None, None, dg0, db0, dg1, db1, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dw1, db1f, dw2, db2)
 
 
-def fused_layer0_ok(x2, sel, layer, precision):
-    """Shapes / settings EncoderLayer0Bf16Fn covers; everything else keeps the generic autograd chain below."""
-    if precision != "bf16" or x2.requires_grad or sel.numel() == 0 or not FUSED_BF16_TRAINING:
+def fused_layer0_shape_ok(layer, n, d, k=None):
+    """Settings / shapes EncoderLayer0Bf16Fn covers (k = number of selected rows; default: the layer's Lambda capped by n)."""
+    if not FUSED_BF16_TRAINING:
         return False
     mha, ff = layer.self_attn, layer.feed_forward
     n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
-    if ff.activation_name != "relu" or n0.eps != n1.eps:
+    if ff.activation_name != "relu" or n0.eps != n1.eps or d % mha.h:
         return False
     if layer.training and (layer.sublayer[0].dropout.p > 0 or layer.sublayer[1].dropout.p > 0 or ff.dropout.p > 0):
         return False
-    n, d = x2.shape
-    k, dk = sel.numel(), d // mha.h
-    return (ops.mfma_attn_supported(k, dk, n, 2 * d) and k <= (224 if dk == 128 else 256) and ops.mfma_attn_bwd_supported(k, dk)
-            and all(p.requires_grad for p in layer.parameters()))
+    if k is None:
+        k = min(int(layer.big_lambda), n)
+    dk = d // mha.h
+    return (k >= 1 and ops.mfma_attn_supported(k, dk, n, 2 * d) and k <= (224 if dk == 128 else 256)
+            and ops.mfma_attn_bwd_supported(k, dk) and all(p.requires_grad for p in layer.parameters()))
 
 
-def critic_train(feats2, w, b):
-    """Critic scores with autograd (library GEMV); the selection itself uses them detached."""
-    return F.linear(feats2, w, b)
+def fused_layer0_ok(x2, sel, layer, precision):
+    """The first-layer chain applies: bf16, the bag is data (no gradient flows into x2), supported shape / settings;
+    everything else keeps the generic autograd chain below."""
+    if precision != "bf16" or x2.requires_grad or sel.numel() == 0:
+        return False
+    return fused_layer0_shape_ok(layer, x2.shape[0], x2.shape[1], sel.numel())
+
+
+class CriticFn(torch.autograd.Function):
+    """scores = x w^T + b (FCLayer, snuffy.py:39-41) on the one-pass critic kernel; with `layer` (bf16 training) the same pass
+    leaves the normalised bf16 copy of the bag for the first encoder layer, as in inference.  Backward: dW = dS^T x (the loss
+    reaches the scores through a max over the bag, so dS is one-hot per class, but nothing here relies on that)."""
+
+    @staticmethod
+    def forward(ctx, x2, w, b, layer, eps):
+        if layer is not None:
+            s, xhat = ops.critic_ln(x2, w, b, eps)
+            layer._xhat_offer = (x2.data_ptr(), tuple(x2.shape), x2._version, float(eps), xhat)
+        else:
+            s = ops.critic(x2, w, b)
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = b is not None
+        return s
+
+    @staticmethod
+    def backward(ctx, ds):
+        x2, w = ctx.saved_tensors
+        ds = ds.float()
+        dw = ds.t() @ x2
+        dx = ds @ w if ctx.needs_input_grad[0] else None
+        return dx, dw, (ds.sum(0) if ctx.has_bias else None), None, None
+
+
+def critic_train(feats2, w, b, layer=None, eps=1e-5):
+    """Critic scores with autograd; the selection itself uses them detached."""
+    return CriticFn.apply(feats2, w, b, layer, eps)
 
 
 def encoder_layer_train(x2, sel, layer, need_attn, precision):

@@ -381,4 +381,14 @@ class MILNet(nn.Module):
             lin = ic.fc[0]
             eps = self.b_classifier.encoder.layers[0].sublayer[0].norm.eps
             return x, SF.critic_scores_with_xhat(x, lin.weight, lin.bias, eps, self.b_classifier.encoder.layers[0])
+        if (type(ic) is FCLayer and cfg is not None and cfg.precision == "bf16" and torch.is_grad_enabled()
+                and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 3 and x.shape[0] == 1 and not x.requires_grad
+                and x.dtype == torch.float32 and x.is_contiguous() and len(self.b_classifier.encoder.layers) > 0):
+            # bf16 training: same one-pass critic, with autograd (the fused first-layer chain consumes the normalised copy)
+            from . import autograd as SA
+            lin = ic.fc[0]
+            layer0 = self.b_classifier.encoder.layers[0]
+            if SA.fused_layer0_shape_ok(layer0, x.shape[1], x.shape[2]):
+                s = SA.critic_train(x[0], lin.weight, lin.bias, layer0, layer0.sublayer[0].norm.eps)
+                return x, s.view(1, x.shape[1], -1)
         return ic(x)
