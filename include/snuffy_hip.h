@@ -121,6 +121,15 @@ int snf_layernorm_bwd_blocks(int64_t n);
 int snf_layernorm_rows_bwd_f32(const float* x, int64_t n, int d, const void* dy, int dy_dtype, int64_t dy_stride,
                                const float* gamma, float eps, const float* residual, float* dx, void* dx_bf16,
                                float* partials, snf_stream_t stream);
+/* Column sums of a [n, d] matrix fused with the elementwise step of the same pass (training: bias gradients next to the ReLU
+ * mask / the bf16 cast / the critic's weight gradient; backward of snuffy.py:39-41, 224-225):
+ *   v = src[i, c] (f32 or bf16) * row_weight[i * weight_stride] (nullable) ; v = 0 where gate_bf16[i, c] <= 0 (nullable: the ReLU
+ *   mask from the activation output) ; dst_bf16[i, c] = bf16(v) (nullable, may alias src) ; partial[b, c] = sum over the rows
+ *   of workgroup b (of the rounded values when dst is given).  partial [snf_colsum_blocks(n), d] f32, summed by the caller.
+ *   d % 8 == 0, d <= 8192, 16-byte aligned buffers. */
+int snf_colsum_blocks(int64_t n);
+int snf_colsum_fused(const void* src, int src_dtype, int64_t n, int d, const float* row_weight, int64_t weight_stride,
+                     const void* gate_bf16, void* dst_bf16, float* partial, snf_stream_t stream);
 int snf_layernorm_rows_split3_f32(const float* x, int64_t n, int d, const int32_t* slot_map, const float* patch_rows,
                                   const float* gamma, const float* beta, float eps, void* out_bf16, snf_stream_t stream);
 

@@ -223,13 +223,12 @@ class EncoderLayer0Bf16Fn(torch.autograd.Function):
         n, d = xhat.shape
         h, eps = ctx.h, ctx.eps
         f32 = torch.float32
-        dz = dz.float()
-        dz16 = dz.to(torch.bfloat16)
+        dz = dz.float().contiguous()
         # ---- FFN: z = y + act(xhat1 W1'^T + b1') W2^T + b2                                                (snuffy.py:224-225)
-        db2 = dz.sum(0)
+        db2, dz16 = ops.colsum_fused(dz, want_bf16=True)                              # bias gradient + the GEMM operand, one pass
         dw2 = _tn_mm(dz16, hid)                                                      # [D, F]
-        dhid = torch.ops.aten.threshold_backward(torch.mm(dz16, w2f), hid, 0)        # [N, F] bf16, ReLU mask from the output
-        db1f = dhid.sum(0, dtype=f32)
+        dhid = torch.mm(dz16, w2f)                                                   # [N, F] bf16
+        db1f, _ = ops.colsum_fused(dhid, gate=hid, inplace=True)                     # ReLU mask from the output + bias gradient
         dw1f = _tn_mm(dhid, xhat)                                                    # [F, D] gradient of the FOLDED weight
         # ---- the K selected rows: y[S] = x_sel = xs + o Wo^T + bo; every other row of y is data             (snuffy.py:108,152-155)
         dyn_s = torch.mm(dhid.index_select(0, sel), w1f, out_dtype=f32)              # d loss / d xhat1[S] (bf16 operands as they are)
@@ -250,7 +249,7 @@ class EncoderLayer0Bf16Fn(torch.autograd.Function):
         xhat.index_copy_(0, sel, xhat0_sel)                                           # back to LayerNorm 0's rows
         dwqvf = _tn_mm(dqv, xhat)                                                     # [2D, D] folded
         xhat.index_copy_(0, sel, xhat1_sel)                                           # (a second backward sees the same state)
-        dbqvf = dqv.sum(0, dtype=f32)
+        dbqvf, _ = ops.colsum_fused(dqv)
         dwk = dkp.t() @ xs
         dbk = dkp.sum(0)
         # ---- unfold  W' = W * gamma,  b' = W beta + b
@@ -311,7 +310,10 @@ class CriticFn(torch.autograd.Function):
     def backward(ctx, ds):
         x2, w = ctx.saved_tensors
         ds = ds.float()
-        dw = ds.t() @ x2
+        if ds.shape[1] <= 4 and x2.shape[1] % 8 == 0 and x2.shape[1] <= 8192:
+            dw = torch.stack([ops.colsum_fused(x2, row_weight=ds[:, c])[0] for c in range(ds.shape[1])])   # one pass per class
+        else:
+            dw = ds.t() @ x2
         dx = ds @ w if ctx.needs_input_grad[0] else None
         return dx, dw, (ds.sum(0) if ctx.has_bias else None), None, None
 

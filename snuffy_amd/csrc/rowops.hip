@@ -376,6 +376,91 @@ __global__ __launch_bounds__(WG) void ln_bwd_rows_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Column sums of a [n, d] matrix fused with the elementwise work that the training step does on the same pass:
+//   v = src[i, c]  (f32 or bf16)  ->  * wgt[i] (optional row weight)  ->  0 where gate[i, c] <= 0 (optional, bf16: the ReLU
+//   mask taken from the activation's OUTPUT)  ->  dst[i, c] = bf16(v) (optional, may alias src)  ;  partial[b, c] += v
+// Replaces  threshold_backward + sum(0),  to(bfloat16) + sum(0)  and the [1, n] x [n, d] GEMM of the critic's weight gradient
+// (train.py:259 backward through snuffy.py:39-41, 224-225).  A workgroup owns a contiguous row range; thread t owns columns
+// 8 t .. 8 t + 7 (+ 2048 j), so its sums need no reduction inside the workgroup; partial [gridDim.x, d] is summed by the caller
+// in a fixed order.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool SRC_BF16, int NCH>
+__global__ __launch_bounds__(256) void colsum_fused_kernel(const void* __restrict__ src, int64_t n, int d,
+                                                           const float* __restrict__ wgt, int64_t wgt_stride,
+                                                           const unsigned short* __restrict__ gate,
+                                                           unsigned short* __restrict__ dst, float* __restrict__ partial,
+                                                           int rows_per_block) {
+    float acc[NCH][8];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > n) r1 = n;
+    for (int64_t row = r0; row < r1; ++row) {
+        const float wv = wgt ? wgt[row * wgt_stride] : 1.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = (j * 256 + threadIdx.x) * 8;
+            if (c < d) {
+                float v[8];
+                if constexpr (SRC_BF16) {
+                    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(src) + row * d + c);
+                    const unsigned w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] = __uint_as_float(w4[e] << 16);
+                        v[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+                    }
+                } else {
+                    const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + row * d + c);
+                    const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + row * d + c + 4);
+                    v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+                }
+                if (wgt) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= wv;
+                }
+                if (gate) {
+                    const uint4 g = *reinterpret_cast<const uint4*>(gate + row * d + c);
+                    const unsigned g4[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (!(__uint_as_float(g4[e] << 16) > 0.f)) v[2 * e] = 0.f;
+                        if (!(__uint_as_float(g4[e] & 0xffff0000u) > 0.f)) v[2 * e + 1] = 0.f;
+                    }
+                }
+                if (dst) {
+                    uint4 o;
+                    o.x = pack_bf16x2(v[0], v[1]), o.y = pack_bf16x2(v[2], v[3]);
+                    o.z = pack_bf16x2(v[4], v[5]), o.w = pack_bf16x2(v[6], v[7]);
+                    *reinterpret_cast<uint4*>(dst + row * d + c) = o;
+                    // the sums are taken over the ROUNDED values that the following GEMMs consume
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned w = e == 0 ? o.x : e == 1 ? o.y : e == 2 ? o.z : o.w;
+                        v[2 * e] = __uint_as_float(w << 16);
+                        v[2 * e + 1] = __uint_as_float(w & 0xffff0000u);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[j][e] += v[e];
+            }
+        }
+    }
+    float* out = partial + (int64_t)blockIdx.x * d;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = (j * 256 + threadIdx.x) * 8;
+        if (c < d) {
+            *reinterpret_cast<float4*>(out + c) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+            *reinterpret_cast<float4*>(out + c + 4) = make_float4(acc[j][4], acc[j][5], acc[j][6], acc[j][7]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // gather / scatter of the K selected rows
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void gather_rows_kernel(const float* __restrict__ x, int64_t n, int d,
@@ -886,6 +971,47 @@ int snf_layernorm_rows_bwd_f32(const float* x, int64_t n, int d, const void* dy,
                                               dy_dtype == SNF_DT_BF16 ? 1 : 0, dy_stride, gamma, eps, residual, dx,
                                               reinterpret_cast<unsigned short*>(dx_bf16), partials));
     return snf::check_launch("ln_bwd_rows_kernel");
+}
+
+int snf_colsum_blocks(int64_t n) {
+    int64_t b = (n + 31) / 32;
+    const int64_t cap = (int64_t)snf::cu_count() * 4;
+    if (b > cap) b = cap;
+    return (int)(b < 1 ? 1 : b);
+}
+
+int snf_colsum_fused(const void* src, int src_dtype, int64_t n, int d, const float* row_weight, int64_t weight_stride,
+                     const void* gate_bf16, void* dst_bf16, float* partial, snf_stream_t stream) {
+    SNF_REQUIRE(src && partial, "snf_colsum_fused: null pointer");
+    SNF_REQUIRE(n >= 1 && d >= 8 && d % 8 == 0 && d <= 8192, "snf_colsum_fused: bad shape n=%lld d=%d (d %% 8 == 0, d <= 8192)",
+                (long long)n, d);
+    SNF_REQUIRE(src_dtype == SNF_DT_F32 || src_dtype == SNF_DT_BF16, "snf_colsum_fused: bad dtype %d", src_dtype);
+    SNF_REQUIRE(aligned16(src) && aligned16(partial) && (!gate_bf16 || aligned16(gate_bf16)) && (!dst_bf16 || aligned16(dst_bf16)),
+                "snf_colsum_fused: buffers must be 16-byte aligned");
+    const int blocks = snf_colsum_blocks(n);
+    const int rpb = (int)((n + blocks - 1) / blocks);
+    const int nch = (d + 2047) / 2048;
+    hipStream_t s = snf::as_stream(stream);
+    const unsigned short* g = reinterpret_cast<const unsigned short*>(gate_bf16);
+    unsigned short* o = reinterpret_cast<unsigned short*>(dst_bf16);
+#define SNF_COLSUM(BF, NC) \
+    hipLaunchKernelGGL((colsum_fused_kernel<BF, NC>), dim3(blocks), dim3(256), 0, s, src, n, d, row_weight, weight_stride, g, o, \
+                       partial, rpb)
+    if (src_dtype == SNF_DT_BF16) {
+        switch (nch) {
+            case 1: SNF_COLSUM(true, 1); break;
+            case 2: SNF_COLSUM(true, 2); break;
+            default: SNF_COLSUM(true, 4); break;
+        }
+    } else {
+        switch (nch) {
+            case 1: SNF_COLSUM(false, 1); break;
+            case 2: SNF_COLSUM(false, 2); break;
+            default: SNF_COLSUM(false, 4); break;
+        }
+    }
+#undef SNF_COLSUM
+    return snf::check_launch("colsum_fused_kernel");
 }
 
 int snf_gather_rows_f32(const float* x, int64_t n, int d, const int64_t* idx, int k, float* out, snf_stream_t stream) {

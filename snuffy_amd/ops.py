@@ -249,6 +249,39 @@ def layernorm_rows_bwd(x, dy, gamma=None, eps=1e-5, residual=None, want_dx=True,
     return dx, dxb, sums[0], sums[1]
 
 
+def colsum_fused(src, row_weight=None, gate=None, want_bf16=False, inplace=False):
+    """Column sums of src [n, d] (f32 or bf16) fused with an optional row weight [n] (f32, any stride), an optional ReLU gate
+    (bf16 [n, d]: elements whose gate is <= 0 are zeroed) and an optional bf16 copy of the result (inplace: written over a
+    bf16 src).  Returns (colsum [d] f32, bf16 copy or None).  See snf_colsum_fused."""
+    if src.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("colsum_fused: src must be float32 or bfloat16")
+    src = _req(src, src.dtype, "src", 2)
+    n, d = src.shape
+    if d % 8 or d > 8192:
+        raise ValueError("colsum_fused: d=%d must be a multiple of 8 and <= 8192" % d)
+    ws = 0
+    if row_weight is not None:
+        if row_weight.dtype != torch.float32 or not row_weight.is_cuda or row_weight.dim() != 1 or row_weight.shape[0] != n:
+            raise ValueError("colsum_fused: row_weight must be a 1-D float32 GPU tensor of %d values (any stride)" % n)
+        ws = row_weight.stride(0)
+    if gate is not None:
+        gate = _req(gate, torch.bfloat16, "gate", 2)
+        if gate.shape != src.shape:
+            raise ValueError("colsum_fused: gate shape %s does not match src %s" % (tuple(gate.shape), tuple(src.shape)))
+    dst = None
+    if inplace:
+        if src.dtype != torch.bfloat16:
+            raise TypeError("colsum_fused: inplace needs a bfloat16 src")
+        dst = src
+    elif want_bf16:
+        dst = torch.empty(n, d, dtype=torch.bfloat16, device=src.device)
+    lib = _ffi.load()
+    part = torch.empty(lib.snf_colsum_blocks(n), d, dtype=torch.float32, device=src.device)
+    check(lib.snf_colsum_fused(_p(src), DT_F32 if src.dtype == torch.float32 else DT_BF16, n, d, _p(row_weight), ws, _p(gate),
+                               _p(dst), _p(part), _stream()), "snf_colsum_fused")
+    return part.sum(0), dst
+
+
 def bias_act_(h, bias, act):
     """h = act(h + bias) in place (snuffy.py:224-225)."""
     if not h.is_cuda or not h.is_contiguous() or h.dim() != 2:

@@ -275,3 +275,30 @@ def test_fused_bf16_layer0_training_matches_generic_and_fp32(n, d, h, lam, monke
                 b = grads[other][k].double()
                 rel = float((a - b).norm() / b.norm().clamp_min(1e-12))
                 assert rel < bound, (train_mode, k, other, rel)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d", [(1000, 768), (4097, 3072), (33, 8), (700, 1536), (5000, 4096)])
+def test_colsum_fused_kernel(n, d):
+    """snf_colsum_fused: plain / weighted / gated column sums, the bf16 copy, the in-place form (vs torch in fp64)."""
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(n + d)
+    x = torch.randn(n, d, generator=g).to(DEV)
+    w2 = torch.randn(n, 2, generator=g).to(DEV)
+    gate = torch.randn(n, d, generator=g).to(DEV).to(torch.bfloat16)
+    gate[0, :8] = 0.0                                                  # a zero gate closes (ReLU' at 0 is 0, as threshold_backward)
+    tol = lambda ref: 2e-5 * max(1.0, ref.abs().max().item()) * (n ** 0.5)
+    s, c = ops.colsum_fused(x)
+    assert c is None and (s.double() - x.double().sum(0)).abs().max().item() <= tol(x.double().sum(0))
+    s, c = ops.colsum_fused(x, want_bf16=True)
+    assert torch.equal(c, x.to(torch.bfloat16)) and (s.double() - c.double().sum(0)).abs().max().item() <= tol(c.double().sum(0))
+    s, _ = ops.colsum_fused(x, row_weight=w2[:, 1])                    # strided weight column
+    ref = (x.double() * w2[:, 1:2].double()).sum(0)
+    assert (s.double() - ref).abs().max().item() <= tol(ref)
+    xb = x.to(torch.bfloat16)
+    want = torch.ops.aten.threshold_backward(xb, gate, 0)
+    s, c = ops.colsum_fused(xb.clone(), gate=gate, want_bf16=True)
+    assert torch.equal(c, want) and (s.double() - want.double().sum(0)).abs().max().item() <= tol(want.double().sum(0))
+    y = xb.clone()
+    s2, c2 = ops.colsum_fused(y, gate=gate, inplace=True)
+    assert c2 is y and torch.equal(y, want) and torch.equal(s2, s)
