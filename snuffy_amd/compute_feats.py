@@ -206,8 +206,20 @@ def compute_feats(args, bags_list, embedder, save_path, patch_labels_dict=None):
             for batch in loader:
                 if on_device:   # uint8 tiles up, one kernel: Resize(224) + / 255 (+ ImageNet normalisation)
                     from .tiles import preprocess_tiles
-                    x = preprocess_tiles(batch['input'].to(device, non_blocking=True), 224,
-                                         normalize=(getattr(args, 'transform', 0) == 1))
+                    u8 = batch['input'].to(device, non_blocking=True)
+                    norm = getattr(args, 'transform', 0) == 1
+                    fe = getattr(embedder, 'feature_extractor', None)
+                    if (getattr(fe, 'precision', None) == 'bf16' and hasattr(fe, 'forward_cols')
+                            and min(u8.shape[1], u8.shape[2]) >= 224 and u8.shape[1] == u8.shape[2]):
+                        # bf16 extractor: the kernel writes the patch-embedding GEMM operand directly (no fp32 image, no patchify)
+                        cols = preprocess_tiles(u8, 224, normalize=norm, want="cols", patch=fe.patch_embed.patch_size)
+                        feats_b = fe.forward_cols(cols, u8.shape[0], 224, 224)
+                        f = feats_b.view(feats_b.shape[0], -1)
+                        feats.append(f)
+                        labels.extend(np.atleast_1d(batch['label'].squeeze().tolist()).tolist())
+                        positions.extend(batch['position'])
+                        continue
+                    x = preprocess_tiles(u8, 224, normalize=norm)
                 else:
                     x = batch['input'].float().to(device, non_blocking=True)
                 f, _ = embedder(x)

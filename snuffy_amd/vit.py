@@ -290,9 +290,18 @@ class VisionTransformer(nn.Module):
         if not x.is_cuda:
             raise SnuffyHipError("input must be a GPU tensor: snuffy_amd has no CPU fallback")
         B, nc, w_, h_ = x.shape
-        W = self._weights_bf16()
         ps = self.patch_embed.patch_size
         cols = ops.vit_patchify(x.float().contiguous(), ps, torch.bfloat16)
+        return self.forward_cols(cols, B, w_, h_)
+
+    @torch.no_grad()
+    def forward_cols(self, cols, B, w_, h_):
+        """bf16 path from the patch-embedding GEMM operand: cols [B * P, 3 * patch * patch] bf16 (im2col rows of B images of
+        w_ x h_ pixels), as snuffy_amd.tiles.preprocess_tiles(want="cols") writes them straight from the uint8 tiles -- the
+        fp32 image tensor and the patchify pass never exist."""
+        if not (cols.is_cuda and cols.dtype == torch.bfloat16 and cols.dim() == 2):
+            raise SnuffyHipError("forward_cols: need the bf16 im2col matrix on the GPU (no CPU fallback)")
+        W = self._weights_bf16()
         # patch embedding = im2col rows x conv weight on the hand-written MFMA kernel                 [B*P, D] bf16
         pe = ops.linear_bf16(cols, W["pe_w"], W["pe_bf"], W["pe_b"], prefer_native=True)
         P = pe.shape[0] // B

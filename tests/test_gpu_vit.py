@@ -257,3 +257,45 @@ def test_compute_feats_device_preprocess_equals_pil_path(tmp_path):
         cf.compute_feats(args, [str(bag_dir)], embedder, str(tmp_path / f"out{mode}"))
         outs[mode] = pd.read_csv(tmp_path / f"out{mode}" / "single" / "normal" / "slide_007.csv").to_numpy()
     assert outs[1].shape == (6, 192) and np.array_equal(outs[0], outs[1])
+
+
+def test_compute_feats_bf16_takes_patch_columns_straight_from_the_tile_kernel(tmp_path):
+    """bf16 extractor + on-device preprocessing: the tile kernel writes the patch-embedding GEMM operand (im2col rows, bf16)
+    and the ViT starts from it (VisionTransformer.forward_cols) -- same CSV as the PIL path through patchify."""
+    import argparse
+
+    import pandas as pd
+    from PIL import Image
+
+    from snuffy_amd import compute_feats as cf
+    from snuffy_amd import vit
+    rng = np.random.RandomState(2)
+    bag_dir = tmp_path / "single" / "tumor" / "slide_011"
+    bag_dir.mkdir(parents=True)
+    for r in range(2):
+        for c in range(2):
+            Image.fromarray(rng.randint(0, 255, (256, 256, 3), dtype=np.uint8)).save(bag_dir / f"{r}_{c}.jpeg", quality=90)
+    calls = {"cols": 0}
+    orig = vit.VisionTransformer.forward_cols
+
+    def counting(self, *a, **kw):
+        calls["cols"] += 1
+        return orig(self, *a, **kw)
+    vit.VisionTransformer.forward_cols = counting
+    try:
+        outs = {}
+        for mode in (1, 0):
+            args = argparse.Namespace(backbone="vit_tiny", embedder="DINO_adapter", patch_size=16, adapter_ffn_scalar="10",
+                                      ffn_num=8, num_classes=1, batch_size=4, num_workers=0, transform=1, dataset="tcga",
+                                      weights=None, precision="bf16", device_preprocess=mode)
+            torch.manual_seed(0)
+            backbone, nf = cf.get_embedder_backbone(args)
+            embedder, _ = cf.get_embedder(args, backbone, nf)
+            before = calls["cols"]
+            cf.compute_feats(args, [str(bag_dir)], embedder, str(tmp_path / f"out{mode}"))
+            if mode == 1:
+                assert calls["cols"] == before + 1                 # one batch of 4 tiles went in as columns
+            outs[mode] = pd.read_csv(tmp_path / f"out{mode}" / "single" / "tumor" / "slide_011.csv").to_numpy()
+    finally:
+        vit.VisionTransformer.forward_cols = orig
+    assert outs[1].shape == (4, 192) and np.array_equal(outs[0], outs[1])
