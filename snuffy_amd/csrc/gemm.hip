@@ -399,10 +399,12 @@ extern "C" int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t 
         return SNF_EUNSUPPORTED;
     }
     if (tile_n != 128 && tile_n != 256) {
-        // 256-wide tiles when they fill the chip evenly (whole rounds of workgroups, or many rounds); else 128-wide
+        // 256-wide tiles once they give most of the chip a tile (>= 0.7 tiles per CU, partial column tiles counted); below
+        // that 128-wide tiles spread the work over more CUs.  Measured on the config-A / config-B / ViT shapes
+        // (profiles/r02_gemm_bench.txt): the rule picks the faster width on all of them but ViT fc2 (5 % off).
         const int64_t t256 = ((m + BM - 1) / BM) * ((n + 255) / 256);
         const int cus = snf::cu_count();
-        tile_n = (n % 256 == 0 && (t256 % cus == 0 || t256 >= 3 * (int64_t)cus)) ? 256 : 128;
+        tile_n = (n > 128 && t256 * 10 >= (int64_t)cus * 7) ? 256 : 128;
     }
     GemmParams P;
     P.a = reinterpret_cast<const unsigned short*>(a);
