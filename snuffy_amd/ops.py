@@ -394,8 +394,16 @@ def sparse_attn_bwd_mfma(q, v, kp, dout, lse, h, mask=None, scale=None, dropout=
                                           float(scale), _p(dq), _p(dv), ldd, gdt, _p(ds), DT_BF16 if bf16 else DT_F32, _stream()),
           "snf_sparse_attn_bwd_mfma")
     if bf16:
-        qh = q.view(n, h, dk).transpose(0, 1)                       # [h, n, dk] (strided view)
-        dkp = torch.bmm(ds.transpose(1, 2), qh).float().transpose(0, 1).reshape(k, d)
+        # dKp = dS^T Q per head: a [k, dk] output over a contraction of n rows -- split over 16 row chunks (one batched GEMM,
+        # partials summed in fp32) so that the library has 16 h tiles to spread instead of h (121 -> 85 us at config B)
+        c = 16
+        if n >= 8192 and n % c == 0:
+            dsv = ds.view(h, c, n // c, k).transpose(2, 3)                          # [h, c, k, n/c]
+            qh = q.reshape(n, h, dk).view(c, n // c, h, dk).permute(2, 0, 1, 3)     # [h, c, n/c, dk]
+            dkp = torch.matmul(dsv, qh).sum(1, dtype=torch.float32).transpose(0, 1).reshape(k, d)
+        else:
+            qh = q.view(n, h, dk).transpose(0, 1)                   # [h, n, dk] (strided view)
+            dkp = torch.bmm(ds.transpose(1, 2), qh).float().transpose(0, 1).reshape(k, d)
         return dq, dkp, dv
     dkp = torch.empty(k, d, dtype=torch.float32, device=q.device)
     wsb = lib.snf_sparse_attn_bwd_workspace_bytes(n, k, h, dk)

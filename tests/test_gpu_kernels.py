@@ -421,7 +421,8 @@ def test_sparse_attn_bwd_matches_autograd_reference(n, k, h, dk, drop):
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("dk", [128, 64])
 @pytest.mark.parametrize("n,k,h,drop", [(1, 1, 1, 0.0), (100, 31, 2, 0.0), (129, 33, 3, 0.0), (1000, 64, 6, 0.0),
-                                        (2500, 200, 6, 0.0), (3000, 224, 2, 0.0), (640, 129, 4, 0.25), (4099, 100, 1, 0.0)])
+                                        (2500, 200, 6, 0.0), (3000, 224, 2, 0.0), (640, 129, 4, 0.25), (4099, 100, 1, 0.0),
+                                        (8192, 200, 2, 0.1)])     # the last one: dKp through the row-chunked batched GEMM
 def test_sparse_attn_bwd_mfma(n, k, h, drop, dt, dk):
     """MFMA backward (dk = 128) against fp64 autograd on the SAME bf16-rounded operands (layout slips show as O(1) errors)
     and against the exact operands at bf16-class tolerance."""
