@@ -181,7 +181,12 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 //   pooling wave:  V(f) loads B(f-1) GEMM2(f-1) out of the P / V images      A(f)  write V(f)
 // B sits AFTER GEMM1 on purpose: the matrix pipe of the SIMD then runs GEMM1 and GEMM2 one after the other instead of
 // both at half speed, and GEMM2 overlaps the VALU-only softmax.
-template <int DK, int NKB, typename QT, bool AUX, bool EXT>
+// TAILP: register pairs of the LAST key block that can hold a real key (8 = all).  K = 200 (the reference's default Lambda)
+// fills 8 keys of its 7th block -- pairs 0, 1 of every lane; with TAILP = 2 the softmax passes skip the other six pairs
+// (12 of the lane's 112 score registers: they hold -inf, would give exp = 0, and their P columns feed output rows that are
+// never stored), i.e. ~11 % of the softmax wave's VALU work, decided at compile time (the run-time form of the same skip
+// measured slower in round 1: its wave-uniform branches cost more than they saved).
+template <int DK, int NKB, typename QT, bool AUX, bool EXT, int TAILP = 8>
 __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
     constexpr int NKS = DK / 16;             // k-steps of GEMM1
     constexpr int NCB = DK / 32;             // 32-wide column blocks of the output
@@ -401,7 +406,8 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
                 static_for<4, 8 * NKB>([&](auto st_t) __attribute__((always_inline)) {
                     constexpr int st = decltype(st_t)::value;
                     constexpr int jb = st / 8, r = 2 * (st % 8);
-                    mx[st % 4] = fmaxf(fmaxf(mx[st % 4], s_acc[jb][r]), s_acc[jb][r + 1]);
+                    if constexpr (!(jb == NKB - 1 && (st % 8) >= TAILP))
+                        mx[st % 4] = fmaxf(fmaxf(mx[st % 4], s_acc[jb][r]), s_acc[jb][r + 1]);
                 });
                 mc = xhalf_max(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]))) * c_exp;
             }
@@ -411,15 +417,16 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
                 // software pipeline: the exponent of pair e + 2 is computed before the exps of pair e issue, and the running
                 // sum takes pair e - 1 -- no instruction sits right behind the one that feeds it
                 constexpr int AHEAD = 2;
+                constexpr int NE = 8 * (NKB - 1) + TAILP;        // register pairs that can hold a real key
                 f32x2 ar[AHEAD + 1];
                 static_for<0, AHEAD>([&](auto e_t) __attribute__((always_inline)) {
                     constexpr int e = decltype(e_t)::value;
                     ar[e] = __builtin_elementwise_fma(f32x2{s_acc[e / 8][2 * (e % 8)], s_acc[e / 8][2 * (e % 8) + 1]}, c2, nm2);
                 });
-                static_for<0, 8 * NKB>([&](auto e_t) __attribute__((always_inline)) {
+                static_for<0, NE>([&](auto e_t) __attribute__((always_inline)) {
                     constexpr int e = decltype(e_t)::value;
                     constexpr int jb = e / 8, pr = e % 8;
-                    if constexpr (e + AHEAD < 8 * NKB) {
+                    if constexpr (e + AHEAD < NE) {
                         constexpr int en = e + AHEAD;
                         ar[en % (AHEAD + 1)] = __builtin_elementwise_fma(
                             f32x2{s_acc[en / 8][2 * (en % 8)], s_acc[en / 8][2 * (en % 8) + 1]}, c2, nm2);
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
                     s_acc[jb][2 * pr + 1] = __builtin_amdgcn_exp2f(ar[e % (AHEAD + 1)][1]);
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                l2 += f32x2{s_acc[NKB - 1][14], s_acc[NKB - 1][15]};
+                l2 += f32x2{s_acc[(NE - 1) / 8][2 * ((NE - 1) % 8)], s_acc[(NE - 1) / 8][2 * ((NE - 1) % 8) + 1]};
                 if constexpr (!EXT) lrow = xhalf_sum(l2[0] + l2[1]);
             }
             const float inv = rvalid ? __builtin_amdgcn_rcpf(lrow) : 0.f;
@@ -458,6 +465,7 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
                 constexpr int jb = decltype(jb_t)::value;
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4) {
+                    if (jb == NKB - 1 && 2 * c4 >= TAILP) continue;   // padding-only columns: nothing to publish
                     f32x2 p01 = f32x2{s_acc[jb][4 * c4], s_acc[jb][4 * c4 + 1]} * inv2;
                     f32x2 p23 = f32x2{s_acc[jb][4 * c4 + 2], s_acc[jb][4 * c4 + 3]} * inv2;
                     if constexpr (AUX) {
@@ -826,12 +834,12 @@ inline bool make_plan(int64_t n, int k, int h, int dk, Plan* pl) {
     return true;
 }
 
-template <int DK, int NKB, typename QT, bool AUX, bool EXT = false>
+template <int DK, int NKB, typename QT, bool AUX, bool EXT = false, int TAILP = 8>
 int launch_variant(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
     constexpr int NKS = DK / 16;
     const size_t lds = (size_t)(NKB * NKS) * 1024 + (size_t)TILE_ROWS * (p_row_bytes(NKB) + 2 * DK);
     static thread_local bool attr_set = false;
-    auto kern = sparse_attn_mfma_kernel<DK, NKB, QT, AUX, EXT>;
+    auto kern = sparse_attn_mfma_kernel<DK, NKB, QT, AUX, EXT, TAILP>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
@@ -875,6 +883,9 @@ int launch_nkb(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
         snf::set_error("sparse_attn_mfma: chunked key-block count %d not built", pl.nkb);
         return SNF_EUNSUPPORTED;
     }
+    // the inference shape of the reference's default (Lambda = 200: 8 keys in the 7th block), bf16 operands, no A / lse output
+    if (pl.nkb == 7 && P.k > 192 && P.k <= 200 && !aux && std::is_same<QT, unsigned short>::value)
+        return launch_variant<DK, 7, QT, false, false, 2>(P, pl, out, s);
     switch (pl.nkb) {
 #ifndef SNF_ATTN_DEV   // development builds instantiate the config-B shape only (the file takes minutes otherwise)
         SNF_ATTN_CASE(1, false)
