@@ -219,7 +219,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SNF_BENCH_FORCE_DIST"):     # the env switch exercises the RCCL code path on one rank (tests)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # "nccl" == RCCL on ROCm
