@@ -121,6 +121,9 @@ int snf_layernorm_bwd_blocks(int64_t n);
 int snf_layernorm_rows_bwd_f32(const float* x, int64_t n, int d, const void* dy, int dy_dtype, int64_t dy_stride,
                                const float* gamma, float eps, const float* residual, float* dx, void* dx_bf16,
                                float* partials, snf_stream_t stream);
+/* x [m, k] f32 (row pitch ldx) -> out [m, 3 k] bf16 = [hi | hi | lo]: the activation image of an fp32-class projection whose
+ * producer is not one of the kernels that can emit it directly (ViT fp32 path: patch columns, attention output). */
+int snf_split3_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16, snf_stream_t stream);
 /* Column sums of a [n, d] matrix fused with the elementwise step of the same pass (training: bias gradients next to the ReLU
  * mask / the bf16 cast / the critic's weight gradient; backward of snuffy.py:39-41, 224-225):
  *   v = src[i, c] (f32 or bf16) * row_weight[i * weight_stride] (nullable) ; v = 0 where gate_bf16[i, c] <= 0 (nullable: the ReLU

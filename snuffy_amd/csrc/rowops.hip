@@ -460,6 +460,31 @@ __global__ __launch_bounds__(256) void colsum_fused_kernel(const void* __restric
     }
 }
 
+// x [m, k] f32 (row pitch ldx) -> out [m, 3 k] bf16 = [hi | hi | lo]: the A operand of an fp32-class (split-bf16 x3) GEMM.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int64_t ldx, int64_t m, int k,
+                                                     unsigned short* __restrict__ out) {
+    const int kq = k >> 3;                                   // 8-element groups per row
+    const int64_t total = m * kq;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / kq;
+        const int c = (int)(i - row * kq) * 8;
+        const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c);
+        const float4 b = *reinterpret_cast<const float4*>(x + row * ldx + c + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            lo[e] = pack_bf16x2(v[2 * e] - __uint_as_float(hi[e] << 16), v[2 * e + 1] - __uint_as_float(hi[e] & 0xffff0000u));
+        }
+        unsigned short* o = out + row * 3 * k + c;
+        const uint4 h4 = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(o) = h4;
+        *reinterpret_cast<uint4*>(o + k) = h4;
+        *reinterpret_cast<uint4*>(o + 2 * k) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // gather / scatter of the K selected rows
 // ---------------------------------------------------------------------------------------------------------------
@@ -1012,6 +1037,20 @@ int snf_colsum_fused(const void* src, int src_dtype, int64_t n, int d, const flo
     }
 #undef SNF_COLSUM
     return snf::check_launch("colsum_fused_kernel");
+}
+
+int snf_split3_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16, snf_stream_t stream) {
+    SNF_REQUIRE(x && out_bf16, "snf_split3_f32: null pointer");
+    SNF_REQUIRE(m >= 1 && k >= 8 && k % 8 == 0 && ldx >= k && ldx % 4 == 0, "snf_split3_f32: bad shape m=%lld k=%d ldx=%lld",
+                (long long)m, k, (long long)ldx);
+    SNF_REQUIRE(aligned16(x) && aligned16(out_bf16), "snf_split3_f32: buffers must be 16-byte aligned");
+    const int64_t total = m * (k >> 3);
+    int64_t blocks = (total + 255) / 256;
+    const int64_t cap = (int64_t)snf::cu_count() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(split3_kernel, dim3((int)blocks), dim3(256), 0, snf::as_stream(stream), x, ldx, m, k,
+                       reinterpret_cast<unsigned short*>(out_bf16));
+    return snf::check_launch("split3_kernel");
 }
 
 int snf_gather_rows_f32(const float* x, int64_t n, int d, const int64_t* idx, int k, float* out, snf_stream_t stream) {

@@ -626,10 +626,18 @@ def split3_weight(w):
 
 
 def split3_rows(x):
-    """x [m, k] f32 -> [m, 3 k] bf16 = [hi | hi | lo] with torch ops (small operands: the K selected rows)."""
-    hi = x.to(torch.bfloat16)
-    lo = (x - hi.float()).to(torch.bfloat16)
-    return torch.cat([hi, hi, lo], dim=1).contiguous()
+    """x [m, k] f32 (row-strided views allowed) -> [m, 3 k] bf16 = [hi | hi | lo] (snf_split3_f32)."""
+    if x.dtype != torch.float32:
+        raise TypeError("split3_rows: x must be float32")
+    x = _rows16(x, "x")
+    m, k = x.shape
+    if k % 8:
+        hi = x.to(torch.bfloat16)
+        lo = (x - hi.float()).to(torch.bfloat16)
+        return torch.cat([hi, hi, lo], dim=1).contiguous()
+    out = torch.empty(m, 3 * k, dtype=torch.bfloat16, device=x.device)
+    check(_ffi.load().snf_split3_f32(_p(x), x.stride(0), m, k, _p(out), _stream()), "snf_split3_f32")
+    return out
 
 
 def gemm_x3_supported(m, n, k):
