@@ -295,6 +295,7 @@ class MILNet(nn.Module):
         through ``p.data`` (they do not bump the version counter) -- call ``invalidate()`` after those."""
         plist = list(self.parameters())
         knobs = tuple((l.big_lambda, l.random_patch_share) for l in self.b_classifier.encoder.layers)
+        knobs += (SF.FP32_GEMM, SF.FP32_ATTENTION)      # module-level arithmetic switches are baked into a capture as well
         return tuple((id(p), p.data_ptr(), p._version) for p in plist), knobs
 
     def invalidate(self):
