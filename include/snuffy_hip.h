@@ -266,7 +266,7 @@ int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const 
 /* ---------------------------------------------------------------------------------------------------------
  * K12-K14  ViT patch-embedding extractor (compute_feats.py:239-247 -> IClassifier -> VisionTransformer.forward)
  *   reference model files: utils_ssls_cf/vision_transformer_with_adapter_dino_version.py (vd), vision_transformer_dino.py,
- *   adapter.py, models_adapter_mae.py.  Dense projections stay library GEMMs; these entry points are the rest.
+ *   adapter.py, models_adapter_mae.py.  The dense projections are snf_gemm_bf16 (above) or library GEMMs by a measured shape policy; these entry points are the rest.
  *
  *   snf_vit_patchify         im2col of PatchEmbed's Conv2d(3, D, p, p)                vd:141-146
  *       img [b, c, hgt, wid] f32 -> cols [b * (hgt/p) * (wid/p), c*p*p] (f32 or bf16), column order (c, i, j) = the

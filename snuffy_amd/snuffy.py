@@ -3,7 +3,8 @@
 Same class names, constructor signatures, forward signatures, return tuples and state-dict keys as the reference
 (reference snuffy.py:34-238), so ``train.py`` / ``roi.py`` style callers switch by changing the import.
 Underneath, every op on the hot path is a hand-written HIP kernel reached through the C ABI of
-``include/snuffy_hip.h``; the dense projections are plain library GEMMs (hipBLASLt via torch.mm).
+``include/snuffy_hip.h``; the dense projections run on the hand-written MFMA GEMM (``snf_gemm_bf16``: every fp32-class
+projection, small bags) or the library GEMM where that is faster (the three config-B-sized bf16 projections).
 
 Differences that are deliberate and documented:
   * top-Lambda tie order is defined (descending score, ascending index) where torch.sort leaves it unspecified;
