@@ -121,6 +121,16 @@ int snf_layernorm_bwd_blocks(int64_t n);
 int snf_layernorm_rows_bwd_f32(const float* x, int64_t n, int d, const void* dy, int dy_dtype, int64_t dy_stride,
                                const float* gamma, float eps, const float* residual, float* dx, void* dx_bf16,
                                float* partials, snf_stream_t stream);
+/* bf16 path: the LayerNorm affine of SublayerConnection (snuffy.py:97,107,110) folded into the projection that follows it
+ * (LN(x) W^T + b = xhat (W * gamma)^T + (W beta + b)), and the gradients of the folded weights taken back to (W, b, gamma, beta):
+ *   fold:    wf_bf16[r, c] = bf16(w[r, c] * gamma[c]) (row pitch ldwf);  bf[r] = sum_c w[r, c] * beta[c] + bias[r] (f32 / bf16, nullable)
+ *   unfold:  dw[r, c] = dwf[r, c] * gamma[c] + dbf[r] * beta[c];  partial [snf_fold_blocks(r), 2, c] = per-workgroup
+ *            (sum_r dwf * w, sum_r dbf[r] * w): dgamma / dbeta are their sums over the first axis.   c <= 2048. */
+int snf_fold_blocks(int r);
+int snf_fold_linear_f32(const float* w, int r, int c, const float* gamma, const float* beta, const float* bias, void* wf_bf16,
+                        int64_t ldwf, float* bf_f32, void* bf_bf16, snf_stream_t stream);
+int snf_unfold_linear_f32(const float* dwf, const float* w, int r, int c, const float* gamma, const float* beta, const float* dbf,
+                          float* dw, float* partial, snf_stream_t stream);
 /* x [m, k] f32 (row pitch ldx) -> out [m, 3 k] bf16 = [hi | hi | lo]: the activation image of an fp32-class projection whose
  * producer is not one of the kernels that can emit it directly (ViT fp32 path: patch columns, attention output). */
 int snf_split3_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16, snf_stream_t stream);

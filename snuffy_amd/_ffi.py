@@ -46,6 +46,11 @@ SIGNATURES = {
     "snf_layernorm_bwd_blocks": (c_int, [c_int64]),
     "snf_layernorm_rows_bwd_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_void_p, c_float, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p]),
+    "snf_fold_blocks": (c_int, [c_int]),
+    "snf_fold_linear_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                    c_void_p]),
+    "snf_unfold_linear_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
     "snf_split3_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "snf_colsum_blocks": (c_int, [c_int64]),
     "snf_colsum_fused": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),

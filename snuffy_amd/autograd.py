@@ -252,16 +252,22 @@ class EncoderLayer0Bf16Fn(torch.autograd.Function):
         dbqvf, _ = ops.colsum_fused(dqv)
         dwk = dkp.t() @ xs
         dbk = dkp.sum(0)
-        # ---- unfold  W' = W * gamma,  b' = W beta + b
-        dwqf, dwvf = dwqvf[:d], dwqvf[d:]
-        dbq, dbv = dbqvf[:d], dbqvf[d:]
-        dg0 = (dwqf * wq).sum(0) + (dwvf * wv).sum(0)
-        db0 = dbq @ wq + dbv @ wv
-        dg1 = (dw1f * w1).sum(0)
-        db1 = db1f @ w1
-        dwq = dwqf * g0 + torch.outer(dbq, b0)
-        dwv = dwvf * g0 + torch.outer(dbv, b0)
-        dw1 = dw1f * g1 + torch.outer(db1f, b1)
+        # ---- unfold  W' = W * gamma,  b' = W beta + b  (one kernel per projection: dW, and the partial sums of dgamma / dbeta)
+        dbq, dbv = dbqvf[:d].contiguous(), dbqvf[d:].contiguous()
+        if d <= 2048:
+            dwq, dgq, dbq0 = ops.unfold_linear(dwqvf[:d], wq, g0, b0, dbq)
+            dwv, dgv, dbv0 = ops.unfold_linear(dwqvf[d:], wv, g0, b0, dbv)
+            dg0, db0 = dgq + dgv, dbq0 + dbv0
+            dw1, dg1, db1 = ops.unfold_linear(dw1f, w1, g1, b1, db1f)
+        else:
+            dwqf, dwvf = dwqvf[:d], dwqvf[d:]
+            dg0 = (dwqf * wq).sum(0) + (dwvf * wv).sum(0)
+            db0 = dbq @ wq + dbv @ wv
+            dg1 = (dw1f * w1).sum(0)
+            db1 = db1f @ w1
+            dwq = dwqf * g0 + torch.outer(dbq, b0)
+            dwv = dwvf * g0 + torch.outer(dbv, b0)
+            dw1 = dw1f * g1 + torch.outer(db1f, b1)
         return (None, None, None, None, dg0, db0, dg1, db1, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dw1, db1f, dw2, db2)
 
 

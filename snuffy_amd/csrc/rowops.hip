@@ -486,6 +486,85 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// LayerNorm affine folded into the following projection, and back (bf16 path, functional._folded / the training chain):
+//   fold:    Wf[r, c] = bf16(W[r, c] * gamma[c]) ;  bf[r] = sum_c W[r, c] * beta[c] + bias[r]
+//   unfold:  dW[r, c] = dWf[r, c] * gamma[c] + dbf[r] * beta[c]
+//            partial[b] = (sum_r dWf[r, c] * W[r, c],  sum_r dbf[r] * W[r, c])   -> dgamma, dbeta after the caller's sum over b
+// one wave per weight row (C <= 2048), the same row helpers as LayerNorm.
+// ---------------------------------------------------------------------------------------------------------------
+template <int VEC, int NV>
+__global__ __launch_bounds__(WG) void fold_linear_kernel(const float* __restrict__ w, int r, int c,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ bias, unsigned short* __restrict__ wf,
+                                                         int64_t ldwf, float* __restrict__ bf, unsigned short* __restrict__ bf16) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[NV * VEC], bt[NV * VEC];
+    load_row<VEC, NV>(gamma, c, lane, g);
+    load_row<VEC, NV>(beta, c, lane, bt);
+    for (int row = blockIdx.x * WAVES + wave; row < r; row += gridDim.x * WAVES) {
+        float x[NV * VEC];
+        load_row<VEC, NV>(w + (int64_t)row * c, c, lane, x);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV * VEC; ++i) {
+            acc = fmaf(x[i], bt[i], acc);
+            x[i] *= g[i];
+        }
+        acc = wave_sum(acc);
+        store_row_bf16<VEC, NV>(wf + (int64_t)row * ldwf, c, lane, x);
+        if (lane == 0) {
+            const float b = acc + (bias ? bias[row] : 0.f);
+            if (bf) bf[row] = b;
+            if (bf16) bf16[row] = f32_to_bf16_bits(b);
+        }
+    }
+}
+
+template <int VEC, int NV>
+__global__ __launch_bounds__(WG) void unfold_linear_kernel(const float* __restrict__ dwf, const float* __restrict__ w, int r, int c,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ dbf, float* __restrict__ dw,
+                                                           float* __restrict__ partial) {
+    constexpr int R = NV * VEC;
+    __shared__ float red[WAVES][2][R * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[R], bt[R], sg[R], sb[R];
+    load_row<VEC, NV>(gamma, c, lane, g);
+    load_row<VEC, NV>(beta, c, lane, bt);
+#pragma unroll
+    for (int i = 0; i < R; ++i) sg[i] = 0.f, sb[i] = 0.f;
+    for (int row = blockIdx.x * WAVES + wave; row < r; row += gridDim.x * WAVES) {
+        float d[R], x[R];
+        load_row<VEC, NV>(dwf + (int64_t)row * c, c, lane, d);
+        load_row<VEC, NV>(w + (int64_t)row * c, c, lane, x);
+        const float db = dbf[row];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            sg[i] = fmaf(d[i], x[i], sg[i]);
+            sb[i] = fmaf(db, x[i], sb[i]);
+            d[i] = fmaf(d[i], g[i], db * bt[i]);
+        }
+        store_row_f32<VEC, NV>(dw + (int64_t)row * c, c, lane, d);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) {
+            red[wave][0][(i * 64 + lane) * VEC + t] = sg[i * VEC + t];
+            red[wave][1][(i * 64 + lane) * VEC + t] = sb[i * VEC + t];
+        }
+    __syncthreads();
+    float* out = partial + (int64_t)blockIdx.x * 2 * c;
+    for (int e = threadIdx.x; e < 2 * c; e += WG) {
+        const int which = e >= c, col = which ? e - c : e;
+        float a = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < WAVES; ++wv) a += red[wv][which][col];
+        out[e] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // gather / scatter of the K selected rows
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void gather_rows_kernel(const float* __restrict__ x, int64_t n, int d,
@@ -1051,6 +1130,39 @@ int snf_split3_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16
     hipLaunchKernelGGL(split3_kernel, dim3((int)blocks), dim3(256), 0, snf::as_stream(stream), x, ldx, m, k,
                        reinterpret_cast<unsigned short*>(out_bf16));
     return snf::check_launch("split3_kernel");
+}
+
+int snf_fold_blocks(int r) {
+    int b = (r + WAVES - 1) / WAVES;
+    const int cap = snf::cu_count() * 2;
+    return b < 1 ? 1 : (b > cap ? cap : b);
+}
+
+int snf_fold_linear_f32(const float* w, int r, int c, const float* gamma, const float* beta, const float* bias, void* wf_bf16,
+                        int64_t ldwf, float* bf_f32, void* bf_bf16, snf_stream_t stream) {
+    SNF_REQUIRE(w && gamma && beta && wf_bf16, "snf_fold_linear_f32: null pointer");
+    SNF_REQUIRE(r >= 1 && c >= 1 && ldwf >= c, "snf_fold_linear_f32: bad shape");
+    const bool al = aligned16(w) && aligned16(gamma) && aligned16(beta) && aligned16(wf_bf16) && ldwf % 8 == 0;
+    RowCfg cfg;
+    SNF_REQUIRE(pick_row_cfg(c, al, &cfg), "snf_fold_linear_f32: c=%d too wide (max 2048)", c);
+    hipStream_t s = snf::as_stream(stream);
+    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((fold_linear_kernel<VEC, NV>), dim3(snf_fold_blocks(r)), dim3(WG), 0, s, w, r, c, gamma,
+                                              beta, bias, reinterpret_cast<unsigned short*>(wf_bf16), ldwf, bf_f32,
+                                              reinterpret_cast<unsigned short*>(bf_bf16)));
+    return snf::check_launch("fold_linear_kernel");
+}
+
+int snf_unfold_linear_f32(const float* dwf, const float* w, int r, int c, const float* gamma, const float* beta, const float* dbf,
+                          float* dw, float* partial, snf_stream_t stream) {
+    SNF_REQUIRE(dwf && w && gamma && beta && dbf && dw && partial, "snf_unfold_linear_f32: null pointer");
+    SNF_REQUIRE(r >= 1 && c >= 1, "snf_unfold_linear_f32: bad shape");
+    const bool al = aligned16(dwf) && aligned16(w) && aligned16(gamma) && aligned16(beta) && aligned16(dw);
+    RowCfg cfg;
+    SNF_REQUIRE(pick_row_cfg(c, al, &cfg), "snf_unfold_linear_f32: c=%d too wide (max 2048)", c);
+    hipStream_t s = snf::as_stream(stream);
+    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((unfold_linear_kernel<VEC, NV>), dim3(snf_fold_blocks(r)), dim3(WG), 0, s, dwf, w, r, c,
+                                              gamma, beta, dbf, dw, partial));
+    return snf::check_launch("unfold_linear_kernel");
 }
 
 int snf_gather_rows_f32(const float* x, int64_t n, int d, const int64_t* idx, int k, float* out, snf_stream_t stream) {

@@ -234,17 +234,35 @@ def _folded(layer):
         return ent[1]
     with torch.no_grad():
         g0, b0, g1, b1 = n0.weight, n0.bias, n1.weight, n1.bias
-        out = dict(
-            # Q and V projections as ONE GEMM over the shared normalised input: output [N, 2D] = [Q | V]
-            wqv=torch.cat([lq.weight * g0, lv.weight * g0]).to(torch.bfloat16).contiguous(),
-            bqv=torch.cat([lq.weight @ b0 + lq.bias, lv.weight @ b0 + lv.bias]).to(torch.bfloat16).contiguous(),
-            bqv_f=torch.cat([lq.weight @ b0 + lq.bias, lv.weight @ b0 + lv.bias]).float().contiguous(),
-            w1=(ff.w_1.weight * g1).to(torch.bfloat16), b1=(ff.w_1.weight @ b1 + ff.w_1.bias).contiguous(),
-            b1h=(ff.w_1.weight @ b1 + ff.w_1.bias).to(torch.bfloat16),
-            w2=ff.w_2.weight.to(torch.bfloat16),
-            # key projection of the K raw selected rows (snuffy.py:190), bf16 operands like Q and V
-            wk=lk.weight.to(torch.bfloat16).contiguous(), bk=lk.bias.to(torch.bfloat16).contiguous(),
-        )
+        d, f = lq.weight.shape[1], ff.w_1.weight.shape[0]
+        bf = torch.bfloat16
+        if lq.weight.is_cuda and d <= 2048 and lq.weight.dtype == torch.float32:
+            # one kernel per projection (snf_fold_linear_f32) instead of ~20 small library ops -- the training chain refolds
+            # after every optimizer step
+            dev = lq.weight.device
+            wqv = torch.empty(2 * d, d, dtype=bf, device=dev)
+            bqv_f = torch.empty(2 * d, dtype=torch.float32, device=dev)
+            bqv = torch.empty(2 * d, dtype=bf, device=dev)
+            ops.fold_linear(lq.weight, g0, b0, lq.bias, wqv[:d], bqv_f[:d], bqv[:d])
+            ops.fold_linear(lv.weight, g0, b0, lv.bias, wqv[d:], bqv_f[d:], bqv[d:])
+            w1 = torch.empty(f, d, dtype=bf, device=dev)
+            b1f = torch.empty(f, dtype=torch.float32, device=dev)
+            b1h = torch.empty(f, dtype=bf, device=dev)
+            ops.fold_linear(ff.w_1.weight, g1, b1, ff.w_1.bias, w1, b1f, b1h)
+            out = dict(wqv=wqv, bqv=bqv, bqv_f=bqv_f, w1=w1, b1=b1f, b1h=b1h, w2=ff.w_2.weight.to(bf),
+                       wk=lk.weight.to(bf).contiguous(), bk=lk.bias.to(bf).contiguous())
+        else:
+            out = dict(
+                # Q and V projections as ONE GEMM over the shared normalised input: output [N, 2D] = [Q | V]
+                wqv=torch.cat([lq.weight * g0, lv.weight * g0]).to(torch.bfloat16).contiguous(),
+                bqv=torch.cat([lq.weight @ b0 + lq.bias, lv.weight @ b0 + lv.bias]).to(torch.bfloat16).contiguous(),
+                bqv_f=torch.cat([lq.weight @ b0 + lq.bias, lv.weight @ b0 + lv.bias]).float().contiguous(),
+                w1=(ff.w_1.weight * g1).to(torch.bfloat16), b1=(ff.w_1.weight @ b1 + ff.w_1.bias).contiguous(),
+                b1h=(ff.w_1.weight @ b1 + ff.w_1.bias).to(torch.bfloat16),
+                w2=ff.w_2.weight.to(torch.bfloat16),
+                # key projection of the K raw selected rows (snuffy.py:190), bf16 operands like Q and V
+                wk=lk.weight.to(torch.bfloat16).contiguous(), bk=lk.bias.to(torch.bfloat16).contiguous(),
+            )
     layer._fold = (key, out)
     return out
 

@@ -282,6 +282,39 @@ def colsum_fused(src, row_weight=None, gate=None, want_bf16=False, inplace=False
     return part.sum(0), dst
 
 
+def fold_linear(w, gamma, beta, bias, out_w, out_bf=None, out_bf16=None):
+    """out_w[r, c] = bf16(w[r, c] * gamma[c]) written into out_w (a [r, c] bf16 view, rows may be strided);
+    out_bf / out_bf16 [r] = w @ beta + bias as f32 / bf16 (either may be None).  See snf_fold_linear_f32."""
+    w = _req(w, torch.float32, "w", 2)
+    r, c = w.shape
+    gamma = _req(gamma, torch.float32, "gamma", 1)
+    beta = _req(beta, torch.float32, "beta", 1)
+    if bias is not None:
+        bias = _req(bias, torch.float32, "bias", 1)
+    if out_w.dtype != torch.bfloat16 or out_w.shape != (r, c) or out_w.stride(1) != 1:
+        raise ValueError("fold_linear: out_w must be a [%d, %d] bfloat16 view with unit column stride" % (r, c))
+    check(_ffi.load().snf_fold_linear_f32(_p(w), r, c, _p(gamma), _p(beta), _p(bias), _p(out_w), out_w.stride(0), _p(out_bf),
+                                          _p(out_bf16), _stream()), "snf_fold_linear_f32")
+
+
+def unfold_linear(dwf, w, gamma, beta, dbf):
+    """Gradients of a folded projection back to its parameters: returns (dW [r, c], dgamma [c], dbeta [c]) with
+    dW = dWf * gamma + outer(dbf, beta), dgamma = sum_r dWf * W, dbeta = W^T dbf.  See snf_unfold_linear_f32."""
+    dwf = _req(dwf, torch.float32, "dwf", 2)
+    w = _req(w, torch.float32, "w", 2)
+    r, c = w.shape
+    gamma = _req(gamma, torch.float32, "gamma", 1)
+    beta = _req(beta, torch.float32, "beta", 1)
+    dbf = _req(dbf, torch.float32, "dbf", 1)
+    lib = _ffi.load()
+    dw = torch.empty(r, c, dtype=torch.float32, device=w.device)
+    part = torch.empty(lib.snf_fold_blocks(r), 2, c, dtype=torch.float32, device=w.device)
+    check(lib.snf_unfold_linear_f32(_p(dwf), _p(w), r, c, _p(gamma), _p(beta), _p(dbf), _p(dw), _p(part), _stream()),
+          "snf_unfold_linear_f32")
+    sums = part.sum(0)
+    return dw, sums[0], sums[1]
+
+
 def bias_act_(h, bias, act):
     """h = act(h + bias) in place (snuffy.py:224-225)."""
     if not h.is_cuda or not h.is_contiguous() or h.dim() != 2:

@@ -302,3 +302,33 @@ def test_colsum_fused_kernel(n, d):
     y = xb.clone()
     s2, c2 = ops.colsum_fused(y, gate=gate, inplace=True)
     assert c2 is y and torch.equal(y, want) and torch.equal(s2, s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("r,c", [(768, 768), (3072, 768), (100, 384), (33, 100), (1536, 2048)])
+def test_fold_and_unfold_linear_kernels(r, c):
+    """snf_fold_linear_f32 / snf_unfold_linear_f32 vs the torch expressions they replace (fp64)."""
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(r + c)
+    w = (torch.randn(r, c, generator=g) / c ** 0.5).to(DEV)
+    gam, bet = (1 + 0.3 * torch.randn(c, generator=g)).to(DEV), (0.2 * torch.randn(c, generator=g)).to(DEV)
+    bias = torch.randn(r, generator=g).to(DEV)
+    big = torch.zeros(r + 5, c + 8, dtype=torch.bfloat16, device=DEV)
+    wf = big[3:3 + r, :c]                                             # a strided destination (rows of a larger buffer)
+    bf, bfh = torch.empty(r, device=DEV), torch.empty(r, dtype=torch.bfloat16, device=DEV)
+    ops.fold_linear(w, gam, bet, bias, wf, bf, bfh)
+    assert torch.equal(wf, (w * gam).to(torch.bfloat16))
+    ref_b = w.double() @ bet.double() + bias.double()
+    assert (bf.double() - ref_b).abs().max().item() <= 2e-6 * max(1.0, ref_b.abs().max().item())
+    assert torch.equal(bfh, bf.to(torch.bfloat16))
+    assert float(big[:3].abs().sum()) == 0 and float(big[3 + r:].abs().sum()) == 0 and float(big[:, c:].abs().sum()) == 0
+    ops.fold_linear(w, gam, bet, None, wf)                            # no bias, no bias outputs
+    dwf = torch.randn(r, c, generator=g).to(DEV)
+    dbf = torch.randn(r, generator=g).to(DEV)
+    dw, dgam, dbet = ops.unfold_linear(dwf, w, gam, bet, dbf)
+    ref_dw = dwf.double() * gam.double() + torch.outer(dbf.double(), bet.double())
+    ref_dg = (dwf.double() * w.double()).sum(0)
+    ref_db = dbf.double() @ w.double()
+    assert (dw.double() - ref_dw).abs().max().item() <= 2e-6 * ref_dw.abs().max().item()
+    assert (dgam.double() - ref_dg).abs().max().item() <= 1e-5 * max(1.0, ref_dg.abs().max().item())
+    assert (dbet.double() - ref_db).abs().max().item() <= 1e-5 * max(1.0, ref_db.abs().max().item())
