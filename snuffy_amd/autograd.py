@@ -232,11 +232,8 @@ class EncoderLayer0Bf16Fn(torch.autograd.Function):
         dw1f = _tn_mm(dhid, xhat)                                                    # [F, D] gradient of the FOLDED weight
         # ---- the K selected rows: y[S] = x_sel = xs + o Wo^T + bo; every other row of y is data             (snuffy.py:108,152-155)
         dyn_s = torch.mm(dhid.index_select(0, sel), w1f, out_dtype=f32)              # d loss / d xhat1[S] (bf16 operands as they are)
-        mu = x_sel.mean(1, keepdim=True)
-        xc = x_sel - mu
-        rstd = torch.rsqrt((xc * xc).mean(1, keepdim=True) + eps)
-        xh = xc * rstd
-        dy_s = dz.index_select(0, sel) + rstd * (dyn_s - dyn_s.mean(1, keepdim=True) - xh * (dyn_s * xh).mean(1, keepdim=True))
+        # dy[S] = dz[S] + LayerNorm-1 backward of dyn_s at the rows x_sel (affine folded away): one kernel
+        dy_s, _, _, _ = ops.layernorm_rows_bwd(x_sel, dyn_s, None, eps, residual=dz.index_select(0, sel), want_param_grads=False)
         dbo = dy_s.sum(0)
         dwo = dy_s.t() @ o
         do = dy_s @ wo

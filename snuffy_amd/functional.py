@@ -194,12 +194,20 @@ class Parts:
         return self.add_bf16 is None and self.add_bias is None and self.slot is None
 
 
+_MATERIALIZE_CONST = {}
+
+
 def materialize(parts):
     if parts.plain:
         return parts.base
     d = parts.base.shape[1]
-    dummy_w = torch.zeros(1, d, dtype=torch.float32, device=parts.base.device)
-    ones = torch.ones(d, dtype=torch.float32, device=parts.base.device)
+    key = (parts.base.device, d)
+    const = _MATERIALIZE_CONST.get(key)
+    if const is None:          # the head kernel assembles z on its way; its own outputs are not wanted here: unit gamma, zero head
+        const = (torch.zeros(1, d, dtype=torch.float32, device=parts.base.device),
+                 torch.ones(d, dtype=torch.float32, device=parts.base.device))
+        _MATERIALIZE_CONST[key] = const
+    dummy_w, ones = const
     _, _, z = ops.ln_mean_head(parts.base, ones, dummy_w[0], 1e-5, dummy_w, None, parts.add_bf16, parts.add_bias,
                                parts.slot, parts.delta, want_z=True)
     return z
