@@ -124,7 +124,9 @@ def test_vit_models_match_reference_goldens(path):
             np.testing.assert_allclose(attn[:, :, ::29, :].cpu().numpy(), z["last_attn"], rtol=0, atol=1e-5)
     fb = model.configure("bf16")(imgs)
     ref = torch.from_numpy(z["feats"])
-    assert rel_err(fb.cpu(), ref) < 2e-2, rel_err(fb.cpu(), ref)                       # bf16 path: 1e-2 per layer, depth <= 2
+    e = rel_err(fb.cpu(), ref)
+    print("MEASURED vit bf16 golden", path.split("/")[-1] if isinstance(path, str) else "", e)
+    assert e < 1e-2, e                                                                 # north-star bf16 class, no depth allowance
 
 
 def test_vit_small_shape_and_iclassifier():
@@ -140,7 +142,9 @@ def test_vit_small_shape_and_iclassifier():
     assert feats.shape == (4, 384) and c.shape == (4, 2)
     assert (feats.cpu() - ref).abs().max() < 1e-3
     fb = model.configure("bf16")(x)
-    assert rel_err(fb.cpu(), ref) < 5e-2
+    e = rel_err(fb.cpu(), ref)
+    print("MEASURED vit_small bf16 depth 12", e)
+    assert e < 1e-2, e                                                                 # north-star bf16 class at depth 12
 
 
 def test_compute_feats_end_to_end(tmp_path):
