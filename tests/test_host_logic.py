@@ -143,3 +143,20 @@ def test_binary_sidecar_loads_exactly_what_the_csv_parses(tmp_path, camelyon16):
     np.random.seed(11)
     _, f_d, _, _ = utils.get_bag_feats(row, args)
     assert np.array_equal(f_d, f_c)
+
+
+def test_weight_gradient_split_k_matches_plain_contraction():
+    """autograd._tn_mm (X^T Y over the bag axis as one batched GEMM over row chunks + fp32 sum): same result as the plain
+    contraction for bag sizes that are / are not a multiple of the chunk count, and the small-bag shortcut."""
+    import torch
+
+    from snuffy_amd import autograd as SA
+    g = torch.Generator().manual_seed(0)
+    for n in (64, 4096, 4099, 8192 + 5):
+        a = torch.randn(n, 24, generator=g).to(torch.bfloat16)
+        b = torch.randn(n, 40, generator=g).to(torch.bfloat16)
+        ref = a.double().t() @ b.double()
+        out = SA._tn_mm(a, b)
+        assert out.dtype == torch.float32 and out.shape == (24, 40)
+        # partials are rounded to bf16 once (2^-9 of their own scale ~ sqrt(n / chunks)) before the fp32 sum
+        assert (out.double() - ref).abs().max().item() <= 8e-3 * max(1.0, (n / 8) ** 0.5 * 3), n
