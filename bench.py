@@ -103,6 +103,9 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
             ops.sparse_attn_fwd(qf[i], kp, vs[i], h)
         kern = "scores_softmax_kernel+pt_v_kernel+reduce_slices_kernel"
         elt = 4
+    # 20 launches over the rotating operand sets: the same duration as the kernel has inside the bag pipeline (rocprofv3 of this
+    # command: 37.9 + 6 us), where Q | V were written by the projection just before.  A 200-launch region over the same sets
+    # runs fully cold (every operand set evicted from the 256 MiB Infinity Cache before it comes back): 46.9 us at config B.
     t_attn = timed(attn, 20, warmup=3)
     # algorithmic bytes: read Q and V once, read Kp, write O;  top-k: read N scores, write K indices
     b_attn = 2 * N * D * elt + K * D * elt + K * D * 4
