@@ -194,10 +194,10 @@ def cpu_baseline(wl, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: a steady-state region (a 30-step region of 16 ms still sits on the clock ramp: 1.87 k vs 2.05 k slides/s at 2000
-    # steps); 400 config-B bags are 0.2 s
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
+    # defaults: a steady-state region of ~1 s (a 30-step region of 16 ms still sits on the clock ramp: 1.87 k slides/s, 400 steps
+    # 1.97 k, 2000 steps 2.05 k at config B; shorter regions also scatter by +-10 % with the GPU's power state)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="cfgB", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--mode", default="eval", choices=["eval", "train"])
