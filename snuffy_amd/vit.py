@@ -281,7 +281,9 @@ class VisionTransformer(nn.Module):
                      fc2_w=blk.mlp.fc2.weight.to(bf), fc2_b=blk.mlp.fc2.bias.to(bf), fc2_bf=blk.mlp.fc2.bias.to(f32))
             if hasattr(blk, "adaptmlp"):
                 d.update(dn_w=blk.adaptmlp.down_proj.weight.to(bf), dn_b=blk.adaptmlp.down_proj.bias.to(bf),
-                         up_w=blk.adaptmlp.up_proj.weight.to(bf), up_b=blk.adaptmlp.up_proj.bias.to(bf))
+                         dn_bf=blk.adaptmlp.down_proj.bias.to(f32),
+                         up_w=blk.adaptmlp.up_proj.weight.to(bf), up_b=blk.adaptmlp.up_proj.bias.to(bf),
+                         up_bf=blk.adaptmlp.up_proj.bias.to(f32))
             w["blocks"].append(d)
         self._bf16_cache = (key, w)
         return w
@@ -332,8 +334,15 @@ class VisionTransformer(nn.Module):
             m = ops.linear_bf16(hdn, wb["fc2_w"], wb["fc2_bf"], wb["fc2_b"])
             u, s2 = None, 1.0
             if has_ad:
-                a = torch._addmm_activation(wb["dn_b"], xb, wb["dn_w"].t())                      # ReLU(down(x))
-                u = torch.addmm(wb["up_b"], a, wb["up_w"].t())
+                # the adapter's skinny projections (D -> bottleneck -> D): 128-wide tiles of the hand-written GEMM are 1.5-1.8x the
+                # library here (tools/adapter_bench.py); bottlenecks below 64 keep the library (k >= 64 in the kernel's domain)
+                bott = wb["dn_w"].shape[0]
+                if ops.gemm_supported(xb.shape[0], bott, xb.shape[1]) and ops.gemm_supported(xb.shape[0], xb.shape[1], bott):
+                    a = ops.gemm_bf16(xb, wb["dn_w"], wb["dn_bf"], "relu", tile_n=128)           # ReLU(down(x))
+                    u = ops.gemm_bf16(a, wb["up_w"], wb["up_bf"], "none", tile_n=128)
+                else:
+                    a = torch._addmm_activation(wb["dn_b"], xb, wb["dn_w"].t())
+                    u = torch.addmm(wb["up_b"], a, wb["up_w"].t())
                 s2 = float(blk.adaptmlp.scale)
             last = i == len(self.blocks) - 1
             nxt = self.norm if last else self.blocks[i + 1].norm1
