@@ -12,8 +12,8 @@ Mirrors the module API and state-dict keys of the reference's inference-time mod
 
 Inference only (parameters of the extractor are frozen in the reference, compute_feats.py:432-433).  Hand-written HIP:
 patchify, token assembly, LayerNorm, residual+LayerNorm fusion, GELU epilogue, multi-head self-attention (exact fp32 and
-bf16 MFMA).  Patch-embed, qkv, proj, fc1 (+ erf GELU) and the adapter projections run on the hand-written MFMA GEMM in the
-bf16 path; fc2 (K = 4D) is a library GEMM.  ``configure(precision=...)``: "fp32" = reference-class
+bf16 MFMA).  Patch-embed, qkv, proj, fc1 (+ erf GELU) and -- for bottlenecks of 64 and more -- the adapter projections run on the
+hand-written MFMA GEMM in the bf16 path; fc2 (K = 4D) and narrower adapters are library GEMMs.  ``configure(precision=...)``: "fp32" = reference-class
 numerics, "bf16" = bf16 GEMM / MFMA operands with an fp32 residual stream.
 """
 import math
