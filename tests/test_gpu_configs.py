@@ -190,3 +190,22 @@ def test_bag_parallel_stepper_equals_trainer_step_world1():
     st.step(xp, torch.tensor([1.0], device=DEV))
     for (k, a), (_, b) in zip(tr.milnet.named_parameters(), twin.named_parameters()):
         assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_bench_rccl_path_on_one_rank(mode):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), here with one rank and the RCCL
+    process group forced on: init, barriers, the max-over-ranks all-reduce, the per-rank all-gather and -- in train mode -- the
+    flat-gradient all-reduce all run on the real backend (an N > 1 run is the driver's)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SNF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541" if mode == "eval" else "29542", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "cfgA",
+           "--steps", "6", "--warmup", "2", "--headline-only", "--no-cpu-baseline", "--no-roofline", "--mode", mode,
+           "--precision", "bf16"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["rccl_ranks"] == 1 and line["n_gpus"] == 1 and line["value"] > 0
+    assert len(line["config"]["per_rank_slides_per_s"]) == 1
