@@ -2,8 +2,13 @@
 """Headline benchmark: slides/sec of the Snuffy MIL aggregator + sparse-attention HBM GB/s on MI355X.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus N ...            (no launcher: re-executes itself as N ranks under torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+
+The headline leg is the reference's arithmetic (--precision fp32: fp32 tensors, products as split-bf16 x3 on the matrix cores);
+the bf16 path is timed beside it (value_bf16 / roofline_bf16).  With N > 1 ranks an eval run also times training steps
+(value_train): that is where the path's one collective, the flat-gradient RCCL all-reduce, lives.
 
 A step = one bag (slide) through MILNet (critic -> top-Lambda -> sparse attention -> FFN -> head) per rank, bags already
 resident in HBM.  Workload = BASELINE.json's metric shape (config B): N=32768 patches, D=768, h=6, Lambda=200.
@@ -36,9 +41,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
 def build_net(D, h, lam, precision, device):
-    from tests.helpers import build_amd_milnet
+    from snuffy_amd.snuffy import build_milnet
     torch.manual_seed(0)
-    net = build_amd_milnet(D, h, "relu", lam, 0.0, 1)
+    net = build_milnet(D, h, "relu", lam, 0.0, 1)
     for _, p in net.named_parameters():
         if p.dim() > 1:
             torch.nn.init.xavier_normal_(p)
@@ -199,7 +204,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="cfgB", choices=sorted(WORKLOADS))
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    # the headline arithmetic is the reference's: fp32 tensors (products on the matrix cores as split-bf16 x3, fp32-class);
+    # the bf16 path (north_star's 1e-2 class) rides beside it as value_bf16 / roofline_bf16
+    ap.add_argument("--precision", default="fp32", choices=["bf16", "fp32"])
     ap.add_argument("--mode", default="eval", choices=["eval", "train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -214,11 +221,30 @@ def main():
     ap.add_argument("--gemm-table", action="store_true",
                     help="apply snuffy_amd/tuning/gemm_gfx950.csv (library-GEMM selections; helps the training shapes, "
                          "nothing measurable for the eval forward)")
+    ap.add_argument("--train-steps", type=int, default=None,
+                    help="timed steps of the training leg that an N > 1 eval run adds (value_train: fwd + bwd + AdamW + the "
+                         "flat-gradient RCCL all-reduce); default min(100, max(5, steps // 20))")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: run the same command line as N ranks of ONE node (one process per
+        # GPU, RCCL over xGMI) and hand back its exit code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU "
+                         "(python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...)"
+                         % (args.gpus, world, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: snuffy_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -251,16 +277,17 @@ def main():
         bags = [torch.randn(1, N, D, generator=g).to(device) for _ in range(nbags)]
     labels = [torch.tensor([float(i % 2)], device=device) for i in range(nbags)]
 
-    def measure(precision, return_attention=False, steps=None, warmup=None, use_graph=None):
+    def measure(precision, return_attention=False, steps=None, warmup=None, use_graph=None, mode=None):
         """Times `steps` steps of one configuration (barrier + synchronize on both sides, max over ranks).
         Returns (elapsed seconds, per-rank seconds, launch mode)."""
         steps = args.steps if steps is None else steps
         warmup = args.warmup if warmup is None else warmup
         use_graph = args.graph if use_graph is None else use_graph
+        mode = args.mode if mode is None else mode
         net = build_net(D, h, lam, precision, device)
         net.configure(return_attention=return_attention)
         launch = "eager"
-        if args.mode == "train":
+        if mode == "train":
             from snuffy_amd.train import BagParallelStepper
             stepper = BagParallelStepper(net, world_size=world, dist=dist, device=device, precision=precision)
 
@@ -340,6 +367,16 @@ def main():
             finally:
                 SF.FP32_GEMM = keep
             extra["f32_library_gemm"] = dict(elapsed=e4, steps=steps_l, launch=l4)
+    train_leg = None
+    if args.mode == "eval" and dist is not None:      # world > 1 (or the forced one-rank RCCL path of the tests)
+        # the eval forward has no collective in its data path (bags are independent): an N-rank eval line says nothing about
+        # the one exchange the north star names, the flat-gradient all-reduce.  The same ranks therefore also time training
+        # steps (fwd + bwd + AdamW + ONE RCCL all-reduce of the flat fp32 gradient per step), reported as value_train.
+        steps_t = args.train_steps or min(100, max(5, args.steps // 20))
+        train_leg = {}
+        for prec in ((args.precision,) if args.headline_only else (args.precision, "bf16" if args.precision == "fp32" else "fp32")):
+            e5, pr5, _ = measure(prec, steps=steps_t, warmup=min(args.warmup, 5), mode="train")
+            train_leg[prec] = dict(elapsed=e5, steps=steps_t, per_rank=pr5)
 
     if rank == 0:
         K = min(lam, N)
@@ -367,6 +404,14 @@ def main():
             else:
                 line["value_" + dt_name[key]] = round(world * rec["steps"] / rec["elapsed"], 3)
                 line["ms_per_step_" + dt_name[key]] = round(rec["elapsed"] / rec["steps"] * 1e3, 4)
+        if train_leg:
+            for prec, rec in train_leg.items():
+                sfx = "" if prec == args.precision else "_" + dt_name[prec]
+                line["value_train" + sfx] = round(world * rec["steps"] / rec["elapsed"], 3)
+                line["ms_per_step_train" + sfx] = round(rec["elapsed"] / rec["steps"] * 1e3, 4)
+            line["train_leg"] = {"steps": train_leg[args.precision]["steps"], "rccl_ranks": world,
+                                 "all_reduce_bytes_per_step": 4 * sum(p.numel() for p in build_net(D, h, lam, "fp32", "cpu").parameters()),
+                                 "what": "fwd + bwd + fused AdamW + ONE flat-gradient all-reduce (sum, /W) per step, 1 bag per rank"}
         line["arithmetic"] = {
             "bf16": "bf16 MFMA operands, fp32 accumulate / softmax / LayerNorm / residual (north_star's 1e-2 class)",
             "f32": "fp32 tensors; products as split-bf16 x3 on the MFMA units (2^-17 per product, fp32 accumulate), "

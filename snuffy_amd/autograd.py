@@ -15,6 +15,7 @@ import math
 import torch
 import torch.nn.functional as F
 
+from . import functional as SF
 from . import ops
 
 # bf16 training: the first encoder layer as one hand-ordered forward / backward chain (EncoderLayer0Bf16Fn) instead of the generic
@@ -126,7 +127,7 @@ class SparseAttnFn(torch.autograd.Function):
             return out, p
         if bf16_operands and ops.mfma_attn_supported(k, dk):
             out, p, _ = ops.sparse_attn_fwd_mfma(q.to(torch.bfloat16), v.to(torch.bfloat16), kp, n, h, need_attn=True)
-        elif ops.x3_attn_supported(k, dk):
+        elif ops.x3_attn_supported(k, dk) and SF.FP32_ATTENTION != "exact":
             out, p, _ = ops.sparse_attn_fwd_x3(q, v, kp, h, need_attn=True)
         else:
             out, p, _ = ops.sparse_attn_fwd(q, kp, v, h, need_attn=True)
@@ -337,6 +338,7 @@ def encoder_layer_train(x2, sel, layer, need_attn, precision):
                                             lq.bias, lk.weight, lk.bias, lv.weight, lv.bias, lo.weight, lo.bias,
                                             ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias)
         return Parts(z), (attn.unsqueeze(0) if attn is not None else None)
+    layer._xhat_offer = None        # chain declined: a normalised copy the critic may have left must not outlive this bag
     # precision "bf16": the dense projections run under torch.autocast (bf16 operands, fp32 accumulate, fp32 master
     # weights); LayerNorm, softmax / attention and the residual stream stay fp32.
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(precision == "bf16")):

@@ -55,6 +55,13 @@ int snf_sparse_attn_fwd_mfma_dropout(const void* q, int64_t ldq, const void* v, 
                        MAX_CHUNKS * (dk == 128 ? 224 : 256));
         return SNF_EUNSUPPORTED;
     }
+    if (dropout_p > 0.f && cp.n_chunks > 1) {
+        // the in-register mask is keyed on the launch's own key index and the chunks' main passes differ in their outputs:
+        // the training shapes (k <= 224 / 256) are one chunk; more keys with dropout take the exact kernels + snf_dropout_mask_f32
+        snf::set_error("snf_sparse_attn_fwd_mfma: dropout is supported for one key chunk only (k <= %d at dk = %d), got k=%d",
+                       dk == 128 ? 224 : 256, dk, k);
+        return SNF_EUNSUPPORTED;
+    }
     const int64_t d = (int64_t)h * dk;
     if (ldq >= (1 << 24) || ldv >= (1 << 24) || n * (ldq > ldv ? ldq : ldv) >= 0x7fffffffll) {
         snf::set_error("snf_sparse_attn_fwd_mfma: n * row pitch = %lld elements exceeds the 32-bit offsets of the kernel",

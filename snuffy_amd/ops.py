@@ -457,6 +457,12 @@ def mfma_attn_supported(k, dk, n=None, ld=None):
     return True
 
 
+def mfma_attn_dropout_supported(k, dk):
+    """In-kernel Philox dropout (forward and the MFMA backward) covers ONE key chunk; more keys use the exact kernels with
+    the mask tensor of dropout_mask()."""
+    return (dk == 64 and 1 <= k <= 256) or (dk == 128 and 1 <= k <= 224)
+
+
 def _rows16(t, name):
     """[n, d] view whose rows are unit-stride and 16-byte aligned (e.g. one half of a fused projection output): the
     kernels take a row pitch, so such views are used in place.  Anything else is made contiguous."""
@@ -571,6 +577,9 @@ def sparse_attn_fwd_mfma(q, v, kp, n, h, scale=None, need_attn=False, need_lse=F
     dt = DT_F32 if q.dtype == torch.float32 else DT_BF16
     kdt = DT_F32 if kp.dtype == torch.float32 else DT_BF16
     pdrop, seed, offset = dropout if dropout is not None else (0.0, 0, 0)
+    if pdrop > 0 and not mfma_attn_dropout_supported(k, dk):
+        raise ValueError("sparse_attn_fwd_mfma: in-kernel dropout needs a single key chunk (k <= %d at dk = %d), got k = %d"
+                         % (224 if dk == 128 else 256, dk, k))
     check(lib.snf_sparse_attn_fwd_mfma_dropout(_p(q), q.stride(0), _p(v), v.stride(0), dt, _p(kp), kdt, n, k, h, dk, float(scale),
                                                _p(out), _p(attn), _p(lse), float(pdrop), int(seed) & (2 ** 64 - 1),
                                                int(offset) & (2 ** 64 - 1), _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_mfma")

@@ -270,6 +270,8 @@ class MILNet(nn.Module):
         return self._forward_eager(x)
 
     def _forward_eager(self, x):
+        for layer in self.b_classifier.encoder.layers[:1]:
+            layer._xhat_offer = None        # a normalised copy left by an earlier forward is never valid for this bag
         feats, classes = self._critic(x)
         prediction_bag, A = self.b_classifier(feats, classes)
         return classes, prediction_bag, A
@@ -394,3 +396,15 @@ class MILNet(nn.Module):
                 s = SA.critic_train(x[0], lin.weight, lin.bias, layer0, layer0.sublayer[0].norm.eps)
                 return x, s.view(1, x.shape[1], -1)
         return ic(x)
+
+
+def build_milnet(feats_size, num_heads, activation="relu", big_lambda=200, random_patch_share=0.0, depth=1, num_classes=1,
+                 mlp_multiplier=4, encoder_dropout=0.0):
+    """MILNet assembled in the order of the reference's train.Snuffy._get_milnet (train.py:861-890): critic FCLayer,
+    MultiHeadedAttention (its dropout left at the default 0.1, as train.py:866-869 does), PositionwiseFeedForward,
+    `depth` deep-copied EncoderLayers, BClassifier.  Weights are whatever the constructors leave (callers initialise)."""
+    i_classifier = FCLayer(in_size=feats_size, out_size=num_classes)
+    attn = MultiHeadedAttention(num_heads, feats_size)
+    ff = PositionwiseFeedForward(feats_size, feats_size * mlp_multiplier, activation, encoder_dropout)
+    layer = EncoderLayer(feats_size, copy.deepcopy(attn), copy.deepcopy(ff), encoder_dropout, big_lambda, random_patch_share)
+    return MILNet(i_classifier, BClassifier(Encoder(layer, depth), num_classes, feats_size))

@@ -43,16 +43,8 @@ class ReplayRNG:
 
 def build_amd_milnet(D, h, act, big_lambda, r, depth, C=1, mlp=4, enc_drop=0.0):
     """Same construction sequence as the reference's train.Snuffy._get_milnet (train.py:861-890)."""
-    import copy
-
     from snuffy_amd import snuffy
-    i_classifier = snuffy.FCLayer(in_size=D, out_size=C)
-    attn = snuffy.MultiHeadedAttention(h, D)
-    ff = snuffy.PositionwiseFeedForward(D, D * mlp, act, enc_drop)
-    b_classifier = snuffy.BClassifier(
-        snuffy.Encoder(snuffy.EncoderLayer(D, copy.deepcopy(attn), copy.deepcopy(ff), enc_drop, big_lambda, r), depth),
-        C, D)
-    return snuffy.MILNet(i_classifier, b_classifier)
+    return snuffy.build_milnet(D, h, act, big_lambda, r, depth, C, mlp, enc_drop)
 
 
 def rel_err(a, b):
