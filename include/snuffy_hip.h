@@ -68,6 +68,8 @@ int snf_critic_ln_f32(const float* x, int64_t n, int d, const float* w, const fl
  *   order, ties by ascending index (== torch.sort(stable=True, descending=True)[:k]); -0.0 == +0.0; NaN sorts
  *   first like torch.  Requires 1 <= k <= n, k <= SNF_TOPK_MAX_K.  One-workgroup radix select on the orderable 32-bit keys (three counting
  *   passes over register-resident keys, LDS integer atomics) + rank sort of the survivors: exact, deterministic.
+ *   Above 65536 scores (and with a workspace of snf_topk_workspace_bytes): histogram launch + the multi-workgroup
+ *   select of the fused selector below.
  * K4  fused gather  xs[j,:] = x[idx[j],:]      replaces index_select/cat, snuffy.py:131,145-147,103-106
  *   snf_topk_gather_f32 = selector then gather in one call (x, xs nullable -> selector only).
  * --------------------------------------------------------------------------------------------------------- */
@@ -79,6 +81,30 @@ int snf_topk_gather_f32(const float* scores, int64_t n, int64_t stride, int k, i
                         int d, float* xs, void* workspace, size_t workspace_bytes, snf_stream_t stream);
 int snf_gather_rows_f32(const float* x, int64_t n, int d, const int64_t* idx, int k, float* out,
                         snf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K1 + K2 fused selector                         FCLayer.forward + torch.sort(...)[:k], snuffy.py:39-41,128-130
+ *   The critic pass already touches every score it writes: snf_critic_select_f32 (one class; xhat_bf16 nullable, as
+ *   snf_critic_ln_f32 when given) also counts the first radix digit (top 11 bits of the orderable key) of each score
+ *   into a small replicated histogram inside `selector_state` -- integer atomics, exact and order-independent.
+ *   snf_topk_select_f32 then runs ceil(n / 4096) workgroups: each reads the histogram, finds the threshold digit,
+ *   classifies its slice and appends the scores above / inside the threshold bin to two short lists; the workgroup
+ *   that arrives last finishes the radix selection on the lists and writes idx_out (same order and tie rule as
+ *   snf_topk_f32, bit for bit).  A crowded threshold bin (> 4096 keys: massive ties) or a histogram whose total is
+ *   not n falls back, inside the same launch, to the exact one-workgroup selection on the scores.
+ *   selector_state: snf_selector_state_bytes() of device memory, 16-byte aligned, zeroed ONCE by the caller; every
+ *   snf_topk_select_f32 leaves it zeroed for the next bag (no memset in the pipeline).  One state per stream.
+ * --------------------------------------------------------------------------------------------------------- */
+size_t snf_selector_state_bytes(void);
+int snf_critic_select_f32(const float* x, int64_t n, int d, const float* w, const float* b, float* scores, float eps,
+                          void* xhat_bf16, void* selector_state, snf_stream_t stream);
+int snf_topk_select_f32(const float* scores, int64_t n, int k, int64_t* idx_out, void* selector_state,
+                        snf_stream_t stream);
+/* the same selection for scores that did NOT come out of snf_critic_select_f32 (any stride): clears the counted part of
+ * `state` (scratch, snf_selector_state_bytes), counts the first digit in its own launch, then selects.  snf_topk_f32
+ * takes this route above 65536 scores. */
+int snf_topk_hist_select_f32(const float* scores, int64_t n, int64_t stride, int k, int64_t* idx_out, void* state,
+                             snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K9  scatter of the K updated rows            replaces y = x.clone(); y[:, S, :] = x_sel, snuffy.py:152-155

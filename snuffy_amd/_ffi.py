@@ -37,6 +37,11 @@ SIGNATURES = {
     "snf_topk_gather_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                     c_size_t, c_void_p]),
     "snf_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "snf_selector_state_bytes": (c_size_t, []),
+    "snf_critic_select_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                      c_void_p]),
+    "snf_topk_select_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "snf_topk_hist_select_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "snf_scatter_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "snf_scatter_add_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "snf_slot_map_i32": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p]),

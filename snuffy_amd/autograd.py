@@ -302,10 +302,11 @@ class CriticFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2, w, b, layer, eps):
         if layer is not None:
-            s, xhat = ops.critic_ln(x2, w, b, eps)
+            s, xhat = ops.critic_select(x2, w, b, eps) or ops.critic_ln(x2, w, b, eps)
             layer._xhat_offer = (x2.data_ptr(), tuple(x2.shape), x2._version, float(eps), xhat)
         else:
-            s = ops.critic(x2, w, b)
+            fused = ops.critic_select(x2, w, b)
+            s = fused[0] if fused is not None else ops.critic(x2, w, b)
         ctx.save_for_backward(x2, w)
         ctx.has_bias = b is not None
         return s

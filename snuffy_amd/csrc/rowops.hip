@@ -8,6 +8,7 @@
 
 #include "common.h"
 #include "philox.h"
+#include "selector.h"
 
 namespace {
 
@@ -92,10 +93,18 @@ template <int VEC, int NV, bool LN>
 __global__ __launch_bounds__(WG) void critic_kernel(const float* __restrict__ x, int64_t n, int d,
                                                     const float* __restrict__ w, const float* __restrict__ b,
                                                     int c_out, float* __restrict__ scores, float eps,
-                                                    unsigned short* __restrict__ xhat) {
+                                                    unsigned short* __restrict__ xhat,
+                                                    unsigned int* __restrict__ sel_hist) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const float inv_d = 1.0f / (float)d;
+    // fused selector (sel_hist != null, c_out == 1): the first radix digit of every score this workgroup writes is counted in
+    // LDS and flushed once, at the end, into one of the global replicas -- integer atomics: exact and order-independent
+    __shared__ unsigned int s_hist[snf::SEL_BINS];
+    if (sel_hist) {
+        for (int i = threadIdx.x; i < snf::SEL_BINS; i += WG) s_hist[i] = 0;
+        __syncthreads();
+    }
     // class-0 weights stay in registers (the usual critic has ONE output), and the next row of x is requested before the
     // current one is reduced: the pass is bound by one HBM round trip per row and wave, not by bytes
     float w0[NV * VEC];
@@ -115,7 +124,10 @@ __global__ __launch_bounds__(WG) void critic_kernel(const float* __restrict__ x,
 #pragma unroll
             for (int i = 0; i < NV * VEC; ++i) acc = fmaf(r[i], w0[i], acc);
             acc = wave_sum(acc);
-            if (lane == 0) scores[row * c_out] = acc + b0;
+            if (lane == 0) {
+                scores[row * c_out] = acc + b0;
+                if (sel_hist) atomicAdd(&s_hist[snf::orderable_desc(acc + b0) >> 21], 1u);
+            }
         }
         for (int c = 1; c < c_out; ++c) {
             float wr[NV * VEC];
@@ -146,6 +158,14 @@ __global__ __launch_bounds__(WG) void critic_kernel(const float* __restrict__ x,
 #pragma unroll
             for (int i = 0; i < NV * VEC; ++i) r[i] = (r[i] - mean) * rstd;
             store_row_bf16<VEC, NV>(xhat + row * d, d, lane, r);
+        }
+    }
+    if (sel_hist) {
+        __syncthreads();
+        unsigned int* g = sel_hist + (blockIdx.x & (snf::SEL_REPL - 1)) * snf::SEL_BINS;
+        for (int i = threadIdx.x; i < snf::SEL_BINS; i += WG) {
+            const unsigned int c = s_hist[i];
+            if (c) __hip_atomic_fetch_add(&g[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -1000,7 +1020,7 @@ int snf_critic_f32(const float* x, int64_t n, int d, const float* w, const float
     SNF_REQUIRE(pick_row_cfg(d, aligned16(x) && aligned16(w), &cfg), "snf_critic_f32: d=%d too wide (max 2048)", d);
     hipStream_t s = snf::as_stream(stream);
     SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((critic_kernel<VEC, NV, false>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w,
-                                              b, c_out, scores, 0.f, (unsigned short*)nullptr));
+                                              b, c_out, scores, 0.f, (unsigned short*)nullptr, (unsigned int*)nullptr));
     int rc = snf::check_launch("critic_kernel");
     if (rc) return rc;
     if (colmax_val || colmax_idx) {
@@ -1019,8 +1039,29 @@ int snf_critic_ln_f32(const float* x, int64_t n, int d, const float* w, const fl
                 "snf_critic_ln_f32: d=%d too wide (max 2048)", d);
     hipStream_t s = snf::as_stream(stream);
     SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((critic_kernel<VEC, NV, true>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w,
-                                              b, c_out, scores, eps, reinterpret_cast<unsigned short*>(xhat_bf16)));
+                                              b, c_out, scores, eps, reinterpret_cast<unsigned short*>(xhat_bf16),
+                                              (unsigned int*)nullptr));
     return snf::check_launch("critic_kernel<ln>");
+}
+
+int snf_critic_select_f32(const float* x, int64_t n, int d, const float* w, const float* b, float* scores, float eps,
+                          void* xhat_bf16, void* selector_state, snf_stream_t stream) {
+    SNF_REQUIRE(x && w && scores && selector_state, "snf_critic_select_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && d >= 1, "snf_critic_select_f32: bad shape n=%lld d=%d", (long long)n, d);
+    SNF_REQUIRE(aligned16(selector_state), "snf_critic_select_f32: state must be 16-byte aligned");
+    RowCfg cfg;
+    SNF_REQUIRE(pick_row_cfg(d, aligned16(x) && aligned16(w) && (!xhat_bf16 || aligned16(xhat_bf16)), &cfg),
+                "snf_critic_select_f32: d=%d too wide (max 2048)", d);
+    hipStream_t s = snf::as_stream(stream);
+    unsigned int* hist = reinterpret_cast<snf::SelectorState*>(selector_state)->hist;
+    if (xhat_bf16) {
+        SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((critic_kernel<VEC, NV, true>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w, b,
+                                                  1, scores, eps, reinterpret_cast<unsigned short*>(xhat_bf16), hist));
+    } else {
+        SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((critic_kernel<VEC, NV, false>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w,
+                                                  b, 1, scores, 0.f, (unsigned short*)nullptr, hist));
+    }
+    return snf::check_launch("critic_kernel<select>");
 }
 
 int snf_layernorm_rows_f32(const float* x, int64_t n, int d, const int32_t* slot_map, const float* patch_rows,

@@ -6,17 +6,17 @@
 // (orderable(score) << 32) | ~index.  Integer compares and integer LDS atomics only -- bit-exact on every run.
 // (History: a multi-round chunked bitonic sort, 60 us at n = 32768, then a register/shuffle bitonic network for n <= 4096
 // -- 29 us at any size, against 11 us for the radix select -- both gone.)
-#include "common.h"
+//
+// Two forms.  (1) ONE workgroup, everything in its LDS / registers (topk_radix_kernel): any n, the form behind snf_topk_f32 up
+// to 64 k scores.  (2) The fused selector (topk_select_kernel): the critic pass that writes the scores has already counted the
+// first radix digit of every key into a small global histogram (selector.h); ceil(n / 4096) workgroups read that histogram,
+// classify their slice (above the threshold bin / inside it) and append the few hundred survivors to two short lists; the
+// workgroup that arrives last finishes the selection on those lists alone.  Same result, bit for bit.
+#include "selector.h"
 
 namespace {
 
-
-__device__ __forceinline__ unsigned int orderable_desc(float f) {
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;  // NaN sorts first (torch semantics)
-    if (u == 0x80000000u) u = 0u;                               // -0.0 == +0.0
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
+using snf::orderable_desc;
 
 // ---------------------------------------------------------------------------------------------------------------
 // Radix select: ONE workgroup, O(n) work.  Three counting passes (11 + 11 + 10 bits of the orderable key, LDS
@@ -57,10 +57,70 @@ __device__ __forceinline__ unsigned int block_excl_scan_1024(unsigned int v, uns
 // IPT > 0: n <= 1024 * IPT and every thread keeps its IPT keys in registers -- the scores are read from memory ONCE (all
 // loads in flight together) instead of once per counting pass plus once for the collection; one workgroup pays a full
 // memory latency per dependent read round, which is what this kernel's time is made of.  IPT == 0: streaming form, any n.
-template <int IPT>
-__global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restrict__ scores, int64_t n, int64_t stride, int k,
-                                                          int64_t* __restrict__ idx_out) {
+// order the k survivors in sel[] (descending composite == descending score, ascending index) and write their indices
+__device__ __forceinline__ void sort_emit(unsigned long long* sel, int k, int64_t* __restrict__ idx_out) {
+    const int tid = threadIdx.x;
+    if (k <= 512) {
+        // rank sort: the composites are distinct, so #(greater) IS the output position.  k broadcast LDS reads per thread and
+        // no further barrier -- the bitonic network below costs log2(k)^2 / 2 workgroup barriers (36 at k = 200).
+        // `parts` adjacent lanes share one survivor (k * parts <= 1024): each counts over a strided quarter of the list, four
+        // independent LDS reads per trip (one dependent read per trip is a full LDS latency each), then a lane-group sum
+        const int parts = k <= 128 ? 8 : (k <= 256 ? 4 : 2);
+        const int cand = tid / parts, part = tid % parts;
+        const unsigned long long mine = cand < k ? sel[cand] : ~0ull;
+        int rank = 0, j2 = part;
+        for (; j2 + 3 * parts < k; j2 += 4 * parts) {
+            const unsigned long long v0 = sel[j2], v1 = sel[j2 + parts], v2 = sel[j2 + 2 * parts], v3 = sel[j2 + 3 * parts];
+            rank += (v0 > mine) + (v1 > mine) + (v2 > mine) + (v3 > mine);
+        }
+        for (; j2 < k; j2 += parts) rank += (sel[j2] > mine) ? 1 : 0;
+        for (int o = 1; o < parts; o <<= 1) rank += __shfl_xor(rank, o, 64);
+        if (cand < k && part == 0) idx_out[rank] = (int64_t)(0xffffffffu - (unsigned int)(mine & 0xffffffffull));
+        return;
+    }
+    int p2 = 1;
+    while (p2 < k) p2 <<= 1;
+    for (int i = k + tid; i < p2; i += 1024) sel[i] = 0ull;
+    for (int size = 2; size <= p2; size <<= 1) {
+        for (int st = size >> 1; st > 0; st >>= 1) {
+            __syncthreads();
+            for (int p = tid; p < p2 / 2; p += 1024) {
+                const int lo = 2 * p - (p & (st - 1));
+                const int hi = lo + st;
+                const bool desc = (lo & size) == 0;
+                const unsigned long long a = sel[lo], b = sel[hi];
+                if (desc ? (a < b) : (a > b)) {
+                    sel[lo] = b;
+                    sel[hi] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < k; j += 1024) idx_out[j] = (int64_t)(0xffffffffu - (unsigned int)(sel[j] & 0xffffffffull));
+}
+
+// LDS of one selection: histogram words (4 x 2048 in the register form, 2048 otherwise), the survivor list, scan scratch
+template <int HIST_WORDS>
+struct TopkLds {
+    __attribute__((aligned(16))) unsigned int hist[HIST_WORDS];
+    unsigned long long sel[RS_MAXK];
+    unsigned int wave_tot[16];
+    unsigned int s_digit, s_above, s_cnt_sel, s_eq_base, s_a, s_b, s_c, s_d;
+};
+
+template <int IPT, int HIST_WORDS>
+__device__ __forceinline__ void topk_radix_body(const float* __restrict__ scores, int64_t n, int64_t stride, int k,
+                                                int64_t* __restrict__ idx_out, TopkLds<HIST_WORDS>& L) {
     constexpr bool REG = IPT > 0;
+    static_assert(HIST_WORDS >= (REG ? 4 * 2048 : 2048), "histogram too small");
+    unsigned int* const hist = L.hist;
+    unsigned long long* const sel = L.sel;
+    unsigned int* const wave_tot = L.wave_tot;
+    unsigned int& s_digit = L.s_digit;
+    unsigned int& s_above = L.s_above;
+    unsigned int& s_cnt_sel = L.s_cnt_sel;
+    unsigned int& s_eq_base = L.s_eq_base;
     // Register form: slots past n hold the key 0, which no score maps to (the smallest orderable key, -inf, is 0x007fffff)
     // and which sits alone in digit 0 of the first pass -- it can never be selected (k <= n), never matches a later prefix
     // and never passes the final threshold, so the per-key loops below carry no bounds test.
@@ -104,10 +164,6 @@ __global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restric
     }
     // first pass: 4 replicas interleaved per digit (word 4 d + lane % 4; 8 replicas measured slower) -- real scores crowd into a few dozen of the 2048
     // (sign, exponent, 2 mantissa bits) bins, and lanes adding to the SAME word serialise; later passes use words 0..2047
-    __shared__ __attribute__((aligned(16))) unsigned int hist[REG ? 4 * 2048 : 2048];
-    __shared__ unsigned long long sel[RS_MAXK];
-    __shared__ unsigned int wave_tot[16];
-    __shared__ unsigned int s_digit, s_above, s_cnt_sel, s_eq_base;
     const int tid = threadIdx.x;
     unsigned int prefix = 0, mask = 0, krem = (unsigned int)k, cnt_eq = 0;
     const int shifts[3] = {21, 10, 0};
@@ -245,46 +301,205 @@ __global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restric
     }
     __syncthreads();
     TSTAMP(9);
-    // order the k survivors (descending composite == descending score, ascending index)
-    if (k <= 512) {
-        // rank sort: the composites are distinct, so #(greater) IS the output position.  k broadcast LDS reads per thread and
-        // no further barrier -- the bitonic network below costs log2(k)^2 / 2 workgroup barriers (36 at k = 200).
-        // `parts` adjacent lanes share one survivor (k * parts <= 1024): each counts over a strided quarter of the list, four
-        // independent LDS reads per trip (one dependent read per trip is a full LDS latency each), then a lane-group sum
-        const int parts = k <= 128 ? 8 : (k <= 256 ? 4 : 2);
-        const int cand = tid / parts, part = tid % parts;
-        const unsigned long long mine = cand < k ? sel[cand] : ~0ull;
-        int rank = 0, j2 = part;
-        for (; j2 + 3 * parts < k; j2 += 4 * parts) {
-            const unsigned long long v0 = sel[j2], v1 = sel[j2 + parts], v2 = sel[j2 + 2 * parts], v3 = sel[j2 + 3 * parts];
-            rank += (v0 > mine) + (v1 > mine) + (v2 > mine) + (v3 > mine);
-        }
-        for (; j2 < k; j2 += parts) rank += (sel[j2] > mine) ? 1 : 0;
-        for (int o = 1; o < parts; o <<= 1) rank += __shfl_xor(rank, o, 64);
-        if (cand < k && part == 0) idx_out[rank] = (int64_t)(0xffffffffu - (unsigned int)(mine & 0xffffffffull));
-        TSTAMP(10);
-        return;
+    sort_emit(sel, k, idx_out);
+    TSTAMP(10);
+}
+
+template <int IPT>
+__global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restrict__ scores, int64_t n, int64_t stride, int k,
+                                                          int64_t* __restrict__ idx_out) {
+    __shared__ TopkLds<(IPT > 0) ? 4 * 2048 : 2048> L;
+    topk_radix_body<IPT>(scores, n, stride, k, idx_out, L);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused selector (form 2)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SEL_SLICE = 4096;   // scores per workgroup: 4 consecutive per thread
+
+// first-digit histogram of a score vector that did not come out of the critic pass (snf_topk_f32 above 64 k scores)
+__global__ __launch_bounds__(1024) void sel_hist_kernel(const float* __restrict__ scores, int64_t n, int64_t stride,
+                                                        snf::SelectorState* __restrict__ st) {
+    __shared__ unsigned int hist[snf::SEL_BINS];
+    const int tid = threadIdx.x;
+    hist[2 * tid] = 0;
+    hist[2 * tid + 1] = 0;
+    __syncthreads();
+    const int64_t base = ((int64_t)blockIdx.x * 1024 + tid) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (base + e < n) atomicAdd(&hist[orderable_desc(scores[(base + e) * stride]) >> 21], 1u);
+    __syncthreads();
+    unsigned int* g = st->hist + (blockIdx.x & (snf::SEL_REPL - 1)) * snf::SEL_BINS;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const unsigned int c = hist[2 * tid + e];
+        if (c) __hip_atomic_fetch_add(&g[2 * tid + e], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    int p2 = 1;
-    while (p2 < k) p2 <<= 1;
-    for (int i = k + tid; i < p2; i += 1024) sel[i] = 0ull;
-    for (int size = 2; size <= p2; size <<= 1) {
-        for (int st = size >> 1; st > 0; st >>= 1) {
-            __syncthreads();
-            for (int p = tid; p < p2 / 2; p += 1024) {
-                const int lo = 2 * p - (p & (st - 1));
-                const int hi = lo + st;
-                const bool desc = (lo & size) == 0;
-                const unsigned long long a = sel[lo], b = sel[hi];
-                if (desc ? (a < b) : (a > b)) {
-                    sel[lo] = b;
-                    sel[hi] = a;
-                }
+}
+
+__global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restrict__ scores, int64_t n, int64_t stride, int k,
+                                                           int64_t* __restrict__ idx_out,
+                                                           snf::SelectorState* __restrict__ st) {
+    __shared__ TopkLds<2048> L;
+    const int tid = threadIdx.x;
+    // this workgroup's slice of the scores, requested before anything else
+    const int64_t base = ((int64_t)blockIdx.x * 1024 + tid) * 4;
+    unsigned int key[4];
+    if (stride == 1 && base + 3 < n && (reinterpret_cast<uintptr_t>(scores) & 15) == 0) {
+        const float4 f = *reinterpret_cast<const float4*>(scores + base);
+        key[0] = orderable_desc(f.x);
+        key[1] = orderable_desc(f.y);
+        key[2] = orderable_desc(f.z);
+        key[3] = orderable_desc(f.w);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) key[e] = (base + e < n) ? orderable_desc(scores[(base + e) * stride]) : 0u;   // key 0: no score
+    }
+    // ---- the first digit's histogram: thread t owns bins 2t, 2t + 1 (summed over the replicas)
+    unsigned int own[2] = {0u, 0u};
+#pragma unroll
+    for (int r = 0; r < snf::SEL_REPL; ++r) {
+        const uint2 h = *reinterpret_cast<const uint2*>(&st->hist[r * snf::SEL_BINS + 2 * tid]);
+        own[0] += h.x;
+        own[1] += h.y;
+    }
+    if (tid == 0) {
+        L.s_a = 0;   // winners of this workgroup
+        L.s_b = 0;   // candidates of this workgroup
+        L.s_digit = 0;
+        L.s_above = 0;
+        L.s_cnt_sel = 0;
+    }
+    const unsigned int local = own[0] + own[1];
+    unsigned int total;
+    const unsigned int below = block_excl_scan_1024(local, L.wave_tot, &total);
+    {
+        unsigned int s_hi = total - below - local;   // keys in the bins above this thread's
+#pragma unroll
+        for (int e = 1; e >= 0; --e) {
+            const unsigned int s_d = s_hi + own[e];   // S(d) = #keys with first digit >= d
+            if (s_d >= (unsigned int)k && s_hi < (unsigned int)k) {
+                L.s_digit = (unsigned int)(2 * tid + e);
+                L.s_above = s_hi;
+                L.s_cnt_sel = own[e];
             }
+            s_hi = s_d;
         }
     }
     __syncthreads();
-    for (int j = tid; j < k; j += 1024) idx_out[j] = (int64_t)(0xffffffffu - (unsigned int)(sel[j] & 0xffffffffull));
+    const unsigned int bstar = L.s_digit, n_above = L.s_above, cnt_eq0 = L.s_cnt_sel;
+    // every workgroup reads the same histogram, so all of them take the same decision.  total != n: the state was left dirty
+    // by an aborted call; a crowded threshold bin (massive ties): both go to the exact one-workgroup selection on the scores
+    const bool fast = total == (unsigned int)n && cnt_eq0 <= (unsigned int)snf::SEL_CAND_CAP;
+    if (fast) {
+        unsigned int pw[4], pc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned int d = key[e] >> 21;
+            pw[e] = pc[e] = 0xffffffffu;
+            if (d > bstar) pw[e] = atomicAdd(&L.s_a, 1u);
+            else if (d == bstar) pc[e] = atomicAdd(&L.s_b, 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            L.s_c = L.s_a ? __hip_atomic_fetch_add(&st->n_win, L.s_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            L.s_d = L.s_b ? __hip_atomic_fetch_add(&st->n_cand, L.s_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        }
+        __syncthreads();
+        const unsigned int bw = L.s_c, bc = L.s_d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned long long comp = ((unsigned long long)key[e] << 32) | (unsigned long long)(0xffffffffu - (unsigned int)(base + e));
+            // 8-byte agent-scope stores: written through to where every other CU reads them (no release fence needed)
+            if (pw[e] != 0xffffffffu && bw + pw[e] < (unsigned int)snf::SEL_MAXK)
+                __hip_atomic_store(&st->win[bw + pw[e]], comp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pc[e] != 0xffffffffu && bc + pc[e] < (unsigned int)snf::SEL_CAND_CAP)
+                __hip_atomic_store(&st->cand[bc + pc[e]], comp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- arrive; the last workgroup finishes alone
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int ticket = __hip_atomic_fetch_add(&st->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        L.s_eq_base = (ticket == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!L.s_eq_base) return;
+    if (fast) {
+        // candidates of the threshold bin in registers (<= 4 per thread), read where the other workgroups wrote them
+        unsigned long long c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned int j = (unsigned int)tid + 1024u * (unsigned int)u;
+            c[u] = j < cnt_eq0 ? __hip_atomic_load(&st->cand[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+        for (unsigned int j = tid; j < n_above; j += 1024)
+            L.sel[j] = __hip_atomic_load(&st->win[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // radix select on the remaining digits of the 64-bit composite (key << 32 | ~index): the low word orders equal keys by
+        // ascending index, so a tie that straddles the k-th place is resolved by the same loop; it ends as soon as the whole
+        // remaining class is taken (normally after the two key digits)
+        unsigned long long prefix = (unsigned long long)bstar << 53, mask = 0x7ffull << 53;
+        unsigned int krem = (unsigned int)k - n_above, cnt_eq = cnt_eq0;
+        const int shifts[5] = {42, 32, 21, 10, 0};
+        const int nbits[5] = {11, 10, 11, 11, 10};
+        for (int pass = 0; pass < 5 && cnt_eq != krem; ++pass) {
+            const int shift = shifts[pass];
+            const unsigned int nb = 1u << nbits[pass];
+            L.hist[2 * tid] = 0;
+            L.hist[2 * tid + 1] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if ((c[u] & mask) == prefix) atomicAdd(&L.hist[(unsigned int)(c[u] >> shift) & (nb - 1)], 1u);
+            __syncthreads();
+            const int dpt = (int)(nb / 1024);
+            unsigned int o2[2] = {0, 0}, loc = 0;
+            for (int e = 0; e < dpt; ++e) {
+                o2[e] = L.hist[dpt * tid + e];
+                loc += o2[e];
+            }
+            unsigned int tot;
+            const unsigned int bel = block_excl_scan_1024(loc, L.wave_tot, &tot);
+            unsigned int s_hi = tot - bel - loc;
+            for (int e = dpt - 1; e >= 0; --e) {
+                const unsigned int s_d = s_hi + o2[e];
+                if (s_d >= krem && s_hi < krem) {
+                    L.s_digit = (unsigned int)(dpt * tid + e);
+                    L.s_above = s_hi;
+                }
+                s_hi = s_d;
+            }
+            __syncthreads();
+            cnt_eq = L.hist[L.s_digit];
+            prefix |= (unsigned long long)L.s_digit << shift;
+            mask |= (unsigned long long)(nb - 1) << shift;
+            krem -= L.s_above;
+            __syncthreads();
+        }
+        if (tid == 0) L.s_cnt_sel = n_above;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c[u] != 0ull && (c[u] & mask) >= prefix) {
+                const unsigned int pos = atomicAdd(&L.s_cnt_sel, 1u);
+                if (pos < (unsigned int)RS_MAXK) L.sel[pos] = c[u];
+            }
+        __syncthreads();
+        sort_emit(L.sel, k, idx_out);
+    } else {
+        topk_radix_body<0>(scores, n, stride, k, idx_out, L);
+        if (tid == 0) st->fallbacks += 1;
+    }
+    // leave the counted state zeroed for the next call (nobody else reads or writes it any more)
+    uint4* hz = reinterpret_cast<uint4*>(st->hist);
+    for (int i = tid; i < snf::SEL_REPL * snf::SEL_BINS / 4; i += 1024) hz[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == 0) {
+        st->n_win = 0;
+        st->n_cand = 0;
+        st->arrive = 0;
+    }
 }
 
 }  // namespace
@@ -295,10 +510,50 @@ extern "C" {
 void snf_debug_topk_trace(unsigned long long* host16) { (void)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_topk_trace), 16 * sizeof(unsigned long long)); }
 #endif
 
+// above this many scores snf_topk_f32 takes the multi-workgroup form (histogram launch + select launch); below it the one
+// workgroup with its keys in registers is as fast or faster (15 us at 32 k scores vs 61 us for the streaming form at 100 k)
+constexpr int64_t TOPK_SINGLE_WG_MAX_N = 65536;
+
+size_t snf_selector_state_bytes(void) { return sizeof(snf::SelectorState); }
+
 size_t snf_topk_workspace_bytes(int64_t n, int k) {
-    (void)n;
     (void)k;
-    return 0;   // the radix-select path keeps its state in LDS; kept in the ABI for forward compatibility
+    return n > TOPK_SINGLE_WG_MAX_N ? sizeof(snf::SelectorState) : 0;   // small inputs keep their state in LDS
+}
+
+static int launch_select(const float* scores, int64_t n, int64_t stride, int k, int64_t* idx_out, snf::SelectorState* st,
+                         hipStream_t s) {
+    const unsigned grid = (unsigned)((n + SEL_SLICE - 1) / SEL_SLICE);
+    hipLaunchKernelGGL(topk_select_kernel, dim3(grid), dim3(1024), 0, s, scores, n, stride, k, idx_out, st);
+    return snf::check_launch("topk_select_kernel");
+}
+
+int snf_topk_select_f32(const float* scores, int64_t n, int k, int64_t* idx_out, void* selector_state, snf_stream_t stream) {
+    SNF_REQUIRE(scores && idx_out && selector_state, "snf_topk_select_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && n < 0x3fffffffll, "snf_topk_select_f32: bad n=%lld", (long long)n);
+    SNF_REQUIRE(k >= 1 && k <= n && k <= RS_MAXK, "snf_topk_select_f32: need 1 <= k <= min(n, %d) (k=%d n=%lld)", RS_MAXK, k,
+                (long long)n);
+    SNF_REQUIRE((reinterpret_cast<uintptr_t>(selector_state) & 15) == 0, "snf_topk_select_f32: state must be 16-byte aligned");
+    return launch_select(scores, n, 1, k, idx_out, reinterpret_cast<snf::SelectorState*>(selector_state), snf::as_stream(stream));
+}
+
+int snf_topk_hist_select_f32(const float* scores, int64_t n, int64_t stride, int k, int64_t* idx_out, void* state,
+                             snf_stream_t stream) {
+    SNF_REQUIRE(scores && idx_out && state, "snf_topk_hist_select_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && n < 0x3fffffffll && stride >= 1, "snf_topk_hist_select_f32: bad n=%lld stride=%lld", (long long)n,
+                (long long)stride);
+    SNF_REQUIRE(k >= 1 && k <= n && k <= RS_MAXK, "snf_topk_hist_select_f32: need 1 <= k <= min(n, %d) (k=%d n=%lld)", RS_MAXK, k,
+                (long long)n);
+    SNF_REQUIRE((reinterpret_cast<uintptr_t>(state) & 15) == 0, "snf_topk_hist_select_f32: state must be 16-byte aligned");
+    hipStream_t s = snf::as_stream(stream);
+    // scratch state: clear the counted part, count the first digit of every score, select
+    snf::SelectorState* st = reinterpret_cast<snf::SelectorState*>(state);
+    if (hipMemsetAsync(st, 0, offsetof(snf::SelectorState, win), s) != hipSuccess) return snf::check_launch("hipMemsetAsync");
+    const unsigned grid = (unsigned)((n + SEL_SLICE - 1) / SEL_SLICE);
+    hipLaunchKernelGGL(sel_hist_kernel, dim3(grid), dim3(1024), 0, s, scores, n, stride, st);
+    int rc = snf::check_launch("sel_hist_kernel");
+    if (rc) return rc;
+    return launch_select(scores, n, stride, k, idx_out, st, s);
 }
 
 int snf_topk_f32(const float* scores, int64_t n, int64_t stride, int k, int64_t* idx_out, void* workspace,
@@ -307,13 +562,16 @@ int snf_topk_f32(const float* scores, int64_t n, int64_t stride, int k, int64_t*
     SNF_REQUIRE(n >= 1 && stride >= 1, "snf_topk_f32: bad n=%lld stride=%lld", (long long)n, (long long)stride);
     SNF_REQUIRE(k >= 1 && k <= n, "snf_topk_f32: need 1 <= k <= n (k=%d n=%lld)", k, (long long)n);
     SNF_REQUIRE(k <= SNF_TOPK_MAX_K, "snf_topk_f32: k=%d exceeds SNF_TOPK_MAX_K=%d", k, SNF_TOPK_MAX_K);
-    SNF_REQUIRE(n < 0xffffffffll, "snf_topk_f32: n too large");
+    SNF_REQUIRE(n < 0x3fffffffll, "snf_topk_f32: n too large");
     hipStream_t s = snf::as_stream(stream);
-    (void)workspace;
-    (void)workspace_bytes;
     SNF_REQUIRE(k <= RS_MAXK, "snf_topk_f32: k=%d exceeds %d", k, RS_MAXK);
+    if (n > TOPK_SINGLE_WG_MAX_N && workspace && workspace_bytes >= sizeof(snf::SelectorState) &&
+        (reinterpret_cast<uintptr_t>(workspace) & 15) == 0)
+        return snf_topk_hist_select_f32(scores, n, stride, k, idx_out, workspace, stream);
     if (n <= 1024 * 8)
         hipLaunchKernelGGL(topk_radix_kernel<8>, dim3(1), dim3(1024), 0, s, scores, n, stride, k, idx_out);
+    else if (n <= 1024 * 16)
+        hipLaunchKernelGGL(topk_radix_kernel<16>, dim3(1), dim3(1024), 0, s, scores, n, stride, k, idx_out);
     else if (n <= 1024 * 32)
         hipLaunchKernelGGL(topk_radix_kernel<32>, dim3(1), dim3(1024), 0, s, scores, n, stride, k, idx_out);
     else if (n <= 1024 * 64)

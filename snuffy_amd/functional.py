@@ -71,7 +71,8 @@ def critic_scores(feats, w, b):
         from . import autograd as SA
         s = SA.critic_train(f2, w, b)                    # training: library GEMV with autograd
     else:
-        s = ops.critic(f2, w, b)
+        fused = ops.critic_select(f2, w, b)              # one class, large bag: the selector's histogram rides in the pass
+        s = fused[0] if fused is not None else ops.critic(f2, w, b)
     return s.view(*lead, w.shape[0])
 
 
@@ -92,7 +93,7 @@ def critic_scores_with_xhat(feats, w, b, eps, layer):
     if f2.dtype != torch.float32 or not f2.is_contiguous():
         layer._xhat_offer = None
         return critic_scores(feats, w, b)             # a converted copy would not be the tensor the encoder sees
-    s, xhat = ops.critic_ln(f2, w, b, eps)
+    s, xhat = ops.critic_select(f2, w, b, eps) or ops.critic_ln(f2, w, b, eps)
     layer._xhat_offer = (f2.data_ptr(), tuple(f2.shape), f2._version, float(eps), xhat)
     return s.view(*lead, w.shape[0])
 

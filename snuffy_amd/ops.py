@@ -9,7 +9,7 @@ import math
 import torch
 
 from . import _ffi
-from ._ffi import ACT_CODES, DT_BF16, DT_BF16_SPLIT3, DT_F32, check
+from ._ffi import ACT_CODES, DT_BF16, DT_BF16_SPLIT3, DT_F32, TOPK_MAX_K, check
 
 
 def _p(t):
@@ -89,6 +89,58 @@ def critic_ln(x, w, b, eps):
     return scores, xhat
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# fused selector (snf_critic_select_f32 + snf_topk_select_f32): the critic pass counts the first radix digit of its scores
+# into a small device-resident state; the selection that follows starts from it.  One state per device (selections are
+# issued on torch's current stream, one after the other); `pending` remembers which score tensor the state describes.
+# ----------------------------------------------------------------------------------------------------------------------
+SELECT_FUSED_MIN_N = 16385       # up to 16 k scores the one-workgroup selection (keys in registers, 9-12 us) is as fast or faster
+_SELECTORS = {}
+
+
+class _Selector:
+    def __init__(self, device):
+        lib = _ffi.load()
+        self.nbytes = int(lib.snf_selector_state_bytes())
+        self.state = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)   # zeroed ONCE; every select re-zeroes it
+        self.pending = None
+
+
+def selector(device, create=True):
+    """The device's selector state; None while a HIP graph is being captured and none exists yet (allocate it outside)."""
+    sel = _SELECTORS.get(device.index)
+    if sel is None and create and not torch.cuda.is_current_stream_capturing():
+        sel = _SELECTORS[device.index] = _Selector(device)
+    return sel
+
+
+def critic_select(x, w, b, eps=None):
+    """The critic pass with the selector's histogram: scores [n, 1] f32 (and xhat [n, d] bf16, the affine-free LayerNorm of x,
+    when eps is given -- as critic_ln).  The following topk(scores.view(-1), k) finishes the selection from the histogram.
+    Returns (scores, xhat or None), or None when the fused form does not apply (then use critic / critic_ln)."""
+    if w.shape[0] != 1 or x.shape[0] < SELECT_FUSED_MIN_N or x.shape[0] >= (1 << 30):
+        return None
+    sel = selector(x.device)
+    if sel is None:
+        return None
+    x = _req(x, torch.float32, "x", 2)
+    w = _req(w, torch.float32, "w", 2)
+    if b is not None:
+        b = _req(b, torch.float32, "b", 1)
+    n, d = x.shape
+    if w.shape[1] != d:
+        raise ValueError("critic_select: w is %s but x has %d features" % (tuple(w.shape), d))
+    if sel.pending is not None:          # an earlier histogram was never consumed: start from a clean state
+        sel.state.zero_()
+        sel.pending = None
+    scores = torch.empty(n, 1, dtype=torch.float32, device=x.device)
+    xhat = torch.empty(n, d, dtype=torch.bfloat16, device=x.device) if eps is not None else None
+    check(_ffi.load().snf_critic_select_f32(_p(x), n, d, _p(w), _p(b), _p(scores), float(eps or 0.0), _p(xhat), _p(sel.state),
+                                            _stream()), "snf_critic_select_f32")
+    sel.pending = (scores.data_ptr(), n, scores._version)
+    return scores, xhat
+
+
 def topk(scores, k, x=None):
     """Indices of the k largest scores, descending, ties by ascending index (snuffy.py:128-130).
 
@@ -108,6 +160,14 @@ def topk(scores, k, x=None):
         raise ValueError("topk: need 1 <= k <= n (k=%d, n=%d)" % (k, n))
     lib = _ffi.load()
     idx = torch.empty(k, dtype=torch.int64, device=scores.device)
+    sel = _SELECTORS.get(scores.device.index)
+    if sel is not None and sel.pending is not None:
+        if x is None and stride == 1 and k <= TOPK_MAX_K and sel.pending == (scores.data_ptr(), n, scores._version):
+            # these scores came out of critic_select: their first-digit histogram is waiting in the selector state
+            _on_current_device(scores, "scores")
+            sel.pending = None
+            check(lib.snf_topk_select_f32(_p(scores), n, k, _p(idx), _p(sel.state), _stream()), "snf_topk_select_f32")
+            return idx
     wsb = lib.snf_topk_workspace_bytes(n, k)
     ws = _ws(wsb, scores.device)
     if x is None:
@@ -118,6 +178,20 @@ def topk(scores, k, x=None):
     check(lib.snf_topk_gather_f32(_p(scores), n, stride, k, _p(idx), _p(x), x.shape[1], _p(xs), _p(ws), wsb,
                                   _stream()), "snf_topk_gather_f32")
     return idx, xs
+
+
+def topk_hist_select(scores, k):
+    """topk() through the multi-workgroup form whatever n is (histogram launch + select launch on a scratch state)."""
+    if not scores.is_cuda or scores.dtype != torch.float32 or scores.dim() != 1:
+        raise TypeError("topk_hist_select: scores must be a 1-D float32 GPU tensor")
+    _on_current_device(scores, "scores")
+    n = scores.shape[0]
+    stride = scores.stride(0) if n > 1 else 1
+    lib = _ffi.load()
+    idx = torch.empty(int(k), dtype=torch.int64, device=scores.device)
+    st = _ws(lib.snf_selector_state_bytes(), scores.device)
+    check(lib.snf_topk_hist_select_f32(_p(scores), n, stride, int(k), _p(idx), _p(st), _stream()), "snf_topk_hist_select_f32")
+    return idx
 
 
 def gather_rows(x, idx):

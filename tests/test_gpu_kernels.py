@@ -60,6 +60,81 @@ def test_topk_strided_and_gather_and_nan():
     assert got[:2] == [17, 500]          # NaN first (torch.sort semantics), then +inf
 
 
+# ---------------------------------------------------------------- K1 + K2 fused selector: bit-exact, every path
+def _score_cases(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    c = torch.randn(n, generator=g)
+    yield "randn", c
+    t = c.clone()
+    m = min(t[::5].numel(), t[1::5].numel())
+    t[::5][:m] = t[1::5][:m]
+    yield "pair ties", t
+    yield "few values", torch.randint(0, 7, (n,), generator=g).float() - 3.0      # crowded threshold bin -> in-launch fallback
+    yield "all equal", torch.full((n,), 0.25)
+    if n >= 8:
+        sp = c.clone()
+        sp[n // 3] = float("nan")
+        sp[n // 2] = float("inf")
+        sp[n // 2 + 1] = float("-inf")
+        sp[5] = -0.0
+        sp[6] = 0.0
+        yield "specials", sp
+    yield "tiny spread", 1.0 + 1e-6 * torch.randn(n, generator=g)                 # every key in ONE first-digit bin
+
+
+@pytest.mark.parametrize("n", [1, 5, 4096, 4097, 12288, 32768, 100000, 300001])
+def test_topk_multi_workgroup_form_vs_oracle(n):
+    """snf_topk_hist_select_f32 (histogram launch + multi-workgroup select) against the stable descending order."""
+    for name, c in _score_cases(n, 11 * n + 1):
+        cd = c.to(DEV)
+        for k in sorted({1, min(n, 10), min(n, 200), min(n, 512), min(n, 2048)}):
+            want = orc.topk_desc_stable(c, k).numpy()
+            got = ops().topk_hist_select(cd, k).cpu().numpy()
+            assert np.array_equal(got, want), (name, n, k)
+    if n >= 8:                                        # strided scores (one class column of a multi-class critic)
+        c2 = torch.randn(n, 3, generator=torch.Generator().manual_seed(n))
+        k = min(n, 77)
+        assert np.array_equal(ops().topk_hist_select(c2.to(DEV)[:, 1], k).cpu().numpy(), orc.topk_desc_stable(c2[:, 1], k).numpy())
+
+
+@pytest.mark.parametrize("n,d,k", [(16385, 384, 200), (32768, 768, 200), (100000, 768, 512), (50000, 96, 2048)])
+def test_fused_selector_critic_plus_select(n, d, k):
+    """critic_select (scores + first-digit histogram in one pass over the bag, optionally the normalised bf16 copy) followed by
+    topk: the scores equal the plain critic's bit for bit and the selection equals the one-workgroup kernel's and the oracle's."""
+    o = ops()
+    g = torch.Generator().manual_seed(n + d)
+    x = torch.randn(n, d, generator=g).to(DEV)
+    w = (torch.randn(1, d, generator=g) / math.sqrt(d)).to(DEV)
+    b = torch.randn(1, generator=g).to(DEV)
+    s_ref = o.critic(x, w, b)
+    for eps in (None, 1e-5):
+        s, xhat = o.critic_select(x, w, b, eps)
+        assert torch.equal(s, s_ref)
+        if eps is not None:
+            assert torch.equal(xhat, o.critic_ln(x, w, b, eps)[1])
+        sel = o.selector(x.device)
+        assert sel.pending is not None
+        idx = o.topk(s.view(-1), k)
+        assert sel.pending is None                   # consumed by the fused select
+        assert np.array_equal(idx.cpu().numpy(), orc.topk_desc_stable(s_ref.view(-1).cpu(), k).numpy())
+        assert int(sel.state.view(torch.int32)[: 4 * 2048 + 3].abs().sum()) == 0      # counted part left zeroed
+    # a histogram that was never consumed (aborted forward) is noticed: first on the host side ...
+    s, _ = o.critic_select(x, w, b)
+    s2, _ = o.critic_select(x, w, b)
+    assert np.array_equal(o.topk(s2.view(-1), k).cpu().numpy(), orc.topk_desc_stable(s_ref.view(-1).cpu(), k).numpy())
+    # ... and, if the host lost track, inside the launch (total != n -> exact one-workgroup selection, state cleaned)
+    sel = o.selector(x.device)
+    before = int(sel.state.view(torch.int32)[4 * 2048 + 3])
+    s, _ = o.critic_select(x, w, b)
+    sel.pending = None
+    s3, _ = o.critic_select(x, w, b)                # adds a second histogram on top of the first
+    assert np.array_equal(o.topk(s3.view(-1), k).cpu().numpy(), orc.topk_desc_stable(s_ref.view(-1).cpu(), k).numpy())
+    assert int(sel.state.view(torch.int32)[4 * 2048 + 3]) == before + 1
+    s4, _ = o.critic_select(x, w, b)                # and the next bag is back on the fast path
+    assert np.array_equal(o.topk(s4.view(-1), k).cpu().numpy(), orc.topk_desc_stable(s_ref.view(-1).cpu(), k).numpy())
+    assert int(sel.state.view(torch.int32)[4 * 2048 + 3]) == before + 1
+
+
 # ---------------------------------------------------------------- K1 critic
 @pytest.mark.parametrize("n,d,c", [(1, 64, 1), (1000, 166, 1), (4099, 384, 2), (513, 768, 1), (100, 2048, 3)])
 def test_critic(n, d, c):
