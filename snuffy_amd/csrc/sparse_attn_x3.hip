@@ -9,17 +9,20 @@
 // tests/test_gpu_kernels.py; the exact vector-ALU kernel gives 4e-7 / 9e-7, the bf16 kernel 5e-3).
 // Softmax, the normalisation and all accumulation are fp32; P is split after the normalisation.
 //
-// The hi + lo images do not fit the two-role kernel's LDS budget (Kp alone is 112 KiB at 224 keys x 128), so this kernel is
-// organised differently: one workgroup (8 waves) per CU walks (head, 32-ROW tile) items and all 8 waves cooperate on a tile:
-//   stage   Q and V rows of the tile: fp32 from HBM one step ahead (registers), split and written as MFMA-shaped images
-//   GEMM1   wave w owns key block w (32 keys): S^T[key, row] = Kp Q^T, 3 MFMAs per 16-deep k-step, operands from LDS
+// Organisation (round 3): one workgroup (8 waves) per CU walks (head, 64-ROW tile) items and all 8 waves cooperate on a tile:
+//   Kp      wave w owns key block w (32 keys) and keeps its hi / lo MFMA fragments in REGISTERS for the whole head (64 VGPRs at
+//           dk = 128) -- a 112 KiB LDS image in the first version, which left room for 32-row tiles only
+//   stage   Q and V rows: fp32 from HBM two tiles ahead (registers), split and written as MFMA-shaped images one tile ahead
+//           (separate Q / P images, V double-buffered), while the current tile's P is being published
+//   GEMM1   S^T[key, row] = Kp Q^T for key block w and both 32-row blocks, 3 MFMAs per 16-deep k-step, the two blocks'
+//           accumulation chains interleaved (a dependent 32x32 MFMA waits for its predecessor)
 //   softmax every lane holds 16 keys of ONE row (C layout of the swapped product) -> block-local max / exp / sum, one
 //           (max, sum) pair per wave and row through LDS, combined exactly (as the key-chunked launches of the bf16 kernel)
-//   GEMM2   O[key, col] += P^T V over the tile's 32 rows: 28 output tiles of 32 x 32 spread over the 8 waves, both operands
+//   GEMM2   O[key, col] += P^T V over the tile's 64 rows: 28 output tiles of 32 x 32 spread over the 8 waves, both operands
 //           by hardware transpose-read (ds_read_b64_tr_b16) out of row-major images, 3 MFMAs per 16-row k-step
-// Four workgroup barriers per tile.  Accumulators stay in registers until the head changes; partial tiles are written in
-// fragment order and summed in ascending workgroup order by a second kernel (no float atomics: bit-reproducible).
-// LDS at dk = 128, 224 keys: Kp hi+lo 112 KiB | Q (later P) hi+lo 28 KiB | V hi+lo 16 KiB | row statistics 2 KiB = 158 KiB.
+// Three workgroup barriers per 64 rows (four per 32 before).  Accumulators stay in registers until the head changes; partial
+// tiles are written in fragment order and summed in ascending workgroup order by a second kernel (no float atomics).
+// LDS at dk = 128, 224 keys: Q hi+lo 32 KiB | P hi+lo 56 KiB | V 2 x (hi+lo) 64 KiB | row statistics 4 KiB = 156 KiB.
 #include <math.h>
 
 #include <type_traits>
@@ -58,7 +61,7 @@ struct X3Params {
     int tiles_per_head, tiles_per_wg, total_tiles, seg_count;
 };
 
-constexpr int TROWS = 32;   // query rows per step
+constexpr int TROWS = 64;   // query rows per step (two 32-row blocks)
 constexpr int p_row_bytes(int nkb) { return 64 * (nkb | 1); }   // odd multiple of 64 B (bank rule of the transpose-read)
 
 template <int I, int N, typename F>
@@ -99,29 +102,28 @@ __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __
 
 // MODE 0: one launch covers all keys.  MODE 1: statistics pass of one key chunk (GEMM1 + max / sum, nothing else).
 // MODE 2: main pass of one key chunk with the row statistics of ALL chunks taken from P.stats.
+//
+// Round 3 organisation: wave w keeps the hi / lo fragments of ITS key block in registers for a whole head (2 NKS fragments = 64
+// VGPRs at dk = 128) instead of re-reading them from a 112 KiB LDS image every tile.  The LDS that frees holds 64-ROW tiles with
+// separate Q, P and (double-buffered) V images, so a tile costs three workgroup barriers instead of four per 32 rows, the next
+// tile's rows are split and written while this tile's P is published, and their HBM loads have a whole tile of latency cover.
 template <int DK, int NKB, bool AUX, int MODE>
 __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
     constexpr int NKS = DK / 16;               // k-steps of GEMM1
     constexpr int NCB = DK / 32;               // 32-wide column blocks of the output
     constexpr int TILES = NKB * NCB;
     constexpr int NT = (TILES + 7) / 8;        // output tiles owned by one wave
+    constexpr int RB = TROWS / 32;             // 32-row blocks per tile
     constexpr int RS = p_row_bytes(NKB);       // row pitch of a P image
     constexpr int VRS = 2 * DK, NCH = DK / 8;  // row pitch of a V image, 16-byte chunks per row
-    constexpr int KP_BYTES = NKB * NKS * 1024;
-    constexpr int Q_BYTES = NKS * 1024, PI_BYTES = TROWS * RS;
-    constexpr int QP_BYTES = (Q_BYTES > PI_BYTES ? Q_BYTES : PI_BYTES);
-    constexpr int V_BYTES = TROWS * VRS;
+    constexpr int Q_BYTES = RB * NKS * 1024, PI_BYTES = TROWS * RS, V_BYTES = TROWS * VRS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4* lds_kph = reinterpret_cast<u32x4*>(smem);                       // [NKB][NKS][64] A fragments of Kp, hi
-    u32x4* lds_kpl = reinterpret_cast<u32x4*>(smem + KP_BYTES);            // lo
-    unsigned char* lds_qp = smem + 2 * KP_BYTES;                           // Q fragments hi | lo, later the P images hi | lo
-    u32x4* lds_qh = reinterpret_cast<u32x4*>(lds_qp);
-    u32x4* lds_ql = reinterpret_cast<u32x4*>(lds_qp + QP_BYTES);
-    unsigned char* lds_ph = lds_qp;
-    unsigned char* lds_pl = lds_qp + QP_BYTES;
-    unsigned char* lds_vh = lds_qp + 2 * QP_BYTES;                         // [32 rows][VRS] row-major, chunk-rotated
-    unsigned char* lds_vl = lds_vh + V_BYTES;
-    f32x2* lds_st = reinterpret_cast<f32x2*>(lds_vl + V_BYTES);            // [8 waves][32 rows] (max * c, sum)
+    u32x4* lds_qh = reinterpret_cast<u32x4*>(smem);                        // [RB][NKS][64] B fragments of Q, hi
+    u32x4* lds_ql = reinterpret_cast<u32x4*>(smem + Q_BYTES);              // lo
+    unsigned char* lds_ph = smem + 2 * Q_BYTES;                            // [64 rows][RS] row-major P, hi
+    unsigned char* lds_pl = lds_ph + PI_BYTES;                             // lo
+    unsigned char* lds_v = lds_pl + PI_BYTES;                              // [2 buffers][hi | lo][64 rows][VRS], chunk-rotated
+    f32x2* lds_st = reinterpret_cast<f32x2*>(lds_v + 4 * V_BYTES);         // [8 waves][64 rows] (max * c, sum)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,55 +139,74 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
     int a = first_head, t = f_begin - first_head * P.tiles_per_head;
     int cur_head = -1;
 
-    // ---- staging of one tile's Q and V rows: piece p of Q = B fragment (kb = p >> 6, lane' = p & 63: row lane' & 31,
-    //      8 k from 16 kb + 8 (lane' >> 5)); piece p of V = 8 columns (chunk p % NCH) of row p / NCH
-    constexpr int NQ = NKS * 64, NV = TROWS * NCH;         // 512 + 512 pieces at dk = 128, 256 + 256 at dk = 64
-    constexpr bool ONE_EACH = (NQ == 512);                  // dk = 128: every thread stages one Q and one V piece
-    f32x8 qpre, vpre;                                       // the next tile's pieces, in flight during the current tile
-    auto fetch = [&](int a_, int t_) __attribute__((always_inline)) {
-        const bool do_q = ONE_EACH || tid < NQ;
-        const int p = ONE_EACH ? tid : (tid < NQ ? tid : tid - NQ);
-        if (do_q) {
-            const int kb = p >> 6, lp = p & 63;
-            int row = t_ * TROWS + (lp & 31);
+    // ---- staging of one tile's Q and V rows: piece p of Q = B fragment (rb, kb, lane': row 32 rb + (lane' & 31), 8 k from
+    //      16 kb + 8 (lane' >> 5)); piece p of V = 8 columns (chunk p % NCH) of row p / NCH
+    constexpr int QPT = RB * NKS * 64 / 512, VPT = TROWS * NCH / 512;     // pieces per thread: 2 + 2 at dk = 128, 1 + 1 at dk = 64
+    f32x8 qpre[QPT], vpre[VPT];                // the rows of the tile after next, in flight for a whole tile
+    int fa = a, ft = t;                        // fetch cursor
+    auto fetch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int p = tid + 512 * i;
+            const int rb = p / (NKS * 64), kb = (p >> 6) & (NKS - 1), lp = p & 63;
+            int row = ft * TROWS + 32 * rb + (lp & 31);
             if (row > n32 - 1) row = n32 - 1;
-            qpre = load8(P.q + (int64_t)row * P.ldq + a_ * DK + 16 * kb + 8 * (lp >> 5));
+            qpre[i] = load8(P.q + (int64_t)row * P.ldq + fa * DK + 16 * kb + 8 * (lp >> 5));
         }
-        if (MODE != 1 && (ONE_EACH || !do_q)) {
-            int row = t_ * TROWS + p / NCH;
-            if (row > n32 - 1) row = n32 - 1;
-            vpre = load8(P.v + (int64_t)row * P.ldv + a_ * DK + 8 * (p % NCH));
+        if constexpr (MODE != 1) {
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                const int p = tid + 512 * i;
+                int row = ft * TROWS + p / NCH;
+                if (row > n32 - 1) row = n32 - 1;
+                vpre[i] = load8(P.v + (int64_t)row * P.ldv + fa * DK + 8 * (p % NCH));
+            }
+        }
+        if (++ft == P.tiles_per_head) {
+            ft = 0;
+            ++fa;
         }
     };
     auto vrot = [](int r) __attribute__((always_inline)) -> int { return DK == 128 ? (r & 3) : ((r >> 1) & 1); };
-    auto commit = [&]() __attribute__((always_inline)) {
-        const bool do_q = ONE_EACH || tid < NQ;
-        const int p = ONE_EACH ? tid : (tid < NQ ? tid : tid - NQ);
+    auto commit = [&](int vbuf) __attribute__((always_inline)) {
         u32x4 hi, lo;
-        if (do_q) {
-            split8(qpre, hi, lo);
-            lds_qh[p] = hi;
-            lds_ql[p] = lo;
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            split8(qpre[i], hi, lo);
+            lds_qh[tid + 512 * i] = hi;
+            lds_ql[tid + 512 * i] = lo;
         }
-        if (MODE != 1 && (ONE_EACH || !do_q)) {
-            split8(vpre, hi, lo);
-            const int row = p / NCH, ch = p % NCH;
-            const int off = row * VRS + 16 * ((ch + 4 * vrot(row)) & (NCH - 1));
-            *reinterpret_cast<u32x4*>(lds_vh + off) = hi;
-            *reinterpret_cast<u32x4*>(lds_vl + off) = lo;
+        if constexpr (MODE != 1) {
+            unsigned char* vh = lds_v + vbuf * 2 * V_BYTES;
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                split8(vpre[i], hi, lo);
+                const int p = tid + 512 * i;
+                const int row = p / NCH, ch = p % NCH;
+                const int off = row * VRS + 16 * ((ch + 4 * vrot(row)) & (NCH - 1));
+                *reinterpret_cast<u32x4*>(vh + off) = hi;
+                *reinterpret_cast<u32x4*>(vh + V_BYTES + off) = lo;
+            }
         }
     };
+    // this wave's key block (w < NKB) as MFMA A fragments, hi and lo, in registers for the whole head
+    bf16x8 kph[NKS], kpl[NKS];
     auto load_kp = [&](int a_) __attribute__((always_inline)) {
-        for (int fr = w; fr < NKB * NKS; fr += 8) {
-            const int jb = fr / NKS, kb = fr - jb * NKS;
-            int key = 32 * jb + j;
+        if (w < NKB) {
+            int key = 32 * w + j;
             const bool pad = key >= P.k;
             if (pad) key = P.k - 1;
-            u32x4 hi, lo;
-            split8(load8(P.kp + (int64_t)key * P.ldkp + a_ * DK + 16 * kb + 8 * hf), hi, lo);
-            if (pad) hi = lo = u32x4{0u, 0u, 0u, 0u};
-            lds_kph[fr * 64 + lane] = hi;
-            lds_kpl[fr * 64 + lane] = lo;
+            f32x8 raw[NKS];
+#pragma unroll
+            for (int kb = 0; kb < NKS; ++kb) raw[kb] = load8(P.kp + (int64_t)key * P.ldkp + a_ * DK + 16 * kb + 8 * hf);
+#pragma unroll
+            for (int kb = 0; kb < NKS; ++kb) {
+                u32x4 hi, lo;
+                split8(raw[kb], hi, lo);
+                if (pad) hi = lo = u32x4{0u, 0u, 0u, 0u};
+                kph[kb] = __builtin_bit_cast(bf16x8, hi);
+                kpl[kb] = __builtin_bit_cast(bf16x8, lo);
+            }
         }
     };
 
@@ -200,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
     const int vrc = 4 * cb + 2 * (rg & 1) + ((ri & 3) >> 1);
     const int voff0 = rr0 * VRS + 16 * ((vrc + 4 * vrot(rr0)) & (NCH - 1)) + 8 * (ri & 1);
     const int voff1 = rr1 * VRS + 16 * ((vrc + 4 * vrot(rr1)) & (NCH - 1)) + 8 * (ri & 1);
-    // P image writer (softmax): row j, 4 keys per 8-byte chunk; chunk (2 c4 + hf) of key block w at position ^ ((j >> 1) & 7)
+    // P image writer (softmax): row 32 rb + j, 4 keys per 8-byte chunk; chunk (2 c4 + hf) of key block w at position ^ ((j >> 1) & 7)
     int waddr[4];
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) waddr[c4] = j * RS + 64 * w + 8 * (((2 * c4) | hf) ^ ((j >> 1) & 7));
@@ -231,16 +252,19 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
     };
 
     zero_acc();
-    fetch(a, t);
+    fetch();                                     // tile f_begin
+    commit(0);
+    if (f_begin + 1 < f_end) fetch();            // tile f_begin + 1 flies under the first tile
     const bool attn_vec = AUX && (P.attn_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(P.attn) & 15) == 0;
     for (int f = f_begin; f < f_end; ++f) {
+        const int vb = (f - f_begin) & 1;
         int an = a, tn = t + 1;
         if (tn == P.tiles_per_head) {
             tn = 0;
             an = a + 1;
         }
         if (a != cur_head) {
-            // new head: everybody is past the previous tile's GEMM2 (closing barrier below), the Kp images are free
+            // new head: this wave's GEMM2 of the previous tile is behind it, so its accumulators can go
             if (MODE != 1 && cur_head >= 0) {
                 flush(cur_head);
                 zero_acc();
@@ -248,127 +272,152 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
             load_kp(a);
             cur_head = a;
         }
-        commit();                                // this tile's Q / V images (fetched one tile ago)
-        if (f + 1 < f_end) fetch(an, tn);        // next tile's rows fly under this tile's work
-        __syncthreads();                         // B1: images complete
+        __syncthreads();                         // B1: Q(f) / V(f) images complete, everybody is past GEMM2(f-1): the P images are free
 
-        // ---- GEMM1 (swapped): S^T[key, row] for key block w; lane = (row j, half hf): keys 32 w + (r&3) + 8 (r>>2) + 4 hf
-        f32x16 s;
-        float mw = -INFINITY, lw = 0.f;
-        const int row = t * TROWS + j;
-        const bool rvalid = row < n32;
+        // ---- GEMM1 (swapped): S^T[key, row] for key block w, both row blocks; lane = (row j, half hf): keys 32 w + (r&3) + 8 (r>>2) + 4 hf
+        f32x16 s[RB];
+        float mw[RB], lw[RB];
         if (w < NKB) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[rb][r] = 0.f;
 #pragma unroll
             for (int kb = 0; kb < NKS; ++kb) {
-                const bf16x8 kh = __builtin_bit_cast(bf16x8, lds_kph[(w * NKS + kb) * 64 + lane]);
-                const bf16x8 kl = __builtin_bit_cast(bf16x8, lds_kpl[(w * NKS + kb) * 64 + lane]);
-                const bf16x8 qh = __builtin_bit_cast(bf16x8, lds_qh[kb * 64 + lane]);
-                const bf16x8 ql = __builtin_bit_cast(bf16x8, lds_ql[kb * 64 + lane]);
-                s = mfma(kl, qh, s);
-                s = mfma(kh, ql, s);
-                s = mfma(kh, qh, s);
+                bf16x8 qh[RB], ql[RB];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    qh[rb] = __builtin_bit_cast(bf16x8, lds_qh[(rb * NKS + kb) * 64 + lane]);
+                    ql[rb] = __builtin_bit_cast(bf16x8, lds_ql[(rb * NKS + kb) * 64 + lane]);
+                }
+                // the two row blocks' accumulation chains alternate: a dependent 32x32 MFMA waits 16 passes for its predecessor
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) s[rb] = mfma(kpl[kb], qh[rb], s[rb]);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) s[rb] = mfma(kph[kb], ql[rb], s[rb]);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) s[rb] = mfma(kph[kb], qh[rb], s[rb]);
             }
             // block-local softmax statistics (padded keys -> -inf)
-            float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                s[r] = key < P.k ? s[r] * c_exp : -INFINITY;
-                mx = fmaxf(mx, s[r]);
-            }
-            mw = xhalf_max(mx);
-            const float mref = mw == -INFINITY ? 0.f : mw;   // a block of padding only (k far below the built capacity): all zeros
-            float l = 0.f;
+            for (int rb = 0; rb < RB; ++rb) {
+                float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] = __builtin_amdgcn_exp2f(s[r] - mref);
-                l += s[r];
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                    s[rb][r] = key < P.k ? s[rb][r] * c_exp : -INFINITY;
+                    mx = fmaxf(mx, s[rb][r]);
+                }
+                mw[rb] = xhalf_max(mx);
+                const float mref = mw[rb] == -INFINITY ? 0.f : mw[rb];   // a block of padding only: all zeros
+                float l = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[rb][r] = __builtin_amdgcn_exp2f(s[rb][r] - mref);
+                    l += s[rb][r];
+                }
+                lw[rb] = xhalf_sum(l);
+                if (hf == 0) lds_st[w * TROWS + 32 * rb + j] = f32x2{mw[rb], lw[rb]};
             }
-            lw = xhalf_sum(l);
-            if (hf == 0) lds_st[w * 32 + j] = f32x2{mw, lw};
         }
         __syncthreads();                         // B2: statistics published, every wave is done with the Q images
 
         if constexpr (MODE == 1) {
             // statistics pass: this chunk's (max, sum) per row, then on to the next tile
-            if (w == 0 && hf == 0 && rvalid) {
-                float m = -INFINITY;
+            if (w < RB && hf == 0) {
+                const int row = t * TROWS + 32 * w + j;
+                if (row < n32) {
+                    float m = -INFINITY;
 #pragma unroll
-                for (int b = 0; b < NKB; ++b) m = fmaxf(m, lds_st[b * 32 + j][0]);
-                float l = 0.f;
+                    for (int b = 0; b < NKB; ++b) m = fmaxf(m, lds_st[b * TROWS + 32 * w + j][0]);
+                    float l = 0.f;
 #pragma unroll
-                for (int b = 0; b < NKB; ++b) {
-                    const f32x2 st = lds_st[b * 32 + j];
-                    if (st[0] != -INFINITY) l = fmaf(st[1], __builtin_amdgcn_exp2f(st[0] - m), l);
+                    for (int b = 0; b < NKB; ++b) {
+                        const f32x2 st = lds_st[b * TROWS + 32 * w + j];
+                        if (st[0] != -INFINITY) l = fmaf(st[1], __builtin_amdgcn_exp2f(st[0] - m), l);
+                    }
+                    P.stats[((int64_t)P.chunk * P.h + a) * P.n + row] = f32x2{m, l};
                 }
-                P.stats[((int64_t)P.chunk * P.h + a) * P.n + row] = f32x2{m, l};
             }
-            __syncthreads();                     // the statistics slots and the Q images are free
+            if (f + 1 < f_end) {
+                commit(0);                       // Q images of the next tile
+                if (f + 2 < f_end) fetch();
+            }
             a = an;
             t = tn;
-            continue;
+            continue;                            // B1 of the next tile orders the statistics slots
         }
         // ---- exact combination over the key blocks, normalisation, publish P = hi + lo
         if (w < NKB) {
-            float m = -INFINITY, l = 0.f;
-            if constexpr (MODE == 2) {
-                const int64_t so = (int64_t)a * P.n + (rvalid ? row : n32 - 1);
-                for (int c = 0; c < P.nchunks; ++c) m = fmaxf(m, P.stats[(int64_t)c * P.h * P.n + so][0]);
-                for (int c = 0; c < P.nchunks; ++c) {
-                    const f32x2 st = P.stats[(int64_t)c * P.h * P.n + so];
-                    if (st[0] != -INFINITY) l = fmaf(st[1], __builtin_amdgcn_exp2f(st[0] - m), l);
-                }
-            } else {
 #pragma unroll
-                for (int b = 0; b < NKB; ++b) m = fmaxf(m, lds_st[b * 32 + j][0]);
+            for (int rb = 0; rb < RB; ++rb) {
+                const int row = t * TROWS + 32 * rb + j;
+                const bool rvalid = row < n32;
+                float m = -INFINITY, l = 0.f;
+                if constexpr (MODE == 2) {
+                    const int64_t so = (int64_t)a * P.n + (rvalid ? row : n32 - 1);
+                    for (int c = 0; c < P.nchunks; ++c) m = fmaxf(m, P.stats[(int64_t)c * P.h * P.n + so][0]);
+                    for (int c = 0; c < P.nchunks; ++c) {
+                        const f32x2 st = P.stats[(int64_t)c * P.h * P.n + so];
+                        if (st[0] != -INFINITY) l = fmaf(st[1], __builtin_amdgcn_exp2f(st[0] - m), l);
+                    }
+                } else {
 #pragma unroll
-                for (int b = 0; b < NKB; ++b) {
-                    const f32x2 st = lds_st[b * 32 + j];
-                    l = fmaf(st[1], __builtin_amdgcn_exp2f(st[0] - m), l);
-                }
-            }
-            const float fscale = rvalid ? __builtin_amdgcn_exp2f(mw - m) / l : 0.f;
-            if constexpr (AUX)
-                if (P.lse && rvalid && hf == 0 && w == 0) P.lse[(int64_t)a * P.n + row] = (m + __log2f(l)) * 0.69314718055994530942f;
-            float* arow = nullptr;
-            if constexpr (AUX) arow = P.attn ? P.attn + ((int64_t)a * P.n + row) * P.attn_ld + 32 * w + 4 * hf : nullptr;
+                    for (int b = 0; b < NKB; ++b) m = fmaxf(m, lds_st[b * TROWS + 32 * rb + j][0]);
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                f32x4 p4 = {s[4 * c4] * fscale, s[4 * c4 + 1] * fscale, s[4 * c4 + 2] * fscale, s[4 * c4 + 3] * fscale};
-                // P is ROUNDED to fp32 here in every variant: without this the compiler contracts the product into the
-                // subtraction of the split below (fma) in the variants that do not store A, and their O differs in the last bits
-                asm volatile("" : "+v"(p4));
-                if constexpr (AUX) {
-                    if (arow && rvalid) {
-                        const int key0 = 32 * w + 8 * c4 + 4 * hf;
-                        if (attn_vec && key0 + 4 <= P.k) {
-                            *reinterpret_cast<f32x4*>(arow + 8 * c4) = p4;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (key0 + e < P.k) arow[8 * c4 + e] = p4[e];
-                        }
+                    for (int b = 0; b < NKB; ++b) {
+                        const f32x2 st = lds_st[b * TROWS + 32 * rb + j];
+                        l = fmaf(st[1], __builtin_amdgcn_exp2f(st[0] - m), l);
                     }
                 }
-                const bf16x2 h01 = __builtin_convertvector(f32x2{p4[0], p4[1]}, bf16x2);
-                const bf16x2 h23 = __builtin_convertvector(f32x2{p4[2], p4[3]}, bf16x2);
-                const f32x2 r01 = f32x2{p4[0], p4[1]} - __builtin_convertvector(h01, f32x2);
-                const f32x2 r23 = f32x2{p4[2], p4[3]} - __builtin_convertvector(h23, f32x2);
-                *reinterpret_cast<u32x2*>(lds_ph + waddr[c4]) = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
-                *reinterpret_cast<u32x2*>(lds_pl + waddr[c4]) =
-                    u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2)),
-                          __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2))};
+                const float fscale = rvalid ? __builtin_amdgcn_exp2f(mw[rb] - m) / l : 0.f;
+                if constexpr (AUX)
+                    if (P.lse && rvalid && hf == 0 && w == 0) P.lse[(int64_t)a * P.n + row] = (m + __log2f(l)) * 0.69314718055994530942f;
+                float* arow = nullptr;
+                if constexpr (AUX) arow = P.attn ? P.attn + ((int64_t)a * P.n + row) * P.attn_ld + 32 * w + 4 * hf : nullptr;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    f32x4 p4 = {s[rb][4 * c4] * fscale, s[rb][4 * c4 + 1] * fscale, s[rb][4 * c4 + 2] * fscale, s[rb][4 * c4 + 3] * fscale};
+                    // P is ROUNDED to fp32 here in every variant: without this the compiler contracts the product into the
+                    // subtraction of the split below (fma) in the variants that do not store A, and their O differs in the last bits
+                    asm volatile("" : "+v"(p4));
+                    if constexpr (AUX) {
+                        if (arow && rvalid) {
+                            const int key0 = 32 * w + 8 * c4 + 4 * hf;
+                            if (attn_vec && key0 + 4 <= P.k) {
+                                *reinterpret_cast<f32x4*>(arow + 8 * c4) = p4;
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (key0 + e < P.k) arow[8 * c4 + e] = p4[e];
+                            }
+                        }
+                    }
+                    const bf16x2 h01 = __builtin_convertvector(f32x2{p4[0], p4[1]}, bf16x2);
+                    const bf16x2 h23 = __builtin_convertvector(f32x2{p4[2], p4[3]}, bf16x2);
+                    const f32x2 r01 = f32x2{p4[0], p4[1]} - __builtin_convertvector(h01, f32x2);
+                    const f32x2 r23 = f32x2{p4[2], p4[3]} - __builtin_convertvector(h23, f32x2);
+                    *reinterpret_cast<u32x2*>(lds_ph + 32 * rb * RS + waddr[c4]) =
+                        u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+                    *reinterpret_cast<u32x2*>(lds_pl + 32 * rb * RS + waddr[c4]) =
+                        u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2)),
+                              __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2))};
+                }
             }
+        }
+        // the next tile's rows (fetched a tile ago): Q images are free since B2, the other V buffer since B1
+        if (f + 1 < f_end) {
+            commit(vb ^ 1);
+            if (f + 2 < f_end) fetch();
         }
         __syncthreads();                         // B3: P images complete
 
-        // ---- GEMM2: O[key, col] += P^T V over the 32 rows of the tile (two 16-row k-steps, 3 MFMAs each)
+        // ---- GEMM2: O[key, col] += P^T V over the 64 rows of the tile (four 16-row k-steps, 3 MFMAs each)
+        const unsigned char* vh_img = lds_v + vb * 2 * V_BYTES;
 #pragma unroll
-        for (int sk = 0; sk < 2; ++sk) {
-            const bf16x8 vh = tr_frag(lds_vh + voff0 + sk * 16 * VRS, lds_vh + voff1 + sk * 16 * VRS);
-            const bf16x8 vl = tr_frag(lds_vl + voff0 + sk * 16 * VRS, lds_vl + voff1 + sk * 16 * VRS);
+        for (int sk = 0; sk < TROWS / 16; ++sk) {
+            const bf16x8 vh = tr_frag(vh_img + voff0 + sk * 16 * VRS, vh_img + voff1 + sk * 16 * VRS);
+            const bf16x8 vl = tr_frag(vh_img + V_BYTES + voff0 + sk * 16 * VRS, vh_img + V_BYTES + voff1 + sk * 16 * VRS);
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti) {
                 if (TILES % 8 == 0 || w + 8 * ti < TILES) {
@@ -381,7 +430,6 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
                 }
             }
         }
-        __syncthreads();                         // B4: images free
         a = an;
         t = tn;
     }
@@ -459,8 +507,8 @@ size_t x3_workspace(const X3Plan& pl, int dk) { return (size_t)pl.num_wg * pl.se
 template <int DK, int NKB, bool AUX, int MODE>
 int x3_launch(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s) {
     constexpr int NKS = DK / 16;
-    constexpr int q_bytes = NKS * 1024, p_bytes = TROWS * p_row_bytes(NKB);
-    constexpr int lds = 2 * NKB * NKS * 1024 + 2 * (q_bytes > p_bytes ? q_bytes : p_bytes) + 2 * TROWS * 2 * DK + 8 * 32 * 8;
+    constexpr int q_bytes = (TROWS / 32) * NKS * 1024, p_bytes = TROWS * p_row_bytes(NKB), v_bytes = TROWS * 2 * DK;
+    constexpr int lds = 2 * q_bytes + 2 * p_bytes + 4 * v_bytes + 8 * TROWS * 8;   // Q hi|lo, P hi|lo, V 2 x (hi|lo), statistics
     static thread_local bool attr_set = false;
     auto kern = sparse_attn_x3_kernel<DK, NKB, AUX, MODE>;
     if (!attr_set) {
