@@ -36,6 +36,8 @@ WORKLOADS = {
     # bags r::W), resident in HBM.  N below is only the nominal length (roofline micro-benchmark shape).
     "cam16": dict(N=30000, D=768, h=6, lam=200, bags=400),
 }
+# BASELINE.json configs[3]: compute_feats.py's DINO ViT-S/16 + adapter (ffn_num 32, scalar 10) over 224 x 224 tiles, batch 512
+VIT = dict(arch="vit_small", width=384, batch=512, img=224, patch=16, ffn_num=32, scalar="10")
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
@@ -148,6 +150,47 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
     return out
 
 
+def vit_leg(device, precision, steps, warmup, world=1, dist=None):
+    """The extractor of BASELINE.json configs[3] on synthetic tiles already resident in HBM: images / s over all ranks (every rank
+    runs its own batches: tile batches are independent, no collective), with the MFMA roofline of the block contractions."""
+    from snuffy_amd import vit
+    torch.manual_seed(0)
+    w = VIT["width"]
+    model = getattr(vit, VIT["arch"])(patch_size=VIT["patch"], adapter_ffn_scalar=VIT["scalar"], adapter_ffn_num=VIT["ffn_num"],
+                                      adapter_d_model=w).to(device).eval().configure(precision)
+    x = torch.rand(VIT["batch"], 3, VIT["img"], VIT["img"], device=device)
+    for _ in range(warmup):
+        model(x)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model(x)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    T = (VIT["img"] // VIT["patch"]) ** 2 + 1
+    flops_img = 12 * (2 * T * w * 3 * w + 4 * T * T * w + 2 * T * w * w + 16 * T * w * w + 4 * T * w * VIT["ffn_num"]) \
+        + 2 * (T - 1) * 3 * VIT["patch"] ** 2 * w
+    rate = world * steps * VIT["batch"] / el
+    issued = 3 if precision == "fp32" else 1      # split-bf16 x3: three bf16 MFMA products per fp32 product
+    return dict(value=round(rate, 1), unit="img/s", ms_per_batch=round(el / steps * 1e3, 3), steps=steps, batch=VIT["batch"],
+                workload="ViT-S/16 + adapter (ffn_num 32), 224 x 224 synthetic tiles, batch %d per rank" % VIT["batch"],
+                roofline=dict(bound="mfma", achieved=round(flops_img * rate / 1e12, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                              frac=round(flops_img * rate / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None,
+                              issued_bf16_tflops=round(issued * flops_img * rate / 1e12, 1),
+                              note="model FLOPs (9.2 GFLOP / image) over the dense bf16 MFMA peak; fp32 issues three bf16 "
+                                   "products per product"))
+
+
 def cpu_baseline(wl, budget_s=25.0):
     """The CPU oracle (a torch-CPU port of the reference's op sequence; it materialises A like the reference) timed on this
     host's cores.  More threads is not faster on a many-core host (round 1: 0.79 slides/s on 128 threads vs 1.7 on 8): the
@@ -203,7 +246,9 @@ def main():
     # 1.97 k, 2000 steps 2.05 k at config B; shorter regions also scatter by +-10 % with the GPU's power state)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", default="cfgB", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfgB", choices=sorted(WORKLOADS) + ["vit"],
+                    help="cfgB (default, BASELINE.json's metric shape) / cfgA / cfgC / cam16: the MIL aggregator; vit: the patch-embedding "
+                         "extractor of configs[3] as the headline (the default run reports it beside the aggregator as vit_*)")
     # the headline arithmetic is the reference's: fp32 tensors (products on the matrix cores as split-bf16 x3, fp32-class);
     # the bf16 path (north_star's 1e-2 class) rides beside it as value_bf16 / roofline_bf16
     ap.add_argument("--precision", default="fp32", choices=["bf16", "fp32"])
@@ -258,6 +303,26 @@ def main():
     if args.gemm_table:
         from snuffy_amd.gemm_tuning import use_pretuned_gemms
         use_pretuned_gemms()
+
+    if args.workload == "vit":
+        steps = min(args.steps, 50)
+        leg = vit_leg(device, args.precision, steps, min(args.warmup, 5), world, dist)
+        if rank == 0:
+            other = "fp32" if args.precision == "bf16" else "bf16"
+            line = {"metric": "images/sec", "value": leg["value"], "unit": "img/s", "n_gpus": world, "steps": steps,
+                    "warmup": min(args.warmup, 5), "ms_per_step": leg["ms_per_batch"], "higher_is_better": True, "scaling": "weak",
+                    "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "f32"}[args.precision], "data": "synthetic",
+                    "config": {"workload": leg["workload"], "parallelism": "tile batches x%d (independent, no collective)" % world},
+                    "roofline": leg["roofline"]}
+            if not args.headline_only and world == 1:
+                o = vit_leg(device, other, max(3, steps // 3), 2)
+                line["value_" + {"bf16": "bf16", "fp32": "f32"}[other]] = o["value"]
+                line["roofline_" + {"bf16": "bf16", "fp32": "f32"}[other]] = o["roofline"]
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     wl = WORKLOADS[args.workload]
     N, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
@@ -423,6 +488,11 @@ def main():
                 other = "fp32" if args.precision == "bf16" else "bf16"
                 for k, v in kernel_rooflines(wl, other, device, args.workload).items():
                     line[k + "_" + dt_name[other]] = v
+        if world == 1 and not args.headline_only and args.workload == "cfgB":
+            # BASELINE.json configs[3] beside the aggregator: the ViT-S/16 + adapter extractor, both arithmetics
+            for prec, st in (("bf16", 8), ("fp32", 3)):
+                leg = vit_leg(device, prec, st, 2)
+                line["vit_" + dt_name[prec]] = {k: leg[k] for k in ("value", "unit", "ms_per_batch", "steps", "batch", "workload", "roofline")}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(line), flush=True)

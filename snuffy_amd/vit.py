@@ -12,9 +12,12 @@ Mirrors the module API and state-dict keys of the reference's inference-time mod
 
 Inference only (parameters of the extractor are frozen in the reference, compute_feats.py:432-433).  Hand-written HIP:
 patchify, token assembly, LayerNorm, residual+LayerNorm fusion, GELU epilogue, multi-head self-attention (exact fp32 and
-bf16 MFMA).  Patch-embed, qkv, proj, fc1 (+ erf GELU) and -- for bottlenecks of 64 and more -- the adapter projections run on the
-hand-written MFMA GEMM in the bf16 path; fc2 (K = 4D) and narrower adapters are library GEMMs.  ``configure(precision=...)``: "fp32" = reference-class
-numerics, "bf16" = bf16 GEMM / MFMA operands with an fp32 residual stream.
+bf16 MFMA).  Every dense contraction of a block -- patch-embed, qkv, proj, fc1 (+ erf GELU), fc2 and the adapter's down / up projections
+(a bottleneck below 64, the DINO recipe's 32 included, is zero-padded to the kernel's 64-deep minimum) -- runs on the hand-written
+MFMA GEMM (csrc/gemm.hip), in both precisions.  ``configure(precision=...)``: "bf16" = bf16 GEMM / MFMA operands with an fp32
+residual stream; "fp32" = fp32 tensors, exact fp32 self-attention, and the projections as split-bf16 x3 products on the matrix cores
+(FP32_GEMM = "x3": every operand as hi + lo bf16 halves over a tripled K axis, fp32 accumulate -- fp32-class, ~1e-5 per product;
+FP32_GEMM = "library" restores plain fp32 library GEMMs).
 """
 import math
 from functools import partial
@@ -25,6 +28,46 @@ import torch.nn.functional as F
 
 from . import ops
 from ._ffi import SnuffyHipError
+
+# fp32 path, the dense projections: "x3" = split-bf16 x3 products on the hand-written MFMA GEMM (as the aggregator's fp32 path,
+# functional.FP32_GEMM), "library" = plain fp32 library GEMMs
+FP32_GEMM = "x3"
+
+
+def _split3_of(weight):
+    """[Wh | Wl | Wh] image of a parameter (ops.split3_weight), cached on the parameter until it is written again."""
+    key = (weight.data_ptr(), weight._version)
+    hit = getattr(weight, "_snf_x3", None)
+    if hit is None or hit[0] != key:
+        hit = (key, ops.split3_weight(weight.detach().reshape(weight.shape[0], -1)))
+        weight._snf_x3 = hit
+    return hit[1]
+
+
+def linear_f32(x, weight, bias, act="none", want_image=False):
+    """act(x W^T + b) of the fp32 path.  x: [m, k] f32, or the bf16 split image [m, 3 k] = [hi | hi | lo] a previous call /
+    ops.layernorm_rows_split3 left.  FP32_GEMM == "x3" (and the shape in the kernel's domain): one bf16 MFMA GEMM over the tripled
+    K axis against [Wh | Wl | Wh]; want_image returns the result as the split image for the next projection (it never exists in
+    fp32).  Otherwise the fp32 library GEMM + the activation kernel."""
+    is_image = x.dtype == torch.bfloat16
+    k = weight[0].numel()
+    m = x.shape[0]
+    n = weight.shape[0]
+    if FP32_GEMM == "x3" and ops.gemm_x3_supported(m, n, k):
+        img = x if is_image else ops.split3_rows(x.float() if x.dtype != torch.float32 else x)
+        b = None if bias is None else bias.detach().float().contiguous()
+        if want_image:
+            return ops.gemm_bf16(img, _split3_of(weight), b, act, split3=True)
+        return ops.gemm_bf16(img, _split3_of(weight), b, act, out_dtype=torch.float32)
+    if is_image:                                   # hi + lo back to fp32 (only when a shape falls out of the kernel's domain)
+        x = x[:, :k].float() + x[:, 2 * k:].float()
+    h = torch.mm(x.float(), weight.reshape(n, -1).t())
+    if act != "none" or bias is not None:
+        if act == "none":
+            h += bias
+        else:
+            ops.bias_act_(h, bias, act)
+    return h                                       # plain fp32 also when an image was asked for: the next call takes either
 
 
 class Adapter(nn.Module):
@@ -63,7 +106,13 @@ class Adapter(nn.Module):
         residual = x if residual is None else residual
         if self.adapter_layernorm_option == 'in':
             x = self.adapter_layer_norm_before(x)
-        up = self.up_proj(F.relu(self.down_proj(x))) * self.scale       # eval: the reference's dropout is inactive
+        shp = x.shape
+        if x.is_cuda and not torch.is_grad_enabled():
+            a = linear_f32(x.reshape(-1, shp[-1]).float().contiguous(), self.down_proj.weight, self.down_proj.bias, "relu",
+                           want_image=True)
+            up = linear_f32(a, self.up_proj.weight, self.up_proj.bias).view(shp) * self.scale
+        else:
+            up = self.up_proj(F.relu(self.down_proj(x))) * self.scale   # eval: the reference's dropout is inactive
         if self.adapter_layernorm_option == 'out':
             up = self.adapter_layer_norm_before(up)
         return up + residual if add_residual else up
@@ -80,10 +129,13 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
+        """x: [..., D] f32, or the split image [m, 3 D] of the normalised tokens (Block.forward)."""
+        image_in = x.dtype == torch.bfloat16
         shp = x.shape
-        h = torch.mm(x.reshape(-1, shp[-1]).float(), self.fc1.weight.t())
-        ops.bias_act_(h, self.fc1.bias, "gelu")
-        return F.linear(h, self.fc2.weight, self.fc2.bias).view(*shp[:-1], -1)
+        x2 = x if image_in else x.reshape(-1, shp[-1]).float().contiguous()
+        h = linear_f32(x2, self.fc1.weight, self.fc1.bias, "gelu", want_image=True)
+        out = linear_f32(h, self.fc2.weight, self.fc2.bias)
+        return out if image_in else out.view(*shp[:-1], -1)
 
 
 class Attention(nn.Module):
@@ -100,10 +152,14 @@ class Attention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
 
     def forward(self, x):
-        B, N, C = x.shape
-        qkv = F.linear(x.reshape(B * N, C).float(), self.qkv.weight, self.qkv.bias)
-        o, attn = ops.vit_attention(qkv, B, N, self.num_heads, self.scale, need_attn=True)
-        return F.linear(o, self.proj.weight, self.proj.bias).view(B, N, C), attn
+        return self._run(x.reshape(-1, x.shape[-1]).float().contiguous(), x.shape[0], x.shape[1])
+
+    def _run(self, x2, B, N, need_attn=True):
+        """x2: [B * N, C] f32 or its split image [B * N, 3 C]."""
+        C = self.proj.weight.shape[0]
+        qkv = linear_f32(x2, self.qkv.weight, self.qkv.bias)
+        o, attn = ops.vit_attention(qkv, B, N, self.num_heads, self.scale, need_attn=need_attn)
+        return linear_f32(o, self.proj.weight, self.proj.bias).view(B, N, C), attn
 
 
 class Block(nn.Module):
@@ -129,13 +185,19 @@ class Block(nn.Module):
     def forward(self, x, return_attention=False):
         B, N, C = x.shape
         x2 = x.reshape(B * N, C).float().contiguous()
-        y, attn = self.attn(ops.layernorm_rows(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps).view(B, N, C))
+        x3 = FP32_GEMM == "x3" and C % 8 == 0 and ops.gemm_x3_supported(B * N, C, C)
+        # x3: the LayerNorm writes its output straight as the split image [hi | hi | lo] the projection GEMM reads
+        ln1 = ops.layernorm_rows_split3(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps) if x3 else \
+            ops.layernorm_rows(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        y, attn = self.attn._run(ln1, B, N, need_attn=return_attention)
         if return_attention:
             return attn
         x = x + y
         ad = self.adaptmlp(x, add_residual=False) if hasattr(self, "adaptmlp") else 0.0
-        xn = ops.layernorm_rows(x.reshape(B * N, C).contiguous(), self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        return x + self.mlp(xn).view(B, N, C) + ad
+        xc = x.reshape(B * N, C).contiguous()
+        ln2 = ops.layernorm_rows_split3(xc, self.norm2.weight, self.norm2.bias, self.norm2.eps) if x3 else \
+            ops.layernorm_rows(xc, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return x + self.mlp(ln2).view(B, N, C) + ad
 
 
 class PatchEmbed(nn.Module):
@@ -151,8 +213,7 @@ class PatchEmbed(nn.Module):
     def forward(self, x):
         B = x.shape[0]
         cols = ops.vit_patchify(x.float().contiguous(), self.patch_size)
-        w = self.proj.weight.reshape(self.proj.weight.shape[0], -1)
-        return F.linear(cols, w, self.proj.bias).view(B, -1, w.shape[0])
+        return linear_f32(cols, self.proj.weight, self.proj.bias).view(B, -1, self.proj.weight.shape[0])
 
 
 class VisionTransformer(nn.Module):
@@ -280,10 +341,17 @@ class VisionTransformer(nn.Module):
                      fc1_w=blk.mlp.fc1.weight.to(bf), fc1_b=blk.mlp.fc1.bias.to(bf), fc1_bf=blk.mlp.fc1.bias.to(f32),
                      fc2_w=blk.mlp.fc2.weight.to(bf), fc2_b=blk.mlp.fc2.bias.to(bf), fc2_bf=blk.mlp.fc2.bias.to(f32))
             if hasattr(blk, "adaptmlp"):
-                d.update(dn_w=blk.adaptmlp.down_proj.weight.to(bf), dn_b=blk.adaptmlp.down_proj.bias.to(bf),
-                         dn_bf=blk.adaptmlp.down_proj.bias.to(f32),
-                         up_w=blk.adaptmlp.up_proj.weight.to(bf), up_b=blk.adaptmlp.up_proj.bias.to(bf),
-                         up_bf=blk.adaptmlp.up_proj.bias.to(f32))
+                dn, up = blk.adaptmlp.down_proj, blk.adaptmlp.up_proj
+                dn_w, dn_b, up_w = dn.weight.detach(), dn.bias.detach(), up.weight.detach()
+                pad = (-dn_w.shape[0]) % 64 if dn_w.shape[0] < 64 else 0
+                if pad:
+                    # a bottleneck below the GEMM's 64-deep minimum (the DINO recipe uses 32): zero rows of the down-projection
+                    # (ReLU(0 + 0) = 0) against zero columns of the up-projection -- the same product, two K steps
+                    dn_w = torch.cat([dn_w, dn_w.new_zeros(pad, dn_w.shape[1])])
+                    dn_b = torch.cat([dn_b, dn_b.new_zeros(pad)])
+                    up_w = torch.cat([up_w, up_w.new_zeros(up_w.shape[0], pad)], dim=1)
+                d.update(dn_w=dn_w.to(bf).contiguous(), dn_b=dn_b.to(bf), dn_bf=dn_b.to(f32).contiguous(),
+                         up_w=up_w.to(bf).contiguous(), up_b=up.bias.to(bf), up_bf=up.bias.to(f32))
             w["blocks"].append(d)
         self._bf16_cache = (key, w)
         return w
@@ -331,11 +399,13 @@ class VisionTransformer(nn.Module):
             # bias + GELU (erf form, as nn.GELU) in the epilogue of the hand-written GEMM: one rounding, no extra pass over the
             # [B*T, 4D] tensor
             hdn = ops.linear_bf16(ln2, wb["fc1_w"], wb["fc1_bf"], wb["fc1_b"], "gelu")
-            m = ops.linear_bf16(hdn, wb["fc2_w"], wb["fc2_bf"], wb["fc2_b"])
+            # fc2 (K = 4 D) on the hand-written kernel too (the library is ~15 % ahead on this long-K shape; the block's
+            # contractions are ours end to end)
+            m = ops.linear_bf16(hdn, wb["fc2_w"], wb["fc2_bf"], wb["fc2_b"], prefer_native=True)
             u, s2 = None, 1.0
             if has_ad:
                 # the adapter's skinny projections (D -> bottleneck -> D): 128-wide tiles of the hand-written GEMM are 1.5-1.8x the
-                # library here (tools/adapter_bench.py); bottlenecks below 64 keep the library (k >= 64 in the kernel's domain)
+                # library here (tools/adapter_bench.py); bottlenecks below 64 arrive zero-padded to 64 (_weights_bf16)
                 bott = wb["dn_w"].shape[0]
                 if ops.gemm_supported(xb.shape[0], bott, xb.shape[1]) and ops.gemm_supported(xb.shape[0], xb.shape[1], bott):
                     a = ops.gemm_bf16(xb, wb["dn_w"], wb["dn_bf"], "relu", tile_n=128)           # ReLU(down(x))

@@ -104,8 +104,14 @@ def build(z):
                                  adapter_d_model=dim, use_adapter=(kind != "dino"))
 
 
+@pytest.mark.parametrize("gemm", ["x3", "library"])
 @pytest.mark.parametrize("path", golden_files("f7_") + golden_files("f8_"), ids=lambda p: p.split("/")[-1][:-4])
-def test_vit_models_match_reference_goldens(path):
+def test_vit_models_match_reference_goldens(path, gemm, monkeypatch):
+    """fp32 path against the reference's own outputs, with the projections as split-bf16 x3 products on the matrix cores (the
+    default: ~1e-5 per product, fp32 accumulate) and as plain fp32 library GEMMs."""
+    from snuffy_amd import vit as vit_mod
+    monkeypatch.setattr(vit_mod, "FP32_GEMM", gemm)
+    tight = gemm == "library"
     z, sd = load_case(path)
     model = build(z)
     assert sorted(model.state_dict().keys()) == sorted(sd.keys())
@@ -114,14 +120,16 @@ def test_vit_models_match_reference_goldens(path):
     imgs = (torch.from_numpy(z["imgs_u8"]).float() / 255.0).to(DEV)
     feats = model(imgs)
     np.testing.assert_allclose(feats.cpu().numpy(), z["feats"], rtol=0, atol=1e-3)      # north-star fp32 tolerance
-    np.testing.assert_allclose(feats.cpu().numpy(), z["feats"], rtol=0, atol=5e-5)      # and reference-class in fact
+    print("MEASURED vit fp32 golden", gemm, path.split("/")[-1], float(np.abs(feats.cpu().numpy() - z["feats"]).max()))
+    np.testing.assert_allclose(feats.cpu().numpy(), z["feats"], rtol=0, atol=5e-5 if tight else 2e-4)   # reference-class in fact
     if str(z["kind"]) != "mae_adapter":
         with torch.no_grad():
             tok = model.prepare_tokens(imgs)
-            np.testing.assert_allclose(tok[:, ::13, :].cpu().numpy(), z["tokens0"], rtol=0, atol=1e-5)
-            np.testing.assert_allclose(model.blocks[0](tok)[:, ::13, :].cpu().numpy(), z["block0"], rtol=0, atol=5e-5)
+            np.testing.assert_allclose(tok[:, ::13, :].cpu().numpy(), z["tokens0"], rtol=0, atol=1e-5 if tight else 5e-5)
+            np.testing.assert_allclose(model.blocks[0](tok)[:, ::13, :].cpu().numpy(), z["block0"], rtol=0,
+                                       atol=5e-5 if tight else 2e-4)
             attn = model.get_last_selfattention(imgs)
-            np.testing.assert_allclose(attn[:, :, ::29, :].cpu().numpy(), z["last_attn"], rtol=0, atol=1e-5)
+            np.testing.assert_allclose(attn[:, :, ::29, :].cpu().numpy(), z["last_attn"], rtol=0, atol=1e-5 if tight else 5e-5)
     fb = model.configure("bf16")(imgs)
     ref = torch.from_numpy(z["feats"])
     e = rel_err(fb.cpu(), ref)
