@@ -79,7 +79,21 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
     elt = 2 if precision == "bf16" else 4
     out = {}
     scores = torch.randn(N, generator=g).to(device)
-    t_topk = timed(lambda: ops.topk(scores, K), 20)
+    t_topk_alone = timed(lambda: ops.topk(scores, K), 20)
+    # the selection as the model dispatches it: the first radix digit is counted inside the critic pass (fused selector), so
+    # top-Lambda costs the select launch plus whatever the histogram adds to the critic -- timed as
+    # (critic + histogram -> select) minus (critic alone) on a resident bag
+    xb = torch.randn(N, D, generator=g).to(device)
+    wc = (torch.randn(1, D, generator=g) / math.sqrt(D)).to(device)
+    bc = torch.zeros(1, device=device)
+    eps = 1e-5 if precision == "bf16" else None        # the bf16 model's critic pass also emits the normalised bf16 copy
+    t_topk, fused = t_topk_alone, False
+    if ops.critic_select(xb, wc, bc, eps) is not None:
+        ops.topk(ops.critic_select(xb, wc, bc, eps)[0].view(-1), K)
+        t_crit = timed((lambda: ops.critic_ln(xb, wc, bc, eps)) if eps is not None else (lambda: ops.critic(xb, wc, bc)), 20)
+        t_both = timed(lambda: ops.topk(ops.critic_select(xb, wc, bc, eps)[0].view(-1), K), 20)
+        t_topk, fused = max(t_both - t_crit, 0.0), True
+    del xb
     kp = torch.randn(K, D, generator=g).to(device)
     kp_in = kp.to(dt)   # the bf16 path hands the kernel a bf16 Kp (output of the bf16 key projection), as the model does
     # rotate over several operand sets so the 256 MiB Infinity Cache cannot serve the re-reads
@@ -144,6 +158,8 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
     out["roofline_topk_attn"] = dict(bound="hbm", achieved=round(b_unit / (t_unit * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS,
                                      unit="GB/s", frac=round(b_unit / (t_unit * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                      us_topk=round(t_topk * 1e3, 2), us_attn=round(t_attn * 1e3, 2),
+                                     us_topk_standalone=round(t_topk_alone * 1e3, 2),
+                                     topk="fused selector: (critic + histogram -> select) - critic" if fused else "one launch on the scores",
                                      algorithmic_bytes=b_unit, survey_8d_bytes=b_unit_8d,
                                      survey_8d_frac=round(b_unit_8d / (t_unit * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
     del qvs

@@ -468,6 +468,170 @@ class SnuffyMulticlass(SmallWeightTrainer):
 ARCH_REGISTRY = {'snuffy': Snuffy, 'snuffy_multiclass': SnuffyMulticlass}
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Runner: the epoch loop around a trainer (reference train.py:523-794) and the CLI entry (train.py:985-1039)
+# ----------------------------------------------------------------------------------------------------------------------
+SAVE_PATH = 'runs'
+
+
+class Runner:
+    """Epoch loop of the reference's Runner: validation before the first epoch, per epoch train / valid / scheduler step, the
+    model's state dict + thresholds + single_weight_parameter saved every epoch under the reference's file names
+    (`{epoch}.pth`, `thresholds_{epoch}.txt`, `single_weight_parameter_{epoch}`), best-AUC bookkeeping, the test pass on the
+    best-AUC and the last epoch with their stored thresholds, and the clean-up of the other epochs' files.  wandb / FROC / ECE
+    plumbing is out of scope.  `data` = (train, valid, test) tuples as utils.load_data / load_mil_data return them; MIL
+    datasets are loaded here when it is None."""
+
+    def __init__(self, args, trainer, data=None, save_path=None, log=print):
+        self.args, self.trainer, self.log = args, trainer, log
+        self.save_path = save_path or os.path.join(SAVE_PATH, args.dataset, str(trainer))
+        if trainer.rank == 0:
+            os.makedirs(self.save_path, exist_ok=True)
+        if data is None:
+            if args.dataset not in MIL_DATASETS:
+                raise Exception(f'Runner: pass data=(train, valid, test) for dataset {args.dataset!r} (utils.load_data on the '
+                                f'split dataframes), or use one of {MIL_DATASETS}')
+            from .utils import load_mil_data
+            data = load_mil_data(args)
+        self.train_data, self.valid_data, self.test_data = data
+        log(f'Num Bags (Train: {len(self.train_data[0])}) (Valid: {len(self.valid_data[0])}) (Test: {len(self.test_data[0])})')
+
+    def _paths(self, epoch):
+        return (os.path.join(self.save_path, f'{epoch}.pth'), os.path.join(self.save_path, f'thresholds_{epoch}.txt'),
+                os.path.join(self.save_path, f'single_weight_parameter_{epoch}'))
+
+    def _save_epoch_model(self, thresholds_optimal, epoch, auc, report_prefix=None):
+        if self.trainer.rank != 0:                     # replicas are identical: one writer
+            return
+        import json
+        model_path, log_path, w_path = self._paths(epoch)
+        torch.save(self.trainer.milnet.state_dict(), model_path)
+        with open(log_path, 'w') as f:
+            json.dump({'auc': float(auc), 'thresholds_optimal': str(list(np.asarray(thresholds_optimal, dtype=np.float64))),
+                       'feats_thresholds_optimal': None}, f)
+        if hasattr(self.trainer, 'single_weight_parameter'):
+            torch.save(self.trainer.single_weight_parameter, w_path)
+        if report_prefix:
+            self.log(f'\t[{report_prefix}] model saved at: {model_path} threshold: {thresholds_optimal}')
+
+    def _load_epoch_model(self, epoch):
+        import ast
+        import json
+        model_path, log_path, w_path = self._paths(epoch)
+        self.trainer.milnet.load_state_dict(torch.load(model_path, map_location=device), strict=True)
+        with open(log_path) as f:
+            rec = json.load(f)
+        thresholds = np.asarray(ast.literal_eval(rec['thresholds_optimal']), dtype=np.float32)
+        if hasattr(self.trainer, 'single_weight_parameter') and os.path.exists(w_path):
+            self.trainer.single_weight_parameter = torch.load(w_path, map_location=device)
+        return thresholds
+
+    def run_train(self):
+        import json
+        import time
+        best_auc, best_auc_epochs = 0, []
+        self.initial_metrics = self.trainer.valid(self.valid_data)              # train.py:611-618
+        for epoch in range(1, self.args.num_epochs + 1):
+            t0 = time.time()
+            tm = self.trainer.train(self.train_data, epoch)
+            vm = self.trainer.valid(self.valid_data)
+            aucs = vm.get('epoch_valid_aucs', [0.0])
+            thr = vm.get('epoch_valid_thresholds_optimal', [0.5] * self.args.num_classes)
+            self.log('Epoch [%d/%d] time %.1fs train loss: %.4f test loss: %.4f, thresholds_optimal: %s, accuracy: %.4f, AUC: %s'
+                     % (epoch, self.args.num_epochs, time.time() - t0, tm['epoch_train_loss'], vm['epoch_valid_loss'], thr,
+                        vm.get('epoch_valid_accuracy', float('nan')),
+                        '|'.join('class-{0}>>{1:.4f}'.format(*k) for k in enumerate(aucs))))
+            if self.trainer.scheduler is not None:
+                self.trainer.scheduler.step()
+            current_auc = aucs[0]
+            prefix = ''
+            if current_auc >= best_auc:
+                prefix = '[best auc]'
+                if current_auc > best_auc:
+                    best_auc_epochs = []
+                best_auc = current_auc
+                best_auc_epochs.append(epoch)
+            self._save_epoch_model(thr, epoch, current_auc, report_prefix=prefix)
+        if self.trainer.rank == 0:
+            with open(os.path.join(self.save_path, 'train_metrics.json'), 'w') as f:
+                json.dump({'best_auc': float(best_auc), 'best_auc_epochs': best_auc_epochs}, f)
+        return [min(best_auc_epochs, default=None)]
+
+    def run_test(self, best_auc_epochs):
+        """Test pass (train.py:752-778) on the earliest best-AUC epoch and the last epoch with THEIR validation thresholds."""
+        out = {}
+        for epoch, tag in ((min([e for e in best_auc_epochs if e is not None], default=None), 'best_auc'),
+                           (self.args.num_epochs, 'last_epoch')):
+            if epoch is None:
+                continue
+            if self.trainer.dist is not None and self.trainer.world_size > 1:
+                self.trainer.dist.barrier()                                     # rank 0 wrote the files
+            thr = self._load_epoch_model(epoch)
+            res = self.trainer.valid(self.test_data, predefined_thresholds_optimal=thr)
+            out[tag] = {k.replace('epoch_valid', tag): v for k, v in res.items()}
+            self.log(f'[{tag}] epoch {epoch}: test loss {res["epoch_valid_loss"]:.4f} accuracy '
+                     f'{res.get("epoch_valid_accuracy", float("nan")):.4f}')
+        return out
+
+    def clean_up(self, best_auc_epochs):
+        """Keep the best-AUC and the last epoch's files (train.py:780-794)."""
+        if self.trainer.rank != 0:
+            return
+        keep = {e for e in best_auc_epochs if e is not None} | {self.args.num_epochs}
+        for epoch in range(1, self.args.num_epochs + 1):
+            if epoch not in keep:
+                for path in self._paths(epoch):
+                    if os.path.exists(path):
+                        os.remove(path)
+
+    def run(self):
+        best = self.run_train()
+        res = self.run_test(best)
+        self.clean_up(best)
+        return res
+
+
+def validate_args(args):
+    """train.py:985-1001: MIL datasets fix the feature width."""
+    args.soft_average = bool(args.soft_average)
+    feats = {'musk1': 166, 'musk2': 166, 'elephant': 230}
+    if args.dataset in feats:
+        args.feats_size = feats[args.dataset]
+        print(f'Setting feats_size to {args.feats_size} for {args.dataset}')
+    return args
+
+
+def main(argv=None, data=None):
+    """CLI entry (train.py:1004-1039): parse, build the trainer from the architecture registry, run.  List-valued flags may come
+    as strings (wandb sweeps) and are literal-eval'd like the reference does.  One process per GPU under torch.distributed.run:
+    the bag-parallel trainer picks RANK / WORLD_SIZE up from the environment."""
+    import ast
+    parser = get_args_parser()
+    parser.add_argument('--cv_num_folds', default=10, type=int)
+    parser.add_argument('--cv_current_fold', default=0, type=int)
+    parser.add_argument('--cv_valid_ratio', default=0.2, type=float)
+    parser.add_argument('--save_path', default=None, type=str)
+    args = validate_args(parser.parse_args(argv))
+    if isinstance(args.betas, str):
+        args.betas = ast.literal_eval(args.betas)
+    if isinstance(args.weight_init__weight_init_i__weight_init_b, str):
+        args.weight_init__weight_init_i__weight_init_b = ast.literal_eval(args.weight_init__weight_init_i__weight_init_b)
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo', rank=rank, world_size=world)
+    try:
+        trainer = ARCH_REGISTRY[args.arch](args, dist, rank, world)
+    except KeyError:
+        raise Exception(f'Invalid Architecture: {args.arch} | Choose from: {ARCH_REGISTRY.keys()}')
+    res = Runner(args, trainer, data=data, save_path=args.save_path).run()
+    if dist is not None:
+        dist.destroy_process_group()
+    return res
+
+
 class BagParallelStepper:
     """bench.py's training step: one resident bag per rank, backward, flat-gradient all-reduce, AdamW (train.py defaults)."""
 
@@ -491,3 +655,7 @@ class BagParallelStepper:
         self.optimizer.step()
         self.optimizer.zero_grad()           # set_to_none: the next backward assigns the gradients, no fill + add per parameter
         return loss.detach()
+
+
+if __name__ == '__main__':
+    main()

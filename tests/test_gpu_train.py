@@ -332,3 +332,91 @@ def test_fold_and_unfold_linear_kernels(r, c):
     assert (dw.double() - ref_dw).abs().max().item() <= 2e-6 * ref_dw.abs().max().item()
     assert (dgam.double() - ref_dg).abs().max().item() <= 1e-5 * max(1.0, ref_dg.abs().max().item())
     assert (dbet.double() - ref_db).abs().max().item() <= 1e-5 * max(1.0, ref_db.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 2])
+def test_snuffy_multiclass_trainer_run_model_and_step(B):
+    """train.SnuffyMulticlass (reference train.py:922-983) end to end: the trainer's own constructor builds the multi-class
+    MILNet, `_run_model` returns (bag_prediction, loss, sigmoid(c)) and one `loss.backward()` +
+    `_after_run_model_in_training_mode` step moves the weights -- all against the CPU oracle (same replayed random draws, oracle
+    autograd, torch's Adam on the CPU)."""
+    import numpy as np
+    from oracle import snuffy_oracle as orc
+    from snuffy_amd import train
+    args = train.get_args_parser().parse_args([])
+    args.arch, args.num_classes, args.feats_size, args.num_heads = "snuffy_multiclass", 2, 64, 2
+    args.big_lambda, args.random_patch_share, args.depth, args.activation = 12, 0.5, 1, "relu"
+    args.optimizer, args.lr, args.weight_decay, args.soft_average = "adam", 1e-3, 5e-3, 1
+    torch.manual_seed(5)
+    tr = train.ARCH_REGISTRY["snuffy_multiclass"](args)
+    assert isinstance(tr, train.SnuffyMulticlass) and str(tr) == "Snuffy_Multiclass_k12_sa1_depth1"
+    for layer in tr.milnet.b_classifier.encoder.layers:
+        layer.self_attn.dropout.p = 0.0              # the reference leaves p = 0.1 on in train mode: not reproducible across devices
+    N = 70
+    x = torch.randn(B, N, 64)
+    y = torch.tensor([[1.0, 0.0], [0.0, 1.0]][:B])
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in tr.milnet.state_dict().items()}
+    w_ref = torch.tensor(0.5, requires_grad=True)
+    # ---- oracle: forward, the trainer's loss mix (train.py:828-846), backward, Adam
+    np.random.seed(21)
+    ins_ref, logits_ref, _ = orc.milnet_forward_multiclass(x, sd, 2, "relu", 12, 0.5, 1)
+    max_ref, _ = torch.max(ins_ref, 1)
+    bce = torch.nn.BCEWithLogitsLoss()
+    loss_ref = w_ref * bce(logits_ref.view(1, -1), y.view(1, -1)) + (1 - w_ref) * bce(max_ref.view(1, -1), y.view(1, -1))
+    pred_ref = ((1 - w_ref) * torch.sigmoid(max_ref) + w_ref * torch.sigmoid(logits_ref)).detach().squeeze()
+    loss_ref.backward()
+    names = [k for k, _ in tr.milnet.named_parameters()]
+    opt_ref = torch.optim.Adam([{"params": [w_ref], "lr": args.lr * args.single_weight__lr_multiplier},
+                                {"params": [sd[k] for k in names]}], lr=args.lr, betas=(0.5, 0.9), weight_decay=args.weight_decay)
+    opt_ref.step()
+    # ---- the trainer on the GPU
+    tr.milnet.train()
+    np.random.seed(21)
+    pred, loss, ins = tr._run_model(x.to(DEV), y.to(DEV))
+    assert ins.shape == (B * N * 2, 1)
+    assert float((ins.detach().cpu().view(-1) - torch.sigmoid(ins_ref.detach()).reshape(-1)).abs().max()) < 1e-5
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    assert float((pred.cpu().reshape(-1) - pred_ref.reshape(-1)).abs().max()) < 1e-5
+    loss.backward()
+    tr._after_run_model_in_training_mode(step=0, num_bags=1, batch_idx=0)
+    for k, p in tr.milnet.named_parameters():
+        ref = sd[k].detach()
+        assert float((p.detach().cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), k
+    assert abs(float(tr.single_weight_parameter) - float(w_ref.detach().clamp(0, 1))) < 1e-6
+
+
+@pytest.mark.gpu
+def test_runner_epoch_loop_checkpoints_and_test_pass(tmp_path):
+    """train.Runner / main (reference train.py:682-794, 1004-1039): validation before epoch 1, train / valid / scheduler step per
+    epoch, `{epoch}.pth` + `thresholds_{epoch}.txt` + `single_weight_parameter_{epoch}` every epoch, best-AUC bookkeeping, the test
+    pass with the stored thresholds, clean-up of the other epochs; the saved state dict reloads into a fresh MILNet bit for bit."""
+    import json
+    import numpy as np
+    from snuffy_amd import train
+    rs = np.random.RandomState(0)
+
+    def split(n):
+        labels = [np.array([float(i % 2)], dtype=np.float32) for i in range(n)]
+        feats = [(rs.randn(40 + 3 * i, 32) + (1.5 if i % 2 else 0.0)).astype(np.float32) for i in range(n)]
+        return labels, feats, [None] * n, [None] * n
+    data = (split(12), split(6), split(6))
+    np.random.seed(0)
+    torch.manual_seed(0)
+    argv = ["--dataset", "synthetic", "--feats_size", "32", "--num_heads", "2", "--big_lambda", "10", "--num_epochs", "3",
+            "--lr", "2e-3", "--optimizer", "adamw", "--save_path", str(tmp_path / "run")]
+    res = train.main(argv, data=data)
+    assert set(res) == {"best_auc", "last_epoch"} and "last_epoch_loss" in res["last_epoch"]
+    run = tmp_path / "run"
+    with open(run / "train_metrics.json") as f:
+        tm = json.load(f)
+    assert tm["best_auc_epochs"] and 0.0 <= tm["best_auc"] <= 1.0
+    keep = {min(tm["best_auc_epochs"]), 3}
+    for epoch in (1, 2, 3):
+        assert (run / f"{epoch}.pth").exists() == (epoch in keep) and (run / f"thresholds_{epoch}.txt").exists() == (epoch in keep)
+    sd = torch.load(run / "3.pth", map_location="cpu")
+    from snuffy_amd.snuffy import build_milnet
+    twin = build_milnet(32, 2, "relu", 10, 0.0, 1)
+    twin.load_state_dict(sd, strict=True)                       # the reference's key names, strict
+    w = torch.load(run / "single_weight_parameter_3", map_location="cpu")
+    assert 0.0 <= float(w) <= 1.0
