@@ -172,6 +172,82 @@ def _tn_mm(a, b, chunks=8):
     return out
 
 
+_MM_F32_OUT = None      # does this torch build take out_dtype on bf16 GEMMs (fp32 results without a bf16 rounding)?
+
+
+def _tn_mm_f32(a, b, chunks=8):
+    """a^T b for bf16 a [n, p], b [n, q] (row-strided views allowed) -> [p, q] f32 with NO bf16 rounding of the result: the
+    contraction over the bag axis of the fp32-class weight gradients.  Library GEMM with an fp32 output (out_dtype), split
+    over row chunks like _tn_mm; a build without out_dtype falls back to the fp32 library GEMM."""
+    global _MM_F32_OUT
+    n = a.shape[0]
+    if _MM_F32_OUT is None:
+        try:
+            torch.mm(a[:8].t(), b[:8], out_dtype=torch.float32)
+            _MM_F32_OUT = True
+        except (TypeError, RuntimeError, NotImplementedError):
+            _MM_F32_OUT = False
+    if not _MM_F32_OUT:
+        return torch.mm(a.float().t(), b.float())
+    m = (n // chunks) * chunks
+    if n < 4096 or m == 0:
+        return torch.mm(a.t(), b, out_dtype=torch.float32)
+    av = a[:m].view(chunks, m // chunks, a.shape[1]).transpose(1, 2)
+    out = torch.bmm(av, b[:m].view(chunks, m // chunks, b.shape[1]), out_dtype=torch.float32).sum(0)
+    if m < n:
+        out += torch.mm(a[m:].t(), b[m:], out_dtype=torch.float32)
+    return out
+
+
+class LinearX3Fn(torch.autograd.Function):
+    """y = x W^T + b with fp32 tensors and fp32-class arithmetic on the matrix cores, forward AND backward (reference train.py:259
+    differentiates nn.Linear in fp32; an fp32 library GEMM runs at 60-100 TFLOP/s here).  Every product is taken as
+    hi hi + hi lo + lo hi of the operands' bf16 halves with fp32 accumulation (~1e-5 per product, as functional.FP32_GEMM = "x3"):
+      forward   the split image [hi | hi | lo] of x against [Wh | Wl | Wh]                     (ops.gemm_bf16, one launch)
+      dx        the split image of dy against the same image of W^T                            (ops.gemm_bf16)
+      dW        [dyh | dyl]^T [xh | xl] over the bag axis -- the two images' last two column blocks, in place -- as ONE library
+                GEMM with an fp32 result; dW = the three blocks hi hi + hi lo + lo hi (lo lo is computed and dropped)
+    The image of x (bf16 [n, 3 k]) is what is saved for the backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        img = ops.split3_rows(x.float() if x.dtype != torch.float32 else x)
+        y = ops.gemm_bf16(img, SF.split3_cached(weight), None if bias is None else bias.detach().float().contiguous(),
+                          out_dtype=torch.float32)
+        ctx.save_for_backward(img, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        img, weight = ctx.saved_tensors
+        n_out, k = weight.shape
+        dimg = ops.split3_rows(dy.float().contiguous())
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_bf16(dimg, SF.split3_cached(weight, transposed=True), None, out_dtype=torch.float32)
+        if ctx.needs_input_grad[1]:
+            g = _tn_mm_f32(dimg[:, n_out:], img[:, k:])                     # [dyh | dyl]^T [xh | xl] -> [2 out, 2 k]
+            dw = g[:n_out, :k] + g[:n_out, k:] + g[n_out:, :k]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.float().sum(0)
+        return dx, dw, db
+
+
+def linear_x3_ok(x, weight):
+    """fp32-class linear on the matrix cores applies: fp32 training path with FP32_GEMM = "x3", shapes in the GEMM's domain."""
+    n, k = x.shape
+    return (SF.FP32_GEMM == "x3" and not torch.is_autocast_enabled() and x.is_cuda and x.dtype == torch.float32 and n >= 256
+            and k % 8 == 0 and weight.shape[0] % 8 == 0 and ops.gemm_x3_supported(n, weight.shape[0], k)
+            and ops.gemm_x3_supported(n, k, weight.shape[0]))
+
+
+def _linear(x, lin):
+    if linear_x3_ok(x, lin.weight):
+        return LinearX3Fn.apply(x, lin.weight, lin.bias)
+    return F.linear(x, lin.weight, lin.bias)
+
+
 class EncoderLayer0Bf16Fn(torch.autograd.Function):
     """EncoderLayer.forward + backward (snuffy.py:126-157) for the FIRST layer of a bf16 training step, as one hand-ordered
     chain: the bag x is data there (no gradient), so nothing upstream of the K selected rows needs d/dx and the backward
@@ -359,9 +435,15 @@ def _encoder_layer_train(x2, sel, layer, need_attn):
     else:
         xs = x2.index_select(0, sel)                                            # snuffy.py:131,145-147
         xn = LayerNormRowsFn.apply(x2, n0.weight, n0.bias, n0.eps)              # snuffy.py:107
-        q = F.linear(xn, lq.weight, lq.bias)
+        if linear_x3_ok(xn, lq.weight) and lq.bias is not None and lv.bias is not None:
+            # fp32: split-bf16 x3 on the MFMA GEMM, forward and backward; Q | V as ONE projection (one image of xn, one dx)
+            d = xn.shape[1]
+            qv = LinearX3Fn.apply(xn, torch.cat([lq.weight, lv.weight]), torch.cat([lq.bias, lv.bias]))
+            q, v = qv[:, :d], qv[:, d:]
+        else:
+            q = F.linear(xn, lq.weight, lq.bias)
+            v = F.linear(xn, lv.weight, lv.bias)
         kp = F.linear(xs, lk.weight, lk.bias)
-        v = F.linear(xn, lv.weight, lv.bias)
         p_drop = mha.dropout.p if training else 0.0
         o, p = SparseAttnFn.apply(q, kp, v, mha.h, p_drop, torch.is_autocast_enabled(), need_attn)
         delta = F.linear(o, lo.weight, lo.bias)                                 # snuffy.py:205
@@ -371,10 +453,10 @@ def _encoder_layer_train(x2, sel, layer, need_attn):
         y = ScatterRowsFn.apply(x2, sel, x_sel)                                 # snuffy.py:154-155
         attn = p.detach().unsqueeze(0) if (need_attn and p is not None) else None
     yn = LayerNormRowsFn.apply(y, n1.weight, n1.bias, n1.eps)
-    hid = _ACT[ff.activation_name](F.linear(yn, ff.w_1.weight, ff.w_1.bias))    # snuffy.py:224-225
+    hid = _ACT[ff.activation_name](_linear(yn, ff.w_1))                         # snuffy.py:224-225
     if training and ff.dropout.p > 0:
         hid = F.dropout(hid, ff.dropout.p, True)
-    f = F.linear(hid, ff.w_2.weight, ff.w_2.bias)
+    f = _linear(hid, ff.w_2)
     if training and drop1.p > 0:
         f = F.dropout(f, drop1.p, True)
     z = y + f.float()                                                           # snuffy.py:110

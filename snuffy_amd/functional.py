@@ -76,6 +76,19 @@ def critic_scores(feats, w, b):
     return s.view(*lead, w.shape[0])
 
 
+def split3_cached(weight, transposed=False):
+    """[Wh | Wl | Wh] image of a parameter (ops.split3_weight) -- or of its transpose -- cached on the parameter until it is
+    written again (optimizer step, load_state_dict)."""
+    key = (weight.data_ptr(), weight._version)
+    name = "_snf_x3t" if transposed else "_snf_x3"
+    hit = getattr(weight, name, None)
+    if hit is None or hit[0] != key:
+        w = weight.detach()
+        hit = (key, ops.split3_weight(w.t().contiguous() if transposed else w))
+        setattr(weight, name, hit)
+    return hit[1]
+
+
 def _needs_grad(*tensors):
     """True when autograd has to see this op: grad mode on and some input / parameter asks for a gradient."""
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)

@@ -507,7 +507,7 @@ class Runner:
         model_path, log_path, w_path = self._paths(epoch)
         torch.save(self.trainer.milnet.state_dict(), model_path)
         with open(log_path, 'w') as f:
-            json.dump({'auc': float(auc), 'thresholds_optimal': str(list(np.asarray(thresholds_optimal, dtype=np.float64))),
+            json.dump({'auc': float(auc), 'thresholds_optimal': str([float(v) for v in np.asarray(thresholds_optimal, dtype=np.float64).reshape(-1)]),
                        'feats_thresholds_optimal': None}, f)
         if hasattr(self.trainer, 'single_weight_parameter'):
             torch.save(self.trainer.single_weight_parameter, w_path)

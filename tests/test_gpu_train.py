@@ -353,6 +353,7 @@ def test_snuffy_multiclass_trainer_run_model_and_step(B):
     assert isinstance(tr, train.SnuffyMulticlass) and str(tr) == "Snuffy_Multiclass_k12_sa1_depth1"
     for layer in tr.milnet.b_classifier.encoder.layers:
         layer.self_attn.dropout.p = 0.0              # the reference leaves p = 0.1 on in train mode: not reproducible across devices
+        layer.feed_forward.dropout.p = 0.0           # ... and the multi-class FFN's default 0.1 as well (train.py:935-939)
     N = 70
     x = torch.randn(B, N, 64)
     y = torch.tensor([[1.0, 0.0], [0.0, 1.0]][:B])
@@ -382,7 +383,9 @@ def test_snuffy_multiclass_trainer_run_model_and_step(B):
     tr._after_run_model_in_training_mode(step=0, num_bags=1, batch_idx=0)
     for k, p in tr.milnet.named_parameters():
         ref = sd[k].detach()
-        assert float((p.detach().cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), k
+        # the key bias has a mathematically zero gradient (softmax is shift-invariant): its Adam step is +-lr of rounding noise
+        tol = 2.1 * args.lr if k.endswith("self_attn.linears.1.bias") else 2e-5 * max(1.0, float(ref.abs().max()))
+        assert float((p.detach().cpu() - ref).abs().max()) <= tol, k
     assert abs(float(tr.single_weight_parameter) - float(w_ref.detach().clamp(0, 1))) < 1e-6
 
 

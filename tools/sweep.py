@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
-"""North-star sweep: synthetic bags N in {1k, 8k, 32k, 100k} x D in {384, 768} (h = 6, Lambda = 200, bf16 path, eval forward)
-on one MI355X: slides/s of the whole aggregator, the sparse-attention and top-Lambda kernels alone, and their share of the
-8 TB/s HBM roof (at the kernels' own operand width and at the fp32 byte figure of SURVEY section 8(d)).
+"""North-star sweep: synthetic bags N in {1k, 8k, 32k, 100k} x D in {384, 768} (h = 6, Lambda = 200, eval forward) on one MI355X,
+in BOTH arithmetics (fp32-class = the reference's, bf16), next to the reference's CPU path (the parity-checked torch-CPU port of
+oracle/, timed on this host's cores; core count stated): slides/s of the whole aggregator, the sparse-attention and top-Lambda
+kernels alone and their share of the 8 TB/s HBM roof (at the kernels' own operand width and at the fp32 byte figure of SURVEY 8(d)).
 
-    python tools/sweep.py [--steps 30] > gpurun_out/sweep.md
+    python tools/sweep.py [--steps 30] [--cpu-threads 32] [--no-cpu] > gpurun_out/sweep.md
 """
 import argparse
 import os
 import sys
+import time
 
 import torch
 
@@ -15,43 +17,82 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import build_net, kernel_rooflines  # noqa: E402
 
 
+def cpu_rate(N, D, lam, threads, budget_s=6.0):
+    """slides/s of the CPU port (oracle.milnet_forward, A materialised as the reference does) at `threads` threads."""
+    from oracle import snuffy_oracle as orc          # CPU baseline column: the checker, timed -- never the product path
+    net = build_net(D, 6, lam, "fp32", "cpu")
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = torch.randn(N, D, generator=torch.Generator().manual_seed(1234))
+    torch.set_num_threads(threads)
+    with torch.no_grad():
+        orc.milnet_forward(x, sd, 6, "relu", lam, 0.0, 1)
+        t0, n = time.perf_counter(), 0
+        while True:
+            orc.milnet_forward(x, sd, 6, "relu", lam, 0.0, 1)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 50:
+                break
+    return n / el
+
+
+def gpu_ms(net, bags, steps, graph):
+    nb = len(bags)
+    net.configure(graph_max_patches=(1 << 20) if graph else 0)
+    with torch.no_grad():
+        for i in range(2 * nb + 4):
+            net(bags[i % nb])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(steps):
+            net(bags[i % nb])
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--lam", type=int, default=200)
+    ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU column (bench.py's sweep finds 16-32 best on a 128-core host)")
+    ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    print("| N | D | K | slides/s (graph replay) | slides/s (eager issue) | ms/bag | attention µs | top-Λ µs | attn frac (bf16 bytes) "
-          "| attn+top-Λ frac (§8(d) fp32 bytes) |")
-    print("|---|---|---|---|---|---|---|---|---|---|")
+    cpu_model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")][0]
+    except (OSError, IndexError):
+        pass
+    print("one MI355X; CPU column: oracle/snuffy_oracle.py (torch-CPU fp32 port of the reference's op sequence) on %s, %d threads of %d cores\n"
+          % (cpu_model, args.cpu_threads, os.cpu_count() or 0))
+    print("| N | D | K | CPU slides/s | fp32-class slides/s | x CPU | bf16 slides/s | x CPU | fp32 attention µs | frac of 8 TB/s | bf16 attention µs "
+          "| frac (bf16 bytes) | top-Λ µs (in pipeline) | fp32 attn+top-Λ frac (§8(d) bytes) | bf16 attn+top-Λ frac (§8(d) bytes) | bf16 slides/s eager issue |")
+    print("|" + "---|" * 16)
     for D in (384, 768):
         for N in (1000, 8192, 32768, 100000):
             wl = dict(N=N, D=D, h=6, lam=args.lam)
-            net = build_net(D, 6, args.lam, "bf16", dev).eval()
             nb = max(2, min(8, int(2.0e9 // (N * D * 4))))
             g = torch.Generator().manual_seed(1234)
             bags = [torch.randn(1, N, D, generator=g).to(dev) for _ in range(nb)]
-            res = {}
-            with torch.no_grad():
-                for mode in ("eager", "graph"):
-                    net.configure(graph_max_patches=(1 << 20) if mode == "graph" else 0)
-                    for i in range(2 * nb + 4):
-                        net(bags[i % nb])
-                    torch.cuda.synchronize()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for i in range(args.steps):
-                        net(bags[i % nb])
-                    e1.record()
-                    torch.cuda.synchronize()
-                    res[mode] = e0.elapsed_time(e1) / args.steps
-            ms = res["graph"]
-            r = kernel_rooflines(wl, "bf16", dev, "sweep")
-            ra, ru = r["roofline"], r["roofline_topk_attn"]
-            print("| %d | %d | %d | %.0f | %.0f | %.3f | %.1f | %.1f | %.3f | %.3f |"
-                  % (N, D, min(args.lam, N), 1e3 / ms, 1e3 / res["eager"], ms, ra["us_per_launch"], ru["us_topk"], ra["frac"],
-                     ru["survey_8d_frac"]), flush=True)
-            del bags, net
+            ms, roof = {}, {}
+            for prec in ("fp32", "bf16"):
+                net = build_net(D, 6, args.lam, prec, dev).eval()
+                ms[prec] = gpu_ms(net, bags, args.steps, True)
+                if prec == "bf16":
+                    ms["bf16_eager"] = gpu_ms(net, bags, args.steps, False)
+                del net
+                roof[prec] = kernel_rooflines(wl, prec, dev, "sweep")
+            cpu = float("nan") if args.no_cpu else cpu_rate(N, D, args.lam, args.cpu_threads)
+            rf, rb = roof["fp32"], roof["bf16"]
+            print("| %d | %d | %d | %.2f | %.0f | %.0f | %.0f | %.0f | %.1f | %.3f | %.1f | %.3f | %.1f | %.3f | %.3f | %.0f |"
+                  % (N, D, min(args.lam, N), cpu, 1e3 / ms["fp32"], 1e3 / ms["fp32"] / cpu, 1e3 / ms["bf16"], 1e3 / ms["bf16"] / cpu,
+                     rf["roofline"]["us_per_launch"], rf["roofline"]["frac"], rb["roofline"]["us_per_launch"], rb["roofline"]["frac"],
+                     rb["roofline_topk_attn"]["us_topk"], rf["roofline_topk_attn"]["survey_8d_frac"],
+                     rb["roofline_topk_attn"]["survey_8d_frac"], 1e3 / ms["bf16_eager"]), flush=True)
+            del bags
             torch.cuda.empty_cache()
 
 
