@@ -298,6 +298,14 @@ int snf_sparse_attn_dkp_f32(const float* ds, const float* q, int64_t n, int k, i
  * --------------------------------------------------------------------------------------------------------- */
 int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t m, int n, int k,
                   int act, void* c, int64_t ldc, int out_dtype, int tile_n, snf_stream_t stream);
+/* The same product in fp32-class arithmetic, ONE pass over the operands: a_img = [hi | hi | lo] image of A (m rows of 3 k bf16
+ * columns, as snf_split3_f32 / snf_layernorm_rows_split3_f32 / snf_gemm_bf16(out_dtype = SNF_DT_BF16_SPLIT3) write it), w_img =
+ * [Wh | Wl | Wh] of W [n, k]; C = act(A W^T + bias) with every product taken as hi hi + hi lo + lo hi (fp32 accumulate).
+ * Equivalent to snf_gemm_bf16 over the 3 k concatenated columns up to summation order; a K step stages the four half images
+ * once (2/3 of the L2 -> LDS bytes and fragment reads per MFMA, 96 MFMAs per wave between barriers).  256 x 256 tiles;
+ * k % 32 == 0.  nn.Linear of snuffy.py:187-190,224-225 and of the ViT blocks in the reference's fp32 arithmetic. */
+int snf_gemm_x3_bf16(const void* a_img, int64_t lda, const void* w_img, int64_t ldw, const float* bias, int64_t m, int n, int k,
+                     int act, void* c, int64_t ldc, int out_dtype, snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K12-K14  ViT patch-embedding extractor (compute_feats.py:239-247 -> IClassifier -> VisionTransformer.forward)

@@ -212,7 +212,7 @@ class LinearX3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         img = ops.split3_rows(x.float() if x.dtype != torch.float32 else x)
-        y = ops.gemm_bf16(img, SF.split3_cached(weight), None if bias is None else bias.detach().float().contiguous(),
+        y = ops.gemm_x3(img, SF.split3_cached(weight), None if bias is None else bias.detach().float().contiguous(),
                           out_dtype=torch.float32)
         ctx.save_for_backward(img, weight)
         ctx.has_bias = bias is not None
@@ -225,7 +225,7 @@ class LinearX3Fn(torch.autograd.Function):
         dimg = ops.split3_rows(dy.float().contiguous())
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm_bf16(dimg, SF.split3_cached(weight, transposed=True), None, out_dtype=torch.float32)
+            dx = ops.gemm_x3(dimg, SF.split3_cached(weight, transposed=True), None, out_dtype=torch.float32)
         if ctx.needs_input_grad[1]:
             g = _tn_mm_f32(dimg[:, n_out:], img[:, k:])                     # [dyh | dyl]^T [xh | xl] -> [2 out, 2 k]
             dw = g[:n_out, :k] + g[:n_out, k:] + g[n_out:, :k]

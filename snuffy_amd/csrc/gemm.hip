@@ -347,6 +347,269 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
     if (wr == 0) __builtin_amdgcn_s_barrier();   // barrier counts of the two wave groups match again
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fp32-class GEMM in ONE pass over the operands: C = act(A W^T + bias) with A given as its split image [hi | hi | lo] (row
+// pitch lda, true width k) and W as [Wh | Wl | Wh].  The concatenated form (gemm_bf16_kernel over 3 k) streams the hi halves
+// twice and pays three K steps of barriers, LDS-DMA issue and fragment reads per 32 true columns; here a step stages the four
+// images (A hi, A lo, W hi, W lo: 64 KiB) once and issues the three products hi hi + hi lo + lo hi out of them: 96 MFMAs per
+// wave and step behind 20 fragment reads -- 2/3 of the L2 -> LDS bytes and of the LDS reads per MFMA, a matrix burst three
+// times as long per barrier.  256 x 256 tiles, two step buffers (128 KiB), all 8 waves in lockstep: the DMA of step s + 1 flies
+// under the MFMA burst of step s.  Register budget: the A-lo fragments are read into the A-hi registers while the second
+// product (hi lo) is still issuing, row block by row block.
+template <int ACT, int OUT>
+__global__ __launch_bounds__(512, 2) void gemm_x3_kernel(GemmParams P) {
+    constexpr int NI = 4, BN = 256;
+    constexpr int IMG = BM * ROWB;               // one 256 x 32 image: 16 KiB
+    constexpr int STEP_BYTES = 4 * IMG;          // A hi | A lo | W hi | W lo
+    constexpr int NC = 4 * NI;
+    constexpr bool OUT_F32 = OUT == 1;
+    constexpr int NST = OUT == 1 ? NC / 4 : OUT == 2 ? 3 * NC / 8 : NC / 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][A hi | A lo | W hi | W lo]
+
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int ns = P.k / BKS;                    // steps per tile (true K)
+
+    const int ntiles = P.tiles_m * P.tiles_n;
+    const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int t_lo, t_hi;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7;
+        t_lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        t_hi = t_lo + q + (xcd < r ? 1 : 0);
+    }
+    int tile = t_lo + wg_in_xcd;
+    if (tile >= t_hi) return;
+
+    struct Src {
+        int a[2], w[2];
+    };
+    auto tile_src = [&](int tl) __attribute__((always_inline)) -> Src {
+        Src s;
+        const int tm = tl / P.tiles_n, tn = tl - tm * P.tiles_n;
+        const int slot = lane & 3;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (2 * wid + j) * 16 + (lane >> 2);
+            int grow = tm * BM + row;
+            if (grow > P.m - 1) grow = P.m - 1;
+            s.a[j] = grow * (int)P.lda + ((slot ^ ((-(row >> 2)) & 3)) << 3);
+            int wrow = tn * BN + row;
+            if (wrow > P.n - 1) wrow = P.n - 1;
+            s.w[j] = wrow * (int)P.ldw + ((slot ^ ((-(row >> 3)) & 3)) << 3);
+        }
+        return s;
+    };
+    // images: A hi at column 0, A lo at column 2 k of [hi | hi | lo]; W hi at column 0, W lo at column k of [Wh | Wl | Wh]
+    auto stage = [&](const Src& s, int kstep, int buf) __attribute__((always_inline)) {
+#ifdef X3_NOSTAGE   // timing ablations (dev builds, tools/gemm_x3_ablate.sh): pieces of the step compiled out, results wrong
+        return;
+#endif
+        unsigned char* base = smem + buf * STEP_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((glb_void*)(P.a + s.a[j] + kstep * BKS), (lds_void*)(base + (2 * wid + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(P.a + s.a[j] + 2 * P.k + kstep * BKS),
+                                             (lds_void*)(base + IMG + (2 * wid + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(P.w + s.w[j] + kstep * BKS),
+                                             (lds_void*)(base + 2 * IMG + (2 * wid + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(P.w + s.w[j] + P.k + kstep * BKS),
+                                             (lds_void*)(base + 3 * IMG + (2 * wid + j) * 1024), 16, 0, 0);
+        }
+    };
+
+    const int fi = lane & 15, fg = lane >> 4;
+    const int fsw = (fg ^ ((-(fi >> 2)) & 3)) << 4;
+    const int xoff = (128 * wr + fi) * ROWB + fsw;                                      // + mi * 1024 (+ IMG for lo)
+    const int woff = 2 * IMG + (64 * wc + 8 * (fi >> 2) + (fi & 3)) * ROWB + fsw;       // + (4 (ni & 1) + 32 (ni >> 1)) * 64 (+ IMG for lo)
+
+    f32x4 acc[8][NI];
+    bf16x8 xf[8], wh[NI], wl[NI];
+    f32x4 bv4[NC / 4];
+#pragma unroll
+    for (int c4 = 0; c4 < NC / 4; ++c4) bv4[c4] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto frag = [&](const unsigned char* p) __attribute__((always_inline)) -> bf16x8 {
+#ifdef X3_NOREAD
+        u32x4 z = {1u, 2u, 3u, (unsigned)lane};
+        asm volatile("" : "+v"(z));
+        return __builtin_bit_cast(bf16x8, z);
+#endif
+        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+    };
+#ifdef X3_NOMFMA
+#define X3_MFMA(a, b, c) ([&]() { f32x4 t_ = (c); asm volatile("" : "+v"(t_) : "v"(a), "v"(b)); return t_; }())
+#else
+#define X3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
+    auto load_bias = [&](int tl) __attribute__((always_inline)) {
+        if (P.bias) {
+            const int tn = tl % P.tiles_n;
+            const int n0 = tn * BN + 64 * wc + 8 * fg;
+            const float* bp0 = P.bias + (n0 + 8 <= P.n ? n0 : 0);
+            const float* bp1 = P.bias + (n0 + 40 <= P.n ? n0 + 32 : 0);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv4[0]) : "v"(bp0) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(bv4[1]) : "v"(bp0) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv4[2]) : "v"(bp1) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(bv4[3]) : "v"(bp1) : "memory");
+        }
+    };
+    auto bias_landed = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int c4 = 0; c4 < NC / 4; ++c4) asm volatile("" : "+v"(bv4[c4]));
+    };
+    auto epilogue = [&](int tl, auto full_t) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_t)::value;
+        const int tm = tl / P.tiles_n, tn = tl - tm * P.tiles_n;
+        const int n0 = tn * BN + 64 * wc + 8 * fg;
+        const int row0 = tm * BM + 128 * wr + fi;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int row = row0 + 16 * mi;
+#pragma unroll
+            for (int h = 0; h < NI / 2; ++h) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = activate<ACT>(acc[mi][2 * h + (e >> 2)][e & 3] + bv4[2 * h + (e >> 2)][e & 3]);
+                const int col = n0 + 32 * h;
+#ifdef X3_NOSTORE
+                const bool ok = v[0] == 123.456f;
+#else
+                const bool ok = FULL || (row < P.m && col + 8 <= P.n);
+#endif
+                if constexpr (OUT_F32) {
+                    float* dst = reinterpret_cast<float*>(P.c) + (int64_t)row * P.ldc + col;
+                    if (ok) {
+                        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    }
+                } else {
+                    unsigned short* dst = reinterpret_cast<unsigned short*>(P.c) + (int64_t)row * P.ldc + col;
+                    const u32x4 pk = {cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
+                    if (ok) *reinterpret_cast<u32x4*>(dst) = pk;
+                    if constexpr (OUT == 2) {
+                        float lo[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            lo[e] = v[e] - __uint_as_float((e & 1) ? (pk[e >> 1] & 0xffff0000u) : (pk[e >> 1] << 16));
+                        const u32x4 pl = {cvt_pk_bf16(lo[0], lo[1]), cvt_pk_bf16(lo[2], lo[3]), cvt_pk_bf16(lo[4], lo[5]), cvt_pk_bf16(lo[6], lo[7])};
+                        if (ok) {
+                            *reinterpret_cast<u32x4*>(dst + P.n) = pk;
+                            *reinterpret_cast<u32x4*>(dst + 2 * (int64_t)P.n) = pl;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    Src cur = tile_src(tile);
+    stage(cur, 0, 0);
+    int buf = 0;
+    while (true) {
+        const int next = tile + wgs_per_xcd;
+        const bool has_next = next < t_hi;
+        const bool full = (tile / P.tiles_n + 1) * BM <= P.m && (tile % P.tiles_n + 1) * BN <= P.n;
+        for (int s = 0; s < ns; ++s) {
+            // this step's four images have landed (every wave waits for its own pieces, then all meet); the other buffer is free:
+            // its last fragment reads belong to the previous step's MFMAs, which every wave has issued before this barrier
+            wait_vmcnt<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* base = smem + buf * STEP_BYTES;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) wh[ni] = frag(base + woff + (4 * (ni & 1) + 32 * (ni >> 1)) * ROWB);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) xf[mi] = frag(base + xoff + mi * 1024);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) wl[ni] = frag(base + IMG + woff + (4 * (ni & 1) + 32 * (ni >> 1)) * ROWB);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < ns) {
+                stage(cur, s + 1, buf ^ 1);
+            } else if (has_next) {
+                cur = tile_src(next);      // the next tile's first step flies under this tile's last burst and its epilogue
+                stage(cur, 0, buf ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- hi hi
+            __builtin_amdgcn_s_setprio(1);
+            if (s == 0) {
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = X3_MFMA(wh[ni], xf[mi], (f32x4{0.f, 0.f, 0.f, 0.f}));
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = X3_MFMA(wh[ni], xf[mi], acc[mi][ni]);
+            }
+            // ---- hi lo; the A-lo fragment of a row block replaces its A-hi fragment as soon as that block's products are issued
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = X3_MFMA(wl[ni], xf[mi], acc[mi][ni]);
+                __builtin_amdgcn_sched_barrier(0);
+                xf[mi] = frag(base + IMG + xoff + mi * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- lo hi
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = X3_MFMA(wh[ni], xf[mi], acc[mi][ni]);
+            __builtin_amdgcn_s_setprio(0);
+            buf ^= 1;
+        }
+        // bias: fetched here (one L2 round trip per tile) instead of being carried in 16 registers through the K loop
+        load_bias(tile);
+        wait_vmcnt<0>();
+        bias_landed();
+        if (full)
+            epilogue(tile, std::true_type{});
+        else
+            epilogue(tile, std::false_type{});
+        if (!has_next) break;
+        tile = next;
+    }
+}
+
+template <int ACT, int OUT>
+int launch_x3(const GemmParams& P, hipStream_t s) {
+    constexpr int lds = 2 * 4 * BM * ROWB;
+    static thread_local bool attr_set = false;
+    auto kern = gemm_x3_kernel<ACT, OUT>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            snf::set_error("gemm_x3: cannot reserve %d bytes of LDS", lds);
+            (void)hipGetLastError();
+            return SNF_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    const int ntiles = P.tiles_m * P.tiles_n;
+    int grid = snf::cu_count() & ~7;
+    if (grid < 8) grid = 8;
+    const int per_xcd = (ntiles + 7) / 8;
+    if (per_xcd * 8 < grid) grid = per_xcd * 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, P);
+    return snf::check_launch("gemm_x3_kernel");
+}
+
+template <int OUT>
+int launch_x3_act(const GemmParams& P, hipStream_t s) {
+    switch (P.act) {
+        case SNF_ACT_RELU: return launch_x3<SNF_ACT_RELU, OUT>(P, s);
+        case SNF_ACT_GELU: return launch_x3<SNF_ACT_GELU, OUT>(P, s);
+        case SNF_ACT_LEAKYRELU: return launch_x3<SNF_ACT_LEAKYRELU, OUT>(P, s);
+        case SNF_ACT_SELU: return launch_x3<SNF_ACT_SELU, OUT>(P, s);
+        default: return launch_x3<SNF_ACT_NONE, OUT>(P, s);
+    }
+}
+
 template <int NI, int ACT, int OUT>
 int launch(const GemmParams& P, hipStream_t s) {
     constexpr int lds = NBUF * (A_BYTES + 64 * NI * ROWB);
@@ -423,4 +686,35 @@ extern "C" int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t 
     if (out_dtype == SNF_DT_BF16_SPLIT3) return tile_n == 256 ? launch_act<4, 2>(P, s) : launch_act<2, 2>(P, s);
     if (tile_n == 256) return out_dtype == SNF_DT_F32 ? launch_act<4, 1>(P, s) : launch_act<4, 0>(P, s);
     return out_dtype == SNF_DT_F32 ? launch_act<2, 1>(P, s) : launch_act<2, 0>(P, s);
+}
+
+extern "C" int snf_gemm_x3_bf16(const void* a_img, int64_t lda, const void* w_img, int64_t ldw, const float* bias, int64_t m, int n,
+                                int k, int act, void* c, int64_t ldc, int out_dtype, snf_stream_t stream) {
+    SNF_REQUIRE(a_img && w_img && c, "snf_gemm_x3_bf16: null pointer");
+    SNF_REQUIRE(m >= 1 && n >= 1 && k >= 1, "snf_gemm_x3_bf16: bad shape m=%lld n=%d k=%d", (long long)m, n, k);
+    SNF_REQUIRE(act >= SNF_ACT_RELU && act <= SNF_ACT_NONE, "snf_gemm_x3_bf16: bad activation code %d", act);
+    SNF_REQUIRE(out_dtype == SNF_DT_F32 || out_dtype == SNF_DT_BF16 || out_dtype == SNF_DT_BF16_SPLIT3,
+                "snf_gemm_x3_bf16: bad output dtype %d", out_dtype);
+    if (k % BKS || k < BKS || n % 8 || lda % 8 || ldw % 8 || ldc % (out_dtype == SNF_DT_F32 ? 4 : 8) || lda < 3 * (int64_t)k ||
+        ldw < 3 * (int64_t)k || ldc < (out_dtype == SNF_DT_BF16_SPLIT3 ? 3 * (int64_t)n : n) ||
+        (reinterpret_cast<uintptr_t>(a_img) | reinterpret_cast<uintptr_t>(w_img) | reinterpret_cast<uintptr_t>(c)) % 16 ||
+        (bias && reinterpret_cast<uintptr_t>(bias) % 16) || m * lda >= 0x7fffffffll || (int64_t)n * ldw >= 0x7fffffffll) {
+        snf::set_error("snf_gemm_x3_bf16: shape m=%lld n=%d k=%d (lda %lld ldw %lld ldc %lld) outside the kernel's domain "
+                       "(k %% 32, n %% 8, images of 3 k columns, 16-byte aligned rows, 31-bit element offsets)",
+                       (long long)m, n, k, (long long)lda, (long long)ldw, (long long)ldc);
+        return SNF_EUNSUPPORTED;
+    }
+    GemmParams P;
+    P.a = reinterpret_cast<const unsigned short*>(a_img);
+    P.w = reinterpret_cast<const unsigned short*>(w_img);
+    P.bias = bias;
+    P.c = c;
+    P.lda = lda, P.ldw = ldw, P.ldc = ldc;
+    P.m = (int)m, P.n = n, P.k = k, P.act = act;
+    P.tiles_m = (int)((m + BM - 1) / BM);
+    P.tiles_n = (n + 255) / 256;
+    P.trace = nullptr;
+    hipStream_t s = snf::as_stream(stream);
+    if (out_dtype == SNF_DT_BF16_SPLIT3) return launch_x3_act<2>(P, s);
+    return out_dtype == SNF_DT_F32 ? launch_x3_act<1>(P, s) : launch_x3_act<0>(P, s);
 }

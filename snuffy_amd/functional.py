@@ -350,7 +350,7 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
         xs, slot = ops.gather_slot_map(x2, sel)                                     # snuffy.py:131,145-147 (+ row -> slot map)
         kp = F.linear(xs, lk.weight, lk.bias)                                       # keys = RAW selected rows (K rows: fp32)
         xn3 = ops.layernorm_rows_split3(x2, n0.weight, n0.bias, n0.eps)             # snuffy.py:107
-        qv = ops.gemm_bf16(xn3, fw["wqv"], fw["bqv"], out_dtype=torch.float32)      # [N, 2D] f32 = [Q | V]
+        qv = ops.gemm_x3(xn3, fw["wqv"], fw["bqv"], out_dtype=torch.float32)      # [N, 2D] f32 = [Q | V]
         del xn3
         q, v = qv[:, :d], qv[:, d:]
         if FP32_ATTENTION == "x3" and ops.x3_attn_supported(k, d // h):
@@ -361,9 +361,9 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
         delta = F.linear(o, lo.weight, lo.bias)                                     # snuffy.py:205
         x_sel = xs + delta                                                          # snuffy.py:108
         yn3 = ops.layernorm_rows_split3(x2, n1.weight, n1.bias, n1.eps, slot=slot, patch_rows=x_sel)   # LN(y), y never built
-        hid3 = ops.gemm_bf16(yn3, fw["w1"], fw["b1"], ff.activation_name, split3=True)   # snuffy.py:224-225, [N, 3F] image
+        hid3 = ops.gemm_x3(yn3, fw["w1"], fw["b1"], ff.activation_name, split3=True)   # snuffy.py:224-225, [N, 3F] image
         del yn3
-        z = ops.gemm_bf16(hid3, fw["w2"], fw["b2"], out_dtype=torch.float32)
+        z = ops.gemm_x3(hid3, fw["w2"], fw["b2"], out_dtype=torch.float32)
         del hid3
         z.add_(x2)
         ops.scatter_add_rows_(z, sel, delta)                                        # rows S: x -> x_sel (snuffy.py:155)

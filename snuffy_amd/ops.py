@@ -731,6 +731,41 @@ def gemm_bf16(a, w, bias=None, act="none", out_dtype=torch.bfloat16, out=None, t
     return out
 
 
+GEMM_X3_FUSED = True        # one-pass fp32-class GEMM kernel (snf_gemm_x3_bf16) where the shape fills the chip with 256 x 256 tiles
+
+
+def gemm_x3(a_img, w_img, bias=None, act="none", out_dtype=torch.float32, out=None, split3=False):
+    """fp32-class act(A W^T + bias) from the split images: a_img [m, 3 k] = [hi | hi | lo] of A, w_img [n, 3 k] = [Wh | Wl | Wh] of
+    W (split3_rows / layernorm_rows_split3 / a previous call with split3=True; split3_weight).  Large shapes take the one-pass
+    kernel (every product hi hi + hi lo + lo hi out of ONE staging of the four half images); the rest the same contraction as a
+    bf16 GEMM over the 3 k concatenated columns (gemm_bf16).  Returns [m, n] (out_dtype) or the split image [m, 3 n]."""
+    m, k3 = a_img.shape
+    n = w_img.shape[0]
+    k = k3 // 3
+    cus = _ffi.load().snf_device_cu_count()
+    t256 = ((m + 255) // 256) * ((n + 255) // 256)
+    if not (GEMM_X3_FUSED and a_img.dtype == torch.bfloat16 and w_img.dtype == torch.bfloat16 and k3 == 3 * k and k % 32 == 0
+            and w_img.shape[1] == k3 and n % 8 == 0 and n >= 256 and t256 * 10 >= cus * 7):
+        return gemm_bf16(a_img, w_img, bias, act, out_dtype, out, split3=split3)
+    a_img = _rows16(a_img, "a_img")
+    w_img = _rows16(w_img, "w_img")
+    if bias is not None:
+        bias = _req(bias, torch.float32, "bias", 1)
+    if split3:
+        if out is None:
+            out = torch.empty(m, 3 * n, dtype=torch.bfloat16, device=a_img.device)
+        odt = DT_BF16_SPLIT3
+    else:
+        if out is None:
+            out = torch.empty(m, n, dtype=out_dtype, device=a_img.device)
+        odt = DT_F32 if out.dtype == torch.float32 else DT_BF16
+    if a_img.stride(0) * m >= 2 ** 31 or w_img.stride(0) * n >= 2 ** 31:
+        return gemm_bf16(a_img, w_img, bias, act, out_dtype, out, split3=split3)
+    check(_ffi.load().snf_gemm_x3_bf16(_p(a_img), a_img.stride(0), _p(w_img), w_img.stride(0), _p(bias), m, n, k, ACT_CODES[act],
+                                       _p(out), out.stride(0), odt, _stream()), "snf_gemm_x3_bf16")
+    return out
+
+
 def split3_weight(w):
     """W [n, k] f32 -> W3 [n, 3 k] bf16 = [Wh | Wl | Wh]: with an activation image [hi | hi | lo] (layernorm_rows_split3,
     gemm_bf16(split3=True)) one bf16 GEMM over the tripled K axis computes hi Wh^T + hi Wl^T + lo Wh^T, i.e. the fp32

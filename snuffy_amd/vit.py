@@ -57,8 +57,8 @@ def linear_f32(x, weight, bias, act="none", want_image=False):
         img = x if is_image else ops.split3_rows(x.float() if x.dtype != torch.float32 else x)
         b = None if bias is None else bias.detach().float().contiguous()
         if want_image:
-            return ops.gemm_bf16(img, _split3_of(weight), b, act, split3=True)
-        return ops.gemm_bf16(img, _split3_of(weight), b, act, out_dtype=torch.float32)
+            return ops.gemm_x3(img, _split3_of(weight), b, act, split3=True)
+        return ops.gemm_x3(img, _split3_of(weight), b, act, out_dtype=torch.float32)
     if is_image:                                   # hi + lo back to fp32 (only when a shape falls out of the kernel's domain)
         x = x[:, :k].float() + x[:, 2 * k:].float()
     h = torch.mm(x.float(), weight.reshape(n, -1).t())

@@ -149,6 +149,41 @@ def test_gemm_x3_is_fp32_class(m, n, k, act):
     assert torch.equal(img128[:, :n], hi) and (act == "gelu" or torch.equal(img128[:, 2 * n:], lo))
 
 
+@pytest.mark.parametrize("m,n,k,act", [(1000, 768, 384, "none"), (4096, 1536, 768, "none"), (777, 3072, 768, "relu"),
+                                       (900, 768, 3072, "none"), (300, 512, 96, "gelu"), (257, 264, 32, "selu"),
+                                       (32768, 1536, 768, "none"), (20000, 256, 64, "leakyrelu")])
+def test_gemm_x3_one_pass_kernel(m, n, k, act):
+    """snf_gemm_x3_bf16 (one staging of the four half images per K step, hi hi + hi lo + lo hi out of it) against fp64 and against
+    the concatenated form: fp32-class error, fp32 / bf16 / split-image outputs, ragged M, partial column tiles, 1 .. 96 K steps."""
+    from snuffy_amd import _ffi, ops
+    g = torch.Generator().manual_seed(m + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g)
+    ref = ref_act(a.double() @ w.double().t() + b.double(), act)
+    a3, w3, bd = ops.split3_rows(a.to(DEV)), ops.split3_weight(w.to(DEV)), b.to(DEV)
+    lib = _ffi.load()
+
+    def run(odt, cols, tdt):
+        out = torch.empty(m, cols, dtype=tdt, device=DEV)
+        _ffi.check(lib.snf_gemm_x3_bf16(ops._p(a3), a3.stride(0), ops._p(w3), w3.stride(0), ops._p(bd), m, n, k, ops.ACT_CODES[act],
+                                        ops._p(out), out.stride(0), odt, ops._stream()), "snf_gemm_x3_bf16")
+        return out
+    out = run(ops.DT_F32, n, torch.float32)
+    scale = max(1.0, ref.abs().max().item())
+    err = (out.cpu().double() - ref).abs().max().item() / scale
+    assert err <= 8e-6, (m, n, k, act, err)
+    cat = ops.gemm_bf16(a3, w3, bd, act, torch.float32)                    # same products, different summation order
+    assert (out - cat).abs().max().item() <= 4e-6 * scale
+    assert torch.equal(out, run(ops.DT_F32, n, torch.float32))             # deterministic
+    img = run(ops.DT_BF16_SPLIT3, 3 * n, torch.bfloat16)
+    hi, lo = _split_host(out)
+    assert torch.equal(img[:, :n], hi) and torch.equal(img[:, n:2 * n], hi)
+    assert ((img[:, :n].float() + img[:, 2 * n:].float()) - out).abs().max().item() <= 2.0 ** -15 * scale
+    ob = run(ops.DT_BF16, n, torch.bfloat16)
+    assert (ob.float() - out).abs().max().item() <= 2.0 ** -8 * scale
+
+
 def test_fp32_path_x3_projections_against_library_projections(monkeypatch):
     """One encoder layer of the fp32 path at config-A size: split-bf16 x3 projections vs the fp32 library GEMMs."""
     from snuffy_amd import functional as SF
