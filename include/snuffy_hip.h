@@ -42,6 +42,7 @@ typedef void* snf_stream_t; /* hipStream_t */
 #define SNF_DT_F32 0
 #define SNF_DT_BF16 1
 #define SNF_DT_BF16_SPLIT3 2 /* [hi | hi | lo] bf16 image of an fp32 value (snf_gemm_bf16 output, snf_layernorm_rows_split3_f32) */
+#define SNF_DT_BF16_HL 3     /* interleaved bf16 image: every 32 columns as [hi(32) | lo(32)], 2 n columns (snf_gemm_hl_bf16) */
 
 const char* snf_version(void);
 const char* snf_last_error(void);
@@ -298,14 +299,20 @@ int snf_sparse_attn_dkp_f32(const float* ds, const float* q, int64_t n, int k, i
  * --------------------------------------------------------------------------------------------------------- */
 int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t m, int n, int k,
                   int act, void* c, int64_t ldc, int out_dtype, int tile_n, snf_stream_t stream);
-/* The same product in fp32-class arithmetic, ONE pass over the operands: a_img = [hi | hi | lo] image of A (m rows of 3 k bf16
- * columns, as snf_split3_f32 / snf_layernorm_rows_split3_f32 / snf_gemm_bf16(out_dtype = SNF_DT_BF16_SPLIT3) write it), w_img =
- * [Wh | Wl | Wh] of W [n, k]; C = act(A W^T + bias) with every product taken as hi hi + hi lo + lo hi (fp32 accumulate).
- * Equivalent to snf_gemm_bf16 over the 3 k concatenated columns up to summation order; a K step stages the four half images
- * once (2/3 of the L2 -> LDS bytes and fragment reads per MFMA, 96 MFMAs per wave between barriers).  256 x 256 tiles;
- * k % 32 == 0.  nn.Linear of snuffy.py:187-190,224-225 and of the ViT blocks in the reference's fp32 arithmetic. */
-int snf_gemm_x3_bf16(const void* a_img, int64_t lda, const void* w_img, int64_t ldw, const float* bias, int64_t m, int n, int k,
+/* The same product in fp32-class arithmetic, ONE pass over the operands.  Both operands are INTERLEAVED split images ("hl"): a
+ * row of 2 k bf16 in which every 32 true columns are stored as [hi(32) | lo(32)] (hi = bf16(v), lo = bf16(v - hi)) -- one
+ * 128-byte line per K step and the same 4 bytes per element as the fp32 tensor.  C = act(A W^T + bias) with every product taken
+ * as hi hi + hi lo + lo hi, fp32 accumulate (~1e-5 per product).  A K step stages ONE line per operand row by full-line LDS-DMA
+ * and issues 96 MFMAs per wave out of 24 fragment reads.  256 x 256 tiles; k % 32 == 0; out_dtype SNF_DT_F32 / SNF_DT_BF16 /
+ * SNF_DT_BF16_HL (the hl image of the result, [m, 2 n], n % 32 == 0: the A operand of the next such GEMM).
+ *   snf_split_hl_f32            x [m, k] f32 (row pitch ldx) -> its hl image [m, 2 k]
+ *   snf_layernorm_rows_hl_f32   snf_layernorm_rows_f32 whose output is written as the hl image (d % 32 == 0)
+ * nn.Linear of snuffy.py:187-190,224-225 and of the ViT blocks in the reference's fp32 arithmetic. */
+int snf_gemm_hl_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ldw, const float* bias, int64_t m, int n, int k,
                      int act, void* c, int64_t ldc, int out_dtype, snf_stream_t stream);
+int snf_split_hl_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16, snf_stream_t stream);
+int snf_layernorm_rows_hl_f32(const float* x, int64_t n, int d, const int32_t* slot_map, const float* patch_rows,
+                              const float* gamma, const float* beta, float eps, void* out_bf16, snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K12-K14  ViT patch-embedding extractor (compute_feats.py:239-247 -> IClassifier -> VisionTransformer.forward)

@@ -21,6 +21,7 @@ ACT_CODES = {"relu": 0, "gelu": 1, "leakyrelu": 2, "selu": 3, "none": 4}
 DT_F32 = 0
 DT_BF16 = 1
 DT_BF16_SPLIT3 = 2
+DT_BF16_HL = 3
 TOPK_MAX_K = 2048
 
 # name -> (restype, argtypes); mirrors include/snuffy_hip.h one to one
@@ -95,7 +96,10 @@ SIGNATURES = {
                                        c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "snf_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
                               c_int, c_int, c_void_p]),
-    "snf_gemm_x3_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
+    "snf_split_hl_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "snf_layernorm_rows_hl_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                          c_void_p, c_void_p]),
+    "snf_gemm_hl_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
                                  c_int, c_void_p]),
     "snf_vit_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "snf_vit_assemble_tokens": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

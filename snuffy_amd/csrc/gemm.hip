@@ -348,23 +348,26 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// fp32-class GEMM in ONE pass over the operands: C = act(A W^T + bias) with A given as its split image [hi | hi | lo] (row
-// pitch lda, true width k) and W as [Wh | Wl | Wh].  The concatenated form (gemm_bf16_kernel over 3 k) streams the hi halves
-// twice and pays three K steps of barriers, LDS-DMA issue and fragment reads per 32 true columns; here a step stages the four
-// images (A hi, A lo, W hi, W lo: 64 KiB) once and issues the three products hi hi + hi lo + lo hi out of them: 96 MFMAs per
-// wave and step behind 20 fragment reads -- 2/3 of the L2 -> LDS bytes and of the LDS reads per MFMA, a matrix burst three
-// times as long per barrier.  256 x 256 tiles, two step buffers (128 KiB), all 8 waves in lockstep: the DMA of step s + 1 flies
-// under the MFMA burst of step s.  Register budget: the A-lo fragments are read into the A-hi registers while the second
-// product (hi lo) is still issuing, row block by row block.
+// fp32-class GEMM in ONE pass over the operands: C = act(A W^T + bias) with both operands given as INTERLEAVED split images
+// ("hl" format): a row of 2 k bf16 in which every 32 true columns c .. c + 31 are stored as [hi(32) | lo(32)], hi = bf16(v),
+// lo = bf16(v - hi) -- 128 contiguous bytes, exactly one L2 line, and the same 4 bytes per element as the fp32 tensor.
+// The concatenated form (gemm_bf16_kernel over [hi | hi | lo] x [Wh | Wl | Wh]) streams the hi halves twice, in 64-byte DMA
+// segments, and pays three K steps of barriers / DMA issue / fragment reads per 32 true columns.  Here a step of 32 true columns
+// stages ONE line per operand row (A 256 x 128 B + W 256 x 128 B = 64 KiB, full-line LDS-DMA) and issues the three products
+// hi hi + hi lo + lo hi out of it: 96 MFMAs per wave and step behind 24 fragment reads.  256 x 256 tiles, two step buffers
+// (128 KiB), all 8 waves in lockstep: the DMA of step s + 1 flies under the MFMA burst of step s.  LDS rows are 128 bytes, so
+// the bank swizzle is the 8-chunk one (chunk ^ f(row) on the DMA source address; f = (row >> 1) & 7 for A, ((row >> 1) & 1) |
+// ((row >> 3) & 3) << 1 for W: every ds_read_b128 lane group of 16 covers the 16 slots of a 256-byte bank row once).
+// Register budget: the A-lo fragments are read into the A-hi registers while the second product (hi lo) is still issuing.
+// OUT: 0 bf16, 1 fp32, 3 the hl image of the fp32 result (operand of the next one-pass GEMM).
 template <int ACT, int OUT>
-__global__ __launch_bounds__(512, 2) void gemm_x3_kernel(GemmParams P) {
+__global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
     constexpr int NI = 4, BN = 256;
-    constexpr int IMG = BM * ROWB;               // one 256 x 32 image: 16 KiB
-    constexpr int STEP_BYTES = 4 * IMG;          // A hi | A lo | W hi | W lo
+    constexpr int ROWL = 128;                    // LDS row: hi(32) | lo(32) bf16
+    constexpr int IMG = BM * ROWL;               // one operand's step image: 32 KiB
+    constexpr int STEP_BYTES = 2 * IMG;          // A | W
     constexpr int NC = 4 * NI;
-    constexpr bool OUT_F32 = OUT == 1;
-    constexpr int NST = OUT == 1 ? NC / 4 : OUT == 2 ? 3 * NC / 8 : NC / 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][A hi | A lo | W hi | W lo]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][A | W]
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -382,53 +385,48 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(GemmParams P) {
     int tile = t_lo + wg_in_xcd;
     if (tile >= t_hi) return;
 
+    // LDS-DMA sources: an image is 32 pieces of 8 rows x 128 B; wave wid stages pieces 4 wid .. 4 wid + 3 of A and of W; lane l
+    // lands at row 8 p + (l >> 3), chunk l & 7 and fetches chunk (l & 7) ^ f(row) of its row's line
     struct Src {
-        int a[2], w[2];
+        int a[4], w[4];
     };
     auto tile_src = [&](int tl) __attribute__((always_inline)) -> Src {
         Src s;
         const int tm = tl / P.tiles_n, tn = tl - tm * P.tiles_n;
-        const int slot = lane & 3;
+        const int c = lane & 7;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = (2 * wid + j) * 16 + (lane >> 2);
+        for (int j = 0; j < 4; ++j) {
+            const int row = (4 * wid + j) * 8 + (lane >> 3);
             int grow = tm * BM + row;
             if (grow > P.m - 1) grow = P.m - 1;
-            s.a[j] = grow * (int)P.lda + ((slot ^ ((-(row >> 2)) & 3)) << 3);
+            s.a[j] = grow * (int)P.lda + ((c ^ ((row >> 1) & 7)) << 3);
             int wrow = tn * BN + row;
             if (wrow > P.n - 1) wrow = P.n - 1;
-            s.w[j] = wrow * (int)P.ldw + ((slot ^ ((-(row >> 3)) & 3)) << 3);
+            s.w[j] = wrow * (int)P.ldw + ((c ^ (((row >> 1) & 1) | (((row >> 3) & 3) << 1))) << 3);
         }
         return s;
     };
-    // images: A hi at column 0, A lo at column 2 k of [hi | hi | lo]; W hi at column 0, W lo at column k of [Wh | Wl | Wh]
     auto stage = [&](const Src& s, int kstep, int buf) __attribute__((always_inline)) {
-#ifdef X3_NOSTAGE   // timing ablations (dev builds, tools/gemm_x3_ablate.sh): pieces of the step compiled out, results wrong
+#ifdef X3_NOSTAGE   // timing ablations (dev builds, tools/gemm_x3_ablate.py): pieces of the step compiled out, results wrong
         return;
 #endif
         unsigned char* base = smem + buf * STEP_BYTES;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            __builtin_amdgcn_global_load_lds((glb_void*)(P.a + s.a[j] + kstep * BKS), (lds_void*)(base + (2 * wid + j) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)(P.a + s.a[j] + 2 * P.k + kstep * BKS),
-                                             (lds_void*)(base + IMG + (2 * wid + j) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)(P.w + s.w[j] + kstep * BKS),
-                                             (lds_void*)(base + 2 * IMG + (2 * wid + j) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)(P.w + s.w[j] + P.k + kstep * BKS),
-                                             (lds_void*)(base + 3 * IMG + (2 * wid + j) * 1024), 16, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((glb_void*)(P.a + s.a[j] + kstep * 64), (lds_void*)(base + (4 * wid + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(P.w + s.w[j] + kstep * 64), (lds_void*)(base + IMG + (4 * wid + j) * 1024), 16, 0, 0);
         }
     };
 
     const int fi = lane & 15, fg = lane >> 4;
-    const int fsw = (fg ^ ((-(fi >> 2)) & 3)) << 4;
-    const int xoff = (128 * wr + fi) * ROWB + fsw;                                      // + mi * 1024 (+ IMG for lo)
-    const int woff = 2 * IMG + (64 * wc + 8 * (fi >> 2) + (fi & 3)) * ROWB + fsw;       // + (4 (ni & 1) + 32 (ni >> 1)) * 64 (+ IMG for lo)
+    const int fa = (fi >> 1) & 7, fw = ((fi >> 1) & 1) | ((fi >> 2) << 1);
+    const int xoff_h = (128 * wr + fi) * ROWL + ((fg ^ fa) << 4), xoff_l = (128 * wr + fi) * ROWL + (((4 + fg) ^ fa) << 4);   // + mi * 2048
+    const int wrow0 = IMG + (64 * wc + 8 * (fi >> 2) + (fi & 3)) * ROWL;
+    const int woff_h = wrow0 + ((fg ^ fw) << 4), woff_l = wrow0 + (((4 + fg) ^ fw) << 4);   // + (4 (ni & 1) + 32 (ni >> 1)) * 128
 
     f32x4 acc[8][NI];
     bf16x8 xf[8], wh[NI], wl[NI];
     f32x4 bv4[NC / 4];
-#pragma unroll
-    for (int c4 = 0; c4 < NC / 4; ++c4) bv4[c4] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto frag = [&](const unsigned char* p) __attribute__((always_inline)) -> bf16x8 {
 #ifdef X3_NOREAD
@@ -444,6 +442,8 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(GemmParams P) {
 #define X3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #endif
     auto load_bias = [&](int tl) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c4 = 0; c4 < NC / 4; ++c4) bv4[c4] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (P.bias) {
             const int tn = tl % P.tiles_n;
             const int n0 = tn * BN + 64 * wc + 8 * fg;
@@ -478,25 +478,27 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(GemmParams P) {
 #else
                 const bool ok = FULL || (row < P.m && col + 8 <= P.n);
 #endif
-                if constexpr (OUT_F32) {
+                if constexpr (OUT == 1) {
                     float* dst = reinterpret_cast<float*>(P.c) + (int64_t)row * P.ldc + col;
                     if (ok) {
                         *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
                     }
                 } else {
-                    unsigned short* dst = reinterpret_cast<unsigned short*>(P.c) + (int64_t)row * P.ldc + col;
                     const u32x4 pk = {cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
-                    if (ok) *reinterpret_cast<u32x4*>(dst) = pk;
-                    if constexpr (OUT == 2) {
+                    if constexpr (OUT == 0) {
+                        unsigned short* dst = reinterpret_cast<unsigned short*>(P.c) + (int64_t)row * P.ldc + col;
+                        if (ok) *reinterpret_cast<u32x4*>(dst) = pk;
+                    } else {   // hl image: the 8 columns sit inside one 32-column chunk: hi at 64 (col / 32) + col % 32, lo 32 further
                         float lo[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
                             lo[e] = v[e] - __uint_as_float((e & 1) ? (pk[e >> 1] & 0xffff0000u) : (pk[e >> 1] << 16));
                         const u32x4 pl = {cvt_pk_bf16(lo[0], lo[1]), cvt_pk_bf16(lo[2], lo[3]), cvt_pk_bf16(lo[4], lo[5]), cvt_pk_bf16(lo[6], lo[7])};
+                        unsigned short* dst = reinterpret_cast<unsigned short*>(P.c) + (int64_t)row * P.ldc + 64 * (col >> 5) + (col & 31);
                         if (ok) {
-                            *reinterpret_cast<u32x4*>(dst + P.n) = pk;
-                            *reinterpret_cast<u32x4*>(dst + 2 * (int64_t)P.n) = pl;
+                            *reinterpret_cast<u32x4*>(dst) = pk;
+                            *reinterpret_cast<u32x4*>(dst + 32) = pl;
                         }
                     }
                 }
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(GemmParams P) {
         const bool has_next = next < t_hi;
         const bool full = (tile / P.tiles_n + 1) * BM <= P.m && (tile % P.tiles_n + 1) * BN <= P.n;
         for (int s = 0; s < ns; ++s) {
-            // this step's four images have landed (every wave waits for its own pieces, then all meet); the other buffer is free:
+            // this step's two images have landed (every wave waits for its own pieces, then all meet); the other buffer is free:
             // its last fragment reads belong to the previous step's MFMAs, which every wave has issued before this barrier
             wait_vmcnt<0>();
             __builtin_amdgcn_sched_barrier(0);
@@ -520,11 +522,11 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(GemmParams P) {
             __builtin_amdgcn_sched_barrier(0);
             const unsigned char* base = smem + buf * STEP_BYTES;
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) wh[ni] = frag(base + woff + (4 * (ni & 1) + 32 * (ni >> 1)) * ROWB);
+            for (int ni = 0; ni < NI; ++ni) wh[ni] = frag(base + woff_h + (4 * (ni & 1) + 32 * (ni >> 1)) * ROWL);
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) xf[mi] = frag(base + xoff + mi * 1024);
+            for (int mi = 0; mi < 8; ++mi) xf[mi] = frag(base + xoff_h + mi * 16 * ROWL);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) wl[ni] = frag(base + IMG + woff + (4 * (ni & 1) + 32 * (ni >> 1)) * ROWB);
+            for (int ni = 0; ni < NI; ++ni) wl[ni] = frag(base + woff_l + (4 * (ni & 1) + 32 * (ni >> 1)) * ROWL);
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < ns) {
                 stage(cur, s + 1, buf ^ 1);
@@ -539,8 +541,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(GemmParams P) {
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = X3_MFMA(wh[ni], xf[mi], (f32x4{0.f, 0.f, 0.f, 0.f}));
+                    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = X3_MFMA(wh[ni], xf[mi], (f32x4{0.f, 0.f, 0.f, 0.f}));
             } else {
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi)
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(GemmParams P) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = X3_MFMA(wl[ni], xf[mi], acc[mi][ni]);
                 __builtin_amdgcn_sched_barrier(0);
-                xf[mi] = frag(base + IMG + xoff + mi * 1024);
+                xf[mi] = frag(base + xoff_l + mi * 16 * ROWL);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // ---- lo hi
@@ -578,13 +579,13 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(GemmParams P) {
 }
 
 template <int ACT, int OUT>
-int launch_x3(const GemmParams& P, hipStream_t s) {
-    constexpr int lds = 2 * 4 * BM * ROWB;
+int launch_hl(const GemmParams& P, hipStream_t s) {
+    constexpr int lds = 2 * 2 * BM * 128;
     static thread_local bool attr_set = false;
-    auto kern = gemm_x3_kernel<ACT, OUT>;
+    auto kern = gemm_hl_kernel<ACT, OUT>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-            snf::set_error("gemm_x3: cannot reserve %d bytes of LDS", lds);
+            snf::set_error("gemm_hl: cannot reserve %d bytes of LDS", lds);
             (void)hipGetLastError();
             return SNF_ELAUNCH;
         }
@@ -596,17 +597,17 @@ int launch_x3(const GemmParams& P, hipStream_t s) {
     const int per_xcd = (ntiles + 7) / 8;
     if (per_xcd * 8 < grid) grid = per_xcd * 8;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, P);
-    return snf::check_launch("gemm_x3_kernel");
+    return snf::check_launch("gemm_hl_kernel");
 }
 
 template <int OUT>
-int launch_x3_act(const GemmParams& P, hipStream_t s) {
+int launch_hl_act(const GemmParams& P, hipStream_t s) {
     switch (P.act) {
-        case SNF_ACT_RELU: return launch_x3<SNF_ACT_RELU, OUT>(P, s);
-        case SNF_ACT_GELU: return launch_x3<SNF_ACT_GELU, OUT>(P, s);
-        case SNF_ACT_LEAKYRELU: return launch_x3<SNF_ACT_LEAKYRELU, OUT>(P, s);
-        case SNF_ACT_SELU: return launch_x3<SNF_ACT_SELU, OUT>(P, s);
-        default: return launch_x3<SNF_ACT_NONE, OUT>(P, s);
+        case SNF_ACT_RELU: return launch_hl<SNF_ACT_RELU, OUT>(P, s);
+        case SNF_ACT_GELU: return launch_hl<SNF_ACT_GELU, OUT>(P, s);
+        case SNF_ACT_LEAKYRELU: return launch_hl<SNF_ACT_LEAKYRELU, OUT>(P, s);
+        case SNF_ACT_SELU: return launch_hl<SNF_ACT_SELU, OUT>(P, s);
+        default: return launch_hl<SNF_ACT_NONE, OUT>(P, s);
     }
 }
 
@@ -688,25 +689,26 @@ extern "C" int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t 
     return out_dtype == SNF_DT_F32 ? launch_act<2, 1>(P, s) : launch_act<2, 0>(P, s);
 }
 
-extern "C" int snf_gemm_x3_bf16(const void* a_img, int64_t lda, const void* w_img, int64_t ldw, const float* bias, int64_t m, int n,
+extern "C" int snf_gemm_hl_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ldw, const float* bias, int64_t m, int n,
                                 int k, int act, void* c, int64_t ldc, int out_dtype, snf_stream_t stream) {
-    SNF_REQUIRE(a_img && w_img && c, "snf_gemm_x3_bf16: null pointer");
-    SNF_REQUIRE(m >= 1 && n >= 1 && k >= 1, "snf_gemm_x3_bf16: bad shape m=%lld n=%d k=%d", (long long)m, n, k);
-    SNF_REQUIRE(act >= SNF_ACT_RELU && act <= SNF_ACT_NONE, "snf_gemm_x3_bf16: bad activation code %d", act);
-    SNF_REQUIRE(out_dtype == SNF_DT_F32 || out_dtype == SNF_DT_BF16 || out_dtype == SNF_DT_BF16_SPLIT3,
-                "snf_gemm_x3_bf16: bad output dtype %d", out_dtype);
-    if (k % BKS || k < BKS || n % 8 || lda % 8 || ldw % 8 || ldc % (out_dtype == SNF_DT_F32 ? 4 : 8) || lda < 3 * (int64_t)k ||
-        ldw < 3 * (int64_t)k || ldc < (out_dtype == SNF_DT_BF16_SPLIT3 ? 3 * (int64_t)n : n) ||
-        (reinterpret_cast<uintptr_t>(a_img) | reinterpret_cast<uintptr_t>(w_img) | reinterpret_cast<uintptr_t>(c)) % 16 ||
+    SNF_REQUIRE(a_hl && w_hl && c, "snf_gemm_hl_bf16: null pointer");
+    SNF_REQUIRE(m >= 1 && n >= 1 && k >= 1, "snf_gemm_hl_bf16: bad shape m=%lld n=%d k=%d", (long long)m, n, k);
+    SNF_REQUIRE(act >= SNF_ACT_RELU && act <= SNF_ACT_NONE, "snf_gemm_hl_bf16: bad activation code %d", act);
+    SNF_REQUIRE(out_dtype == SNF_DT_F32 || out_dtype == SNF_DT_BF16 || out_dtype == SNF_DT_BF16_HL,
+                "snf_gemm_hl_bf16: bad output dtype %d", out_dtype);
+    const bool hl_out = out_dtype == SNF_DT_BF16_HL;
+    if (k % BKS || k < BKS || n % 8 || (hl_out && n % 32) || lda % 8 || ldw % 8 || ldc % (out_dtype == SNF_DT_F32 ? 4 : 8) ||
+        lda < 2 * (int64_t)k || ldw < 2 * (int64_t)k || ldc < (hl_out ? 2 * (int64_t)n : n) ||
+        (reinterpret_cast<uintptr_t>(a_hl) | reinterpret_cast<uintptr_t>(w_hl) | reinterpret_cast<uintptr_t>(c)) % 16 ||
         (bias && reinterpret_cast<uintptr_t>(bias) % 16) || m * lda >= 0x7fffffffll || (int64_t)n * ldw >= 0x7fffffffll) {
-        snf::set_error("snf_gemm_x3_bf16: shape m=%lld n=%d k=%d (lda %lld ldw %lld ldc %lld) outside the kernel's domain "
-                       "(k %% 32, n %% 8, images of 3 k columns, 16-byte aligned rows, 31-bit element offsets)",
+        snf::set_error("snf_gemm_hl_bf16: shape m=%lld n=%d k=%d (lda %lld ldw %lld ldc %lld) outside the kernel's domain "
+                       "(k %% 32, n %% 8 (%% 32 for an hl output), images of 2 k columns, 16-byte aligned rows, 31-bit element offsets)",
                        (long long)m, n, k, (long long)lda, (long long)ldw, (long long)ldc);
         return SNF_EUNSUPPORTED;
     }
     GemmParams P;
-    P.a = reinterpret_cast<const unsigned short*>(a_img);
-    P.w = reinterpret_cast<const unsigned short*>(w_img);
+    P.a = reinterpret_cast<const unsigned short*>(a_hl);
+    P.w = reinterpret_cast<const unsigned short*>(w_hl);
     P.bias = bias;
     P.c = c;
     P.lda = lda, P.ldw = ldw, P.ldc = ldc;
@@ -715,6 +717,6 @@ extern "C" int snf_gemm_x3_bf16(const void* a_img, int64_t lda, const void* w_im
     P.tiles_n = (n + 255) / 256;
     P.trace = nullptr;
     hipStream_t s = snf::as_stream(stream);
-    if (out_dtype == SNF_DT_BF16_SPLIT3) return launch_x3_act<2>(P, s);
-    return out_dtype == SNF_DT_F32 ? launch_x3_act<1>(P, s) : launch_x3_act<0>(P, s);
+    if (hl_out) return launch_hl_act<3>(P, s);
+    return out_dtype == SNF_DT_F32 ? launch_hl_act<1>(P, s) : launch_hl_act<0>(P, s);
 }

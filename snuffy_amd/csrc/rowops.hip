@@ -271,7 +271,7 @@ __global__ __launch_bounds__(WG) void layernorm_rows_kernel(const float* __restr
         const int64_t orow = out_row_idx ? out_row_idx[row] : row;
         if (out_f32) store_row_f32<VEC, NV>(out_f32 + orow * d, d, lane, r);
         if (out_bf16 && !split3) store_row_bf16<VEC, NV>(out_bf16 + orow * d, d, lane, r);
-        if (out_bf16 && split3) {
+        if (out_bf16 && split3 == 1) {
             // [hi | hi | lo] image of the row (3 d bf16): the A operand of a split-bf16 x3 GEMM (gemm.hip, header comment)
             float lo[NV * VEC];
 #pragma unroll
@@ -280,6 +280,27 @@ __global__ __launch_bounds__(WG) void layernorm_rows_kernel(const float* __restr
             store_row_bf16<VEC, NV>(o3, d, lane, r);
             store_row_bf16<VEC, NV>(o3 + d, d, lane, r);
             store_row_bf16<VEC, NV>(o3 + 2 * d, d, lane, lo);
+        }
+        if constexpr (VEC == 4) {
+            if (out_bf16 && split3 == 2) {
+                // interleaved ("hl") image of the row (2 d bf16): every 32 columns as [hi(32) | lo(32)] -- one 128-byte line per
+                // K step of the one-pass fp32-class GEMM (gemm.hip, gemm_hl_kernel).  A lane's 4 consecutive columns share a chunk.
+                unsigned short* o2 = out_bf16 + orow * 2 * d;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int e = (i * 64 + lane) * 4;
+                    if (e < d) {
+                        uint2 hi, lo;
+                        hi.x = pack_bf16x2(r[i * 4], r[i * 4 + 1]);
+                        hi.y = pack_bf16x2(r[i * 4 + 2], r[i * 4 + 3]);
+                        lo.x = pack_bf16x2(r[i * 4] - __uint_as_float(hi.x << 16), r[i * 4 + 1] - __uint_as_float(hi.x & 0xffff0000u));
+                        lo.y = pack_bf16x2(r[i * 4 + 2] - __uint_as_float(hi.y << 16), r[i * 4 + 3] - __uint_as_float(hi.y & 0xffff0000u));
+                        unsigned short* o = o2 + 64 * (e >> 5) + (e & 31);
+                        *reinterpret_cast<uint2*>(o) = hi;
+                        *reinterpret_cast<uint2*>(o + 32) = lo;
+                    }
+                }
+            }
         }
         if (lane == 0) {
             if (mean_out) mean_out[orow] = mean;
@@ -502,6 +523,29 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
         *reinterpret_cast<uint4*>(o) = h4;
         *reinterpret_cast<uint4*>(o + k) = h4;
         *reinterpret_cast<uint4*>(o + 2 * k) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+
+// x [m, k] f32 (row pitch ldx) -> out [m, 2 k] bf16, interleaved: columns 32 c .. 32 c + 31 as [hi(32) | lo(32)] (k % 32 == 0)
+__global__ __launch_bounds__(256) void split_hl_kernel(const float* __restrict__ x, int64_t ldx, int64_t m, int k,
+                                                       unsigned short* __restrict__ out) {
+    const int kq = k >> 3;
+    const int64_t total = m * kq;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / kq;
+        const int c = (int)(i - row * kq) * 8;
+        const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c);
+        const float4 b = *reinterpret_cast<const float4*>(x + row * ldx + c + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            lo[e] = pack_bf16x2(v[2 * e] - __uint_as_float(hi[e] << 16), v[2 * e + 1] - __uint_as_float(hi[e] & 0xffff0000u));
+        }
+        unsigned short* o = out + row * 2 * k + 64 * (c >> 5) + (c & 31);
+        *reinterpret_cast<uint4*>(o) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(o + 32) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
 }
 
@@ -1157,6 +1201,37 @@ int snf_colsum_fused(const void* src, int src_dtype, int64_t n, int d, const flo
     }
 #undef SNF_COLSUM
     return snf::check_launch("colsum_fused_kernel");
+}
+
+int snf_layernorm_rows_hl_f32(const float* x, int64_t n, int d, const int32_t* slot_map, const float* patch_rows,
+                              const float* gamma, const float* beta, float eps, void* out_bf16, snf_stream_t stream) {
+    SNF_REQUIRE(x && out_bf16, "snf_layernorm_rows_hl_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && d >= 32 && d % 32 == 0, "snf_layernorm_rows_hl_f32: d=%d must be a multiple of 32", d);
+    SNF_REQUIRE(!slot_map || patch_rows, "snf_layernorm_rows_hl_f32: slot_map without patch_rows");
+    SNF_REQUIRE(aligned16(x) && (!patch_rows || aligned16(patch_rows)) && (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)) &&
+                    aligned16(out_bf16), "snf_layernorm_rows_hl_f32: buffers must be 16-byte aligned");
+    RowCfg cfg;
+    SNF_REQUIRE(pick_row_cfg(d, true, &cfg) && cfg.vec == 4, "snf_layernorm_rows_hl_f32: d=%d too wide (max 2048)", d);
+    hipStream_t s = snf::as_stream(stream);
+    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((layernorm_rows_kernel<VEC, NV>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d,
+                                              slot_map, patch_rows, gamma, beta, eps, (float*)nullptr,
+                                              reinterpret_cast<unsigned short*>(out_bf16), (float*)nullptr, (float*)nullptr,
+                                              (const int64_t*)nullptr, 2));
+    return snf::check_launch("layernorm_rows_kernel<hl>");
+}
+
+int snf_split_hl_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16, snf_stream_t stream) {
+    SNF_REQUIRE(x && out_bf16, "snf_split_hl_f32: null pointer");
+    SNF_REQUIRE(m >= 1 && k >= 32 && k % 32 == 0 && ldx >= k && ldx % 4 == 0, "snf_split_hl_f32: bad shape m=%lld k=%d ldx=%lld",
+                (long long)m, k, (long long)ldx);
+    SNF_REQUIRE(aligned16(x) && aligned16(out_bf16), "snf_split_hl_f32: buffers must be 16-byte aligned");
+    const int64_t total = m * (k >> 3);
+    int64_t blocks = (total + 255) / 256;
+    const int64_t cap = (int64_t)snf::cu_count() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(split_hl_kernel, dim3((int)blocks), dim3(256), 0, snf::as_stream(stream), x, ldx, m, k,
+                       reinterpret_cast<unsigned short*>(out_bf16));
+    return snf::check_launch("split_hl_kernel");
 }
 
 int snf_split3_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16, snf_stream_t stream) {

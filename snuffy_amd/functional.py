@@ -303,8 +303,12 @@ def _split_weights(layer):
     if ent is not None and ent[0] == key:
         return ent[1]
     with torch.no_grad():
+        wqv = torch.cat([lq.weight, lv.weight])
         out = dict(
-            wqv=ops.split3_weight(torch.cat([lq.weight, lv.weight])),                  # [2D, 3D]: output [Q | V]
+            # interleaved images for the one-pass kernel (ops.gemm_hl), built lazily by the branch that uses them
+            hl=lambda: out.setdefault("_hl", dict(wqv=ops.split_hl_weight(wqv), w1=ops.split_hl_weight(ff.w_1.weight),
+                                                  w2=ops.split_hl_weight(ff.w_2.weight))),
+            wqv=ops.split3_weight(wqv),                                                # [2D, 3D]: output [Q | V]
             bqv=torch.cat([lq.bias, lv.bias]).float().contiguous(),
             w1=ops.split3_weight(ff.w_1.weight), b1=ff.w_1.bias.detach().float().contiguous(),
             w2=ops.split3_weight(ff.w_2.weight), b2=ff.w_2.bias.detach().float().contiguous(),
@@ -347,10 +351,19 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
         # (activations [hi | hi | lo], weights [Wh | Wl | Wh]; products to ~2^-17, fp32 accumulate) -- the fp32 library
         # GEMMs these replace were 85 % of a config-B bag (profiles/r02_bench_cfgB_fp32_kernel_stats.csv)
         fw = _split_weights(layer)
+        f = ff.w_1.weight.shape[0]
+        # large bags: the one-pass kernel on interleaved [hi(32) | lo(32)] images (one full-line DMA per operand row and K step,
+        # 96 MFMAs per 24 fragment reads); otherwise the concatenated form over [hi | hi | lo]
+        hl = d % 32 == 0 and f % 32 == 0 and ops.hl_eligible(n, 2 * d, d) and ops.hl_eligible(n, f, d) and ops.hl_eligible(n, d, f)
+        fh = fw["hl"]() if hl else None
         xs, slot = ops.gather_slot_map(x2, sel)                                     # snuffy.py:131,145-147 (+ row -> slot map)
         kp = F.linear(xs, lk.weight, lk.bias)                                       # keys = RAW selected rows (K rows: fp32)
-        xn3 = ops.layernorm_rows_split3(x2, n0.weight, n0.bias, n0.eps)             # snuffy.py:107
-        qv = ops.gemm_x3(xn3, fw["wqv"], fw["bqv"], out_dtype=torch.float32)      # [N, 2D] f32 = [Q | V]
+        if hl:
+            xn3 = ops.layernorm_rows_hl(x2, n0.weight, n0.bias, n0.eps)             # snuffy.py:107
+            qv = ops.gemm_hl(xn3, fh["wqv"], fw["bqv"])                             # [N, 2D] f32 = [Q | V]
+        else:
+            xn3 = ops.layernorm_rows_split3(x2, n0.weight, n0.bias, n0.eps)
+            qv = ops.gemm_x3(xn3, fw["wqv"], fw["bqv"], out_dtype=torch.float32)
         del xn3
         q, v = qv[:, :d], qv[:, d:]
         if FP32_ATTENTION == "x3" and ops.x3_attn_supported(k, d // h):
@@ -360,10 +373,16 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
         del q, v, qv
         delta = F.linear(o, lo.weight, lo.bias)                                     # snuffy.py:205
         x_sel = xs + delta                                                          # snuffy.py:108
-        yn3 = ops.layernorm_rows_split3(x2, n1.weight, n1.bias, n1.eps, slot=slot, patch_rows=x_sel)   # LN(y), y never built
-        hid3 = ops.gemm_x3(yn3, fw["w1"], fw["b1"], ff.activation_name, split3=True)   # snuffy.py:224-225, [N, 3F] image
-        del yn3
-        z = ops.gemm_x3(hid3, fw["w2"], fw["b2"], out_dtype=torch.float32)
+        if hl:
+            yn3 = ops.layernorm_rows_hl(x2, n1.weight, n1.bias, n1.eps, slot=slot, patch_rows=x_sel)   # LN(y), y never built
+            hid3 = ops.gemm_hl(yn3, fh["w1"], fw["b1"], ff.activation_name, hl_out=True)   # snuffy.py:224-225, [N, 2F] image
+            del yn3
+            z = ops.gemm_hl(hid3, fh["w2"], fw["b2"])
+        else:
+            yn3 = ops.layernorm_rows_split3(x2, n1.weight, n1.bias, n1.eps, slot=slot, patch_rows=x_sel)
+            hid3 = ops.gemm_x3(yn3, fw["w1"], fw["b1"], ff.activation_name, split3=True)   # [N, 3F] image
+            del yn3
+            z = ops.gemm_x3(hid3, fw["w2"], fw["b2"], out_dtype=torch.float32)
         del hid3
         z.add_(x2)
         ops.scatter_add_rows_(z, sel, delta)                                        # rows S: x -> x_sel (snuffy.py:155)

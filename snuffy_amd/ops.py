@@ -9,7 +9,7 @@ import math
 import torch
 
 from . import _ffi
-from ._ffi import ACT_CODES, DT_BF16, DT_BF16_SPLIT3, DT_F32, TOPK_MAX_K, check
+from ._ffi import ACT_CODES, DT_BF16, DT_BF16_HL, DT_BF16_SPLIT3, DT_F32, TOPK_MAX_K, check
 
 
 def _p(t):
@@ -731,38 +731,87 @@ def gemm_bf16(a, w, bias=None, act="none", out_dtype=torch.bfloat16, out=None, t
     return out
 
 
-GEMM_X3_FUSED = True        # one-pass fp32-class GEMM kernel (snf_gemm_x3_bf16) where the shape fills the chip with 256 x 256 tiles
+GEMM_HL = True        # one-pass fp32-class GEMM kernel (snf_gemm_hl_bf16) where the shape fills the chip with 256 x 256 tiles
 
 
 def gemm_x3(a_img, w_img, bias=None, act="none", out_dtype=torch.float32, out=None, split3=False):
-    """fp32-class act(A W^T + bias) from the split images: a_img [m, 3 k] = [hi | hi | lo] of A, w_img [n, 3 k] = [Wh | Wl | Wh] of
-    W (split3_rows / layernorm_rows_split3 / a previous call with split3=True; split3_weight).  Large shapes take the one-pass
-    kernel (every product hi hi + hi lo + lo hi out of ONE staging of the four half images); the rest the same contraction as a
-    bf16 GEMM over the 3 k concatenated columns (gemm_bf16).  Returns [m, n] (out_dtype) or the split image [m, 3 n]."""
-    m, k3 = a_img.shape
-    n = w_img.shape[0]
-    k = k3 // 3
+    """fp32-class act(A W^T + bias) from the [hi | hi | lo] / [Wh | Wl | Wh] images as ONE bf16 GEMM over the 3 k concatenated
+    columns (gemm_bf16): the form for shapes the one-pass kernel (gemm_hl) does not cover."""
+    return gemm_bf16(a_img, w_img, bias, act, out_dtype, out, split3=split3)
+
+
+def hl_eligible(m, n, k):
+    """Shapes the one-pass fp32-class GEMM takes: 256 x 256 tiles have to fill the chip (>= 0.7 tiles per CU), k % 32 == 0."""
+    if not GEMM_HL or k % 32 or n % 8 or n < 256 or k < 32 or m * 2 * k >= 2 ** 31 or n * 2 * k >= 2 ** 31:
+        return False
     cus = _ffi.load().snf_device_cu_count()
-    t256 = ((m + 255) // 256) * ((n + 255) // 256)
-    if not (GEMM_X3_FUSED and a_img.dtype == torch.bfloat16 and w_img.dtype == torch.bfloat16 and k3 == 3 * k and k % 32 == 0
-            and w_img.shape[1] == k3 and n % 8 == 0 and n >= 256 and t256 * 10 >= cus * 7):
-        return gemm_bf16(a_img, w_img, bias, act, out_dtype, out, split3=split3)
-    a_img = _rows16(a_img, "a_img")
-    w_img = _rows16(w_img, "w_img")
+    return ((m + 255) // 256) * ((n + 255) // 256) * 10 >= cus * 7
+
+
+def split_hl_rows(x):
+    """x [m, k] f32 (row-strided views allowed, k % 32 == 0) -> its interleaved split image [m, 2 k] bf16: every 32 columns as
+    [hi(32) | lo(32)] (snf_split_hl_f32) -- the A operand of gemm_hl."""
+    if x.dtype != torch.float32:
+        raise TypeError("split_hl_rows: x must be float32")
+    x = _rows16(x, "x")
+    m, k = x.shape
+    if k % 32:
+        raise ValueError("split_hl_rows: k = %d is not a multiple of 32" % k)
+    out = torch.empty(m, 2 * k, dtype=torch.bfloat16, device=x.device)
+    check(_ffi.load().snf_split_hl_f32(_p(x), x.stride(0), m, k, _p(out), _stream()), "snf_split_hl_f32")
+    return out
+
+
+def split_hl_weight(w):
+    """W [n, k] f32 -> its interleaved split image [n, 2 k] bf16 (the W operand of gemm_hl)."""
+    w = w.detach().float()
+    n, k = w.shape
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi.view(n, k // 32, 32), lo.view(n, k // 32, 32)], dim=2).reshape(n, 2 * k).contiguous()
+
+
+def layernorm_rows_hl(x, gamma, beta, eps=1e-5, slot=None, patch_rows=None):
+    """LayerNorm over rows (as layernorm_rows) written as the interleaved split image [n, 2 d] (d % 32 == 0)."""
+    x = _req(x, torch.float32, "x", 2)
+    n, d = x.shape
+    if gamma is not None:
+        gamma = _req(gamma, torch.float32, "gamma", 1)
+    if beta is not None:
+        beta = _req(beta, torch.float32, "beta", 1)
+    if slot is not None:
+        slot = _req(slot, torch.int32, "slot", 1)
+        patch_rows = _req(patch_rows, torch.float32, "patch_rows", 2)
+    out = torch.empty(n, 2 * d, dtype=torch.bfloat16, device=x.device)
+    check(_ffi.load().snf_layernorm_rows_hl_f32(_p(x), n, d, _p(slot), _p(patch_rows), _p(gamma), _p(beta), float(eps), _p(out),
+                                                _stream()), "snf_layernorm_rows_hl_f32")
+    return out
+
+
+def gemm_hl(a_hl, w_hl, bias=None, act="none", out_dtype=torch.float32, out=None, hl_out=False):
+    """fp32-class act(A W^T + bias) in ONE pass over the interleaved split images a_hl [m, 2 k], w_hl [n, 2 k] (split_hl_rows /
+    layernorm_rows_hl / a previous call with hl_out=True; split_hl_weight): every product hi hi + hi lo + lo hi, fp32 accumulate.
+    Returns [m, n] (out_dtype) or, with hl_out, the hl image [m, 2 n] of the result."""
+    if a_hl.dtype != torch.bfloat16 or w_hl.dtype != torch.bfloat16:
+        raise TypeError("gemm_hl: operands must be bfloat16 hl images")
+    a_hl = _rows16(a_hl, "a_hl")
+    w_hl = _rows16(w_hl, "w_hl")
+    m, k2 = a_hl.shape
+    n = w_hl.shape[0]
+    if w_hl.shape[1] != k2 or k2 % 64:
+        raise ValueError("gemm_hl: images are %s and %s" % (tuple(a_hl.shape), tuple(w_hl.shape)))
     if bias is not None:
         bias = _req(bias, torch.float32, "bias", 1)
-    if split3:
+    if hl_out:
         if out is None:
-            out = torch.empty(m, 3 * n, dtype=torch.bfloat16, device=a_img.device)
-        odt = DT_BF16_SPLIT3
+            out = torch.empty(m, 2 * n, dtype=torch.bfloat16, device=a_hl.device)
+        odt = DT_BF16_HL
     else:
         if out is None:
-            out = torch.empty(m, n, dtype=out_dtype, device=a_img.device)
+            out = torch.empty(m, n, dtype=out_dtype, device=a_hl.device)
         odt = DT_F32 if out.dtype == torch.float32 else DT_BF16
-    if a_img.stride(0) * m >= 2 ** 31 or w_img.stride(0) * n >= 2 ** 31:
-        return gemm_bf16(a_img, w_img, bias, act, out_dtype, out, split3=split3)
-    check(_ffi.load().snf_gemm_x3_bf16(_p(a_img), a_img.stride(0), _p(w_img), w_img.stride(0), _p(bias), m, n, k, ACT_CODES[act],
-                                       _p(out), out.stride(0), odt, _stream()), "snf_gemm_x3_bf16")
+    check(_ffi.load().snf_gemm_hl_bf16(_p(a_hl), a_hl.stride(0), _p(w_hl), w_hl.stride(0), _p(bias), m, n, k2 // 2, ACT_CODES[act],
+                                       _p(out), out.stride(0), odt, _stream()), "snf_gemm_hl_bf16")
     return out
 
 

@@ -152,36 +152,51 @@ def test_gemm_x3_is_fp32_class(m, n, k, act):
 @pytest.mark.parametrize("m,n,k,act", [(1000, 768, 384, "none"), (4096, 1536, 768, "none"), (777, 3072, 768, "relu"),
                                        (900, 768, 3072, "none"), (300, 512, 96, "gelu"), (257, 264, 32, "selu"),
                                        (32768, 1536, 768, "none"), (20000, 256, 64, "leakyrelu")])
-def test_gemm_x3_one_pass_kernel(m, n, k, act):
-    """snf_gemm_x3_bf16 (one staging of the four half images per K step, hi hi + hi lo + lo hi out of it) against fp64 and against
-    the concatenated form: fp32-class error, fp32 / bf16 / split-image outputs, ragged M, partial column tiles, 1 .. 96 K steps."""
-    from snuffy_amd import _ffi, ops
+def test_gemm_hl_one_pass_kernel(m, n, k, act):
+    """snf_gemm_hl_bf16 (interleaved [hi(32) | lo(32)] images, one full-line staging per K step, hi hi + hi lo + lo hi out of it)
+    against fp64 and against the concatenated form: fp32-class error, fp32 / bf16 / hl-image outputs, ragged M, partial column
+    tiles, 1 .. 96 K steps; the producers of the format (split kernel, LayerNorm, host weight split) against their definition."""
+    from snuffy_amd import ops
     g = torch.Generator().manual_seed(m + k)
     a = torch.randn(m, k, generator=g)
     w = torch.randn(n, k, generator=g) / k ** 0.5
     b = torch.randn(n, generator=g)
     ref = ref_act(a.double() @ w.double().t() + b.double(), act)
-    a3, w3, bd = ops.split3_rows(a.to(DEV)), ops.split3_weight(w.to(DEV)), b.to(DEV)
-    lib = _ffi.load()
-
-    def run(odt, cols, tdt):
-        out = torch.empty(m, cols, dtype=tdt, device=DEV)
-        _ffi.check(lib.snf_gemm_x3_bf16(ops._p(a3), a3.stride(0), ops._p(w3), w3.stride(0), ops._p(bd), m, n, k, ops.ACT_CODES[act],
-                                        ops._p(out), out.stride(0), odt, ops._stream()), "snf_gemm_x3_bf16")
-        return out
-    out = run(ops.DT_F32, n, torch.float32)
+    ad, wd, bd = a.to(DEV), w.to(DEV), b.to(DEV)
+    a_hl, w_hl = ops.split_hl_rows(ad), ops.split_hl_weight(wd)
+    hi, lo = _split_host(ad)
+    assert a_hl.shape == (m, 2 * k) and w_hl.shape == (n, 2 * k)
+    v = a_hl.view(m, k // 32, 2, 32)
+    assert torch.equal(v[:, :, 0].reshape(m, k), hi) and torch.equal(v[:, :, 1].reshape(m, k), lo)
+    out = ops.gemm_hl(a_hl, w_hl, bd, act)
     scale = max(1.0, ref.abs().max().item())
     err = (out.cpu().double() - ref).abs().max().item() / scale
     assert err <= 8e-6, (m, n, k, act, err)
-    cat = ops.gemm_bf16(a3, w3, bd, act, torch.float32)                    # same products, different summation order
+    cat = ops.gemm_x3(ops.split3_rows(ad), ops.split3_weight(wd), bd, act)   # same products, different summation order
     assert (out - cat).abs().max().item() <= 4e-6 * scale
-    assert torch.equal(out, run(ops.DT_F32, n, torch.float32))             # deterministic
-    img = run(ops.DT_BF16_SPLIT3, 3 * n, torch.bfloat16)
-    hi, lo = _split_host(out)
-    assert torch.equal(img[:, :n], hi) and torch.equal(img[:, n:2 * n], hi)
-    assert ((img[:, :n].float() + img[:, 2 * n:].float()) - out).abs().max().item() <= 2.0 ** -15 * scale
-    ob = run(ops.DT_BF16, n, torch.bfloat16)
+    assert torch.equal(out, ops.gemm_hl(a_hl, w_hl, bd, act))                # deterministic
+    ob = ops.gemm_hl(a_hl, w_hl, bd, act, out_dtype=torch.bfloat16)
     assert (ob.float() - out).abs().max().item() <= 2.0 ** -8 * scale
+    if n % 32 == 0:
+        img = ops.gemm_hl(a_hl, w_hl, bd, act, hl_out=True).view(m, n // 32, 2, 32)
+        hi, lo = _split_host(out)
+        assert torch.equal(img[:, :, 0].reshape(m, n), hi)
+        assert ((img[:, :, 0].reshape(m, n).float() + img[:, :, 1].reshape(m, n).float()) - out).abs().max().item() <= 2.0 ** -15 * scale
+
+
+@pytest.mark.parametrize("n,d", [(700, 384), (513, 768), (64, 96), (1000, 2048)])
+def test_layernorm_rows_hl_is_the_interleaved_split_of_the_fp32_rows(n, d):
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(n + d)
+    x = (torch.randn(n, d, generator=g) * 3 + 1).to(DEV)
+    gam, bet = torch.randn(d, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
+    slot = torch.full((n,), -1, dtype=torch.int32)
+    slot[[3, n // 2, n - 1]] = torch.tensor([0, 1, 2], dtype=torch.int32)
+    patch = torch.randn(3, d, generator=g).to(DEV)
+    for kw in ({}, {"slot": slot.to(DEV), "patch_rows": patch}):
+        hi, lo = _split_host(ops.layernorm_rows(x, gam, bet, 1e-5, **kw))
+        got = ops.layernorm_rows_hl(x, gam, bet, 1e-5, **kw).view(n, d // 32, 2, 32)
+        assert torch.equal(got[:, :, 0].reshape(n, d), hi) and torch.equal(got[:, :, 1].reshape(n, d), lo)
 
 
 def test_fp32_path_x3_projections_against_library_projections(monkeypatch):
