@@ -34,40 +34,96 @@ from ._ffi import SnuffyHipError
 FP32_GEMM = "x3"
 
 
-def _split3_of(weight):
-    """[Wh | Wl | Wh] image of a parameter (ops.split3_weight), cached on the parameter until it is written again."""
+def _image_of(weight, fmt):
+    """Split image of a parameter ("hl": interleaved [hi(32) | lo(32)], ops.split_hl_weight; "cat": [Wh | Wl | Wh],
+    ops.split3_weight), cached on the parameter until it is written again."""
     key = (weight.data_ptr(), weight._version)
-    hit = getattr(weight, "_snf_x3", None)
+    name = "_snf_img_" + fmt
+    hit = getattr(weight, name, None)
     if hit is None or hit[0] != key:
-        hit = (key, ops.split3_weight(weight.detach().reshape(weight.shape[0], -1)))
-        weight._snf_x3 = hit
+        w2 = weight.detach().reshape(weight.shape[0], -1)
+        hit = (key, ops.split_hl_weight(w2) if fmt == "hl" else ops.split3_weight(w2))
+        setattr(weight, name, hit)
     return hit[1]
 
 
-def linear_f32(x, weight, bias, act="none", want_image=False):
-    """act(x W^T + b) of the fp32 path.  x: [m, k] f32, or the bf16 split image [m, 3 k] = [hi | hi | lo] a previous call /
-    ops.layernorm_rows_split3 left.  FP32_GEMM == "x3" (and the shape in the kernel's domain): one bf16 MFMA GEMM over the tripled
-    K axis against [Wh | Wl | Wh]; want_image returns the result as the split image for the next projection (it never exists in
-    fp32).  Otherwise the fp32 library GEMM + the activation kernel."""
-    is_image = x.dtype == torch.bfloat16
-    k = weight[0].numel()
-    m = x.shape[0]
+class SplitImage:
+    """An fp32 activation held as its bf16 split image: fmt "hl" ([m, 2 k], interleaved) or "cat" ([m, 3 k] = [hi | hi | lo])."""
+
+    def __init__(self, data, fmt, k):
+        self.data, self.fmt, self.k = data, fmt, k
+
+    def to_f32(self):
+        m = self.data.shape[0]
+        if self.fmt == "hl":
+            v = self.data.view(m, self.k // 32, 2, 32).float()
+            return (v[:, :, 0] + v[:, :, 1]).reshape(m, self.k)
+        return self.data[:, :self.k].float() + self.data[:, 2 * self.k:].float()
+
+
+def image_format(m, weight):
+    """Format of the split image a projection with `weight` wants for m rows: "hl" (one-pass kernel) where 256 x 256 tiles fill the
+    chip, "cat" (concatenated K) where only the 32-deep-step kernel applies, None = plain fp32 (library GEMM)."""
+    n, k = weight.shape[0], weight[0].numel()
+    if FP32_GEMM != "x3":
+        return None
+    if ops.hl_eligible(m, n, k):
+        return "hl"
+    return "cat" if (k % 8 == 0 and ops.gemm_x3_supported(m, n, k)) else None
+
+
+def split_image(x, fmt):
+    x = x.float() if x.dtype != torch.float32 else x
+    return SplitImage(ops.split_hl_rows(x) if fmt == "hl" else ops.split3_rows(x), fmt, x.shape[1])
+
+
+def layernorm_image(x2, norm, fmt):
+    """LayerNorm(x2) as the image a following projection wants (written by the LayerNorm kernel itself), or plain fp32."""
+    if fmt == "hl" and x2.shape[1] % 32 == 0:
+        return SplitImage(ops.layernorm_rows_hl(x2, norm.weight, norm.bias, norm.eps), "hl", x2.shape[1])
+    if fmt == "cat":
+        return SplitImage(ops.layernorm_rows_split3(x2, norm.weight, norm.bias, norm.eps), "cat", x2.shape[1])
+    y = ops.layernorm_rows(x2, norm.weight, norm.bias, norm.eps)
+    return split_image(y, fmt) if fmt else y
+
+
+def linear_f32(x, weight, bias, act="none", image_for=None):
+    """act(x W^T + b) of the fp32 path.  x: [m, k] f32 or a SplitImage.  FP32_GEMM == "x3": split-bf16 x3 products on the hand-written
+    MFMA GEMMs -- the one-pass kernel on interleaved images where the shape fills the chip, the concatenated form otherwise -- else
+    (or for shapes outside both kernels' domains) the fp32 library GEMM + the activation kernel.  image_for = the weight of the
+    NEXT projection: the result is returned as the split image that projection wants, straight from this GEMM's epilogue (it never
+    exists in fp32)."""
+    m = x.data.shape[0] if isinstance(x, SplitImage) else x.shape[0]
     n = weight.shape[0]
-    if FP32_GEMM == "x3" and ops.gemm_x3_supported(m, n, k):
-        img = x if is_image else ops.split3_rows(x.float() if x.dtype != torch.float32 else x)
-        b = None if bias is None else bias.detach().float().contiguous()
-        if want_image:
-            return ops.gemm_x3(img, _split3_of(weight), b, act, split3=True)
-        return ops.gemm_x3(img, _split3_of(weight), b, act, out_dtype=torch.float32)
-    if is_image:                                   # hi + lo back to fp32 (only when a shape falls out of the kernel's domain)
-        x = x[:, :k].float() + x[:, 2 * k:].float()
+    fmt = image_format(m, weight)
+    out_fmt = image_format(m, image_for) if image_for is not None else None
+    if out_fmt == "hl" and n % 32:
+        out_fmt = "cat"
+    b = None if bias is None else bias.detach().float().contiguous()
+    if fmt is not None:
+        if not isinstance(x, SplitImage):
+            x = split_image(x, fmt)
+        elif x.fmt != fmt:
+            x = split_image(x.to_f32(), fmt)
+        w_img = _image_of(weight, fmt)
+        if fmt == "hl":
+            if out_fmt == "hl":
+                return SplitImage(ops.gemm_hl(x.data, w_img, b, act, hl_out=True), "hl", n)
+            y = ops.gemm_hl(x.data, w_img, b, act)
+        else:
+            if out_fmt == "cat":
+                return SplitImage(ops.gemm_x3(x.data, w_img, b, act, split3=True), "cat", n)
+            y = ops.gemm_x3(x.data, w_img, b, act, out_dtype=torch.float32)
+        return split_image(y, out_fmt) if out_fmt else y
+    if isinstance(x, SplitImage):
+        x = x.to_f32()
     h = torch.mm(x.float(), weight.reshape(n, -1).t())
     if act != "none" or bias is not None:
         if act == "none":
             h += bias
         else:
             ops.bias_act_(h, bias, act)
-    return h                                       # plain fp32 also when an image was asked for: the next call takes either
+    return split_image(h, out_fmt) if out_fmt else h
 
 
 class Adapter(nn.Module):
@@ -109,7 +165,7 @@ class Adapter(nn.Module):
         shp = x.shape
         if x.is_cuda and not torch.is_grad_enabled():
             a = linear_f32(x.reshape(-1, shp[-1]).float().contiguous(), self.down_proj.weight, self.down_proj.bias, "relu",
-                           want_image=True)
+                           image_for=self.up_proj.weight)
             up = linear_f32(a, self.up_proj.weight, self.up_proj.bias).view(shp) * self.scale
         else:
             up = self.up_proj(F.relu(self.down_proj(x))) * self.scale   # eval: the reference's dropout is inactive
@@ -129,13 +185,12 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
-        """x: [..., D] f32, or the split image [m, 3 D] of the normalised tokens (Block.forward)."""
-        image_in = x.dtype == torch.bfloat16
-        shp = x.shape
-        x2 = x if image_in else x.reshape(-1, shp[-1]).float().contiguous()
-        h = linear_f32(x2, self.fc1.weight, self.fc1.bias, "gelu", want_image=True)
+        """x: [..., D] f32, or the SplitImage of the normalised tokens (Block.forward)."""
+        image_in = isinstance(x, SplitImage)
+        x2 = x if image_in else x.reshape(-1, x.shape[-1]).float().contiguous()
+        h = linear_f32(x2, self.fc1.weight, self.fc1.bias, "gelu", image_for=self.fc2.weight)
         out = linear_f32(h, self.fc2.weight, self.fc2.bias)
-        return out if image_in else out.view(*shp[:-1], -1)
+        return out if image_in else out.view(*x.shape[:-1], -1)
 
 
 class Attention(nn.Module):
@@ -155,7 +210,7 @@ class Attention(nn.Module):
         return self._run(x.reshape(-1, x.shape[-1]).float().contiguous(), x.shape[0], x.shape[1])
 
     def _run(self, x2, B, N, need_attn=True):
-        """x2: [B * N, C] f32 or its split image [B * N, 3 C]."""
+        """x2: [B * N, C] f32 or its SplitImage."""
         C = self.proj.weight.shape[0]
         qkv = linear_f32(x2, self.qkv.weight, self.qkv.bias)
         o, attn = ops.vit_attention(qkv, B, N, self.num_heads, self.scale, need_attn=need_attn)
@@ -185,18 +240,15 @@ class Block(nn.Module):
     def forward(self, x, return_attention=False):
         B, N, C = x.shape
         x2 = x.reshape(B * N, C).float().contiguous()
-        x3 = FP32_GEMM == "x3" and C % 8 == 0 and ops.gemm_x3_supported(B * N, C, C)
-        # x3: the LayerNorm writes its output straight as the split image [hi | hi | lo] the projection GEMM reads
-        ln1 = ops.layernorm_rows_split3(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps) if x3 else \
-            ops.layernorm_rows(x2, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        # x3: the LayerNorm writes its output straight as the split image the projection GEMM reads
+        ln1 = layernorm_image(x2, self.norm1, image_format(B * N, self.attn.qkv.weight))
         y, attn = self.attn._run(ln1, B, N, need_attn=return_attention)
         if return_attention:
             return attn
         x = x + y
         ad = self.adaptmlp(x, add_residual=False) if hasattr(self, "adaptmlp") else 0.0
         xc = x.reshape(B * N, C).contiguous()
-        ln2 = ops.layernorm_rows_split3(xc, self.norm2.weight, self.norm2.bias, self.norm2.eps) if x3 else \
-            ops.layernorm_rows(xc, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        ln2 = layernorm_image(xc, self.norm2, image_format(B * N, self.mlp.fc1.weight))
         return x + self.mlp(ln2).view(B, N, C) + ad
 
 
