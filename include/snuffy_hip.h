@@ -310,6 +310,9 @@ int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const 
  * nn.Linear of snuffy.py:187-190,224-225 and of the ViT blocks in the reference's fp32 arithmetic. */
 int snf_gemm_hl_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ldw, const float* bias, int64_t m, int n, int k,
                      int act, void* c, int64_t ldc, int out_dtype, snf_stream_t stream);
+/* fp32 output with a residual: C = act(A W^T + bias) + resid [m, ldr] -- z = x + W2 act(W1 LN(y)) of snuffy.py:110 in one pass */
+int snf_gemm_hl_resid_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ldw, const float* bias, const float* resid,
+                           int64_t ldr, int64_t m, int n, int k, int act, void* c, int64_t ldc, int out_dtype, snf_stream_t stream);
 int snf_split_hl_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16, snf_stream_t stream);
 int snf_layernorm_rows_hl_f32(const float* x, int64_t n, int d, const int32_t* slot_map, const float* patch_rows,
                               const float* gamma, const float* beta, float eps, void* out_bf16, snf_stream_t stream);

@@ -51,6 +51,8 @@ struct GemmParams {
     int act;
     int tiles_m, tiles_n;
     unsigned long long* trace;   // dev builds only (SNF_GEMM_TRACE), else null
+    const float* resid = nullptr;   // gemm_hl_kernel, fp32 output: C += resid[m, ldr] (the residual stream of the FFN, snuffy.py:110)
+    int64_t ldr = 0;
 };
 
 constexpr int BM = 256, BKS = 32;
@@ -480,6 +482,15 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
 #endif
                 if constexpr (OUT == 1) {
                     float* dst = reinterpret_cast<float*>(P.c) + (int64_t)row * P.ldc + col;
+                    if (P.resid && ok) {   // residual added after the activation: z = x + W2 act(...) in one pass over z
+                        const float* rp = P.resid + (int64_t)row * P.ldr + col;
+                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] += r0[e];
+                            v[4 + e] += r1[e];
+                        }
+                    }
                     if (ok) {
                         *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -691,12 +702,20 @@ extern "C" int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t 
 
 extern "C" int snf_gemm_hl_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ldw, const float* bias, int64_t m, int n,
                                 int k, int act, void* c, int64_t ldc, int out_dtype, snf_stream_t stream) {
+    return snf_gemm_hl_resid_bf16(a_hl, lda, w_hl, ldw, bias, nullptr, 0, m, n, k, act, c, ldc, out_dtype, stream);
+}
+
+extern "C" int snf_gemm_hl_resid_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ldw, const float* bias,
+                                      const float* resid, int64_t ldr, int64_t m, int n, int k, int act, void* c, int64_t ldc,
+                                      int out_dtype, snf_stream_t stream) {
     SNF_REQUIRE(a_hl && w_hl && c, "snf_gemm_hl_bf16: null pointer");
     SNF_REQUIRE(m >= 1 && n >= 1 && k >= 1, "snf_gemm_hl_bf16: bad shape m=%lld n=%d k=%d", (long long)m, n, k);
     SNF_REQUIRE(act >= SNF_ACT_RELU && act <= SNF_ACT_NONE, "snf_gemm_hl_bf16: bad activation code %d", act);
     SNF_REQUIRE(out_dtype == SNF_DT_F32 || out_dtype == SNF_DT_BF16 || out_dtype == SNF_DT_BF16_HL,
                 "snf_gemm_hl_bf16: bad output dtype %d", out_dtype);
     const bool hl_out = out_dtype == SNF_DT_BF16_HL;
+    SNF_REQUIRE(!resid || (out_dtype == SNF_DT_F32 && ldr >= n && ldr % 4 == 0 && reinterpret_cast<uintptr_t>(resid) % 16 == 0),
+                "snf_gemm_hl_bf16: a residual needs an fp32 output and 16-byte aligned rows (ldr=%lld)", (long long)ldr);
     if (k % BKS || k < BKS || n % 8 || (hl_out && n % 32) || lda % 8 || ldw % 8 || ldc % (out_dtype == SNF_DT_F32 ? 4 : 8) ||
         lda < 2 * (int64_t)k || ldw < 2 * (int64_t)k || ldc < (hl_out ? 2 * (int64_t)n : n) ||
         (reinterpret_cast<uintptr_t>(a_hl) | reinterpret_cast<uintptr_t>(w_hl) | reinterpret_cast<uintptr_t>(c)) % 16 ||
@@ -716,6 +735,8 @@ extern "C" int snf_gemm_hl_bf16(const void* a_hl, int64_t lda, const void* w_hl,
     P.tiles_m = (int)((m + BM - 1) / BM);
     P.tiles_n = (n + 255) / 256;
     P.trace = nullptr;
+    P.resid = resid;
+    P.ldr = ldr;
     hipStream_t s = snf::as_stream(stream);
     if (hl_out) return launch_hl_act<3>(P, s);
     return out_dtype == SNF_DT_F32 ? launch_hl_act<1>(P, s) : launch_hl_act<0>(P, s);

@@ -305,14 +305,20 @@ def _split_weights(layer):
     with torch.no_grad():
         wqv = torch.cat([lq.weight, lv.weight])
         out = dict(
-            # interleaved images for the one-pass kernel (ops.gemm_hl), built lazily by the branch that uses them
-            hl=lambda: out.setdefault("_hl", dict(wqv=ops.split_hl_weight(wqv), w1=ops.split_hl_weight(ff.w_1.weight),
-                                                  w2=ops.split_hl_weight(ff.w_2.weight))),
             wqv=ops.split3_weight(wqv),                                                # [2D, 3D]: output [Q | V]
             bqv=torch.cat([lq.bias, lv.bias]).float().contiguous(),
             w1=ops.split3_weight(ff.w_1.weight), b1=ff.w_1.bias.detach().float().contiguous(),
             w2=ops.split3_weight(ff.w_2.weight), b2=ff.w_2.bias.detach().float().contiguous(),
         )
+    hl_cache = {}
+
+    def hl():
+        """interleaved images for the one-pass kernel (ops.gemm_hl): built once, by the first forward that takes that branch"""
+        if not hl_cache:
+            with torch.no_grad():
+                hl_cache.update(wqv=ops.split_hl_weight(wqv), w1=ops.split_hl_weight(ff.w_1.weight), w2=ops.split_hl_weight(ff.w_2.weight))
+        return hl_cache
+    out["hl"] = hl
     layer._fold3 = (key, out)
     return out
 
@@ -377,14 +383,14 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
             yn3 = ops.layernorm_rows_hl(x2, n1.weight, n1.bias, n1.eps, slot=slot, patch_rows=x_sel)   # LN(y), y never built
             hid3 = ops.gemm_hl(yn3, fh["w1"], fw["b1"], ff.activation_name, hl_out=True)   # snuffy.py:224-225, [N, 2F] image
             del yn3
-            z = ops.gemm_hl(hid3, fh["w2"], fw["b2"])
+            z = ops.gemm_hl(hid3, fh["w2"], fw["b2"], resid=x2)                    # x + W2 hid + b2: the residual rides in the epilogue
         else:
             yn3 = ops.layernorm_rows_split3(x2, n1.weight, n1.bias, n1.eps, slot=slot, patch_rows=x_sel)
             hid3 = ops.gemm_x3(yn3, fw["w1"], fw["b1"], ff.activation_name, split3=True)   # [N, 3F] image
             del yn3
             z = ops.gemm_x3(hid3, fw["w2"], fw["b2"], out_dtype=torch.float32)
+            z.add_(x2)
         del hid3
-        z.add_(x2)
         ops.scatter_add_rows_(z, sel, delta)                                        # rows S: x -> x_sel (snuffy.py:155)
         return Parts(z), (attn.unsqueeze(0) if attn is not None else None)
 

@@ -788,10 +788,11 @@ def layernorm_rows_hl(x, gamma, beta, eps=1e-5, slot=None, patch_rows=None):
     return out
 
 
-def gemm_hl(a_hl, w_hl, bias=None, act="none", out_dtype=torch.float32, out=None, hl_out=False):
+def gemm_hl(a_hl, w_hl, bias=None, act="none", out_dtype=torch.float32, out=None, hl_out=False, resid=None):
     """fp32-class act(A W^T + bias) in ONE pass over the interleaved split images a_hl [m, 2 k], w_hl [n, 2 k] (split_hl_rows /
     layernorm_rows_hl / a previous call with hl_out=True; split_hl_weight): every product hi hi + hi lo + lo hi, fp32 accumulate.
-    Returns [m, n] (out_dtype) or, with hl_out, the hl image [m, 2 n] of the result."""
+    Returns [m, n] (out_dtype) or, with hl_out, the hl image [m, 2 n] of the result.  resid [m, n] f32 (fp32 output only) is added
+    after the activation, in the epilogue."""
     if a_hl.dtype != torch.bfloat16 or w_hl.dtype != torch.bfloat16:
         raise TypeError("gemm_hl: operands must be bfloat16 hl images")
     a_hl = _rows16(a_hl, "a_hl")
@@ -810,8 +811,14 @@ def gemm_hl(a_hl, w_hl, bias=None, act="none", out_dtype=torch.float32, out=None
         if out is None:
             out = torch.empty(m, n, dtype=out_dtype, device=a_hl.device)
         odt = DT_F32 if out.dtype == torch.float32 else DT_BF16
-    check(_ffi.load().snf_gemm_hl_bf16(_p(a_hl), a_hl.stride(0), _p(w_hl), w_hl.stride(0), _p(bias), m, n, k2 // 2, ACT_CODES[act],
-                                       _p(out), out.stride(0), odt, _stream()), "snf_gemm_hl_bf16")
+    ldr = 0
+    if resid is not None:
+        if hl_out or out.dtype != torch.float32 or resid.dtype != torch.float32 or tuple(resid.shape) != (m, n):
+            raise ValueError("gemm_hl: resid needs an fp32 [m, n] tensor and an fp32 output")
+        resid = _rows16(resid, "resid")
+        ldr = resid.stride(0)
+    check(_ffi.load().snf_gemm_hl_resid_bf16(_p(a_hl), a_hl.stride(0), _p(w_hl), w_hl.stride(0), _p(bias), _p(resid), ldr, m, n,
+                                             k2 // 2, ACT_CODES[act], _p(out), out.stride(0), odt, _stream()), "snf_gemm_hl_bf16")
     return out
 
 

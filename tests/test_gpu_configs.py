@@ -108,7 +108,9 @@ def test_vit_small_adapter_batch_512():
         bdiff = float((feats.float() - sub.float()).abs().max())
         measured[precision] = {"max_abs_err": err, "rel_err": rerr, "batch_vs_subbatch": bdiff,
                                "ref_absmax": float(ref.abs().max())}
-        assert bdiff <= (1e-5 if precision == "fp32" else tol), (precision, bdiff)
+        # fp32: a batch of 512 takes the one-pass x3 GEMM kernel, sub-batches of 4 the concatenated form (both fp32-class, different
+        # summation order) -- equal to ~1e-5 of the feature scale, not bit for bit
+        assert bdiff <= (1e-4 if precision == "fp32" else tol), (precision, bdiff)
         # north-star tolerance classes: 1e-3 fp32, 1e-2 bf16 -- on features normalised by their own scale (the final
         # LayerNorm puts them at O(1); max |feat| is recorded next to the error)
         assert rerr < tol, (precision, err, rerr)

@@ -175,6 +175,8 @@ def test_gemm_hl_one_pass_kernel(m, n, k, act):
     cat = ops.gemm_x3(ops.split3_rows(ad), ops.split3_weight(wd), bd, act)   # same products, different summation order
     assert (out - cat).abs().max().item() <= 4e-6 * scale
     assert torch.equal(out, ops.gemm_hl(a_hl, w_hl, bd, act))                # deterministic
+    res = torch.randn(m, n, generator=g).to(DEV)
+    assert (ops.gemm_hl(a_hl, w_hl, bd, act, resid=res) - (out + res)).abs().max().item() <= 1e-6 * scale   # residual in the epilogue
     ob = ops.gemm_hl(a_hl, w_hl, bd, act, out_dtype=torch.bfloat16)
     assert (ob.float() - out).abs().max().item() <= 2.0 ** -8 * scale
     if n % 32 == 0:

@@ -17,7 +17,10 @@ if __name__ == "__main__":
     from snuffy_amd import build as B
     B.build_lib()
     os.makedirs(VAR, exist_ok=True)
+    only = sys.argv[2:]
     for name, defs in VARIANTS.items():
+        if only and name not in only:
+            continue
         obj = os.path.join(VAR, "gemm_%s.o" % name)
         subprocess.run([B._hipcc()] + B.FLAGS + defs + ["-c", os.path.join(B.CSRC, "gemm.hip"), "-o", obj], check=True)
         objs = [os.path.join(B.OBJDIR, os.path.basename(s)[:-4] + ".o") for s in B.sources() if not s.endswith("/gemm.hip")] + [obj]

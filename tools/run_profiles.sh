@@ -1,14 +1,26 @@
-set -x
-python bench.py --steps 30 --warmup 5 > gpurun_out/r02_bench_cfgB.json 2> gpurun_out/r02_bench_cfgB.err
-bash tools/prof_bench.sh r02a > gpurun_out/r02a.txt 2>&1
-bash tools/prof_bench.sh r02f --precision fp32 --steps 10 > gpurun_out/r02f.txt 2>&1
-bash tools/prof_bench.sh r02t --mode train --precision bf16 --steps 10 --warmup 3 > gpurun_out/r02t.txt 2>&1
-bash tools/prof_vit.sh r02v > gpurun_out/r02v.txt 2>&1
-bash tools/pmc_traffic.sh gpurun_out/r02_traffic > gpurun_out/r02_traffic.txt 2>&1
-python tools/bench_vit.py > gpurun_out/r02_vit.txt 2>&1
-python bench.py --mode train --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > gpurun_out/r02_bench_cfgB_train.json 2>/dev/null
-python bench.py --workload cfgA --no-cpu-baseline --steps 50 > gpurun_out/r02_bench_cfgA.json 2>/dev/null
-python bench.py --workload cfgC --no-cpu-baseline --steps 20 > gpurun_out/r02_bench_cfgC.json 2>/dev/null
-python bench.py --workload cam16 --no-cpu-baseline --headline-only --steps 50 > gpurun_out/r02_bench_cam16.json 2>/dev/null
-python tools/gemm_bench.py cfgB cfgA vit > gpurun_out/r02_gemm_bench.txt 2>&1
-tail -3 gpurun_out/r02_traffic.txt
+# End-of-round measurement run (GPU box, repo root): bench lines, rocprofv3 kernel stats, PMC traffic of the attention kernels,
+# micro-benchmarks.  Everything lands under gpurun_out/r03/; copy what is to be judged into profiles/.   bash tools/run_profiles.sh
+R=r03; O=gpurun_out/$R; mkdir -p $O
+T="timeout 600"
+$T python bench.py > $O/bench_cfgB.json 2> $O/bench_cfgB.err
+$T bash tools/prof_bench.sh ${R}_f32 --precision fp32 --steps 200 > $O/prof_f32.txt 2>&1
+$T bash tools/prof_bench.sh ${R}_bf16 --precision bf16 --steps 200 > $O/prof_bf16.txt 2>&1
+$T bash tools/prof_bench.sh ${R}_train_bf16 --mode train --precision bf16 --steps 20 --warmup 5 > $O/prof_train_bf16.txt 2>&1
+$T bash tools/prof_bench.sh ${R}_train_f32 --mode train --precision fp32 --steps 20 --warmup 5 > $O/prof_train_f32.txt 2>&1
+$T bash tools/prof_bench.sh ${R}_vit_bf16 --workload vit --precision bf16 --steps 5 > $O/prof_vit_bf16.txt 2>&1
+$T bash tools/pmc_traffic.sh $O/traffic > $O/traffic.txt 2>&1
+WHAT=x3B $T bash tools/pmc_attn.sh $O/pmc_x3 > /dev/null 2>&1; python tools/pmc_summary.py $O/pmc_x3 sparse_attn_x3 > $O/attn_x3_pmc_sq.txt 2>&1
+WHAT=attnB $T bash tools/pmc_attn.sh $O/pmc_bf16 > /dev/null 2>&1; python tools/pmc_summary.py $O/pmc_bf16 sparse_attn_mfma > $O/attn_mfma_pmc_sq.txt 2>&1
+$T python bench.py --mode train --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_cfgB_train_bf16.json 2>/dev/null
+$T python bench.py --mode train --precision fp32 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_cfgB_train_f32.json 2>/dev/null
+$T python bench.py --workload cfgA --no-cpu-baseline --steps 200 > $O/bench_cfgA.json 2>/dev/null
+$T python bench.py --workload cfgC --no-cpu-baseline --steps 50 > $O/bench_cfgC.json 2>/dev/null
+$T python bench.py --workload cam16 --no-cpu-baseline --headline-only --steps 100 > $O/bench_cam16.json 2>/dev/null
+$T python bench.py --workload vit --steps 10 > $O/bench_vit.json 2>/dev/null
+$T python tools/gemm_bench.py cfgB cfgA vit > $O/gemm_bench.txt 2>&1
+$T python tools/gemm_x3_bench.py cfgB cfgA vit > $O/gemm_x3_bench.txt 2>&1
+$T python tools/topk_bench.py > $O/topk_bench.txt 2>&1
+$T python tools/kbench.py x3 > $O/attn_x3_timing.txt 2>&1
+$T tools/probes/dma_pacing_probe.bin > $O/dma_pacing_probe.txt 2>&1
+for n in f32 bf16 train_bf16 train_f32 vit_bf16; do cp gpurun_out/prof_${R}_$n/p_kernel_stats.csv $O/${n}_kernel_stats.csv 2>/dev/null; done
+tail -4 $O/traffic.txt; head -c 600 $O/bench_cfgB.json
