@@ -8,4 +8,4 @@ Kernels live in snuffy_amd/csrc (HIP, built into snuffy_amd/lib/libsnuffy_hip.so
 from . import _ffi  # noqa: F401
 from ._ffi import SnuffyHipError  # noqa: F401
 
-__version__ = "0.2.0"
+__version__ = "0.3.0"

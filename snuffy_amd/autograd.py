@@ -288,7 +288,8 @@ class EncoderLayer0Bf16Fn(torch.autograd.Function):
         z = SF.materialize(SF.Parts(x2, add_bf16=zb, add_bias=bb2, slot=slot, delta=delta))
         ctx.save_for_backward(sel, xhat0_sel, qv, kp, lse, o, xs, x_sel, hid, g0, b0, g1, b1, wq, wk, wv, wo, w1,
                               fw["w1"], fw["w2"])
-        ctx.xhat = xhat          # rows S are swapped in place during backward (and swapped back): kept outside the version check
+        ctx.xhat = xhat          # read-only in backward; outside save_for_backward because the forward wrote rows S in place after the
+        #                          Q|V projection had read it (the version check would reject it)
         ctx.h, ctx.eps, ctx.drop = h, eps, drop
         ctx.mark_non_differentiable(*([attn] if attn is not None else []))
         return z, attn
@@ -319,10 +320,11 @@ class EncoderLayer0Bf16Fn(torch.autograd.Function):
         dq, dkp, dv = ops.sparse_attn_bwd_mfma(q, v, kp, do.contiguous(), lse, h, dropout=ctx.drop, fused_bf16_grads=True)
         dqv = dq._base                                                                # [N, 2D] bf16 = [dQ | dV]
         del dq, dv
-        xhat1_sel = xhat.index_select(0, sel)
-        xhat.index_copy_(0, sel, xhat0_sel)                                           # back to LayerNorm 0's rows
+        # xhat holds LayerNorm 1's rows at S since the forward re-normalised them in place; the Q|V projection saw LayerNorm 0's.
+        # The buffer is only READ here: dW = dqv^T xhat + dqv[S]^T (xhat0[S] - xhat1[S]), a K-row correction of the big product
         dwqvf = _tn_mm(dqv, xhat)                                                     # [2D, D] folded
-        xhat.index_copy_(0, sel, xhat1_sel)                                           # (a second backward sees the same state)
+        corr = (xhat0_sel.float() - xhat.index_select(0, sel).float())               # [K, D]
+        dwqvf += dqv.index_select(0, sel).float().t() @ corr
         dbqvf, _ = ops.colsum_fused(dqv)
         dwk = dkp.t() @ xs
         dbk = dkp.sum(0)

@@ -42,7 +42,7 @@ int cu_count() {
 
 extern "C" {
 
-const char* snf_version(void) { return "snuffy_hip 0.2.0 (gfx950)"; }
+const char* snf_version(void) { return "snuffy_hip 0.3.0 (gfx950)"; }
 const char* snf_last_error(void) { return snf::g_err; }
 int snf_device_cu_count(void) {
     int dev = 0;

@@ -692,9 +692,12 @@ def linear_bf16(a, w, bias_f32=None, bias_bf16=None, act="none", prefer_native=N
         bias_bf16 = bias_f32.to(torch.bfloat16)
     if act == "relu" and bias_bf16 is not None:
         return torch._addmm_activation(bias_bf16, a, w.t())
-    out = torch.addmm(bias_bf16, a, w.t()) if bias_bf16 is not None else torch.mm(a, w.t())
-    if act != "none":
-        bias_act_(out, None, act)
+    if act == "none":
+        return torch.addmm(bias_bf16, a, w.t()) if bias_bf16 is not None else torch.mm(a, w.t())
+    # activations the library cannot fuse: ONE rounding of the biased pre-activation, like the native epilogue (fp32 bias applied
+    # together with the activation in a single pass over the product)
+    out = torch.mm(a, w.t())
+    bias_act_(out, bias_f32 if bias_f32 is not None else (bias_bf16.float() if bias_bf16 is not None else None), act)
     return out
 
 
