@@ -310,17 +310,20 @@ def _split_weights(layer):
             w1=ops.split3_weight(ff.w_1.weight), b1=ff.w_1.bias.detach().float().contiguous(),
             w2=ops.split3_weight(ff.w_2.weight), b2=ff.w_2.bias.detach().float().contiguous(),
         )
-    hl_cache = {}
-
-    def hl():
-        """interleaved images for the one-pass kernel (ops.gemm_hl): built once, by the first forward that takes that branch"""
-        if not hl_cache:
-            with torch.no_grad():
-                hl_cache.update(wqv=ops.split_hl_weight(wqv), w1=ops.split_hl_weight(ff.w_1.weight), w2=ops.split_hl_weight(ff.w_2.weight))
-        return hl_cache
-    out["hl"] = hl
+    out["_wqv_f32"] = wqv            # kept for the interleaved images of the one-pass kernel (_hl_weights), built on first use
     layer._fold3 = (key, out)
     return out
+
+
+def _hl_weights(layer, fw):
+    """Interleaved ("hl") images of the layer's projection weights for the one-pass fp32-class GEMM (ops.gemm_hl): built once per
+    parameter version, by the first forward that takes that branch (plain tensors in the layer's cache: the module stays picklable)."""
+    if "hl" not in fw:
+        ff = layer.feed_forward
+        with torch.no_grad():
+            fw["hl"] = dict(wqv=ops.split_hl_weight(fw["_wqv_f32"]), w1=ops.split_hl_weight(ff.w_1.weight),
+                            w2=ops.split_hl_weight(ff.w_2.weight))
+    return fw["hl"]
 
 
 def invalidate_folded(layer):
@@ -361,7 +364,7 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
         # large bags: the one-pass kernel on interleaved [hi(32) | lo(32)] images (one full-line DMA per operand row and K step,
         # 96 MFMAs per 24 fragment reads); otherwise the concatenated form over [hi | hi | lo]
         hl = d % 32 == 0 and f % 32 == 0 and ops.hl_eligible(n, 2 * d, d) and ops.hl_eligible(n, f, d) and ops.hl_eligible(n, d, f)
-        fh = fw["hl"]() if hl else None
+        fh = _hl_weights(layer, fw) if hl else None
         xs, slot = ops.gather_slot_map(x2, sel)                                     # snuffy.py:131,145-147 (+ row -> slot map)
         kp = F.linear(xs, lk.weight, lk.bias)                                       # keys = RAW selected rows (K rows: fp32)
         if hl:

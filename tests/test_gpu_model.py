@@ -302,3 +302,27 @@ def test_graph_replay_equals_eager(precision):
     with torch.no_grad():
         rnd(small[0])
     assert len(rnd._graphs) == 0
+
+
+@pytest.mark.gpu
+def test_module_stays_picklable_and_copyable_after_forwards():
+    """The per-layer caches (folded bf16 weights, split images of both formats, selector hand-over) hold plain tensors: a MILNet that
+    has run forwards in both precisions can still be deep-copied and pickled whole (torch.save(model)), and the copy computes the same."""
+    import copy
+    import io
+    net = build_amd_milnet(768, 6, "relu", 200, 0.0, 1).to(DEV).eval()
+    x = torch.randn(1, 40000, 768, device=DEV)             # large enough for the fused selector and the one-pass GEMM
+    with torch.no_grad():
+        outs = {}
+        for precision in ("fp32", "bf16"):
+            net.configure(precision=precision, return_attention=False)
+            outs[precision] = net(x)[1].clone()
+        twin = copy.deepcopy(net)
+        buf = io.BytesIO()
+        torch.save(net, buf)
+        buf.seek(0)
+        loaded = torch.load(buf, weights_only=False)
+        for m in (twin, loaded):
+            for precision in ("fp32", "bf16"):
+                m.configure(precision=precision, return_attention=False)
+                assert torch.equal(m(x)[1], outs[precision]), precision
