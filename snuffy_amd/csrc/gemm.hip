@@ -539,6 +539,7 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) wl[ni] = frag(base + woff_l + (4 * (ni & 1) + 32 * (ni >> 1)) * ROWL);
             __builtin_amdgcn_sched_barrier(0);
+            // the next step's DMA behind the fragment reads (issued ahead of them it measured the same: +-3 % run to run)
             if (s + 1 < ns) {
                 stage(cur, s + 1, buf ^ 1);
             } else if (has_next) {
