@@ -360,6 +360,46 @@ int snf_tile_preprocess_u8(const void* img_u8, int b, int h, int w, int c, int o
                            int hks, const int* vbounds, const int* vcoef, int vks, int normalize, const float* mean,
                            const float* std_, float* out_f32, void* cols_bf16, int patch, snf_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Varlen path: MANY bags in one launch (bags of <= 8 k patches are launch-latency bound).
+ *     The reference runs one bag per forward (train.py:468-473 batch_size 1; snuffy.py:130-131 indexes with a 1-D tensor); this
+ *     is the same per-bag arithmetic with the bags' rows PACKED into one [T, .] tensor, offsets[bags + 1] = first row of each bag.
+ *     Row-wise kernels (critic, LayerNorm, the projections, the FFN) already take packed rows; the three per-bag reductions get
+ *     segmented forms.  Every segmented launch is the CONCATENATION of the bags' own grids (workgroup wg0 + i of bag b does what
+ *     workgroup i of the bag's own launch does), so results are bit-identical to the per-bag entry points above.
+ *   snf_topk_segmented_f32       K2 of every bag (offsets in DEVICE memory; idx_out [bags, k] = indices inside the bag).
+ *   snf_sparse_attn_varlen_plan / snf_sparse_attn_x3_varlen_plan
+ *                                host-side geometry of a varlen attention launch: offsets in HOST memory; call with
+ *                                table = NULL for the sizes, then with a host buffer of *table_ints_needed int32 words, upload
+ *                                it once per batch composition and pass the device copy to the launch.
+ *   snf_sparse_attn_fwd_mfma_varlen   K7 bf16 form: q, v [T, ld] bf16, kp [bags * k, h * dk] (bag b's keys in rows b k ..),
+ *                                out [bags * k, h * dk] f32, attn [h, T, k] / lse [h, T] nullable.  Single key chunk
+ *                                (k <= 224 at dk = 128, 256 at dk = 64), inference only (no dropout).
+ *   snf_sparse_attn_fwd_x3_varlen     K7 fp32-class form on f32 q, v, kp; same layout and limits.
+ *   snf_ln_mean_head_varlen_plan / snf_ln_mean_head_varlen_f32
+ *                                K11 for every bag: logits [bags, c_out], pooled [bags, d] nullable.
+ * --------------------------------------------------------------------------------------------------------- */
+int snf_topk_segmented_f32(const float* scores, const int64_t* offsets_dev, int bags, int64_t max_n, int k, int64_t* idx_out,
+                           snf_stream_t stream);
+int snf_sparse_attn_varlen_plan(const int64_t* offsets, int bags, int k, int h, int dk, int32_t* table, size_t table_ints,
+                                size_t* table_ints_needed, size_t* workspace_bytes);
+int snf_sparse_attn_fwd_mfma_varlen(const void* q, int64_t ldq, const void* v, int64_t ldv, const void* kp, int kp_dtype,
+                                    const int64_t* offsets, int bags, int k, int h, int dk, float scale, float* out, float* attn,
+                                    float* lse, const int32_t* table_dev, void* workspace, size_t workspace_bytes,
+                                    snf_stream_t stream);
+int snf_sparse_attn_x3_varlen_plan(const int64_t* offsets, int bags, int k, int h, int dk, int32_t* table, size_t table_ints,
+                                   size_t* table_ints_needed, size_t* workspace_bytes);
+int snf_sparse_attn_fwd_x3_varlen(const float* q, int64_t ldq, const float* v, int64_t ldv, const float* kp, const int64_t* offsets,
+                                  int bags, int k, int h, int dk, float scale, float* out, float* attn, float* lse,
+                                  const int32_t* table_dev, void* workspace, size_t workspace_bytes, snf_stream_t stream);
+int snf_ln_mean_head_varlen_plan(const int64_t* offsets, int bags, int d, int32_t* table, size_t table_ints,
+                                 size_t* table_ints_needed, size_t* workspace_bytes);
+int snf_ln_mean_head_varlen_f32(const float* z, const int64_t* offsets, int bags, int d, const void* add_bf16,
+                                const float* add_bias, const int32_t* slot_map, const float* delta_rows, float* z_out,
+                                const float* gamma, const float* beta, float eps, const float* w_head, const float* b_head,
+                                int c_out, float* logits, float* pooled, const int32_t* table_dev, void* workspace,
+                                size_t workspace_bytes, snf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,9 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
 # The SLP vectoriser is off for the attention kernel: it pairs the running softmax sums into v_pk_add_f32 and then needs
 # three v_mov per four probabilities to re-pair them for the explicit v_pk_mul / v_cvt_pk of the normalisation.
 EXTRA_FLAGS = {"sparse_attn_mfma.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
-               "sparse_attn_mfma_dk64.hip": ["-fno-honor-nans", "-fno-slp-vectorize"], "vit.hip": ["-fno-honor-nans"],
+               "sparse_attn_mfma_dk64.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
+               "sparse_attn_mfma_varlen.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
+               "sparse_attn_mfma_varlen_dk64.hip": ["-fno-honor-nans", "-fno-slp-vectorize"], "vit.hip": ["-fno-honor-nans"],
                "sparse_attn_x3.hip": ["-fno-honor-nans"]}
 
 

@@ -834,9 +834,24 @@ __global__ __launch_bounds__(WG) void ln_colsum_kernel(const float* __restrict__
                                                        const int32_t* __restrict__ slot_map,
                                                        const float* __restrict__ delta_rows,
                                                        float* __restrict__ z_out,
-                                                       float* __restrict__ partial /*[grid, d]*/) {
+                                                       float* __restrict__ partial /*[grid, d]*/,
+                                                       const int* __restrict__ vl = nullptr, int vl_bags = 0) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    int bid = blockIdx.x, gdim = gridDim.x;
+    if (vl) {
+        // varlen (many bags, one launch): this workgroup is workgroup (bid - wg0) of the bag's own launch of `parts` workgroups --
+        // same rows, same order, so the bag's column sums are bit-identical to a per-bag launch.  Descriptor: wg0, row0, n, parts
+        const int* __restrict__ dsc = vl + 4 * vl[4 * vl_bags + bid];
+        const int64_t row0 = dsc[1];
+        bid -= dsc[0];
+        n = dsc[2];
+        gdim = dsc[3];
+        z += row0 * d;
+        if (add_bf16) add_bf16 += row0 * d;
+        if (slot_map) slot_map += row0;
+        if (z_out) z_out += row0 * d;
+    }
     float acc[NV * VEC];
 #pragma unroll
     for (int i = 0; i < NV * VEC; ++i) acc[i] = 0.f;
@@ -846,7 +861,7 @@ __global__ __launch_bounds__(WG) void ln_colsum_kernel(const float* __restrict__
     // The pass is latency-bound (PMC: waves parked on vmcnt 79 % of their cycles, one row = one HBM round trip per trip):
     // the NEXT row's loads (f32 base + raw bf16 addend) are issued before the current row is reduced, so every wave keeps
     // two rows in flight.  Rows are consumed in the same order as before -> bit-identical sums.
-    const int64_t rstride = (int64_t)gridDim.x * WAVES;
+    const int64_t rstride = (int64_t)gdim * WAVES;
     float nz[NV * VEC];     // prefetched base row
     uint2 nb[NV];           // prefetched raw bf16 addend (VEC == 4 only)
     auto issue = [&](int64_t row) __attribute__((always_inline)) {
@@ -861,7 +876,7 @@ __global__ __launch_bounds__(WG) void ln_colsum_kernel(const float* __restrict__
             }
         }
     };
-    int64_t row = (int64_t)blockIdx.x * WAVES + wave;
+    int64_t row = (int64_t)bid * WAVES + wave;
     if (row < n) issue(row);
     for (; row < n; row += rstride) {
         float r[NV * VEC];
@@ -937,8 +952,15 @@ __global__ __launch_bounds__(WG) void ln_colsum_kernel(const float* __restrict__
 // p = sl, sl+NSLICE, ... of 64 columns; its 4 waves split those rows again and combine through LDS in a fixed order.
 constexpr int HEAD_NSLICE = 16;
 __global__ __launch_bounds__(256) void ln_colreduce_kernel(const float* __restrict__ partial, int nparts, int d,
-                                                           float* __restrict__ partial2 /*[NSLICE, d]*/) {
+                                                           float* __restrict__ partial2 /*[NSLICE, d]*/,
+                                                           const int* __restrict__ vl = nullptr) {
     __shared__ float red[4][64];
+    if (vl) {   // varlen: blockIdx.z = bag, its own partial rows and second-level slices
+        const int* __restrict__ dsc = vl + 4 * blockIdx.z;
+        partial += (int64_t)dsc[0] * d;
+        nparts = dsc[3];
+        partial2 += (int64_t)blockIdx.z * HEAD_NSLICE * d;
+    }
     const int c = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + c;
     const int sl = blockIdx.y;
@@ -954,8 +976,15 @@ __global__ __launch_bounds__(256) void ln_colreduce_kernel(const float* __restri
 __global__ __launch_bounds__(256) void head_gemv_kernel(const float* __restrict__ partial2, int64_t n, int d,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ w_head, const float* __restrict__ b_head,
-                                                        float* __restrict__ pooled_out, float* __restrict__ logits) {
+                                                        float* __restrict__ pooled_out, float* __restrict__ logits,
+                                                        const int* __restrict__ vl = nullptr) {
     __shared__ float red[256];
+    if (vl) {   // varlen: blockIdx.y = bag
+        partial2 += (int64_t)blockIdx.y * HEAD_NSLICE * d;
+        n = vl[4 * blockIdx.y + 2];
+        logits += (int64_t)blockIdx.y * gridDim.x;
+        if (pooled_out) pooled_out += (int64_t)blockIdx.y * d;
+    }
     const int c = blockIdx.x;
     const float inv_n = 1.0f / (float)n;
     float acc = 0.f;
@@ -1410,6 +1439,81 @@ int snf_ln_mean_head_f32(const float* z, int64_t n, int d, const void* add_bf16,
     if (rc) return rc;
     hipLaunchKernelGGL(head_gemv_kernel, dim3(c_out), dim3(256), 0, s, partial2, n, d, gamma, beta, w_head, b_head, pooled,
                        logits);
+    return snf::check_launch("head_gemv_kernel");
+}
+
+// ---- varlen head: logits of every bag of a packed residual stream in three launches (instead of three per bag) --------------
+// Plan: offsets [bags + 1] in HOST memory; table (host, may be null to size it) = [bags][4] (wg0, row0, n, parts) + the bag of
+// every stage-1 workgroup.  Every bag keeps the partition of its own launch, so its logits are bit-identical to a per-bag call.
+int snf_ln_mean_head_varlen_plan(const int64_t* offsets, int bags, int d, int32_t* table, size_t table_ints,
+                                 size_t* table_ints_needed, size_t* workspace_bytes) {
+    SNF_REQUIRE(offsets && bags >= 1 && d >= 1, "snf_ln_mean_head_varlen_plan: bad arguments");
+    int64_t total = 0;
+    for (int b = 0; b < bags; ++b) {
+        const int64_t n = offsets[b + 1] - offsets[b];
+        SNF_REQUIRE(n >= 1 && offsets[b + 1] < 0x7fffffffll, "snf_ln_mean_head_varlen_plan: bag %d has %lld rows", b, (long long)n);
+        total += ln_head_parts(n);
+    }
+    SNF_REQUIRE(total < 0x3fffffff, "snf_ln_mean_head_varlen_plan: too many workgroups");
+    const size_t need = (size_t)4 * bags + (size_t)total;
+    if (table_ints_needed) *table_ints_needed = need;
+    if (workspace_bytes) *workspace_bytes = ((size_t)total + (size_t)bags * HEAD_NSLICE) * d * sizeof(float);
+    if (table) {
+        SNF_REQUIRE(table_ints >= need, "snf_ln_mean_head_varlen_plan: table %zu < %zu ints", table_ints, need);
+        int64_t wg = 0;
+        for (int b = 0; b < bags; ++b) {
+            const int64_t n = offsets[b + 1] - offsets[b];
+            const int parts = ln_head_parts(n);
+            table[4 * b + 0] = (int32_t)wg, table[4 * b + 1] = (int32_t)offsets[b], table[4 * b + 2] = (int32_t)n;
+            table[4 * b + 3] = parts;
+            for (int i = 0; i < parts; ++i) table[(size_t)4 * bags + wg + i] = b;
+            wg += parts;
+        }
+    }
+    return SNF_OK;
+}
+
+// z [T, d] packed rows (same optional addends as snf_ln_mean_head_f32, slot_map / delta_rows in packed coordinates);
+// logits [bags, c_out], pooled [bags, d] or null
+int snf_ln_mean_head_varlen_f32(const float* z, const int64_t* offsets, int bags, int d, const void* add_bf16,
+                                const float* add_bias, const int32_t* slot_map, const float* delta_rows, float* z_out,
+                                const float* gamma, const float* beta, float eps, const float* w_head, const float* b_head,
+                                int c_out, float* logits, float* pooled, const int32_t* table_dev, void* workspace,
+                                size_t workspace_bytes, snf_stream_t stream) {
+    SNF_REQUIRE(z && offsets && w_head && logits && workspace && table_dev, "snf_ln_mean_head_varlen_f32: null pointer");
+    SNF_REQUIRE(!slot_map || delta_rows, "snf_ln_mean_head_varlen_f32: slot_map without delta_rows");
+    SNF_REQUIRE(bags >= 1 && d >= 1 && c_out >= 1, "snf_ln_mean_head_varlen_f32: bad shape");
+    int64_t total = 0;
+    for (int b = 0; b < bags; ++b) {
+        SNF_REQUIRE(offsets[b + 1] > offsets[b], "snf_ln_mean_head_varlen_f32: empty bag %d", b);
+        total += ln_head_parts(offsets[b + 1] - offsets[b]);
+    }
+    const size_t need = ((size_t)total + (size_t)bags * HEAD_NSLICE) * d * sizeof(float);
+    if (workspace_bytes < need) {
+        snf::set_error("snf_ln_mean_head_varlen_f32: workspace %zu < %zu", workspace_bytes, need);
+        return SNF_EWORKSPACE;
+    }
+    RowCfg cfg;
+    // packed rows start at row0 * d elements: 16-byte alignment of every bag's first row needs d % 4 == 0 (pick_row_cfg checks it)
+    const bool al = aligned16(z) && (!add_bf16 || aligned16(add_bf16)) && (!add_bias || aligned16(add_bias)) &&
+                    (!delta_rows || aligned16(delta_rows)) && (!z_out || aligned16(z_out));
+    SNF_REQUIRE(pick_row_cfg(d, al, &cfg), "snf_ln_mean_head_varlen_f32: d=%d too wide (max 2048)", d);
+    hipStream_t s = snf::as_stream(stream);
+    float* partial = reinterpret_cast<float*>(workspace);
+    float* partial2 = partial + (size_t)total * d;
+    const int64_t n_all = offsets[bags];
+    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((ln_colsum_kernel<VEC, NV>), dim3((unsigned)total), dim3(WG),
+                                              WAVES * NV * VEC * 64 * sizeof(float), s, z, n_all, d, eps,
+                                              reinterpret_cast<const unsigned short*>(add_bf16), add_bias, slot_map,
+                                              delta_rows, z_out, partial, table_dev, bags));
+    int rc = snf::check_launch("ln_colsum_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((d + 63) / 64, HEAD_NSLICE, bags), dim3(256), 0, s, partial, 0, d, partial2,
+                       table_dev);
+    rc = snf::check_launch("ln_colreduce_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(head_gemv_kernel, dim3(c_out, bags), dim3(256), 0, s, partial2, n_all, d, gamma, beta, w_head, b_head,
+                       pooled, logits, table_dev);
     return snf::check_launch("head_gemv_kernel");
 }
 

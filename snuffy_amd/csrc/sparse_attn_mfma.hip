@@ -90,6 +90,9 @@ int snf_sparse_attn_fwd_mfma_dropout(const void* q, int64_t ldq, const void* v, 
     P.h = h;
     P.scale = scale;
     P.attn_ld = k;
+    P.n_stride = n;
+    P.vl = nullptr;
+    P.vl_bags = 0;
     P.partial = reinterpret_cast<float*>(workspace);
     P.trace = g_attn_trace;
     P.trace_wg = g_attn_trace_wg;
@@ -148,6 +151,91 @@ int snf_sparse_attn_fwd_mfma_dropout(const void* q, int64_t ldq, const void* v, 
         if (rc) return rc;
     }
     return SNF_OK;
+}
+
+// ---- varlen: many bags in one launch (small bags are launch-latency bound: SURVEY 7 step 8) ---------------------------------
+// offsets[bags + 1] (HOST memory) = first packed row of every bag.  Sizes of the plan table (int32 words, built on the host by
+// this call when `table` is given and uploaded by the caller once per batch composition) and of the launch workspace.
+int snf_sparse_attn_varlen_plan(const int64_t* offsets, int bags, int k, int h, int dk, int32_t* table, size_t table_ints,
+                                size_t* table_ints_needed, size_t* workspace_bytes) {
+    SNF_REQUIRE(offsets && bags >= 1 && k >= 1 && h >= 1, "snf_sparse_attn_varlen_plan: bad arguments");
+    VarlenPlan vp;
+    if (!make_varlen_plan(offsets, bags, k, h, dk, &vp, nullptr, 0)) {
+        snf::set_error("snf_sparse_attn_varlen_plan: unsupported shape (bags=%d k=%d dk=%d: need dk in {64, 128}, k <= %d, "
+                       "non-empty bags)", bags, k, dk, dk == 128 ? 224 : 256);
+        return SNF_EUNSUPPORTED;
+    }
+    const size_t need = (size_t)snf_attn::VL_DESC * bags + (size_t)vp.total_wg;
+    if (table_ints_needed) *table_ints_needed = need;
+    if (workspace_bytes)
+        *workspace_bytes = ((size_t)vp.partial_slots * (size_t)(vp.nkb * (dk / 32)) * 1024 * sizeof(float) + 255) / 256 * 256 +
+                           kp_staging_bytes(k * bags, h, dk);
+    if (table) {
+        SNF_REQUIRE(table_ints >= need, "snf_sparse_attn_varlen_plan: table %zu < %zu ints", table_ints, need);
+        make_varlen_plan(offsets, bags, k, h, dk, &vp, table, table_ints);
+    }
+    return SNF_OK;
+}
+
+// q, v [T, ld] bf16 (T = offsets[bags] packed rows), kp [bags * k, h * dk] (bag b's keys in rows b k .. b k + k - 1),
+// out [bags * k, h * dk] f32, attn [h, T, k] / lse [h, T] or null.  table_dev = the uploaded plan table.
+int snf_sparse_attn_fwd_mfma_varlen(const void* q, int64_t ldq, const void* v, int64_t ldv, const void* kp, int kp_dtype,
+                                    const int64_t* offsets, int bags, int k, int h, int dk, float scale, float* out, float* attn,
+                                    float* lse, const int32_t* table_dev, void* workspace, size_t workspace_bytes,
+                                    snf_stream_t stream) {
+    SNF_REQUIRE(q && v && kp && out && offsets && table_dev, "snf_sparse_attn_fwd_mfma_varlen: null pointer");
+    SNF_REQUIRE(kp_dtype == SNF_DT_F32 || kp_dtype == SNF_DT_BF16, "snf_sparse_attn_fwd_mfma_varlen: bad kp dtype %d", kp_dtype);
+    VarlenPlan vp;
+    if (bags < 1 || !make_varlen_plan(offsets, bags, k, h, dk, &vp, nullptr, 0)) {
+        snf::set_error("snf_sparse_attn_fwd_mfma_varlen: unsupported shape (bags=%d k=%d dk=%d)", bags, k, dk);
+        return SNF_EUNSUPPORTED;
+    }
+    const int64_t d = (int64_t)h * dk, total = offsets[bags];
+    int64_t nmax = 0;
+    for (int b = 0; b < bags; ++b) nmax = offsets[b + 1] - offsets[b] > nmax ? offsets[b + 1] - offsets[b] : nmax;
+    if (ldq >= (1 << 24) || ldv >= (1 << 24) || nmax * (ldq > ldv ? ldq : ldv) >= 0x7fffffffll) {
+        snf::set_error("snf_sparse_attn_fwd_mfma_varlen: bag rows * row pitch exceeds the 32-bit offsets of the kernel");
+        return SNF_EUNSUPPORTED;
+    }
+    SNF_REQUIRE(ldq >= d && ldv >= d && (ldq % 8) == 0 && (ldv % 8) == 0,
+                "snf_sparse_attn_fwd_mfma_varlen: ldq=%lld / ldv=%lld must be >= h*dk and keep rows 16-byte aligned",
+                (long long)ldq, (long long)ldv);
+    SNF_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(kp) & 15) == 0,
+                "snf_sparse_attn_fwd_mfma_varlen: q / v / kp must be 16-byte aligned");
+    const size_t partial_bytes = ((size_t)vp.partial_slots * (size_t)(vp.nkb * (dk / 32)) * 1024 * sizeof(float) + 255) / 256 * 256;
+    const size_t need = partial_bytes + (kp_dtype == SNF_DT_F32 ? kp_staging_bytes(k * bags, h, dk) : 0);
+    if (!workspace || workspace_bytes < need) {
+        snf::set_error("snf_sparse_attn_fwd_mfma_varlen: workspace %zu < %zu", workspace_bytes, need);
+        return SNF_EWORKSPACE;
+    }
+    hipStream_t s = snf::as_stream(stream);
+    const unsigned short* kp16 = reinterpret_cast<const unsigned short*>(kp);
+    if (kp_dtype == SNF_DT_F32) {
+        unsigned short* stage = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(workspace) + partial_bytes);
+        const int64_t groups = (int64_t)k * bags * d / 8;
+        hipLaunchKernelGGL(kp_to_bf16_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(kp), stage, groups);
+        int rc = snf::check_launch("kp_to_bf16_kernel");
+        if (rc) return rc;
+        kp16 = stage;
+    }
+    AttnParams P;
+    P.q = q, P.v = v, P.kp = kp16;
+    P.n = total, P.ldq = ldq, P.ldv = ldv, P.ldkp = d;
+    P.k = k, P.h = h, P.scale = scale;
+    P.attn = attn, P.attn_ld = k, P.lse = lse;
+    P.stats = nullptr, P.stats_out = nullptr, P.n_chunks = 1;
+    P.partial = reinterpret_cast<float*>(workspace);
+    P.tiles_per_head = P.tiles_per_wg = P.total_tiles = P.seg_count = 0;   // per bag, from the table
+    P.trace = nullptr, P.trace_wg = 0;
+    P.drop = snf::make_dropout(0.f, 0, 0);
+    P.n_stride = total;
+    P.vl = table_dev, P.vl_bags = bags;
+    Plan pl;
+    pl.num_wg = (int)vp.total_wg, pl.nkb = vp.nkb;
+    pl.tiles_per_head = pl.tiles_per_wg = pl.total_tiles = pl.seg_count = 0;
+    return dk == 128 ? snf::attn_launch_varlen_dk128(P, pl, out, s) : snf::attn_launch_varlen_dk64(P, pl, out, s);
 }
 
 }  // extern "C"

@@ -62,7 +62,16 @@ struct AttnParams {
     // registers (philox.h) and applied to the normalised probabilities before they are published -- O and the returned A
     // are those of the dropped P, as in the reference.  thresh == 0: off.  Only the AUX variants look at it.
     snf::DropoutState drop;
+    int64_t n_stride;  // rows per head of attn / lse (= n for one bag; the packed row count of a varlen launch)
+    // varlen launch (many bags in one grid, VL kernels): table of VL_DESC ints per bag, then the bag of every workgroup
+    const int* vl;
+    int vl_bags;
 };
+// One bag of a varlen launch.  The grid is the concatenation of the bags' own single-bag grids: workgroup wg0 + i does exactly
+// what workgroup i of that bag's own launch does (same tiles, same partial tiles, same summation order in the reduction), so a
+// packed launch is bit-identical to the per-bag launches it replaces.
+constexpr int VL_DESC = 12;   // wg0, row0, n, out_row0 (= first Kp / output row), tiles_per_head, tiles_per_wg, total_tiles,
+                              // seg_count, part0 (first partial slot), num_wg, 0, 0
 struct Plan {
     int num_wg, tiles_per_head, tiles_per_wg, total_tiles, seg_count, nkb;
 };
@@ -71,6 +80,7 @@ struct Plan {
 namespace {
 using snf_attn::AttnParams;
 using snf_attn::Plan;
+using snf_attn::VL_DESC;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -186,9 +196,29 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 // (12 of the lane's 112 score registers: they hold -inf, would give exp = 0, and their P columns feed output rows that are
 // never stored), i.e. ~11 % of the softmax wave's VALU work, decided at compile time (the run-time form of the same skip
 // measured slower in round 1: its wave-uniform branches cost more than they saved).
-template <int DK, int NKB, typename QT, bool AUX, bool EXT, int TAILP = 8>
-__global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
+template <int DK, int NKB, typename QT, bool AUX, bool EXT, int TAILP = 8, bool VL = false>
+__global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams PA) {
     constexpr int NKS = DK / 16;             // k-steps of GEMM1
+    AttnParams P = PA;
+    int bid = blockIdx.x;
+    if constexpr (VL) {
+        // varlen: become workgroup (bid - wg0) of this bag's own launch (descriptor: scalar loads, once per workgroup)
+        const int* __restrict__ tb = PA.vl;
+        const int* __restrict__ dsc = tb + VL_DESC * tb[VL_DESC * PA.vl_bags + bid];
+        const int row0 = dsc[1];
+        bid -= dsc[0];
+        P.n = dsc[2];
+        P.q = reinterpret_cast<const QT*>(PA.q) + (int64_t)row0 * PA.ldq;
+        P.v = reinterpret_cast<const QT*>(PA.v) + (int64_t)row0 * PA.ldv;
+        P.kp = PA.kp + (int64_t)dsc[3] * PA.ldkp;
+        if (PA.attn) P.attn = PA.attn + (int64_t)row0 * PA.attn_ld;
+        if (PA.lse) P.lse = PA.lse + row0;
+        P.tiles_per_head = dsc[4];
+        P.tiles_per_wg = dsc[5];
+        P.total_tiles = dsc[6];
+        P.seg_count = dsc[7];
+        P.partial = PA.partial + (int64_t)dsc[8] * (NKB * (DK / 32)) * 1024;
+    }
     constexpr int NCB = DK / 32;             // 32-wide column blocks of the output
     constexpr int NT = (NKB * NCB + 3) / 4;  // output tiles owned by one pooling wave
     constexpr int M2 = 8 * NT;               // GEMM2 MFMAs per tile and wave
@@ -212,14 +242,14 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
     // debug trace (tools/attn_trace.py): phases 0..4 are stamped by the softmax waves (step start, GEMM1 done, B passed,
     // softmax done, A passed), 5..7 by the pooling waves (B passed, GEMM2 done, A passed)
     auto stamp = [&](int phase) __attribute__((always_inline)) {
-        if (P.trace && (int)blockIdx.x == P.trace_wg && lane == 0)
+        if (P.trace && bid == P.trace_wg && lane == 0)
             P.trace[(trace_it * 8 + phase) * 4 + w] = __builtin_amdgcn_s_memtime();
     };
     auto stamp_abs = [&](int slot) __attribute__((always_inline)) {  // slots 56..63 of the trace: kernel milestones
-        if (P.trace && (int)blockIdx.x == P.trace_wg && lane == 0) P.trace[(slot * 8) * 4 + w] = __builtin_amdgcn_s_memtime();
+        if (P.trace && bid == P.trace_wg && lane == 0) P.trace[(slot * 8) * 4 + w] = __builtin_amdgcn_s_memtime();
     };
 
-    const int f_begin = blockIdx.x * P.tiles_per_wg;
+    const int f_begin = bid * P.tiles_per_wg;
     int f_end = f_begin + P.tiles_per_wg;
     if (f_end > P.total_tiles) f_end = P.total_tiles;
     const int first_head = f_begin / P.tiles_per_head;
@@ -442,7 +472,7 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
             }
             const float inv = rvalid ? __builtin_amdgcn_rcpf(lrow) : 0.f;
             if constexpr (AUX)
-                if (P.lse && rvalid && hf == 0) P.lse[(int64_t)a * P.n + row] = mc * 0.69314718055994530942f + __logf(lrow);
+                if (P.lse && rvalid && hf == 0) P.lse[(int64_t)a * P.n_stride + row] = mc * 0.69314718055994530942f + __logf(lrow);
             stamp(3);
 
             // ---- A: every pooling wave finished the GEMM2 reads of the previous images (they got there long ago: GEMM2 is
@@ -454,7 +484,7 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
             int klim = 0;
             if constexpr (AUX) {
                 // attention matrix: this lane owns 4 consecutive keys per (block, c4) of ONE row -> 16-byte stores
-                arow = P.attn + ((int64_t)a * P.n + row) * P.attn_ld + 4 * hf;
+                arow = P.attn + ((int64_t)a * P.n_stride + row) * P.attn_ld + 4 * hf;
                 // keys this lane may store, relative to its first one.  Opaque to the optimiser on purpose: the bound is
                 // loop-invariant, and hoisting the 28..112 compare masks out of the tile loop spills ~240 SGPRs.
                 klim = (P.attn && rvalid) ? P.k - 4 * hf : 0;
@@ -575,7 +605,7 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams P) {
         };
         auto flush = [&](int head) __attribute__((always_inline)) {
             const int seg = head - first_head;
-            float* dst = P.partial + ((int64_t)blockIdx.x * P.seg_count + seg) * (int64_t)(NKB * NCB) * 1024;
+            float* dst = P.partial + ((int64_t)bid * P.seg_count + seg) * (int64_t)(NKB * NCB) * 1024;
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti) {
                 const int t_idx = w + 4 * ti;
@@ -762,9 +792,16 @@ __global__ __launch_bounds__(256, 1) void sparse_attn_stats_kernel(AttnParams P)
 template <int DK, int NKB>
 __global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __restrict__ partial, int num_wg, int seg_count,
                                                               int tiles_per_head, int tiles_per_wg, int total_tiles,
-                                                              int k, int h, float* __restrict__ out) {
+                                                              int k, int h, float* __restrict__ out,
+                                                              const int* __restrict__ vl = nullptr) {
     constexpr int NCB = DK / 32;
     constexpr int TILES = NKB * NCB;
+    if (vl) {   // varlen: blockIdx.z = bag; the bag's own launch geometry, partial slots and output rows
+        const int* __restrict__ dsc = vl + VL_DESC * blockIdx.z;
+        tiles_per_head = dsc[4], tiles_per_wg = dsc[5], total_tiles = dsc[6], seg_count = dsc[7], num_wg = dsc[9];
+        partial += (int64_t)dsc[8] * TILES * 1024;
+        out += (int64_t)dsc[3] * (h * DK);
+    }
     const int a = blockIdx.y;
     // one wave per workgroup: 4 TILES h small workgroups (672 at config B) spread over all CUs; as 168 workgroups of 4 waves
     // the pass left a third of the chip idle
@@ -834,12 +871,12 @@ inline bool make_plan(int64_t n, int k, int h, int dk, Plan* pl) {
     return true;
 }
 
-template <int DK, int NKB, typename QT, bool AUX, bool EXT = false, int TAILP = 8>
+template <int DK, int NKB, typename QT, bool AUX, bool EXT = false, int TAILP = 8, bool VL = false>
 int launch_variant(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
     constexpr int NKS = DK / 16;
     const size_t lds = (size_t)(NKB * NKS) * 1024 + (size_t)TILE_ROWS * (p_row_bytes(NKB) + 2 * DK);
     static thread_local bool attr_set = false;
-    auto kern = sparse_attn_mfma_kernel<DK, NKB, QT, AUX, EXT, TAILP>;
+    auto kern = sparse_attn_mfma_kernel<DK, NKB, QT, AUX, EXT, TAILP, VL>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
@@ -853,9 +890,70 @@ int launch_variant(const AttnParams& P, const Plan& pl, float* out, hipStream_t 
     int rc = snf::check_launch("sparse_attn_mfma_kernel");
     if (rc) return rc;
     constexpr int TILES = NKB * (DK / 32);
-    hipLaunchKernelGGL((reduce_partials_kernel<DK, NKB>), dim3(TILES * 4, P.h), dim3(64), 0, s, P.partial, pl.num_wg,
-                       pl.seg_count, pl.tiles_per_head, pl.tiles_per_wg, pl.total_tiles, P.k, P.h, out);
+    // varlen: pl.num_wg is the whole grid (all bags), one reduction slice (blockIdx.z) per bag
+    hipLaunchKernelGGL((reduce_partials_kernel<DK, NKB>), dim3(TILES * 4, P.h, VL ? P.vl_bags : 1), dim3(64), 0, s, P.partial,
+                       pl.num_wg, pl.seg_count, pl.tiles_per_head, pl.tiles_per_wg, pl.total_tiles, P.k, P.h, out,
+                       VL ? P.vl : nullptr);
     return snf::check_launch("reduce_partials_kernel");
+}
+
+// varlen launches: bf16 Q | V (what the packed pipeline produces), single key chunk
+template <int DK>
+int launch_nkb_varlen(const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {
+    using QT = unsigned short;
+    const bool aux = P.attn != nullptr || P.lse != nullptr;
+    if (pl.nkb == 7 && P.k > 192 && P.k <= 200 && !aux) return launch_variant<DK, 7, QT, false, false, 2, true>(P, pl, out, s);
+#define SNF_ATTN_VL_CASE(NB)                                                                                              \
+    case NB:                                                                                                              \
+        return aux ? launch_variant<DK, NB, QT, true, false, 8, true>(P, pl, out, s)                                      \
+                   : launch_variant<DK, NB, QT, false, false, 8, true>(P, pl, out, s);
+    switch (pl.nkb) {
+#ifndef SNF_ATTN_DEV
+        SNF_ATTN_VL_CASE(1)
+        SNF_ATTN_VL_CASE(2)
+        SNF_ATTN_VL_CASE(4)
+        SNF_ATTN_VL_CASE(6)
+        case 8:
+            if constexpr (DK == 64)
+                return aux ? launch_variant<DK, 8, QT, true, false, 8, true>(P, pl, out, s)
+                           : launch_variant<DK, 8, QT, false, false, 8, true>(P, pl, out, s);
+            break;
+#endif
+        SNF_ATTN_VL_CASE(7)
+        default: break;
+    }
+#undef SNF_ATTN_VL_CASE
+    snf::set_error("sparse_attn_mfma (varlen): key-block count %d not built", pl.nkb);
+    return SNF_EUNSUPPORTED;
+}
+
+// Geometry of a varlen launch: every bag keeps the plan of its own launch (make_plan), the grids are concatenated.
+// table (host memory, may be null to size it) = [bags][VL_DESC] descriptors, then the bag index of every workgroup.
+struct VarlenPlan {
+    int64_t total_wg, partial_slots;   // workgroups of the whole launch; partial tiles-slots (num_wg * seg_count summed)
+    int nkb;
+};
+inline bool make_varlen_plan(const int64_t* offsets, int bags, int k, int h, int dk, VarlenPlan* vp, int32_t* table,
+                             size_t table_ints) {
+    vp->total_wg = 0, vp->partial_slots = 0, vp->nkb = 0;
+    for (int b = 0; b < bags; ++b) {
+        const int64_t n = offsets[b + 1] - offsets[b];
+        Plan pl;
+        if (n < 1 || offsets[b] > 0x7fffffffll || !make_plan(n, k, h, dk, &pl)) return false;
+        if (table) {
+            if ((size_t)(VL_DESC * bags) + (size_t)(vp->total_wg + pl.num_wg) > table_ints) return false;
+            int32_t* d = table + (size_t)VL_DESC * b;
+            d[0] = (int32_t)vp->total_wg, d[1] = (int32_t)offsets[b], d[2] = (int32_t)n, d[3] = b * k;
+            d[4] = pl.tiles_per_head, d[5] = pl.tiles_per_wg, d[6] = pl.total_tiles, d[7] = pl.seg_count;
+            d[8] = (int32_t)vp->partial_slots, d[9] = pl.num_wg, d[10] = 0, d[11] = 0;
+            for (int i = 0; i < pl.num_wg; ++i) table[(size_t)VL_DESC * bags + vp->total_wg + i] = b;
+        }
+        vp->total_wg += pl.num_wg;
+        vp->partial_slots += (int64_t)pl.num_wg * pl.seg_count;
+        vp->nkb = pl.nkb;
+        if (vp->total_wg > 0x3fffffff || vp->partial_slots > 0x3fffffff) return false;
+    }
+    return bags >= 1;
 }
 
 #define SNF_ATTN_CASE(NB, EXT)                                                                     \
@@ -974,4 +1072,6 @@ int attn_launch_dk128(int qv_dtype, bool stats_pass, const snf_attn::AttnParams&
                       hipStream_t s);
 int attn_launch_dk64(int qv_dtype, bool stats_pass, const snf_attn::AttnParams& P, const snf_attn::Plan& pl, float* out,
                      hipStream_t s);
+int attn_launch_varlen_dk128(const snf_attn::AttnParams& P, const snf_attn::Plan& pl, float* out, hipStream_t s);
+int attn_launch_varlen_dk64(const snf_attn::AttnParams& P, const snf_attn::Plan& pl, float* out, hipStream_t s);
 }  // namespace snf

@@ -59,7 +59,15 @@ struct X3Params {
     int nchunks, chunk;
     float* partial;    // [num_wg * seg_count][tiles][4][64][4]
     int tiles_per_head, tiles_per_wg, total_tiles, seg_count;
+    int64_t n_stride;  // rows per head of attn / lse (= n; the packed row count of a varlen launch)
+    const int* vl;     // varlen launch: [bags][VL_DESC] descriptors, then the bag of every workgroup (see below)
+    int vl_bags;
 };
+// Varlen launch (many bags in one grid, single key chunk): the grid is the concatenation of the bags' own grids -- workgroup
+// wg0 + i does exactly what workgroup i of that bag's own launch does (same tiles, partial tiles and summation order), so the
+// packed launch is bit-identical to the per-bag launches it replaces.
+// descriptor: wg0, row0, n, out_row0 (first Kp / output row), tiles_per_head, tiles_per_wg, total_tiles, seg_count, part0, num_wg
+constexpr int VL_DESC = 12;
 
 constexpr int TROWS = 64;   // query rows per step (two 32-row blocks)
 constexpr int p_row_bytes(int nkb) { return 64 * (nkb | 1); }   // odd multiple of 64 B (bank rule of the transpose-read)
@@ -107,9 +115,25 @@ __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __
 // VGPRs at dk = 128) instead of re-reading them from a 112 KiB LDS image every tile.  The LDS that frees holds 64-ROW tiles with
 // separate Q, P and (double-buffered) V images, so a tile costs three workgroup barriers instead of four per 32 rows, the next
 // tile's rows are split and written while this tile's P is published, and their HBM loads have a whole tile of latency cover.
-template <int DK, int NKB, bool AUX, int MODE>
-__global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
+template <int DK, int NKB, bool AUX, int MODE, bool VL = false>
+__global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params PA) {
     constexpr int NKS = DK / 16;               // k-steps of GEMM1
+    X3Params P = PA;
+    int bid = blockIdx.x;
+    if constexpr (VL) {
+        const int* __restrict__ tb = PA.vl;
+        const int* __restrict__ dsc = tb + VL_DESC * tb[VL_DESC * PA.vl_bags + bid];
+        const int row0 = dsc[1];
+        bid -= dsc[0];
+        P.n = dsc[2];
+        P.q = PA.q + (int64_t)row0 * PA.ldq;
+        P.v = PA.v + (int64_t)row0 * PA.ldv;
+        P.kp = PA.kp + (int64_t)dsc[3] * PA.ldkp;
+        if (PA.attn) P.attn = PA.attn + (int64_t)row0 * PA.attn_ld;
+        if (PA.lse) P.lse = PA.lse + row0;
+        P.tiles_per_head = dsc[4], P.tiles_per_wg = dsc[5], P.total_tiles = dsc[6], P.seg_count = dsc[7];
+        P.partial = PA.partial + (int64_t)dsc[8] * (NKB * (DK / 32)) * 1024;
+    }
     constexpr int NCB = DK / 32;               // 32-wide column blocks of the output
     constexpr int TILES = NKB * NCB;
     constexpr int NT = (TILES + 7) / 8;        // output tiles owned by one wave
@@ -131,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
     const int n32 = (int)P.n;
     const float c_exp = P.scale * 1.44269504088896340736f;
 
-    const int f_begin = blockIdx.x * P.tiles_per_wg;
+    const int f_begin = bid * P.tiles_per_wg;
     int f_end = f_begin + P.tiles_per_wg;
     if (f_end > P.total_tiles) f_end = P.total_tiles;
     if (f_begin >= f_end) return;
@@ -235,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
     };
     auto flush = [&](int head) __attribute__((always_inline)) {
         const int seg = head - first_head;
-        float* dst = P.partial + ((int64_t)blockIdx.x * P.seg_count + seg) * (int64_t)TILES * 1024;
+        float* dst = P.partial + ((int64_t)bid * P.seg_count + seg) * (int64_t)TILES * 1024;
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
             const int t_idx = w + 8 * ti;
@@ -372,9 +396,9 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
                 }
                 const float fscale = rvalid ? __builtin_amdgcn_exp2f(mw[rb] - m) / l : 0.f;
                 if constexpr (AUX)
-                    if (P.lse && rvalid && hf == 0 && w == 0) P.lse[(int64_t)a * P.n + row] = (m + __log2f(l)) * 0.69314718055994530942f;
+                    if (P.lse && rvalid && hf == 0 && w == 0) P.lse[(int64_t)a * P.n_stride + row] = (m + __log2f(l)) * 0.69314718055994530942f;
                 float* arow = nullptr;
-                if constexpr (AUX) arow = P.attn ? P.attn + ((int64_t)a * P.n + row) * P.attn_ld + 32 * w + 4 * hf : nullptr;
+                if constexpr (AUX) arow = P.attn ? P.attn + ((int64_t)a * P.n_stride + row) * P.attn_ld + 32 * w + 4 * hf : nullptr;
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4) {
                     f32x4 p4 = {s[rb][4 * c4] * fscale, s[rb][4 * c4 + 1] * fscale, s[rb][4 * c4 + 2] * fscale, s[rb][4 * c4 + 3] * fscale};
@@ -439,8 +463,15 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params P) {
 // out[key, a*DK + col] = sum over the (workgroup, segment) partials of head a, ascending workgroup order
 template <int DK, int NKB>
 __global__ __launch_bounds__(64) void x3_reduce_kernel(const float* __restrict__ partial, int num_wg, int seg_count,
-                                                        int tiles_per_head, int tiles_per_wg, int k, int h, float* __restrict__ out) {
+                                                        int tiles_per_head, int tiles_per_wg, int k, int h, float* __restrict__ out,
+                                                        const int* __restrict__ vl = nullptr) {
     constexpr int NCB = DK / 32, TILES = NKB * NCB;
+    if (vl) {   // varlen: blockIdx.z = bag
+        const int* __restrict__ dsc = vl + VL_DESC * blockIdx.z;
+        tiles_per_head = dsc[4], tiles_per_wg = dsc[5], seg_count = dsc[7], num_wg = dsc[9];
+        partial += (int64_t)dsc[8] * TILES * 1024;
+        out += (int64_t)dsc[3] * (h * DK);
+    }
     const int a = blockIdx.y;
     const int unit = blockIdx.x;   // (tile, q4): one wave per workgroup, so that the 4 TILES h units spread over all CUs
     const int lane = threadIdx.x;
@@ -504,13 +535,13 @@ bool x3_plan(int64_t n, int k, int h, int dk, X3Plan* pl) {
 }
 size_t x3_workspace(const X3Plan& pl, int dk) { return (size_t)pl.num_wg * pl.seg_count * (size_t)(pl.nkb * (dk / 32)) * 1024 * sizeof(float); }
 
-template <int DK, int NKB, bool AUX, int MODE>
+template <int DK, int NKB, bool AUX, int MODE, bool VL = false>
 int x3_launch(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s) {
     constexpr int NKS = DK / 16;
     constexpr int q_bytes = (TROWS / 32) * NKS * 1024, p_bytes = TROWS * p_row_bytes(NKB), v_bytes = TROWS * 2 * DK;
     constexpr int lds = 2 * q_bytes + 2 * p_bytes + 4 * v_bytes + 8 * TROWS * 8;   // Q hi|lo, P hi|lo, V 2 x (hi|lo), statistics
     static thread_local bool attr_set = false;
-    auto kern = sparse_attn_x3_kernel<DK, NKB, AUX, MODE>;
+    auto kern = sparse_attn_x3_kernel<DK, NKB, AUX, MODE, VL>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             snf::set_error("sparse_attn_x3: cannot reserve %d bytes of LDS", lds);
@@ -523,9 +554,54 @@ int x3_launch(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s) {
     int rc = snf::check_launch("sparse_attn_x3_kernel");
     if (rc || MODE == 1) return rc;
     constexpr int TILES = NKB * (DK / 32);
-    hipLaunchKernelGGL((x3_reduce_kernel<DK, NKB>), dim3(TILES * 4, P.h), dim3(64), 0, s, P.partial, pl.num_wg, pl.seg_count,
-                       pl.tiles_per_head, pl.tiles_per_wg, P.k, P.h, out);
+    hipLaunchKernelGGL((x3_reduce_kernel<DK, NKB>), dim3(TILES * 4, P.h, VL ? P.vl_bags : 1), dim3(64), 0, s, P.partial, pl.num_wg,
+                       pl.seg_count, pl.tiles_per_head, pl.tiles_per_wg, P.k, P.h, out, VL ? P.vl : nullptr);
     return snf::check_launch("x3_reduce_kernel");
+}
+template <int DK>
+int x3_dispatch_varlen(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s) {
+    const bool aux = P.attn != nullptr || P.lse != nullptr;
+#define SNF_X3_VL_CASE(NB) \
+    case NB: return aux ? x3_launch<DK, NB, true, 0, true>(P, pl, out, s) : x3_launch<DK, NB, false, 0, true>(P, pl, out, s);
+    switch (pl.nkb) {
+        SNF_X3_VL_CASE(2)
+        SNF_X3_VL_CASE(4)
+        SNF_X3_VL_CASE(7)
+        case 8:
+            if constexpr (DK == 64)
+                return aux ? x3_launch<DK, 8, true, 0, true>(P, pl, out, s) : x3_launch<DK, 8, false, 0, true>(P, pl, out, s);
+            break;
+        default: break;
+    }
+#undef SNF_X3_VL_CASE
+    snf::set_error("sparse_attn_x3 (varlen): key-block count %d not built", pl.nkb);
+    return SNF_EUNSUPPORTED;
+}
+struct X3VarlenPlan {
+    int64_t total_wg, partial_slots;
+    int nkb;
+};
+bool x3_varlen_plan(const int64_t* offsets, int bags, int k, int h, int dk, X3VarlenPlan* vp, int32_t* table, size_t table_ints) {
+    vp->total_wg = 0, vp->partial_slots = 0, vp->nkb = 0;
+    if (bags < 1 || k > (dk == 128 ? 224 : 256)) return false;   // single key chunk only
+    for (int b = 0; b < bags; ++b) {
+        const int64_t n = offsets[b + 1] - offsets[b];
+        X3Plan pl;
+        if (n < 1 || offsets[b] > 0x7fffffffll || !x3_plan(n, k, h, dk, &pl)) return false;
+        if (table) {
+            if ((size_t)(VL_DESC * bags) + (size_t)(vp->total_wg + pl.num_wg) > table_ints) return false;
+            int32_t* d = table + (size_t)VL_DESC * b;
+            d[0] = (int32_t)vp->total_wg, d[1] = (int32_t)offsets[b], d[2] = (int32_t)n, d[3] = b * k;
+            d[4] = pl.tiles_per_head, d[5] = pl.tiles_per_wg, d[6] = pl.total_tiles, d[7] = pl.seg_count;
+            d[8] = (int32_t)vp->partial_slots, d[9] = pl.num_wg, d[10] = 0, d[11] = 0;
+            for (int i = 0; i < pl.num_wg; ++i) table[(size_t)VL_DESC * bags + vp->total_wg + i] = b;
+        }
+        vp->total_wg += pl.num_wg;
+        vp->partial_slots += (int64_t)pl.num_wg * pl.seg_count;
+        vp->nkb = pl.nkb;
+        if (vp->total_wg > 0x3fffffff || vp->partial_slots > 0x3fffffff) return false;
+    }
+    return true;
 }
 template <int DK, int NB>
 int x3_modes(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s, int mode) {
@@ -605,6 +681,7 @@ int snf_sparse_attn_fwd_x3(const float* q, int64_t ldq, const float* v, int64_t 
     P.nchunks = ch.count, P.chunk = 0;
     P.tiles_per_head = pl.tiles_per_head, P.tiles_per_wg = pl.tiles_per_wg, P.total_tiles = pl.total_tiles;
     P.seg_count = pl.seg_count;
+    P.n_stride = n, P.vl = nullptr, P.vl_bags = 0;
     hipStream_t s = snf::as_stream(stream);
     if (ch.count == 1) return dk == 128 ? x3_dispatch<128>(P, pl, out, s, 0) : x3_dispatch<64>(P, pl, out, s, 0);
     // key chunks: statistics of every chunk first, then the chunks' main passes with the softmax exact over all keys
@@ -621,6 +698,62 @@ int snf_sparse_attn_fwd_x3(const float* q, int64_t ldq, const float* v, int64_t 
             if (rc) return rc;
         }
     return SNF_OK;
+}
+
+// ---- varlen (see snf_sparse_attn_varlen_plan in sparse_attn_mfma.hip for the protocol; this is the fp32-class kernel's plan) ----
+int snf_sparse_attn_x3_varlen_plan(const int64_t* offsets, int bags, int k, int h, int dk, int32_t* table, size_t table_ints,
+                                   size_t* table_ints_needed, size_t* workspace_bytes) {
+    SNF_REQUIRE(offsets && bags >= 1 && k >= 1 && h >= 1, "snf_sparse_attn_x3_varlen_plan: bad arguments");
+    X3VarlenPlan vp;
+    if (!x3_varlen_plan(offsets, bags, k, h, dk, &vp, nullptr, 0)) {
+        snf::set_error("snf_sparse_attn_x3_varlen_plan: unsupported shape (bags=%d k=%d dk=%d: dk in {64, 128}, k <= %d, non-empty "
+                       "bags)", bags, k, dk, dk == 128 ? 224 : 256);
+        return SNF_EUNSUPPORTED;
+    }
+    const size_t need = (size_t)VL_DESC * bags + (size_t)vp.total_wg;
+    if (table_ints_needed) *table_ints_needed = need;
+    if (workspace_bytes) *workspace_bytes = (size_t)vp.partial_slots * (size_t)(vp.nkb * (dk / 32)) * 1024 * sizeof(float);
+    if (table) {
+        SNF_REQUIRE(table_ints >= need, "snf_sparse_attn_x3_varlen_plan: table %zu < %zu ints", table_ints, need);
+        x3_varlen_plan(offsets, bags, k, h, dk, &vp, table, table_ints);
+    }
+    return SNF_OK;
+}
+
+// q, v [T, ld] f32 packed rows, kp [bags * k, h * dk] f32, out [bags * k, h * dk], attn [h, T, k] / lse [h, T] or null
+int snf_sparse_attn_fwd_x3_varlen(const float* q, int64_t ldq, const float* v, int64_t ldv, const float* kp, const int64_t* offsets,
+                                  int bags, int k, int h, int dk, float scale, float* out, float* attn, float* lse,
+                                  const int32_t* table_dev, void* workspace, size_t workspace_bytes, snf_stream_t stream) {
+    SNF_REQUIRE(q && v && kp && out && offsets && table_dev, "snf_sparse_attn_fwd_x3_varlen: null pointer");
+    X3VarlenPlan vp;
+    if (!x3_varlen_plan(offsets, bags, k, h, dk, &vp, nullptr, 0)) {
+        snf::set_error("snf_sparse_attn_fwd_x3_varlen: unsupported shape (bags=%d k=%d dk=%d)", bags, k, dk);
+        return SNF_EUNSUPPORTED;
+    }
+    const int64_t d = (int64_t)h * dk, total = offsets[bags];
+    SNF_REQUIRE(ldq >= d && ldv >= d && (ldq % 4) == 0 && (ldv % 4) == 0, "snf_sparse_attn_fwd_x3_varlen: ldq=%lld / ldv=%lld must be "
+                ">= h*dk and keep rows 16-byte aligned", (long long)ldq, (long long)ldv);
+    SNF_REQUIRE(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(kp)) & 15) == 0,
+                "snf_sparse_attn_fwd_x3_varlen: q / v / kp must be 16-byte aligned");
+    const size_t need = (size_t)vp.partial_slots * (size_t)(vp.nkb * (dk / 32)) * 1024 * sizeof(float);
+    if (!workspace || workspace_bytes < need) {
+        snf::set_error("snf_sparse_attn_fwd_x3_varlen: workspace %zu < %zu", workspace_bytes, need);
+        return SNF_EWORKSPACE;
+    }
+    X3Params P;
+    P.q = q, P.v = v, P.kp = kp;
+    P.n = total, P.ldq = ldq, P.ldv = ldv, P.ldkp = d;
+    P.k = k, P.h = h, P.scale = scale;
+    P.attn = attn, P.attn_ld = k, P.lse = lse;
+    P.partial = reinterpret_cast<float*>(workspace);
+    P.stats = nullptr, P.nchunks = 1, P.chunk = 0;
+    P.tiles_per_head = P.tiles_per_wg = P.total_tiles = P.seg_count = 0;   // per bag, from the table
+    P.n_stride = total, P.vl = table_dev, P.vl_bags = bags;
+    X3Plan pl;
+    pl.num_wg = (int)vp.total_wg, pl.nkb = vp.nkb;
+    pl.tiles_per_head = pl.tiles_per_wg = pl.total_tiles = pl.seg_count = 0;
+    hipStream_t s = snf::as_stream(stream);
+    return dk == 128 ? x3_dispatch_varlen<128>(P, pl, out, s) : x3_dispatch_varlen<64>(P, pl, out, s);
 }
 
 }  // extern "C"

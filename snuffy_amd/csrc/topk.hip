@@ -312,6 +312,17 @@ __global__ __launch_bounds__(1024) void topk_radix_kernel(const float* __restric
     topk_radix_body<IPT>(scores, n, stride, k, idx_out, L);
 }
 
+// many bags, one launch: workgroup b runs the one-workgroup form on scores[offsets[b] .. offsets[b + 1]) and writes the bag's k
+// indices (relative to the bag's first row) to idx_out[b * k ..] -- the same kernel body as a per-bag launch, same results
+template <int IPT>
+__global__ __launch_bounds__(1024) void topk_radix_segmented_kernel(const float* __restrict__ scores,
+                                                                    const int64_t* __restrict__ offsets, int k,
+                                                                    int64_t* __restrict__ idx_out) {
+    __shared__ TopkLds<(IPT > 0) ? 4 * 2048 : 2048> L;
+    const int64_t lo = offsets[blockIdx.x], hi = offsets[blockIdx.x + 1];
+    topk_radix_body<IPT>(scores + lo, hi - lo, 1, k, idx_out + (int64_t)blockIdx.x * k, L);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Fused selector (form 2)
 // ---------------------------------------------------------------------------------------------------------------
@@ -579,6 +590,29 @@ int snf_topk_f32(const float* scores, int64_t n, int64_t stride, int k, int64_t*
     else
         hipLaunchKernelGGL(topk_radix_kernel<0>, dim3(1), dim3(1024), 0, s, scores, n, stride, k, idx_out);
     return snf::check_launch("topk_radix_kernel");
+}
+
+// top-k of every bag of a packed score vector in ONE launch (varlen path).  offsets [bags + 1] int64 in DEVICE memory, max_n =
+// the longest bag (picks the register budget), every bag needs at least k scores.  idx_out [bags, k]: indices inside the bag.
+int snf_topk_segmented_f32(const float* scores, const int64_t* offsets_dev, int bags, int64_t max_n, int k, int64_t* idx_out,
+                           snf_stream_t stream) {
+    SNF_REQUIRE(scores && offsets_dev && idx_out, "snf_topk_segmented_f32: null pointer");
+    SNF_REQUIRE(bags >= 1 && max_n >= 1 && max_n < 0x3fffffffll, "snf_topk_segmented_f32: bad bags=%d max_n=%lld", bags,
+                (long long)max_n);
+    SNF_REQUIRE(k >= 1 && k <= max_n && k <= RS_MAXK, "snf_topk_segmented_f32: need 1 <= k <= min(max_n, %d) (k=%d)", RS_MAXK, k);
+    hipStream_t s = snf::as_stream(stream);
+    const dim3 grid((unsigned)bags), wg(1024);
+    if (max_n <= 1024 * 8)
+        hipLaunchKernelGGL(topk_radix_segmented_kernel<8>, grid, wg, 0, s, scores, offsets_dev, k, idx_out);
+    else if (max_n <= 1024 * 16)
+        hipLaunchKernelGGL(topk_radix_segmented_kernel<16>, grid, wg, 0, s, scores, offsets_dev, k, idx_out);
+    else if (max_n <= 1024 * 32)
+        hipLaunchKernelGGL(topk_radix_segmented_kernel<32>, grid, wg, 0, s, scores, offsets_dev, k, idx_out);
+    else if (max_n <= 1024 * 64)
+        hipLaunchKernelGGL(topk_radix_segmented_kernel<64>, grid, wg, 0, s, scores, offsets_dev, k, idx_out);
+    else
+        hipLaunchKernelGGL(topk_radix_segmented_kernel<0>, grid, wg, 0, s, scores, offsets_dev, k, idx_out);
+    return snf::check_launch("topk_radix_segmented_kernel");
 }
 
 int snf_topk_gather_f32(const float* scores, int64_t n, int64_t stride, int k, int64_t* idx_out, const float* x, int d,

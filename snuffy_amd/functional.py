@@ -230,8 +230,13 @@ def materialize(parts):
     return z
 
 
-def head(parts, norm, linear):
-    """logits = Linear(mean_n LayerNorm(z))  (snuffy.py:86,71), residual assembly fused into the read."""
+def head(parts, norm, linear, packed=None):
+    """logits = Linear(mean_n LayerNorm(z))  (snuffy.py:86,71), residual assembly fused into the read.  packed (ops.PackedBags):
+    the rows are B packed bags -> logits [B, C], one mean per bag."""
+    if packed is not None:
+        logits, _ = ops.ln_mean_head_varlen(parts.base, packed, norm.weight, norm.bias, norm.eps, linear.weight, linear.bias,
+                                            parts.add_bf16, parts.add_bias, parts.slot, parts.delta)
+        return logits
     if torch.is_grad_enabled() and (parts.base.requires_grad or norm.weight.requires_grad or linear.weight.requires_grad):
         from . import autograd as SA
         return SA.head_train(materialize(parts), norm, linear)
@@ -333,15 +338,22 @@ def invalidate_folded(layer):
     layer._xhat_offer = None
 
 
-def encoder_layer(x2, sel, layer, need_attn, precision):
-    """EncoderLayer.forward (snuffy.py:126-157) for x2 [N, D] and selected rows sel [K].  Returns (Parts, A)."""
-    if torch.is_grad_enabled() and (x2.requires_grad or any(p.requires_grad for p in layer.parameters())):
+def encoder_layer(x2, sel, layer, need_attn, precision, packed=None):
+    """EncoderLayer.forward (snuffy.py:126-157) for x2 [N, D] and selected rows sel [K].  Returns (Parts, A).
+
+    packed (ops.PackedBags, inference only): x2 holds the rows of B bags and sel the B x K selected rows in packed coordinates
+    (bag b's K rows at sel[b K : (b + 1) K]).  Everything row-wise runs once over the packed rows; only the attention changes
+    kernel entry (one varlen launch: every bag attends to its own K keys).  A is then [1, h, T, K] over the packed rows."""
+    if packed is None and torch.is_grad_enabled() and (x2.requires_grad or any(p.requires_grad for p in layer.parameters())):
         from . import autograd as SA  # training path (custom backward kernels); also when only the input asks for a gradient
         return SA.encoder_layer_train(x2, sel, layer, need_attn, precision)
     n, d = x2.shape
     mha, ff = layer.self_attn, layer.feed_forward
     h = mha.h
     k = sel.shape[0]
+    kb = k // packed.bags if packed is not None else k            # keys of ONE bag
+    if packed is not None and (kb < 1 or not ops.varlen_attn_supported(precision, kb, d // h)):
+        raise SnuffyHipError("packed bags: %d keys per bag at head width %d is outside the varlen attention kernels" % (kb, d // h))
     n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
     lq, lk, lv, lo = mha.linears
     if k == 0:
@@ -375,7 +387,9 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
             qv = ops.gemm_x3(xn3, fw["wqv"], fw["bqv"], out_dtype=torch.float32)
         del xn3
         q, v = qv[:, :d], qv[:, d:]
-        if FP32_ATTENTION == "x3" and ops.x3_attn_supported(k, d // h):
+        if packed is not None:
+            o, attn, _ = ops.sparse_attn_fwd_x3_varlen(q, v, kp, packed, kb, h, need_attn=need_attn)
+        elif FP32_ATTENTION == "x3" and ops.x3_attn_supported(k, d // h):
             o, attn, _ = ops.sparse_attn_fwd_x3(q, v, kp, h, need_attn=need_attn)    # snuffy.py:160-168
         else:
             o, attn, _ = ops.sparse_attn_fwd(q.contiguous(), kp, v.contiguous(), h, need_attn=need_attn)
@@ -403,7 +417,9 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
         xn = ops.layernorm_rows(x2, n0.weight, n0.bias, n0.eps)                     # snuffy.py:107
         q = F.linear(xn, lq.weight, lq.bias)
         v = F.linear(xn, lv.weight, lv.bias)
-        if FP32_ATTENTION == "x3" and ops.x3_attn_supported(k, d // h):
+        if packed is not None:
+            o, attn, _ = ops.sparse_attn_fwd_x3_varlen(q, v, kp, packed, kb, h, need_attn=need_attn)
+        elif FP32_ATTENTION == "x3" and ops.x3_attn_supported(k, d // h):
             o, attn, _ = ops.sparse_attn_fwd_x3(q, v, kp, h, need_attn=need_attn)    # snuffy.py:160-168, fp32-class on MFMA
         else:
             o, attn, _ = ops.sparse_attn_fwd(q, kp, v, h, need_attn=need_attn)       # exact fp32 on the vector ALUs
@@ -430,12 +446,15 @@ def encoder_layer(x2, sel, layer, need_attn, precision):
         ops.layernorm_rows(x2, None, None, n0.eps, out=xhat)
     qv = ops.linear_bf16(xhat, fw["wqv"], fw["bqv_f"], fw["bqv"])                   # [N, 2D] bf16 = [Q | V], bias epilogue
     q, v = qv[:, :d], qv[:, d:]                                                     # row-strided views, used in place
-    if ops.mfma_attn_supported(k, d // h, n, qv.stride(0)):
+    if packed is not None or ops.mfma_attn_supported(k, d // h, n, qv.stride(0)):
         # keys = RAW selected rows: the gather also leaves them in bf16, the projection runs like Q | V (bf16 operands,
         # fp32 accumulate, bf16 out) and the attention kernel reads Kp as it is
         xs, slot, xs16 = ops.gather_slot_map(x2, sel, bf16_copy=True)               # snuffy.py:131,145-147 (+ row -> slot map)
         kp = torch.addmm(fw["bk"], xs16, fw["wk"].t())
-        o, attn, _ = ops.sparse_attn_fwd_mfma(q, v, kp, n, h, need_attn=need_attn)
+        if packed is not None:
+            o, attn, _ = ops.sparse_attn_fwd_mfma_varlen(q, v, kp, packed, kb, h, need_attn=need_attn)
+        else:
+            o, attn, _ = ops.sparse_attn_fwd_mfma(q, v, kp, n, h, need_attn=need_attn)
     else:
         xs, slot = ops.gather_slot_map(x2, sel)
         kp = F.linear(xs, lk.weight, lk.bias)

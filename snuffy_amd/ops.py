@@ -613,6 +613,153 @@ def sparse_attn_fwd_x3(q, v, kp, h, scale=None, need_attn=False, need_lse=False)
     return out, attn, lse
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# varlen path: many bags per launch (include/snuffy_hip.h "Varlen path")
+# ----------------------------------------------------------------------------------------------------------------------
+class PackedBags:
+    """Row offsets of B bags packed into one [T, .] tensor, on the host (launch geometry) and on the device (segmented top-k),
+    plus the launch plans derived from them (built on the host once per kernel shape, uploaded once)."""
+
+    def __init__(self, sizes, device):
+        import numpy as np
+        sizes = [int(n) for n in sizes]
+        if not sizes or min(sizes) < 1:
+            raise ValueError("PackedBags: need at least one bag and no empty bag, got sizes %s" % (sizes,))
+        self.sizes = sizes
+        self.bags = len(sizes)
+        self.max_n = max(sizes)
+        self.host = np.zeros(self.bags + 1, dtype=np.int64)
+        np.cumsum(sizes, out=self.host[1:])
+        self.total = int(self.host[-1])
+        self.device = torch.device(device)
+        self.dev = torch.from_numpy(self.host).to(self.device)
+        self._plans = {}
+
+    def _host_ptr(self):
+        return ctypes.c_void_p(self.host.ctypes.data)
+
+    def plan(self, kind, *shape):
+        """(device table int32, workspace bytes) of a segmented launch: kind in {"mfma", "x3", "head"}."""
+        import numpy as np
+        key = (kind,) + tuple(shape)
+        hit = self._plans.get(key)
+        if hit is not None:
+            return hit
+        lib = _ffi.load()
+        need, wsb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        fn = {"mfma": lib.snf_sparse_attn_varlen_plan, "x3": lib.snf_sparse_attn_x3_varlen_plan,
+              "head": lib.snf_ln_mean_head_varlen_plan}[kind]
+        check(fn(self._host_ptr(), self.bags, *shape, None, 0, ctypes.byref(need), ctypes.byref(wsb)), "varlen plan (%s)" % kind)
+        table = np.zeros(need.value, dtype=np.int32)
+        check(fn(self._host_ptr(), self.bags, *shape, ctypes.c_void_p(table.ctypes.data), table.size, ctypes.byref(need),
+                 ctypes.byref(wsb)), "varlen plan (%s)" % kind)
+        hit = self._plans[key] = (torch.from_numpy(table).to(self.device), int(wsb.value))
+        return hit
+
+
+def varlen_attn_supported(precision_kind, k, dk):
+    """Single key chunk only: k <= 224 (dk = 128) / 256 (dk = 64); the fp32-class kernel is built for 2, 4, 7 (8) key blocks."""
+    return (dk == 128 and 1 <= k <= 224) or (dk == 64 and 1 <= k <= 256)
+
+
+def topk_segmented(scores, packed, k):
+    """Top-k of every bag of a packed score vector in one launch: [B, k] int64 indices INSIDE each bag (descending score, ties
+    by ascending index -- the same one-workgroup kernel body as topk(), one workgroup per bag)."""
+    scores = _req(scores, torch.float32, "scores", 1)
+    k = int(k)
+    if scores.shape[0] != packed.total or not (1 <= k <= min(packed.sizes)) or k > TOPK_MAX_K:
+        raise ValueError("topk_segmented: %d scores for %d packed rows, k=%d, shortest bag %d"
+                         % (scores.shape[0], packed.total, k, min(packed.sizes)))
+    idx = torch.empty(packed.bags, k, dtype=torch.int64, device=scores.device)
+    check(_ffi.load().snf_topk_segmented_f32(_p(scores), _p(packed.dev), packed.bags, packed.max_n, k, _p(idx), _stream()),
+          "snf_topk_segmented_f32")
+    return idx
+
+
+def sparse_attn_fwd_mfma_varlen(q, v, kp, packed, k, h, scale=None, need_attn=False, need_lse=False):
+    """bf16-MFMA sparse attention of B packed bags in one launch.  q, v [T, d] bf16 (row-strided views allowed), kp [B * k, d]
+    (bag b's keys in rows b k ..) -> (out [B * k, d] f32, attn [h, T, k] or None, lse [h, T] or None); bit-identical to
+    sparse_attn_fwd_mfma() bag by bag."""
+    if q.dtype != torch.bfloat16 or v.dtype != torch.bfloat16:
+        raise TypeError("sparse_attn_fwd_mfma_varlen: q and v must be bfloat16")
+    q = _rows16(q, "q")
+    v = _rows16(v, "v")
+    if kp.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("sparse_attn_fwd_mfma_varlen: kp must be float32 or bfloat16")
+    kp = _req(kp, kp.dtype, "kp", 2)
+    t, d = q.shape
+    if t != packed.total or v.shape != q.shape or kp.shape != (packed.bags * k, d) or d % h:
+        raise ValueError("sparse_attn_fwd_mfma_varlen: q %s v %s kp %s do not match %d packed rows, %d bags x %d keys"
+                         % (tuple(q.shape), tuple(v.shape), tuple(kp.shape), packed.total, packed.bags, k))
+    dk = d // h
+    scale = 1.0 / math.sqrt(dk) if scale is None else scale
+    table, wsb = packed.plan("mfma", k, h, dk)
+    ws = _ws(wsb, q.device)
+    out = torch.empty(packed.bags * k, d, dtype=torch.float32, device=q.device)
+    attn = torch.empty(h, t, k, dtype=torch.float32, device=q.device) if need_attn else None
+    lse = torch.empty(h, t, dtype=torch.float32, device=q.device) if need_lse else None
+    kdt = DT_F32 if kp.dtype == torch.float32 else DT_BF16
+    check(_ffi.load().snf_sparse_attn_fwd_mfma_varlen(_p(q), q.stride(0), _p(v), v.stride(0), _p(kp), kdt, packed._host_ptr(),
+                                                      packed.bags, k, h, dk, float(scale), _p(out), _p(attn), _p(lse), _p(table),
+                                                      _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_mfma_varlen")
+    return out, attn, lse
+
+
+def sparse_attn_fwd_x3_varlen(q, v, kp, packed, k, h, scale=None, need_attn=False, need_lse=False):
+    """fp32-class sparse attention of B packed bags in one launch (f32 q, v [T, d], kp [B * k, d]); bit-identical to
+    sparse_attn_fwd_x3() bag by bag."""
+    if q.dtype != torch.float32 or v.dtype != torch.float32:
+        raise TypeError("sparse_attn_fwd_x3_varlen: q and v must be float32")
+    q = _rows16(q, "q")
+    v = _rows16(v, "v")
+    kp = _req(kp, torch.float32, "kp", 2)
+    t, d = q.shape
+    if t != packed.total or v.shape != q.shape or kp.shape != (packed.bags * k, d) or d % h:
+        raise ValueError("sparse_attn_fwd_x3_varlen: q %s v %s kp %s do not match %d packed rows, %d bags x %d keys"
+                         % (tuple(q.shape), tuple(v.shape), tuple(kp.shape), packed.total, packed.bags, k))
+    dk = d // h
+    scale = 1.0 / math.sqrt(dk) if scale is None else scale
+    table, wsb = packed.plan("x3", k, h, dk)
+    ws = _ws(wsb, q.device)
+    out = torch.empty(packed.bags * k, d, dtype=torch.float32, device=q.device)
+    attn = torch.empty(h, t, k, dtype=torch.float32, device=q.device) if need_attn else None
+    lse = torch.empty(h, t, dtype=torch.float32, device=q.device) if need_lse else None
+    check(_ffi.load().snf_sparse_attn_fwd_x3_varlen(_p(q), q.stride(0), _p(v), v.stride(0), _p(kp), packed._host_ptr(), packed.bags,
+                                                    k, h, dk, float(scale), _p(out), _p(attn), _p(lse), _p(table), _p(ws), wsb,
+                                                    _stream()), "snf_sparse_attn_fwd_x3_varlen")
+    return out, attn, lse
+
+
+def ln_mean_head_varlen(z, packed, gamma, beta, eps, w_head, b_head, add_bf16=None, add_bias=None, slot=None, delta_rows=None):
+    """ln_mean_head() of every packed bag in three launches: (logits [B, C], pooled [B, D]); bit-identical bag by bag."""
+    z = _req(z, torch.float32, "z", 2)
+    t, d = z.shape
+    if t != packed.total:
+        raise ValueError("ln_mean_head_varlen: %d rows for %d packed rows" % (t, packed.total))
+    if add_bf16 is not None:
+        add_bf16 = _req(add_bf16, torch.bfloat16, "add_bf16", 2)
+    if add_bias is not None:
+        add_bias = _req(add_bias, torch.float32, "add_bias", 1)
+    if slot is not None:
+        slot = _req(slot, torch.int32, "slot", 1)
+        delta_rows = _req(delta_rows, torch.float32, "delta_rows", 2)
+    gamma = _req(gamma, torch.float32, "gamma", 1)
+    beta = _req(beta, torch.float32, "beta", 1)
+    w_head = _req(w_head, torch.float32, "w_head", 2)
+    if b_head is not None:
+        b_head = _req(b_head, torch.float32, "b_head", 1)
+    c = w_head.shape[0]
+    table, wsb = packed.plan("head", d)
+    ws = _ws(wsb, z.device)
+    logits = torch.empty(packed.bags, c, dtype=torch.float32, device=z.device)
+    pooled = torch.empty(packed.bags, d, dtype=torch.float32, device=z.device)
+    check(_ffi.load().snf_ln_mean_head_varlen_f32(_p(z), packed._host_ptr(), packed.bags, d, _p(add_bf16), _p(add_bias), _p(slot),
+                                                  _p(delta_rows), None, _p(gamma), _p(beta), float(eps), _p(w_head), _p(b_head), c,
+                                                  _p(logits), _p(pooled), _p(table), _p(ws), wsb, _stream()),
+          "snf_ln_mean_head_varlen_f32")
+    return logits, pooled
+
+
 def dropout_mask(h, n, k, p, seed, offset, device):
     """The attention kernels' dropout mask as a tensor [h, n, k] f32 (0 or 1 / (1 - p)) -- see snf_dropout_mask_f32."""
     m = torch.empty(h, n, k, dtype=torch.float32, device=device)

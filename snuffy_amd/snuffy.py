@@ -374,6 +374,113 @@ class MILNet(nn.Module):
         # the graphs share one pool: the outputs are only valid until the next replay, so hand out copies
         return tuple(o.clone() if isinstance(o, torch.Tensor) else o for o in out)
 
+    # ---- many bags per launch (varlen path) ---------------------------------------------------------------------------
+    def _packable(self, bags):
+        """The packed path covers inference of the binary model with a plain FCLayer critic on bags long enough for a uniform
+        selection size (every bag at least Lambda patches) and short enough for the one-workgroup selector."""
+        cfg = self.b_classifier.cfg
+        layers = list(self.b_classifier.encoder.layers)
+        if (len(bags) < 2 or self.training or torch.is_grad_enabled() or type(self.i_classifier) is not FCLayer or not layers
+                or not all(type(l) is EncoderLayer for l in layers) or cfg.precision not in ("fp32", "bf16")):
+            return False
+        if self.i_classifier.fc[0].weight.shape[0] != 1:
+            return False
+        if cfg.precision == "fp32" and SF.FP32_ATTENTION != "x3":
+            return False
+        x0 = bags[0]
+        for x in bags:
+            if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.device == x0.device
+                    and ((x.dim() == 3 and x.shape[0] == 1) or x.dim() == 2) and x.shape[-1] == x0.shape[-1]):
+                return False
+        d = x0.shape[-1]
+        h = layers[0].self_attn.h
+        nmin = min(x.shape[-2] for x in bags)
+        nmax = max(x.shape[-2] for x in bags)
+        if nmax > 65536 or d % h or d % 4:
+            return False
+        kb = None
+        for l in layers:
+            k1 = math.ceil(l.big_lambda * l.top_big_lambda_share)
+            k2 = int(l.big_lambda * l.random_patch_share)
+            if k1 < 1 or nmin < k1 + k2 or (kb is not None and (k1, k2) != kb) or l.self_attn.h != h:
+                return False
+            kb = (k1, k2)
+        if sum(kb) * len(bags) > (1 << 20):
+            return False
+        n0, n1 = layers[0].sublayer[0].norm, layers[0].sublayer[1].norm
+        if cfg.precision == "bf16" and any(l.sublayer[0].norm.eps != l.sublayer[1].norm.eps for l in layers):
+            return False
+        return SF.ops.varlen_attn_supported(cfg.precision, sum(kb), d // h)
+
+    def forward_bags(self, bags):
+        """``[self(x) for x in bags]`` with the bags' rows packed into ONE set of launches (bags of <= 8 k patches
+        are launch-latency bound -- ~25 launches per bag whatever its size).  bags: sequence of [1, N_b, D] (or [N_b, D]) fp32 GPU
+        tensors.  Returns the list of (classes [1, N_b, 1], prediction_bag [1, C], A [1, h, N_b, K] or None) tuples the per-bag
+        forwards return: same selections (bit-exact, random share included: the numpy draws are made bag by bag in the order the
+        per-bag forwards make them), the segmented kernels bit-identical to their per-bag forms; the projections run over the
+        packed rows, so a library / tile choice that depends on the row count can move logits by fp32 / bf16 rounding.
+        Falls back to the per-bag loop when the bags cannot be packed (training, multiclass critic, a bag shorter than Lambda, ...)."""
+        bags = list(bags)
+        if not self._packable(bags):
+            return [self(x) for x in bags]
+        packed = SF.ops.PackedBags([x.shape[-2] for x in bags], bags[0].device)
+        x_cat = torch.cat([x.reshape(-1, x.shape[-1]) for x in bags])
+        return self.forward_packed(x_cat, packed)
+
+    def forward_packed(self, x_cat, packed):
+        """forward_bags() on rows that are already packed: x_cat [T, D] fp32, packed = ops.PackedBags(sizes, device) (keep it
+        between calls with the same bag sizes: it caches the launch plans)."""
+        enc = self.b_classifier.encoder
+        cfg = self.b_classifier.cfg
+        layers = list(enc.layers)
+        lin = self.i_classifier.fc[0]
+        x_cat = SF.as_2d(x_cat)
+        for layer in layers[:1]:
+            layer._xhat_offer = None
+        if cfg.precision == "bf16":
+            eps = layers[0].sublayer[0].norm.eps
+            s, xhat = SF.ops.critic_ln(x_cat, lin.weight, lin.bias, eps)            # same kernel as the per-bag critic pass
+            layers[0]._xhat_offer = (x_cat.data_ptr(), tuple(x_cat.shape), x_cat._version, float(eps), xhat)
+        else:
+            s = SF.ops.critic(x_cat, lin.weight, lin.bias)
+        c1 = s.reshape(-1)
+        l0 = layers[0]
+        k1 = math.ceil(l0.big_lambda * l0.top_big_lambda_share)
+        k2 = int(l0.big_lambda * l0.random_patch_share)
+        top = SF.ops.topk_segmented(c1, packed, k1)                                   # [B, k1] inside each bag
+        first = packed.dev[:-1].unsqueeze(1)
+        rnd = None
+        if k2 > 0:
+            # the reference's draws (snuffy.py:134-143), in the order the per-bag forwards consume the global numpy stream:
+            # bag by bag, and inside a bag layer by layer (every layer draws from the complement of the same `top`)
+            top_h = top.cpu().numpy()
+            draws = np.empty((len(layers), packed.bags, k2), dtype=np.int64)
+            for b, n in enumerate(packed.sizes):
+                mask = np.ones(n, dtype=bool)
+                mask[top_h[b]] = False
+                remaining = np.nonzero(mask)[0]
+                for li in range(len(layers)):
+                    draws[li, b] = np.random.choice(remaining, k2, replace=False)
+            rnd = torch.from_numpy(draws).to(top.device)                             # [layers, B, k2]
+        parts = attn = None
+        x2 = x_cat
+        for li, layer in enumerate(layers):
+            if parts is not None:
+                x2 = SF.materialize(parts)
+            sel_local = top if rnd is None else torch.cat((top, rnd[li]), dim=1)     # [B, K]: top ++ random, as snuffy.py:145
+            layer.last_selection = None
+            layer.last_selection_bags = (top, None if rnd is None else rnd[li])
+            sel = (sel_local + first).reshape(-1)
+            parts, attn = SF.encoder_layer(x2, sel, layer, (li == len(layers) - 1) and cfg.return_attention, cfg.precision,
+                                           packed=packed)
+        logits = SF.head(parts, enc.norm, self.b_classifier.linear, packed=packed)   # [B, C]
+        out = []
+        for b, n in enumerate(packed.sizes):
+            lo = int(packed.host[b])
+            a_b = attn[:, :, lo:lo + n, :] if attn is not None else None
+            out.append((s[lo:lo + n].view(1, n, -1), logits[b].view(1, -1), a_b))
+        return out
+
     def _critic(self, x):
         """i_classifier(x); in the bf16 inference path of a plain FCLayer critic the same pass over the bag also produces
         the normalised input of the first encoder layer (snf_critic_ln_f32) -- identical values, one HBM read less."""

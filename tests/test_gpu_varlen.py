@@ -1,0 +1,211 @@
+"""Varlen path: many bags per launch.  The segmented kernels against their per-bag forms (bit-identical: every
+segmented launch is the concatenation of the bags' own grids), MILNet.forward_bags against the per-bag forwards (same selections,
+same draws of the random share) and against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import snuffy_oracle as orc
+from tests.helpers import build_amd_milnet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+SIZES = [300, 1000, 129, 5000, 2048, 777]
+
+
+def _packed(sizes):
+    from snuffy_amd import ops
+    return ops.PackedBags(sizes, DEV)
+
+
+def test_topk_segmented_matches_per_bag_selection():
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for sizes, k in ((SIZES, 100), ([200, 9000, 20000, 40000, 201], 200), ([64, 64], 64), ([70000, 3000], 150)):
+        pk = _packed(sizes)
+        s = torch.randn(pk.total, generator=g)
+        s[::7] = s[3]                      # ties: the stable rule (ascending index) must hold inside every bag
+        s[5] = float("inf")
+        s[pk.total - 1] = float("-inf")
+        s = s.to(DEV)
+        got = ops.topk_segmented(s, pk, k)
+        for b, n in enumerate(sizes):
+            lo = int(pk.host[b])
+            ref = ops.topk(s[lo:lo + n].clone(), k)
+            assert torch.equal(got[b], ref), (sizes, b)
+            c = s[lo:lo + n].cpu().numpy()
+            order = np.lexsort((np.arange(n), -c))[:k]          # descending score, ascending index
+            assert np.array_equal(got[b].cpu().numpy(), order)
+
+
+@pytest.mark.parametrize("d,h,k", [(768, 6, 200), (768, 6, 224), (384, 6, 200), (384, 6, 37), (256, 2, 64)])
+@pytest.mark.parametrize("need_attn", [False, True])
+def test_attention_bf16_varlen_bit_identical_to_per_bag(d, h, k, need_attn):
+    from snuffy_amd import ops
+    sizes = [n for n in SIZES if n >= k] + [k]
+    pk = _packed(sizes)
+    g = torch.Generator().manual_seed(1)
+    qv = torch.randn(pk.total, 2 * d, generator=g).to(DEV).to(torch.bfloat16)
+    kp = (torch.randn(pk.bags * k, d, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
+    q, v = qv[:, :d], qv[:, d:]
+    out, attn, lse = ops.sparse_attn_fwd_mfma_varlen(q, v, kp, pk, k, h, need_attn=need_attn, need_lse=need_attn)
+    assert out.shape == (pk.bags * k, d)
+    for b, n in enumerate(sizes):
+        lo = int(pk.host[b])
+        qb = qv[lo:lo + n]
+        o1, a1, l1 = ops.sparse_attn_fwd_mfma(qb[:, :d], qb[:, d:], kp[b * k:(b + 1) * k], n, h, need_attn=need_attn,
+                                              need_lse=need_attn)
+        assert torch.equal(out[b * k:(b + 1) * k], o1), (b, n)
+        if need_attn:
+            assert torch.equal(attn[:, lo:lo + n], a1)
+            assert torch.equal(lse[:, lo:lo + n], l1)
+    # and against fp64 on one bag (the kernels agree with each other; this pins them to the definition)
+    b = 1
+    lo, n = int(pk.host[b]), sizes[b]
+    dk = d // h
+    qd = qv[lo:lo + n, :d].double().view(n, h, dk).transpose(0, 1)
+    vd = qv[lo:lo + n, d:].double().view(n, h, dk).transpose(0, 1)
+    kd = kp[b * k:(b + 1) * k].double().view(k, h, dk).transpose(0, 1)
+    p = torch.softmax(qd @ kd.transpose(1, 2) / dk ** 0.5, dim=-1)
+    ref = (p.transpose(1, 2) @ vd).transpose(0, 1).reshape(k, d)
+    err = (out[b * k:(b + 1) * k].double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-2, err
+
+
+@pytest.mark.parametrize("d,h,k", [(768, 6, 200), (384, 6, 200), (384, 6, 50), (768, 6, 100)])
+@pytest.mark.parametrize("need_attn", [False, True])
+def test_attention_x3_varlen_bit_identical_to_per_bag(d, h, k, need_attn):
+    from snuffy_amd import ops
+    sizes = [n for n in SIZES if n >= k] + [k]
+    pk = _packed(sizes)
+    g = torch.Generator().manual_seed(2)
+    qv = torch.randn(pk.total, 2 * d, generator=g).to(DEV)
+    kp = (torch.randn(pk.bags * k, d, generator=g) * 0.5).to(DEV)
+    q, v = qv[:, :d], qv[:, d:]
+    out, attn, lse = ops.sparse_attn_fwd_x3_varlen(q, v, kp, pk, k, h, need_attn=need_attn, need_lse=need_attn)
+    for b, n in enumerate(sizes):
+        lo = int(pk.host[b])
+        qb = qv[lo:lo + n]
+        o1, a1, l1 = ops.sparse_attn_fwd_x3(qb[:, :d], qb[:, d:], kp[b * k:(b + 1) * k], h, need_attn=need_attn, need_lse=need_attn)
+        assert torch.equal(out[b * k:(b + 1) * k], o1), (b, n)
+        if need_attn:
+            assert torch.equal(attn[:, lo:lo + n], a1)
+            assert torch.equal(lse[:, lo:lo + n], l1)
+    b = 0
+    lo, n = int(pk.host[b]), sizes[b]
+    dk = d // h
+    qd = qv[lo:lo + n, :d].double().view(n, h, dk).transpose(0, 1)
+    vd = qv[lo:lo + n, d:].double().view(n, h, dk).transpose(0, 1)
+    kd = kp[b * k:(b + 1) * k].double().view(k, h, dk).transpose(0, 1)
+    p = torch.softmax(qd @ kd.transpose(1, 2) / dk ** 0.5, dim=-1)
+    ref = (p.transpose(1, 2) @ vd).transpose(0, 1).reshape(k, d)
+    err = (out[b * k:(b + 1) * k].double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("d", [384, 768, 102])
+def test_head_varlen_bit_identical_to_per_bag(d):
+    from snuffy_amd import ops
+    sizes = SIZES + [1, 3]
+    pk = _packed(sizes)
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(pk.total, d, generator=g).to(DEV)
+    add = torch.randn(pk.total, d, generator=g).to(DEV).to(torch.bfloat16)
+    bias = torch.randn(d, generator=g).to(DEV)
+    gamma, beta = torch.randn(d, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
+    wh, bh = torch.randn(2, d, generator=g).to(DEV), torch.randn(2, generator=g).to(DEV)
+    # two patched rows in every bag (slots in packed coordinates)
+    sel = torch.tensor([int(pk.host[b]) + j for b, n in enumerate(sizes) for j in ((0, n - 1) if n > 1 else (0,))], device=DEV)
+    delta = torch.randn(sel.shape[0], d, generator=g).to(DEV)
+    slot = ops.slot_map(sel, pk.total)
+    for kw in (dict(), dict(add_bf16=add, add_bias=bias, slot=slot, delta_rows=delta)):
+        logits, pooled = ops.ln_mean_head_varlen(z, pk, gamma, beta, 1e-5, wh, bh, **kw)
+        for b, n in enumerate(sizes):
+            lo = int(pk.host[b])
+            kb = {}
+            if kw:
+                in_bag = (sel >= lo) & (sel < lo + n)
+                kb = dict(add_bf16=add[lo:lo + n], add_bias=bias, slot=ops.slot_map(sel[in_bag] - lo, n), delta_rows=delta[in_bag])
+            l1, p1, _ = ops.ln_mean_head(z[lo:lo + n], gamma, beta, 1e-5, wh, bh, **kb)
+            assert torch.equal(logits[b], l1), (b, n)
+            assert torch.equal(pooled[b], p1)
+
+
+def _net(d, h, lam, r, depth, precision, seed=0):
+    torch.manual_seed(seed)
+    net = build_amd_milnet(d, h, "relu", lam, r, depth).to(DEV).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() > 1:
+                torch.nn.init.xavier_uniform_(p)
+    net.configure(precision=precision, return_attention=True)
+    return net
+
+
+def _bags(sizes, d, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(1, n, d, generator=g).to(DEV) for n in sizes]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("d,lam,r,depth", [(384, 200, 0.0, 1), (768, 200, 0.0, 1), (384, 64, 0.25, 2), (384, 200, 0.5, 1)])
+def test_forward_bags_matches_per_bag_forwards(precision, d, lam, r, depth):
+    """Same selections (bit-exact, random share included), same A / logits up to the rounding of projections run over a
+    different row count (tile / library choice), for a length mix that includes a bag of exactly Lambda patches."""
+    sizes = [lam, 1000, 333, 4100, 2048]
+    net = _net(d, 6, lam, r, depth, precision)
+    bags = _bags(sizes, d)
+    with torch.no_grad():
+        np.random.seed(11)
+        ref, sel_ref = [], []
+        for x in bags:
+            ref.append(net(x))
+            sel_ref.append([tuple(None if t is None else t.clone() for t in l.last_selection) for l in net.b_classifier.encoder.layers])
+        np.random.seed(11)
+        assert net._packable(bags)
+        got = net.forward_bags(bags)
+        after_packed = np.random.rand()
+        np.random.seed(11)
+        [net(x) for x in bags]
+        assert np.random.rand() == after_packed          # the numpy stream is left where the per-bag loop leaves it
+    for li, layer in enumerate(net.b_classifier.encoder.layers):       # selections, random share included: bit-exact
+        top, rnd = layer.last_selection_bags
+        for b in range(len(bags)):
+            assert torch.equal(top[b], sel_ref[b][li][0])
+            assert (rnd is None and sel_ref[b][li][1] is None) or torch.equal(rnd[b], sel_ref[b][li][1])
+    tol_logit, tol_a = (2e-5, 2e-6) if precision == "fp32" else (2e-2, 2e-2)
+    for b, ((c0, y0, a0), (c1, y1, a1)) in enumerate(zip(ref, got)):
+        assert c1.shape == c0.shape and y1.shape == y0.shape and a1.shape == a0.shape
+        assert torch.equal(c0, c1)                       # critic scores: same kernel, row-wise
+        assert (y0 - y1).abs().max().item() <= tol_logit * max(1.0, y0.abs().max().item()), (b, y0, y1)
+        assert (a0 - a1).abs().max().item() <= tol_a, b
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 2e-2)])
+def test_forward_bags_vs_oracle(precision, tol):
+    d, h, lam = 384, 6, 200
+    sizes = [1000, 1500, 600, 250]
+    net = _net(d, h, lam, 0.0, 1, precision)
+    bags = _bags(sizes, d, seed=9)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        got = net.forward_bags(bags)
+    top, _ = net.b_classifier.encoder.layers[0].last_selection_bags
+    for b, x in enumerate(bags):
+        classes, logits, attn, sels = orc.milnet_forward(x[0].cpu(), sd, h, "relu", lam, 0.0, 1)
+        assert np.array_equal(sels[0].numpy(), top[b].cpu().numpy())                   # bit-exact top-Lambda indices per bag
+        assert (got[b][0][0].cpu() - classes).abs().max().item() <= 2e-5
+        assert (got[b][1][0].cpu() - logits).abs().max().item() <= tol * max(1.0, logits.abs().max().item())
+        assert (got[b][2][0].cpu() - attn).abs().max().item() <= tol
+
+
+def test_forward_bags_falls_back_when_not_packable():
+    net = _net(384, 6, 200, 0.0, 1, "bf16")
+    bags = _bags([1000, 150], 384)          # the second bag is shorter than Lambda: K differs per bag
+    with torch.no_grad():
+        assert not net._packable(bags)
+        got = net.forward_bags(bags)
+        ref = [net(x) for x in bags]
+    for (c0, y0, a0), (c1, y1, a1) in zip(ref, got):
+        assert torch.equal(c0, c1) and torch.equal(y0, y1) and torch.equal(a0, a1)
