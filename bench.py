@@ -55,6 +55,21 @@ def build_net(D, h, lam, precision, device):
     return net.to(device).configure(precision=precision, return_attention=False)
 
 
+def small_bag_leg(device, precision, n=1000, d=384, nbags=64, steps=10):
+    """Small bags are launch-latency bound one at a time: slides/s of `nbags` bags of n patches, one bag per
+    forward (graph replay) against MILNet.forward_bags (all of them in one set of launches, graph replay)."""
+    net = build_net(d, 6, 200, precision, device).eval()
+    g = torch.Generator().manual_seed(77)
+    bags = [torch.randn(1, n, d, generator=g).to(device) for _ in range(nbags)]
+    net.configure(graph_max_patches=1 << 20)
+    with torch.no_grad():
+        per_bag = nbags / (timed(lambda: [net(x) for x in bags], steps) * 1e-3)
+        packed = nbags / (timed(lambda: net.forward_bags(bags), steps) * 1e-3)
+    return {"workload": "%d bags x %d patches, D=%d, h=6, Lambda=200, eval forward, %s" % (nbags, n, d, precision),
+            "slides_per_s_one_bag_per_forward": round(per_bag, 1), "slides_per_s_packed": round(packed, 1),
+            "what": "MILNet.forward_bags: segmented top-k / attention / head kernels over the packed rows, same selections"}
+
+
 def timed(fn, iters, warmup=2):
     """Average ms per call measured with HIP events on torch's current stream (the stream our kernels launch on)."""
     for _ in range(warmup):
@@ -509,6 +524,8 @@ def main():
             for prec, st in (("bf16", 8), ("fp32", 3)):
                 leg = vit_leg(device, prec, st, 2)
                 line["vit_" + dt_name[prec]] = {k: leg[k] for k in ("value", "unit", "ms_per_batch", "steps", "batch", "workload", "roofline")}
+        if world == 1 and not args.headline_only and args.workload == "cfgB":
+            line["small_bags"] = small_bag_leg(device, args.precision)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(line), flush=True)

@@ -365,8 +365,11 @@ int snf_tile_preprocess_u8(const void* img_u8, int b, int h, int w, int c, int o
  *     The reference runs one bag per forward (train.py:468-473 batch_size 1; snuffy.py:130-131 indexes with a 1-D tensor); this
  *     is the same per-bag arithmetic with the bags' rows PACKED into one [T, .] tensor, offsets[bags + 1] = first row of each bag.
  *     Row-wise kernels (critic, LayerNorm, the projections, the FFN) already take packed rows; the three per-bag reductions get
- *     segmented forms.  Every segmented launch is the CONCATENATION of the bags' own grids (workgroup wg0 + i of bag b does what
- *     workgroup i of the bag's own launch does), so results are bit-identical to the per-bag entry points above.
+ *     segmented forms.  Every segmented launch is the CONCATENATION of per-bag grids (workgroup wg0 + i of bag b does what
+ *     workgroup i of a launch of that bag alone does): a bag's result never depends on what it is packed with, bit for bit.
+ *     top-k and the head are also bit-identical to the single-bag entry points above; the attention launches give small bags
+ *     more rows per workgroup than a lone launch would (fewer partial tiles), so against snf_sparse_attn_fwd_mfma / _x3 the
+ *     fp32 summation order of the [k, dk] partial tiles can differ (<= 1e-6 relative).
  *   snf_topk_segmented_f32       K2 of every bag (offsets in DEVICE memory; idx_out [bags, k] = indices inside the bag).
  *   snf_sparse_attn_varlen_plan / snf_sparse_attn_x3_varlen_plan
  *                                host-side geometry of a varlen attention launch: offsets in HOST memory; call with

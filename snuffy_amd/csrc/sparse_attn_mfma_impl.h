@@ -67,9 +67,11 @@ struct AttnParams {
     const int* vl;
     int vl_bags;
 };
-// One bag of a varlen launch.  The grid is the concatenation of the bags' own single-bag grids: workgroup wg0 + i does exactly
-// what workgroup i of that bag's own launch does (same tiles, same partial tiles, same summation order in the reduction), so a
-// packed launch is bit-identical to the per-bag launches it replaces.
+// One bag of a varlen launch.  The grid is the concatenation of per-bag grids: every bag keeps a plan of its own (make_plan with
+// packed = true, a function of the bag's length only) and workgroup wg0 + i does what workgroup i of a launch of that bag alone
+// would do (same tiles, same partial tiles, same summation order in the reduction) -- a bag's result does not depend on what it
+// is packed with, bit for bit.  Against the single-bag entry points (latency plan: one tile per workgroup for small bags) only
+// the fp32 summation order of the partial tiles can differ.
 constexpr int VL_DESC = 12;   // wg0, row0, n, out_row0 (= first Kp / output row), tiles_per_head, tiles_per_wg, total_tiles,
                               // seg_count, part0 (first partial slot), num_wg, 0, 0
 struct Plan {
@@ -842,7 +844,7 @@ __global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __rest
 
 
 
-inline bool make_plan(int64_t n, int k, int h, int dk, Plan* pl) {
+inline bool make_plan(int64_t n, int k, int h, int dk, Plan* pl, bool packed = false) {
     if (!(dk == 64 || dk == 128) || k < 1 || k > (dk == 128 ? 224 : 256)) return false;   // LDS: Kp + P + V images
     int nkb = (k + 31) / 32;
     // instantiated key-block counts
@@ -861,6 +863,12 @@ inline bool make_plan(int64_t n, int k, int h, int dk, Plan* pl) {
     int cus = snf::cu_count();
     int64_t num_wg = total < cus ? total : cus;
     int64_t tpw = (total + num_wg - 1) / num_wg;
+    // A bag inside a PACKED (varlen) launch does not have the chip to itself: at least SMALL_BAG_TILES tiles (1024 rows) per
+    // workgroup, so a head of a small bag is one or two partial tiles instead of one per 128 rows -- the partial tiles are the
+    // bulk of such a launch's bytes (measured: 64 bags x 1000 rows, 87 -> 54 us + reduction 40 -> 29 us).  A bag launched ALONE
+    // keeps one tile per workgroup: its tiles run side by side on idle CUs (8 in a row cost it ~25 us of latency, measured).
+    constexpr int64_t SMALL_BAG_TILES = 8;
+    if (packed && total <= cus) tpw = tph < SMALL_BAG_TILES ? tph : SMALL_BAG_TILES;
     num_wg = (total + tpw - 1) / tpw;
     pl->num_wg = (int)num_wg;
     pl->tiles_per_head = (int)tph;
@@ -939,7 +947,7 @@ inline bool make_varlen_plan(const int64_t* offsets, int bags, int k, int h, int
     for (int b = 0; b < bags; ++b) {
         const int64_t n = offsets[b + 1] - offsets[b];
         Plan pl;
-        if (n < 1 || offsets[b] > 0x7fffffffll || !make_plan(n, k, h, dk, &pl)) return false;
+        if (n < 1 || offsets[b] > 0x7fffffffll || !make_plan(n, k, h, dk, &pl, true)) return false;
         if (table) {
             if ((size_t)(VL_DESC * bags) + (size_t)(vp->total_wg + pl.num_wg) > table_ints) return false;
             int32_t* d = table + (size_t)VL_DESC * b;

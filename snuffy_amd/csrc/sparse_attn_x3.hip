@@ -63,9 +63,9 @@ struct X3Params {
     const int* vl;     // varlen launch: [bags][VL_DESC] descriptors, then the bag of every workgroup (see below)
     int vl_bags;
 };
-// Varlen launch (many bags in one grid, single key chunk): the grid is the concatenation of the bags' own grids -- workgroup
-// wg0 + i does exactly what workgroup i of that bag's own launch does (same tiles, partial tiles and summation order), so the
-// packed launch is bit-identical to the per-bag launches it replaces.
+// Varlen launch (many bags in one grid, single key chunk): the grid is the concatenation of per-bag grids -- every bag keeps a
+// plan of its own (x3_plan with packed = true, a function of its length only), so a bag's result does not depend on what it is
+// packed with, bit for bit; against snf_sparse_attn_fwd_x3 only the fp32 summation order of the partial tiles can differ.
 // descriptor: wg0, row0, n, out_row0 (first Kp / output row), tiles_per_head, tiles_per_wg, total_tiles, seg_count, part0, num_wg
 constexpr int VL_DESC = 12;
 
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(64) void x3_reduce_kernel(const float* __restrict__
 struct X3Plan {
     int num_wg, tiles_per_head, tiles_per_wg, total_tiles, seg_count, nkb;
 };
-bool x3_plan(int64_t n, int k, int h, int dk, X3Plan* pl) {
+bool x3_plan(int64_t n, int k, int h, int dk, X3Plan* pl, bool packed = false) {
     if (!(dk == 64 || dk == 128) || k < 1 || k > (dk == 128 ? 224 : 256) || n < 1) return false;
     const int need = (k + 31) / 32;
     const int opts[] = {2, 4, 7, 8};
@@ -523,7 +523,10 @@ bool x3_plan(int64_t n, int k, int h, int dk, X3Plan* pl) {
     if (total > 0x7fffffff) return false;
     const int cus = snf::cu_count();
     int64_t num_wg = total < cus ? total : cus;
-    const int64_t tpw = (total + num_wg - 1) / num_wg;
+    int64_t tpw = (total + num_wg - 1) / num_wg;
+    // a bag inside a packed (varlen) launch: at least 16 tiles (1024 rows) per workgroup -- see make_plan of the bf16 kernel
+    constexpr int64_t SMALL_BAG_TILES = 16;
+    if (packed && total <= cus) tpw = tph < SMALL_BAG_TILES ? tph : SMALL_BAG_TILES;
     num_wg = (total + tpw - 1) / tpw;
     pl->num_wg = (int)num_wg;
     pl->tiles_per_head = (int)tph;
@@ -587,7 +590,7 @@ bool x3_varlen_plan(const int64_t* offsets, int bags, int k, int h, int dk, X3Va
     for (int b = 0; b < bags; ++b) {
         const int64_t n = offsets[b + 1] - offsets[b];
         X3Plan pl;
-        if (n < 1 || offsets[b] > 0x7fffffffll || !x3_plan(n, k, h, dk, &pl)) return false;
+        if (n < 1 || offsets[b] > 0x7fffffffll || !x3_plan(n, k, h, dk, &pl, true)) return false;
         if (table) {
             if ((size_t)(VL_DESC * bags) + (size_t)(vp->total_wg + pl.num_wg) > table_ints) return false;
             int32_t* d = table + (size_t)VL_DESC * b;

@@ -338,6 +338,16 @@ def invalidate_folded(layer):
     layer._xhat_offer = None
 
 
+def _rows_linear(x, lin):
+    """x W^T + b of an fp32 [rows, D] operand: the fp32 library GEMM for the K selected rows of one bag; thousands of rows (the
+    B x K selected rows of a packed batch) go through the fp32-class split-bf16 x3 MFMA kernel like the [N, .] projections."""
+    m, k = x.shape
+    n = lin.weight.shape[0]
+    if FP32_GEMM == "x3" and m >= 2048 and ops.gemm_x3_supported(m, n, k) and not _needs_grad(x, lin.weight, lin.bias):
+        return ops.gemm_x3(ops.split3_rows(x), split3_cached(lin.weight), lin.bias.detach(), out_dtype=torch.float32)
+    return F.linear(x, lin.weight, lin.bias)
+
+
 def encoder_layer(x2, sel, layer, need_attn, precision, packed=None):
     """EncoderLayer.forward (snuffy.py:126-157) for x2 [N, D] and selected rows sel [K].  Returns (Parts, A).
 
@@ -378,7 +388,7 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None):
         hl = d % 32 == 0 and f % 32 == 0 and ops.hl_eligible(n, 2 * d, d) and ops.hl_eligible(n, f, d) and ops.hl_eligible(n, d, f)
         fh = _hl_weights(layer, fw) if hl else None
         xs, slot = ops.gather_slot_map(x2, sel)                                     # snuffy.py:131,145-147 (+ row -> slot map)
-        kp = F.linear(xs, lk.weight, lk.bias)                                       # keys = RAW selected rows (K rows: fp32)
+        kp = _rows_linear(xs, lk)                                       # keys = RAW selected rows (K rows: fp32)
         if hl:
             xn3 = ops.layernorm_rows_hl(x2, n0.weight, n0.bias, n0.eps)             # snuffy.py:107
             qv = ops.gemm_hl(xn3, fh["wqv"], fw["bqv"])                             # [N, 2D] f32 = [Q | V]
@@ -394,7 +404,7 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None):
         else:
             o, attn, _ = ops.sparse_attn_fwd(q.contiguous(), kp, v.contiguous(), h, need_attn=need_attn)
         del q, v, qv
-        delta = F.linear(o, lo.weight, lo.bias)                                     # snuffy.py:205
+        delta = _rows_linear(o, lo)                                     # snuffy.py:205
         x_sel = xs + delta                                                          # snuffy.py:108
         if hl:
             yn3 = ops.layernorm_rows_hl(x2, n1.weight, n1.bias, n1.eps, slot=slot, patch_rows=x_sel)   # LN(y), y never built
@@ -413,7 +423,7 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None):
 
     if precision == "fp32":
         xs, slot = ops.gather_slot_map(x2, sel)                                     # snuffy.py:131,145-147 (+ row -> slot map)
-        kp = F.linear(xs, lk.weight, lk.bias)                                       # keys = RAW selected rows
+        kp = _rows_linear(xs, lk)                                       # keys = RAW selected rows
         xn = ops.layernorm_rows(x2, n0.weight, n0.bias, n0.eps)                     # snuffy.py:107
         q = F.linear(xn, lq.weight, lq.bias)
         v = F.linear(xn, lv.weight, lv.bias)
@@ -424,7 +434,7 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None):
         else:
             o, attn, _ = ops.sparse_attn_fwd(q, kp, v, h, need_attn=need_attn)       # exact fp32 on the vector ALUs
         del q, v, xn
-        delta = F.linear(o, lo.weight, lo.bias)                                     # snuffy.py:205
+        delta = _rows_linear(o, lo)                                     # snuffy.py:205
         x_sel = xs + delta                                                          # snuffy.py:108
         yn = ops.layernorm_rows(x2, n1.weight, n1.bias, n1.eps, slot=slot, patch_rows=x_sel)  # LN(y), y never built
         hid = torch.mm(yn, ff.w_1.weight.t())
@@ -457,10 +467,10 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None):
             o, attn, _ = ops.sparse_attn_fwd_mfma(q, v, kp, n, h, need_attn=need_attn)
     else:
         xs, slot = ops.gather_slot_map(x2, sel)
-        kp = F.linear(xs, lk.weight, lk.bias)
+        kp = _rows_linear(xs, lk)
         o, attn, _ = ops.sparse_attn_fwd(q.float(), kp, v.float(), h, need_attn=need_attn)
     del q, v, qv
-    delta = F.linear(o, lo.weight, lo.bias)
+    delta = _rows_linear(o, lo)
     x_sel = xs + delta
     ops.layernorm_rows(x_sel, None, None, n1.eps, out=xhat, out_row_idx=sel)        # re-normalise the K rows in place
     # W1 + bias + activation in the GEMM epilogue: [N, F] bf16.  GELU is the reference's erf form (nn.GELU(), snuffy.py:218) --

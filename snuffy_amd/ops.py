@@ -678,8 +678,9 @@ def topk_segmented(scores, packed, k):
 
 def sparse_attn_fwd_mfma_varlen(q, v, kp, packed, k, h, scale=None, need_attn=False, need_lse=False):
     """bf16-MFMA sparse attention of B packed bags in one launch.  q, v [T, d] bf16 (row-strided views allowed), kp [B * k, d]
-    (bag b's keys in rows b k ..) -> (out [B * k, d] f32, attn [h, T, k] or None, lse [h, T] or None); bit-identical to
-    sparse_attn_fwd_mfma() bag by bag."""
+    (bag b's keys in rows b k ..) -> (out [B * k, d] f32, attn [h, T, k] or None, lse [h, T] or None).  A bag's result
+    does not depend on what it is packed with (bit for bit); against sparse_attn_fwd_mfma() bag by bag P / lse are identical and
+    O differs by the fp32 order of the partial sums only (small bags get more rows per workgroup here)."""
     if q.dtype != torch.bfloat16 or v.dtype != torch.bfloat16:
         raise TypeError("sparse_attn_fwd_mfma_varlen: q and v must be bfloat16")
     q = _rows16(q, "q")
@@ -706,8 +707,8 @@ def sparse_attn_fwd_mfma_varlen(q, v, kp, packed, k, h, scale=None, need_attn=Fa
 
 
 def sparse_attn_fwd_x3_varlen(q, v, kp, packed, k, h, scale=None, need_attn=False, need_lse=False):
-    """fp32-class sparse attention of B packed bags in one launch (f32 q, v [T, d], kp [B * k, d]); bit-identical to
-    sparse_attn_fwd_x3() bag by bag."""
+    """fp32-class sparse attention of B packed bags in one launch (f32 q, v [T, d], kp [B * k, d]); composition-independent bit
+    for bit, O within the fp32 summation order of sparse_attn_fwd_x3() bag by bag."""
     if q.dtype != torch.float32 or v.dtype != torch.float32:
         raise TypeError("sparse_attn_fwd_x3_varlen: q and v must be float32")
     q = _rows16(q, "q")

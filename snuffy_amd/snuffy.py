@@ -311,7 +311,7 @@ class MILNet(nn.Module):
             SF.invalidate_folded(layer)
         return self
 
-    _GRAPH_STATE = ("_graphs", "_graph_seen", "_graph_pool", "_graph_sig")
+    _GRAPH_STATE = ("_graphs", "_graph_seen", "_graph_pool", "_graph_sig", "_packed_bags")
 
     def __deepcopy__(self, memo):
         """Captured HIP graphs belong to this instance's buffers: a copy starts without them."""
@@ -407,7 +407,6 @@ class MILNet(nn.Module):
             kb = (k1, k2)
         if sum(kb) * len(bags) > (1 << 20):
             return False
-        n0, n1 = layers[0].sublayer[0].norm, layers[0].sublayer[1].norm
         if cfg.precision == "bf16" and any(l.sublayer[0].norm.eps != l.sublayer[1].norm.eps for l in layers):
             return False
         return SF.ops.varlen_attn_supported(cfg.precision, sum(kb), d // h)
@@ -417,19 +416,92 @@ class MILNet(nn.Module):
         are launch-latency bound -- ~25 launches per bag whatever its size).  bags: sequence of [1, N_b, D] (or [N_b, D]) fp32 GPU
         tensors.  Returns the list of (classes [1, N_b, 1], prediction_bag [1, C], A [1, h, N_b, K] or None) tuples the per-bag
         forwards return: same selections (bit-exact, random share included: the numpy draws are made bag by bag in the order the
-        per-bag forwards make them), the segmented kernels bit-identical to their per-bag forms; the projections run over the
-        packed rows, so a library / tile choice that depends on the row count can move logits by fp32 / bf16 rounding.
+        per-bag forwards make them); a bag's outputs do not depend on what it is packed with.  Against the per-bag forwards the
+        top-k and head kernels are bit-identical, the attention sums its partial tiles in another order, and the projections
+        run over the packed rows (a library / tile choice that depends on the row count): logits move by fp32 / bf16 rounding.
         Falls back to the per-bag loop when the bags cannot be packed (training, multiclass critic, a bag shorter than Lambda, ...)."""
         bags = list(bags)
         if not self._packable(bags):
             return [self(x) for x in bags]
-        packed = SF.ops.PackedBags([x.shape[-2] for x in bags], bags[0].device)
-        x_cat = torch.cat([x.reshape(-1, x.shape[-1]) for x in bags])
-        return self.forward_packed(x_cat, packed)
+        sizes = tuple(x.shape[-2] for x in bags)
+        rows = [x.reshape(-1, x.shape[-1]) for x in bags]
+        lim = getattr(self, "_graph_max_patches", 0)
+        if lim > 0 and max(sizes) <= lim and all(l.random_patch_share == 0 for l in self.b_classifier.encoder.layers):
+            return self._forward_bags_graph(rows, sizes)
+        packed = self._packed_cache(sizes, bags[0].device)
+        return self.forward_packed(torch.cat(rows), packed)
+
+    def _packed_cache(self, sizes, device):
+        """PackedBags (offsets + launch plans) of the most recent batch compositions."""
+        cache = self.__dict__.setdefault("_packed_bags", {})
+        key = (sizes, str(device))
+        pk = cache.get(key)
+        if pk is None:
+            if len(cache) >= 64:
+                cache.pop(next(iter(cache)))
+            pk = cache[key] = SF.ops.PackedBags(sizes, device)
+        return pk
+
+    def _forward_bags_graph(self, rows, sizes):
+        """forward_bags() as ONE captured HIP graph per batch composition (configure(graph_max_patches=...), deterministic
+        selection only): the bags are copied into the graph's static packed buffer and the ~30 launches replay without the host."""
+        sig = self._weights_signature()
+        if sig != getattr(self, "_graph_sig", None):
+            self._graphs.clear()
+            self._graph_seen.clear()
+            self._graph_sig = sig
+        cfg = self.b_classifier.cfg
+        dev = rows[0].device
+        key = ("bags", sizes, dev, cfg.precision, cfg.return_attention)
+        ent = self._graphs.get(key)
+        if ent is None:
+            packed = self._packed_cache(sizes, dev)
+            static_x = torch.cat(rows)
+            try:
+                cur = torch.cuda.current_stream()
+                side = torch.cuda.Stream()
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self._forward_packed_raw(static_x, packed)
+                cur.wait_stream(side)
+                if self._graph_pool is None:
+                    self._graph_pool = torch.cuda.graph_pool_handle()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
+                    out = self._forward_packed_raw(static_x, packed)
+            except Exception as exc:
+                import warnings
+                warnings.warn("snuffy_amd: HIP-graph capture of the packed inference forward failed (%s: %s); graph replay is "
+                              "disabled for this model" % (type(exc).__name__, exc), RuntimeWarning, stacklevel=2)
+                self._graph_max_patches = 0
+                torch.cuda.synchronize()
+                return self.forward_packed(torch.cat(rows), packed)
+            if len(self._graphs) >= self._GRAPH_SHAPES:
+                self._graphs.pop(next(iter(self._graphs)))
+            ent = self._graphs[key] = (graph, static_x, out, packed)
+        graph, static_x, out, packed = ent
+        torch.cat(rows, out=static_x)
+        graph.replay()
+        # the graphs share one pool: outputs are valid until the next replay -- three copies per batch, then per-bag views
+        return self._split_packed(tuple(o.clone() if o is not None else None for o in out), packed)
 
     def forward_packed(self, x_cat, packed):
         """forward_bags() on rows that are already packed: x_cat [T, D] fp32, packed = ops.PackedBags(sizes, device) (keep it
         between calls with the same bag sizes: it caches the launch plans)."""
+        return self._split_packed(self._forward_packed_raw(x_cat, packed), packed)
+
+    @staticmethod
+    def _split_packed(raw, packed):
+        s, logits, attn = raw
+        out = []
+        for b, n in enumerate(packed.sizes):
+            lo = int(packed.host[b])
+            out.append((s[lo:lo + n].view(1, n, -1), logits[b].view(1, -1), attn[:, :, lo:lo + n, :] if attn is not None else None))
+        return out
+
+    def _forward_packed_raw(self, x_cat, packed):
+        """(critic scores [T, 1], logits [B, C], A [1, h, T, K] or None) over the packed rows."""
         enc = self.b_classifier.encoder
         cfg = self.b_classifier.cfg
         layers = list(enc.layers)
@@ -474,12 +546,7 @@ class MILNet(nn.Module):
             parts, attn = SF.encoder_layer(x2, sel, layer, (li == len(layers) - 1) and cfg.return_attention, cfg.precision,
                                            packed=packed)
         logits = SF.head(parts, enc.norm, self.b_classifier.linear, packed=packed)   # [B, C]
-        out = []
-        for b, n in enumerate(packed.sizes):
-            lo = int(packed.host[b])
-            a_b = attn[:, :, lo:lo + n, :] if attn is not None else None
-            out.append((s[lo:lo + n].view(1, n, -1), logits[b].view(1, -1), a_b))
-        return out
+        return s, logits, attn
 
     def _critic(self, x):
         """i_classifier(x); in the bf16 inference path of a plain FCLayer critic the same pass over the bag also produces

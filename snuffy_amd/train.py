@@ -61,6 +61,11 @@ def get_args_parser():
     p.add_argument('--betas', default=[0.5, 0.9])
     p.add_argument('--l2normed_embeddings', default=0, type=int)
     p.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help='eval-forward arithmetic (snuffy_amd)')
+    p.add_argument('--eval_bags_per_launch', default=1, type=int,
+                   help='snuffy_amd: the evaluation loops pack up to this many SMALL bags (<= --eval_pack_max_patches patches each) '
+                        'into one set of launches (MILNet.forward_bags: same selections, same draws of the random share; '
+                        'projections over the packed rows, so logits can move by rounding).  1 = one bag per forward, as the reference')
+    p.add_argument('--eval_pack_max_patches', default=16384, type=int)
     return p
 
 
@@ -310,15 +315,31 @@ class Trainer:
         num_bags = len(labels)
         mine = list(range(self.rank, num_bags, self.world_size))
         losses, preds = [], []
-        for i in mine:
+
+        def load(i):
             f = feats[i]
             if not torch.is_tensor(f) and self.args.l2normed_embeddings == 1:
                 f = f / np.linalg.norm(f, axis=1, keepdims=True)
-            bag_feats = self._bag_to_device(f)
-            bag_label = torch.as_tensor(np.asarray(labels[i], dtype=np.float32).reshape(1, -1), device=device)
-            bag_prediction, loss, _ = self._run_model(bag_feats, bag_label)
-            losses.append(loss.reshape(1).float())
-            preds.append(bag_prediction.reshape(-1).float())
+            return (self._bag_to_device(f),
+                    torch.as_tensor(np.asarray(labels[i], dtype=np.float32).reshape(1, -1), device=device))
+
+        per_launch = int(getattr(self.args, 'eval_bags_per_launch', 1) or 1)
+        pack_max = int(getattr(self.args, 'eval_pack_max_patches', 16384))
+        can_pack = per_launch > 1 and hasattr(self.milnet, 'forward_bags') and hasattr(self, '_outputs_to_loss')
+        pos = 0
+        while pos < len(mine):
+            chunk = [load(i) for i in mine[pos:pos + (per_launch if can_pack else 1)]]
+            pos += len(chunk)
+            if len(chunk) > 1 and all(b.shape[-2] <= pack_max for b, _ in chunk):
+                # small bags: one set of launches for the chunk (forward_bags falls back to the per-bag loop by itself when the
+                # chunk cannot be packed); the loss / prediction arithmetic per bag is the per-bag path's
+                outs = self.milnet.forward_bags([b for b, _ in chunk])
+                results = [self._run_model(b, y, outputs=o) for (b, y), o in zip(chunk, outs)]
+            else:
+                results = [self._run_model(b, y) for b, y in chunk]
+            for bag_prediction, loss, _ in results:
+                losses.append(loss.reshape(1).float())
+                preds.append(bag_prediction.reshape(-1).float())
         ncls = int(np.asarray(labels[0]).size)
         rows = torch.cat([torch.cat(losses).view(-1, 1), torch.stack(preds)], dim=1) if mine else \
             torch.zeros(0, 1 + ncls, device=device)
@@ -378,8 +399,10 @@ class SmallWeightTrainer(Trainer):
                    lr=self.args.lr, betas=(self.args.betas[0], self.args.betas[1]), weight_decay=self.args.weight_decay,
                    **_fused_step([self.single_weight_parameter] + list(self.milnet.parameters())))
 
-    def _run_model(self, bag_feats, bag_label):
-        ins_prediction, bag_prediction, _ = self.milnet(bag_feats)
+    _outputs_to_loss = True      # _run_model accepts the model outputs of a packed forward (Trainer.valid)
+
+    def _run_model(self, bag_feats, bag_label, outputs=None):
+        ins_prediction, bag_prediction, _ = self.milnet(bag_feats) if outputs is None else outputs
         max_prediction, _ = torch.max(ins_prediction, 0 if ins_prediction.dim() == 2 else 1)
         bag_loss = self.criterion(bag_prediction.view(1, -1), bag_label.view(1, -1))
         max_loss = self.criterion(max_prediction.view(1, -1), bag_label.view(1, -1))
@@ -426,8 +449,8 @@ class Snuffy(SmallWeightTrainer):
         milnet.configure(precision=getattr(a, 'precision', 'fp32'), return_attention=False)   # A is discarded, train.py:830
         return milnet
 
-    def _run_model(self, bag_feats, bag_label):
-        bag_prediction, loss, ins_prediction = super()._run_model(bag_feats, bag_label)
+    def _run_model(self, bag_feats, bag_label, outputs=None):
+        bag_prediction, loss, ins_prediction = super()._run_model(bag_feats, bag_label, outputs)
         return bag_prediction, loss, torch.sigmoid(ins_prediction.view(-1, 1))
 
     def __str__(self):
@@ -457,8 +480,8 @@ class SnuffyMulticlass(SmallWeightTrainer):
         milnet.b_classifier.configure(precision=getattr(a, 'precision', 'fp32'), return_attention=False)
         return milnet
 
-    def _run_model(self, bag_feats, bag_label):
-        bag_prediction, loss, ins_prediction = super()._run_model(bag_feats, bag_label)
+    def _run_model(self, bag_feats, bag_label, outputs=None):
+        bag_prediction, loss, ins_prediction = super()._run_model(bag_feats, bag_label, outputs)
         return bag_prediction, loss, torch.sigmoid(ins_prediction.view(-1, 1))
 
     def __str__(self):

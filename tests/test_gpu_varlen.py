@@ -1,6 +1,7 @@
-"""Varlen path: many bags per launch.  The segmented kernels against their per-bag forms (bit-identical: every
-segmented launch is the concatenation of the bags' own grids), MILNet.forward_bags against the per-bag forwards (same selections,
-same draws of the random share) and against the CPU oracle."""
+"""Varlen path: many bags per launch.  The segmented kernels against their per-bag forms (top-k and head
+bit-identical; attention: same P bit for bit, O up to the fp32 order of the partial sums, and independent of the batch composition
+bit for bit), MILNet.forward_bags against the per-bag forwards (same selections, same draws of the random share) and against the
+CPU oracle."""
 import numpy as np
 import pytest
 import torch
@@ -41,7 +42,7 @@ def test_topk_segmented_matches_per_bag_selection():
 
 @pytest.mark.parametrize("d,h,k", [(768, 6, 200), (768, 6, 224), (384, 6, 200), (384, 6, 37), (256, 2, 64)])
 @pytest.mark.parametrize("need_attn", [False, True])
-def test_attention_bf16_varlen_bit_identical_to_per_bag(d, h, k, need_attn):
+def test_attention_bf16_varlen_vs_per_bag_and_composition_independent(d, h, k, need_attn):
     from snuffy_amd import ops
     sizes = [n for n in SIZES if n >= k] + [k]
     pk = _packed(sizes)
@@ -56,10 +57,17 @@ def test_attention_bf16_varlen_bit_identical_to_per_bag(d, h, k, need_attn):
         qb = qv[lo:lo + n]
         o1, a1, l1 = ops.sparse_attn_fwd_mfma(qb[:, :d], qb[:, d:], kp[b * k:(b + 1) * k], n, h, need_attn=need_attn,
                                               need_lse=need_attn)
-        assert torch.equal(out[b * k:(b + 1) * k], o1), (b, n)
+        # the single-bag entry point spreads a small bag over more workgroups: same P, O up to the fp32 order of the partial sums
+        assert (out[b * k:(b + 1) * k] - o1).abs().max().item() <= 2e-6 * o1.abs().max().item(), (b, n)
         if need_attn:
             assert torch.equal(attn[:, lo:lo + n], a1)
             assert torch.equal(lse[:, lo:lo + n], l1)
+        # ... and a bag's result does not depend on what it is packed with: alone in a varlen launch, bit for bit
+        o2, a2, l2 = ops.sparse_attn_fwd_mfma_varlen(qb[:, :d], qb[:, d:], kp[b * k:(b + 1) * k], _packed([n]), k, h,
+                                                     need_attn=need_attn, need_lse=need_attn)
+        assert torch.equal(out[b * k:(b + 1) * k], o2), (b, n)
+        if need_attn:
+            assert torch.equal(attn[:, lo:lo + n], a2) and torch.equal(lse[:, lo:lo + n], l2)
     # and against fp64 on one bag (the kernels agree with each other; this pins them to the definition)
     b = 1
     lo, n = int(pk.host[b]), sizes[b]
@@ -75,7 +83,7 @@ def test_attention_bf16_varlen_bit_identical_to_per_bag(d, h, k, need_attn):
 
 @pytest.mark.parametrize("d,h,k", [(768, 6, 200), (384, 6, 200), (384, 6, 50), (768, 6, 100)])
 @pytest.mark.parametrize("need_attn", [False, True])
-def test_attention_x3_varlen_bit_identical_to_per_bag(d, h, k, need_attn):
+def test_attention_x3_varlen_vs_per_bag_and_composition_independent(d, h, k, need_attn):
     from snuffy_amd import ops
     sizes = [n for n in SIZES if n >= k] + [k]
     pk = _packed(sizes)
@@ -88,10 +96,15 @@ def test_attention_x3_varlen_bit_identical_to_per_bag(d, h, k, need_attn):
         lo = int(pk.host[b])
         qb = qv[lo:lo + n]
         o1, a1, l1 = ops.sparse_attn_fwd_x3(qb[:, :d], qb[:, d:], kp[b * k:(b + 1) * k], h, need_attn=need_attn, need_lse=need_attn)
-        assert torch.equal(out[b * k:(b + 1) * k], o1), (b, n)
+        assert (out[b * k:(b + 1) * k] - o1).abs().max().item() <= 2e-6 * o1.abs().max().item(), (b, n)
         if need_attn:
             assert torch.equal(attn[:, lo:lo + n], a1)
             assert torch.equal(lse[:, lo:lo + n], l1)
+        o2, a2, l2 = ops.sparse_attn_fwd_x3_varlen(qb[:, :d], qb[:, d:], kp[b * k:(b + 1) * k], _packed([n]), k, h,
+                                                   need_attn=need_attn, need_lse=need_attn)
+        assert torch.equal(out[b * k:(b + 1) * k], o2), (b, n)
+        if need_attn:
+            assert torch.equal(attn[:, lo:lo + n], a2) and torch.equal(lse[:, lo:lo + n], l2)
     b = 0
     lo, n = int(pk.host[b]), sizes[b]
     dk = d // h
@@ -174,7 +187,9 @@ def test_forward_bags_matches_per_bag_forwards(precision, d, lam, r, depth):
         for b in range(len(bags)):
             assert torch.equal(top[b], sel_ref[b][li][0])
             assert (rnd is None and sel_ref[b][li][1] is None) or torch.equal(rnd[b], sel_ref[b][li][1])
-    tol_logit, tol_a = (2e-5, 2e-6) if precision == "fp32" else (2e-2, 2e-2)
+    # fp32-class: products to 2^-17 in both runs, but the packed projections may take another kernel form (row count) and the
+    # B x K selected rows go through the x3 GEMM instead of the fp32 library -- measured 5e-6 on A at depth 2
+    tol_logit, tol_a = (2e-5, 2e-5) if precision == "fp32" else (2e-2, 2e-2)
     for b, ((c0, y0, a0), (c1, y1, a1)) in enumerate(zip(ref, got)):
         assert c1.shape == c0.shape and y1.shape == y0.shape and a1.shape == a0.shape
         assert torch.equal(c0, c1)                       # critic scores: same kernel, row-wise
@@ -209,3 +224,27 @@ def test_forward_bags_falls_back_when_not_packable():
         ref = [net(x) for x in bags]
     for (c0, y0, a0), (c1, y1, a1) in zip(ref, got):
         assert torch.equal(c0, c1) and torch.equal(y0, y1) and torch.equal(a0, a1)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+def test_trainer_valid_packs_small_bags(precision, tol):
+    """Trainer.valid with --eval_bags_per_launch 4 against the per-bag loop: same predictions / loss to rounding, for a set that
+    mixes packable chunks, a chunk with a bag shorter than Lambda (forward_bags falls back) and a bag above the pack limit."""
+    from snuffy_amd.train import Snuffy, get_args_parser
+    a = get_args_parser().parse_args([])
+    a.feats_size, a.optimizer, a.num_epochs, a.precision, a.random_patch_share = 384, "adamw", 2, precision, 0.25
+    torch.manual_seed(0)
+    np.random.seed(0)
+    tr = Snuffy(a)
+    sizes = [400, 900, 250, 1300, 600, 150, 700, 800, 5000, 300, 310]
+    g = torch.Generator().manual_seed(4)
+    feats = [torch.randn(n, 384, generator=g).numpy() for n in sizes]
+    labels = [np.array([i % 2], dtype=np.float32) for i in range(len(sizes))]
+    np.random.seed(3)
+    ref = tr.valid((labels, feats))
+    a.eval_bags_per_launch, a.eval_pack_max_patches = 4, 4096
+    np.random.seed(3)
+    got = tr.valid((labels, feats))
+    assert np.abs(ref["predictions"] - got["predictions"]).max() <= tol
+    assert abs(ref["epoch_valid_loss"] - got["epoch_valid_loss"]) <= tol
+    assert np.array_equal(ref["labels"], got["labels"])

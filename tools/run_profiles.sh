@@ -21,6 +21,10 @@ $T python tools/gemm_bench.py cfgB cfgA vit > $O/gemm_bench.txt 2>&1
 $T python tools/gemm_x3_bench.py cfgB cfgA vit > $O/gemm_x3_bench.txt 2>&1
 $T python tools/topk_bench.py > $O/topk_bench.txt 2>&1
 $T python tools/kbench.py x3 > $O/attn_x3_timing.txt 2>&1
+$T python tools/varlen_bench.py > $O/varlen_bench.md 2> $O/varlen_bench.err
+$T bash tools/prof_cmd.sh ${R}_varlen_1k_bf16 python tools/varlen_one.py 1000 384 bf16 64 > $O/prof_varlen_1k_bf16.txt 2>&1
+$T bash tools/prof_cmd.sh ${R}_varlen_8k_f32 python tools/varlen_one.py 8192 384 fp32 16 > $O/prof_varlen_8k_f32.txt 2>&1
+$T bash tools/pmc_vit.sh $O/pmc_vit > $O/vit_mfma_pmc.txt 2>&1
 $T tools/probes/dma_pacing_probe.bin > $O/dma_pacing_probe.txt 2>&1
-for n in f32 bf16 train_bf16 train_f32 vit_bf16; do cp gpurun_out/prof_${R}_$n/p_kernel_stats.csv $O/${n}_kernel_stats.csv 2>/dev/null; done
+for n in f32 bf16 train_bf16 train_f32 vit_bf16 varlen_1k_bf16 varlen_8k_f32; do cp gpurun_out/prof_${R}_$n/p_kernel_stats.csv $O/${n}_kernel_stats.csv 2>/dev/null; done
 tail -4 $O/traffic.txt; head -c 600 $O/bench_cfgB.json

@@ -52,6 +52,24 @@ def gpu_ms(net, bags, steps, graph):
     return e0.elapsed_time(e1) / steps
 
 
+def packed_rate(net, N, D, dev, steps, nbags=16):
+    """slides/s of MILNet.forward_bags over `nbags` bags of N patches (graph replay)."""
+    g = torch.Generator().manual_seed(4321)
+    bags = [torch.randn(1, N, D, generator=g).to(dev) for _ in range(nbags)]
+    net.configure(graph_max_patches=1 << 20)
+    with torch.no_grad():
+        for _ in range(3):
+            net.forward_bags(bags)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            net.forward_bags(bags)
+        e1.record()
+        torch.cuda.synchronize()
+    return nbags * steps * 1e3 / e0.elapsed_time(e1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=30)
@@ -69,29 +87,34 @@ def main():
     print("one MI355X; CPU column: oracle/snuffy_oracle.py (torch-CPU fp32 port of the reference's op sequence) on %s, %d threads of %d cores\n"
           % (cpu_model, args.cpu_threads, os.cpu_count() or 0))
     print("| N | D | K | CPU slides/s | fp32-class slides/s | x CPU | bf16 slides/s | x CPU | fp32 attention µs | frac of 8 TB/s | bf16 attention µs "
-          "| frac (bf16 bytes) | top-Λ µs (in pipeline) | fp32 attn+top-Λ frac (§8(d) bytes) | bf16 attn+top-Λ frac (§8(d) bytes) | bf16 slides/s eager issue |")
-    print("|" + "---|" * 16)
+          "| frac (bf16 bytes) | top-Λ µs (in pipeline) | fp32 attn+top-Λ frac (§8(d) bytes) | bf16 attn+top-Λ frac (§8(d) bytes) | bf16 slides/s eager issue "
+          "| fp32-class, 16 bags per launch | bf16, 16 bags per launch |")
+    print("|" + "---|" * 18)
     for D in (384, 768):
         for N in (1000, 8192, 32768, 100000):
             wl = dict(N=N, D=D, h=6, lam=args.lam)
             nb = max(2, min(8, int(2.0e9 // (N * D * 4))))
             g = torch.Generator().manual_seed(1234)
             bags = [torch.randn(1, N, D, generator=g).to(dev) for _ in range(nb)]
-            ms, roof = {}, {}
+            ms, roof, packed = {}, {}, {}
             for prec in ("fp32", "bf16"):
                 net = build_net(D, 6, args.lam, prec, dev).eval()
                 ms[prec] = gpu_ms(net, bags, args.steps, True)
                 if prec == "bf16":
                     ms["bf16_eager"] = gpu_ms(net, bags, args.steps, False)
+                if N <= 8192:      # small bags: MILNet.forward_bags, 16 bags per set of launches (graph replay)
+                    packed[prec] = packed_rate(net, N, D, dev, args.steps)
                 del net
                 roof[prec] = kernel_rooflines(wl, prec, dev, "sweep")
             cpu = float("nan") if args.no_cpu else cpu_rate(N, D, args.lam, args.cpu_threads)
             rf, rb = roof["fp32"], roof["bf16"]
-            print("| %d | %d | %d | %.2f | %.0f | %.0f | %.0f | %.0f | %.1f | %.3f | %.1f | %.3f | %.1f | %.3f | %.3f | %.0f |"
+            print("| %d | %d | %d | %.2f | %.0f | %.0f | %.0f | %.0f | %.1f | %.3f | %.1f | %.3f | %.1f | %.3f | %.3f | %.0f | %s | %s |"
                   % (N, D, min(args.lam, N), cpu, 1e3 / ms["fp32"], 1e3 / ms["fp32"] / cpu, 1e3 / ms["bf16"], 1e3 / ms["bf16"] / cpu,
                      rf["roofline"]["us_per_launch"], rf["roofline"]["frac"], rb["roofline"]["us_per_launch"], rb["roofline"]["frac"],
                      rb["roofline_topk_attn"]["us_topk"], rf["roofline_topk_attn"]["survey_8d_frac"],
-                     rb["roofline_topk_attn"]["survey_8d_frac"], 1e3 / ms["bf16_eager"]), flush=True)
+                     rb["roofline_topk_attn"]["survey_8d_frac"], 1e3 / ms["bf16_eager"],
+                     "%.0f" % packed["fp32"] if "fp32" in packed else "–", "%.0f" % packed["bf16"] if "bf16" in packed else "–"),
+                  flush=True)
             del bags
             torch.cuda.empty_cache()
 
