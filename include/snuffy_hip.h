@@ -370,7 +370,8 @@ int snf_tile_preprocess_u8(const void* img_u8, int b, int h, int w, int c, int o
  *     top-k and the head are also bit-identical to the single-bag entry points above; the attention launches give small bags
  *     more rows per workgroup than a lone launch would (fewer partial tiles), so against snf_sparse_attn_fwd_mfma / _x3 the
  *     fp32 summation order of the [k, dk] partial tiles can differ (<= 1e-6 relative).
- *   snf_topk_segmented_f32       K2 of every bag (offsets in DEVICE memory; idx_out [bags, k] = indices inside the bag).
+ *   snf_topk_segmented_f32       K2 of every bag (offsets in DEVICE memory; idx_out [bags, k] = indices inside the bag; a bag
+ *                                with fewer than k rows fills its first n_b entries only).
  *   snf_sparse_attn_varlen_plan / snf_sparse_attn_x3_varlen_plan
  *                                host-side geometry of a varlen attention launch: offsets in HOST memory; call with
  *                                table = NULL for the sizes, then with a host buffer of *table_ints_needed int32 words, upload
@@ -395,6 +396,13 @@ int snf_sparse_attn_x3_varlen_plan(const int64_t* offsets, int bags, int k, int 
 int snf_sparse_attn_fwd_x3_varlen(const float* q, int64_t ldq, const float* v, int64_t ldv, const float* kp, const int64_t* offsets,
                                   int bags, int k, int h, int dk, float scale, float* out, float* attn, float* lse,
                                   const int32_t* table_dev, void* workspace, size_t workspace_bytes, snf_stream_t stream);
+/* Ragged form for SMALL bags (exact fp32, any head width, every bag with its own key count: a bag shorter than Lambda selects
+ * all of its rows -- snuffy.py:129 `min(ceil(...), n)` -- as the MIL benchmark sets do).  desc_dev [bags][4] int32 in DEVICE
+ * memory = (first packed row, rows, first key row, keys) per bag; kp / out [sum of keys, h * dk]; attn [h, T, kmax] nullable
+ * (bag b's A = attn[:, row0 : row0 + n, :k]).  kmax <= 256 and (16 + dk) * kmax floats of LDS <= 160 KiB. */
+int snf_sparse_attn_fwd_ragged_f32(const float* q, int64_t ldq, const float* v, int64_t ldv, const float* kp, const int32_t* desc_dev,
+                                   int bags, int64_t n_total, int kmax, int h, int dk, float scale, float* out, float* attn,
+                                   float* lse, snf_stream_t stream);
 int snf_ln_mean_head_varlen_plan(const int64_t* offsets, int bags, int d, int32_t* table, size_t table_ints,
                                  size_t* table_ints_needed, size_t* workspace_bytes);
 int snf_ln_mean_head_varlen_f32(const float* z, const int64_t* offsets, int bags, int d, const void* add_bf16,

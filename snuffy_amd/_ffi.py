@@ -111,6 +111,8 @@ SIGNATURES = {
     "snf_sparse_attn_x3_varlen_plan": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "snf_sparse_attn_fwd_x3_varlen": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                               c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "snf_sparse_attn_fwd_ragged_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, c_int, c_int,
+                                               c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "snf_ln_mean_head_varlen_plan": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "snf_ln_mean_head_varlen_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

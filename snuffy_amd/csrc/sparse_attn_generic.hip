@@ -336,6 +336,76 @@ inline int generic_slices(int64_t n) {
     return (int)s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Ragged varlen form (exact fp32, any head width): many SMALL bags in one launch, every bag with its own number of keys
+// (a bag shorter than Lambda selects all of its rows: K_b = N_b -- the MIL benchmark sets, MUSK / Elephant, live here).
+// One workgroup per (bag, head); rows in chunks of 16: the chunk's probabilities go through LDS, every thread owns a fixed
+// set of output elements O[key, col] (kept in LDS) and adds the chunk's rows in ascending order -> deterministic.
+// desc[bag] = (row0, n, key0, k): first packed row / rows / first key row (= first output row) / keys of the bag.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int RG_ROWS = 16;
+__global__ __launch_bounds__(256) void ragged_attn_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ v,
+                                                          int64_t ldv, const float* __restrict__ kp, const int* __restrict__ desc,
+                                                          int h, int dk, int kmax, float scale, float* __restrict__ out,
+                                                          float* __restrict__ attn /*[h, T, kmax] nullable*/, int64_t n_total,
+                                                          float* __restrict__ lse /*[h, T] nullable*/) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int bag = blockIdx.x, a = blockIdx.y;
+    const int row0 = desc[4 * bag], n = desc[4 * bag + 1], key0 = desc[4 * bag + 2], k = desc[4 * bag + 3];
+    const int64_t d = (int64_t)h * dk;
+    float* lp = lds;                         // [RG_ROWS][kmax] scores, then probabilities
+    float* lo = lds + RG_ROWS * kmax;        // [k][dk] output accumulators
+    const int tid = threadIdx.x;
+    const int nout = k * dk;
+    for (int e = tid; e < nout; e += 256) lo[e] = 0.f;
+    const int r = tid >> 4, l = tid & 15;    // phase 1: 16 threads per row, keys l, l + 16, ...
+    const float* kpa = kp + (int64_t)key0 * d + a * dk;
+    for (int c0 = 0; c0 < n; c0 += RG_ROWS) {
+        const int row = c0 + r;
+        const bool rvalid = row < n;
+        const float* qr = q + (int64_t)(row0 + (rvalid ? row : n - 1)) * ldq + a * dk;
+        float mx = -INFINITY;
+        for (int j = l; j < k; j += 16) {
+            const float* kj = kpa + (int64_t)j * d;
+            float sc = 0.f;
+            for (int c = 0; c < dk; ++c) sc = fmaf(qr[c], kj[c], sc);
+            sc *= scale;
+            lp[r * kmax + j] = sc;
+            mx = fmaxf(mx, sc);
+        }
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+        float sum = 0.f;
+        for (int j = l; j < k; j += 16) {
+            const float e = __expf(lp[r * kmax + j] - mx);
+            lp[r * kmax + j] = e;
+            sum += e;
+        }
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+        const float inv = rvalid ? 1.f / sum : 0.f;
+        for (int j = l; j < k; j += 16) {
+            const float pj = lp[r * kmax + j] * inv;
+            lp[r * kmax + j] = pj;
+            if (attn && rvalid) attn[((int64_t)a * n_total + row0 + row) * kmax + j] = pj;
+        }
+        if (lse && rvalid && l == 0) lse[(int64_t)a * n_total + row0 + row] = mx + __logf(sum);
+        __syncthreads();
+        // phase 2: O[j, c] += sum over the chunk's rows of P[row, j] * V[row, c]
+        const int rows = n - c0 < RG_ROWS ? n - c0 : RG_ROWS;
+        for (int e = tid; e < nout; e += 256) {
+            const int j = e / dk, c = e - j * dk;
+            float acc = lo[e];
+            for (int rr = 0; rr < rows; ++rr)
+                acc = fmaf(lp[rr * kmax + j], v[(int64_t)(row0 + c0 + rr) * ldv + a * dk + c], acc);
+            lo[e] = acc;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < nout; e += 256) {
+        const int j = e / dk, c = e - j * dk;
+        out[(int64_t)(key0 + j) * d + a * dk + c] = lo[e];
+    }
+}
+
 }  // namespace
 
 namespace snf {
@@ -473,6 +543,37 @@ int snf_sparse_attn_fwd_f32(const float* q, const float* kp, const float* v, int
     if (rgrid > 2048) rgrid = 2048;
     hipLaunchKernelGGL(reduce_slices_kernel, dim3(rgrid), dim3(256), 0, s, partial, slices, k, h, dk, out);
     return snf::check_launch("reduce_slices_kernel");
+}
+
+// Ragged varlen attention, exact fp32 (see ragged_attn_kernel).  desc_dev [bags][4] int32 = (row0, n, key0, k) per bag in DEVICE
+// memory; q, v [T, ld] f32, kp [sum k, h * dk] f32; out [sum k, h * dk]; attn [h, T, kmax] / lse [h, T] nullable (a bag's A is
+// attn[:, row0 : row0 + n, :k]).  Limits: kmax <= 256, (16 kmax + kmax dk) floats of LDS <= 160 KiB, i.e. dk <= 144 at kmax = 256.
+int snf_sparse_attn_fwd_ragged_f32(const float* q, int64_t ldq, const float* v, int64_t ldv, const float* kp, const int32_t* desc_dev,
+                                   int bags, int64_t n_total, int kmax, int h, int dk, float scale, float* out, float* attn,
+                                   float* lse, snf_stream_t stream) {
+    SNF_REQUIRE(q && v && kp && out && desc_dev, "snf_sparse_attn_fwd_ragged_f32: null pointer");
+    SNF_REQUIRE(bags >= 1 && bags <= 0x7fffffff && h >= 1 && h <= 65535 && dk >= 1 && kmax >= 1 && n_total >= 1,
+                "snf_sparse_attn_fwd_ragged_f32: bad shape");
+    const size_t lds = ((size_t)RG_ROWS * kmax + (size_t)kmax * dk) * sizeof(float);
+    if (kmax > 256 || lds > 160 * 1024) {
+        snf::set_error("snf_sparse_attn_fwd_ragged_f32: kmax=%d dk=%d needs %zu bytes of LDS (limit 160 KiB, kmax <= 256)", kmax, dk,
+                       lds);
+        return SNF_EUNSUPPORTED;
+    }
+    SNF_REQUIRE(ldq >= (int64_t)h * dk && ldv >= (int64_t)h * dk, "snf_sparse_attn_fwd_ragged_f32: row pitch below h * dk");
+    static thread_local size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ragged_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            snf::set_error("snf_sparse_attn_fwd_ragged_f32: cannot reserve %zu bytes of LDS", lds);
+            (void)hipGetLastError();
+            return SNF_ELAUNCH;
+        }
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(ragged_attn_kernel, dim3((unsigned)bags, (unsigned)h), dim3(256), lds, snf::as_stream(stream), q, ldq, v, ldv,
+                       kp, desc_dev, h, dk, kmax, scale, out, attn, n_total, lse);
+    return snf::check_launch("ragged_attn_kernel");
 }
 
 }  // extern "C"

@@ -320,7 +320,9 @@ __global__ __launch_bounds__(1024) void topk_radix_segmented_kernel(const float*
                                                                     int64_t* __restrict__ idx_out) {
     __shared__ TopkLds<(IPT > 0) ? 4 * 2048 : 2048> L;
     const int64_t lo = offsets[blockIdx.x], hi = offsets[blockIdx.x + 1];
-    topk_radix_body<IPT>(scores + lo, hi - lo, 1, k, idx_out + (int64_t)blockIdx.x * k, L);
+    // a bag shorter than k selects (and orders) all of its rows: entries k_b .. k - 1 of its output row are not written
+    const int kb = hi - lo < k ? (int)(hi - lo) : k;
+    topk_radix_body<IPT>(scores + lo, hi - lo, 1, kb, idx_out + (int64_t)blockIdx.x * k, L);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -593,13 +595,14 @@ int snf_topk_f32(const float* scores, int64_t n, int64_t stride, int k, int64_t*
 }
 
 // top-k of every bag of a packed score vector in ONE launch (varlen path).  offsets [bags + 1] int64 in DEVICE memory, max_n =
-// the longest bag (picks the register budget), every bag needs at least k scores.  idx_out [bags, k]: indices inside the bag.
+// the longest bag (picks the register budget).  idx_out [bags, k]: indices inside the bag; a bag with n_b < k scores fills only
+// its first n_b entries (all of its rows, ordered).
 int snf_topk_segmented_f32(const float* scores, const int64_t* offsets_dev, int bags, int64_t max_n, int k, int64_t* idx_out,
                            snf_stream_t stream) {
     SNF_REQUIRE(scores && offsets_dev && idx_out, "snf_topk_segmented_f32: null pointer");
     SNF_REQUIRE(bags >= 1 && max_n >= 1 && max_n < 0x3fffffffll, "snf_topk_segmented_f32: bad bags=%d max_n=%lld", bags,
                 (long long)max_n);
-    SNF_REQUIRE(k >= 1 && k <= max_n && k <= RS_MAXK, "snf_topk_segmented_f32: need 1 <= k <= min(max_n, %d) (k=%d)", RS_MAXK, k);
+    SNF_REQUIRE(k >= 1 && k <= RS_MAXK, "snf_topk_segmented_f32: need 1 <= k <= %d (k=%d)", RS_MAXK, k);
     hipStream_t s = snf::as_stream(stream);
     const dim3 grid((unsigned)bags), wg(1024);
     if (max_n <= 1024 * 8)

@@ -348,12 +348,14 @@ def _rows_linear(x, lin):
     return F.linear(x, lin.weight, lin.bias)
 
 
-def encoder_layer(x2, sel, layer, need_attn, precision, packed=None):
+def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None):
     """EncoderLayer.forward (snuffy.py:126-157) for x2 [N, D] and selected rows sel [K].  Returns (Parts, A).
 
     packed (ops.PackedBags, inference only): x2 holds the rows of B bags and sel the B x K selected rows in packed coordinates
     (bag b's K rows at sel[b K : (b + 1) K]).  Everything row-wise runs once over the packed rows; only the attention changes
-    kernel entry (one varlen launch: every bag attends to its own K keys).  A is then [1, h, T, K] over the packed rows."""
+    kernel entry (one varlen launch: every bag attends to its own K keys).  A is then [1, h, T, K] over the packed rows.
+    ragged (ops.RaggedKeys, with packed): the bags select different numbers of rows (sel is their concatenation) -- small bags,
+    exact-fp32 ragged attention kernel, A [1, h, T, Kmax] with bag b's columns 0 .. K_b - 1 valid."""
     if packed is None and torch.is_grad_enabled() and (x2.requires_grad or any(p.requires_grad for p in layer.parameters())):
         from . import autograd as SA  # training path (custom backward kernels); also when only the input asks for a gradient
         return SA.encoder_layer_train(x2, sel, layer, need_attn, precision)
@@ -362,7 +364,11 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None):
     h = mha.h
     k = sel.shape[0]
     kb = k // packed.bags if packed is not None else k            # keys of ONE bag
-    if packed is not None and (kb < 1 or not ops.varlen_attn_supported(precision, kb, d // h)):
+    if ragged is not None:
+        if packed is None or ragged.total != k or not ops.ragged_attn_supported(ragged.kmax, d // h):
+            raise SnuffyHipError("ragged packed bags: %d keys (max %d per bag) at head width %d is outside the ragged attention "
+                                 "kernel" % (k, ragged.kmax, d // h))
+    elif packed is not None and (kb < 1 or not ops.varlen_attn_supported(precision, kb, d // h)):
         raise SnuffyHipError("packed bags: %d keys per bag at head width %d is outside the varlen attention kernels" % (kb, d // h))
     n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
     lq, lk, lv, lo = mha.linears
@@ -397,7 +403,9 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None):
             qv = ops.gemm_x3(xn3, fw["wqv"], fw["bqv"], out_dtype=torch.float32)
         del xn3
         q, v = qv[:, :d], qv[:, d:]
-        if packed is not None:
+        if ragged is not None:
+            o, attn, _ = ops.sparse_attn_fwd_ragged(q, v, kp, packed, ragged, h, need_attn=need_attn)
+        elif packed is not None:
             o, attn, _ = ops.sparse_attn_fwd_x3_varlen(q, v, kp, packed, kb, h, need_attn=need_attn)
         elif FP32_ATTENTION == "x3" and ops.x3_attn_supported(k, d // h):
             o, attn, _ = ops.sparse_attn_fwd_x3(q, v, kp, h, need_attn=need_attn)    # snuffy.py:160-168
@@ -427,7 +435,9 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None):
         xn = ops.layernorm_rows(x2, n0.weight, n0.bias, n0.eps)                     # snuffy.py:107
         q = F.linear(xn, lq.weight, lq.bias)
         v = F.linear(xn, lv.weight, lv.bias)
-        if packed is not None:
+        if ragged is not None:
+            o, attn, _ = ops.sparse_attn_fwd_ragged(q, v, kp, packed, ragged, h, need_attn=need_attn)
+        elif packed is not None:
             o, attn, _ = ops.sparse_attn_fwd_x3_varlen(q, v, kp, packed, kb, h, need_attn=need_attn)
         elif FP32_ATTENTION == "x3" and ops.x3_attn_supported(k, d // h):
             o, attn, _ = ops.sparse_attn_fwd_x3(q, v, kp, h, need_attn=need_attn)    # snuffy.py:160-168, fp32-class on MFMA
@@ -456,7 +466,7 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None):
         ops.layernorm_rows(x2, None, None, n0.eps, out=xhat)
     qv = ops.linear_bf16(xhat, fw["wqv"], fw["bqv_f"], fw["bqv"])                   # [N, 2D] bf16 = [Q | V], bias epilogue
     q, v = qv[:, :d], qv[:, d:]                                                     # row-strided views, used in place
-    if packed is not None or ops.mfma_attn_supported(k, d // h, n, qv.stride(0)):
+    if ragged is None and (packed is not None or ops.mfma_attn_supported(k, d // h, n, qv.stride(0))):
         # keys = RAW selected rows: the gather also leaves them in bf16, the projection runs like Q | V (bf16 operands,
         # fp32 accumulate, bf16 out) and the attention kernel reads Kp as it is
         xs, slot, xs16 = ops.gather_slot_map(x2, sel, bf16_copy=True)               # snuffy.py:131,145-147 (+ row -> slot map)
@@ -468,7 +478,12 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None):
     else:
         xs, slot = ops.gather_slot_map(x2, sel)
         kp = _rows_linear(xs, lk)
-        o, attn, _ = ops.sparse_attn_fwd(q.float(), kp, v.float(), h, need_attn=need_attn)
+        if ragged is not None:
+            qvf = qv.float()
+            o, attn, _ = ops.sparse_attn_fwd_ragged(qvf[:, :d], qvf[:, d:], kp, packed, ragged, h, need_attn=need_attn)
+            del qvf
+        else:
+            o, attn, _ = ops.sparse_attn_fwd(q.float(), kp, v.float(), h, need_attn=need_attn)
     del q, v, qv
     delta = _rows_linear(o, lo)
     x_sel = xs + delta

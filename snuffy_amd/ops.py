@@ -638,6 +638,14 @@ class PackedBags:
     def _host_ptr(self):
         return ctypes.c_void_p(self.host.ctypes.data)
 
+    def ragged(self, kbs):
+        """RaggedKeys for per-bag key counts `kbs` (cached)."""
+        key = ("ragged",) + tuple(int(k) for k in kbs)
+        hit = self._plans.get(key)
+        if hit is None:
+            hit = self._plans[key] = RaggedKeys(self, kbs)
+        return hit
+
     def plan(self, kind, *shape):
         """(device table int32, workspace bytes) of a segmented launch: kind in {"mfma", "x3", "head"}."""
         import numpy as np
@@ -657,6 +665,69 @@ class PackedBags:
         return hit
 
 
+class RaggedKeys:
+    """Per-bag key counts of a packed batch whose bags do not all select the same number of rows (bags shorter than Lambda select
+    all of theirs): key-row offsets, the kernel's per-bag descriptors and the index helpers that turn the padded [B, k] output of
+    topk_segmented() into the flat list of selected rows in packed coordinates."""
+
+    def __init__(self, packed, kbs):
+        import numpy as np
+        kbs = [int(k) for k in kbs]
+        if len(kbs) != packed.bags or any(k < 1 or k > n for k, n in zip(kbs, packed.sizes)):
+            raise ValueError("RaggedKeys: need 1 <= k_b <= n_b for every bag")
+        self.kbs = kbs
+        self.kmax = max(kbs)
+        self.koff = np.zeros(packed.bags + 1, dtype=np.int64)
+        np.cumsum(kbs, out=self.koff[1:])
+        self.total = int(self.koff[-1])
+        desc = np.stack([packed.host[:-1], np.asarray(packed.sizes), self.koff[:-1], np.asarray(kbs)], axis=1).astype(np.int32)
+        self.desc = torch.from_numpy(np.ascontiguousarray(desc)).to(packed.device)
+        self._row0 = packed.host[:-1].copy()
+        self._np = np
+
+    def flat_index(self, pitch):
+        """(positions of the valid entries in a padded [B, pitch] array, first packed row of each entry's bag), device int64."""
+        np = self._np
+        hit = getattr(self, "_flat", None)
+        if hit is None or hit[0] != pitch:
+            pos = np.concatenate([b * pitch + np.arange(k, dtype=np.int64) for b, k in enumerate(self.kbs)])
+            base = np.repeat(self._row0, self.kbs)
+            hit = self._flat = (pitch, torch.from_numpy(pos).to(self.desc.device), torch.from_numpy(base).to(self.desc.device))
+        return hit[1], hit[2]
+
+
+def ragged_attn_supported(kmax, dk):
+    return 1 <= kmax <= 256 and (16 + dk) * kmax * 4 <= 160 * 1024
+
+
+def sparse_attn_fwd_ragged(q, v, kp, packed, rag, h, scale=None, need_attn=False, need_lse=False):
+    """Exact-fp32 sparse attention of B packed SMALL bags with per-bag key counts (snf_sparse_attn_fwd_ragged_f32).  q, v [T, d]
+    f32 (row-strided views allowed), kp [sum K_b, d] f32 -> (out [sum K_b, d], attn [h, T, kmax] or None, lse [h, T] or None);
+    bag b's probabilities are attn[:, row0 : row0 + n_b, :K_b]."""
+    if q.dtype != torch.float32 or v.dtype != torch.float32:
+        raise TypeError("sparse_attn_fwd_ragged: q and v must be float32")
+    q = _req_nc(q, "q")
+    v = _req_nc(v, "v")
+    if q.stride(1) != 1:
+        q = q.contiguous()
+    if v.stride(1) != 1:
+        v = v.contiguous()
+    kp = _req(kp, torch.float32, "kp", 2)
+    t, d = q.shape
+    if t != packed.total or v.shape != q.shape or kp.shape != (rag.total, d) or d % h:
+        raise ValueError("sparse_attn_fwd_ragged: q %s v %s kp %s do not match %d packed rows / %d keys"
+                         % (tuple(q.shape), tuple(v.shape), tuple(kp.shape), packed.total, rag.total))
+    dk = d // h
+    scale = 1.0 / math.sqrt(dk) if scale is None else scale
+    out = torch.empty(rag.total, d, dtype=torch.float32, device=q.device)
+    attn = torch.empty(h, t, rag.kmax, dtype=torch.float32, device=q.device) if need_attn else None
+    lse = torch.empty(h, t, dtype=torch.float32, device=q.device) if need_lse else None
+    check(_ffi.load().snf_sparse_attn_fwd_ragged_f32(_p(q), q.stride(0), _p(v), v.stride(0), _p(kp), _p(rag.desc), packed.bags, t,
+                                                     rag.kmax, h, dk, float(scale), _p(out), _p(attn), _p(lse), _stream()),
+          "snf_sparse_attn_fwd_ragged_f32")
+    return out, attn, lse
+
+
 def varlen_attn_supported(precision_kind, k, dk):
     """Single key chunk only: k <= 224 (dk = 128) / 256 (dk = 64); the fp32-class kernel is built for 2, 4, 7 (8) key blocks."""
     return (dk == 128 and 1 <= k <= 224) or (dk == 64 and 1 <= k <= 256)
@@ -664,12 +735,12 @@ def varlen_attn_supported(precision_kind, k, dk):
 
 def topk_segmented(scores, packed, k):
     """Top-k of every bag of a packed score vector in one launch: [B, k] int64 indices INSIDE each bag (descending score, ties
-    by ascending index -- the same one-workgroup kernel body as topk(), one workgroup per bag)."""
+    by ascending index -- the same one-workgroup kernel body as topk(), one workgroup per bag).  A bag with fewer than k rows fills
+    only its first n_b entries (all of its rows, ordered); the rest of its output row is uninitialised."""
     scores = _req(scores, torch.float32, "scores", 1)
     k = int(k)
-    if scores.shape[0] != packed.total or not (1 <= k <= min(packed.sizes)) or k > TOPK_MAX_K:
-        raise ValueError("topk_segmented: %d scores for %d packed rows, k=%d, shortest bag %d"
-                         % (scores.shape[0], packed.total, k, min(packed.sizes)))
+    if scores.shape[0] != packed.total or not (1 <= k <= TOPK_MAX_K):
+        raise ValueError("topk_segmented: %d scores for %d packed rows, k=%d" % (scores.shape[0], packed.total, k))
     idx = torch.empty(packed.bags, k, dtype=torch.int64, device=scores.device)
     check(_ffi.load().snf_topk_segmented_f32(_p(scores), _p(packed.dev), packed.bags, packed.max_n, k, _p(idx), _stream()),
           "snf_topk_segmented_f32")

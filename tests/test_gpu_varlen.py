@@ -248,3 +248,110 @@ def test_trainer_valid_packs_small_bags(precision, tol):
     assert np.abs(ref["predictions"] - got["predictions"]).max() <= tol
     assert abs(ref["epoch_valid_loss"] - got["epoch_valid_loss"]) <= tol
     assert np.array_equal(ref["labels"], got["labels"])
+
+
+# ---- ragged groups: bags shorter than Lambda (they select all their rows) and head widths outside the MFMA kernels --------------
+def test_topk_segmented_with_bags_shorter_than_k():
+    from snuffy_amd import ops
+    sizes = [5, 300, 1, 40, 200, 199]
+    pk = _packed(sizes)
+    g = torch.Generator().manual_seed(6)
+    s = torch.randn(pk.total, generator=g)
+    s[::5] = s[1]
+    s = s.to(DEV)
+    got = ops.topk_segmented(s, pk, 200)
+    for b, n in enumerate(sizes):
+        lo = int(pk.host[b])
+        kb = min(200, n)
+        c = s[lo:lo + n].cpu().numpy()
+        order = np.lexsort((np.arange(n), -c))[:kb]
+        assert np.array_equal(got[b, :kb].cpu().numpy(), order), (b, n)
+
+
+@pytest.mark.parametrize("d,h", [(166, 2), (230, 2), (384, 6), (64, 1)])
+def test_ragged_attention_vs_exact_per_bag(d, h):
+    from snuffy_amd import ops
+    sizes = [5, 40, 1, 17, 300, 2, 33]
+    kbs = [min(200, n) for n in sizes]
+    pk = _packed(sizes)
+    rag = pk.ragged(kbs)
+    g = torch.Generator().manual_seed(8)
+    q = torch.randn(pk.total, d, generator=g).to(DEV)
+    v = torch.randn(pk.total, d, generator=g).to(DEV)
+    kp = (torch.randn(sum(kbs), d, generator=g) * 0.5).to(DEV)
+    out, attn, lse = ops.sparse_attn_fwd_ragged(q, v, kp, pk, rag, h, need_attn=True, need_lse=True)
+    assert out.shape == (sum(kbs), d) and attn.shape == (h, pk.total, max(kbs))
+    for b, n in enumerate(sizes):
+        lo, k0, kb = int(pk.host[b]), int(rag.koff[b]), kbs[b]
+        o1, a1, l1 = ops.sparse_attn_fwd(q[lo:lo + n], kp[k0:k0 + kb], v[lo:lo + n], h, need_attn=True, need_lse=True)
+        assert (out[k0:k0 + kb] - o1).abs().max().item() <= 2e-5 * max(1.0, o1.abs().max().item()), (b, n)
+        assert (attn[:, lo:lo + n, :kb] - a1).abs().max().item() <= 2e-6
+        assert (lse[:, lo:lo + n] - l1).abs().max().item() <= 2e-5
+    # and the definition (fp64), one bag
+    b = 4
+    lo, n, k0, kb, dk = int(pk.host[b]), sizes[b], int(rag.koff[b]), kbs[b], d // h
+    qd = q[lo:lo + n].double().view(n, h, dk).transpose(0, 1)
+    vd = v[lo:lo + n].double().view(n, h, dk).transpose(0, 1)
+    kd = kp[k0:k0 + kb].double().view(kb, h, dk).transpose(0, 1)
+    p = torch.softmax(qd @ kd.transpose(1, 2) / dk ** 0.5, dim=-1)
+    ref = (p.transpose(1, 2) @ vd).transpose(0, 1).reshape(kb, d)
+    assert (out[k0:k0 + kb].double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+def _musk_like(n_bags, d, seed):
+    rs = np.random.RandomState(seed)
+    sizes = [int(v) for v in rs.randint(2, 41, n_bags)]
+    sizes[3] = 1
+    return sizes
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("d,h,depth", [(166, 2, 1), (230, 2, 2)])
+def test_forward_bags_on_a_musk_shaped_set(precision, d, h, depth):
+    """The MIL benchmark shape (train.py:993-995: D = 166 / 230, --num_heads 2, bags of 1-40 instances, all shorter than
+    Lambda = 200 so every row is selected): 40 bags in one set of launches against the per-bag forwards and the oracle."""
+    sizes = _musk_like(40, d, 3)
+    net = _net(d, h, 200, 0.0, depth, precision)
+    bags = _bags(sizes, d, seed=12)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        groups = net._pack_groups(bags)
+        assert groups == [(list(range(len(bags))), True)]
+        got = net.forward_bags(bags)
+        top, _ = net.b_classifier.encoder.layers[0].last_selection_bags
+        ref = [net(x) for x in bags]
+    tol = 2e-5 if precision == "fp32" else 2e-2
+    for b, ((c0, y0, a0), (c1, y1, a1)) in enumerate(zip(ref, got)):
+        n = sizes[b]
+        assert c1.shape == c0.shape and y1.shape == y0.shape and a1.shape == a0.shape == (1, h, n, n)
+        assert torch.equal(c0, c1)
+        assert (y0 - y1).abs().max().item() <= tol * max(1.0, y0.abs().max().item()), b
+        assert (a0 - a1).abs().max().item() <= tol
+        if precision == "fp32" and b < 8:
+            classes, logits, attn, sels = orc.milnet_forward(bags[b][0].cpu(), sd, h, "relu", 200, 0.0, depth)
+            assert np.array_equal(sels[0].numpy(), top[b, :n].cpu().numpy())
+            assert (y1[0].cpu() - logits).abs().max().item() <= 1e-4 * max(1.0, logits.abs().max().item())
+            assert (a1[0].cpu() - attn).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_forward_bags_mixes_uniform_and_ragged_groups(precision):
+    sizes = [1000, 150, 2000, 60, 180, 700, 5000]
+    net = _net(384, 6, 200, 0.0, 1, precision)
+    bags = _bags(sizes, 384, seed=13)
+    with torch.no_grad():
+        groups = net._pack_groups(bags)
+        assert groups == [([0, 2, 5, 6], False), ([1, 3, 4], True)]
+        got = net.forward_bags(bags)
+        net.configure(graph_max_patches=1 << 16)
+        got_graph = net.forward_bags(bags)
+        got_graph2 = net.forward_bags(bags)
+        net.configure(graph_max_patches=0)
+        ref = [net(x) for x in bags]
+    tol = 2e-5 if precision == "fp32" else 2e-2
+    for b, ((c0, y0, a0), (c1, y1, a1), (c2, y2, a2), (c3, y3, a3)) in enumerate(zip(ref, got, got_graph, got_graph2)):
+        assert a1.shape == a0.shape
+        assert torch.equal(c0, c1)
+        assert (y0 - y1).abs().max().item() <= tol * max(1.0, y0.abs().max().item()), b
+        assert (a0 - a1).abs().max().item() <= tol
+        assert torch.equal(y1, y2) and torch.equal(a1, a2) and torch.equal(y2, y3)      # graph replay == eager issue, bit for bit
