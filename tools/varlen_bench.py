@@ -55,6 +55,29 @@ def main():
                               flush=True)
                 del net, pool
                 torch.cuda.empty_cache()
+    musk_like(dev, args.steps)
+
+
+def musk_like(dev, steps):
+    """The MIL benchmark shape (train.py:993-995): 92 bags of 2-40 instances, D = 166, --num_heads 2, Lambda = 200 (every row of a
+    bag is selected): one bag per forward against all 92 in one set of launches."""
+    import numpy as np
+    rs = np.random.RandomState(0)
+    sizes = [int(v) for v in rs.randint(2, 41, 92)]
+    g = torch.Generator().manual_seed(5)
+    print("\n| set | arithmetic | per bag, eager (slides/s) | per bag, graph replay | packed, eager | packed, graph replay |")
+    print("|" + "---|" * 6)
+    for prec in ("fp32", "bf16"):
+        net = build_net(166, 2, 200, prec, dev).eval()
+        bags = [torch.randn(1, n, 166, generator=g).to(dev) for n in sizes]
+        with torch.no_grad():
+            net.configure(graph_max_patches=0)
+            e_bag = rate(lambda: [net(x) for x in bags], len(bags), steps)
+            e_pk = rate(lambda: net.forward_bags(bags), len(bags), steps)
+            net.configure(graph_max_patches=1 << 16)
+            g_bag = rate(lambda: [net(x) for x in bags], len(bags), steps)
+            g_pk = rate(lambda: net.forward_bags(bags), len(bags), steps)
+        print("| 92 bags x 2-40 instances, D=166, h=2 | %s | %.0f | %.0f | %.0f | %.0f |" % (prec, e_bag, g_bag, e_pk, g_pk), flush=True)
 
 
 if __name__ == "__main__":
