@@ -170,6 +170,12 @@ int snf_split3_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16
 int snf_colsum_blocks(int64_t n);
 int snf_colsum_fused(const void* src, int src_dtype, int64_t n, int d, const float* row_weight, int64_t weight_stride,
                      const void* gate_bf16, void* dst_bf16, float* partial, snf_stream_t stream);
+/* critic scores + LayerNorm (with affine) of the same rows in one pass, the normalised rows as the interleaved hi / lo image
+ * (= snf_critic_f32 + snf_layernorm_rows_hl_f32 with one read of x; FCLayer.forward snuffy.py:39-41 + SublayerConnection.norm
+ * snuffy.py:107).  d % 32 == 0; selector_state nullable (one class: also counts the selector's first radix digit). */
+int snf_critic_ln_hl_f32(const float* x, int64_t n, int d, const float* w, const float* b, int c_out, float* scores,
+                         const float* gamma, const float* beta, float eps, void* out_hl, void* selector_state,
+                         snf_stream_t stream);
 int snf_layernorm_rows_split3_f32(const float* x, int64_t n, int d, const int32_t* slot_map, const float* patch_rows,
                                   const float* gamma, const float* beta, float eps, void* out_bf16, snf_stream_t stream);
 

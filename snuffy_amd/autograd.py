@@ -205,8 +205,8 @@ class LinearX3Fn(torch.autograd.Function):
     hi hi + hi lo + lo hi of the operands' bf16 halves with fp32 accumulation (~1e-5 per product, as functional.FP32_GEMM = "x3"):
       forward   the split image [hi | hi | lo] of x against [Wh | Wl | Wh]                     (ops.gemm_bf16, one launch)
       dx        the split image of dy against the same image of W^T                            (ops.gemm_bf16)
-      dW        [dyh | dyl]^T [xh | xl] over the bag axis -- the two images' last two column blocks, in place -- as ONE library
-                GEMM with an fp32 result; dW = the three blocks hi hi + hi lo + lo hi (lo lo is computed and dropped)
+      dW        dyh^T xh + dyh^T xl + dyl^T xh over the bag axis -- column blocks of the two images, in place -- as three library
+                GEMMs with fp32 results (lo lo is never computed)
     The image of x (bf16 [n, 3 k]) is what is saved for the backward."""
 
     @staticmethod
@@ -227,8 +227,13 @@ class LinearX3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_x3(dimg, SF.split3_cached(weight, transposed=True), None, out_dtype=torch.float32)
         if ctx.needs_input_grad[1]:
-            g = _tn_mm_f32(dimg[:, n_out:], img[:, k:])                     # [dyh | dyl]^T [xh | xl] -> [2 out, 2 k]
-            dw = g[:n_out, :k] + g[:n_out, k:] + g[n_out:, :k]
+            # dyh^T xh + dyh^T xl + dyl^T xh over the bag axis: three fp32-output GEMMs on column blocks of the two images, in place
+            # (one GEMM over [dyh | dyl]^T [xh | xl] also computes the dropped lo lo block: a quarter more work, measured 682 vs 3 x 170 us)
+            dyh, dyl = dimg[:, n_out:2 * n_out], dimg[:, 2 * n_out:]
+            xh, xl = img[:, k:2 * k], img[:, 2 * k:]
+            dw = _tn_mm_f32(dyh, xh)
+            dw += _tn_mm_f32(dyh, xl)
+            dw += _tn_mm_f32(dyl, xh)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum(0)
         return dx, dw, db

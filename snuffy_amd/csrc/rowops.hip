@@ -89,12 +89,16 @@ __device__ __forceinline__ void store_row_bf16(unsigned short* __restrict__ row,
 // ---------------------------------------------------------------------------------------------------------------
 // LN = also emit the row-normalised bf16 copy (x - mean) * rstd that the first encoder layer needs (its LayerNorm affine is
 // folded into the projection weights): the bag is read from HBM once for both, instead of once per kernel.
-template <int VEC, int NV, bool LN>
+// LN == 2 (fp32-class path): emit LayerNorm(x) WITH its affine as the interleaved hi / lo image the one-pass GEMM reads
+// (the output of snf_layernorm_rows_hl_f32 up to the last fp32 place of the normalised value) instead of the affine-free bf16 copy.
+template <int VEC, int NV, int LN>
 __global__ __launch_bounds__(WG) void critic_kernel(const float* __restrict__ x, int64_t n, int d,
                                                     const float* __restrict__ w, const float* __restrict__ b,
                                                     int c_out, float* __restrict__ scores, float eps,
                                                     unsigned short* __restrict__ xhat,
-                                                    unsigned int* __restrict__ sel_hist) {
+                                                    unsigned int* __restrict__ sel_hist,
+                                                    const float* __restrict__ gamma = nullptr,
+                                                    const float* __restrict__ beta = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const float inv_d = 1.0f / (float)d;
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(WG) void critic_kernel(const float* __restrict__ x,
             acc = wave_sum(acc);
             if (lane == 0) scores[row * c_out + c] = acc + (b ? b[c] : 0.f);
         }
-        if constexpr (LN) {   // same arithmetic, in the same order, as layernorm_rows_kernel without affine
+        if constexpr (LN != 0) {   // same arithmetic, in the same order, as layernorm_rows_kernel
             float s1 = 0.f;
 #pragma unroll
             for (int i = 0; i < NV * VEC; ++i) s1 += r[i];
@@ -157,7 +161,33 @@ __global__ __launch_bounds__(WG) void critic_kernel(const float* __restrict__ x,
             const float rstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
             for (int i = 0; i < NV * VEC; ++i) r[i] = (r[i] - mean) * rstd;
-            store_row_bf16<VEC, NV>(xhat + row * d, d, lane, r);
+            if constexpr (LN == 1) store_row_bf16<VEC, NV>(xhat + row * d, d, lane, r);
+            if constexpr (LN == 2 && VEC == 4) {
+                // affine (the registers that held the critic weights' row are free again only after the loop: gamma / beta are
+                // re-read per row from L1 / L2 -- 2 x d floats against the d floats of the row itself)
+                float g[NV * VEC], bt[NV * VEC];
+                load_row<VEC, NV>(gamma, d, lane, g);
+                load_row<VEC, NV>(beta, d, lane, bt);
+#pragma unroll
+                for (int i = 0; i < NV * VEC; ++i) {
+                    r[i] = fmaf(r[i], g[i], bt[i]);
+                }
+                unsigned short* o2 = xhat + row * 2 * d;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int e = (i * 64 + lane) * 4;
+                    if (e < d) {
+                        uint2 hi, lo;
+                        hi.x = pack_bf16x2(r[i * 4], r[i * 4 + 1]);
+                        hi.y = pack_bf16x2(r[i * 4 + 2], r[i * 4 + 3]);
+                        lo.x = pack_bf16x2(r[i * 4] - __uint_as_float(hi.x << 16), r[i * 4 + 1] - __uint_as_float(hi.x & 0xffff0000u));
+                        lo.y = pack_bf16x2(r[i * 4 + 2] - __uint_as_float(hi.y << 16), r[i * 4 + 3] - __uint_as_float(hi.y & 0xffff0000u));
+                        unsigned short* o = o2 + 64 * (e >> 5) + (e & 31);
+                        *reinterpret_cast<uint2*>(o) = hi;
+                        *reinterpret_cast<uint2*>(o + 32) = lo;
+                    }
+                }
+            }
         }
     }
     if (sel_hist) {
@@ -1092,7 +1122,7 @@ int snf_critic_f32(const float* x, int64_t n, int d, const float* w, const float
     RowCfg cfg;
     SNF_REQUIRE(pick_row_cfg(d, aligned16(x) && aligned16(w), &cfg), "snf_critic_f32: d=%d too wide (max 2048)", d);
     hipStream_t s = snf::as_stream(stream);
-    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((critic_kernel<VEC, NV, false>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w,
+    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((critic_kernel<VEC, NV, 0>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w,
                                               b, c_out, scores, 0.f, (unsigned short*)nullptr, (unsigned int*)nullptr));
     int rc = snf::check_launch("critic_kernel");
     if (rc) return rc;
@@ -1111,7 +1141,7 @@ int snf_critic_ln_f32(const float* x, int64_t n, int d, const float* w, const fl
     SNF_REQUIRE(pick_row_cfg(d, aligned16(x) && aligned16(w) && aligned16(xhat_bf16), &cfg),
                 "snf_critic_ln_f32: d=%d too wide (max 2048)", d);
     hipStream_t s = snf::as_stream(stream);
-    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((critic_kernel<VEC, NV, true>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w,
+    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((critic_kernel<VEC, NV, 1>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w,
                                               b, c_out, scores, eps, reinterpret_cast<unsigned short*>(xhat_bf16),
                                               (unsigned int*)nullptr));
     return snf::check_launch("critic_kernel<ln>");
@@ -1128,13 +1158,48 @@ int snf_critic_select_f32(const float* x, int64_t n, int d, const float* w, cons
     hipStream_t s = snf::as_stream(stream);
     unsigned int* hist = reinterpret_cast<snf::SelectorState*>(selector_state)->hist;
     if (xhat_bf16) {
-        SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((critic_kernel<VEC, NV, true>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w, b,
+        SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((critic_kernel<VEC, NV, 1>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w, b,
                                                   1, scores, eps, reinterpret_cast<unsigned short*>(xhat_bf16), hist));
     } else {
-        SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((critic_kernel<VEC, NV, false>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w,
+        SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((critic_kernel<VEC, NV, 0>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w,
                                                   b, 1, scores, 0.f, (unsigned short*)nullptr, hist));
     }
     return snf::check_launch("critic_kernel<select>");
+}
+
+// critic + LayerNorm (with affine) of the same rows in ONE pass over the bag, the normalised rows leaving as the interleaved
+// hi / lo image of the one-pass fp32-class GEMM (= snf_critic_f32 + snf_layernorm_rows_hl_f32, one HBM read of x instead of two).
+// selector_state nullable: when given (one class), the first radix digit of the scores is counted as in snf_critic_select_f32.
+int snf_critic_ln_hl_f32(const float* x, int64_t n, int d, const float* w, const float* b, int c_out, float* scores,
+                         const float* gamma, const float* beta, float eps, void* out_hl, void* selector_state,
+                         snf_stream_t stream) {
+    SNF_REQUIRE(x && w && scores && gamma && beta && out_hl, "snf_critic_ln_hl_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && d >= 32 && d % 32 == 0 && c_out >= 1, "snf_critic_ln_hl_f32: bad shape n=%lld d=%d c=%d (d % 32 == 0)",
+                (long long)n, d, c_out);
+    SNF_REQUIRE(!selector_state || (c_out == 1 && aligned16(selector_state)), "snf_critic_ln_hl_f32: the selector needs one class "
+                "and a 16-byte aligned state");
+    SNF_REQUIRE(aligned16(x) && aligned16(w) && aligned16(gamma) && aligned16(beta) && aligned16(out_hl),
+                "snf_critic_ln_hl_f32: buffers must be 16-byte aligned");
+    RowCfg cfg;
+    SNF_REQUIRE(pick_row_cfg(d, true, &cfg) && cfg.vec == 4, "snf_critic_ln_hl_f32: d=%d too wide (max 2048)", d);
+    hipStream_t s = snf::as_stream(stream);
+    unsigned int* hist = selector_state ? reinterpret_cast<snf::SelectorState*>(selector_state)->hist : nullptr;
+    switch (cfg.nv) {
+#define SNF_CRITIC_HL_CASE(N)                                                                                              \
+    case N:                                                                                                                 \
+        hipLaunchKernelGGL((critic_kernel<4, N, 2>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d, w, b, c_out, scores, eps,  \
+                           reinterpret_cast<unsigned short*>(out_hl), hist, gamma, beta);                                   \
+        break;
+        SNF_CRITIC_HL_CASE(1)
+        SNF_CRITIC_HL_CASE(2)
+        SNF_CRITIC_HL_CASE(3)
+        SNF_CRITIC_HL_CASE(4)
+        SNF_CRITIC_HL_CASE(6)
+        default:
+            SNF_CRITIC_HL_CASE(8)
+#undef SNF_CRITIC_HL_CASE
+    }
+    return snf::check_launch("critic_kernel<ln, hl>");
 }
 
 int snf_layernorm_rows_f32(const float* x, int64_t n, int d, const int32_t* slot_map, const float* patch_rows,

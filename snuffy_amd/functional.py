@@ -111,6 +111,40 @@ def critic_scores_with_xhat(feats, w, b, eps, layer):
     return s.view(*lead, w.shape[0])
 
 
+def hl_layer_eligible(layer, n, d):
+    """The fp32-class encoder layer takes the one-pass GEMMs on interleaved images for a bag of n rows (encoder_layer's test)."""
+    ff = layer.feed_forward
+    f = ff.w_1.weight.shape[0]
+    return (FP32_GEMM == "x3" and d % 32 == 0 and f % 32 == 0 and ops.gemm_supported(n, d, 3 * ff.w_2.weight.shape[1])
+            and ops.gemm_supported(n, 2 * d, 3 * d) and ops.hl_eligible(n, 2 * d, d) and ops.hl_eligible(n, f, d)
+            and ops.hl_eligible(n, d, f))
+
+
+def critic_scores_with_hl(feats, w, b, layer):
+    """critic_scores() of the fp32-class path that also leaves LayerNorm_0(x) -- with its affine, as the interleaved hi / lo image
+    of the one-pass GEMM -- on `layer` for encoder_layer(): one read of the bag instead of two (snf_critic_ln_hl_f32)."""
+    lead = feats.shape[:-1]
+    f2 = feats.reshape(-1, feats.shape[-1])
+    n0 = layer.sublayer[0].norm
+    if (not f2.is_cuda or f2.dtype != torch.float32 or not f2.is_contiguous() or n0.weight is None or n0.bias is None
+            or not hl_layer_eligible(layer, f2.shape[0], f2.shape[1])):
+        layer._xn3_offer = None
+        return critic_scores(feats, w, b)
+    s, img = ops.critic_ln_hl(f2, w, b, n0.weight, n0.bias, n0.eps)
+    layer._xn3_offer = (f2.data_ptr(), tuple(f2.shape), f2._version, float(n0.eps), n0.weight.data_ptr(), n0.weight._version,
+                        n0.bias.data_ptr(), n0.bias._version, img)
+    return s.view(*lead, w.shape[0])
+
+
+def _take_xn3(layer, x2, n0):
+    offer = getattr(layer, "_xn3_offer", None)
+    layer._xn3_offer = None
+    if offer is not None and offer[:8] == (x2.data_ptr(), tuple(x2.shape), x2._version, float(n0.eps), n0.weight.data_ptr(),
+                                           n0.weight._version, n0.bias.data_ptr(), n0.bias._version):
+        return offer[8]
+    return None
+
+
 def _take_xhat(layer, x2, eps):
     offer = getattr(layer, "_xhat_offer", None)
     layer._xhat_offer = None
@@ -336,6 +370,7 @@ def invalidate_folded(layer):
     layer._fold = None
     layer._fold3 = None
     layer._xhat_offer = None
+    layer._xn3_offer = None
 
 
 def _rows_linear(x, lin):
@@ -395,8 +430,10 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
         fh = _hl_weights(layer, fw) if hl else None
         xs, slot = ops.gather_slot_map(x2, sel)                                     # snuffy.py:131,145-147 (+ row -> slot map)
         kp = _rows_linear(xs, lk)                                       # keys = RAW selected rows (K rows: fp32)
+        xn3 = _take_xn3(layer, x2, n0)                                              # left by the critic pass, if any
         if hl:
-            xn3 = ops.layernorm_rows_hl(x2, n0.weight, n0.bias, n0.eps)             # snuffy.py:107
+            if xn3 is None:
+                xn3 = ops.layernorm_rows_hl(x2, n0.weight, n0.bias, n0.eps)         # snuffy.py:107
             qv = ops.gemm_hl(xn3, fh["wqv"], fw["bqv"])                             # [N, 2D] f32 = [Q | V]
         else:
             xn3 = ops.layernorm_rows_split3(x2, n0.weight, n0.bias, n0.eps)

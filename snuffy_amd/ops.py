@@ -141,6 +141,33 @@ def critic_select(x, w, b, eps=None):
     return scores, xhat
 
 
+def critic_ln_hl(x, w, b, gamma, beta, eps):
+    """One pass over the bag for the fp32-class path: (scores [n, c] f32, LayerNorm(x) with its affine as the interleaved hi / lo
+    image [n, 2 d] bf16 -- the operand layernorm_rows_hl() would produce, to the last fp32 place of the normalised value).  With one class and a bag long enough for
+    the fused selector the pass also counts the selector's histogram (the following topk() starts from it)."""
+    x = _req(x, torch.float32, "x", 2)
+    w = _req(w, torch.float32, "w", 2)
+    if b is not None:
+        b = _req(b, torch.float32, "b", 1)
+    gamma = _req(gamma, torch.float32, "gamma", 1)
+    beta = _req(beta, torch.float32, "beta", 1)
+    n, d = x.shape
+    c = w.shape[0]
+    if w.shape[1] != d or d % 32:
+        raise ValueError("critic_ln_hl: w is %s, x has %d features (need d %% 32 == 0)" % (tuple(w.shape), d))
+    sel = selector(x.device) if (c == 1 and SELECT_FUSED_MIN_N <= n < (1 << 30)) else None
+    if sel is not None and sel.pending is not None:
+        sel.state.zero_()
+        sel.pending = None
+    scores = torch.empty(n, c, dtype=torch.float32, device=x.device)
+    img = torch.empty(n, 2 * d, dtype=torch.bfloat16, device=x.device)
+    check(_ffi.load().snf_critic_ln_hl_f32(_p(x), n, d, _p(w), _p(b), c, _p(scores), _p(gamma), _p(beta), float(eps), _p(img),
+                                           _p(sel.state) if sel is not None else None, _stream()), "snf_critic_ln_hl_f32")
+    if sel is not None:
+        sel.pending = (scores.data_ptr(), n, scores._version)
+    return scores, img
+
+
 def topk(scores, k, x=None):
     """Indices of the k largest scores, descending, ties by ascending index (snuffy.py:128-130).
 

@@ -272,6 +272,7 @@ class MILNet(nn.Module):
     def _forward_eager(self, x):
         for layer in self.b_classifier.encoder.layers[:1]:
             layer._xhat_offer = None        # a normalised copy left by an earlier forward is never valid for this bag
+            layer._xn3_offer = None
         feats, classes = self._critic(x)
         prediction_bag, A = self.b_classifier(feats, classes)
         return classes, prediction_bag, A
@@ -607,6 +608,12 @@ class MILNet(nn.Module):
             lin = ic.fc[0]
             eps = self.b_classifier.encoder.layers[0].sublayer[0].norm.eps
             return x, SF.critic_scores_with_xhat(x, lin.weight, lin.bias, eps, self.b_classifier.encoder.layers[0])
+        if (type(ic) is FCLayer and cfg is not None and cfg.precision == "fp32" and not torch.is_grad_enabled()
+                and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 3 and x.shape[0] == 1
+                and len(self.b_classifier.encoder.layers) > 0 and type(self.b_classifier.encoder.layers[0]) is EncoderLayer):
+            # fp32-class inference on large bags: the critic pass also emits LayerNorm_0(x) as the image of the Q|V projection
+            lin = ic.fc[0]
+            return x, SF.critic_scores_with_hl(x, lin.weight, lin.bias, self.b_classifier.encoder.layers[0])
         if (type(ic) is FCLayer and cfg is not None and cfg.precision == "bf16" and torch.is_grad_enabled()
                 and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 3 and x.shape[0] == 1 and not x.requires_grad
                 and x.dtype == torch.float32 and x.is_contiguous() and len(self.b_classifier.encoder.layers) > 0):

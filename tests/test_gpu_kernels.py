@@ -611,3 +611,35 @@ def test_training_attention_is_reproducible_under_manual_seed():
         outs.append((o.detach().clone(), q.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert not torch.equal(outs[0][0], outs[2][0])
+
+
+@pytest.mark.parametrize("n,d", [(1000, 384), (20000, 768), (333, 64), (40000, 1024)])
+def test_critic_ln_hl_one_pass_equals_the_two_kernels(n, d):
+    """snf_critic_ln_hl_f32 (fp32-class path: critic + LayerNorm_0 with affine -> interleaved hi / lo image, one read of the bag)
+    against snf_critic_f32 + snf_layernorm_rows_hl_f32: scores bit for bit; the image to the last fp32 bit of the normalised
+    value (the two kernels' row statistics can differ in the last place, which shows in ~1 % of the lo halves and, where a value
+    sits on a bf16 rounding boundary, moves hi by one step with lo compensating -- the same 2^-17 class either way); above the
+    fused-selector threshold the top-k that follows starts from the histogram the pass counted."""
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(n + d)
+    x = (torch.randn(n, d, generator=g) * 2 + 0.3).to(DEV)
+    w = (torch.randn(1, d, generator=g) / d ** 0.5).to(DEV)
+    b = torch.randn(1, generator=g).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(d, generator=g)).to(DEV)
+    s, img = ops.critic_ln_hl(x, w, b, gamma, beta, 1e-5)
+    s_ref = ops.critic(x, w, b)
+    img_ref = ops.layernorm_rows_hl(x, gamma, beta, 1e-5)
+    assert torch.equal(s, s_ref)
+
+    def value(im):
+        v = im.view(n, d // 32, 2, 32).float()
+        return (v[:, :, 0] + v[:, :, 1]).reshape(n, d)
+    v1, v2 = value(img), value(img_ref)
+    assert (v1 - v2).abs().max().item() <= 2.0 ** -14 * max(1.0, v2.abs().max().item())
+    assert (img.view(torch.int16) != img_ref.view(torch.int16)).float().mean().item() < 0.03
+    exact = torch.nn.functional.layer_norm(x.double(), (d,), gamma.double(), beta.double(), 1e-5)
+    assert (v1.double() - exact).abs().max().item() <= 2.0 ** -14 * max(1.0, exact.abs().max().item())
+    top = ops.topk(s.view(-1), 200)
+    ref = torch.sort(s_ref.view(-1), descending=True, stable=True)[1][:200]
+    assert torch.equal(top, ref)

@@ -423,3 +423,24 @@ def test_runner_epoch_loop_checkpoints_and_test_pass(tmp_path):
     twin.load_state_dict(sd, strict=True)                       # the reference's key names, strict
     w = torch.load(run / "single_weight_parameter_3", map_location="cpu")
     assert 0.0 <= float(w) <= 1.0
+
+
+@pytest.mark.parametrize("n,k,m", [(4096, 768, 1536), (1000, 384, 384), (8200, 256, 1024)])
+def test_linear_x3_fn_forward_and_gradients_vs_fp64(n, k, m):
+    """autograd.LinearX3Fn (fp32-class linear of the fp32 training path): y, dx, dW, db against fp64 -- products to 2^-17, fp32
+    accumulation over up to 8 k rows; dW as three block GEMMs over the images' hi / lo column blocks."""
+    from snuffy_amd import autograd as SA
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, k, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(m, k, generator=g) / k ** 0.5).to(DEV).requires_grad_(True)
+    b = torch.randn(m, generator=g).to(DEV).requires_grad_(True)
+    dy = torch.randn(n, m, generator=g).to(DEV)
+    assert SA.linear_x3_ok(x, w)
+    y = SA.LinearX3Fn.apply(x, w, b)
+    y.backward(dy)
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    yd = torch.nn.functional.linear(xd, wd, bd)
+    yd.backward(dy.double())
+    for name, got, ref in (("y", y, yd), ("dx", x.grad, xd.grad), ("dw", w.grad, wd.grad), ("db", b.grad, bd.grad)):
+        err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 3e-5, (name, err)
