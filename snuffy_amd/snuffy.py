@@ -418,15 +418,33 @@ class MILNet(nn.Module):
         uniform_dims = (d % 4 == 0 and SF.ops.varlen_attn_supported(cfg.precision, k1 + k2, d // h)
                         and (cfg.precision == "bf16" or SF.FP32_ATTENTION == "x3"))
         if k2 > 0:
-            ok = uniform_dims and min(sizes) >= k1 + k2 and max(sizes) <= 65536 and (k1 + k2) * len(bags) <= (1 << 20)
+            ok = (uniform_dims and min(sizes) >= k1 + k2 and max(sizes) <= 65536 and (k1 + k2) * len(bags) <= (1 << 20)
+                  and sum(sizes) <= self._PACK_MAX_ROWS)      # one group only: the draws must stay in bag order
             return [(list(range(len(bags))), False)] if ok else None
         uni = [i for i, n in enumerate(sizes) if uniform_dims and k1 <= n <= 65536]
         rest = [i for i in range(len(bags)) if i not in set(uni)]
         rag = [i for i in rest if sizes[i] <= self._RAGGED_MAX_ROWS]
         if rag and not SF.ops.ragged_attn_supported(min(k1, max(sizes[i] for i in rag)), d // h):
             rag = []
-        groups = [(g, r) for g, r in ((uni, False), (rag, True)) if len(g) >= 2]
+        groups = []
+        for g, r in ((uni, False), (rag, True)):
+            groups += [(c, r) for c in self._chunk_rows(g, sizes) if len(c) >= 2]
         return groups or None
+
+    _PACK_MAX_ROWS = 196608     # rows of one packed launch set: the GEMMs address their [T, 3F] images with 32-bit element offsets
+
+    def _chunk_rows(self, idx, sizes):
+        """Split a group into consecutive chunks of at most _PACK_MAX_ROWS packed rows."""
+        chunks, cur, rows = [], [], 0
+        for i in idx:
+            if cur and rows + sizes[i] > self._PACK_MAX_ROWS:
+                chunks.append(cur)
+                cur, rows = [], 0
+            cur.append(i)
+            rows += sizes[i]
+        if cur:
+            chunks.append(cur)
+        return chunks
 
     def _packable(self, bags):
         """True when forward_bags() runs ALL of `bags` as one uniform packed batch."""

@@ -355,3 +355,17 @@ def test_forward_bags_mixes_uniform_and_ragged_groups(precision):
         assert (y0 - y1).abs().max().item() <= tol * max(1.0, y0.abs().max().item()), b
         assert (a0 - a1).abs().max().item() <= tol
         assert torch.equal(y1, y2) and torch.equal(a1, a2) and torch.equal(y2, y3)      # graph replay == eager issue, bit for bit
+
+
+def test_forward_bags_splits_large_batches_into_row_capped_chunks():
+    net = _net(384, 6, 200, 0.0, 1, "bf16")
+    net._PACK_MAX_ROWS = 5000
+    sizes = [2000, 2500, 1000, 3000, 1500, 4000, 900, 800]
+    bags = _bags(sizes, 384, seed=14)
+    with torch.no_grad():
+        groups = net._pack_groups(bags)
+        assert groups == [([0, 1], False), ([2, 3], False), ([5, 6], False)]       # 4 and 7 end up alone: per-bag forwards
+        got = net.forward_bags(bags)
+        ref = [net(x) for x in bags]
+    for (c0, y0, a0), (c1, y1, a1) in zip(ref, got):
+        assert torch.equal(c0, c1) and (y0 - y1).abs().max().item() <= 2e-2 and (a0 - a1).abs().max().item() <= 2e-2
