@@ -82,6 +82,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // x (8 fp32) -> hi = bf16(x), lo = bf16(x - hi)
 __device__ __forceinline__ void split8(const f32x8 x, u32x4& hi, u32x4& lo) {
+#ifdef X3_ABL_NOSPLIT   // timing ablation (tools/x3_ablate.sh): two cheap packs instead of the split, wrong numbers
+    const u32x4 a = __builtin_bit_cast(u32x4, f32x4{x[0], x[2], x[4], x[6]}), b = __builtin_bit_cast(u32x4, f32x4{x[1], x[3], x[5], x[7]});
+    hi = (a >> 16) | (b & 0xffff0000u);
+    lo = (a & 0xffffu) | (b << 16);
+    return;
+#endif
     const bf16x8 h = __builtin_convertvector(x, bf16x8);
     const f32x8 r = x - __builtin_convertvector(h, f32x8);
     hi = __builtin_bit_cast(u32x4, h);
