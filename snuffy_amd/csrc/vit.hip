@@ -44,6 +44,38 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const int gh = H / ps, gw = W / ps;
     const int64_t total = (int64_t)B * C * gh * ps * gw;  // number of ps-long segments
     const int kdim = C * ps * ps;
+    // every segment starts on a 16-byte boundary in both tensors when ps and W are multiples of 4 and the bases are aligned
+    const bool vec = (ps & 3) == 0 && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(cols) & 15) == 0;
+    if (vec) {
+        // one thread per 4 pixels, consecutive threads on consecutive pixels of an image row: fully coalesced 16-byte loads, and the
+        // ps / 4 threads of a segment write its 2 ps (bf16) or 4 ps (f32) bytes side by side
+        const int qps = ps >> 2;
+        const int64_t quads = total * qps;
+        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)gridDim.x * blockDim.x) {
+            const int j = (int)(q % qps) * 4;
+            const int64_t s = q / qps;
+            const int gx = (int)(s % gw);
+            int64_t t = s / gw;
+            const int i = (int)(t % ps);
+            t /= ps;
+            const int gy = (int)(t % gh);
+            t /= gh;
+            const int c = (int)(t % C);
+            const int b = (int)(t / C);
+            const float4 v = *reinterpret_cast<const float4*>(img + (((int64_t)b * C + c) * H + (gy * ps + i)) * W + gx * ps + j);
+            const int64_t off = (((int64_t)b * gh + gy) * gw + gx) * kdim + (c * ps + i) * ps + j;
+            if (BF16) {
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16_bits(v.x) | ((unsigned)f32_to_bf16_bits(v.y) << 16);
+                o.y = (unsigned)f32_to_bf16_bits(v.z) | ((unsigned)f32_to_bf16_bits(v.w) << 16);
+                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(cols) + off) = o;
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(cols) + off) = v;
+            }
+        }
+        return;
+    }
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (int64_t)gridDim.x * blockDim.x) {
         // decompose with gx fastest: neighbouring threads read neighbouring segments of one image row (coalesced)
         int gx = (int)(s % gw);
@@ -74,6 +106,34 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(const void* __rest
                                                               float* __restrict__ tokens) {
     const int T = P + 1;
     const int64_t total = (int64_t)B * T * D;
+    if ((D & 3) == 0 && ((reinterpret_cast<uintptr_t>(pe) | reinterpret_cast<uintptr_t>(cls) | reinterpret_cast<uintptr_t>(pos) |
+                          reinterpret_cast<uintptr_t>(tokens)) & 15) == 0) {
+        // four features per thread: 16-byte loads / stores (same values as the scalar form below)
+        const int dq = D >> 2;
+        const int64_t quads = total >> 2;
+        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)gridDim.x * blockDim.x) {
+            const int d = (int)(q % dq) * 4;
+            const int64_t r = q / dq;
+            const int t = (int)(r % T);
+            const int b = (int)(r / T);
+            float4 v;
+            if (t == 0) {
+                v = *reinterpret_cast<const float4*>(cls + d);
+            } else {
+                const int64_t src = ((int64_t)b * P + (t - 1)) * D + d;
+                if (BF16) {
+                    const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(pe) + src);
+                    v = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16),
+                                    __uint_as_float(h.y & 0xffff0000u));
+                } else {
+                    v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(pe) + src);
+                }
+            }
+            const float4 pz = *reinterpret_cast<const float4*>(pos + (int64_t)t * D + d);
+            *reinterpret_cast<float4*>(tokens + q * 4) = make_float4(v.x + pz.x, v.y + pz.y, v.z + pz.z, v.w + pz.w);
+        }
+        return;
+    }
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         int d = (int)(e % D);
         int64_t r = e / D;
