@@ -88,7 +88,7 @@ def main():
           % (cpu_model, args.cpu_threads, os.cpu_count() or 0))
     print("| N | D | K | CPU slides/s | fp32-class slides/s | x CPU | bf16 slides/s | x CPU | fp32 attention µs | frac of 8 TB/s | bf16 attention µs "
           "| frac (bf16 bytes) | top-Λ µs (in pipeline) | fp32 attn+top-Λ frac (§8(d) bytes) | bf16 attn+top-Λ frac (§8(d) bytes) | bf16 slides/s eager issue "
-          "| fp32-class, 16 bags per launch | bf16, 16 bags per launch |")
+          "| fp32-class packed (64 bags per launch at N = 1000, 16 at 8192) | bf16 packed |")
     print("|" + "---|" * 18)
     for D in (384, 768):
         for N in (1000, 8192, 32768, 100000):
@@ -103,7 +103,7 @@ def main():
                 if prec == "bf16":
                     ms["bf16_eager"] = gpu_ms(net, bags, args.steps, False)
                 if N <= 8192:      # small bags: MILNet.forward_bags, 16 bags per set of launches (graph replay)
-                    packed[prec] = packed_rate(net, N, D, dev, args.steps)
+                    packed[prec] = packed_rate(net, N, D, dev, args.steps, nbags=64 if N <= 1024 else 16)
                 del net
                 roof[prec] = kernel_rooflines(wl, prec, dev, "sweep")
             cpu = float("nan") if args.no_cpu else cpu_rate(N, D, args.lam, args.cpu_threads)
