@@ -68,6 +68,7 @@ def pack_groups(net, bags):
 
 
 PACK_MAX_ROWS = 196608      # rows of one packed launch set: the GEMMs address their [T, 3F] images with 32-bit element offsets
+PACKED_GRAPHS = 32          # captured batch compositions kept per model (oldest dropped first)
 
 
 def chunk_rows(net, idx, sizes):
@@ -150,6 +151,13 @@ def forward_bags_graph(net, rows, sizes, ragged=False):
     ent = net._graphs.get(key)
     if ent is None:
         packed = packed_cache(net, sizes, dev)
+        if key not in net._graph_seen:
+            # a composition is captured only when it comes back (a capture costs three extra forwards and pins a [T, D] buffer):
+            # a loader that never repeats a batch stays on the eager path
+            if len(net._graph_seen) > 8192:
+                net._graph_seen.clear()
+            net._graph_seen.add(key)
+            return split_packed(forward_packed_raw(net, torch.cat(rows), packed, ragged), packed)
         static_x = torch.cat(rows)
         try:
             cur = torch.cuda.current_stream()
@@ -173,6 +181,9 @@ def forward_bags_graph(net, rows, sizes, ragged=False):
             return split_packed(forward_packed_raw(net, torch.cat(rows), packed, ragged), packed)
         if len(net._graphs) >= net._GRAPH_SHAPES:
             net._graphs.pop(next(iter(net._graphs)))
+        held = [k for k in net._graphs if k and k[0] == "bags"]
+        if len(held) >= PACKED_GRAPHS:                 # every packed graph pins its own packed input buffer
+            net._graphs.pop(held[0])
         ent = net._graphs[key] = (graph, static_x, out, packed)
     graph, static_x, out, packed = ent
     torch.cat(rows, out=static_x)

@@ -344,8 +344,10 @@ def test_forward_bags_mixes_uniform_and_ragged_groups(precision):
         assert groups == [([0, 2, 5, 6], False), ([1, 3, 4], True)]
         got = net.forward_bags(bags)
         net.configure(graph_max_patches=1 << 16)
-        got_graph = net.forward_bags(bags)
-        got_graph2 = net.forward_bags(bags)
+        net.forward_bags(bags)                        # first sight of a composition: eager (remembered)
+        got_graph = net.forward_bags(bags)            # second: captured and replayed
+        got_graph2 = net.forward_bags(bags)           # third: replay only
+        assert sum(1 for k in net._graphs if k and k[0] == "bags") == 2      # one graph per group
         net.configure(graph_max_patches=0)
         ref = [net(x) for x in bags]
     tol = 2e-5 if precision == "fp32" else 2e-2
