@@ -325,7 +325,10 @@ class Trainer:
 
         per_launch = int(getattr(self.args, 'eval_bags_per_launch', 1) or 1)
         pack_max = int(getattr(self.args, 'eval_pack_max_patches', 16384))
-        can_pack = per_launch > 1 and hasattr(self.milnet, 'forward_bags') and hasattr(self, '_outputs_to_loss')
+        # a subclass that overrides _run_model with the reference's two-argument signature keeps the one-bag-per-forward loop
+        import inspect
+        can_pack = (per_launch > 1 and hasattr(self.milnet, 'forward_bags') and hasattr(self, '_outputs_to_loss')
+                    and 'outputs' in inspect.signature(self._run_model).parameters)
         pos = 0
         while pos < len(mine):
             chunk = [load(i) for i in mine[pos:pos + (per_launch if can_pack else 1)]]
