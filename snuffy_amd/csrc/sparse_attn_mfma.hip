@@ -93,6 +93,7 @@ int snf_sparse_attn_fwd_mfma_dropout(const void* q, int64_t ldq, const void* v, 
     P.n_stride = n;
     P.vl = nullptr;
     P.vl_bags = 0;
+    P.out_direct = nullptr;
     P.partial = reinterpret_cast<float*>(workspace);
     P.trace = g_attn_trace;
     P.trace_wg = g_attn_trace_wg;
@@ -232,9 +233,11 @@ int snf_sparse_attn_fwd_mfma_varlen(const void* q, int64_t ldq, const void* v, i
     P.drop = snf::make_dropout(0.f, 0, 0);
     P.n_stride = total;
     P.vl = table_dev, P.vl_bags = bags;
+    P.out_direct = out;
     Plan pl;
     pl.num_wg = (int)vp.total_wg, pl.nkb = vp.nkb;
     pl.tiles_per_head = pl.tiles_per_wg = pl.total_tiles = pl.seg_count = 0;
+    if (vp.all_direct) pl.tiles_per_head = -1;   // launch_variant: no reduction pass
     return dk == 128 ? snf::attn_launch_varlen_dk128(P, pl, out, s) : snf::attn_launch_varlen_dk64(P, pl, out, s);
 }
 

@@ -66,6 +66,10 @@ struct AttnParams {
     // varlen launch (many bags in one grid, VL kernels): table of VL_DESC ints per bag, then the bag of every workgroup
     const int* vl;
     int vl_bags;
+    // varlen: output [rows, h * dk] for bags whose heads fit ONE workgroup each (descriptor flag 10: tiles_per_wg == tiles_per_head):
+    // such a workgroup holds the head's complete [k, dk] result and stores it straight to its place -- no partial tile, no
+    // reduction pass for that bag (a 64 x 1000-patch batch spent 29 us copying single partial tiles).  Null: always partials.
+    float* out_direct;
 };
 // One bag of a varlen launch.  The grid is the concatenation of per-bag grids: every bag keeps a plan of its own (make_plan with
 // packed = true, a function of the bag's length only) and workgroup wg0 + i does what workgroup i of a launch of that bag alone
@@ -73,7 +77,7 @@ struct AttnParams {
 // is packed with, bit for bit.  Against the single-bag entry points (latency plan: one tile per workgroup for small bags) only
 // the fp32 summation order of the partial tiles can differ.
 constexpr int VL_DESC = 12;   // wg0, row0, n, out_row0 (= first Kp / output row), tiles_per_head, tiles_per_wg, total_tiles,
-                              // seg_count, part0 (first partial slot), num_wg, 0, 0
+                              // seg_count, part0 (first partial slot), num_wg, direct (one workgroup per head), 0
 struct Plan {
     int num_wg, tiles_per_head, tiles_per_wg, total_tiles, seg_count, nkb;
 };
@@ -220,6 +224,7 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams PA) {
         P.total_tiles = dsc[6];
         P.seg_count = dsc[7];
         P.partial = PA.partial + (int64_t)dsc[8] * (NKB * (DK / 32)) * 1024;
+        P.out_direct = (PA.out_direct && dsc[10]) ? PA.out_direct + (int64_t)dsc[3] * ((int64_t)PA.h * DK) : nullptr;
     }
     constexpr int NCB = DK / 32;             // 32-wide column blocks of the output
     constexpr int NT = (NKB * NCB + 3) / 4;  // output tiles owned by one pooling wave
@@ -606,6 +611,25 @@ __global__ __launch_bounds__(512) void sparse_attn_mfma_kernel(AttnParams PA) {
             });
         };
         auto flush = [&](int head) __attribute__((always_inline)) {
+            if constexpr (VL) {
+                if (P.out_direct) {   // this workgroup owns the whole head: registers 4 q4 + i of tile (kb, cb) = O[32 kb + i + 8 q4 + 4 hf, 32 cb + j]
+                    const int64_t ld = (int64_t)P.h * DK;
+#pragma unroll
+                    for (int ti = 0; ti < NT; ++ti) {
+                        const int t_idx = w + 4 * ti;
+                        if (t_idx < NKB * NCB) {
+                            const int kb_ = t_idx / NCB, cb_ = t_idx - kb_ * NCB;
+                            float* dcol = P.out_direct + head * DK + 32 * cb_ + j;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int key = 32 * kb_ + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                                if (key < P.k) dcol[(int64_t)key * ld] = acc_o[ti][r];
+                            }
+                        }
+                    }
+                    return;
+                }
+            }
             const int seg = head - first_head;
             float* dst = P.partial + ((int64_t)bid * P.seg_count + seg) * (int64_t)(NKB * NCB) * 1024;
 #pragma unroll
@@ -795,11 +819,12 @@ template <int DK, int NKB>
 __global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __restrict__ partial, int num_wg, int seg_count,
                                                               int tiles_per_head, int tiles_per_wg, int total_tiles,
                                                               int k, int h, float* __restrict__ out,
-                                                              const int* __restrict__ vl = nullptr) {
+                                                              const int* __restrict__ vl = nullptr, int direct_bags = 0) {
     constexpr int NCB = DK / 32;
     constexpr int TILES = NKB * NCB;
     if (vl) {   // varlen: blockIdx.z = bag; the bag's own launch geometry, partial slots and output rows
         const int* __restrict__ dsc = vl + VL_DESC * blockIdx.z;
+        if (dsc[10] && direct_bags) return;   // the main kernel stored this bag's heads itself
         tiles_per_head = dsc[4], tiles_per_wg = dsc[5], total_tiles = dsc[6], seg_count = dsc[7], num_wg = dsc[9];
         partial += (int64_t)dsc[8] * TILES * 1024;
         out += (int64_t)dsc[3] * (h * DK);
@@ -898,10 +923,11 @@ int launch_variant(const AttnParams& P, const Plan& pl, float* out, hipStream_t 
     int rc = snf::check_launch("sparse_attn_mfma_kernel");
     if (rc) return rc;
     constexpr int TILES = NKB * (DK / 32);
+    if (VL && P.out_direct && pl.tiles_per_head == -1) return SNF_OK;   // every bag stored its heads itself (make_varlen_plan)
     // varlen: pl.num_wg is the whole grid (all bags), one reduction slice (blockIdx.z) per bag
     hipLaunchKernelGGL((reduce_partials_kernel<DK, NKB>), dim3(TILES * 4, P.h, VL ? P.vl_bags : 1), dim3(64), 0, s, P.partial,
                        pl.num_wg, pl.seg_count, pl.tiles_per_head, pl.tiles_per_wg, pl.total_tiles, P.k, P.h, out,
-                       VL ? P.vl : nullptr);
+                       VL ? P.vl : nullptr, (VL && P.out_direct) ? 1 : 0);
     return snf::check_launch("reduce_partials_kernel");
 }
 
@@ -940,20 +966,23 @@ int launch_nkb_varlen(const AttnParams& P, const Plan& pl, float* out, hipStream
 struct VarlenPlan {
     int64_t total_wg, partial_slots;   // workgroups of the whole launch; partial tiles-slots (num_wg * seg_count summed)
     int nkb;
+    bool all_direct;                   // every bag has one workgroup per head: no reduction pass at all
 };
 inline bool make_varlen_plan(const int64_t* offsets, int bags, int k, int h, int dk, VarlenPlan* vp, int32_t* table,
                              size_t table_ints) {
-    vp->total_wg = 0, vp->partial_slots = 0, vp->nkb = 0;
+    vp->total_wg = 0, vp->partial_slots = 0, vp->nkb = 0, vp->all_direct = true;
     for (int b = 0; b < bags; ++b) {
         const int64_t n = offsets[b + 1] - offsets[b];
         Plan pl;
         if (n < 1 || offsets[b] > 0x7fffffffll || !make_plan(n, k, h, dk, &pl, true)) return false;
+        const bool direct = pl.tiles_per_wg == pl.tiles_per_head;   // workgroup i of the bag = head i, whole
+        vp->all_direct = vp->all_direct && direct;
         if (table) {
             if ((size_t)(VL_DESC * bags) + (size_t)(vp->total_wg + pl.num_wg) > table_ints) return false;
             int32_t* d = table + (size_t)VL_DESC * b;
             d[0] = (int32_t)vp->total_wg, d[1] = (int32_t)offsets[b], d[2] = (int32_t)n, d[3] = b * k;
             d[4] = pl.tiles_per_head, d[5] = pl.tiles_per_wg, d[6] = pl.total_tiles, d[7] = pl.seg_count;
-            d[8] = (int32_t)vp->partial_slots, d[9] = pl.num_wg, d[10] = 0, d[11] = 0;
+            d[8] = (int32_t)vp->partial_slots, d[9] = pl.num_wg, d[10] = direct ? 1 : 0, d[11] = 0;
             for (int i = 0; i < pl.num_wg; ++i) table[(size_t)VL_DESC * bags + vp->total_wg + i] = b;
         }
         vp->total_wg += pl.num_wg;

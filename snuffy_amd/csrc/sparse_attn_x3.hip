@@ -62,11 +62,14 @@ struct X3Params {
     int64_t n_stride;  // rows per head of attn / lse (= n; the packed row count of a varlen launch)
     const int* vl;     // varlen launch: [bags][VL_DESC] descriptors, then the bag of every workgroup (see below)
     int vl_bags;
+    float* out_direct; // varlen: output [rows, h * dk] for bags with one workgroup per head (descriptor flag 10): stored straight from the
+                       // accumulators, no partial tile and no reduction pass for that bag; null = always partials
 };
 // Varlen launch (many bags in one grid, single key chunk): the grid is the concatenation of per-bag grids -- every bag keeps a
 // plan of its own (x3_plan with packed = true, a function of its length only), so a bag's result does not depend on what it is
 // packed with, bit for bit; against snf_sparse_attn_fwd_x3 only the fp32 summation order of the partial tiles can differ.
-// descriptor: wg0, row0, n, out_row0 (first Kp / output row), tiles_per_head, tiles_per_wg, total_tiles, seg_count, part0, num_wg
+// descriptor: wg0, row0, n, out_row0 (first Kp / output row), tiles_per_head, tiles_per_wg, total_tiles, seg_count, part0, num_wg,
+// direct (tiles_per_wg == tiles_per_head: workgroup i of the bag is head i, whole)
 constexpr int VL_DESC = 12;
 
 constexpr int TROWS = 64;   // query rows per step (two 32-row blocks)
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params PA) {
         if (PA.lse) P.lse = PA.lse + row0;
         P.tiles_per_head = dsc[4], P.tiles_per_wg = dsc[5], P.total_tiles = dsc[6], P.seg_count = dsc[7];
         P.partial = PA.partial + (int64_t)dsc[8] * (NKB * (DK / 32)) * 1024;
+        P.out_direct = (PA.out_direct && dsc[10]) ? PA.out_direct + (int64_t)dsc[3] * ((int64_t)PA.h * DK) : nullptr;
     }
     constexpr int NCB = DK / 32;               // 32-wide column blocks of the output
     constexpr int TILES = NKB * NCB;
@@ -264,6 +268,25 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params PA) {
             for (int r = 0; r < 16; ++r) acc_o[ti][r] = 0.f;
     };
     auto flush = [&](int head) __attribute__((always_inline)) {
+        if constexpr (VL) {
+            if (P.out_direct) {   // the whole head is in this workgroup: register 4 q4 + i of tile (kb, cb) = O[32 kb + i + 8 q4 + 4 hf, 32 cb + j]
+                const int64_t ld = (int64_t)P.h * DK;
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) {
+                    const int t_idx = w + 8 * ti;
+                    if (t_idx < TILES) {
+                        const int kb_ = t_idx / NCB, cb_ = t_idx - kb_ * NCB;
+                        float* dcol = P.out_direct + head * DK + 32 * cb_ + j;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = 32 * kb_ + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                            if (key < P.k) dcol[(int64_t)key * ld] = acc_o[ti][r];
+                        }
+                    }
+                }
+                return;
+            }
+        }
         const int seg = head - first_head;
         float* dst = P.partial + ((int64_t)bid * P.seg_count + seg) * (int64_t)TILES * 1024;
 #pragma unroll
@@ -470,10 +493,11 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params PA) {
 template <int DK, int NKB>
 __global__ __launch_bounds__(64) void x3_reduce_kernel(const float* __restrict__ partial, int num_wg, int seg_count,
                                                         int tiles_per_head, int tiles_per_wg, int k, int h, float* __restrict__ out,
-                                                        const int* __restrict__ vl = nullptr) {
+                                                        const int* __restrict__ vl = nullptr, int direct_bags = 0) {
     constexpr int NCB = DK / 32, TILES = NKB * NCB;
     if (vl) {   // varlen: blockIdx.z = bag
         const int* __restrict__ dsc = vl + VL_DESC * blockIdx.z;
+        if (dsc[10] && direct_bags) return;   // the main kernel stored this bag's heads itself
         tiles_per_head = dsc[4], tiles_per_wg = dsc[5], seg_count = dsc[7], num_wg = dsc[9];
         partial += (int64_t)dsc[8] * TILES * 1024;
         out += (int64_t)dsc[3] * (h * DK);
@@ -563,8 +587,10 @@ int x3_launch(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s) {
     int rc = snf::check_launch("sparse_attn_x3_kernel");
     if (rc || MODE == 1) return rc;
     constexpr int TILES = NKB * (DK / 32);
+    if (VL && P.out_direct && pl.tiles_per_head == -1) return SNF_OK;   // every bag stored its heads itself (x3_varlen_plan)
     hipLaunchKernelGGL((x3_reduce_kernel<DK, NKB>), dim3(TILES * 4, P.h, VL ? P.vl_bags : 1), dim3(64), 0, s, P.partial, pl.num_wg,
-                       pl.seg_count, pl.tiles_per_head, pl.tiles_per_wg, P.k, P.h, out, VL ? P.vl : nullptr);
+                       pl.seg_count, pl.tiles_per_head, pl.tiles_per_wg, P.k, P.h, out, VL ? P.vl : nullptr,
+                       (VL && P.out_direct) ? 1 : 0);
     return snf::check_launch("x3_reduce_kernel");
 }
 template <int DK>
@@ -589,20 +615,23 @@ int x3_dispatch_varlen(const X3Params& P, const X3Plan& pl, float* out, hipStrea
 struct X3VarlenPlan {
     int64_t total_wg, partial_slots;
     int nkb;
+    bool all_direct;   // every bag has one workgroup per head: no reduction pass
 };
 bool x3_varlen_plan(const int64_t* offsets, int bags, int k, int h, int dk, X3VarlenPlan* vp, int32_t* table, size_t table_ints) {
-    vp->total_wg = 0, vp->partial_slots = 0, vp->nkb = 0;
+    vp->total_wg = 0, vp->partial_slots = 0, vp->nkb = 0, vp->all_direct = true;
     if (bags < 1 || k > (dk == 128 ? 224 : 256)) return false;   // single key chunk only
     for (int b = 0; b < bags; ++b) {
         const int64_t n = offsets[b + 1] - offsets[b];
         X3Plan pl;
         if (n < 1 || offsets[b] > 0x7fffffffll || !x3_plan(n, k, h, dk, &pl, true)) return false;
+        const bool direct = pl.tiles_per_wg == pl.tiles_per_head;
+        vp->all_direct = vp->all_direct && direct;
         if (table) {
             if ((size_t)(VL_DESC * bags) + (size_t)(vp->total_wg + pl.num_wg) > table_ints) return false;
             int32_t* d = table + (size_t)VL_DESC * b;
             d[0] = (int32_t)vp->total_wg, d[1] = (int32_t)offsets[b], d[2] = (int32_t)n, d[3] = b * k;
             d[4] = pl.tiles_per_head, d[5] = pl.tiles_per_wg, d[6] = pl.total_tiles, d[7] = pl.seg_count;
-            d[8] = (int32_t)vp->partial_slots, d[9] = pl.num_wg, d[10] = 0, d[11] = 0;
+            d[8] = (int32_t)vp->partial_slots, d[9] = pl.num_wg, d[10] = direct ? 1 : 0, d[11] = 0;
             for (int i = 0; i < pl.num_wg; ++i) table[(size_t)VL_DESC * bags + vp->total_wg + i] = b;
         }
         vp->total_wg += pl.num_wg;
@@ -690,7 +719,7 @@ int snf_sparse_attn_fwd_x3(const float* q, int64_t ldq, const float* v, int64_t 
     P.nchunks = ch.count, P.chunk = 0;
     P.tiles_per_head = pl.tiles_per_head, P.tiles_per_wg = pl.tiles_per_wg, P.total_tiles = pl.total_tiles;
     P.seg_count = pl.seg_count;
-    P.n_stride = n, P.vl = nullptr, P.vl_bags = 0;
+    P.n_stride = n, P.vl = nullptr, P.vl_bags = 0, P.out_direct = nullptr;
     hipStream_t s = snf::as_stream(stream);
     if (ch.count == 1) return dk == 128 ? x3_dispatch<128>(P, pl, out, s, 0) : x3_dispatch<64>(P, pl, out, s, 0);
     // key chunks: statistics of every chunk first, then the chunks' main passes with the softmax exact over all keys
@@ -757,10 +786,11 @@ int snf_sparse_attn_fwd_x3_varlen(const float* q, int64_t ldq, const float* v, i
     P.partial = reinterpret_cast<float*>(workspace);
     P.stats = nullptr, P.nchunks = 1, P.chunk = 0;
     P.tiles_per_head = P.tiles_per_wg = P.total_tiles = P.seg_count = 0;   // per bag, from the table
-    P.n_stride = total, P.vl = table_dev, P.vl_bags = bags;
+    P.n_stride = total, P.vl = table_dev, P.vl_bags = bags, P.out_direct = out;
     X3Plan pl;
     pl.num_wg = (int)vp.total_wg, pl.nkb = vp.nkb;
     pl.tiles_per_head = pl.tiles_per_wg = pl.total_tiles = pl.seg_count = 0;
+    if (vp.all_direct) pl.tiles_per_head = -1;   // x3_launch: no reduction pass
     hipStream_t s = snf::as_stream(stream);
     return dk == 128 ? x3_dispatch_varlen<128>(P, pl, out, s) : x3_dispatch_varlen<64>(P, pl, out, s);
 }

@@ -220,12 +220,14 @@ def forward_packed_raw(net, x_cat, packed, ragged=False):
     x_cat = SF.as_2d(x_cat)
     for layer in layers[:1]:
         layer._xhat_offer = None
+        layer._xn3_offer = None
     if cfg.precision == "bf16":
         eps = layers[0].sublayer[0].norm.eps
         s, xhat = SF.ops.critic_ln(x_cat, lin.weight, lin.bias, eps)            # same kernel as the per-bag critic pass
         layers[0]._xhat_offer = (x_cat.data_ptr(), tuple(x_cat.shape), x_cat._version, float(eps), xhat)
     else:
-        s = SF.ops.critic(x_cat, lin.weight, lin.bias)
+        # fp32-class: where the layer takes the one-pass GEMMs, the critic pass also leaves LayerNorm_0's image (one read of the rows)
+        s = SF.critic_scores_with_hl(x_cat, lin.weight, lin.bias, layers[0])
     c1 = s.reshape(-1)
     l0 = layers[0]
     k1 = math.ceil(l0.big_lambda * l0.top_big_lambda_share)

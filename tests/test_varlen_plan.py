@@ -47,6 +47,7 @@ def test_attention_plan_covers_every_tile_once(which, tile_rows, small_tiles, si
             assert tpw == min(tph, small_tiles)                              # a bag that cannot fill the chip: >= 1024 rows / workgroup
         assert seg >= -(-tpw // tph) + (1 if tpw % tph else 0) and seg >= 1   # partial slots for every head a workgroup can touch
         assert np.all(wg_bag[wg0:wg0 + num_wg] == i)
+        assert d[10] == (1 if tpw == tph else 0)        # one workgroup per head: the bag's output is stored without a reduction
         # a bag's plan does not depend on the batch: the same bag alone gives the same descriptor (but for the batch offsets)
         rc1, t1, _, _ = _attn_plan(getattr(lib, which), [n], k, h, dk)
         assert rc1 == 0 and np.array_equal(t1[4:10][[0, 1, 2, 3, 5]], d[4:10][[0, 1, 2, 3, 5]])
