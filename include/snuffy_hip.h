@@ -170,6 +170,11 @@ int snf_split3_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16
 int snf_colsum_blocks(int64_t n);
 int snf_colsum_fused(const void* src, int src_dtype, int64_t n, int d, const float* row_weight, int64_t weight_stride,
                      const void* gate_bf16, void* dst_bf16, float* partial, snf_stream_t stream);
+/* Skinny fp32-class projection for the K selected rows of a bag (key / output projections, snuffy.py:190, 205; the tile GEMMs
+ * need thousands of rows): out [r, c] (f32 or bf16: out_dtype) = x [r, k] f32 . w [c, k]^T f32 + bias, every product as split-bf16 x3
+ * on the matrix cores with the split done in registers.  r <= 8192, k % 16 == 0, rows 16-byte aligned. */
+int snf_linear_rows_x3_f32(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int r, int c, int k, void* out,
+                           int64_t ldo, int out_dtype, snf_stream_t stream);
 /* critic scores + LayerNorm (with affine) of the same rows in one pass, the normalised rows as the interleaved hi / lo image
  * (= snf_critic_f32 + snf_layernorm_rows_hl_f32 with one read of x; FCLayer.forward snuffy.py:39-41 + SublayerConnection.norm
  * snuffy.py:107).  d % 32 == 0; selector_state nullable (one class: also counts the selector's first radix digit). */

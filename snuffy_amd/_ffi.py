@@ -62,6 +62,8 @@ SIGNATURES = {
     "snf_colsum_fused": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "snf_layernorm_rows_split3_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                               c_void_p, c_void_p]),
+    "snf_linear_rows_x3_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_int,
+                                       c_void_p]),
     "snf_critic_ln_hl_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float,
                                      c_void_p, c_void_p, c_void_p]),
     "snf_bias_act": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p]),

@@ -657,6 +657,106 @@ int launch_act(const GemmParams& P, hipStream_t s) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Skinny fp32-class projection: out[R, C] = x[R, K] w[C, K]^T + bias for a FEW HUNDRED rows (the K selected rows of a bag: key and
+// output projections, snuffy.py:190, 205).  The tile kernels above need >= 256 rows per workgroup and thousands of tiles; the fp32
+// library GEMM takes ~10 us for 200 x 768 x 768.  Here a workgroup owns a 32 x 32 output block, its 8 waves split the K axis, every
+// wave splits its fp32 operands into bf16 hi / lo in registers (no images in memory) and issues hi hi + hi lo + lo hi on
+// v_mfma_f32_32x32x16_bf16; the partial blocks are summed through LDS in a fixed order.  Rows / columns past R / C are clamped
+// on load and masked on store.  k % 16 == 0, rows 16-byte aligned.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16s;
+typedef __attribute__((ext_vector_type(8))) float f32x8s;
+__device__ __forceinline__ void skinny_split8(const f32x8s v, bf16x8& hi, bf16x8& lo) {
+    hi = __builtin_convertvector(v, bf16x8);
+    lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8s), bf16x8);
+}
+__device__ __forceinline__ f32x8s skinny_load8(const float* p) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    return f32x8s{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+template <bool OUT_BF16>
+__global__ __launch_bounds__(512) void skinny_linear_x3_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                                int64_t ldw, const float* __restrict__ bias, int r, int c, int k,
+                                                                void* __restrict__ out, int64_t ldo) {
+    constexpr int NW = 8, BATCH = 6;                        // waves splitting the K axis; MFMA steps (16 deep) requested at once
+    __shared__ float red[NW - 1][32 * 32];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 31, hf = lane >> 5;
+    const int row0 = blockIdx.y * 32, col0 = blockIdx.x * 32;
+    int xr = row0 + j, wr = col0 + j;
+    if (xr > r - 1) xr = r - 1;
+    if (wr > c - 1) wr = c - 1;
+    // the K axis in 16-deep steps, split evenly over the waves: the whole pass is ONE memory round trip per wave when its share
+    // fits a batch (k <= 768), so every load of the workgroup is in flight before the first MFMA
+    const int steps = k >> 4, per = (steps + NW - 1) / NW;
+    const int s_lo = wv * per, s_hi = s_lo + per < steps ? s_lo + per : steps;
+    const float* xp = x + (int64_t)xr * ldx + 8 * hf;
+    const float* wp = w + (int64_t)wr * ldw + 8 * hf;
+    f32x16s acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // A = w fragment (output column on the lane), B = x fragment (row on the lane): C[col, row] -- lane (row j, half hf) then holds
+    // columns (i & 3) + 8 (i >> 2) + 4 hf of ITS row in registers
+    for (int s0 = s_lo; s0 < s_hi; s0 += BATCH) {
+        // branch-free on purpose: a predicate around the loads makes the compiler wait for each pair before it requests the next
+        // (six serial round trips: 12 us for 200 x 768 x 768).  Steps past the wave's share re-read its last step and contribute 0.
+        f32x8s xv[BATCH], wvv[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int st = s0 + u < s_hi ? s0 + u : s_hi - 1;
+            xv[u] = skinny_load8(xp + 16 * st);
+            wvv[u] = skinny_load8(wp + 16 * st);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // every load of the batch is requested before the first split / MFMA
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            bf16x8 xh, xl, wh, wl;
+            const float live = s0 + u < s_hi ? 1.f : 0.f;
+            skinny_split8(xv[u] * live, xh, xl);
+            skinny_split8(wvv[u], wh, wl);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc, 0, 0, 0);
+        }
+    }
+    // sum the waves' blocks in a fixed order (waves 1.. through LDS, wave 0 adds them to its own)
+    if (wv > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wv - 1][i * 64 + lane] = acc[i];
+    }
+    __syncthreads();
+    // wave 0 sums, adds the bias and parks the block row-major in LDS; then every thread stores along a row (a lane of the MFMA
+    // result holds one ROW's columns 4 apart in registers: stored from there, every 4-byte store of a wave hits another line)
+    __shared__ float blk[32][33];
+    if (wv == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = acc[i];
+#pragma unroll
+            for (int q = 0; q < NW - 1; ++q) v += red[q][i * 64 + lane];
+            const int cl = (i & 3) + 8 * (i >> 2) + 4 * hf;
+            blk[j][cl] = v;
+        }
+    }
+    // the bias of this thread's column (threads 0..511 cover columns e & 31: the same column in both rounds), requested before the
+    // barrier -- added in wave 0's registers it was 16 conditional loads, each a full round trip
+    const int bcol = col0 + (threadIdx.x & 31);
+    const float bv = (bias && bcol < c) ? bias[bcol] : 0.f;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * 32; e += 512) {
+        const int rl = e >> 5, cl = e & 31;
+        const int row = row0 + rl, col = col0 + cl;
+        if (row < r && col < c) {
+            const float v = blk[rl][cl] + bv;
+            if constexpr (OUT_BF16)
+                reinterpret_cast<unsigned short*>(out)[(int64_t)row * ldo + col] = (unsigned short)(cvt_pk_bf16(v, 0.f) & 0xffffu);
+            else
+                reinterpret_cast<float*>(out)[(int64_t)row * ldo + col] = v;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t m, int n,
@@ -741,4 +841,24 @@ extern "C" int snf_gemm_hl_resid_bf16(const void* a_hl, int64_t lda, const void*
     hipStream_t s = snf::as_stream(stream);
     if (hl_out) return launch_hl_act<3>(P, s);
     return out_dtype == SNF_DT_F32 ? launch_hl_act<1>(P, s) : launch_hl_act<0>(P, s);
+}
+
+// out [r, c] (f32 or bf16, row pitch ldo) = x [r, k] (f32, row pitch ldx) w [c, k]^T (f32, row pitch ldw) + bias [c] (nullable), fp32-class
+// (split-bf16 x3 on the matrix cores, fp32 accumulate).  For the few hundred selected rows of a bag; r <= 8192, k % 64 == 0.
+extern "C" int snf_linear_rows_x3_f32(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int r, int c, int k,
+                                      void* out, int64_t ldo, int out_dtype, snf_stream_t stream) {
+    SNF_REQUIRE(x && w && out, "snf_linear_rows_x3_f32: null pointer");
+    SNF_REQUIRE(r >= 1 && r <= 8192 && c >= 1 && k >= 16 && k % 16 == 0, "snf_linear_rows_x3_f32: bad shape r=%d c=%d k=%d "
+                "(r <= 8192, k %% 16 == 0)", r, c, k);
+    SNF_REQUIRE(out_dtype == SNF_DT_F32 || out_dtype == SNF_DT_BF16, "snf_linear_rows_x3_f32: bad out dtype %d", out_dtype);
+    SNF_REQUIRE(ldx >= k && ldw >= k && ldo >= c && (ldx % 4) == 0 && (ldw % 4) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0,
+                "snf_linear_rows_x3_f32: x / w rows must be 16-byte aligned");
+    const dim3 grid((unsigned)((c + 31) / 32), (unsigned)((r + 31) / 32));
+    hipStream_t s = snf::as_stream(stream);
+    if (out_dtype == SNF_DT_BF16)
+        hipLaunchKernelGGL(skinny_linear_x3_kernel<true>, grid, dim3(512), 0, s, x, ldx, w, ldw, bias, r, c, k, out, ldo);
+    else
+        hipLaunchKernelGGL(skinny_linear_x3_kernel<false>, grid, dim3(512), 0, s, x, ldx, w, ldw, bias, r, c, k, out, ldo);
+    return snf::check_launch("skinny_linear_x3_kernel");
 }

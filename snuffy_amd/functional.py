@@ -374,12 +374,17 @@ def invalidate_folded(layer):
 
 
 def _rows_linear(x, lin):
-    """x W^T + b of an fp32 [rows, D] operand: the fp32 library GEMM for the K selected rows of one bag; thousands of rows (the
-    B x K selected rows of a packed batch) go through the fp32-class split-bf16 x3 MFMA kernel like the [N, .] projections."""
+    """x W^T + b of an fp32 [rows, D] operand, fp32-class on the matrix cores (FP32_GEMM == "x3"): the skinny kernel for the K selected
+    rows of one bag, the tile kernel over split images for thousands of rows (the B x K selected rows of a packed batch); the fp32
+    library GEMM for FP32_GEMM == "library", under autograd and for shapes outside both kernels."""
     m, k = x.shape
     n = lin.weight.shape[0]
-    if FP32_GEMM == "x3" and m >= 2048 and ops.gemm_x3_supported(m, n, k) and not _needs_grad(x, lin.weight, lin.bias):
-        return ops.gemm_x3(ops.split3_rows(x), split3_cached(lin.weight), lin.bias.detach(), out_dtype=torch.float32)
+    if FP32_GEMM == "x3" and not _needs_grad(x, lin.weight, lin.bias) and x.dtype == torch.float32 and lin.weight.dtype == torch.float32:
+        if m >= 2048 and ops.gemm_x3_supported(m, n, k):
+            return ops.gemm_x3(ops.split3_rows(x), split3_cached(lin.weight), lin.bias.detach(), out_dtype=torch.float32)
+        if m < 2048 and ops.linear_rows_x3_supported(m, n, k):
+            # the K rows of one bag: skinny kernel, operands split in registers (the fp32 library GEMM took ~10 us per projection)
+            return ops.linear_rows_x3(x, lin.weight.detach(), None if lin.bias is None else lin.bias.detach())
     return F.linear(x, lin.weight, lin.bias)
 
 
@@ -507,7 +512,12 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
         # keys = RAW selected rows: the gather also leaves them in bf16, the projection runs like Q | V (bf16 operands,
         # fp32 accumulate, bf16 out) and the attention kernel reads Kp as it is
         xs, slot, xs16 = ops.gather_slot_map(x2, sel, bf16_copy=True)               # snuffy.py:131,145-147 (+ row -> slot map)
-        kp = torch.addmm(fw["bk"], xs16, fw["wk"].t())
+        if (FP32_GEMM == "x3" and xs.shape[0] < 2048 and ops.linear_rows_x3_supported(xs.shape[0], d, d)
+                and lk.weight.dtype == torch.float32):
+            # keys of one bag: fp32-class product of the fp32 rows, rounded once to the bf16 the attention kernel reads
+            kp = ops.linear_rows_x3(xs, lk.weight.detach(), lk.bias.detach(), out_dtype=torch.bfloat16)
+        else:
+            kp = torch.addmm(fw["bk"], xs16, fw["wk"].t())
         if packed is not None:
             o, attn, _ = ops.sparse_attn_fwd_mfma_varlen(q, v, kp, packed, kb, h, need_attn=need_attn)
         else:

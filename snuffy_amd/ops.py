@@ -1096,6 +1096,29 @@ def split3_rows(x):
     return out
 
 
+def linear_rows_x3_supported(r, c, k):
+    return 1 <= r <= 8192 and c >= 1 and k >= 16 and k % 16 == 0
+
+
+def linear_rows_x3(x, w, bias=None, out_dtype=torch.float32):
+    """x [r, k] f32 @ w [c, k]^T f32 + bias for a few hundred rows (the K selected rows of a bag), fp32-class: split-bf16 x3 on the
+    matrix cores with the operands split in registers (snf_linear_rows_x3_f32) -> [r, c] f32 or bf16."""
+    if x.dtype != torch.float32 or w.dtype != torch.float32:
+        raise TypeError("linear_rows_x3: x and w must be float32")
+    x = _rows16(x, "x")
+    w = _rows16(w, "w")
+    r, k = x.shape
+    c = w.shape[0]
+    if w.shape[1] != k or not linear_rows_x3_supported(r, c, k) or out_dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("linear_rows_x3: x %s w %s outside the kernel (r <= 8192, k %% 16 == 0)" % (tuple(x.shape), tuple(w.shape)))
+    if bias is not None:
+        bias = _req(bias, torch.float32, "bias", 1)
+    out = torch.empty(r, c, dtype=out_dtype, device=x.device)
+    check(_ffi.load().snf_linear_rows_x3_f32(_p(x), x.stride(0), _p(w), w.stride(0), _p(bias), r, c, k, _p(out), c,
+                                             DT_F32 if out_dtype == torch.float32 else DT_BF16, _stream()), "snf_linear_rows_x3_f32")
+    return out
+
+
 def gemm_x3_supported(m, n, k):
     return gemm_supported(m, n, 3 * k) and m * 3 * k < 2 ** 31 and n * 3 * k < 2 ** 31
 

@@ -218,3 +218,23 @@ def test_fp32_path_x3_projections_against_library_projections(monkeypatch):
     assert torch.equal(c3, c0)
     assert (l3 - l0).abs().max().item() <= 2e-5 * max(1.0, l0.abs().max().item())
     assert (a3 - a0).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("r,c,k", [(200, 768, 768), (1, 384, 384), (37, 100, 128), (512, 1536, 64), (224, 768, 3072)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_linear_rows_x3_skinny_kernel_vs_fp64(r, c, k, out_dtype):
+    """snf_linear_rows_x3_f32: the key / output projections of the K selected rows -- fp32-class (split-bf16 x3, split in registers),
+    any r <= 8192 and c, k % 64 == 0; against fp64, and deterministic."""
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(r * 7 + c)
+    x = torch.randn(r, k, generator=g).to(DEV)
+    w = (torch.randn(c, k, generator=g) / k ** 0.5).to(DEV)
+    b = torch.randn(c, generator=g).to(DEV)
+    y = ops.linear_rows_x3(x, w, b, out_dtype=out_dtype)
+    assert y.shape == (r, c) and y.dtype == out_dtype
+    ref = x.double() @ w.double().t() + b.double()
+    tol = 2e-5 if out_dtype == torch.float32 else 5e-3
+    assert (y.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    assert torch.equal(y, ops.linear_rows_x3(x, w, b, out_dtype=out_dtype))
+    y0 = ops.linear_rows_x3(x[:, :k], w, None, out_dtype=torch.float32)       # no bias
+    assert (y0.double() - (ref - b.double())).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
