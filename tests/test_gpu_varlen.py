@@ -371,3 +371,41 @@ def test_forward_bags_splits_large_batches_into_row_capped_chunks():
         ref = [net(x) for x in bags]
     for (c0, y0, a0), (c1, y1, a1) in zip(ref, got):
         assert torch.equal(c0, c1) and (y0 - y1).abs().max().item() <= 2e-2 and (a0 - a1).abs().max().item() <= 2e-2
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("SNF_FUZZ_SEEDS", "10")))))
+def test_forward_bags_random_compositions(seed):
+    """Random models and batch compositions (bag lengths from 1 patch up, below and above Lambda, head widths inside and outside
+    the MFMA kernels, both arithmetics, depth 1-3): forward_bags against the per-bag forwards."""
+    rs = np.random.RandomState(1000 + seed)
+    d, h = [(64, 1), (128, 2), (384, 6), (768, 6), (166, 2), (256, 4), (384, 3), (96, 2)][rs.randint(8)]
+    lam = int(rs.choice([16, 64, 200, 224]))
+    depth = int(rs.randint(1, 4))
+    precision = ["fp32", "bf16"][rs.randint(2)]
+    if d // h not in (64, 128) and lam > 200:
+        lam = 200
+    nb = int(rs.randint(2, 9))
+    sizes = [int(v) for v in np.clip(np.round(np.exp(rs.uniform(0, np.log(6000), nb))), 1, 6000)]
+    net = _net(d, h, lam, 0.0, depth, precision, seed=seed)
+    bags = _bags(sizes, d, seed=100 + seed)
+    with torch.no_grad():
+        got = net.forward_bags(bags)
+        ref = [net(x) for x in bags]
+    tol = 5e-5 if precision == "fp32" else 3e-2
+    sd = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+    for b, ((c0, y0, a0), (c1, y1, a1)) in enumerate(zip(ref, got)):
+        what = (d, h, lam, depth, precision, sizes, b)
+        assert c1.shape == c0.shape and y1.shape == y0.shape and a1.shape == a0.shape, what
+        assert torch.equal(c0, c1)
+        assert (y0 - y1).abs().max().item() <= tol * max(1.0, y0.abs().max().item()), what
+        da = (a0 - a1).abs().max().item()
+        if depth == 1 or da <= tol:
+            assert da <= tol, what
+        else:
+            # deeper stacks of these random nets (peaked softmaxes) amplify the last-place differences of the first layer: both
+            # paths then sit ~1e-4 .. 1e-3 from the fp64 result on A (logits stay within 2e-6) -- the packed path must not be
+            # further from the truth than the per-bag one
+            _, _, a64, _ = orc.milnet_forward(bags[b][0].cpu().double(), sd, h, "relu", lam, 0.0, depth)
+            e_ref = (a0[0].cpu().double() - a64).abs().max().item()
+            e_got = (a1[0].cpu().double() - a64).abs().max().item()
+            assert e_got <= 3 * max(e_ref, tol), (what, e_got, e_ref)
