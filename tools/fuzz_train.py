@@ -12,6 +12,9 @@ from snuffy_amd.snuffy import build_milnet  # noqa: E402
 
 DEV = "cuda"
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+if os.environ.get("SNF_PLAIN_FP32"):          # plain fp32 arithmetic in the fp32 path (library GEMMs, exact attention)
+    from snuffy_amd import functional as _SF
+    _SF.FP32_GEMM, _SF.FP32_ATTENTION = "library", "exact"
 rs = np.random.RandomState(11)
 bad = 0
 for case in range(ncases):
