@@ -264,6 +264,19 @@ int snf_sparse_attn_fwd_x3(const float* q, int64_t ldq, const float* v, int64_t 
                            int dk, float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
                            snf_stream_t stream);
 
+/* K7 (fp32-class, pre-split operands)    the same attention() of snuffy.py:160-168, same arithmetic (split-bf16 x3, fp32
+ * softmax / accumulate), for operands that already ARE split: q_hl, v_hl = interleaved "hl" images [n, ld] bf16 (every 32 true
+ * columns c .. c + 31 of the fp32 tensor stored as [hi(32) | lo(32)], hi = bf16(x), lo = bf16(x - hi): what snf_gemm_hl_bf16
+ * writes with out_dtype SNF_DT_BF16_HL and snf_split_hl_f32 makes of an fp32 tensor; 4 bytes per element like the fp32 tensor);
+ * row pitches in bf16 elements (>= 2 h dk, 16-byte aligned rows: the halves of a fused [Q | V] image are taken in place);
+ * kp [k, h dk] f32.  Software-pipelined kernel: LDS-DMA of full lines, one wave per key block, GEMM1 / GEMM2 MFMAs interleaved
+ * with the softmax vector work in every wave's own instruction stream (csrc/sparse_attn_x3p.hip).  dk = 128, k <= 256 (one
+ * launch); other shapes SNF_EUNSUPPORTED (the caller keeps snf_sparse_attn_fwd_x3).  Outputs as snf_sparse_attn_fwd_x3. */
+size_t snf_sparse_attn_fwd_x3_hl_workspace_bytes(int64_t n, int k, int h, int dk);
+int snf_sparse_attn_fwd_x3_hl(const void* q_hl, int64_t ldq, const void* v_hl, int64_t ldv, const float* kp, int64_t n, int k, int h,
+                              int dk, float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
+                              snf_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * K7-bwd  sparse attention backward, exact fp32    replaces autograd through attention(), snuffy.py:160-168
  *   p [h, n, k] = the probabilities the forward returned (attn);  mask [h, n, k] nullable = dropout keep-mask already

@@ -22,7 +22,8 @@ EXTRA_FLAGS = {"sparse_attn_mfma.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]
                "sparse_attn_mfma_dk64.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
                "sparse_attn_mfma_varlen.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
                "sparse_attn_mfma_varlen_dk64.hip": ["-fno-honor-nans", "-fno-slp-vectorize"], "vit.hip": ["-fno-honor-nans"],
-               "sparse_attn_x3.hip": ["-fno-honor-nans"]}
+               "sparse_attn_x3.hip": ["-fno-honor-nans"],
+               "sparse_attn_x3p.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -50,6 +51,8 @@ def _compile(src, force, hdr_mtime):
     cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
     if os.environ.get("SNF_ATTN_DEV"):   # development: only the config-B attention variants (7 key blocks)
         cmd.insert(1, "-DSNF_ATTN_DEV")
+    for d in os.environ.get("SNF_EXTRA_DEFS", "").split():   # development: timing ablations (-DX3P_ABL_...), never in a shipped build
+        cmd.insert(1, "-D" + d)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

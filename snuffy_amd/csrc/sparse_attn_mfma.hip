@@ -1,10 +1,12 @@
 // K7 (fast form), translation unit 1: the dk = 128 kernel variants and the C entry points (see sparse_attn_mfma_impl.h).
 #include "sparse_attn_mfma_impl.h"
 
-namespace {
-unsigned long long* g_attn_trace = nullptr;  // debug hook, see snf_debug_attn_trace
+namespace snf {
+unsigned long long* g_attn_trace = nullptr;  // debug hook, see snf_debug_attn_trace (also read by sparse_attn_x3p.hip)
 int g_attn_trace_wg = 0;
-}  // namespace
+}  // namespace snf
+using snf::g_attn_trace;
+using snf::g_attn_trace_wg;
 
 namespace snf {
 int attn_launch_dk128(int qv_dtype, bool stats_pass, const AttnParams& P, const Plan& pl, float* out, hipStream_t s) {

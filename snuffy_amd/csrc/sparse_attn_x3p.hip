@@ -1,0 +1,796 @@
+// K7, fp32-class, round 4: the split-bf16 x3 sparse attention of sparse_attn_x3.hip re-organised so that the matrix pipe and the
+// vector ALU overlap INSIDE every wave's instruction stream (PMC of the round-3 kernel: MFMA busy 33 % + VALU 35 % of the SIMD
+// cycles, adding up because its phases -- GEMM1 | softmax | GEMM2 -- were separated by workgroup barriers and every wave was in
+// the same phase at the same time).
+//
+//   per head a:   P_a = softmax_j(Q_a Kp_a^T * scale)  [n, k]      O_a = P_a^T V_a  [k, dk]        (snuffy.py:160-168)
+//
+// What is different:
+//   * operands arrive PRE-SPLIT: Q and V as the interleaved "hl" images the projection GEMM writes in its epilogue (every 32 true
+//     columns as [hi(32) | lo(32)] bf16, gemm.hip) -- the same 4 bytes per element as the fp32 tensors and the same hi / lo values
+//     the round-3 kernel derived in registers.  Rows go HBM -> LDS by LDS-DMA in full 512-byte lines per row and head (no staging
+//     registers, no split, no ds_write), two tiles ahead.
+//   * ONE WAVE PER SIMD, TWO KEY BLOCKS PER WAVE (workgroup = ceil(k / 64) waves, 512 registers each): wave w owns keys 64 w ..
+//     64 w + 63 for everything -- their Kp fragments (registers, whole head), the scores S^T[64 keys, 32 rows] of every tile,
+//     their softmax, and the 64 x dk slice of the output accumulator.  P^T of a key block is produced and consumed by the same
+//     wave: it goes through a wave-private LDS region only to change from the accumulator layout (lane = row) to the A-operand
+//     layout (lane = key), with no barrier.  The only cross-wave exchange per tile is one (max, sum) pair per row and wave.
+//   * 32-row tiles, ONE workgroup barrier per tile, two-stage software pipeline.  Iteration i issues, in one instruction stream,
+//         first half:   GEMM1(i + 1) on the matrix pipe  |  combine + normalise + split + publish P(i) on the vector ALU
+//         second half:  GEMM2(i)     on the matrix pipe  |  max / exp2 / sum of S(i + 1), publish its statistics
+//     with the vector work cut into small units that are dropped, by hand, into the gaps behind the MFMAs (an in-order wave only
+//     overlaps the two pipes if its own stream alternates them; consecutive MFMAs always go to different accumulators -- the two
+//     key blocks alternate -- because a dependent MFMA issued behind a gap pays the full pipeline latency).
+//   * the scale (and log2 e) is folded into Kp before its split; padded keys are masked only in the last wave's own code path.
+//
+// LDS (dk = 128): Q ring 3 x 17 KiB (rows padded to 528 B: conflict-free B reads at immediate offsets) | V ring 3 x 16 KiB |
+// P 4 KiB per key block (hi 2 KiB + lo 2 KiB) | statistics 2 x waves x 256 B  = 133 KiB at 8 key blocks.
+// Partial accumulators and their deterministic reduction as in sparse_attn_x3.hip (same layout).
+#include <math.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace snf {
+extern unsigned long long* g_attn_trace;   // debug hook of sparse_attn_mfma.hip (snf_debug_attn_trace)
+extern int g_attn_trace_wg;
+}  // namespace snf
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+struct X3PParams {
+    const unsigned short* q;   // hl image [n, ldq] bf16: head a, true column c at 2 a dk + 64 (c / 32) + c % 32 (hi), + 32 (lo)
+    const unsigned short* v;   // hl image [n, ldv]
+    const float* kp;           // [k, ldkp] f32
+    const u32x4* kp_frag;      // workspace: the fragment-ordered split image of kp (x3p_prep_kp_kernel)
+    int64_t n, ldq, ldv, ldkp;
+    int k, h;
+    float scale;
+    float* attn;               // [h, n, attn_ld] (already offset to this launch's first key) or null
+    int64_t attn_ld;
+    float* lse;                // [h, n] or null
+    const f32x2* stats;        // MODE 2 (one key chunk of several): [h, n] (row max in scaled log2 units, row sum) over ALL keys
+    float* partial;            // [num_wg * seg_count][NKB * dk / 32 tiles][4][64][4]
+    int tiles_per_head, tiles_per_wg, total_tiles, seg_count;
+    unsigned long long* trace;   // dev builds (X3P_TRACE): s_memtime stamps of workgroup trace_wg, [wave][64 iterations][8]
+    int trace_wg;
+};
+
+constexpr int TR = 32;       // query rows per tile
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ f32x8 load8(const float* p) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+__device__ __forceinline__ void split8(const f32x8 x, u32x4& hi, u32x4& lo) {
+    const bf16x8 h = __builtin_convertvector(x, bf16x8);
+    const f32x8 r = x - __builtin_convertvector(h, f32x8);
+    hi = __builtin_bit_cast(u32x4, h);
+    lo = __builtin_bit_cast(u32x4, __builtin_convertvector(r, bf16x8));
+}
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigned char* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ float xhalf_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ unsigned cvt_pk(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+#define X3P_FENCE() __builtin_amdgcn_sched_barrier(0)
+// s_waitcnt vmcnt(0) in the form hipcc's wait-count pass understands (vmcnt = 0, expcnt / lgkmcnt untouched): the LDS-DMAs are
+// inline asm and invisible to that pass, so it must also be told when ITS OWN loads (spill reloads of the slow paths) are done --
+// otherwise it parks a vmcnt(0) for them inside the fast loop, where it drains the prefetch every iteration
+#define X3P_WAIT_VM0()                          \
+    do {                                        \
+        __builtin_amdgcn_s_waitcnt(0x0F70);     \
+        asm volatile("" ::: "memory");          \
+    } while (0)
+
+#ifdef X3P_TRACE
+#define X3P_STAMP(it, k)                                                                                          \
+    do {                                                                                                          \
+        if (P.trace && bid == P.trace_wg && lane == 0 && (it) >= 0 && (it) < 64)                                  \
+            P.trace[(w * 64 + (it)) * 8 + (k)] = __builtin_amdgcn_s_memtime();                                    \
+    } while (0)
+#else
+#define X3P_STAMP(it, k) do { } while (0)
+#endif
+
+// (head, tile) cursor over the flattened item space of one workgroup
+struct Cur {
+    int a, t;
+};
+
+constexpr int x3p_qslot(int dk) { return ((TR * (4 * dk + 16) + 1023) / 1024) * 1024; }   // padded Q slot, whole DMA instructions
+constexpr int x3p_lds_bytes(int dk, int nkb, int bpw) {
+    const int nw = (nkb + bpw - 1) / bpw, ndma = x3p_qslot(dk) / 1024 + TR * 4 * dk / 1024;
+    return 3 * x3p_qslot(dk) + 3 * TR * 4 * dk + nkb * (TR * 64 * 2) + 2 * nw * TR * 8 + nw * ((ndma + nw - 1) / nw) * 256;
+}
+
+// MODE 0: all keys in this launch.  (MODE 2, a key chunk with the row statistics of all chunks given: not built yet.)
+template <int DK, int NKB, int BPW, bool AUX, int MODE>
+__global__ __launch_bounds__(64 * ((NKB + BPW - 1) / BPW), BPW == 1 ? 2 : 1) void sparse_attn_x3p_kernel(const X3PParams P) {
+    static_assert(DK == 128 && MODE == 0, "sparse_attn_x3p: dk = 128, MODE 0 only");
+    constexpr int NW = (NKB + BPW - 1) / BPW;   // waves (BPW = key blocks per wave: 2 -> one wave per SIMD, 1 -> two)
+#ifndef X3P_KP_AGPR
+#define X3P_KP_AGPR 3
+#endif
+    constexpr int KP_AGPR = X3P_KP_AGPR;     // how many of the wave's four 32-register key-fragment sets are parked in AGPRs
+    constexpr int NKS = DK / 16;             // k-steps of GEMM1
+    constexpr int NCB = DK / 32;             // 32-column blocks of the output
+    constexpr int ROWB = 4 * DK;             // bytes of one row of one head in an hl image
+    constexpr int QP = ROWB + 16;            // row pitch of a Q slot: one 16-byte pad chunk per row (bank rotation of the B reads)
+    constexpr int QCH = QP / 16;             // 16-byte positions per Q row (33)
+    constexpr int QSLOT = x3p_qslot(DK);     // 17 KiB
+    constexpr int NQDMA = QSLOT / 1024;      // LDS-DMA instructions of a Q tile (17)
+    constexpr int VSLOT = TR * ROWB;         // 16 KiB, rows of [hi plane 256 B | lo plane 256 B], chunk-rotated
+    constexpr int NVDMA = VSLOT / 1024;      // 16
+    constexpr int NDMA = NQDMA + NVDMA;
+    constexpr int DMA_U = (NDMA + NW - 1) / NW;         // per wave, at most
+    constexpr int Q_OFF = 0, V_OFF = 3 * QSLOT, P_OFF = V_OFF + 3 * VSLOT;
+    constexpr int PBUF = TR * 64 * 2;        // the P image of one key block: hi plane 2 KiB | lo plane 2 KiB
+    constexpr int ST_OFF = P_OFF + NKB * PBUF;
+    constexpr int TB_OFF = ST_OFF + 2 * NW * TR * 8;        // per-lane DMA source offsets, [NW][DMA_U][64] ints
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, hf = lane >> 5;
+    const int n32 = (int)P.n;
+    const int bid = blockIdx.x;
+
+    const int f_begin = bid * P.tiles_per_wg;
+    int f_end = f_begin + P.tiles_per_wg;
+    if (f_end > P.total_tiles) f_end = P.total_tiles;
+    if (f_begin >= f_end) return;
+    const int T = f_end - f_begin;            // items of this workgroup
+    const int first_head = f_begin / P.tiles_per_head;
+    // cursors of the items i .. i + 3 of the pipeline (head, tile), advanced by one item per iteration: no division in the loop
+    auto cur_next = [&](Cur c) __attribute__((always_inline)) -> Cur {
+        ++c.t;
+        if (c.t == P.tiles_per_head) c.t = 0, ++c.a;
+        return c;
+    };
+
+    // ---------------------------------------------------------------- LDS-DMA of one tile's Q or V rows
+    // An instruction fills 1 KiB = 64 lanes x 16 B of its slot, lane-linear; which 16 bytes of the tile a lane FETCHES is free.
+    //   Q instruction e (0 .. 16): position p = 64 e + lane -> row p / 33, chunk p % 33 of the row's 512-byte line (chunk 32 = pad)
+    //   V instruction e (0 .. 15): row 2 e + (lane >> 5), position s = lane & 31: plane s >> 4, 64-byte column group ((s >> 2) & 3) ^ (row & 3)
+    //                              (keeps the four rows of a transpose-read in four different 64-byte bank segments)
+    // Every instruction reads whole 128-byte lines of two or three consecutive rows.  Wave w issues instructions w, w + NW, ...
+    const int ldq_b = (int)(P.ldq * 2), ldv_b = (int)(P.ldv * 2);
+    auto dma_rc = [&](int u, int& row, int& chunk) __attribute__((always_inline)) {
+        const int e = w + NW * u;
+        if (e < NQDMA) {
+            const int p = 64 * e + lane;
+            row = p / QCH;
+            chunk = p - row * QCH;
+            if (chunk > 31) chunk = 31;
+            if (row > TR - 1) row = TR - 1;
+        } else {
+            const int ev = e - NQDMA, s = lane & 31;
+            row = 2 * ev + (lane >> 5);
+            const int g = ((s >> 2) & 3) ^ (row & 3);      // position group s >> 2 holds column group g of its plane
+            chunk = 8 * g + 4 * (s >> 4) + (s & 3);
+        }
+    };
+    // The per-lane source offsets of a FULL tile (row_in_tile * ld_bytes + 16 * chunk) are parked in LDS: registers are the scarce
+    // resource of this kernel, and the offsets are needed once per iteration, right behind the barrier.
+    int* const dma_tab = reinterpret_cast<int*>(smem + TB_OFF) + w * (DMA_U * 64) + lane;
+#pragma unroll
+    for (int u = 0; u < DMA_U; ++u) {
+        int row, chunk;
+        dma_rc(u, row, chunk);
+        dma_tab[u * 64] = row * (w + NW * u < NQDMA ? ldq_b : ldv_b) + 16 * chunk;
+    }
+    struct DmaOff {
+        int o[DMA_U];
+    };
+    auto load_dma_off = [&]() __attribute__((always_inline)) -> DmaOff {
+        DmaOff d;
+#pragma unroll
+        for (int u = 0; u < DMA_U; ++u) d.o[u] = dma_tab[u * 64];
+        return d;
+    };
+    // one instruction: 32-bit per-lane offset + 64-bit wave-uniform base (SGPR pair) -> 1 KiB at the wave-uniform LDS address dst.
+    // Hand-written: behind the builtin hipcc puts s_waitcnt vmcnt(0) in front of the first LDS read it cannot prove disjoint from
+    // the DMA's destination (the transpose-reads of the OTHER ring slots, mid-iteration), which drains the prefetch every
+    // iteration.  The asm form is invisible to that pass; the kernel's own s_waitcnt vmcnt + s_barrier at the end of the iteration
+    // order the data (cdna_hip_programming.md 5.7: M0 is written in the statement that uses it, and restored).
+    auto dma_1k = [&](const unsigned char* base, int off, int dst) __attribute__((always_inline)) {
+#ifdef X3P_ABL_NODMA   // timing ablation: no operand traffic at all (results wrong)
+        asm volatile("" ::"v"(off), "s"(base), "s"(dst));
+#else
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(off), "s"(base), "s"(dst)
+                     : "memory");
+#endif
+    };
+    // item c's Q rows -> Q slot sq (if doq), item cv's V rows -> V slot sv (if dov)
+    auto issue_dma = [&](const DmaOff& dma_off, bool doq, Cur cq, int sq, bool dov, Cur cv, int sv) __attribute__((always_inline)) {
+        const unsigned char* bq = reinterpret_cast<const unsigned char*>(P.q) + (int64_t)(cq.t * TR) * ldq_b + (int64_t)cq.a * ROWB;
+        const unsigned char* bv = reinterpret_cast<const unsigned char*>(P.v) + (int64_t)(cv.t * TR) * ldv_b + (int64_t)cv.a * ROWB;
+        const bool partq = cq.t * TR + TR > n32, partv = cv.t * TR + TR > n32;   // last tile of the bag: rows past the end
+#pragma unroll
+        for (int u = 0; u < DMA_U; ++u) {
+            const int e = w + NW * u;
+            if (e < NDMA) {
+                const bool isq = e < NQDMA;
+                if (isq ? doq : dov) {
+                    int off = dma_off.o[u];
+                    if (isq ? partq : partv) {   // re-read the last row instead (the P of such rows is forced to 0)
+                        int row, chunk;
+                        dma_rc(u, row, chunk);
+                        const int rmax = n32 - 1 - (isq ? cq.t : cv.t) * TR;
+                        if (row > rmax) row = rmax;
+                        off = row * (isq ? ldq_b : ldv_b) + 16 * chunk;
+                    }
+                    dma_1k(isq ? bq : bv, off, isq ? Q_OFF + sq * QSLOT + e * 1024 : V_OFF + sv * VSLOT + (e - NQDMA) * 1024);
+                }
+            }
+        }
+    };
+
+    // ---------------------------------------------------------------- addressing (one register per stream where possible)
+    // GEMM1 B fragment (kb, lo) of lane (row j, half hf): chunk 8 (kb >> 1) + 4 lo + 2 (kb & 1) + hf of row j -- an immediate offset
+    const int q_lane = Q_OFF + j * QP + 16 * hf;
+    // GEMM2 transpose-reads (lane = 16-lane group g x index i, as sparse_attn_x3.hip): rows rr0 / rr0 + 4 of a 16-row k-step
+    const int rg = lane >> 4, ri = lane & 15;
+    const int rr0 = 8 * (rg >> 1) + (ri >> 2), rr1 = rr0 + 4;
+    const int rch = 4 * (rg & 1) + (ri & 3);
+    const int p_wave = P_OFF + w * BPW * PBUF;                           // this wave's P images (key blocks BPW w ..)
+    const int poff0 = p_wave + rr0 * 64 + 8 * (rch ^ ((rr0 >> 1) & 7));
+    const int poff1 = p_wave + rr1 * 64 + 8 * (rch ^ ((rr1 >> 1) & 7));
+    // V fragment of column block cb, row rr0 (rr1: + 4 rows): 64-byte column group cb ^ (rr0 & 3) -> voff0 ^ (64 cb)
+    const int voff0 = V_OFF + rr0 * ROWB + 64 * (rr0 & 3) + 32 * (rg & 1) + 8 * (ri & 3);
+    // P image writer: row j, 8-byte chunk (2 c4 + hf) of the 64-byte row at position ^ ((j >> 1) & 7) -> waddr0 ^ (16 c4)
+    const int waddr0 = p_wave + j * 64 + 8 * (hf ^ ((j >> 1) & 7));
+    const int st_lane = ST_OFF + 8 * j;                                  // statistics [2][NW][TR] of (max, sum)
+    const bool attn_vec = AUX && (P.attn_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(P.attn) & 15) == 0;
+
+    // fragment reads
+    auto q_frag = [&](int qa, int kb, int lo) __attribute__((always_inline)) -> bf16x8 {
+        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(smem + qa + 16 * (8 * (kb >> 1) + 4 * lo + 2 * (kb & 1))));
+    };
+    auto v_frag = [&](int va, int sk, int lo) __attribute__((always_inline)) -> bf16x8 {
+        const unsigned char* vp = smem + va + sk * 16 * ROWB + 256 * lo;
+        return tr_frag(vp, vp + 4 * ROWB);
+    };
+    auto p_frag = [&](int blk, int sk, int lo) __attribute__((always_inline)) -> bf16x8 {
+        const int o = blk * PBUF + lo * (PBUF / 2) + sk * 16 * 64;
+        return tr_frag(smem + poff0 + o, smem + poff1 + o);
+    };
+
+    // ================================================================ the wave program, for NB key blocks (BPW, fewer in the last wave)
+    // LASTW: this wave owns the last key block (its padded keys are masked)
+    auto run = [&](auto lastw_t) __attribute__((always_inline)) {
+        constexpr bool LASTW = decltype(lastw_t)::value;
+        constexpr int NB = LASTW ? NKB - BPW * (NW - 1) : BPW;
+        constexpr int MASKB = LASTW ? NB - 1 : -1;                       // block (0 / 1) whose padded keys are masked, or none
+        const int klast = P.k - 32 * (NKB - 1);                          // valid keys of the last key block
+
+        // ---- Kp fragments of the wave's key blocks: MFMA A operands, hi and lo, for the whole head -- 16-byte loads out of the
+        // fragment-ordered image x3p_prep_kp_kernel made of Kp (scaled and split there: nothing but the loads happens here, so a
+        // head change inside a workgroup's range costs one L2 round trip)
+        bf16x8 kph[NB][NKS], kpl[NB][NKS];
+        auto load_kp = [&](int a_) __attribute__((always_inline)) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const u32x4* src = P.kp_frag + ((int64_t)(a_ * NKB + BPW * w + b) * NKS * 2) * 64 + lane;
+#pragma unroll
+                for (int kb = 0; kb < NKS; ++kb) {
+                    kph[b][kb] = __builtin_bit_cast(bf16x8, src[(2 * kb) * 64]);
+                    kpl[b][kb] = __builtin_bit_cast(bf16x8, src[(2 * kb + 1) * 64]);
+                }
+            }
+            if constexpr (BPW == 2) {
+                // one wave per SIMD = 256 architectural + 256 accumulation registers, and only MFMA operands can live in the
+                // latter: park key fragments there (they are read by MFMAs only), the vector work keeps the VGPRs
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int kb = 0; kb < NKS; ++kb) {
+                        if (KP_AGPR > 2 * b) asm volatile("" : "+a"(kph[b][kb]));
+                        if (KP_AGPR > 2 * b + 1) asm volatile("" : "+a"(kpl[b][kb]));
+                    }
+            }
+        };
+        // ---- state
+        f32x16 Tacc[NB];                      // score accumulators of GEMM1 (tile i + 1)
+        float E[NB][16];                      // exp2(s - max) of tile i
+        float mw = 0.f;                       // the wave's row maximum that belongs to E
+        f32x16 acc_o[NB][NCB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) E[b][r] = 0.f, Tacc[b][r] = 0.f;
+        }
+        auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc_o[b][cb][r] = 0.f;
+        };
+        zero_acc();
+        auto flush = [&](int head) __attribute__((always_inline)) {
+            const int seg = head - first_head;
+            float* dst = P.partial + ((int64_t)bid * P.seg_count + seg) * (int64_t)(NKB * NCB) * 1024;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const int t_idx = (BPW * w + b) * NCB + cb;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4)
+                        if (32 * (BPW * w + b) + 8 * q4 < P.k) {
+                            const f32x4 v4 = {acc_o[b][cb][q4 * 4], acc_o[b][cb][q4 * 4 + 1], acc_o[b][cb][q4 * 4 + 2], acc_o[b][cb][q4 * 4 + 3]};
+                            *reinterpret_cast<f32x4*>(dst + ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4) = v4;
+                        }
+                }
+        };
+
+        // ---- the vector work of one iteration, cut into UNITS (executed in this order)
+        //   first half, tile i (E -> P images of this wave's key blocks):
+        //     0               fetch the (max, sum) pairs of all waves (published before the last barrier)
+        //     1               max over the waves;  2 .. 1 + NW: one wave's exp2 / fma each;  2 + NW: the row's factor
+        //     then per block, per 4-key chunk: {scale 4 values, pack hi, store | residuals | pack lo, store}
+        //   second half, tile i + 1 (score tuples -> E):
+        //     2 per block     max over 8 scores each (MASKB: padded keys -> -inf first);  then 1: across the lane halves
+        //     16 per block    e = exp2(s - max), running sums
+        //     1               sum across the halves, publish (max, sum) of the wave's 32 rows
+        constexpr int U_NORM = NW + 3, N_FIRST = U_NORM + 12 * NB;
+        constexpr int U_MAX = N_FIRST, U_XH = U_MAX + 2 * NB, U_EXP = U_XH + 1, U_PUB = U_EXP + 16 * NB, NUNITS = U_PUB + 1;
+        struct VS {
+            float mx[2 * NB], l0, l1, m, l, fscale;
+            f32x2 sv[NW];
+            f32x4 p4;
+            unsigned h01, h23;
+            float r0, r1, r2, r3;
+        };
+        auto masked = [&](float x, int b, int r) __attribute__((always_inline)) -> float {
+            if (b == MASKB) return ((r & 3) + 8 * (r >> 2) + 4 * hf) < klast ? x : -INFINITY;
+            return x;
+        };
+        // cno / rows_ok: the (head, tile) of tile i and the number of its rows that exist (0 in the fill iteration: P := 0)
+        auto unit = [&](auto u_t, VS& s, int par_n, const Cur cno, int rows_ok) __attribute__((always_inline)) {
+            constexpr int u = decltype(u_t)::value;
+            if constexpr (u == 0) {
+#pragma unroll
+                for (int b = 0; b < NW; ++b) s.sv[b] = *reinterpret_cast<const f32x2*>(smem + st_lane + (par_n * NW + b) * (TR * 8));
+            } else if constexpr (u == 1) {
+                float m = s.sv[0][0];
+#pragma unroll
+                for (int b = 1; b < NW; ++b) m = fmaxf(m, s.sv[b][0]);
+                s.m = m, s.l = 0.f;
+            } else if constexpr (u < 2 + NW) {
+                constexpr int b = u - 2;
+                s.l = fmaf(s.sv[b][1], __builtin_amdgcn_exp2f(s.sv[b][0] - s.m), s.l);
+            } else if constexpr (u == 2 + NW) {
+                const bool rvalid = j < rows_ok;
+                if constexpr (AUX)
+                    if (P.lse && rvalid && hf == 0 && w == 0)
+                        P.lse[(int64_t)cno.a * P.n + cno.t * TR + j] = (s.m + __log2f(s.l)) * 0.69314718055994530942f;
+                float fs = __builtin_amdgcn_exp2f(mw - s.m) * __builtin_amdgcn_rcpf(s.l);
+                asm volatile("" : "+v"(fs));              // keep the select below a select (no branch around the exp / rcp)
+                s.fscale = rvalid ? fs : 0.f;
+            } else if constexpr (u < N_FIRST) {
+                constexpr int b = (u - U_NORM) / 12, c4 = ((u - U_NORM) % 12) / 3, part = (u - U_NORM) % 3;
+                unsigned char* pb = smem + (waddr0 ^ (16 * c4)) + b * PBUF;
+                if constexpr (part == 0) {
+                    s.p4 = f32x4{E[b][4 * c4] * s.fscale, E[b][4 * c4 + 1] * s.fscale, E[b][4 * c4 + 2] * s.fscale, E[b][4 * c4 + 3] * s.fscale};
+                    if constexpr (AUX) {
+                        if (P.attn && j < rows_ok) {
+                            const int key0 = 32 * (BPW * w + b) + 8 * c4 + 4 * hf;
+                            float* arow = P.attn + ((int64_t)cno.a * P.n + cno.t * TR + j) * P.attn_ld + key0;
+                            if (attn_vec && key0 + 4 <= P.k) {
+                                *reinterpret_cast<f32x4*>(arow) = s.p4;
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (key0 + e < P.k) arow[e] = s.p4[e];
+                            }
+                        }
+                    }
+                    s.h01 = cvt_pk(s.p4[0], s.p4[1]), s.h23 = cvt_pk(s.p4[2], s.p4[3]);
+                    *reinterpret_cast<u32x2*>(pb) = u32x2{s.h01, s.h23};
+                } else if constexpr (part == 1) {
+                    s.r0 = s.p4[0] - __uint_as_float(s.h01 << 16), s.r1 = s.p4[1] - __uint_as_float(s.h01 & 0xffff0000u);
+                    s.r2 = s.p4[2] - __uint_as_float(s.h23 << 16), s.r3 = s.p4[3] - __uint_as_float(s.h23 & 0xffff0000u);
+                } else {
+                    *reinterpret_cast<u32x2*>(pb + PBUF / 2) = u32x2{cvt_pk(s.r0, s.r1), cvt_pk(s.r2, s.r3)};
+                }
+            } else if constexpr (u < U_XH) {
+                constexpr int b = (u - U_MAX) / 2, r0 = 8 * ((u - U_MAX) % 2);
+                float x[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) x[r] = masked(Tacc[b][r0 + r], b, r0 + r);
+                float mx = fmaxf(fmaxf(x[0], x[1]), x[2]);
+                mx = fmaxf(fmaxf(mx, x[3]), x[4]);
+                mx = fmaxf(fmaxf(mx, x[5]), x[6]);
+                s.mx[u - U_MAX] = fmaxf(mx, x[7]);
+            } else if constexpr (u == U_XH) {
+                // the exp pass reads the score tuples again instead of keeping copies of the max pass alive
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if constexpr (BPW == 2) asm volatile("" : "+a"(Tacc[b])); else asm volatile("" : "+v"(Tacc[b]));
+                }
+                float mx = s.mx[0];
+#pragma unroll
+                for (int q = 1; q < 2 * NB; ++q) mx = fmaxf(mx, s.mx[q]);
+                mw = xhalf_max(mx);
+                s.l0 = 0.f, s.l1 = 0.f;
+            } else if constexpr (u < U_PUB) {
+                constexpr int b = (u - U_EXP) / 16, r = (u - U_EXP) % 16;
+                E[b][r] = __builtin_amdgcn_exp2f(masked(Tacc[b][r], b, r) - mw);
+                if constexpr (r & 1) s.l1 += E[b][r]; else s.l0 += E[b][r];
+            } else {
+                const float lsum = xhalf_sum(s.l0 + s.l1);
+                *reinterpret_cast<f32x2*>(smem + st_lane + ((par_n ^ 1) * NW + w) * (TR * 8)) = f32x2{mw, lsum};   // both halves: same pair
+            }
+        };
+        // MFMA slots of an iteration: NB 3 NKS of GEMM1, then NB 3 NKS of GEMM2.  GEMM1 issues the 3 NB MFMAs of a k-step back to
+        // back (the accumulation chain of a key block is ONE dependent chain: an MFMA that follows its predecessor directly gets
+        // the accumulator forwarded, one that follows a gap waits out the whole pipeline) and then the vector units of those slots;
+        // the other wave of the SIMD fills the matrix pipe meanwhile.  GEMM2 rotates over 4 NB accumulators: one MFMA, one gap.
+        // The first-half units ride behind slots 0 .. H - 3 NB - 1, so that the P images are complete before the first
+        // transpose-read is requested; the second-half units behind slots H + 4 .. 2 H - 1 (the last GEMM1 results are in flight).
+        constexpr int H = NB * 3 * NKS;
+        constexpr int F_LO = 0, F_HI = H - 3 * NB, S_LO = H + 4, S_HI = 2 * H;
+#define X3P_UB1(k) ((k) <= F_LO ? 0 : (k) >= F_HI ? N_FIRST : (((k) - F_LO) * N_FIRST + (F_HI - F_LO) / 2) / (F_HI - F_LO))
+#define X3P_UB2(k) ((k) <= S_LO ? N_FIRST : (k) >= S_HI ? NUNITS : N_FIRST + (((k) - S_LO) * (NUNITS - N_FIRST) + (S_HI - S_LO) / 2) / (S_HI - S_LO))
+#define X3P_UB(k) ((k) < H ? X3P_UB1(k) : X3P_UB2(k))
+
+        // ---- one pipeline iteration: GEMM1(i + 1) | normalise(i), then GEMM2(i) | statistics(i + 1).
+        // Tile x lives in ring slot x % 3; statistics of tile x in buffer x & 1.  DMA issued here: Q(i + 3), V(i + 2).
+        // The SAME body runs the fill (i = -1: tile -1 does not exist -> rows_ok = 0, P = 0; its accumulators are zeroed again
+        // before tile 0) and the drain (i = T - 1: GEMM1 / statistics of a tile T that does not exist run on stale operands and
+        // are never consumed): one code path means one register allocation, and no spill code anywhere near the loop.
+        auto iteration = [&](int i, int slot_q, int slot_v, const DmaOff& doff, const Cur cno, const Cur c2, const Cur c3,
+                             int rows_ok) __attribute__((always_inline)) {
+            const int par_n = i & 1;
+            const int qa = q_lane + slot_q * QSLOT;         // Q(i + 1): slot (i + 1) % 3
+            int va[NCB];                                    // V(i): slot i % 3
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) va[cb] = (voff0 + slot_v * VSLOT) ^ (64 * cb);
+
+            // nothing of this wave is in flight here (the wait that closed the last iteration); said again INSIDE the loop body for
+            // hipcc's wait-count pass, which otherwise spreads waits for loads of the loop pre-header over the body -- where, the
+            // LDS-DMAs being invisible to it, they would drain the prefetch every iteration
+            X3P_WAIT_VM0();
+            X3P_STAMP(i + 1, 0);
+            issue_dma(doff, i + 3 < T, c3, slot_v, i + 2 < T, c2, slot_q == 2 ? 0 : slot_q + 1);   // (i + 3) % 3 = i % 3;  (i + 2) % 3
+            X3P_STAMP(i + 1, 1);
+            VS vs;
+            bf16x8 ql[NKS], qh[NKS], vl[2 * NCB], vh[2 * NCB], ph[NB][2], pl[NB][2];
+            ql[0] = q_frag(qa, 0, 1);
+            qh[0] = q_frag(qa, 0, 0);
+            // ---------------- first half: GEMM1.  k-step e: products Kh Ql, Kl Qh, Kh Qh for every key block, back to back
+            static_for<0, NKS>([&](auto e_t) __attribute__((always_inline)) {
+                constexpr int e = decltype(e_t)::value;
+                X3P_FENCE();
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if constexpr (e == 0)
+                        Tacc[b] = mfma(kph[b][e], ql[e], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+                    else
+                        Tacc[b] = mfma(kph[b][e], ql[e], Tacc[b]);
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) Tacc[b] = mfma(kpl[b][e], qh[e], Tacc[b]);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) Tacc[b] = mfma(kph[b][e], qh[e], Tacc[b]);
+                if constexpr (e + 1 < NKS) {                // the next k-step's fragments
+                    ql[e + 1] = q_frag(qa, e + 1, 1);
+                    qh[e + 1] = q_frag(qa, e + 1, 0);
+                } else {                                    // all P chunks are written: first step of GEMM2
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) ph[bb][0] = p_frag(bb, 0, 0);
+                    vl[0] = v_frag(va[0], 0, 1);
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) pl[bb][0] = p_frag(bb, 0, 1);
+                    vh[0] = v_frag(va[0], 0, 0);
+                }
+                X3P_FENCE();
+                static_for<X3P_UB(3 * NB * e), X3P_UB(3 * NB * (e + 1))>([&](auto u_t) __attribute__((always_inline)) {
+                    unit(u_t, vs, par_n, cno, rows_ok);
+                });
+            });
+            X3P_STAMP(i + 1, 2);
+            // ---------------- second half: GEMM2.  step e = (16-row k-step e / 4, column block e % 4): Ph Vl, Pl Vh, Ph Vh
+            static_for<0, 2 * NCB>([&](auto e_t) __attribute__((always_inline)) {
+                constexpr int e = decltype(e_t)::value, sk = e / NCB, cb = e % NCB;
+                constexpr int e1 = e + 1, sk1 = e1 / NCB, cb1 = e1 % NCB;
+                static_for<0, 3 * NB>([&](auto m_t) __attribute__((always_inline)) {
+                    constexpr int mi = decltype(m_t)::value, k = H + 3 * NB * e + mi, prod = mi / NB, b = mi % NB;
+                    X3P_FENCE();
+                    if constexpr (prod == 0) acc_o[b][cb] = mfma(ph[b][sk], vl[e], acc_o[b][cb]);
+                    if constexpr (prod == 1) acc_o[b][cb] = mfma(pl[b][sk], vh[e], acc_o[b][cb]);
+                    if constexpr (prod == 2) acc_o[b][cb] = mfma(ph[b][sk], vh[e], acc_o[b][cb]);
+                    if constexpr (e1 < 2 * NCB) {           // the next step's fragments
+                        if constexpr (mi == 0) vl[e1] = v_frag(va[cb1], sk1, 1);
+                        if constexpr (mi == NB) vh[e1] = v_frag(va[cb1], sk1, 0);
+                        if constexpr (cb1 == 0 && mi == 1) {
+#pragma unroll
+                            for (int bb = 0; bb < NB; ++bb) ph[bb][sk1] = p_frag(bb, sk1, 0);
+                        }
+                        if constexpr (cb1 == 0 && mi == NB + 1) {
+#pragma unroll
+                            for (int bb = 0; bb < NB; ++bb) pl[bb][sk1] = p_frag(bb, sk1, 1);
+                        }
+                    }
+                    static_for<X3P_UB(k), X3P_UB(k + 1)>([&](auto u_t) __attribute__((always_inline)) { unit(u_t, vs, par_n, cno, rows_ok); });
+                });
+            });
+            X3P_FENCE();
+            X3P_STAMP(i + 1, 3);
+        };
+
+        // ---- the pipeline.  Prologue DMA: Q(0), Q(1), V(0), V(1); iteration i issues Q(i + 3), V(i + 2).
+        Cur c0, c1, c2, c3;                   // items i, i + 1, i + 2, i + 3
+        c1.a = first_head, c1.t = f_begin - first_head * P.tiles_per_head;   // item 0
+        c0 = c1;                              // item -1 does not exist (any valid cursor)
+        c2 = cur_next(c1);
+        c3 = cur_next(c2);
+        DmaOff doff = load_dma_off();
+        issue_dma(doff, true, c1, 0, true, c1, 0);
+        issue_dma(doff, 1 < T, c2, 1, 1 < T, c2, 1);
+        int head_g1 = c1.a, head_g2 = -1;     // heads whose Kp fragments / accumulators are in registers
+        load_kp(head_g1);
+        X3P_WAIT_VM0();
+        __builtin_amdgcn_s_barrier();
+        int slot_q = 0, slot_v = 2;           // (i + 1) % 3, i % 3 for i = -1
+        for (int i = -1; i < T; ++i) {
+            // head changes (wave-uniform, rare): accumulators of a finished head out, Kp fragments of the next head in
+            if (i >= 0 && c0.a != head_g2) {
+                if (head_g2 >= 0) flush(head_g2);
+                zero_acc();
+                head_g2 = c0.a;
+            }
+            if (i + 1 < T && c1.a != head_g1) {
+                load_kp(c1.a);
+                head_g1 = c1.a;
+            }
+            int rows_ok = 0;
+            if (i >= 0) {
+                rows_ok = n32 - c0.t * TR;
+                if (rows_ok > TR) rows_ok = TR;
+            }
+            iteration(i, slot_q, slot_v, doff, c0, c2, c3, rows_ok);
+            doff = load_dma_off();            // for the next iteration
+            // the DMAs issued in this iteration have landed for this wave; together with the barrier: for every wave
+            X3P_WAIT_VM0();
+            X3P_STAMP(i + 1, 4);
+            __builtin_amdgcn_s_barrier();
+            X3P_STAMP(i + 1, 5);
+            slot_v = slot_q;
+            slot_q = slot_q == 2 ? 0 : slot_q + 1;
+            c0 = c1, c1 = c2, c2 = c3, c3 = cur_next(c3);
+        }
+        flush(head_g2);
+#undef X3P_UB
+#undef X3P_UB1
+#undef X3P_UB2
+    };
+    if (w == NW - 1)
+        run(std::true_type{});
+    else
+        run(std::false_type{});
+}
+
+// Kp [k, h dk] f32 -> the MFMA A fragments the attention waves keep in registers: [h][nkb][dk / 16][hi | lo][64 lanes] x 16 bytes,
+// value = Kp * scale * log2(e) (the softmax runs in base 2), hi = bf16(v), lo = bf16(v - hi); padded keys are zero.
+// One wave per (head, key block).
+template <int DK>
+__global__ __launch_bounds__(64) void x3p_prep_kp_kernel(const float* __restrict__ kp, int64_t ldkp, int k, int nkb, float c_exp,
+                                                          u32x4* __restrict__ out) {
+    constexpr int NKS = DK / 16;
+    const int a = blockIdx.y, b = blockIdx.x, lane = threadIdx.x;
+    int key = 32 * b + (lane & 31);
+    const bool pad = key >= k;
+    if (pad) key = k - 1;
+    const int hf = lane >> 5;
+    u32x4* dst = out + ((int64_t)(a * nkb + b) * NKS * 2) * 64 + lane;
+    f32x8 raw[NKS];
+#pragma unroll
+    for (int kb = 0; kb < NKS; ++kb) raw[kb] = load8(kp + (int64_t)key * ldkp + a * DK + 16 * kb + 8 * hf);
+#pragma unroll
+    for (int kb = 0; kb < NKS; ++kb) {
+        u32x4 hi, lo;
+        split8(raw[kb] * c_exp, hi, lo);
+        if (pad) hi = lo = u32x4{0u, 0u, 0u, 0u};
+        dst[(2 * kb) * 64] = hi;
+        dst[(2 * kb + 1) * 64] = lo;
+    }
+}
+
+// out[key, a*DK + col] = sum over the (workgroup, segment) partials of head a, ascending workgroup order (fixed: bit-reproducible)
+template <int DK>
+__global__ __launch_bounds__(64) void x3p_reduce_kernel(const float* __restrict__ partial, int nkb, int num_wg, int seg_count,
+                                                         int tiles_per_head, int tiles_per_wg, int k, int h, float* __restrict__ out) {
+    constexpr int NCB = DK / 32;
+    const int tiles = nkb * NCB;
+    const int a = blockIdx.y;
+    const int unit = blockIdx.x;   // (tile, q4): one wave per workgroup, so that the units spread over all CUs
+    const int lane = threadIdx.x;
+    const int t_idx = unit >> 2, q4 = unit & 3;
+    if (32 * (t_idx / NCB) + 8 * q4 >= k) return;
+    const int f_lo = a * tiles_per_head, f_hi = (a + 1) * tiles_per_head - 1;
+    const int b_lo = f_lo / tiles_per_wg;
+    int b_hi = f_hi / tiles_per_wg;
+    if (b_hi > num_wg - 1) b_hi = num_wg - 1;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const int64_t off = ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4;
+    for (int b = b_lo; b <= b_hi; b += 16) {
+        f32x4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (b + u <= b_hi) {
+                const int seg = a - ((b + u) * tiles_per_wg) / tiles_per_head;
+                v[u] = *reinterpret_cast<const f32x4*>(partial + ((int64_t)(b + u) * seg_count + seg) * (int64_t)tiles * 1024 + off);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    const int kb = t_idx / NCB, cbk = t_idx - kb * NCB;
+    const int col = a * DK + 32 * cbk + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int key = 32 * kb + i + 8 * q4 + 4 * (lane >> 5);
+        if (key < k) out[(int64_t)key * (h * DK) + col] = s[i];
+    }
+}
+
+struct X3PPlan {
+    int num_wg, tiles_per_head, tiles_per_wg, total_tiles, seg_count, nkb;
+};
+bool x3p_plan(int64_t n, int k, int h, int dk, X3PPlan* pl) {
+    if (dk != 128 || k < 1 || k > 256 || n < 1 || h < 1) return false;
+    const int64_t tph = (n + TR - 1) / TR, total = tph * h;
+    if (total > 0x7fffffff) return false;
+    const int cus = snf::cu_count();
+    int64_t num_wg = total < cus ? total : cus;
+    const int64_t tpw = (total + num_wg - 1) / num_wg;
+    num_wg = (total + tpw - 1) / tpw;
+    pl->num_wg = (int)num_wg;
+    pl->tiles_per_head = (int)tph;
+    pl->tiles_per_wg = (int)tpw;
+    pl->total_tiles = (int)total;
+    pl->seg_count = (int)((tpw + tph - 1) / tph + 1);
+    pl->nkb = (k + 31) / 32;
+    return true;
+}
+size_t x3p_partial_bytes(const X3PPlan& pl, int dk) { return (size_t)pl.num_wg * pl.seg_count * (size_t)(pl.nkb * (dk / 32)) * 1024 * sizeof(float); }
+size_t x3p_kpfrag_bytes(const X3PPlan& pl, int h, int dk) { return (size_t)h * pl.nkb * (dk / 16) * 2 * 64 * 16; }
+size_t x3p_workspace(const X3PPlan& pl, int h, int dk) { return x3p_partial_bytes(pl, dk) + x3p_kpfrag_bytes(pl, h, dk); }
+
+template <int DK, int NKB, int BPW, bool AUX>
+int x3p_launch(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s) {
+    constexpr int lds = x3p_lds_bytes(DK, NKB, BPW);
+    auto kern = sparse_attn_x3p_kernel<DK, NKB, BPW, AUX, 0>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        snf::set_error("sparse_attn_x3p: cannot reserve %d bytes of LDS", lds);
+        (void)hipGetLastError();
+        return SNF_ELAUNCH;
+    }
+    hipLaunchKernelGGL((x3p_prep_kp_kernel<DK>), dim3(NKB, P.h), dim3(64), 0, s, P.kp, P.ldkp, P.k, NKB, P.scale * 1.44269504088896340736f,
+                       const_cast<u32x4*>(P.kp_frag));
+    int rc0 = snf::check_launch("x3p_prep_kp_kernel");
+    if (rc0) return rc0;
+    hipLaunchKernelGGL(kern, dim3(pl.num_wg), dim3(64 * ((NKB + BPW - 1) / BPW)), lds, s, P);
+    int rc = snf::check_launch("sparse_attn_x3p_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL((x3p_reduce_kernel<DK>), dim3(NKB * (DK / 32) * 4, P.h), dim3(64), 0, s, P.partial, NKB, pl.num_wg, pl.seg_count,
+                       pl.tiles_per_head, pl.tiles_per_wg, P.k, P.h, out);
+    return snf::check_launch("x3p_reduce_kernel");
+}
+template <int DK>
+int x3p_dispatch(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s) {
+    const bool aux = P.attn != nullptr || P.lse != nullptr;
+    static const int bpw = getenv("SNF_X3P_BPW") ? atoi(getenv("SNF_X3P_BPW")) : 1;   // development switch
+#define SNF_X3P_CASE(NB) \
+    case NB: return bpw == 2 ? (aux ? x3p_launch<DK, NB, 2, true>(P, pl, out, s) : x3p_launch<DK, NB, 2, false>(P, pl, out, s)) \
+                             : (aux ? x3p_launch<DK, NB, 1, true>(P, pl, out, s) : x3p_launch<DK, NB, 1, false>(P, pl, out, s));
+    switch (pl.nkb) {
+#ifndef SNF_ATTN_DEV
+        SNF_X3P_CASE(1)
+        SNF_X3P_CASE(2)
+        SNF_X3P_CASE(3)
+        SNF_X3P_CASE(4)
+        SNF_X3P_CASE(5)
+        SNF_X3P_CASE(6)
+#endif
+        SNF_X3P_CASE(7)
+#ifndef SNF_ATTN_DEV
+        SNF_X3P_CASE(8)
+#endif
+        default: break;
+    }
+#undef SNF_X3P_CASE
+    snf::set_error("sparse_attn_x3p: key-block count %d not built", pl.nkb);
+    return SNF_EUNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t snf_sparse_attn_fwd_x3_hl_workspace_bytes(int64_t n, int k, int h, int dk) {
+    X3PPlan pl;
+    if (!x3p_plan(n, k, h, dk, &pl)) return 0;
+    return x3p_workspace(pl, h, dk);
+}
+
+int snf_sparse_attn_fwd_x3_hl(const void* q_hl, int64_t ldq, const void* v_hl, int64_t ldv, const float* kp, int64_t n, int k, int h,
+                              int dk, float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
+                              snf_stream_t stream) {
+    SNF_REQUIRE(q_hl && v_hl && kp && out, "snf_sparse_attn_fwd_x3_hl: null pointer");
+    X3PPlan pl;
+    if (!x3p_plan(n, k, h, dk, &pl)) {
+        snf::set_error("snf_sparse_attn_fwd_x3_hl: unsupported shape n=%lld k=%d h=%d dk=%d (dk = 128, 1 <= k <= 256)", (long long)n, k, h, dk);
+        return SNF_EUNSUPPORTED;
+    }
+    const int64_t d = (int64_t)h * dk;
+    SNF_REQUIRE(ldq >= 2 * d && ldv >= 2 * d && (ldq % 8) == 0 && (ldv % 8) == 0, "snf_sparse_attn_fwd_x3_hl: ldq=%lld / ldv=%lld must be "
+                ">= 2*h*dk bf16 and keep rows 16-byte aligned", (long long)ldq, (long long)ldv);
+    SNF_REQUIRE(((reinterpret_cast<uintptr_t>(q_hl) | reinterpret_cast<uintptr_t>(v_hl) | reinterpret_cast<uintptr_t>(kp)) & 15) == 0,
+                "snf_sparse_attn_fwd_x3_hl: q / v / kp must be 16-byte aligned");
+    const size_t need = x3p_workspace(pl, h, dk);
+    if (!workspace || workspace_bytes < need) {
+        snf::set_error("snf_sparse_attn_fwd_x3_hl: workspace %zu < %zu", workspace_bytes, need);
+        return SNF_EWORKSPACE;
+    }
+    X3PParams P;
+    P.q = reinterpret_cast<const unsigned short*>(q_hl), P.v = reinterpret_cast<const unsigned short*>(v_hl), P.kp = kp;
+    P.n = n, P.ldq = ldq, P.ldv = ldv, P.ldkp = d;
+    P.k = k, P.h = h, P.scale = scale;
+    P.attn = attn, P.attn_ld = k, P.lse = lse;
+    P.stats = nullptr;
+    P.trace = snf::g_attn_trace, P.trace_wg = snf::g_attn_trace_wg;
+    P.partial = reinterpret_cast<float*>(workspace);
+    P.kp_frag = reinterpret_cast<const u32x4*>(reinterpret_cast<unsigned char*>(workspace) + x3p_partial_bytes(pl, dk));
+    P.tiles_per_head = pl.tiles_per_head, P.tiles_per_wg = pl.tiles_per_wg, P.total_tiles = pl.total_tiles;
+    P.seg_count = pl.seg_count;
+    return x3p_dispatch<128>(P, pl, out, snf::as_stream(stream));
+}
+
+}  // extern "C"

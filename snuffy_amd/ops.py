@@ -640,6 +640,38 @@ def sparse_attn_fwd_x3(q, v, kp, h, scale=None, need_attn=False, need_lse=False)
     return out, attn, lse
 
 
+def x3_hl_attn_supported(k, dk):
+    """Shapes of the pipelined fp32-class attention kernel on pre-split operands (snf_sparse_attn_fwd_x3_hl)."""
+    return dk == 128 and 1 <= k <= 256
+
+
+def sparse_attn_fwd_x3_hl(q_hl, v_hl, kp, h, scale=None, need_attn=False, need_lse=False):
+    """fp32-class sparse attention on PRE-SPLIT operands (snf_sparse_attn_fwd_x3_hl): q_hl, v_hl [n, 2 d] bf16 interleaved split
+    images (split_hl_rows / gemm_hl(hl_out=True); row-strided views allowed, e.g. the two halves of the [Q | V] projection's
+    image), kp [k, d] f32 -> (out [k, d] f32, attn [h, n, k] or None, lse [h, n] or None)."""
+    if q_hl.dtype != torch.bfloat16 or v_hl.dtype != torch.bfloat16:
+        raise TypeError("sparse_attn_fwd_x3_hl: q_hl and v_hl must be bfloat16 hl images")
+    q_hl = _rows16(q_hl, "q_hl")
+    v_hl = _rows16(v_hl, "v_hl")
+    kp = _req(kp, torch.float32, "kp", 2)
+    n, d2 = q_hl.shape
+    k, d = kp.shape
+    if d2 != 2 * d or d % h or v_hl.shape != q_hl.shape:
+        raise ValueError("sparse_attn_fwd_x3_hl: inconsistent shapes q_hl %s v_hl %s kp %s h %d" % (tuple(q_hl.shape), tuple(v_hl.shape),
+                                                                                                   tuple(kp.shape), h))
+    dk = d // h
+    scale = 1.0 / math.sqrt(dk) if scale is None else scale
+    lib = _ffi.load()
+    out = torch.empty(k, d, dtype=torch.float32, device=q_hl.device)
+    attn = torch.empty(h, n, k, dtype=torch.float32, device=q_hl.device) if need_attn else None
+    lse = torch.empty(h, n, dtype=torch.float32, device=q_hl.device) if need_lse else None
+    wsb = lib.snf_sparse_attn_fwd_x3_hl_workspace_bytes(n, k, h, dk)
+    ws = _ws(wsb, q_hl.device)
+    check(lib.snf_sparse_attn_fwd_x3_hl(_p(q_hl), q_hl.stride(0), _p(v_hl), v_hl.stride(0), _p(kp), n, k, h, dk, float(scale), _p(out),
+                                        _p(attn), _p(lse), _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_x3_hl")
+    return out, attn, lse
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # varlen path: many bags per launch (include/snuffy_hip.h "Varlen path")
 # ----------------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,13 @@
+#!/bin/bash
+# development: build the config-B variant of the pipelined attention kernel with ablation defines and time / trace it
+# usage (on the GPU box): tools/x3p_abl.sh "<defs>" [bpw] [trace-wg]
+set -e
+cd "$(dirname "$0")/.."
+touch snuffy_amd/csrc/sparse_attn_x3p.hip
+SNF_ATTN_DEV=1 SNF_EXTRA_DEFS="$1" python -c "from snuffy_amd.build import build_lib; build_lib()" 
+echo "== defs: [$1] bpw=${2:-1}"
+if [ -n "$3" ]; then
+  SNF_X3P_BPW=${2:-1} python tools/x3p_trace.py $3 2>&1 | grep -v amdgpu.ids
+else
+  SNF_X3P_BPW=${2:-1} python tools/x3p_dev.py 32768 200 6 --time 2>&1 | grep -v amdgpu.ids
+fi
