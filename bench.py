@@ -86,6 +86,7 @@ def timed(fn, iters, warmup=2):
 
 def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
     """Live timing of the north-star kernels on synthetic operands of the workload's shape."""
+    from snuffy_amd import functional as SF
     from snuffy_amd import ops
     N, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
     K, dk = min(lam, N), D // h
@@ -121,6 +122,17 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
             i = state["i"] = (state["i"] + 1) % nset
             ops.sparse_attn_fwd_mfma(qvs[i][:, :D], qvs[i][:, D:], kp_in, N, h)
         kern = "sparse_attn_mfma_kernel+reduce_partials_kernel"
+    elif precision == "fp32" and SF.X3_HL_ATTENTION and SF.FP32_GEMM == "x3" and ops.x3_hl_attn_supported(K, dk) \
+            and ops.hl_eligible(N, 2 * D, D):
+        # what functional.encoder_layer dispatches for a bag this size: the pipelined split-bf16 x3 kernel on the hl image the
+        # Q | V projection writes (4 bytes per element, like the fp32 tensor); three launches: Kp split, main, reduction
+        imgs = [ops.split_hl_rows(qv.float()) for qv in qvs]      # [N, 4 D] bf16 = image of Q | image of V
+
+        def attn():
+            i = state["i"] = (state["i"] + 1) % nset
+            ops.sparse_attn_fwd_x3_hl(imgs[i][:, :2 * D], imgs[i][:, 2 * D:], kp, h)
+        kern = "sparse_attn_x3p_kernel+x3p_prep_kp_kernel+x3p_reduce_kernel"
+        elt = 4
     elif precision == "fp32" and ops.x3_attn_supported(K, dk):   # the fp32 path's kernel: split-bf16 x 3 on the matrix cores
         vs = [qv[:, D:].float().contiguous() for qv in qvs]
         qf = [qv[:, :D].float().contiguous() for qv in qvs]
@@ -152,6 +164,12 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
         if precision == "bf16":
             def run_warm():
                 ops.sparse_attn_fwd_mfma(buf[:, :D], buf[:, D:], kp_in, N, h)
+        elif kern.startswith("sparse_attn_x3p"):
+            src = imgs[0]
+            buf = torch.empty_like(src)
+
+            def run_warm():
+                ops.sparse_attn_fwd_x3_hl(buf[:, :2 * D], buf[:, 2 * D:], kp, h)
         else:
             def run_warm():
                 ops.sparse_attn_fwd_x3(buf[:, :D], buf[:, D:], kp, h)

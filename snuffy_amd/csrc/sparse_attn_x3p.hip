@@ -1,7 +1,8 @@
 // K7, fp32-class, round 4: the split-bf16 x3 sparse attention of sparse_attn_x3.hip re-organised so that the matrix pipe and the
 // vector ALU overlap INSIDE every wave's instruction stream (PMC of the round-3 kernel: MFMA busy 33 % + VALU 35 % of the SIMD
 // cycles, adding up because its phases -- GEMM1 | softmax | GEMM2 -- were separated by workgroup barriers and every wave was in
-// the same phase at the same time).
+// the same phase at the same time; on gfx950 the MFMAs of one wave do not hide the vector work of its SIMD partner, only the
+// vector instructions a wave places between its OWN MFMAs are free).
 //
 //   per head a:   P_a = softmax_j(Q_a Kp_a^T * scale)  [n, k]      O_a = P_a^T V_a  [k, dk]        (snuffy.py:160-168)
 //
@@ -9,22 +10,22 @@
 //   * operands arrive PRE-SPLIT: Q and V as the interleaved "hl" images the projection GEMM writes in its epilogue (every 32 true
 //     columns as [hi(32) | lo(32)] bf16, gemm.hip) -- the same 4 bytes per element as the fp32 tensors and the same hi / lo values
 //     the round-3 kernel derived in registers.  Rows go HBM -> LDS by LDS-DMA in full 512-byte lines per row and head (no staging
-//     registers, no split, no ds_write), two tiles ahead.
-//   * ONE WAVE PER SIMD, TWO KEY BLOCKS PER WAVE (workgroup = ceil(k / 64) waves, 512 registers each): wave w owns keys 64 w ..
-//     64 w + 63 for everything -- their Kp fragments (registers, whole head), the scores S^T[64 keys, 32 rows] of every tile,
-//     their softmax, and the 64 x dk slice of the output accumulator.  P^T of a key block is produced and consumed by the same
-//     wave: it goes through a wave-private LDS region only to change from the accumulator layout (lane = row) to the A-operand
-//     layout (lane = key), with no barrier.  The only cross-wave exchange per tile is one (max, sum) pair per row and wave.
+//     registers, no split, no ds_write), three tiles ahead; Kp is split once per call by a tiny kernel into fragment order.
+//   * ONE WAVE PER KEY BLOCK (workgroup = ceil(k / 32) waves, two per SIMD): wave w owns keys 32 w .. 32 w + 31 for everything --
+//     their Kp fragments (registers, whole head), the scores S^T[32 keys, 32 rows] of every tile, their softmax, and the 32 x dk
+//     slice of the output accumulator.  P^T of a key block is produced and consumed by the same wave: it goes through a
+//     wave-private LDS region only to change from the accumulator layout (lane = row) to the A-operand layout (lane = key), with
+//     no barrier.  The only cross-wave exchange per tile is one (max, sum) pair per row and wave.
 //   * 32-row tiles, ONE workgroup barrier per tile, two-stage software pipeline.  Iteration i issues, in one instruction stream,
 //         first half:   GEMM1(i + 1) on the matrix pipe  |  combine + normalise + split + publish P(i) on the vector ALU
-//         second half:  GEMM2(i)     on the matrix pipe  |  max / exp2 / sum of S(i + 1), publish its statistics
-//     with the vector work cut into small units that are dropped, by hand, into the gaps behind the MFMAs (an in-order wave only
-//     overlaps the two pipes if its own stream alternates them; consecutive MFMAs always go to different accumulators -- the two
-//     key blocks alternate -- because a dependent MFMA issued behind a gap pays the full pipeline latency).
+//         second half:  GEMM2(i)     on the matrix pipe  |  max / exp2 / sum of S(i + 1), its statistics, the LDS-DMA issue
+//     with the vector work cut into small units that are dropped, by hand, into the gaps behind the MFMAs.  GEMM1 accumulates
+//     into TWO register tuples alternately (summed in the statistics pass): a dependent MFMA issued behind a gap waits out the
+//     whole matrix pipeline.
 //   * the scale (and log2 e) is folded into Kp before its split; padded keys are masked only in the last wave's own code path.
 //
 // LDS (dk = 128): Q ring 3 x 17 KiB (rows padded to 528 B: conflict-free B reads at immediate offsets) | V ring 3 x 16 KiB |
-// P 4 KiB per key block (hi 2 KiB + lo 2 KiB) | statistics 2 x waves x 256 B  = 133 KiB at 8 key blocks.
+// P 4 KiB per key block (hi 2 KiB + lo 2 KiB) | statistics 2 x waves x 256 B | DMA offset table  = 140 KiB at 8 key blocks.
 // Partial accumulators and their deterministic reduction as in sparse_attn_x3.hip (same layout).
 #include <math.h>
 #include <stdlib.h>
@@ -107,6 +108,21 @@ __device__ __forceinline__ float xhalf_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+// timing ablations (dev builds, tools/x3p_abl.sh; results wrong): a stage's MFMAs replaced by an opaque use of their operands
+__device__ __forceinline__ f32x16 mfma_off(bf16x8 a, bf16x8 b, f32x16 c) {
+    asm volatile("" : "+v"(c) : "v"(a), "v"(b));
+    return c;
+}
+#ifdef X3P_ABL_NO_G1
+#define X3P_MFMA1 mfma_off
+#else
+#define X3P_MFMA1 mfma
+#endif
+#ifdef X3P_ABL_NO_G2
+#define X3P_MFMA2 mfma_off
+#else
+#define X3P_MFMA2 mfma
+#endif
 __device__ __forceinline__ unsigned cvt_pk(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
 }
@@ -126,8 +142,15 @@ __device__ __forceinline__ unsigned cvt_pk(float a, float b) {
         if (P.trace && bid == P.trace_wg && lane == 0 && (it) >= 0 && (it) < 64)                                  \
             P.trace[(w * 64 + (it)) * 8 + (k)] = __builtin_amdgcn_s_memtime();                                    \
     } while (0)
+// finer: stamp idx (0 .. 15) inside iteration `it`, second table behind the first
+#define X3P_STAMP2(it, idx)                                                                                       \
+    do {                                                                                                          \
+        if (P.trace && bid == P.trace_wg && lane == 0 && (it) >= 0 && (it) < 64)                                  \
+            P.trace[8 * 64 * 8 + (w * 64 + (it)) * 16 + (idx)] = __builtin_amdgcn_s_memtime();                    \
+    } while (0)
 #else
 #define X3P_STAMP(it, k) do { } while (0)
+#define X3P_STAMP2(it, idx) do { } while (0)
 #endif
 
 // (head, tile) cursor over the flattened item space of one workgroup
@@ -136,20 +159,21 @@ struct Cur {
 };
 
 constexpr int x3p_qslot(int dk) { return ((TR * (4 * dk + 16) + 1023) / 1024) * 1024; }   // padded Q slot, whole DMA instructions
-constexpr int x3p_lds_bytes(int dk, int nkb, int bpw) {
-    const int nw = (nkb + bpw - 1) / bpw, ndma = x3p_qslot(dk) / 1024 + TR * 4 * dk / 1024;
-    return 3 * x3p_qslot(dk) + 3 * TR * 4 * dk + nkb * (TR * 64 * 2) + 2 * nw * TR * 8 + nw * ((ndma + nw - 1) / nw) * 256;
+constexpr int x3p_dma_u(int n, int nw) { return (n + nw - 1) / nw; }
+constexpr int x3p_lds_bytes(int dk, int nkb) {
+    const int nq = x3p_qslot(dk) / 1024, nv = TR * 4 * dk / 1024;
+    return 3 * x3p_qslot(dk) + 3 * TR * 4 * dk + nkb * (TR * 64 * 2) + 2 * nkb * TR * 8 + nkb * (x3p_dma_u(nq, nkb) + x3p_dma_u(nv, nkb)) * 256;
 }
 
 // MODE 0: all keys in this launch.  (MODE 2, a key chunk with the row statistics of all chunks given: not built yet.)
-template <int DK, int NKB, int BPW, bool AUX, int MODE>
-__global__ __launch_bounds__(64 * ((NKB + BPW - 1) / BPW), BPW == 1 ? 2 : 1) void sparse_attn_x3p_kernel(const X3PParams P) {
+template <int DK, int NKB, bool AUX, int MODE>
+__global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PParams P) {
     static_assert(DK == 128 && MODE == 0, "sparse_attn_x3p: dk = 128, MODE 0 only");
-    constexpr int NW = (NKB + BPW - 1) / BPW;   // waves (BPW = key blocks per wave: 2 -> one wave per SIMD, 1 -> two)
-#ifndef X3P_KP_AGPR
-#define X3P_KP_AGPR 3
+    constexpr int NW = NKB;                  // waves: one per key block
+#ifndef X3P_NACC
+#define X3P_NACC 1   // measured: 2 (no MFMA behind its predecessor's result) costs 16 registers + 16 adds and buys nothing at 2 waves / SIMD
 #endif
-    constexpr int KP_AGPR = X3P_KP_AGPR;     // how many of the wave's four 32-register key-fragment sets are parked in AGPRs
+    constexpr int NACC = X3P_NACC;           // score accumulators of GEMM1 that alternate (2: no MFMA follows its predecessor's result)
     constexpr int NKS = DK / 16;             // k-steps of GEMM1
     constexpr int NCB = DK / 32;             // 32-column blocks of the output
     constexpr int ROWB = 4 * DK;             // bytes of one row of one head in an hl image
@@ -157,14 +181,13 @@ __global__ __launch_bounds__(64 * ((NKB + BPW - 1) / BPW), BPW == 1 ? 2 : 1) voi
     constexpr int QCH = QP / 16;             // 16-byte positions per Q row (33)
     constexpr int QSLOT = x3p_qslot(DK);     // 17 KiB
     constexpr int NQDMA = QSLOT / 1024;      // LDS-DMA instructions of a Q tile (17)
-    constexpr int VSLOT = TR * ROWB;         // 16 KiB, rows of [hi plane 256 B | lo plane 256 B], chunk-rotated
+    constexpr int VSLOT = TR * ROWB;         // 16 KiB, rows of [hi plane 256 B | lo plane 256 B], 64-byte groups XOR-rotated
     constexpr int NVDMA = VSLOT / 1024;      // 16
-    constexpr int NDMA = NQDMA + NVDMA;
-    constexpr int DMA_U = (NDMA + NW - 1) / NW;         // per wave, at most
+    constexpr int UQ = x3p_dma_u(NQDMA, NW), UV = x3p_dma_u(NVDMA, NW);   // DMA instructions per wave and tile, at most
     constexpr int Q_OFF = 0, V_OFF = 3 * QSLOT, P_OFF = V_OFF + 3 * VSLOT;
     constexpr int PBUF = TR * 64 * 2;        // the P image of one key block: hi plane 2 KiB | lo plane 2 KiB
     constexpr int ST_OFF = P_OFF + NKB * PBUF;
-    constexpr int TB_OFF = ST_OFF + 2 * NW * TR * 8;        // per-lane DMA source offsets, [NW][DMA_U][64] ints
+    constexpr int TB_OFF = ST_OFF + 2 * NW * TR * 8;        // per-lane DMA source offsets, [NW][UQ + UV][64] ints
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -179,7 +202,7 @@ __global__ __launch_bounds__(64 * ((NKB + BPW - 1) / BPW), BPW == 1 ? 2 : 1) voi
     if (f_begin >= f_end) return;
     const int T = f_end - f_begin;            // items of this workgroup
     const int first_head = f_begin / P.tiles_per_head;
-    // cursors of the items i .. i + 3 of the pipeline (head, tile), advanced by one item per iteration: no division in the loop
+    // cursors of the items of the pipeline (head, tile), advanced by one item per iteration: no division in the loop
     auto cur_next = [&](Cur c) __attribute__((always_inline)) -> Cur {
         ++c.t;
         if (c.t == P.tiles_per_head) c.t = 0, ++c.a;
@@ -191,81 +214,109 @@ __global__ __launch_bounds__(64 * ((NKB + BPW - 1) / BPW), BPW == 1 ? 2 : 1) voi
     //   Q instruction e (0 .. 16): position p = 64 e + lane -> row p / 33, chunk p % 33 of the row's 512-byte line (chunk 32 = pad)
     //   V instruction e (0 .. 15): row 2 e + (lane >> 5), position s = lane & 31: plane s >> 4, 64-byte column group ((s >> 2) & 3) ^ (row & 3)
     //                              (keeps the four rows of a transpose-read in four different 64-byte bank segments)
-    // Every instruction reads whole 128-byte lines of two or three consecutive rows.  Wave w issues instructions w, w + NW, ...
+    // Every instruction reads whole 128-byte lines of two or three consecutive rows.  Wave w issues Q instructions w, w + NW, ..
+    // and V instructions w, w + NW, ..
     const int ldq_b = (int)(P.ldq * 2), ldv_b = (int)(P.ldv * 2);
-    auto dma_rc = [&](int u, int& row, int& chunk) __attribute__((always_inline)) {
-        const int e = w + NW * u;
-        if (e < NQDMA) {
-            const int p = 64 * e + lane;
-            row = p / QCH;
-            chunk = p - row * QCH;
-            if (chunk > 31) chunk = 31;
-            if (row > TR - 1) row = TR - 1;
-        } else {
-            const int ev = e - NQDMA, s = lane & 31;
-            row = 2 * ev + (lane >> 5);
-            const int g = ((s >> 2) & 3) ^ (row & 3);      // position group s >> 2 holds column group g of its plane
-            chunk = 8 * g + 4 * (s >> 4) + (s & 3);
-        }
+    auto q_rc = [&](int e, int& row, int& chunk) __attribute__((always_inline)) {
+        const int p = 64 * e + lane;
+        row = p / QCH;
+        chunk = p - row * QCH;
+        if (chunk > 31) chunk = 31;
+        if (row > TR - 1) row = TR - 1;
+    };
+    auto v_rc = [&](int e, int& row, int& chunk) __attribute__((always_inline)) {
+        const int s = lane & 31;
+        row = 2 * e + (lane >> 5);
+        const int g = ((s >> 2) & 3) ^ (row & 3);          // position group s >> 2 holds column group g of its plane
+        chunk = 8 * g + 4 * (s >> 4) + (s & 3);
     };
     // The per-lane source offsets of a FULL tile (row_in_tile * ld_bytes + 16 * chunk) are parked in LDS: registers are the scarce
-    // resource of this kernel, and the offsets are needed once per iteration, right behind the barrier.
-    int* const dma_tab = reinterpret_cast<int*>(smem + TB_OFF) + w * (DMA_U * 64) + lane;
+    // resource of this kernel, and an offset is needed once per iteration.
+    int* const dma_tab = reinterpret_cast<int*>(smem + TB_OFF) + w * ((UQ + UV) * 64) + lane;
 #pragma unroll
-    for (int u = 0; u < DMA_U; ++u) {
+    for (int u = 0; u < UQ; ++u) {
         int row, chunk;
-        dma_rc(u, row, chunk);
-        dma_tab[u * 64] = row * (w + NW * u < NQDMA ? ldq_b : ldv_b) + 16 * chunk;
+        q_rc(w + NW * u, row, chunk);
+        dma_tab[u * 64] = row * ldq_b + 16 * chunk;
     }
-    struct DmaOff {
-        int o[DMA_U];
-    };
-    auto load_dma_off = [&]() __attribute__((always_inline)) -> DmaOff {
-        DmaOff d;
 #pragma unroll
-        for (int u = 0; u < DMA_U; ++u) d.o[u] = dma_tab[u * 64];
-        return d;
-    };
+    for (int u = 0; u < UV; ++u) {
+        int row, chunk;
+        v_rc(w + NW * u, row, chunk);
+        dma_tab[(UQ + u) * 64] = row * ldv_b + 16 * chunk;
+    }
     // one instruction: 32-bit per-lane offset + 64-bit wave-uniform base (SGPR pair) -> 1 KiB at the wave-uniform LDS address dst.
     // Hand-written: behind the builtin hipcc puts s_waitcnt vmcnt(0) in front of the first LDS read it cannot prove disjoint from
-    // the DMA's destination (the transpose-reads of the OTHER ring slots, mid-iteration), which drains the prefetch every
-    // iteration.  The asm form is invisible to that pass; the kernel's own s_waitcnt vmcnt + s_barrier at the end of the iteration
-    // order the data (cdna_hip_programming.md 5.7: M0 is written in the statement that uses it, and restored).
+    // the DMA's destination (the transpose-reads of the OTHER ring slots), which drains the prefetch every iteration.  The asm form
+    // is invisible to that pass; the kernel's own counted s_waitcnt vmcnt + s_barrier at the end of an iteration order the data
+    // (cdna_hip_programming.md 5.7: M0 is written in the statement that uses it, and restored).
     auto dma_1k = [&](const unsigned char* base, int off, int dst) __attribute__((always_inline)) {
 #ifdef X3P_ABL_NODMA   // timing ablation: no operand traffic at all (results wrong)
         asm volatile("" ::"v"(off), "s"(base), "s"(dst));
 #else
         unsigned keep;
+        // (readfirstlane: the operands ARE wave-uniform, but the asm "s" constraint needs the compiler to know it in every instantiation)
+        const uint64_t b64 = reinterpret_cast<uint64_t>(base);
+        const uint64_t bu = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
-                     : "v"(off), "s"(base), "s"(dst)
+                     : "v"(off), "s"(bu), "s"(__builtin_amdgcn_readfirstlane(dst))
                      : "memory");
 #endif
     };
-    // item c's Q rows -> Q slot sq (if doq), item cv's V rows -> V slot sv (if dov)
-    auto issue_dma = [&](const DmaOff& dma_off, bool doq, Cur cq, int sq, bool dov, Cur cv, int sv) __attribute__((always_inline)) {
-        const unsigned char* bq = reinterpret_cast<const unsigned char*>(P.q) + (int64_t)(cq.t * TR) * ldq_b + (int64_t)cq.a * ROWB;
-        const unsigned char* bv = reinterpret_cast<const unsigned char*>(P.v) + (int64_t)(cv.t * TR) * ldv_b + (int64_t)cv.a * ROWB;
-        const bool partq = cq.t * TR + TR > n32, partv = cv.t * TR + TR > n32;   // last tile of the bag: rows past the end
-#pragma unroll
-        for (int u = 0; u < DMA_U; ++u) {
-            const int e = w + NW * u;
-            if (e < NDMA) {
-                const bool isq = e < NQDMA;
-                if (isq ? doq : dov) {
-                    int off = dma_off.o[u];
-                    if (isq ? partq : partv) {   // re-read the last row instead (the P of such rows is forced to 0)
-                        int row, chunk;
-                        dma_rc(u, row, chunk);
-                        const int rmax = n32 - 1 - (isq ? cq.t : cv.t) * TR;
-                        if (row > rmax) row = rmax;
-                        off = row * (isq ? ldq_b : ldv_b) + 16 * chunk;
-                    }
-                    dma_1k(isq ? bq : bv, off, isq ? Q_OFF + sq * QSLOT + e * 1024 : V_OFF + sv * VSLOT + (e - NQDMA) * 1024);
-                }
-            }
-        }
+    struct DmaCtx {                           // wave-uniform, per tile pair to fetch
+        const unsigned char *bq, *bv;
+        unsigned mask;                        // bit u: instruction u of the wave's list (Q: u < UQ, V: UQ + ..) is to be issued
+        int dstq, dstv;
     };
+    unsigned full_mask = 0;                   // the instructions this wave owns
+#pragma unroll
+    for (int u = 0; u < UQ; ++u) full_mask |= (w + NW * u < NQDMA) ? 1u << u : 0u;
+#pragma unroll
+    for (int u = 0; u < UV; ++u) full_mask |= (w + NW * u < NVDMA) ? 1u << (UQ + u) : 0u;
+    const unsigned tile_q_b = (unsigned)(TR * ldq_b), tile_v_b = (unsigned)(TR * ldv_b);
+    // instruction u of the wave's list, full tile (the common case: nothing but the table lookup and the instruction)
+    auto dma_unit = [&](auto u_t, const DmaCtx& dc, int off) __attribute__((always_inline)) {
+        constexpr int u = decltype(u_t)::value;
+        constexpr bool isq = u < UQ;
+        constexpr int uu = isq ? u : u - UQ;
+        if (dc.mask & (1u << u)) dma_1k(isq ? dc.bq : dc.bv, off, (isq ? dc.dstq : dc.dstv) + NW * uu * 1024);
+    };
+    // the same for the last tile of a bag: rows past the end re-read the last row (their P is forced to 0).  Rare: not interleaved.
+    auto dma_partial = [&](const DmaCtx& dc, unsigned mask, int rmaxq, int rmaxv) __attribute__((always_inline)) {
+        static_for<0, UQ + UV>([&](auto u_t) __attribute__((always_inline)) {
+            constexpr int u = decltype(u_t)::value;
+            constexpr bool isq = u < UQ;
+            constexpr int uu = isq ? u : u - UQ;
+            if (mask & (1u << u)) {
+                int row, chunk;
+                if constexpr (isq) q_rc(w + NW * uu, row, chunk); else v_rc(w + NW * uu, row, chunk);
+                const int rmax = isq ? rmaxq : rmaxv;
+                if (row > rmax) row = rmax;
+                dma_1k(isq ? dc.bq : dc.bv, row * (isq ? ldq_b : ldv_b) + 16 * chunk, (isq ? dc.dstq : dc.dstv) + NW * uu * 1024);
+            }
+        });
+    };
+    // Q rows of item cq -> Q slot sq (if doq), V rows of item cv -> V slot sv (if dov).  Partial tiles are issued here, at once.
+    auto dma_ctx = [&](bool doq, Cur cq, int sq, bool dov, Cur cv, int sv) __attribute__((always_inline)) -> DmaCtx {
+        DmaCtx dc;
+        dc.bq = reinterpret_cast<const unsigned char*>(P.q) + (uint64_t)((unsigned)cq.t * (uint64_t)tile_q_b) + (unsigned)(cq.a * ROWB);
+        dc.bv = reinterpret_cast<const unsigned char*>(P.v) + (uint64_t)((unsigned)cv.t * (uint64_t)tile_v_b) + (unsigned)(cv.a * ROWB);
+        dc.dstq = Q_OFF + sq * QSLOT + w * 1024, dc.dstv = V_OFF + sv * VSLOT + w * 1024;
+        dc.mask = full_mask & ((doq ? (1u << UQ) - 1u : 0u) | (dov ? ((1u << UV) - 1u) << UQ : 0u));
+        const int rmaxq = n32 - 1 - cq.t * TR, rmaxv = n32 - 1 - cv.t * TR;   // last existing row, tile-relative
+        unsigned part = 0;
+        if (rmaxq < TR - 1) part |= (1u << UQ) - 1u;
+        if (rmaxv < TR - 1) part |= ((1u << UV) - 1u) << UQ;
+        part &= dc.mask;
+        if (part) {
+            dma_partial(dc, part, rmaxq, rmaxv);
+            dc.mask &= ~part;
+        }
+        return dc;
+    };
+    // NOTE: instructions issued by dma_ctx itself (partial tiles) are counted by the caller through popcount(issued) below
 
     // ---------------------------------------------------------------- addressing (one register per stream where possible)
     // GEMM1 B fragment (kb, lo) of lane (row j, half hf): chunk 8 (kb >> 1) + 4 lo + 2 (kb & 1) + hf of row j -- an immediate offset
@@ -274,7 +325,7 @@ __global__ __launch_bounds__(64 * ((NKB + BPW - 1) / BPW), BPW == 1 ? 2 : 1) voi
     const int rg = lane >> 4, ri = lane & 15;
     const int rr0 = 8 * (rg >> 1) + (ri >> 2), rr1 = rr0 + 4;
     const int rch = 4 * (rg & 1) + (ri & 3);
-    const int p_wave = P_OFF + w * BPW * PBUF;                           // this wave's P images (key blocks BPW w ..)
+    const int p_wave = P_OFF + w * PBUF;                                 // this wave's P image
     const int poff0 = p_wave + rr0 * 64 + 8 * (rch ^ ((rr0 >> 1) & 7));
     const int poff1 = p_wave + rr1 * 64 + 8 * (rch ^ ((rr1 >> 1) & 7));
     // V fragment of column block cb, row rr0 (rr1: + 4 rows): 64-byte column group cb ^ (rr0 & 3) -> voff0 ^ (64 cb)
@@ -292,118 +343,125 @@ __global__ __launch_bounds__(64 * ((NKB + BPW - 1) / BPW), BPW == 1 ? 2 : 1) voi
         const unsigned char* vp = smem + va + sk * 16 * ROWB + 256 * lo;
         return tr_frag(vp, vp + 4 * ROWB);
     };
-    auto p_frag = [&](int blk, int sk, int lo) __attribute__((always_inline)) -> bf16x8 {
-        const int o = blk * PBUF + lo * (PBUF / 2) + sk * 16 * 64;
+    auto p_frag = [&](int sk, int lo) __attribute__((always_inline)) -> bf16x8 {
+        const int o = lo * (PBUF / 2) + sk * 16 * 64;
         return tr_frag(smem + poff0 + o, smem + poff1 + o);
     };
 
-    // ================================================================ the wave program, for NB key blocks (BPW, fewer in the last wave)
+    // ================================================================ the wave program
     // LASTW: this wave owns the last key block (its padded keys are masked)
     auto run = [&](auto lastw_t) __attribute__((always_inline)) {
         constexpr bool LASTW = decltype(lastw_t)::value;
-        constexpr int NB = LASTW ? NKB - BPW * (NW - 1) : BPW;
-        constexpr int MASKB = LASTW ? NB - 1 : -1;                       // block (0 / 1) whose padded keys are masked, or none
         const int klast = P.k - 32 * (NKB - 1);                          // valid keys of the last key block
 
-        // ---- Kp fragments of the wave's key blocks: MFMA A operands, hi and lo, for the whole head -- 16-byte loads out of the
+        // ---- Kp fragments of the wave's key block: MFMA A operands, hi and lo, for the whole head -- 16-byte loads out of the
         // fragment-ordered image x3p_prep_kp_kernel made of Kp (scaled and split there: nothing but the loads happens here, so a
         // head change inside a workgroup's range costs one L2 round trip)
-        bf16x8 kph[NB][NKS], kpl[NB][NKS];
+        bf16x8 kph[NKS], kpl[NKS];
         auto load_kp = [&](int a_) __attribute__((always_inline)) {
+            const u32x4* src = P.kp_frag + ((int64_t)(a_ * NKB + w) * NKS * 2) * 64 + lane;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const u32x4* src = P.kp_frag + ((int64_t)(a_ * NKB + BPW * w + b) * NKS * 2) * 64 + lane;
-#pragma unroll
-                for (int kb = 0; kb < NKS; ++kb) {
-                    kph[b][kb] = __builtin_bit_cast(bf16x8, src[(2 * kb) * 64]);
-                    kpl[b][kb] = __builtin_bit_cast(bf16x8, src[(2 * kb + 1) * 64]);
-                }
-            }
-            if constexpr (BPW == 2) {
-                // one wave per SIMD = 256 architectural + 256 accumulation registers, and only MFMA operands can live in the
-                // latter: park key fragments there (they are read by MFMAs only), the vector work keeps the VGPRs
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-#pragma unroll
-                    for (int kb = 0; kb < NKS; ++kb) {
-                        if (KP_AGPR > 2 * b) asm volatile("" : "+a"(kph[b][kb]));
-                        if (KP_AGPR > 2 * b + 1) asm volatile("" : "+a"(kpl[b][kb]));
-                    }
+            for (int kb = 0; kb < NKS; ++kb) {
+                kph[kb] = __builtin_bit_cast(bf16x8, src[(2 * kb) * 64]);
+                kpl[kb] = __builtin_bit_cast(bf16x8, src[(2 * kb + 1) * 64]);
             }
         };
         // ---- state
-        f32x16 Tacc[NB];                      // score accumulators of GEMM1 (tile i + 1)
-        float E[NB][16];                      // exp2(s - max) of tile i
+        f32x16 Ta, Tb;                        // score accumulators of GEMM1 (tile i + 1), even / odd MFMAs
+        float E[16];                          // exp2(s - max) of tile i
         float mw = 0.f;                       // the wave's row maximum that belongs to E
-        f32x16 acc_o[NB][NCB];
+        f32x16 acc_o[NCB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) E[b][r] = 0.f, Tacc[b][r] = 0.f;
-        }
+        for (int r = 0; r < 16; ++r) E[r] = 0.f, Ta[r] = 0.f, Tb[r] = 0.f;
         auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+            for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc_o[b][cb][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc_o[cb][r] = 0.f;
         };
         zero_acc();
         auto flush = [&](int head) __attribute__((always_inline)) {
             const int seg = head - first_head;
             float* dst = P.partial + ((int64_t)bid * P.seg_count + seg) * (int64_t)(NKB * NCB) * 1024;
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int t_idx = w * NCB + cb;
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) {
-                    const int t_idx = (BPW * w + b) * NCB + cb;
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4)
-                        if (32 * (BPW * w + b) + 8 * q4 < P.k) {
-                            const f32x4 v4 = {acc_o[b][cb][q4 * 4], acc_o[b][cb][q4 * 4 + 1], acc_o[b][cb][q4 * 4 + 2], acc_o[b][cb][q4 * 4 + 3]};
-                            *reinterpret_cast<f32x4*>(dst + ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4) = v4;
-                        }
-                }
+                for (int q4 = 0; q4 < 4; ++q4)
+                    if (32 * w + 8 * q4 < P.k) {
+                        const f32x4 v4 = {acc_o[cb][q4 * 4], acc_o[cb][q4 * 4 + 1], acc_o[cb][q4 * 4 + 2], acc_o[cb][q4 * 4 + 3]};
+                        *reinterpret_cast<f32x4*>(dst + ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4) = v4;
+                    }
+            }
         };
 
-        // ---- the vector work of one iteration, cut into UNITS (executed in this order)
-        //   first half, tile i (E -> P images of this wave's key blocks):
-        //     0               fetch the (max, sum) pairs of all waves (published before the last barrier)
-        //     1               max over the waves;  2 .. 1 + NW: one wave's exp2 / fma each;  2 + NW: the row's factor
-        //     then per block, per 4-key chunk: {scale 4 values, pack hi, store | residuals | pack lo, store}
-        //   second half, tile i + 1 (score tuples -> E):
-        //     2 per block     max over 8 scores each (MASKB: padded keys -> -inf first);  then 1: across the lane halves
-        //     16 per block    e = exp2(s - max), running sums
+        // ---- the vector (and scalar) work of one iteration, cut into UNITS (executed in this order).  A unit is a handful of
+        // instructions; the three-instruction chains (subtract -> exp2 -> accumulate) are software-pipelined ACROSS units.
+        //   first half, tile i (E -> P image of this wave's key block):
+        //     1               fetch the (max, sum) pairs of all waves (published before the last barrier)
+        //     1               max over the waves
+        //     NW + 2          wave b: d_b = max_b - max | e_(b-1) = exp2(d_(b-1)) | l += sum_(b-2) e_(b-2)
+        //     1               the row's factor exp2(max_wave - max) / l (0 for rows that do not exist)
+        //     12              per 4-key chunk: {scale 4 values, pack hi, store | residuals | pack lo, store}
+        //   second half, tile i + 1 (score tuples -> E) and the DMA of the tiles to come:
+        //     2               s = Ta + Tb, max over 8 scores each (LASTW: padded keys -> -inf first);  then 1: across the lane halves
+        //     16 + 2          score r: x_r = s_r - max | e_(r-1) = exp2(x_(r-1)) | sum += e_(r-2)
         //     1               sum across the halves, publish (max, sum) of the wave's 32 rows
-        constexpr int U_NORM = NW + 3, N_FIRST = U_NORM + 12 * NB;
-        constexpr int U_MAX = N_FIRST, U_XH = U_MAX + 2 * NB, U_EXP = U_XH + 1, U_PUB = U_EXP + 16 * NB, NUNITS = U_PUB + 1;
+        //     UQ + UV         one LDS-DMA instruction each: rows of Q(i + 3) / V(i + 2)
+        constexpr int U_CMAX = 1, U_CW = 2, U_FS = U_CW + NW + 2, U_NORM = U_FS + 1, N_FIRST = U_NORM + 12;
+        // second-half sequence: offsets | max, max, halves | 18 exp stages with the NDU DMA instructions spread between them | publish
+        constexpr int NDU = UQ + UV, N_SECOND = 4 + 18 + NDU + 1, NUNITS = N_FIRST + N_SECOND;
+        struct SecondMap {
+            int kind[N_SECOND], arg[N_SECOND];   // kind 0: offset fetch, 1: max, 2: halves, 3: exp stage, 4: DMA, 5: publish
+            constexpr SecondMap() : kind{}, arg{} {
+                int v = 0, d = 0;
+                kind[v] = 0, arg[v++] = 0;
+                kind[v] = 1, arg[v++] = 0;
+                kind[v] = 1, arg[v++] = 1;
+                kind[v] = 2, arg[v++] = 0;
+                for (int q = 0; q < 18; ++q) {
+                    kind[v] = 3, arg[v++] = q;
+                    while (d < NDU && (d + 1) * 18 <= (q + 1) * NDU) kind[v] = 4, arg[v++] = d++;
+                }
+                kind[v] = 5, arg[v++] = 0;
+            }
+        };
+        constexpr SecondMap smap{};
         struct VS {
-            float mx[2 * NB], l0, l1, m, l, fscale;
+            float mx0, mx1, l0, l1, m, l, fscale, d0, d1, e0, e1, x0, x1;
+            int doff[UQ + UV];                // per-lane source offsets of this wave's DMA instructions (fetched from LDS early)
             f32x2 sv[NW];
             f32x4 p4;
             unsigned h01, h23;
             float r0, r1, r2, r3;
         };
-        auto masked = [&](float x, int b, int r) __attribute__((always_inline)) -> float {
-            if (b == MASKB) return ((r & 3) + 8 * (r >> 2) + 4 * hf) < klast ? x : -INFINITY;
+        auto masked = [&](float x, int r) __attribute__((always_inline)) -> float {
+            if constexpr (LASTW) return ((r & 3) + 8 * (r >> 2) + 4 * hf) < klast ? x : -INFINITY;
             return x;
         };
         // cno / rows_ok: the (head, tile) of tile i and the number of its rows that exist (0 in the fill iteration: P := 0)
-        auto unit = [&](auto u_t, VS& s, int par_n, const Cur cno, int rows_ok) __attribute__((always_inline)) {
+        auto unit = [&](auto u_t, VS& s, int par_n, const Cur cno, int rows_ok, const DmaCtx& dc) __attribute__((always_inline)) {
             constexpr int u = decltype(u_t)::value;
+#ifdef X3P_ABL_NO_U1
+            if constexpr (u < N_FIRST) return;
+#endif
+#ifdef X3P_ABL_NO_U2
+            if constexpr (u >= N_FIRST) { if constexpr (smap.kind[u - N_FIRST] != 4 && smap.kind[u - N_FIRST] != 0) return; }
+#endif
             if constexpr (u == 0) {
 #pragma unroll
                 for (int b = 0; b < NW; ++b) s.sv[b] = *reinterpret_cast<const f32x2*>(smem + st_lane + (par_n * NW + b) * (TR * 8));
-            } else if constexpr (u == 1) {
+            } else if constexpr (u == U_CMAX) {
                 float m = s.sv[0][0];
 #pragma unroll
                 for (int b = 1; b < NW; ++b) m = fmaxf(m, s.sv[b][0]);
                 s.m = m, s.l = 0.f;
-            } else if constexpr (u < 2 + NW) {
-                constexpr int b = u - 2;
-                s.l = fmaf(s.sv[b][1], __builtin_amdgcn_exp2f(s.sv[b][0] - s.m), s.l);
-            } else if constexpr (u == 2 + NW) {
+            } else if constexpr (u < U_FS) {
+                constexpr int b = u - U_CW;       // stage b: sub of wave b, exp of wave b - 1, fma of wave b - 2
+                if constexpr (b >= 2) s.l = fmaf(s.sv[b - 2][1], (b & 1) ? s.e1 : s.e0, s.l);
+                if constexpr (b >= 1 && b - 1 < NW) ((b & 1) ? s.e0 : s.e1) = __builtin_amdgcn_exp2f((b & 1) ? s.d0 : s.d1);
+                if constexpr (b < NW) ((b & 1) ? s.d1 : s.d0) = s.sv[b][0] - s.m;
+            } else if constexpr (u == U_FS) {
                 const bool rvalid = j < rows_ok;
                 if constexpr (AUX)
                     if (P.lse && rvalid && hf == 0 && w == 0)
@@ -412,13 +470,16 @@ __global__ __launch_bounds__(64 * ((NKB + BPW - 1) / BPW), BPW == 1 ? 2 : 1) voi
                 asm volatile("" : "+v"(fs));              // keep the select below a select (no branch around the exp / rcp)
                 s.fscale = rvalid ? fs : 0.f;
             } else if constexpr (u < N_FIRST) {
-                constexpr int b = (u - U_NORM) / 12, c4 = ((u - U_NORM) % 12) / 3, part = (u - U_NORM) % 3;
-                unsigned char* pb = smem + (waddr0 ^ (16 * c4)) + b * PBUF;
+                constexpr int c4 = (u - U_NORM) / 3, part = (u - U_NORM) % 3;
+                unsigned char* pb = smem + (waddr0 ^ (16 * c4));
                 if constexpr (part == 0) {
-                    s.p4 = f32x4{E[b][4 * c4] * s.fscale, E[b][4 * c4 + 1] * s.fscale, E[b][4 * c4 + 2] * s.fscale, E[b][4 * c4 + 3] * s.fscale};
+                    s.p4 = f32x4{E[4 * c4] * s.fscale, E[4 * c4 + 1] * s.fscale, E[4 * c4 + 2] * s.fscale, E[4 * c4 + 3] * s.fscale};
+                    // P is ROUNDED to fp32 here in every variant: without this the compiler contracts the product into the subtraction
+                    // of the split below (fma) in the variants that do not store A, and their O differs in the last bits
+                    asm volatile("" : "+v"(s.p4));
                     if constexpr (AUX) {
                         if (P.attn && j < rows_ok) {
-                            const int key0 = 32 * (BPW * w + b) + 8 * c4 + 4 * hf;
+                            const int key0 = 32 * w + 8 * c4 + 4 * hf;
                             float* arow = P.attn + ((int64_t)cno.a * P.n + cno.t * TR + j) * P.attn_ld + key0;
                             if (attn_vec && key0 + 4 <= P.k) {
                                 *reinterpret_cast<f32x4*>(arow) = s.p4;
@@ -437,141 +498,155 @@ __global__ __launch_bounds__(64 * ((NKB + BPW - 1) / BPW), BPW == 1 ? 2 : 1) voi
                 } else {
                     *reinterpret_cast<u32x2*>(pb + PBUF / 2) = u32x2{cvt_pk(s.r0, s.r1), cvt_pk(s.r2, s.r3)};
                 }
-            } else if constexpr (u < U_XH) {
-                constexpr int b = (u - U_MAX) / 2, r0 = 8 * ((u - U_MAX) % 2);
-                float x[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) x[r] = masked(Tacc[b][r0 + r], b, r0 + r);
-                float mx = fmaxf(fmaxf(x[0], x[1]), x[2]);
-                mx = fmaxf(fmaxf(mx, x[3]), x[4]);
-                mx = fmaxf(fmaxf(mx, x[5]), x[6]);
-                s.mx[u - U_MAX] = fmaxf(mx, x[7]);
-            } else if constexpr (u == U_XH) {
-                // the exp pass reads the score tuples again instead of keeping copies of the max pass alive
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    if constexpr (BPW == 2) asm volatile("" : "+a"(Tacc[b])); else asm volatile("" : "+v"(Tacc[b]));
-                }
-                float mx = s.mx[0];
-#pragma unroll
-                for (int q = 1; q < 2 * NB; ++q) mx = fmaxf(mx, s.mx[q]);
-                mw = xhalf_max(mx);
-                s.l0 = 0.f, s.l1 = 0.f;
-            } else if constexpr (u < U_PUB) {
-                constexpr int b = (u - U_EXP) / 16, r = (u - U_EXP) % 16;
-                E[b][r] = __builtin_amdgcn_exp2f(masked(Tacc[b][r], b, r) - mw);
-                if constexpr (r & 1) s.l1 += E[b][r]; else s.l0 += E[b][r];
             } else {
-                const float lsum = xhalf_sum(s.l0 + s.l1);
-                *reinterpret_cast<f32x2*>(smem + st_lane + ((par_n ^ 1) * NW + w) * (TR * 8)) = f32x2{mw, lsum};   // both halves: same pair
+                constexpr int kind = smap.kind[u - N_FIRST], arg = smap.arg[u - N_FIRST];
+                if constexpr (kind == 0) {
+#pragma unroll
+                    for (int d = 0; d < NDU; ++d) s.doff[d] = dma_tab[d * 64];
+                } else if constexpr (kind == 1) {
+                    constexpr int r0 = 8 * arg;
+#pragma unroll
+                    for (int r = r0; r < r0 + 8; ++r) Ta[r] = masked(NACC == 2 ? Ta[r] + Tb[r] : Ta[r], r);
+                    float mx = fmaxf(fmaxf(Ta[r0], Ta[r0 + 1]), Ta[r0 + 2]);
+                    mx = fmaxf(fmaxf(mx, Ta[r0 + 3]), Ta[r0 + 4]);
+                    mx = fmaxf(fmaxf(mx, Ta[r0 + 5]), Ta[r0 + 6]);
+                    mx = fmaxf(mx, Ta[r0 + 7]);
+                    if constexpr (arg == 0) s.mx0 = mx; else s.mx1 = mx;
+                } else if constexpr (kind == 2) {
+                    mw = xhalf_max(fmaxf(s.mx0, s.mx1));
+                    s.l0 = 0.f, s.l1 = 0.f;
+                } else if constexpr (kind == 3) {
+                    constexpr int q = arg;        // stage q: sub of score q, exp of score q - 1, add of score q - 2
+                    if constexpr (q >= 2) {
+                        if constexpr (q & 1) s.l1 += E[q - 2]; else s.l0 += E[q - 2];
+                    }
+                    if constexpr (q >= 1 && q - 1 < 16) E[q - 1] = __builtin_amdgcn_exp2f((q & 1) ? s.x0 : s.x1);
+                    if constexpr (q < 16) ((q & 1) ? s.x1 : s.x0) = Ta[q] - mw;
+                } else if constexpr (kind == 4) {
+                    dma_unit(std::integral_constant<int, arg>{}, dc, s.doff[arg]);
+                } else {
+                    const float lsum = xhalf_sum(s.l0 + s.l1);
+                    *reinterpret_cast<f32x2*>(smem + st_lane + ((par_n ^ 1) * NW + w) * (TR * 8)) = f32x2{mw, lsum};   // both halves: same pair
+                }
             }
         };
-        // MFMA slots of an iteration: NB 3 NKS of GEMM1, then NB 3 NKS of GEMM2.  GEMM1 issues the 3 NB MFMAs of a k-step back to
-        // back (the accumulation chain of a key block is ONE dependent chain: an MFMA that follows its predecessor directly gets
-        // the accumulator forwarded, one that follows a gap waits out the whole pipeline) and then the vector units of those slots;
-        // the other wave of the SIMD fills the matrix pipe meanwhile.  GEMM2 rotates over 4 NB accumulators: one MFMA, one gap.
-        // The first-half units ride behind slots 0 .. H - 3 NB - 1, so that the P images are complete before the first
-        // transpose-read is requested; the second-half units behind slots H + 4 .. 2 H - 1 (the last GEMM1 results are in flight).
-        constexpr int H = NB * 3 * NKS;
-        constexpr int F_LO = 0, F_HI = H - 3 * NB, S_LO = H + 4, S_HI = 2 * H;
+        // MFMA slots of an iteration: 3 NKS of GEMM1, then 3 NKS of GEMM2; one MFMA, then the units of its slot.  The first-half
+        // units ride behind slots 0 .. H - 4, so that the P image is complete before the first transpose-read is requested; the
+        // second-half units behind slots H + 2 .. 2 H - 1 (the last GEMM1 results are in flight).
+        constexpr int H = 3 * NKS;
+        constexpr int F_LO = 0, F_HI = H - 3, S_LO = H + 2, S_HI = 2 * H;
 #define X3P_UB1(k) ((k) <= F_LO ? 0 : (k) >= F_HI ? N_FIRST : (((k) - F_LO) * N_FIRST + (F_HI - F_LO) / 2) / (F_HI - F_LO))
 #define X3P_UB2(k) ((k) <= S_LO ? N_FIRST : (k) >= S_HI ? NUNITS : N_FIRST + (((k) - S_LO) * (NUNITS - N_FIRST) + (S_HI - S_LO) / 2) / (S_HI - S_LO))
 #define X3P_UB(k) ((k) < H ? X3P_UB1(k) : X3P_UB2(k))
 
-        // ---- one pipeline iteration: GEMM1(i + 1) | normalise(i), then GEMM2(i) | statistics(i + 1).
-        // Tile x lives in ring slot x % 3; statistics of tile x in buffer x & 1.  DMA issued here: Q(i + 3), V(i + 2).
+        // ---- one pipeline iteration: GEMM1(i + 1) | normalise(i), then GEMM2(i) | statistics(i + 1) | DMA of Q(i + 3), V(i + 2).
+        // Tile x lives in ring slot x % 3; statistics of tile x in buffer x & 1.
         // The SAME body runs the fill (i = -1: tile -1 does not exist -> rows_ok = 0, P = 0; its accumulators are zeroed again
         // before tile 0) and the drain (i = T - 1: GEMM1 / statistics of a tile T that does not exist run on stale operands and
         // are never consumed): one code path means one register allocation, and no spill code anywhere near the loop.
-        auto iteration = [&](int i, int slot_q, int slot_v, const DmaOff& doff, const Cur cno, const Cur c2, const Cur c3,
-                             int rows_ok) __attribute__((always_inline)) {
+        auto iteration = [&](int i, int slot_q, int slot_v, const Cur cno, const DmaCtx& dc, int rows_ok) __attribute__((always_inline)) {
             const int par_n = i & 1;
             const int qa = q_lane + slot_q * QSLOT;         // Q(i + 1): slot (i + 1) % 3
             int va[NCB];                                    // V(i): slot i % 3
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) va[cb] = (voff0 + slot_v * VSLOT) ^ (64 * cb);
-
-            // nothing of this wave is in flight here (the wait that closed the last iteration); said again INSIDE the loop body for
-            // hipcc's wait-count pass, which otherwise spreads waits for loads of the loop pre-header over the body -- where, the
-            // LDS-DMAs being invisible to it, they would drain the prefetch every iteration
-            X3P_WAIT_VM0();
             X3P_STAMP(i + 1, 0);
-            issue_dma(doff, i + 3 < T, c3, slot_v, i + 2 < T, c2, slot_q == 2 ? 0 : slot_q + 1);   // (i + 3) % 3 = i % 3;  (i + 2) % 3
-            X3P_STAMP(i + 1, 1);
             VS vs;
-            bf16x8 ql[NKS], qh[NKS], vl[2 * NCB], vh[2 * NCB], ph[NB][2], pl[NB][2];
+            bf16x8 ql[NKS], qh[NKS], vl[2 * NCB], vh[2 * NCB], ph[2], pl[2];
             ql[0] = q_frag(qa, 0, 1);
             qh[0] = q_frag(qa, 0, 0);
-            // ---------------- first half: GEMM1.  k-step e: products Kh Ql, Kl Qh, Kh Qh for every key block, back to back
+            // ---------------- first half: GEMM1.  k-step e: products Kh Ql, Kl Qh, Kh Qh, the two accumulators alternating
             static_for<0, NKS>([&](auto e_t) __attribute__((always_inline)) {
                 constexpr int e = decltype(e_t)::value;
-                X3P_FENCE();
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    if constexpr (e == 0)
-                        Tacc[b] = mfma(kph[b][e], ql[e], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
-                    else
-                        Tacc[b] = mfma(kph[b][e], ql[e], Tacc[b]);
-                }
-#pragma unroll
-                for (int b = 0; b < NB; ++b) Tacc[b] = mfma(kpl[b][e], qh[e], Tacc[b]);
-#pragma unroll
-                for (int b = 0; b < NB; ++b) Tacc[b] = mfma(kph[b][e], qh[e], Tacc[b]);
-                if constexpr (e + 1 < NKS) {                // the next k-step's fragments
+                X3P_STAMP2(i + 1, e);
+                if constexpr (e + 1 < NKS) {                // the next k-step's fragments, a whole step ahead of their first use
+                    X3P_FENCE();
                     ql[e + 1] = q_frag(qa, e + 1, 1);
                     qh[e + 1] = q_frag(qa, e + 1, 0);
-                } else {                                    // all P chunks are written: first step of GEMM2
-#pragma unroll
-                    for (int bb = 0; bb < NB; ++bb) ph[bb][0] = p_frag(bb, 0, 0);
-                    vl[0] = v_frag(va[0], 0, 1);
-#pragma unroll
-                    for (int bb = 0; bb < NB; ++bb) pl[bb][0] = p_frag(bb, 0, 1);
-                    vh[0] = v_frag(va[0], 0, 0);
                 }
-                X3P_FENCE();
-                static_for<X3P_UB(3 * NB * e), X3P_UB(3 * NB * (e + 1))>([&](auto u_t) __attribute__((always_inline)) {
-                    unit(u_t, vs, par_n, cno, rows_ok);
+                static_for<0, 3>([&](auto m_t) __attribute__((always_inline)) {
+                    constexpr int mi = decltype(m_t)::value, k = 3 * e + mi;
+                    X3P_FENCE();
+                    f32x16& acc = (NACC == 2 && (k & 1)) ? Tb : Ta;
+                    const f32x16 c0 = k < NACC ? f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f} : acc;
+                    if constexpr (mi == 0) acc = X3P_MFMA1(kph[e], ql[e], c0);
+                    if constexpr (mi == 1) acc = X3P_MFMA1(kpl[e], qh[e], c0);
+                    if constexpr (mi == 2) acc = X3P_MFMA1(kph[e], qh[e], c0);
+                    if constexpr (e + 1 == NKS) {           // all P chunks are written: the first step of GEMM2
+                        if constexpr (mi == 0) ph[0] = p_frag(0, 0), vl[0] = v_frag(va[0], 0, 1);
+                        if constexpr (mi == 1) vl[1] = v_frag(va[1], 0, 1), pl[0] = p_frag(0, 1);
+                        if constexpr (mi == 2) vh[0] = v_frag(va[0], 0, 0), vh[1] = v_frag(va[1], 0, 0);
+                    }
+                    static_for<X3P_UB(k), X3P_UB(k + 1)>([&](auto u_t) __attribute__((always_inline)) {
+                        unit(u_t, vs, par_n, cno, rows_ok, dc);
+                    });
                 });
             });
             X3P_STAMP(i + 1, 2);
-            // ---------------- second half: GEMM2.  step e = (16-row k-step e / 4, column block e % 4): Ph Vl, Pl Vh, Ph Vh
-            static_for<0, 2 * NCB>([&](auto e_t) __attribute__((always_inline)) {
-                constexpr int e = decltype(e_t)::value, sk = e / NCB, cb = e % NCB;
-                constexpr int e1 = e + 1, sk1 = e1 / NCB, cb1 = e1 % NCB;
-                static_for<0, 3 * NB>([&](auto m_t) __attribute__((always_inline)) {
-                    constexpr int mi = decltype(m_t)::value, k = H + 3 * NB * e + mi, prod = mi / NB, b = mi % NB;
+            // ---------------- second half: GEMM2.  step e = (16-row k-step e / 2, column-block pair e % 2): the products Ph Vl, Pl Vh,
+            // Ph Vh of the pair's two column blocks alternate, so that an MFMA never follows its predecessor on the same accumulator
+            // behind a gap (it would wait out the whole matrix pipeline)
+            static_for<0, NCB>([&](auto e_t) __attribute__((always_inline)) {
+                constexpr int e = decltype(e_t)::value, sk = e / 2, c0 = 2 * (e % 2);
+                constexpr int e1 = e + 1, sk1 = e1 / 2, n0 = 2 * (e1 % 2);
+                X3P_STAMP2(i + 1, 8 + e);
+                static_for<0, 6>([&](auto m_t) __attribute__((always_inline)) {
+                    constexpr int mi = decltype(m_t)::value, k = H + 6 * e + mi, prod = mi / 2, cb = c0 + (mi & 1);
                     X3P_FENCE();
-                    if constexpr (prod == 0) acc_o[b][cb] = mfma(ph[b][sk], vl[e], acc_o[b][cb]);
-                    if constexpr (prod == 1) acc_o[b][cb] = mfma(pl[b][sk], vh[e], acc_o[b][cb]);
-                    if constexpr (prod == 2) acc_o[b][cb] = mfma(ph[b][sk], vh[e], acc_o[b][cb]);
-                    if constexpr (e1 < 2 * NCB) {           // the next step's fragments
-                        if constexpr (mi == 0) vl[e1] = v_frag(va[cb1], sk1, 1);
-                        if constexpr (mi == NB) vh[e1] = v_frag(va[cb1], sk1, 0);
-                        if constexpr (cb1 == 0 && mi == 1) {
-#pragma unroll
-                            for (int bb = 0; bb < NB; ++bb) ph[bb][sk1] = p_frag(bb, sk1, 0);
-                        }
-                        if constexpr (cb1 == 0 && mi == NB + 1) {
-#pragma unroll
-                            for (int bb = 0; bb < NB; ++bb) pl[bb][sk1] = p_frag(bb, sk1, 1);
-                        }
+                    if constexpr (prod == 0) acc_o[cb] = X3P_MFMA2(ph[sk], vl[2 * e + (mi & 1)], acc_o[cb]);
+                    if constexpr (prod == 1) acc_o[cb] = X3P_MFMA2(pl[sk], vh[2 * e + (mi & 1)], acc_o[cb]);
+                    if constexpr (prod == 2) acc_o[cb] = X3P_MFMA2(ph[sk], vh[2 * e + (mi & 1)], acc_o[cb]);
+                    if constexpr (e1 < NCB) {               // the next pair's fragments, three slots ahead of their first use
+                        if constexpr (mi == 0) vl[2 * e1] = v_frag(va[n0], sk1, 1);
+                        if constexpr (mi == 1) vl[2 * e1 + 1] = v_frag(va[n0 + 1], sk1, 1);
+                        if constexpr (mi == 2) vh[2 * e1] = v_frag(va[n0], sk1, 0);
+                        if constexpr (mi == 3) vh[2 * e1 + 1] = v_frag(va[n0 + 1], sk1, 0);
+                        if constexpr (n0 == 0 && mi == 0) ph[sk1] = p_frag(sk1, 0);
+                        if constexpr (n0 == 0 && mi == 1) pl[sk1] = p_frag(sk1, 1);
                     }
-                    static_for<X3P_UB(k), X3P_UB(k + 1)>([&](auto u_t) __attribute__((always_inline)) { unit(u_t, vs, par_n, cno, rows_ok); });
+                    static_for<X3P_UB(k), X3P_UB(k + 1)>([&](auto u_t) __attribute__((always_inline)) {
+                        unit(u_t, vs, par_n, cno, rows_ok, dc);
+                    });
                 });
             });
             X3P_FENCE();
             X3P_STAMP(i + 1, 3);
         };
+        // wait until at most n of this wave's LDS-DMA instructions are in flight: they complete in order, so everything issued before
+        // the last n has landed.  (AUX builds also have stores in flight, which are not ordered with the loads: drain everything.)
+        auto wait_dma = [&](int n) __attribute__((always_inline)) {
+            if constexpr (AUX) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                static_assert(UQ + UV <= 40, "wait_dma: more DMA instructions per wave than the switch covers");
+#define X3P_VMC(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+                switch (n) {
+                    X3P_VMC(0) X3P_VMC(1) X3P_VMC(2) X3P_VMC(3) X3P_VMC(4) X3P_VMC(5) X3P_VMC(6) X3P_VMC(7) X3P_VMC(8) X3P_VMC(9)
+                    X3P_VMC(10) X3P_VMC(11) X3P_VMC(12) X3P_VMC(13) X3P_VMC(14) X3P_VMC(15) X3P_VMC(16) X3P_VMC(17) X3P_VMC(18) X3P_VMC(19)
+                    X3P_VMC(20) X3P_VMC(21) X3P_VMC(22) X3P_VMC(23) X3P_VMC(24) X3P_VMC(25) X3P_VMC(26) X3P_VMC(27) X3P_VMC(28) X3P_VMC(29)
+                    X3P_VMC(30) X3P_VMC(31) X3P_VMC(32) X3P_VMC(33) X3P_VMC(34) X3P_VMC(35) X3P_VMC(36) X3P_VMC(37) X3P_VMC(38) X3P_VMC(39)
+                    default: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+                }
+#undef X3P_VMC
+            }
+        };
 
-        // ---- the pipeline.  Prologue DMA: Q(0), Q(1), V(0), V(1); iteration i issues Q(i + 3), V(i + 2).
+        // ---- the pipeline.  The second half of iteration i issues the DMA of Q(i + 3) -> Q slot i % 3 (GEMM1 read Q(i) out of it
+        // in iteration i - 1) and of V(i + 2) -> V slot (i + 2) % 3 (GEMM2 read V(i - 1) out of it in iteration i - 1): both slots
+        // are free since the last barrier.  These instructions stay in flight across the barrier that closes iteration i; the wait
+        // at the end of iteration i + 1 retires them (vmcnt counts down in issue order: "at most this iteration's own" means every
+        // older one has landed), and the barrier behind it makes them visible to the other waves, two iterations before the
+        // first read (GEMM1(i + 3) / GEMM2(i + 2) in iteration i + 2).  Before the loop: Q(0), V(0), Q(1).
         Cur c0, c1, c2, c3;                   // items i, i + 1, i + 2, i + 3
         c1.a = first_head, c1.t = f_begin - first_head * P.tiles_per_head;   // item 0
         c0 = c1;                              // item -1 does not exist (any valid cursor)
         c2 = cur_next(c1);
         c3 = cur_next(c2);
-        DmaOff doff = load_dma_off();
-        issue_dma(doff, true, c1, 0, true, c1, 0);
-        issue_dma(doff, 1 < T, c2, 1, 1 < T, c2, 1);
+        {
+            const DmaCtx d0 = dma_ctx(true, c1, 0, true, c1, 0), d1 = dma_ctx(1 < T, c2, 1, false, c2, 1);
+            static_for<0, UQ + UV>([&](auto u_t) __attribute__((always_inline)) { dma_unit(u_t, d0, dma_tab[decltype(u_t)::value * 64]); });
+            static_for<0, UQ>([&](auto u_t) __attribute__((always_inline)) { dma_unit(u_t, d1, dma_tab[decltype(u_t)::value * 64]); });
+        }
         int head_g1 = c1.a, head_g2 = -1;     // heads whose Kp fragments / accumulators are in registers
         load_kp(head_g1);
         X3P_WAIT_VM0();
@@ -583,20 +658,23 @@ __global__ __launch_bounds__(64 * ((NKB + BPW - 1) / BPW), BPW == 1 ? 2 : 1) voi
                 if (head_g2 >= 0) flush(head_g2);
                 zero_acc();
                 head_g2 = c0.a;
+                X3P_WAIT_VM0();
             }
             if (i + 1 < T && c1.a != head_g1) {
                 load_kp(c1.a);
                 head_g1 = c1.a;
+                X3P_WAIT_VM0();
             }
             int rows_ok = 0;
             if (i >= 0) {
                 rows_ok = n32 - c0.t * TR;
                 if (rows_ok > TR) rows_ok = TR;
             }
-            iteration(i, slot_q, slot_v, doff, c0, c2, c3, rows_ok);
-            doff = load_dma_off();            // for the next iteration
-            // the DMAs issued in this iteration have landed for this wave; together with the barrier: for every wave
-            X3P_WAIT_VM0();
+            const unsigned want = full_mask & ((i + 3 < T ? (1u << UQ) - 1u : 0u) | (i + 2 < T ? ((1u << UV) - 1u) << UQ : 0u));
+            const DmaCtx dc = dma_ctx(i + 3 < T, c3, slot_v, i + 2 < T, c2, slot_q == 2 ? 0 : slot_q + 1);
+            iteration(i, slot_q, slot_v, c0, dc, rows_ok);
+            // everything issued BEFORE this iteration has landed for this wave; together with the barrier: for every wave
+            wait_dma(__builtin_popcount(want));
             X3P_STAMP(i + 1, 4);
             __builtin_amdgcn_s_barrier();
             X3P_STAMP(i + 1, 5);
@@ -609,6 +687,9 @@ __global__ __launch_bounds__(64 * ((NKB + BPW - 1) / BPW), BPW == 1 ? 2 : 1) voi
 #undef X3P_UB1
 #undef X3P_UB2
     };
+    // the second-dispatched waves of a SIMD lose every arbitration to the first at equal priority and set the iteration time
+    // (in-kernel trace: first half 1450 ticks for waves 0-3, 2480 for waves 4-6): static priority for them (guide T5, static form)
+    if (w >= 4) __builtin_amdgcn_s_setprio(1);
     if (w == NW - 1)
         run(std::true_type{});
     else
@@ -684,7 +765,7 @@ struct X3PPlan {
     int num_wg, tiles_per_head, tiles_per_wg, total_tiles, seg_count, nkb;
 };
 bool x3p_plan(int64_t n, int k, int h, int dk, X3PPlan* pl) {
-    if (dk != 128 || k < 1 || k > 256 || n < 1 || h < 1) return false;
+    if (dk != 128 || k < 97 || k > 256 || n < 1 || h < 1) return false;   // 4 .. 8 key blocks (fewer: too few waves per CU, and too many DMA instructions per wave)
     const int64_t tph = (n + TR - 1) / TR, total = tph * h;
     if (total > 0x7fffffff) return false;
     const int cus = snf::cu_count();
@@ -703,10 +784,10 @@ size_t x3p_partial_bytes(const X3PPlan& pl, int dk) { return (size_t)pl.num_wg *
 size_t x3p_kpfrag_bytes(const X3PPlan& pl, int h, int dk) { return (size_t)h * pl.nkb * (dk / 16) * 2 * 64 * 16; }
 size_t x3p_workspace(const X3PPlan& pl, int h, int dk) { return x3p_partial_bytes(pl, dk) + x3p_kpfrag_bytes(pl, h, dk); }
 
-template <int DK, int NKB, int BPW, bool AUX>
+template <int DK, int NKB, bool AUX>
 int x3p_launch(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s) {
-    constexpr int lds = x3p_lds_bytes(DK, NKB, BPW);
-    auto kern = sparse_attn_x3p_kernel<DK, NKB, BPW, AUX, 0>;
+    constexpr int lds = x3p_lds_bytes(DK, NKB);
+    auto kern = sparse_attn_x3p_kernel<DK, NKB, AUX, 0>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
         snf::set_error("sparse_attn_x3p: cannot reserve %d bytes of LDS", lds);
         (void)hipGetLastError();
@@ -716,7 +797,7 @@ int x3p_launch(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s)
                        const_cast<u32x4*>(P.kp_frag));
     int rc0 = snf::check_launch("x3p_prep_kp_kernel");
     if (rc0) return rc0;
-    hipLaunchKernelGGL(kern, dim3(pl.num_wg), dim3(64 * ((NKB + BPW - 1) / BPW)), lds, s, P);
+    hipLaunchKernelGGL(kern, dim3(pl.num_wg), dim3(64 * NKB), lds, s, P);
     int rc = snf::check_launch("sparse_attn_x3p_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL((x3p_reduce_kernel<DK>), dim3(NKB * (DK / 32) * 4, P.h), dim3(64), 0, s, P.partial, NKB, pl.num_wg, pl.seg_count,
@@ -726,15 +807,10 @@ int x3p_launch(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s)
 template <int DK>
 int x3p_dispatch(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s) {
     const bool aux = P.attn != nullptr || P.lse != nullptr;
-    static const int bpw = getenv("SNF_X3P_BPW") ? atoi(getenv("SNF_X3P_BPW")) : 1;   // development switch
 #define SNF_X3P_CASE(NB) \
-    case NB: return bpw == 2 ? (aux ? x3p_launch<DK, NB, 2, true>(P, pl, out, s) : x3p_launch<DK, NB, 2, false>(P, pl, out, s)) \
-                             : (aux ? x3p_launch<DK, NB, 1, true>(P, pl, out, s) : x3p_launch<DK, NB, 1, false>(P, pl, out, s));
+    case NB: return aux ? x3p_launch<DK, NB, true>(P, pl, out, s) : x3p_launch<DK, NB, false>(P, pl, out, s);
     switch (pl.nkb) {
 #ifndef SNF_ATTN_DEV
-        SNF_X3P_CASE(1)
-        SNF_X3P_CASE(2)
-        SNF_X3P_CASE(3)
         SNF_X3P_CASE(4)
         SNF_X3P_CASE(5)
         SNF_X3P_CASE(6)
@@ -766,7 +842,7 @@ int snf_sparse_attn_fwd_x3_hl(const void* q_hl, int64_t ldq, const void* v_hl, i
     SNF_REQUIRE(q_hl && v_hl && kp && out, "snf_sparse_attn_fwd_x3_hl: null pointer");
     X3PPlan pl;
     if (!x3p_plan(n, k, h, dk, &pl)) {
-        snf::set_error("snf_sparse_attn_fwd_x3_hl: unsupported shape n=%lld k=%d h=%d dk=%d (dk = 128, 1 <= k <= 256)", (long long)n, k, h, dk);
+        snf::set_error("snf_sparse_attn_fwd_x3_hl: unsupported shape n=%lld k=%d h=%d dk=%d (dk = 128, 97 <= k <= 256)", (long long)n, k, h, dk);
         return SNF_EUNSUPPORTED;
     }
     const int64_t d = (int64_t)h * dk;

@@ -26,6 +26,9 @@ ACTIVATIONS = ("relu", "gelu", "leakyrelu", "selu")      # reference snuffy.py:2
 # fp64 this leaves P within 3.5e-6, O within 1e-5 relative and a bag's logits within 3e-5 of the reference goldens: inside
 # north_star's 1e-3 fp32 class by 30x, but NOT bit-level fp32 -- "exact" / "library" are the plain-fp32 settings.
 FP32_ATTENTION = "x3"
+# with FP32_ATTENTION == "x3": the pipelined kernel on pre-split operands (snf_sparse_attn_fwd_x3_hl) wherever the layer runs on the
+# one-pass hl GEMMs and the shape allows (dk = 128, <= 256 keys); False keeps the round-3 kernel on fp32 operands
+X3_HL_ATTENTION = True
 # fp32 path, the [N, .] projections: "x3" = split-bf16 products on the hand-written MFMA GEMM (fp32-class: logits within
 # ~1e-5 of the exact path), "library" = fp32 library GEMMs.
 FP32_GEMM = "x3"
@@ -436,16 +439,22 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
         xs, slot = ops.gather_slot_map(x2, sel)                                     # snuffy.py:131,145-147 (+ row -> slot map)
         kp = _rows_linear(xs, lk)                                       # keys = RAW selected rows (K rows: fp32)
         xn3 = _take_xn3(layer, x2, n0)                                              # left by the critic pass, if any
+        # pre-split operands for the pipelined attention kernel: the projection's epilogue writes [Q | V] as its hl image (the same
+        # hi / lo values the attention kernel would derive from the fp32 tensor, the same 4 bytes per element)
+        hl_attn = (hl and ragged is None and packed is None and FP32_ATTENTION == "x3" and X3_HL_ATTENTION
+                   and ops.x3_hl_attn_supported(k, d // h))
         if hl:
             if xn3 is None:
                 xn3 = ops.layernorm_rows_hl(x2, n0.weight, n0.bias, n0.eps)         # snuffy.py:107
-            qv = ops.gemm_hl(xn3, fh["wqv"], fw["bqv"])                             # [N, 2D] f32 = [Q | V]
+            qv = ops.gemm_hl(xn3, fh["wqv"], fw["bqv"], hl_out=hl_attn)             # [N, 2D] f32 = [Q | V] (or its [N, 4D] image)
         else:
             xn3 = ops.layernorm_rows_split3(x2, n0.weight, n0.bias, n0.eps)
             qv = ops.gemm_x3(xn3, fw["wqv"], fw["bqv"], out_dtype=torch.float32)
         del xn3
-        q, v = qv[:, :d], qv[:, d:]
-        if ragged is not None:
+        q, v = (None, None) if hl_attn else (qv[:, :d], qv[:, d:])
+        if hl_attn:
+            o, attn, _ = ops.sparse_attn_fwd_x3_hl(qv[:, :2 * d], qv[:, 2 * d:], kp, h, need_attn=need_attn)   # snuffy.py:160-168
+        elif ragged is not None:
             o, attn, _ = ops.sparse_attn_fwd_ragged(q, v, kp, packed, ragged, h, need_attn=need_attn)
         elif packed is not None:
             o, attn, _ = ops.sparse_attn_fwd_x3_varlen(q, v, kp, packed, kb, h, need_attn=need_attn)

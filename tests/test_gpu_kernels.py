@@ -422,6 +422,63 @@ def test_sparse_attn_x3_config_b_walks_heads_and_spike():
         ops().sparse_attn_fwd_x3(q.to(DEV), v.to(DEV), torch.zeros(8 * 224 + 1, d, device=DEV), h)   # more than 8 key chunks
 
 
+@pytest.mark.parametrize("n,k,h", [(1000, 200, 6), (4097, 224, 3), (33, 128, 2), (1, 97, 1), (5000, 100, 2), (2000, 256, 2), (777, 129, 2),
+                                   (300, 160, 1), (6401, 200, 6)])
+def test_sparse_attn_x3_hl_fp32_class(n, k, h):
+    """snf_sparse_attn_fwd_x3_hl (the pipelined split-bf16 x 3 kernel on PRE-SPLIT hl operands) against the fp64 oracle on the
+    unrounded operands: same arithmetic class as snf_sparse_attn_fwd_x3 (the hl image carries exactly the hi / lo halves that
+    kernel derives from the fp32 tensor), same bounds.  Tile counts from one to several per workgroup, ragged last tiles, every
+    key-block count the kernel is built for (4 .. 8), rows past the end, head changes inside a workgroup's range."""
+    dk = 128
+    g = torch.Generator().manual_seed(n * 7 + k)
+    d = h * dk
+    q, kp, v = torch.randn(n, d, generator=g), torch.randn(k, d, generator=g), torch.randn(n, d, generator=g)
+    img = ops().split_hl_rows(torch.cat([q, v], dim=1).to(DEV))            # [n, 4 d]: image of Q | image of V, as the projection leaves it
+    qi, vi = img[:, :2 * d], img[:, 2 * d:]
+    o, attn, lse = ops().sparse_attn_fwd_x3_hl(qi, vi, kp.to(DEV), h, need_attn=True, need_lse=True)
+    o_ref, p_ref = attn_ref(q, kp, v, h)
+    assert (attn.cpu().double() - p_ref).abs().max() < 6e-6
+    assert rel_err(o.cpu(), o_ref) < 2e-5
+    s_ref = (q.double().view(n, h, dk).transpose(0, 1) @ kp.double().view(k, h, dk).transpose(0, 1).transpose(1, 2)) / dk ** 0.5
+    assert (lse.cpu().double() - torch.logsumexp(s_ref, dim=-1)).abs().max() < 3e-5
+    assert (attn.sum(-1) - 1).abs().max() < 1e-5
+    # without the A / lse outputs (the inference call): the same bits, and bit-identical run to run (fixed-order reduction)
+    o2, a2, _ = ops().sparse_attn_fwd_x3_hl(qi, vi, kp.to(DEV), h)
+    o3, _, _ = ops().sparse_attn_fwd_x3_hl(qi, vi, kp.to(DEV), h)
+    assert a2 is None and torch.equal(o2, o3) and torch.equal(o2, o)
+    # and the round-3 kernel on the fp32 tensors the images were made of
+    if k <= 224:
+        o4, a4, _ = ops().sparse_attn_fwd_x3(q.to(DEV), v.to(DEV), kp.to(DEV), h, need_attn=True)
+        assert (attn - a4).abs().max() < 6e-6 and rel_err(o.cpu(), o4.cpu()) < 2e-5
+
+
+def test_sparse_attn_x3_hl_config_b_spike_and_domain():
+    """Config-B size (24 tiles per workgroup, head changes inside six workgroups' ranges) + a dominating key (no overflow) +
+    the shapes the entry point refuses."""
+    n, k, h, dk = 32768, 200, 6, 128
+    g = torch.Generator().manual_seed(11)
+    d = h * dk
+    q, kp, v = torch.randn(n, d, generator=g), torch.randn(k, d, generator=g), torch.randn(n, d, generator=g)
+    q[7] *= 40.0
+    kp[3] *= 25.0
+    img = ops().split_hl_rows(torch.cat([q, v], dim=1).to(DEV))
+    o, attn, _ = ops().sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], kp.to(DEV), h, need_attn=True)
+    assert torch.isfinite(o).all() and torch.isfinite(attn).all()
+    rows = torch.arange(0, n, 61)
+    o_ref, p_ref = attn_ref(q, kp, v, h)
+    assert (attn[:, rows.to(DEV), :].cpu().double() - p_ref[:, rows, :]).abs().max() < 1e-3   # spiked operands: see the x3 test
+    assert rel_err(o.cpu(), o_ref) < 1e-3
+    # column-sum checksum at full size: sum_k O[k, :] = sum_n V[n, :] (every row's probabilities sum to one)
+    assert rel_err(o.cpu().view(k, h, dk).sum(0), v.view(n, h, dk).sum(0)) < 1e-4
+    from snuffy_amd import SnuffyHipError
+    with pytest.raises(SnuffyHipError):
+        ops().sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], torch.zeros(96, d, device=DEV), h)    # fewer than 4 key blocks
+    with pytest.raises(SnuffyHipError):
+        ops().sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], torch.zeros(257, d, device=DEV), h)   # more than 8
+    with pytest.raises(SnuffyHipError):
+        ops().sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], torch.zeros(200, d, device=DEV), 12)  # dk = 64
+
+
 def test_mfma_rejects_unsupported_shapes():
     from snuffy_amd import SnuffyHipError
     q = torch.zeros(64, 96, device=DEV)

@@ -9,5 +9,5 @@ echo "== defs: [$1] bpw=${2:-1}"
 if [ -n "$3" ]; then
   SNF_X3P_BPW=${2:-1} python tools/x3p_trace.py $3 2>&1 | grep -v amdgpu.ids
 else
-  SNF_X3P_BPW=${2:-1} python tools/x3p_dev.py 32768 200 6 --time 2>&1 | grep -v amdgpu.ids
+  SNF_X3P_BPW=${2:-1} python tools/x3p_dev.py 32768 200 6 --time 2>&1 | grep -v amdgpu.ids | grep "x3_hl"
 fi

@@ -21,13 +21,14 @@ img = ops.split_hl_rows(qv)
 kp = torch.randn(k, d, device="cuda")
 for _ in range(3):
     ops.sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], kp, h)
-buf = torch.zeros(8 * 64 * 8, dtype=torch.int64, device="cuda")
+buf = torch.zeros(8 * 64 * 8 + 8 * 64 * 16, dtype=torch.int64, device="cuda")
 lib.snf_debug_attn_trace_wg(WG)
 lib.snf_debug_attn_trace(ctypes.c_void_p(buf.data_ptr()))
 ops.sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], kp, h)
 torch.cuda.synchronize()
 lib.snf_debug_attn_trace(None)
-t = buf.cpu().view(8, 64, 8)
+t2 = buf.cpu()[8 * 64 * 8:].view(8, 64, 16)
+t = buf.cpu()[:8 * 64 * 8].view(8, 64, 8)
 names = ["top", "dma issued", "first half", "second half", "vm wait", "barrier"]
 for w in range(8):
     if t[w].abs().sum() == 0:
@@ -40,3 +41,5 @@ for w in range(8):
             continue
         base = int(row[0])
         print("  it %2d  start %8d | " % (it - 1, base - t0) + "  ".join("%s +%d" % (names[k], int(row[k]) - base) for k in range(1, 6) if int(row[k])))
+        if it in (6, 7) and int(t2[w, it, 0]):
+            print("        fine: " + " ".join("%d" % (int(t2[w, it, k]) - base) for k in range(12)))
