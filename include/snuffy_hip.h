@@ -270,8 +270,8 @@ int snf_sparse_attn_fwd_x3(const float* q, int64_t ldq, const float* v, int64_t 
  * writes with out_dtype SNF_DT_BF16_HL and snf_split_hl_f32 makes of an fp32 tensor; 4 bytes per element like the fp32 tensor);
  * row pitches in bf16 elements (>= 2 h dk, 16-byte aligned rows: the halves of a fused [Q | V] image are taken in place);
  * kp [k, h dk] f32.  Software-pipelined kernel: LDS-DMA of full lines, one wave per key block, GEMM1 / GEMM2 MFMAs interleaved
- * with the softmax vector work in every wave's own instruction stream (csrc/sparse_attn_x3p.hip).  dk = 128, 97 <= k <= 256 (one
- * launch, 4 .. 8 key blocks); other shapes SNF_EUNSUPPORTED (the caller keeps snf_sparse_attn_fwd_x3).  Outputs as snf_sparse_attn_fwd_x3. */
+ * with the softmax vector work in every wave's own instruction stream (csrc/sparse_attn_x3p.hip).  dk = 128, 97 <= k <= 2048: up to 256 keys
+ * (4 .. 8 key blocks) in one launch, more as up to 8 key chunks -- a statistics pass per chunk, then the chunks' main passes; other shapes SNF_EUNSUPPORTED (the caller keeps snf_sparse_attn_fwd_x3).  Outputs as snf_sparse_attn_fwd_x3. */
 size_t snf_sparse_attn_fwd_x3_hl_workspace_bytes(int64_t n, int k, int h, int dk);
 int snf_sparse_attn_fwd_x3_hl(const void* q_hl, int64_t ldq, const void* v_hl, int64_t ldv, const float* kp, int64_t n, int k, int h,
                               int dk, float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,

@@ -520,14 +520,20 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
     Src cur = tile_src(tile);
     stage(cur, 0, 0);
     int buf = 0;
+    bool after_epilogue = false;   // the previous tile's stores may still be in flight (they count in vmcnt)
     while (true) {
         const int next = tile + wgs_per_xcd;
         const bool has_next = next < t_hi;
         const bool full = (tile / P.tiles_n + 1) * BM <= P.m && (tile % P.tiles_n + 1) * BN <= P.n;
         for (int s = 0; s < ns; ++s) {
             // this step's two images have landed (every wave waits for its own pieces, then all meet); the other buffer is free:
-            // its last fragment reads belong to the previous step's MFMAs, which every wave has issued before this barrier
-            wait_vmcnt<0>();
+            // its last fragment reads belong to the previous step's MFMAs, which every wave has issued before this barrier.
+            // First step behind an epilogue: its images were waited for BEFORE the epilogue (the wait behind the bias loads), the
+            // only thing in flight is the tile's store burst -- which must not be waited for here: every workgroup of the chip
+            // stores its 256 KiB tile at the same moment, and draining that burst in front of the next tile's first MFMA was 40 us
+            // of the Q | V projection (round-3 ablation).  The stores drain under the first step's MFMA burst instead.
+            if (!(s == 0 && after_epilogue)) wait_vmcnt<0>();
+            after_epilogue = false;
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -585,6 +591,7 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
             epilogue(tile, std::true_type{});
         else
             epilogue(tile, std::false_type{});
+        after_epilogue = true;
         if (!has_next) break;
         tile = next;
     }

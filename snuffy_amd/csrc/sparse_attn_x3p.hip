@@ -65,7 +65,9 @@ struct X3PParams {
     float* attn;               // [h, n, attn_ld] (already offset to this launch's first key) or null
     int64_t attn_ld;
     float* lse;                // [h, n] or null
-    const f32x2* stats;        // MODE 2 (one key chunk of several): [h, n] (row max in scaled log2 units, row sum) over ALL keys
+    f32x2* stats;              // key-chunked launches: [nchunks][h][n] (row max in scaled log2 units, row sum) per chunk.  MODE 1 writes
+                               // chunk `chunk`'s pair per row, MODE 2 reads all chunks' pairs (softmax exact over all keys)
+    int nchunks, chunk;
     float* partial;            // [num_wg * seg_count][NKB * dk / 32 tiles][4][64][4]
     int tiles_per_head, tiles_per_wg, total_tiles, seg_count;
     unsigned long long* trace;   // dev builds (X3P_TRACE): s_memtime stamps of workgroup trace_wg, [wave][64 iterations][8]
@@ -165,10 +167,12 @@ constexpr int x3p_lds_bytes(int dk, int nkb) {
     return 3 * x3p_qslot(dk) + 3 * TR * 4 * dk + nkb * (TR * 64 * 2) + 2 * nkb * TR * 8 + nkb * (x3p_dma_u(nq, nkb) + x3p_dma_u(nv, nkb)) * 256;
 }
 
-// MODE 0: all keys in this launch.  (MODE 2, a key chunk with the row statistics of all chunks given: not built yet.)
+// MODE 0: all keys in this launch.  MODE 1: statistics pass of one key chunk (GEMM1 + max / sum per row, written to P.stats; no
+// GEMM2, V is not touched).  MODE 2: main pass of one key chunk with the row statistics of ALL chunks taken from P.stats.
 template <int DK, int NKB, bool AUX, int MODE>
 __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PParams P) {
-    static_assert(DK == 128 && MODE == 0, "sparse_attn_x3p: dk = 128, MODE 0 only");
+    static_assert(DK == 128 && MODE >= 0 && MODE <= 2, "sparse_attn_x3p: dk = 128");
+    constexpr bool DRAIN = AUX || MODE != 0;   // global loads / stores of the kernel's own in the loop: no counted DMA waits
     constexpr int NW = NKB;                  // waves: one per key block
 #ifndef X3P_NACC
 #define X3P_NACC 1   // measured: 2 (no MFMA behind its predecessor's result) costs 16 registers + 16 adds and buys nothing at 2 waves / SIMD
@@ -449,20 +453,41 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
             if constexpr (u >= N_FIRST) { if constexpr (smap.kind[u - N_FIRST] != 4 && smap.kind[u - N_FIRST] != 0) return; }
 #endif
             if constexpr (u == 0) {
+                if constexpr (MODE == 2) {   // every chunk's (max, sum) of this lane's row, from the statistics passes
+                    int row = cno.t * TR + j;
+                    if (row > n32 - 1) row = n32 - 1;
+                    const f32x2* st = P.stats + (int64_t)cno.a * P.n + row;
+                    s.m = -INFINITY;
+                    for (int c = 0; c < P.nchunks; ++c) s.m = fmaxf(s.m, st[(int64_t)c * P.h * P.n][0]);
+                    s.l = 0.f;
+                    for (int c = 0; c < P.nchunks; ++c) {
+                        const f32x2 pr = st[(int64_t)c * P.h * P.n];
+                        s.l = fmaf(pr[1], __builtin_amdgcn_exp2f(pr[0] - s.m), s.l);
+                    }
+                } else {
 #pragma unroll
-                for (int b = 0; b < NW; ++b) s.sv[b] = *reinterpret_cast<const f32x2*>(smem + st_lane + (par_n * NW + b) * (TR * 8));
+                    for (int b = 0; b < NW; ++b) s.sv[b] = *reinterpret_cast<const f32x2*>(smem + st_lane + (par_n * NW + b) * (TR * 8));
+                }
             } else if constexpr (u == U_CMAX) {
-                float m = s.sv[0][0];
+                if constexpr (MODE != 2) {
+                    float m = s.sv[0][0];
 #pragma unroll
-                for (int b = 1; b < NW; ++b) m = fmaxf(m, s.sv[b][0]);
-                s.m = m, s.l = 0.f;
+                    for (int b = 1; b < NW; ++b) m = fmaxf(m, s.sv[b][0]);
+                    s.m = m, s.l = 0.f;
+                }
             } else if constexpr (u < U_FS) {
+                if constexpr (MODE == 2) return;
                 constexpr int b = u - U_CW;       // stage b: sub of wave b, exp of wave b - 1, fma of wave b - 2
                 if constexpr (b >= 2) s.l = fmaf(s.sv[b - 2][1], (b & 1) ? s.e1 : s.e0, s.l);
                 if constexpr (b >= 1 && b - 1 < NW) ((b & 1) ? s.e0 : s.e1) = __builtin_amdgcn_exp2f((b & 1) ? s.d0 : s.d1);
                 if constexpr (b < NW) ((b & 1) ? s.d1 : s.d0) = s.sv[b][0] - s.m;
             } else if constexpr (u == U_FS) {
                 const bool rvalid = j < rows_ok;
+                if constexpr (MODE == 1) {   // this chunk's pair of the row; nothing else happens to tile i in a statistics pass
+                    if (rvalid && hf == 0 && w == 0) P.stats[((int64_t)P.chunk * P.h + cno.a) * P.n + cno.t * TR + j] = f32x2{s.m, s.l};
+                    s.fscale = 0.f;
+                    return;
+                }
                 if constexpr (AUX)
                     if (P.lse && rvalid && hf == 0 && w == 0)
                         P.lse[(int64_t)cno.a * P.n + cno.t * TR + j] = (s.m + __log2f(s.l)) * 0.69314718055994530942f;
@@ -470,6 +495,7 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
                 asm volatile("" : "+v"(fs));              // keep the select below a select (no branch around the exp / rcp)
                 s.fscale = rvalid ? fs : 0.f;
             } else if constexpr (u < N_FIRST) {
+                if constexpr (MODE == 1) return;
                 constexpr int c4 = (u - U_NORM) / 3, part = (u - U_NORM) % 3;
                 unsigned char* pb = smem + (waddr0 ^ (16 * c4));
                 if constexpr (part == 0) {
@@ -525,8 +551,10 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
                 } else if constexpr (kind == 4) {
                     dma_unit(std::integral_constant<int, arg>{}, dc, s.doff[arg]);
                 } else {
-                    const float lsum = xhalf_sum(s.l0 + s.l1);
-                    *reinterpret_cast<f32x2*>(smem + st_lane + ((par_n ^ 1) * NW + w) * (TR * 8)) = f32x2{mw, lsum};   // both halves: same pair
+                    if constexpr (MODE != 2) {
+                        const float lsum = xhalf_sum(s.l0 + s.l1);
+                        *reinterpret_cast<f32x2*>(smem + st_lane + ((par_n ^ 1) * NW + w) * (TR * 8)) = f32x2{mw, lsum};   // both halves: same pair
+                    }
                 }
             }
         };
@@ -572,7 +600,7 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
                     if constexpr (mi == 0) acc = X3P_MFMA1(kph[e], ql[e], c0);
                     if constexpr (mi == 1) acc = X3P_MFMA1(kpl[e], qh[e], c0);
                     if constexpr (mi == 2) acc = X3P_MFMA1(kph[e], qh[e], c0);
-                    if constexpr (e + 1 == NKS) {           // all P chunks are written: the first step of GEMM2
+                    if constexpr (e + 1 == NKS && MODE != 1) {   // all P chunks are written: the first step of GEMM2
                         if constexpr (mi == 0) ph[0] = p_frag(0, 0), vl[0] = v_frag(va[0], 0, 1);
                         if constexpr (mi == 1) vl[1] = v_frag(va[1], 0, 1), pl[0] = p_frag(0, 1);
                         if constexpr (mi == 2) vh[0] = v_frag(va[0], 0, 0), vh[1] = v_frag(va[1], 0, 0);
@@ -593,10 +621,12 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
                 static_for<0, 6>([&](auto m_t) __attribute__((always_inline)) {
                     constexpr int mi = decltype(m_t)::value, k = H + 6 * e + mi, prod = mi / 2, cb = c0 + (mi & 1);
                     X3P_FENCE();
-                    if constexpr (prod == 0) acc_o[cb] = X3P_MFMA2(ph[sk], vl[2 * e + (mi & 1)], acc_o[cb]);
-                    if constexpr (prod == 1) acc_o[cb] = X3P_MFMA2(pl[sk], vh[2 * e + (mi & 1)], acc_o[cb]);
-                    if constexpr (prod == 2) acc_o[cb] = X3P_MFMA2(ph[sk], vh[2 * e + (mi & 1)], acc_o[cb]);
-                    if constexpr (e1 < NCB) {               // the next pair's fragments, three slots ahead of their first use
+                    if constexpr (MODE != 1) {
+                        if constexpr (prod == 0) acc_o[cb] = X3P_MFMA2(ph[sk], vl[2 * e + (mi & 1)], acc_o[cb]);
+                        if constexpr (prod == 1) acc_o[cb] = X3P_MFMA2(pl[sk], vh[2 * e + (mi & 1)], acc_o[cb]);
+                        if constexpr (prod == 2) acc_o[cb] = X3P_MFMA2(ph[sk], vh[2 * e + (mi & 1)], acc_o[cb]);
+                    }
+                    if constexpr (e1 < NCB && MODE != 1) {  // the next pair's fragments, a step ahead of their first use
                         if constexpr (mi == 0) vl[2 * e1] = v_frag(va[n0], sk1, 1);
                         if constexpr (mi == 1) vl[2 * e1 + 1] = v_frag(va[n0 + 1], sk1, 1);
                         if constexpr (mi == 2) vh[2 * e1] = v_frag(va[n0], sk1, 0);
@@ -615,7 +645,7 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
         // wait until at most n of this wave's LDS-DMA instructions are in flight: they complete in order, so everything issued before
         // the last n has landed.  (AUX builds also have stores in flight, which are not ordered with the loads: drain everything.)
         auto wait_dma = [&](int n) __attribute__((always_inline)) {
-            if constexpr (AUX) {
+            if constexpr (DRAIN) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
                 static_assert(UQ + UV <= 40, "wait_dma: more DMA instructions per wave than the switch covers");
@@ -643,7 +673,7 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
         c2 = cur_next(c1);
         c3 = cur_next(c2);
         {
-            const DmaCtx d0 = dma_ctx(true, c1, 0, true, c1, 0), d1 = dma_ctx(1 < T, c2, 1, false, c2, 1);
+            const DmaCtx d0 = dma_ctx(true, c1, 0, MODE != 1, c1, 0), d1 = dma_ctx(1 < T, c2, 1, false, c2, 1);
             static_for<0, UQ + UV>([&](auto u_t) __attribute__((always_inline)) { dma_unit(u_t, d0, dma_tab[decltype(u_t)::value * 64]); });
             static_for<0, UQ>([&](auto u_t) __attribute__((always_inline)) { dma_unit(u_t, d1, dma_tab[decltype(u_t)::value * 64]); });
         }
@@ -654,7 +684,7 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
         int slot_q = 0, slot_v = 2;           // (i + 1) % 3, i % 3 for i = -1
         for (int i = -1; i < T; ++i) {
             // head changes (wave-uniform, rare): accumulators of a finished head out, Kp fragments of the next head in
-            if (i >= 0 && c0.a != head_g2) {
+            if (MODE != 1 && i >= 0 && c0.a != head_g2) {
                 if (head_g2 >= 0) flush(head_g2);
                 zero_acc();
                 head_g2 = c0.a;
@@ -670,8 +700,9 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
                 rows_ok = n32 - c0.t * TR;
                 if (rows_ok > TR) rows_ok = TR;
             }
-            const unsigned want = full_mask & ((i + 3 < T ? (1u << UQ) - 1u : 0u) | (i + 2 < T ? ((1u << UV) - 1u) << UQ : 0u));
-            const DmaCtx dc = dma_ctx(i + 3 < T, c3, slot_v, i + 2 < T, c2, slot_q == 2 ? 0 : slot_q + 1);
+            const bool dov = MODE != 1 && i + 2 < T;   // a statistics pass never touches V
+            const unsigned want = full_mask & ((i + 3 < T ? (1u << UQ) - 1u : 0u) | (dov ? ((1u << UV) - 1u) << UQ : 0u));
+            const DmaCtx dc = dma_ctx(i + 3 < T, c3, slot_v, dov, c2, slot_q == 2 ? 0 : slot_q + 1);
             iteration(i, slot_q, slot_v, c0, dc, rows_ok);
             // everything issued BEFORE this iteration has landed for this wave; together with the barrier: for every wave
             wait_dma(__builtin_popcount(want));
@@ -682,7 +713,7 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
             slot_q = slot_q == 2 ? 0 : slot_q + 1;
             c0 = c1, c1 = c2, c2 = c3, c3 = cur_next(c3);
         }
-        flush(head_g2);
+        if constexpr (MODE != 1) flush(head_g2);
 #undef X3P_UB
 #undef X3P_UB1
 #undef X3P_UB2
@@ -784,10 +815,10 @@ size_t x3p_partial_bytes(const X3PPlan& pl, int dk) { return (size_t)pl.num_wg *
 size_t x3p_kpfrag_bytes(const X3PPlan& pl, int h, int dk) { return (size_t)h * pl.nkb * (dk / 16) * 2 * 64 * 16; }
 size_t x3p_workspace(const X3PPlan& pl, int h, int dk) { return x3p_partial_bytes(pl, dk) + x3p_kpfrag_bytes(pl, h, dk); }
 
-template <int DK, int NKB, bool AUX>
+template <int DK, int NKB, bool AUX, int MODE>
 int x3p_launch(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s) {
     constexpr int lds = x3p_lds_bytes(DK, NKB);
-    auto kern = sparse_attn_x3p_kernel<DK, NKB, AUX, 0>;
+    auto kern = sparse_attn_x3p_kernel<DK, NKB, AUX, MODE>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
         snf::set_error("sparse_attn_x3p: cannot reserve %d bytes of LDS", lds);
         (void)hipGetLastError();
@@ -799,16 +830,22 @@ int x3p_launch(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s)
     if (rc0) return rc0;
     hipLaunchKernelGGL(kern, dim3(pl.num_wg), dim3(64 * NKB), lds, s, P);
     int rc = snf::check_launch("sparse_attn_x3p_kernel");
-    if (rc) return rc;
+    if (rc || MODE == 1) return rc;
     hipLaunchKernelGGL((x3p_reduce_kernel<DK>), dim3(NKB * (DK / 32) * 4, P.h), dim3(64), 0, s, P.partial, NKB, pl.num_wg, pl.seg_count,
                        pl.tiles_per_head, pl.tiles_per_wg, P.k, P.h, out);
     return snf::check_launch("x3p_reduce_kernel");
 }
-template <int DK>
-int x3p_dispatch(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s) {
+template <int DK, int NB>
+int x3p_modes(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s, int mode) {
     const bool aux = P.attn != nullptr || P.lse != nullptr;
+    if (mode == 1) return x3p_launch<DK, NB, false, 1>(P, pl, out, s);
+    if (mode == 2) return aux ? x3p_launch<DK, NB, true, 2>(P, pl, out, s) : x3p_launch<DK, NB, false, 2>(P, pl, out, s);
+    return aux ? x3p_launch<DK, NB, true, 0>(P, pl, out, s) : x3p_launch<DK, NB, false, 0>(P, pl, out, s);
+}
+template <int DK>
+int x3p_dispatch(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s, int mode) {
 #define SNF_X3P_CASE(NB) \
-    case NB: return aux ? x3p_launch<DK, NB, true>(P, pl, out, s) : x3p_launch<DK, NB, false>(P, pl, out, s);
+    case NB: return x3p_modes<DK, NB>(P, pl, out, s, mode);
     switch (pl.nkb) {
 #ifndef SNF_ATTN_DEV
         SNF_X3P_CASE(4)
@@ -826,23 +863,48 @@ int x3p_dispatch(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t 
     return SNF_EUNSUPPORTED;
 }
 
+// keys per launch: 256 at most (8 key blocks); more keys run as up to 8 chunks of (almost) equal size, a multiple of 4:
+// statistics pass per chunk, then the chunks' main passes with the softmax exact over all keys
+struct X3PChunks {
+    int count, size;
+};
+bool x3p_chunks(int k, int dk, X3PChunks* c) {
+    if (dk != 128 || k < 97 || k > 8 * 256) return false;
+    c->count = (k + 255) / 256;
+    c->size = c->count == 1 ? k : ((k + c->count - 1) / c->count + 3) & ~3;
+    return true;
+}
+struct X3PLayout {   // workspace: partial accumulators | Kp fragment image | statistics
+    size_t partial, kpfrag, stats;
+};
+bool x3p_layout(int64_t n, int k, int h, int dk, X3PChunks* ch, X3PLayout* lay) {
+    X3PPlan pl;
+    if (h < 1 || !x3p_chunks(k, dk, ch) || !x3p_plan(n, ch->size, h, dk, &pl)) return false;
+    lay->partial = x3p_partial_bytes(pl, dk);        // the first chunks are the largest
+    lay->kpfrag = x3p_kpfrag_bytes(pl, h, dk);
+    lay->stats = ch->count > 1 ? (size_t)ch->count * h * n * sizeof(f32x2) : 0;
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t snf_sparse_attn_fwd_x3_hl_workspace_bytes(int64_t n, int k, int h, int dk) {
-    X3PPlan pl;
-    if (!x3p_plan(n, k, h, dk, &pl)) return 0;
-    return x3p_workspace(pl, h, dk);
+    X3PChunks ch;
+    X3PLayout lay;
+    if (!x3p_layout(n, k, h, dk, &ch, &lay)) return 0;
+    return lay.partial + lay.kpfrag + lay.stats;
 }
 
 int snf_sparse_attn_fwd_x3_hl(const void* q_hl, int64_t ldq, const void* v_hl, int64_t ldv, const float* kp, int64_t n, int k, int h,
                               int dk, float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
                               snf_stream_t stream) {
     SNF_REQUIRE(q_hl && v_hl && kp && out, "snf_sparse_attn_fwd_x3_hl: null pointer");
-    X3PPlan pl;
-    if (!x3p_plan(n, k, h, dk, &pl)) {
-        snf::set_error("snf_sparse_attn_fwd_x3_hl: unsupported shape n=%lld k=%d h=%d dk=%d (dk = 128, 97 <= k <= 256)", (long long)n, k, h, dk);
+    X3PChunks ch;
+    X3PLayout lay;
+    if (n < 1 || !x3p_layout(n, k, h, dk, &ch, &lay)) {
+        snf::set_error("snf_sparse_attn_fwd_x3_hl: unsupported shape n=%lld k=%d h=%d dk=%d (dk = 128, 97 <= k <= 2048)", (long long)n, k, h, dk);
         return SNF_EUNSUPPORTED;
     }
     const int64_t d = (int64_t)h * dk;
@@ -850,23 +912,43 @@ int snf_sparse_attn_fwd_x3_hl(const void* q_hl, int64_t ldq, const void* v_hl, i
                 ">= 2*h*dk bf16 and keep rows 16-byte aligned", (long long)ldq, (long long)ldv);
     SNF_REQUIRE(((reinterpret_cast<uintptr_t>(q_hl) | reinterpret_cast<uintptr_t>(v_hl) | reinterpret_cast<uintptr_t>(kp)) & 15) == 0,
                 "snf_sparse_attn_fwd_x3_hl: q / v / kp must be 16-byte aligned");
-    const size_t need = x3p_workspace(pl, h, dk);
+    const size_t need = lay.partial + lay.kpfrag + lay.stats;
     if (!workspace || workspace_bytes < need) {
         snf::set_error("snf_sparse_attn_fwd_x3_hl: workspace %zu < %zu", workspace_bytes, need);
         return SNF_EWORKSPACE;
     }
+    unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
     X3PParams P;
     P.q = reinterpret_cast<const unsigned short*>(q_hl), P.v = reinterpret_cast<const unsigned short*>(v_hl), P.kp = kp;
     P.n = n, P.ldq = ldq, P.ldv = ldv, P.ldkp = d;
     P.k = k, P.h = h, P.scale = scale;
     P.attn = attn, P.attn_ld = k, P.lse = lse;
-    P.stats = nullptr;
     P.trace = snf::g_attn_trace, P.trace_wg = snf::g_attn_trace_wg;
-    P.partial = reinterpret_cast<float*>(workspace);
-    P.kp_frag = reinterpret_cast<const u32x4*>(reinterpret_cast<unsigned char*>(workspace) + x3p_partial_bytes(pl, dk));
-    P.tiles_per_head = pl.tiles_per_head, P.tiles_per_wg = pl.tiles_per_wg, P.total_tiles = pl.total_tiles;
-    P.seg_count = pl.seg_count;
-    return x3p_dispatch<128>(P, pl, out, snf::as_stream(stream));
+    P.partial = reinterpret_cast<float*>(ws);
+    P.kp_frag = reinterpret_cast<const u32x4*>(ws + lay.partial);
+    P.stats = reinterpret_cast<f32x2*>(ws + lay.partial + lay.kpfrag);
+    P.nchunks = ch.count, P.chunk = 0;
+    hipStream_t s = snf::as_stream(stream);
+    // pass 0: everything in one launch (one chunk).  Otherwise pass 1: statistics of every chunk, pass 2: the chunks' main passes
+    for (int pass = ch.count == 1 ? 0 : 1; pass <= (ch.count == 1 ? 0 : 2); ++pass)
+        for (int c = 0; c < ch.count; ++c) {
+            const int k0 = c * ch.size, kc = k - k0 < ch.size ? k - k0 : ch.size;
+            X3PPlan pl;
+            if (!x3p_plan(n, kc, h, dk, &pl)) {
+                snf::set_error("snf_sparse_attn_fwd_x3_hl: chunk of %d keys outside the kernel", kc);
+                return SNF_EUNSUPPORTED;
+            }
+            X3PParams C = P;
+            C.kp = kp + (int64_t)k0 * d;
+            C.k = kc, C.chunk = c;
+            C.attn = (pass != 1 && attn) ? attn + k0 : nullptr;
+            C.lse = (pass != 1 && c == 0) ? lse : nullptr;
+            C.tiles_per_head = pl.tiles_per_head, C.tiles_per_wg = pl.tiles_per_wg, C.total_tiles = pl.total_tiles;
+            C.seg_count = pl.seg_count;
+            int rc = x3p_dispatch<128>(C, pl, out + (int64_t)k0 * d, s, pass);
+            if (rc) return rc;
+        }
+    return SNF_OK;
 }
 
 }  // extern "C"

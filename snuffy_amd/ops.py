@@ -642,7 +642,7 @@ def sparse_attn_fwd_x3(q, v, kp, h, scale=None, need_attn=False, need_lse=False)
 
 def x3_hl_attn_supported(k, dk):
     """Shapes of the pipelined fp32-class attention kernel on pre-split operands (snf_sparse_attn_fwd_x3_hl)."""
-    return dk == 128 and 97 <= k <= 256
+    return dk == 128 and 97 <= k <= 2048
 
 
 def sparse_attn_fwd_x3_hl(q_hl, v_hl, kp, h, scale=None, need_attn=False, need_lse=False):

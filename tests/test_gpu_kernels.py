@@ -423,7 +423,9 @@ def test_sparse_attn_x3_config_b_walks_heads_and_spike():
 
 
 @pytest.mark.parametrize("n,k,h", [(1000, 200, 6), (4097, 224, 3), (33, 128, 2), (1, 97, 1), (5000, 100, 2), (2000, 256, 2), (777, 129, 2),
-                                   (300, 160, 1), (6401, 200, 6)])
+                                   (300, 160, 1), (6401, 200, 6),
+                                   # more than 256 keys: key chunks with exact cross-chunk statistics
+                                   (3000, 512, 6), (700, 257, 2), (1500, 601, 3), (257, 1790, 1), (100, 2048, 2)])
 def test_sparse_attn_x3_hl_fp32_class(n, k, h):
     """snf_sparse_attn_fwd_x3_hl (the pipelined split-bf16 x 3 kernel on PRE-SPLIT hl operands) against the fp64 oracle on the
     unrounded operands: same arithmetic class as snf_sparse_attn_fwd_x3 (the hl image carries exactly the hi / lo halves that
@@ -438,7 +440,7 @@ def test_sparse_attn_x3_hl_fp32_class(n, k, h):
     o, attn, lse = ops().sparse_attn_fwd_x3_hl(qi, vi, kp.to(DEV), h, need_attn=True, need_lse=True)
     o_ref, p_ref = attn_ref(q, kp, v, h)
     assert (attn.cpu().double() - p_ref).abs().max() < 6e-6
-    assert rel_err(o.cpu(), o_ref) < 2e-5
+    assert rel_err(o.cpu(), o_ref) < (2e-5 if k <= 256 else 4e-5)      # few rows under many keys: O is a short sum of small P
     s_ref = (q.double().view(n, h, dk).transpose(0, 1) @ kp.double().view(k, h, dk).transpose(0, 1).transpose(1, 2)) / dk ** 0.5
     assert (lse.cpu().double() - torch.logsumexp(s_ref, dim=-1)).abs().max() < 3e-5
     assert (attn.sum(-1) - 1).abs().max() < 1e-5
@@ -474,7 +476,7 @@ def test_sparse_attn_x3_hl_config_b_spike_and_domain():
     with pytest.raises(SnuffyHipError):
         ops().sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], torch.zeros(96, d, device=DEV), h)    # fewer than 4 key blocks
     with pytest.raises(SnuffyHipError):
-        ops().sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], torch.zeros(257, d, device=DEV), h)   # more than 8
+        ops().sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], torch.zeros(2049, d, device=DEV), h)  # more than 8 chunks
     with pytest.raises(SnuffyHipError):
         ops().sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], torch.zeros(200, d, device=DEV), 12)  # dk = 64
 

@@ -82,4 +82,4 @@ if __name__ == "__main__":
         ok = check(*sh) and ok
     print("PARITY", "OK" if ok else "FAIL")
     if "--time" in sys.argv:
-        timeit(32768, 200, 6)
+        timeit(*(shapes[0] if args else (32768, 200, 6)))
