@@ -335,6 +335,8 @@ def main():
     ap.add_argument("--mode", default="eval", choices=["eval", "train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--preroll-s", dest="preroll_s", type=float, default=0.6,
+                    help="untimed pre-roll (seconds of the same steps) in front of every timed region, after the --warmup steps")
     ap.add_argument("--no-graph", dest="graph", action="store_false",
                     help="issue every kernel of the eval forward from Python instead of replaying HIP graphs "
                          "(MILNet.configure(graph_max_patches=...)).  Same kernels and bit-identical results either way; the "
@@ -465,6 +467,16 @@ def main():
         for i in range(warmup):
             step(i)
         torch.cuda.synchronize()
+        # untimed pre-roll by TIME on top of the W warm-up steps: a short timed region (the driver times 20 steps = 26 ms) would
+        # otherwise sit on the clock ramp of a GPU that was idle a moment ago (round 3: 758 slides/s over 20 steps against
+        # 777-818 over 2000).  Same steps, same bags, not timed; the timed region below is still EXACTLY `steps` steps.
+        t_pre = time.perf_counter()
+        j = 0
+        while time.perf_counter() - t_pre < args.preroll_s:
+            for _ in range(8):
+                step(warmup + j)
+                j += 1
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -513,7 +525,8 @@ def main():
                 SF.FP32_GEMM = keep
             extra["f32_library_gemm"] = dict(elapsed=e4, steps=steps_l, launch=l4)
     train_leg = None
-    if args.mode == "eval" and dist is not None:      # world > 1 (or the forced one-rank RCCL path of the tests)
+    if args.mode == "eval" and (dist is not None or not args.headline_only):   # at N = 1 too: one short leg, so that the
+        # driver's single-GPU record also carries a training number (no collective at world 1: the stepper is the trainer)
         # the eval forward has no collective in its data path (bags are independent): an N-rank eval line says nothing about
         # the one exchange the north star names, the flat-gradient all-reduce.  The same ranks therefore also time training
         # steps (fwd + bwd + AdamW + ONE RCCL all-reduce of the flat fp32 gradient per step), reported as value_train.

@@ -435,6 +435,14 @@ int snf_ln_mean_head_varlen_f32(const float* z, const int64_t* offsets, int bags
                                 int c_out, float* logits, float* pooled, const int32_t* table_dev, void* workspace,
                                 size_t workspace_bytes, snf_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Debug hooks (development tools only: tools/attn_trace.py, tools/x3p_trace.py; nothing in the product path calls them).
+ * snf_debug_attn_trace(buf): device buffer of u64 that dev builds of the attention kernels (X3P_TRACE / SNF_ATTN_TRACE defines)
+ * fill with s_memtime stamps of workgroup snf_debug_attn_trace_wg(wg); null switches the stamps off.  Shipped builds carry no
+ * stamp code: the calls only set two host-side variables. */
+void snf_debug_attn_trace(void* buf);
+void snf_debug_attn_trace_wg(int wg);
+
 #ifdef __cplusplus
 }
 #endif

@@ -368,12 +368,25 @@ def _hl_weights(layer, fw):
     return fw["hl"]
 
 
+_PARAM_CACHES = ("_snf_x3", "_snf_x3t", "_snf_img_hl", "_snf_img_cat")
+
+
+def drop_param_caches(module):
+    """Forget the split images cached ON the parameters of `module` (split3_cached here, vit._image_of): they are keyed on
+    (data_ptr, _version), and an edit through `p.data` changes neither -- invalidate() is the documented way to say so."""
+    for prm in module.parameters():
+        for name in _PARAM_CACHES:
+            if hasattr(prm, name):
+                delattr(prm, name)
+
+
 def invalidate_folded(layer):
     """Drop the layer's folded bf16 weights and any pending critic hand-over (after editing parameters through .data)."""
     layer._fold = None
     layer._fold3 = None
     layer._xhat_offer = None
     layer._xn3_offer = None
+    drop_param_caches(layer)
 
 
 def _rows_linear(x, lin):
@@ -384,7 +397,8 @@ def _rows_linear(x, lin):
     n = lin.weight.shape[0]
     if FP32_GEMM == "x3" and not _needs_grad(x, lin.weight, lin.bias) and x.dtype == torch.float32 and lin.weight.dtype == torch.float32:
         if m >= 2048 and ops.gemm_x3_supported(m, n, k):
-            return ops.gemm_x3(ops.split3_rows(x), split3_cached(lin.weight), lin.bias.detach(), out_dtype=torch.float32)
+            return ops.gemm_x3(ops.split3_rows(x), split3_cached(lin.weight), None if lin.bias is None else lin.bias.detach(),
+                               out_dtype=torch.float32)
         if m < 2048 and ops.linear_rows_x3_supported(m, n, k):
             # the K rows of one bag: skinny kernel, operands split in registers (the fp32 library GEMM took ~10 us per projection)
             return ops.linear_rows_x3(x, lin.weight.detach(), None if lin.bias is None else lin.bias.detach())

@@ -310,6 +310,7 @@ class MILNet(nn.Module):
             self._graph_sig = None
         for layer in self.b_classifier.encoder.layers:
             SF.invalidate_folded(layer)
+        SF.drop_param_caches(self)        # split images cached on the parameters themselves (fp32-class training / key projections)
         return self
 
     _GRAPH_STATE = ("_graphs", "_graph_seen", "_graph_pool", "_graph_sig", "_packed_bags")

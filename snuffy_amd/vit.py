@@ -307,6 +307,13 @@ class VisionTransformer(nn.Module):
         self.precision = precision
         return self
 
+    def invalidate(self):
+        """Forget everything derived from the current weights (the split images cached on the parameters): call it after editing
+        parameters through `.data` -- an edit that changes neither data_ptr nor _version, the keys of those caches."""
+        from . import functional as SF
+        SF.drop_param_caches(self)
+        return self
+
     # -- reference helper API ---------------------------------------------------------------------------------------
     def interpolate_pos_encoding(self, x, w, h):
         """Positional table for a w x h pixel input (reference ...dino_version.py:196-216): the stored table at the training

@@ -326,3 +326,28 @@ def test_module_stays_picklable_and_copyable_after_forwards():
             for precision in ("fp32", "bf16"):
                 m.configure(precision=precision, return_attention=False)
                 assert torch.equal(m(x)[1], outs[precision]), precision
+
+
+def test_invalidate_after_data_edit_drops_split_weight_caches():
+    """the split-weight images cached on the parameters (_snf_x3 / _snf_x3t, keyed on data_ptr and _version) survive an
+    edit through `.data`; MILNet.invalidate() is the documented remedy and must drop them: the forward after edit + invalidate
+    equals the forward of a freshly built net with the edited weights."""
+    from snuffy_amd import functional as SF
+    D, h, N = 384, 6, 3000
+    net = synth_state(D, h, 1).to(DEV).eval().configure(precision="fp32")
+    x = torch.randn(1, N, D, generator=torch.Generator().manual_seed(3)).to(DEV)
+    with torch.no_grad():
+        net(x)                                             # populates every cache derived from the weights
+        lk = net.b_classifier.encoder.layers[0].self_attn.linears[1]
+        SF.split3_cached(lk.weight)                        # the training-path cache on the parameter itself
+        assert hasattr(lk.weight, "_snf_x3")
+        for p_ in net.parameters():
+            if p_.dim() > 1:
+                p_.data.mul_(1.25)                         # an EMA-style edit: same storage, same version counter
+        net.invalidate()
+        assert not hasattr(lk.weight, "_snf_x3")
+        _, logits, _ = net(x)
+        fresh = synth_state(D, h, 1).to(DEV).eval().configure(precision="fp32")
+        fresh.load_state_dict(net.state_dict())
+        _, logits_ref, _ = fresh(x)
+    assert torch.allclose(logits, logits_ref, atol=1e-6), (logits, logits_ref)
