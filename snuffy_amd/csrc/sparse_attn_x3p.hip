@@ -68,6 +68,12 @@ struct X3PParams {
     f32x2* stats;              // key-chunked launches: [nchunks][h][n] (row max in scaled log2 units, row sum) per chunk.  MODE 1 writes
                                // chunk `chunk`'s pair per row, MODE 2 reads all chunks' pairs (softmax exact over all keys)
     int nchunks, chunk;
+    // merged key-chunk launches (K > 256, every chunk the same number of key blocks): ONE grid holds the workgroups of all `merged`
+    // chunks, co-resident; workgroup b serves chunk (b / 8) % merged of row range (b / (8 merged)) * 8 + b % 8, so that the workgroups
+    // that stream the same Q / V rows sit on the same XCD (b % 8), start together and share those rows through its L2.  k is then
+    // the TOTAL key count, kp_frag / partial / attn the first chunk's; chunk c starts at key c * chunk_size.
+    int merged, chunk_size;
+    int64_t kpfrag_stride, partial_stride;   // per chunk, in u32x4 / float units
     float* partial;            // [num_wg * seg_count][NKB * dk / 32 tiles][4][64][4]
     int tiles_per_head, tiles_per_wg, total_tiles, seg_count;
     unsigned long long* trace;   // dev builds (X3P_TRACE): s_memtime stamps of workgroup trace_wg, [wave][64 iterations][8]
@@ -198,7 +204,24 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, hf = lane >> 5;
     const int n32 = (int)P.n;
-    const int bid = blockIdx.x;
+    int bid = blockIdx.x;
+    // key chunk of this workgroup (wave-uniform, from the block index only)
+    int chunk = P.chunk, kk = P.k;
+    const u32x4* kp_frag = P.kp_frag;
+    float* partial = P.partial;
+    float* attn_base = P.attn;
+    if constexpr (MODE != 0) {
+        if (P.merged > 1) {
+            const int slot = bid >> 3;
+            chunk = slot % P.merged;
+            bid = (slot / P.merged) * 8 + (bid & 7);
+            const int k0 = chunk * P.chunk_size;
+            kk = P.k - k0 < P.chunk_size ? P.k - k0 : P.chunk_size;
+            kp_frag += chunk * P.kpfrag_stride;
+            partial += chunk * P.partial_stride;
+            if (attn_base) attn_base += k0;
+        }
+    }
 
     const int f_begin = bid * P.tiles_per_wg;
     int f_end = f_begin + P.tiles_per_wg;
@@ -337,7 +360,7 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
     // P image writer: row j, 8-byte chunk (2 c4 + hf) of the 64-byte row at position ^ ((j >> 1) & 7) -> waddr0 ^ (16 c4)
     const int waddr0 = p_wave + j * 64 + 8 * (hf ^ ((j >> 1) & 7));
     const int st_lane = ST_OFF + 8 * j;                                  // statistics [2][NW][TR] of (max, sum)
-    const bool attn_vec = AUX && (P.attn_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(P.attn) & 15) == 0;
+    const bool attn_vec = AUX && (P.attn_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(attn_base) & 15) == 0;
 
     // fragment reads
     auto q_frag = [&](int qa, int kb, int lo) __attribute__((always_inline)) -> bf16x8 {
@@ -356,14 +379,14 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
     // LASTW: this wave owns the last key block (its padded keys are masked)
     auto run = [&](auto lastw_t) __attribute__((always_inline)) {
         constexpr bool LASTW = decltype(lastw_t)::value;
-        const int klast = P.k - 32 * (NKB - 1);                          // valid keys of the last key block
+        const int klast = kk - 32 * (NKB - 1);                          // valid keys of the last key block
 
         // ---- Kp fragments of the wave's key block: MFMA A operands, hi and lo, for the whole head -- 16-byte loads out of the
         // fragment-ordered image x3p_prep_kp_kernel made of Kp (scaled and split there: nothing but the loads happens here, so a
         // head change inside a workgroup's range costs one L2 round trip)
         bf16x8 kph[NKS], kpl[NKS];
         auto load_kp = [&](int a_) __attribute__((always_inline)) {
-            const u32x4* src = P.kp_frag + ((int64_t)(a_ * NKB + w) * NKS * 2) * 64 + lane;
+            const u32x4* src = kp_frag + ((int64_t)(a_ * NKB + w) * NKS * 2) * 64 + lane;
 #pragma unroll
             for (int kb = 0; kb < NKS; ++kb) {
                 kph[kb] = __builtin_bit_cast(bf16x8, src[(2 * kb) * 64]);
@@ -386,13 +409,13 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
         zero_acc();
         auto flush = [&](int head) __attribute__((always_inline)) {
             const int seg = head - first_head;
-            float* dst = P.partial + ((int64_t)bid * P.seg_count + seg) * (int64_t)(NKB * NCB) * 1024;
+            float* dst = partial + ((int64_t)bid * P.seg_count + seg) * (int64_t)(NKB * NCB) * 1024;
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const int t_idx = w * NCB + cb;
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4)
-                    if (32 * w + 8 * q4 < P.k) {
+                    if (32 * w + 8 * q4 < kk) {
                         const f32x4 v4 = {acc_o[cb][q4 * 4], acc_o[cb][q4 * 4 + 1], acc_o[cb][q4 * 4 + 2], acc_o[cb][q4 * 4 + 3]};
                         *reinterpret_cast<f32x4*>(dst + ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4) = v4;
                     }
@@ -484,12 +507,12 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
             } else if constexpr (u == U_FS) {
                 const bool rvalid = j < rows_ok;
                 if constexpr (MODE == 1) {   // this chunk's pair of the row; nothing else happens to tile i in a statistics pass
-                    if (rvalid && hf == 0 && w == 0) P.stats[((int64_t)P.chunk * P.h + cno.a) * P.n + cno.t * TR + j] = f32x2{s.m, s.l};
+                    if (rvalid && hf == 0 && w == 0) P.stats[((int64_t)chunk * P.h + cno.a) * P.n + cno.t * TR + j] = f32x2{s.m, s.l};
                     s.fscale = 0.f;
                     return;
                 }
                 if constexpr (AUX)
-                    if (P.lse && rvalid && hf == 0 && w == 0)
+                    if (P.lse && chunk == 0 && rvalid && hf == 0 && w == 0)
                         P.lse[(int64_t)cno.a * P.n + cno.t * TR + j] = (s.m + __log2f(s.l)) * 0.69314718055994530942f;
                 float fs = __builtin_amdgcn_exp2f(mw - s.m) * __builtin_amdgcn_rcpf(s.l);
                 asm volatile("" : "+v"(fs));              // keep the select below a select (no branch around the exp / rcp)
@@ -504,15 +527,15 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
                     // of the split below (fma) in the variants that do not store A, and their O differs in the last bits
                     asm volatile("" : "+v"(s.p4));
                     if constexpr (AUX) {
-                        if (P.attn && j < rows_ok) {
+                        if (attn_base && j < rows_ok) {
                             const int key0 = 32 * w + 8 * c4 + 4 * hf;
-                            float* arow = P.attn + ((int64_t)cno.a * P.n + cno.t * TR + j) * P.attn_ld + key0;
-                            if (attn_vec && key0 + 4 <= P.k) {
+                            float* arow = attn_base + ((int64_t)cno.a * P.n + cno.t * TR + j) * P.attn_ld + key0;
+                            if (attn_vec && key0 + 4 <= kk) {
                                 *reinterpret_cast<f32x4*>(arow) = s.p4;
                             } else {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
-                                    if (key0 + e < P.k) arow[e] = s.p4[e];
+                                    if (key0 + e < kk) arow[e] = s.p4[e];
                             }
                         }
                     }
@@ -732,9 +755,14 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
 // One wave per (head, key block).
 template <int DK>
 __global__ __launch_bounds__(64) void x3p_prep_kp_kernel(const float* __restrict__ kp, int64_t ldkp, int k, int nkb, float c_exp,
-                                                          u32x4* __restrict__ out) {
+                                                          u32x4* __restrict__ out, int chunk_size, int64_t out_stride) {
     constexpr int NKS = DK / 16;
     const int a = blockIdx.y, b = blockIdx.x, lane = threadIdx.x;
+    {   // key chunk blockIdx.z (merged launches; one chunk otherwise: chunk_size = k)
+        const int k0 = blockIdx.z * chunk_size;
+        kp += (int64_t)k0 * ldkp, out += blockIdx.z * out_stride;
+        k = k - k0 < chunk_size ? k - k0 : chunk_size;
+    }
     int key = 32 * b + (lane & 31);
     const bool pad = key >= k;
     if (pad) key = k - 1;
@@ -756,10 +784,16 @@ __global__ __launch_bounds__(64) void x3p_prep_kp_kernel(const float* __restrict
 // out[key, a*DK + col] = sum over the (workgroup, segment) partials of head a, ascending workgroup order (fixed: bit-reproducible)
 template <int DK>
 __global__ __launch_bounds__(64) void x3p_reduce_kernel(const float* __restrict__ partial, int nkb, int num_wg, int seg_count,
-                                                         int tiles_per_head, int tiles_per_wg, int k, int h, float* __restrict__ out) {
+                                                         int tiles_per_head, int tiles_per_wg, int k, int h, float* __restrict__ out,
+                                                         int chunk_size, int64_t partial_stride) {
     constexpr int NCB = DK / 32;
     const int tiles = nkb * NCB;
     const int a = blockIdx.y;
+    {   // key chunk blockIdx.z (merged launches; one chunk otherwise: chunk_size = k)
+        const int k0 = blockIdx.z * chunk_size;
+        partial += blockIdx.z * partial_stride, out += (int64_t)k0 * (h * DK);
+        k = k - k0 < chunk_size ? k - k0 : chunk_size;
+    }
     const int unit = blockIdx.x;   // (tile, q4): one wave per workgroup, so that the units spread over all CUs
     const int lane = threadIdx.x;
     const int t_idx = unit >> 2, q4 = unit & 3;
@@ -795,11 +829,11 @@ __global__ __launch_bounds__(64) void x3p_reduce_kernel(const float* __restrict_
 struct X3PPlan {
     int num_wg, tiles_per_head, tiles_per_wg, total_tiles, seg_count, nkb;
 };
-bool x3p_plan(int64_t n, int k, int h, int dk, X3PPlan* pl) {
+bool x3p_plan(int64_t n, int k, int h, int dk, X3PPlan* pl, int max_wg = 0) {
     if (dk != 128 || k < 97 || k > 256 || n < 1 || h < 1) return false;   // 4 .. 8 key blocks (fewer: too few waves per CU, and too many DMA instructions per wave)
     const int64_t tph = (n + TR - 1) / TR, total = tph * h;
     if (total > 0x7fffffff) return false;
-    const int cus = snf::cu_count();
+    const int cus = max_wg > 0 ? max_wg : snf::cu_count();
     int64_t num_wg = total < cus ? total : cus;
     const int64_t tpw = (total + num_wg - 1) / num_wg;
     num_wg = (total + tpw - 1) / tpw;
@@ -824,15 +858,21 @@ int x3p_launch(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s)
         (void)hipGetLastError();
         return SNF_ELAUNCH;
     }
-    hipLaunchKernelGGL((x3p_prep_kp_kernel<DK>), dim3(NKB, P.h), dim3(64), 0, s, P.kp, P.ldkp, P.k, NKB, P.scale * 1.44269504088896340736f,
-                       const_cast<u32x4*>(P.kp_frag));
-    int rc0 = snf::check_launch("x3p_prep_kp_kernel");
-    if (rc0) return rc0;
-    hipLaunchKernelGGL(kern, dim3(pl.num_wg), dim3(64 * NKB), lds, s, P);
+    const int nch = P.merged > 1 ? P.merged : 1;
+    const int csize = P.merged > 1 ? P.chunk_size : P.k;
+    if (MODE != 2 || P.merged <= 1) {   // (the merged statistics launch has already made the fragments of every chunk)
+        hipLaunchKernelGGL((x3p_prep_kp_kernel<DK>), dim3(NKB, P.h, nch), dim3(64), 0, s, P.kp, P.ldkp, P.k, NKB,
+                           P.scale * 1.44269504088896340736f, const_cast<u32x4*>(P.kp_frag), csize, P.kpfrag_stride);
+        int rc0 = snf::check_launch("x3p_prep_kp_kernel");
+        if (rc0) return rc0;
+    }
+    // merged: 8 XCDs x (row ranges per XCD) x chunks, the chunk index innermost within an XCD's slots
+    const int grid = P.merged > 1 ? 8 * ((pl.num_wg + 7) / 8) * nch : pl.num_wg;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NKB), lds, s, P);
     int rc = snf::check_launch("sparse_attn_x3p_kernel");
     if (rc || MODE == 1) return rc;
-    hipLaunchKernelGGL((x3p_reduce_kernel<DK>), dim3(NKB * (DK / 32) * 4, P.h), dim3(64), 0, s, P.partial, NKB, pl.num_wg, pl.seg_count,
-                       pl.tiles_per_head, pl.tiles_per_wg, P.k, P.h, out);
+    hipLaunchKernelGGL((x3p_reduce_kernel<DK>), dim3(NKB * (DK / 32) * 4, P.h, nch), dim3(64), 0, s, P.partial, NKB, pl.num_wg, pl.seg_count,
+                       pl.tiles_per_head, pl.tiles_per_wg, P.k, P.h, out, csize, P.partial_stride);
     return snf::check_launch("x3p_reduce_kernel");
 }
 template <int DK, int NB>
@@ -876,12 +916,25 @@ bool x3p_chunks(int k, int dk, X3PChunks* c) {
 }
 struct X3PLayout {   // workspace: partial accumulators | Kp fragment image | statistics
     size_t partial, kpfrag, stats;
+    bool merged;       // all chunks in one statistics launch and one main launch (partial / kpfrag then hold every chunk's region)
+    X3PPlan plan;      // of the first chunk (merged: of every chunk)
 };
+// Merged launches need every chunk's workgroups co-resident (one per CU: the kernel's LDS) and the same block size for all chunks.
+int x3p_merged_ranges(const X3PChunks& ch, int k) {
+    if (ch.count < 2) return 0;
+    const int last = k - (ch.count - 1) * ch.size;
+    if ((last + 31) / 32 != (ch.size + 31) / 32) return 0;
+    const int per_xcd = snf::cu_count() / 8 / ch.count;
+    return per_xcd >= 1 ? 8 * per_xcd : 0;
+}
 bool x3p_layout(int64_t n, int k, int h, int dk, X3PChunks* ch, X3PLayout* lay) {
-    X3PPlan pl;
-    if (h < 1 || !x3p_chunks(k, dk, ch) || !x3p_plan(n, ch->size, h, dk, &pl)) return false;
-    lay->partial = x3p_partial_bytes(pl, dk);        // the first chunks are the largest
-    lay->kpfrag = x3p_kpfrag_bytes(pl, h, dk);
+    if (h < 1 || !x3p_chunks(k, dk, ch)) return false;
+    const int ranges = x3p_merged_ranges(*ch, k);
+    lay->merged = ranges > 0;
+    if (!x3p_plan(n, ch->size, h, dk, &lay->plan, ranges)) return false;
+    const size_t copies = lay->merged ? ch->count : 1;
+    lay->partial = copies * x3p_partial_bytes(lay->plan, dk);        // the first chunks are the largest
+    lay->kpfrag = copies * x3p_kpfrag_bytes(lay->plan, h, dk);
     lay->stats = ch->count > 1 ? (size_t)ch->count * h * n * sizeof(f32x2) : 0;
     return true;
 }
@@ -928,7 +981,21 @@ int snf_sparse_attn_fwd_x3_hl(const void* q_hl, int64_t ldq, const void* v_hl, i
     P.kp_frag = reinterpret_cast<const u32x4*>(ws + lay.partial);
     P.stats = reinterpret_cast<f32x2*>(ws + lay.partial + lay.kpfrag);
     P.nchunks = ch.count, P.chunk = 0;
+    P.merged = 0, P.chunk_size = k, P.kpfrag_stride = 0, P.partial_stride = 0;
     hipStream_t s = snf::as_stream(stream);
+    if (lay.merged) {   // statistics of all chunks in one launch, then all main passes in one launch (+ one prep, one reduction)
+        const X3PPlan& pl = lay.plan;
+        P.merged = ch.count, P.chunk_size = ch.size;
+        P.kpfrag_stride = (int64_t)(lay.kpfrag / ch.count / sizeof(u32x4));
+        P.partial_stride = (int64_t)(lay.partial / ch.count / sizeof(float));
+        P.tiles_per_head = pl.tiles_per_head, P.tiles_per_wg = pl.tiles_per_wg, P.total_tiles = pl.total_tiles;
+        P.seg_count = pl.seg_count;
+        X3PParams S1 = P;
+        S1.attn = nullptr, S1.lse = nullptr;
+        int rc = x3p_dispatch<128>(S1, pl, out, s, 1);
+        if (rc) return rc;
+        return x3p_dispatch<128>(P, pl, out, s, 2);
+    }
     // pass 0: everything in one launch (one chunk).  Otherwise pass 1: statistics of every chunk, pass 2: the chunks' main passes
     for (int pass = ch.count == 1 ? 0 : 1; pass <= (ch.count == 1 ? 0 : 2); ++pass)
         for (int c = 0; c < ch.count; ++c) {
