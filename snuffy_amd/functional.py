@@ -32,6 +32,10 @@ X3_HL_ATTENTION = True
 # fp32 path, the [N, .] projections: "x3" = split-bf16 products on the hand-written MFMA GEMM (fp32-class: logits within
 # ~1e-5 of the exact path), "library" = fp32 library GEMMs.
 FP32_GEMM = "x3"
+# fp32 path on the one-pass hl GEMMs: ONE normalised image xhat = (x - mean) rstd serves both sublayers (the LayerNorm affines are
+# folded into Wq | Wv and W1, in fp64, rounded once; after the attention only the K patched rows are re-normalised into the image)
+# instead of a second full LayerNorm pass over the bag -- what the bf16 path has always done.  Needs equal eps in both LayerNorms.
+FP32_SHARED_NORM = True
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -133,18 +137,44 @@ def critic_scores_with_hl(feats, w, b, layer):
             or not hl_layer_eligible(layer, f2.shape[0], f2.shape[1])):
         layer._xn3_offer = None
         return critic_scores(feats, w, b)
-    s, img = ops.critic_ln_hl(f2, w, b, n0.weight, n0.bias, n0.eps)
-    layer._xn3_offer = (f2.data_ptr(), tuple(f2.shape), f2._version, float(n0.eps), n0.weight.data_ptr(), n0.weight._version,
-                        n0.bias.data_ptr(), n0.bias._version, img)
+    if shared_norm_layer(layer):
+        one, zero = _unit_affine(f2.device, f2.shape[1])
+        s, img = ops.critic_ln_hl(f2, w, b, one, zero, n0.eps)          # xhat itself: the affine lives in the folded weights
+    else:
+        s, img = ops.critic_ln_hl(f2, w, b, n0.weight, n0.bias, n0.eps)
+    layer._xn3_offer = (_xn3_key(f2, n0, shared_norm_layer(layer)), img)
     return s.view(*lead, w.shape[0])
 
 
-def _take_xn3(layer, x2, n0):
+_UNIT_AFFINE = {}
+
+
+def _unit_affine(device, d):
+    ent = _UNIT_AFFINE.get((str(device), d))
+    if ent is None:
+        ent = _UNIT_AFFINE[(str(device), d)] = (torch.ones(d, device=device), torch.zeros(d, device=device))
+    return ent
+
+
+def shared_norm_layer(layer):
+    """encoder_layer()'s fp32 hl branch keeps ONE normalised image for both sublayers of this layer (FP32_SHARED_NORM)."""
+    n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
+    return (FP32_SHARED_NORM and n0.eps == n1.eps and n0.weight is not None and n0.bias is not None and n1.weight is not None
+            and n1.bias is not None)
+
+
+def _xn3_key(x2, n0, shared):
+    if shared:
+        return (x2.data_ptr(), tuple(x2.shape), x2._version, float(n0.eps), "xhat")
+    return (x2.data_ptr(), tuple(x2.shape), x2._version, float(n0.eps), n0.weight.data_ptr(), n0.weight._version,
+            n0.bias.data_ptr(), n0.bias._version)
+
+
+def _take_xn3(layer, x2, n0, shared=False):
     offer = getattr(layer, "_xn3_offer", None)
     layer._xn3_offer = None
-    if offer is not None and offer[:8] == (x2.data_ptr(), tuple(x2.shape), x2._version, float(n0.eps), n0.weight.data_ptr(),
-                                           n0.weight._version, n0.bias.data_ptr(), n0.bias._version):
-        return offer[8]
+    if offer is not None and offer[0] == _xn3_key(x2, n0, shared):
+        return offer[1]
     return None
 
 
@@ -368,6 +398,28 @@ def _hl_weights(layer, fw):
     return fw["hl"]
 
 
+def _hl_weights_folded(layer):
+    """hl images of Wq | Wv and W1 with the LayerNorm affines folded in (FP32_SHARED_NORM):  LN(x) W^T + b = xhat (W * gamma)^T +
+    (W beta + b).  The fold is done in fp64 and rounded once to fp32 before the hi / lo split; cached like _split_weights."""
+    n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
+    lq, lk, lv, lo = layer.self_attn.linears
+    ff = layer.feed_forward
+    plist = [n0.weight, n0.bias, n1.weight, n1.bias, lq.weight, lq.bias, lv.weight, lv.bias, ff.w_1.weight, ff.w_1.bias]
+    key = tuple((id(p), p.data_ptr(), p._version) for p in plist)
+    ent = getattr(layer, "_fold3f", None)
+    if ent is not None and ent[0] == key:
+        return ent[1]
+    with torch.no_grad():
+        g0, b0, g1, b1 = (t.double() for t in (n0.weight, n0.bias, n1.weight, n1.bias))
+        wqv = torch.cat([lq.weight, lv.weight]).double()
+        bqv = torch.cat([lq.bias, lv.bias]).double()
+        w1, bb1 = ff.w_1.weight.double(), ff.w_1.bias.double()
+        out = dict(wqv=ops.split_hl_weight((wqv * g0).float().contiguous()), bqv=(wqv @ b0 + bqv).float().contiguous(),
+                   w1=ops.split_hl_weight((w1 * g1).float().contiguous()), b1=(w1 @ b1 + bb1).float().contiguous())
+    layer._fold3f = (key, out)
+    return out
+
+
 _PARAM_CACHES = ("_snf_x3", "_snf_x3t", "_snf_img_hl", "_snf_img_cat")
 
 
@@ -384,6 +436,7 @@ def invalidate_folded(layer):
     """Drop the layer's folded bf16 weights and any pending critic hand-over (after editing parameters through .data)."""
     layer._fold = None
     layer._fold3 = None
+    layer._fold3f = None
     layer._xhat_offer = None
     layer._xn3_offer = None
     drop_param_caches(layer)
@@ -452,19 +505,25 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
         fh = _hl_weights(layer, fw) if hl else None
         xs, slot = ops.gather_slot_map(x2, sel)                                     # snuffy.py:131,145-147 (+ row -> slot map)
         kp = _rows_linear(xs, lk)                                       # keys = RAW selected rows (K rows: fp32)
-        xn3 = _take_xn3(layer, x2, n0)                                              # left by the critic pass, if any
+        shared = hl and shared_norm_layer(layer)
+        fhf = _hl_weights_folded(layer) if shared else None
+        xn3 = _take_xn3(layer, x2, n0, shared)                                      # left by the critic pass, if any
         # pre-split operands for the pipelined attention kernel: the projection's epilogue writes [Q | V] as its hl image (the same
         # hi / lo values the attention kernel would derive from the fp32 tensor, the same 4 bytes per element)
         hl_attn = (hl and ragged is None and packed is None and FP32_ATTENTION == "x3" and X3_HL_ATTENTION
                    and ops.x3_hl_attn_supported(k, d // h))
         if hl:
             if xn3 is None:
-                xn3 = ops.layernorm_rows_hl(x2, n0.weight, n0.bias, n0.eps)         # snuffy.py:107
-            qv = ops.gemm_hl(xn3, fh["wqv"], fw["bqv"], hl_out=hl_attn)             # [N, 2D] f32 = [Q | V] (or its [N, 4D] image)
+                xn3 = ops.layernorm_rows_hl(x2, None if shared else n0.weight, None if shared else n0.bias, n0.eps)   # snuffy.py:107
+            if shared:
+                qv = ops.gemm_hl(xn3, fhf["wqv"], fhf["bqv"], hl_out=hl_attn)
+            else:
+                qv = ops.gemm_hl(xn3, fh["wqv"], fw["bqv"], hl_out=hl_attn)         # [N, 2D] f32 = [Q | V] (or its [N, 4D] image)
         else:
             xn3 = ops.layernorm_rows_split3(x2, n0.weight, n0.bias, n0.eps)
             qv = ops.gemm_x3(xn3, fw["wqv"], fw["bqv"], out_dtype=torch.float32)
-        del xn3
+        if not shared:
+            del xn3
         q, v = (None, None) if hl_attn else (qv[:, :d], qv[:, d:])
         if hl_attn:
             o, attn, _ = ops.sparse_attn_fwd_x3_hl(qv[:, :2 * d], qv[:, 2 * d:], kp, h, need_attn=need_attn)   # snuffy.py:160-168
@@ -479,7 +538,13 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
         del q, v, qv
         delta = _rows_linear(o, lo)                                     # snuffy.py:205
         x_sel = xs + delta                                                          # snuffy.py:108
-        if hl:
+        if shared:
+            # y differs from x in the K selected rows only: re-normalise those into the image the first sublayer used
+            xn3.index_copy_(0, sel.long(), ops.layernorm_rows_hl(x_sel, None, None, n1.eps))
+            hid3 = ops.gemm_hl(xn3, fhf["w1"], fhf["b1"], ff.activation_name, hl_out=True)   # snuffy.py:224-225, [N, 2F] image
+            del xn3
+            z = ops.gemm_hl(hid3, fh["w2"], fw["b2"], resid=x2)                    # x + W2 hid + b2: the residual rides in the epilogue
+        elif hl:
             yn3 = ops.layernorm_rows_hl(x2, n1.weight, n1.bias, n1.eps, slot=slot, patch_rows=x_sel)   # LN(y), y never built
             hid3 = ops.gemm_hl(yn3, fh["w1"], fw["b1"], ff.activation_name, hl_out=True)   # snuffy.py:224-225, [N, 2F] image
             del yn3

@@ -220,6 +220,33 @@ def test_fp32_path_x3_projections_against_library_projections(monkeypatch):
     assert (a3 - a0).abs().max().item() <= 2e-5
 
 
+def test_fp32_path_shared_normalisation_against_two_layernorm_passes(monkeypatch):
+    """fp32 hl branch at config-B width: ONE normalised image + LayerNorm affines folded into Wq | Wv and W1 (FP32_SHARED_NORM) against
+    the two full LayerNorm passes with affine; non-trivial gamma / beta; depth 2 so that a layer without the critic hand-over runs too."""
+    from snuffy_amd import functional as SF
+    torch.manual_seed(1)
+    n, d = 20000, 768
+    from tests.helpers import build_amd_milnet
+    net = build_amd_milnet(d, 6, "relu", 200, 0.0, 2).to(DEV).eval()
+    with torch.no_grad():
+        for layer in net.b_classifier.encoder.layers:
+            for sub in layer.sublayer:
+                sub.norm.weight.uniform_(0.5, 1.5)
+                sub.norm.bias.uniform_(-0.3, 0.3)
+    net.invalidate()
+    net.configure(precision="fp32")
+    x = torch.randn(1, n, d, device=DEV) * 0.7
+    with torch.no_grad():
+        monkeypatch.setattr(SF, "FP32_SHARED_NORM", True)
+        c1, l1, a1 = net(x)
+        assert SF.shared_norm_layer(net.b_classifier.encoder.layers[0]) and SF.hl_layer_eligible(net.b_classifier.encoder.layers[0], n, d)
+        monkeypatch.setattr(SF, "FP32_SHARED_NORM", False)
+        c0, l0, a0 = net(x)
+    assert torch.equal(c1, c0)
+    assert (l1 - l0).abs().max().item() <= 1e-5 * max(1.0, l0.abs().max().item())
+    assert (a1 - a0).abs().max().item() <= 1e-5
+
+
 @pytest.mark.parametrize("r,c,k", [(200, 768, 768), (1, 384, 384), (37, 100, 128), (512, 1536, 64), (224, 768, 3072)])
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
 def test_linear_rows_x3_skinny_kernel_vs_fp64(r, c, k, out_dtype):
