@@ -337,6 +337,15 @@ int snf_gemm_hl_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ld
 /* fp32 output with a residual: C = act(A W^T + bias) + resid [m, ldr] -- z = x + W2 act(W1 LN(y)) of snuffy.py:110 in one pass */
 int snf_gemm_hl_resid_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ldw, const float* bias, const float* resid,
                            int64_t ldr, int64_t m, int n, int k, int act, void* c, int64_t ldc, int out_dtype, snf_stream_t stream);
+/* The same with split-K of the LAST, partly filled round of 256 x 256 tiles (e.g. the FFN output projection of config B: 384 tiles on
+ * 256 CUs): each tile of that round goes to 2..4 workgroups, a K range each; the last one to finish adds the others' fp32 partial tiles
+ * in a fixed order and runs the epilogue (bit-reproducible; any activation / output type / residual).  workspace: at least
+ * snf_gemm_hl_ws_bytes(m, n, k) bytes (0 = this shape does not split; workspace may then be NULL); its first 4096 bytes must be zero
+ * before the first call and are left zero by every call.  NULL workspace = snf_gemm_hl_resid_bf16. */
+size_t snf_gemm_hl_ws_bytes(int64_t m, int n, int k);
+int snf_gemm_hl_ws_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ldw, const float* bias, const float* resid,
+                        int64_t ldr, int64_t m, int n, int k, int act, void* c, int64_t ldc, int out_dtype, void* workspace,
+                        size_t workspace_bytes, snf_stream_t stream);
 int snf_split_hl_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16, snf_stream_t stream);
 int snf_layernorm_rows_hl_f32(const float* x, int64_t n, int d, const int32_t* slot_map, const float* patch_rows,
                               const float* gamma, const float* beta, float eps, void* out_bf16, snf_stream_t stream);

@@ -53,7 +53,16 @@ struct GemmParams {
     unsigned long long* trace;   // dev builds only (SNF_GEMM_TRACE), else null
     const float* resid = nullptr;   // gemm_hl_kernel, fp32 output: C += resid[m, ldr] (the residual stream of the FFN, snuffy.py:110)
     int64_t ldr = 0;
+    // gemm_hl_kernel, split-K of the LAST, partly filled round of tiles (snf_gemm_hl_ws_bf16): an XCD whose q tiles leave r = q % W of
+    // its W workgroups busy in the last round gives each of those tiles to S = min(W / r, split_cap) workgroups, a K range each.
+    // Every part but the last to finish parks its accumulators in a slab; the last arriver (ticket) adds them in part order and runs the
+    // epilogue.  ws: [8 * split_rcap] tickets (zero between launches), then [8 * split_rcap][split_cap] slabs of 256 KiB.
+    unsigned int* split_cnt = nullptr;
+    float* split_slab = nullptr;
+    int split_cap = 0, split_rcap = 0;
 };
+constexpr int HL_SPLIT_MIN_STEPS = 8;   // a K part is at least this many 32-column steps
+constexpr int HL_SPLIT_MAX = 4;
 
 constexpr int BM = 256, BKS = 32;
 // ring of step buffers and LDS-DMA distance in steps.  A deeper ring (5 buffers = all 160 KiB, 3 steps ahead) measured the
@@ -362,7 +371,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
 // ((row >> 3) & 3) << 1 for W: every ds_read_b128 lane group of 16 covers the 16 slots of a 256-byte bank row once).
 // Register budget: the A-lo fragments are read into the A-hi registers while the second product (hi lo) is still issuing.
 // OUT: 0 bf16, 1 fp32, 3 the hl image of the fp32 result (operand of the next one-pass GEMM).
-template <int ACT, int OUT>
+// SPLIT (second launch of snf_gemm_hl_ws_bf16): the tiles of the last, partly filled round, one K part per workgroup (see GemmParams).
+template <int ACT, int OUT, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
     constexpr int NI = 4, BN = 256;
     constexpr int ROWL = 128;                    // LDS row: hi(32) | lo(32) bf16
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wid >> 2, wc = wid & 3;
-    const int ns = P.k / BKS;                    // steps per tile (true K)
+    const int ns_all = P.k / BKS;                // steps per tile (true K)
 
     const int ntiles = P.tiles_m * P.tiles_n;
     const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
@@ -384,17 +394,51 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
         t_lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
         t_hi = t_lo + q + (xcd < r ? 1 : 0);
     }
+    // split-K of the last round (P.split_cap >= 2): the plain launch walks the full rounds only, the SPLIT launch gives workgroup
+    // i of the XCD part i / r of remainder tile i % r
+    int sp_part = 0, sp_parts = 1, sp_slot = 0, sp_tile = -1;
+    if (P.split_cap >= 2) {
+        const int q_x = t_hi - t_lo, full_rounds = q_x / wgs_per_xcd, r = q_x - full_rounds * wgs_per_xcd;
+        int sn = r > 0 ? wgs_per_xcd / r : 0;
+        if (sn > P.split_cap) sn = P.split_cap;
+        if (sn > ns_all / HL_SPLIT_MIN_STEPS) sn = ns_all / HL_SPLIT_MIN_STEPS;
+        if (sn >= 2 && r <= P.split_rcap) {
+            if constexpr (SPLIT) {
+                if (wg_in_xcd < r * sn) {
+                    const int jr = wg_in_xcd % r;
+                    sp_tile = t_lo + full_rounds * wgs_per_xcd + jr;
+                    sp_part = wg_in_xcd / r, sp_parts = sn, sp_slot = xcd * P.split_rcap + jr;
+                }
+            } else {
+                t_hi = t_lo + full_rounds * wgs_per_xcd;
+            }
+        }
+    }
     int tile = t_lo + wg_in_xcd;
-    if (tile >= t_hi) return;
+    if constexpr (SPLIT) {
+        // (integer divisions run on the vector ALU: say that the results are wave-uniform)
+        tile = __builtin_amdgcn_readfirstlane(sp_tile);
+        sp_part = __builtin_amdgcn_readfirstlane(sp_part), sp_parts = __builtin_amdgcn_readfirstlane(sp_parts);
+        sp_slot = __builtin_amdgcn_readfirstlane(sp_slot);
+        if (tile < 0) return;
+        t_hi = tile + 1;
+        asm volatile("" : "+s"(t_hi));
+    } else {
+        if (tile >= t_hi) return;
+    }
+    // a K part is the same K loop over shifted operand bases: the loop keeps its shape (and its register allocation)
+    const int s_begin = SPLIT ? __builtin_amdgcn_readfirstlane(sp_part * ns_all / sp_parts) : 0;
+    const int ns = SPLIT ? __builtin_amdgcn_readfirstlane((sp_part + 1) * ns_all / sp_parts) - s_begin : ns_all;
+    const unsigned short* const a_base = P.a + (SPLIT ? s_begin * 64 : 0);
+    const unsigned short* const w_base = P.w + (SPLIT ? s_begin * 64 : 0);
 
     // LDS-DMA sources: an image is 32 pieces of 8 rows x 128 B; wave wid stages pieces 4 wid .. 4 wid + 3 of A and of W; lane l
     // lands at row 8 p + (l >> 3), chunk l & 7 and fetches chunk (l & 7) ^ f(row) of its row's line
     struct Src {
         int a[4], w[4];
     };
-    auto tile_src = [&](int tl) __attribute__((always_inline)) -> Src {
+    auto tile_src_mn = [&](int tm, int tn) __attribute__((always_inline)) -> Src {
         Src s;
-        const int tm = tl / P.tiles_n, tn = tl - tm * P.tiles_n;
         const int c = lane & 7;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -408,6 +452,10 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
         }
         return s;
     };
+    auto tile_src = [&](int tl) __attribute__((always_inline)) -> Src {
+        const int tm = tl / P.tiles_n;
+        return tile_src_mn(tm, tl - tm * P.tiles_n);
+    };
     auto stage = [&](const Src& s, int kstep, int buf) __attribute__((always_inline)) {
 #ifdef X3_NOSTAGE   // timing ablations (dev builds, tools/gemm_x3_ablate.py): pieces of the step compiled out, results wrong
         return;
@@ -415,8 +463,8 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
         unsigned char* base = smem + buf * STEP_BYTES;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((glb_void*)(P.a + s.a[j] + kstep * 64), (lds_void*)(base + (4 * wid + j) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)(P.w + s.w[j] + kstep * 64), (lds_void*)(base + IMG + (4 * wid + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(a_base + s.a[j] + kstep * 64), (lds_void*)(base + (4 * wid + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(w_base + s.w[j] + kstep * 64), (lds_void*)(base + IMG + (4 * wid + j) * 1024), 16, 0, 0);
         }
     };
 
@@ -518,6 +566,9 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
     };
 
     Src cur = tile_src(tile);
+    // SPLIT: one tile per workgroup.  The loop below keeps the shape of the tile walk all the same (has_next is false at run time,
+    // not at compile time): with `cur` loop-invariant hipcc carries eight 64-bit DMA addresses through a K loop that has no register
+    // to spare -- they spill, and their reloads sit between the barrier and the MFMA burst of every step.
     stage(cur, 0, 0);
     int buf = 0;
     bool after_epilogue = false;   // the previous tile's stores may still be in flight (they count in vmcnt)
@@ -583,6 +634,52 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
             __builtin_amdgcn_s_setprio(0);
             buf ^= 1;
         }
+        if constexpr (SPLIT) {
+            // Whoever draws the last ticket adds the other parts' slabs to its accumulators in part order and runs the epilogue;
+            // everybody else parks its accumulators and leaves (cdna_hip_programming.md, in-launch split-K: plain slab stores ->
+            // vmcnt(0) -> barrier -> one agent release -> ticket; reducer: one agent acquire -> barrier -> plain loads).
+            // The ticket is broadcast through the step buffers, idle by now: a second __shared__ object would make hipcc drain the
+            // LDS-DMA in front of every fragment read of the K loop.
+            volatile unsigned int& s_ticket = *reinterpret_cast<volatile unsigned int*>(smem);
+            float* slab0 = P.split_slab + (size_t)sp_slot * P.split_cap * (size_t)(BM * BN);
+            // (opaque thread index: the addresses below must not be computed ahead of the K loop, whose registers are all taken)
+            unsigned tix = threadIdx.x;
+            asm volatile("" : "+v"(tix));
+            f32x4* mine = reinterpret_cast<f32x4*>(slab0 + (size_t)sp_part * (BM * BN)) + tix;
+            wait_vmcnt<0>();
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) mine[(mi * NI + ni) * 512] = acc[mi][ni];
+            wait_vmcnt<0>();
+            __syncthreads();
+            if (tix == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                s_ticket = __hip_atomic_fetch_add(P.split_cnt + sp_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            if (s_ticket != (unsigned)(sp_parts - 1)) return;
+            __syncthreads();
+            if (tix == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(P.split_cnt + sp_slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+            }
+            __syncthreads();
+            // sum in part order (fixed: bit-reproducible whoever arrives last); this workgroup's own part comes from its registers
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                    for (int pp = 0; pp < sp_parts; ++pp) {
+                        f32x4 v = acc[mi][ni];
+                        if (pp != sp_part) v = reinterpret_cast<const f32x4*>(slab0 + (size_t)pp * (BM * BN))[(mi * NI + ni) * 512 + tix];
+                        sum = pp == 0 ? v : sum + v;
+                    }
+                    acc[mi][ni] = sum;
+                }
+        }
         // bias: fetched here (one L2 round trip per tile) instead of being carried in 16 registers through the K loop
         load_bias(tile);
         wait_vmcnt<0>();
@@ -613,10 +710,28 @@ int launch_hl(const GemmParams& P, hipStream_t s) {
     const int ntiles = P.tiles_m * P.tiles_n;
     int grid = snf::cu_count() & ~7;
     if (grid < 8) grid = 8;
+    {   // development probe (tools/gemm_hl_occupancy_probe.py): walk the tiles with fewer workgroups than CUs
+        static const int dbg_grid = getenv("SNF_GEMM_HL_GRID") ? atoi(getenv("SNF_GEMM_HL_GRID")) & ~7 : 0;
+        if (dbg_grid >= 8 && dbg_grid < grid && P.split_cap < 2) grid = dbg_grid;
+    }
     const int per_xcd = (ntiles + 7) / 8;
     if (per_xcd * 8 < grid) grid = per_xcd * 8;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, P);
-    return snf::check_launch("gemm_hl_kernel");
+    int rc = snf::check_launch("gemm_hl_kernel");
+    if (rc || P.split_cap < 2) return rc;
+    // the last, partly filled round: every remainder tile on 2 .. 4 workgroups, a K range each (same grid: same tile -> XCD map)
+    static thread_local bool attr_set2 = false;
+    auto kern2 = gemm_hl_kernel<ACT, OUT, true>;
+    if (!attr_set2) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            snf::set_error("gemm_hl: cannot reserve %d bytes of LDS", lds);
+            (void)hipGetLastError();
+            return SNF_ELAUNCH;
+        }
+        attr_set2 = true;
+    }
+    hipLaunchKernelGGL(kern2, dim3(grid), dim3(512), lds, s, P);
+    return snf::check_launch("gemm_hl_kernel<split>");
 }
 
 template <int OUT>
@@ -813,9 +928,60 @@ extern "C" int snf_gemm_hl_bf16(const void* a_hl, int64_t lda, const void* w_hl,
     return snf_gemm_hl_resid_bf16(a_hl, lda, w_hl, ldw, bias, nullptr, 0, m, n, k, act, c, ldc, out_dtype, stream);
 }
 
+namespace {
+// split-K geometry of the last round (see GemmParams): the largest remainder r over the 8 XCDs and the largest part count
+struct HlSplit {
+    int cap, rcap;
+};
+HlSplit hl_split_geometry(int64_t m, int n, int k) {
+    HlSplit g = {0, 0};
+    if (m < 1 || n < 1 || k < BKS) return g;
+    const int64_t ntiles64 = ((m + BM - 1) / BM) * ((n + 255) / 256);
+    if (ntiles64 > 0x7fffffff) return g;
+    const int ntiles = (int)ntiles64, ns = k / BKS;
+    int grid = snf::cu_count() & ~7;
+    if (grid < 8) grid = 8;
+    const int per_xcd = (ntiles + 7) / 8;
+    if (per_xcd * 8 < grid) grid = per_xcd * 8;
+    const int w = grid >> 3;
+    // Only where the partly filled round is a large share of the launch: measured (tools/gemm_hl_splitk_time.py) 423 -> 401 us on
+    // config B's FFN output projection (1.5 rounds), but +1..2 % on config C's shapes (4.6 .. 18 rounds): behind many full rounds
+    // the second launch and the slab round trip cost more than the idle workgroups of the last round did -- a half-filled chip
+    // runs its tiles 1.25 .. 1.4x faster (clock 2.18 -> 2.40 GHz at the 1.4 kW cap, less L2 / fabric contention).
+    if (ntiles > 2 * grid) return g;
+    for (int x = 0; x < 8; ++x) {
+        const int q = ntiles / 8 + (x < (ntiles & 7) ? 1 : 0), r = q % w;
+        if (r == 0) continue;
+        int sn = w / r;
+        if (sn > HL_SPLIT_MAX) sn = HL_SPLIT_MAX;
+        if (sn > ns / HL_SPLIT_MIN_STEPS) sn = ns / HL_SPLIT_MIN_STEPS;
+        if (sn < 2) continue;
+        if (sn > g.cap) g.cap = sn;
+        if (r > g.rcap) g.rcap = r;
+    }
+    if (g.cap < 2) g.cap = g.rcap = 0;
+    return g;
+}
+constexpr size_t HL_TICKET_BYTES = 4096;
+}  // namespace
+
+// Workspace of snf_gemm_hl_ws_bf16 for this shape; 0 = the shape has no partly filled last round worth splitting.  The first 4096
+// bytes (tickets) must be ZERO before the first call; every call leaves them zero.
+extern "C" size_t snf_gemm_hl_ws_bytes(int64_t m, int n, int k) {
+    const HlSplit g = hl_split_geometry(m, n, k);
+    if (g.cap < 2 || 8 * g.rcap * sizeof(unsigned int) > HL_TICKET_BYTES) return 0;
+    return HL_TICKET_BYTES + (size_t)8 * g.rcap * g.cap * (size_t)(BM * 256) * sizeof(float);
+}
+
 extern "C" int snf_gemm_hl_resid_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ldw, const float* bias,
                                       const float* resid, int64_t ldr, int64_t m, int n, int k, int act, void* c, int64_t ldc,
                                       int out_dtype, snf_stream_t stream) {
+    return snf_gemm_hl_ws_bf16(a_hl, lda, w_hl, ldw, bias, resid, ldr, m, n, k, act, c, ldc, out_dtype, nullptr, 0, stream);
+}
+
+extern "C" int snf_gemm_hl_ws_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ldw, const float* bias,
+                                   const float* resid, int64_t ldr, int64_t m, int n, int k, int act, void* c, int64_t ldc,
+                                   int out_dtype, void* workspace, size_t workspace_bytes, snf_stream_t stream) {
     SNF_REQUIRE(a_hl && w_hl && c, "snf_gemm_hl_bf16: null pointer");
     SNF_REQUIRE(m >= 1 && n >= 1 && k >= 1, "snf_gemm_hl_bf16: bad shape m=%lld n=%d k=%d", (long long)m, n, k);
     SNF_REQUIRE(act >= SNF_ACT_RELU && act <= SNF_ACT_NONE, "snf_gemm_hl_bf16: bad activation code %d", act);
@@ -845,6 +1011,19 @@ extern "C" int snf_gemm_hl_resid_bf16(const void* a_hl, int64_t lda, const void*
     P.trace = nullptr;
     P.resid = resid;
     P.ldr = ldr;
+    if (workspace) {
+        const size_t need = snf_gemm_hl_ws_bytes(m, n, k);
+        if (need) {
+            if (workspace_bytes < need || reinterpret_cast<uintptr_t>(workspace) % 16) {
+                snf::set_error("snf_gemm_hl_ws_bf16: workspace %zu < %zu (or not 16-byte aligned)", workspace_bytes, need);
+                return SNF_EWORKSPACE;
+            }
+            const HlSplit g = hl_split_geometry(m, n, k);
+            P.split_cnt = reinterpret_cast<unsigned int*>(workspace);
+            P.split_slab = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + HL_TICKET_BYTES);
+            P.split_cap = g.cap, P.split_rcap = g.rcap;
+        }
+    }
     hipStream_t s = snf::as_stream(stream);
     if (hl_out) return launch_hl_act<3>(P, s);
     return out_dtype == SNF_DT_F32 ? launch_hl_act<1>(P, s) : launch_hl_act<0>(P, s);

@@ -1098,9 +1098,29 @@ def gemm_hl(a_hl, w_hl, bias=None, act="none", out_dtype=torch.float32, out=None
             raise ValueError("gemm_hl: resid needs an fp32 [m, n] tensor and an fp32 output")
         resid = _rows16(resid, "resid")
         ldr = resid.stride(0)
-    check(_ffi.load().snf_gemm_hl_resid_bf16(_p(a_hl), a_hl.stride(0), _p(w_hl), w_hl.stride(0), _p(bias), _p(resid), ldr, m, n,
-                                             k2 // 2, ACT_CODES[act], _p(out), out.stride(0), odt, _stream()), "snf_gemm_hl_bf16")
+    lib = _ffi.load()
+    ws, ws_bytes = None, 0
+    if GEMM_HL_SPLITK:
+        ws_bytes = int(lib.snf_gemm_hl_ws_bytes(m, n, k2 // 2))
+        if ws_bytes:
+            ws = _hl_workspace(a_hl.device, ws_bytes)
+    check(lib.snf_gemm_hl_ws_bf16(_p(a_hl), a_hl.stride(0), _p(w_hl), w_hl.stride(0), _p(bias), _p(resid), ldr, m, n, k2 // 2,
+                                  ACT_CODES[act], _p(out), out.stride(0), odt, _p(ws), ws_bytes, _stream()), "snf_gemm_hl_ws_bf16")
     return out
+
+
+GEMM_HL_SPLITK = True   # split-K of the last, partly filled round of tiles (snf_gemm_hl_ws_bf16); False: plain tile walk
+_HL_WS = {}
+
+
+def _hl_workspace(device, nbytes):
+    """Per-device workspace of the split-K GEMM: tickets (zero between launches; zeroed here once) + partial-tile slabs.  One buffer
+    per device, grown on demand: launches on a device's compute stream are ordered, so they can share it."""
+    key = str(device)
+    ws = _HL_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _HL_WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    return ws
 
 
 def split3_weight(w):

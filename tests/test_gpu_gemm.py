@@ -186,6 +186,45 @@ def test_gemm_hl_one_pass_kernel(m, n, k, act):
         assert ((img[:, :, 0].reshape(m, n).float() + img[:, :, 1].reshape(m, n).float()) - out).abs().max().item() <= 2.0 ** -15 * scale
 
 
+@pytest.mark.parametrize("m,n,k,act", [(32768, 768, 3072, "none"), (100000, 1536, 768, "relu"), (5000, 768, 3072, "gelu"),
+                                       (33000, 520, 1024, "none"), (900, 768, 3072, "none"), (70000, 768, 256, "none")])
+def test_gemm_hl_split_k_of_the_last_round(m, n, k, act, monkeypatch):
+    """snf_gemm_hl_ws_bf16: the tiles of the last, partly filled round (config B's FFN output projection: 384 tiles on 256 CUs) run as
+    2 .. 4 K parts on otherwise idle workgroups, combined by the last arriver in part order -- against fp64, against the plain tile
+    walk, bit-reproducible, every output type, tickets left clean."""
+    from snuffy_amd import _ffi, ops
+    g = torch.Generator().manual_seed(m + n + k)
+    a = (torch.randn(m, k, generator=g) * 0.5).to(DEV)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(DEV)
+    b = torch.randn(n, generator=g).to(DEV)
+    res = torch.randn(m, n, generator=g).to(DEV)
+    a_hl, w_hl = ops.split_hl_rows(a), ops.split_hl_weight(w)
+    splits = int(_ffi.load().snf_gemm_hl_ws_bytes(m, n, k)) > 0
+    if (m, n, k) in ((32768, 768, 3072), (900, 768, 3072), (33000, 520, 1024)):
+        assert splits          # 1.5 rounds / a 12-tile launch on 16 workgroups / 390 tiles: the last round is split
+    if m in (100000, 70000):
+        assert not splits      # many full rounds (not worth it) / parts would be shorter than 8 K steps
+    monkeypatch.setattr(ops, "GEMM_HL_SPLITK", True)
+    out = ops.gemm_hl(a_hl, w_hl, b, act, resid=res)
+    assert torch.equal(out, ops.gemm_hl(a_hl, w_hl, b, act, resid=res))
+    if splits:
+        ws = ops._HL_WS[str(a.device)]
+        assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0
+    img = ops.gemm_hl(a_hl, w_hl, b, act, hl_out=True) if n % 32 == 0 else None
+    ob = ops.gemm_hl(a_hl, w_hl, b, act, out_dtype=torch.bfloat16)
+    monkeypatch.setattr(ops, "GEMM_HL_SPLITK", False)
+    plain = ops.gemm_hl(a_hl, w_hl, b, act, resid=res)
+    scale = max(1.0, plain.abs().max().item())
+    assert (out - plain).abs().max().item() <= 2e-6 * scale
+    rows = torch.cat([torch.arange(0, 300), torch.arange(m - 300, m)])           # fp64 on a sample of rows (first / last tiles)
+    ref = ref_act(a[rows].cpu().double() @ w.cpu().double().t() + b.cpu().double(), act) + res[rows].cpu().double()
+    assert (out[rows].cpu().double() - ref).abs().max().item() <= 8e-6 * scale
+    assert (ob.float() - (plain - res)).abs().max().item() <= 2.0 ** -7 * scale
+    if img is not None:
+        v = img.view(m, n // 32, 2, 32)
+        assert ((v[:, :, 0].reshape(m, n).float() + v[:, :, 1].reshape(m, n).float()) - (plain - res)).abs().max().item() <= 2.0 ** -15 * scale
+
+
 @pytest.mark.parametrize("n,d", [(700, 384), (513, 768), (64, 96), (1000, 2048)])
 def test_layernorm_rows_hl_is_the_interleaved_split_of_the_fp32_rows(n, d):
     from snuffy_amd import ops
