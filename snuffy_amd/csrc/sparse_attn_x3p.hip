@@ -395,11 +395,11 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
         };
         // ---- state
         f32x16 Ta, Tb;                        // score accumulators of GEMM1 (tile i + 1), even / odd MFMAs
-        float E[16];                          // exp2(s - max) of tile i
+        f32x2 E2[8];                          // exp2(s - max) of tile i, as register pairs (packed fp32 arithmetic)
         float mw = 0.f;                       // the wave's row maximum that belongs to E
         f32x16 acc_o[NCB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) E[r] = 0.f, Ta[r] = 0.f, Tb[r] = 0.f;
+        for (int r = 0; r < 16; ++r) E2[r >> 1][r & 1] = 0.f, Ta[r] = 0.f, Tb[r] = 0.f;
         auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
@@ -436,8 +436,10 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
         //     1               sum across the halves, publish (max, sum) of the wave's 32 rows
         //     UQ + UV         one LDS-DMA instruction each: rows of Q(i + 3) / V(i + 2)
         constexpr int U_CMAX = 1, U_CW = 2, U_FS = U_CW + NW + 2, U_NORM = U_FS + 1, N_FIRST = U_NORM + 12;
-        // second-half sequence: offsets | max, max, halves | 18 exp stages with the NDU DMA instructions spread between them | publish
-        constexpr int NDU = UQ + UV, N_SECOND = 4 + 18 + NDU + 1, NUNITS = N_FIRST + N_SECOND;
+        // second-half sequence: offsets | max, max, halves | NXS exp stages with the NDU DMA instructions spread between them | publish
+        // exp stages work on PAIRS of scores (v_pk_add_f32 for the subtraction and the running sums; the exponentials are scalar)
+        constexpr int NXS = 10;
+        constexpr int NDU = UQ + UV, N_SECOND = 4 + NXS + NDU + 1, NUNITS = N_FIRST + N_SECOND;
         struct SecondMap {
             int kind[N_SECOND], arg[N_SECOND];   // kind 0: offset fetch, 1: max, 2: halves, 3: exp stage, 4: DMA, 5: publish
             constexpr SecondMap() : kind{}, arg{} {
@@ -446,16 +448,17 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
                 kind[v] = 1, arg[v++] = 0;
                 kind[v] = 1, arg[v++] = 1;
                 kind[v] = 2, arg[v++] = 0;
-                for (int q = 0; q < 18; ++q) {
+                for (int q = 0; q < NXS; ++q) {
                     kind[v] = 3, arg[v++] = q;
-                    while (d < NDU && (d + 1) * 18 <= (q + 1) * NDU) kind[v] = 4, arg[v++] = d++;
+                    while (d < NDU && (d + 1) * NXS <= (q + 1) * NDU) kind[v] = 4, arg[v++] = d++;
                 }
                 kind[v] = 5, arg[v++] = 0;
             }
         };
         constexpr SecondMap smap{};
         struct VS {
-            float mx0, mx1, l0, l1, m, l, fscale, d0, d1, e0, e1, x0, x1;
+            float mx0, mx1, m, l, fscale, d0, d1, e0, e1;
+            f32x2 l2, x0, x1;
             int doff[UQ + UV];                // per-lane source offsets of this wave's DMA instructions (fetched from LDS early)
             f32x2 sv[NW];
             f32x4 p4;
@@ -522,7 +525,9 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
                 constexpr int c4 = (u - U_NORM) / 3, part = (u - U_NORM) % 3;
                 unsigned char* pb = smem + (waddr0 ^ (16 * c4));
                 if constexpr (part == 0) {
-                    s.p4 = f32x4{E[4 * c4] * s.fscale, E[4 * c4 + 1] * s.fscale, E[4 * c4 + 2] * s.fscale, E[4 * c4 + 3] * s.fscale};
+                    const f32x2 fs2 = {s.fscale, s.fscale};
+                    const f32x2 e01 = E2[2 * c4] * fs2, e23 = E2[2 * c4 + 1] * fs2;
+                    s.p4 = f32x4{e01[0], e01[1], e23[0], e23[1]};
                     // P is ROUNDED to fp32 here in every variant: without this the compiler contracts the product into the subtraction
                     // of the split below (fma) in the variants that do not store A, and their O differs in the last bits
                     asm volatile("" : "+v"(s.p4));
@@ -542,8 +547,9 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
                     s.h01 = cvt_pk(s.p4[0], s.p4[1]), s.h23 = cvt_pk(s.p4[2], s.p4[3]);
                     *reinterpret_cast<u32x2*>(pb) = u32x2{s.h01, s.h23};
                 } else if constexpr (part == 1) {
-                    s.r0 = s.p4[0] - __uint_as_float(s.h01 << 16), s.r1 = s.p4[1] - __uint_as_float(s.h01 & 0xffff0000u);
-                    s.r2 = s.p4[2] - __uint_as_float(s.h23 << 16), s.r3 = s.p4[3] - __uint_as_float(s.h23 & 0xffff0000u);
+                    const f32x2 ra = f32x2{s.p4[0], s.p4[1]} - f32x2{__uint_as_float(s.h01 << 16), __uint_as_float(s.h01 & 0xffff0000u)};
+                    const f32x2 rb = f32x2{s.p4[2], s.p4[3]} - f32x2{__uint_as_float(s.h23 << 16), __uint_as_float(s.h23 & 0xffff0000u)};
+                    s.r0 = ra[0], s.r1 = ra[1], s.r2 = rb[0], s.r3 = rb[1];
                 } else {
                     *reinterpret_cast<u32x2*>(pb + PBUF / 2) = u32x2{cvt_pk(s.r0, s.r1), cvt_pk(s.r2, s.r3)};
                 }
@@ -563,19 +569,20 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
                     if constexpr (arg == 0) s.mx0 = mx; else s.mx1 = mx;
                 } else if constexpr (kind == 2) {
                     mw = xhalf_max(fmaxf(s.mx0, s.mx1));
-                    s.l0 = 0.f, s.l1 = 0.f;
+                    s.l2 = f32x2{0.f, 0.f};
                 } else if constexpr (kind == 3) {
-                    constexpr int q = arg;        // stage q: sub of score q, exp of score q - 1, add of score q - 2
-                    if constexpr (q >= 2) {
-                        if constexpr (q & 1) s.l1 += E[q - 2]; else s.l0 += E[q - 2];
+                    constexpr int q = arg;        // stage q: sub of score pair q, exp of pair q - 1, add of pair q - 2
+                    if constexpr (q >= 2) s.l2 += E2[q - 2];
+                    if constexpr (q >= 1 && q - 1 < 8) {
+                        const f32x2 x = (q & 1) ? s.x0 : s.x1;
+                        E2[q - 1] = f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
                     }
-                    if constexpr (q >= 1 && q - 1 < 16) E[q - 1] = __builtin_amdgcn_exp2f((q & 1) ? s.x0 : s.x1);
-                    if constexpr (q < 16) ((q & 1) ? s.x1 : s.x0) = Ta[q] - mw;
+                    if constexpr (q < 8) ((q & 1) ? s.x1 : s.x0) = f32x2{Ta[2 * q], Ta[2 * q + 1]} - f32x2{mw, mw};
                 } else if constexpr (kind == 4) {
                     dma_unit(std::integral_constant<int, arg>{}, dc, s.doff[arg]);
                 } else {
                     if constexpr (MODE != 2) {
-                        const float lsum = xhalf_sum(s.l0 + s.l1);
+                        const float lsum = xhalf_sum(s.l2[0] + s.l2[1]);
                         *reinterpret_cast<f32x2*>(smem + st_lane + ((par_n ^ 1) * NW + w) * (TR * 8)) = f32x2{mw, lsum};   // both halves: same pair
                     }
                 }
@@ -782,10 +789,13 @@ __global__ __launch_bounds__(64) void x3p_prep_kp_kernel(const float* __restrict
 }
 
 // out[key, a*DK + col] = sum over the (workgroup, segment) partials of head a, ascending workgroup order (fixed: bit-reproducible)
+// Four waves per unit: wave q sums every fourth batch of 16 partials (all 16 loads of a batch in flight), the four sums meet in LDS
+// and are added in wave order -- a fixed order whatever the timing.  (One wave per unit walked the ~43 partials of a config-B head
+// in three dependent round trips: 8 us for 27 MB.)
 template <int DK>
-__global__ __launch_bounds__(64) void x3p_reduce_kernel(const float* __restrict__ partial, int nkb, int num_wg, int seg_count,
-                                                         int tiles_per_head, int tiles_per_wg, int k, int h, float* __restrict__ out,
-                                                         int chunk_size, int64_t partial_stride) {
+__global__ __launch_bounds__(256) void x3p_reduce_kernel(const float* __restrict__ partial, int nkb, int num_wg, int seg_count,
+                                                          int tiles_per_head, int tiles_per_wg, int k, int h, float* __restrict__ out,
+                                                          int chunk_size, int64_t partial_stride) {
     constexpr int NCB = DK / 32;
     const int tiles = nkb * NCB;
     const int a = blockIdx.y;
@@ -794,17 +804,18 @@ __global__ __launch_bounds__(64) void x3p_reduce_kernel(const float* __restrict_
         partial += blockIdx.z * partial_stride, out += (int64_t)k0 * (h * DK);
         k = k - k0 < chunk_size ? k - k0 : chunk_size;
     }
-    const int unit = blockIdx.x;   // (tile, q4): one wave per workgroup, so that the units spread over all CUs
-    const int lane = threadIdx.x;
+    const int unit = blockIdx.x;   // (tile, q4): one small workgroup per unit, so that the units spread over all CUs
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
     const int t_idx = unit >> 2, q4 = unit & 3;
     if (32 * (t_idx / NCB) + 8 * q4 >= k) return;
+    __shared__ f32x4 part[3][64];
     const int f_lo = a * tiles_per_head, f_hi = (a + 1) * tiles_per_head - 1;
     const int b_lo = f_lo / tiles_per_wg;
     int b_hi = f_hi / tiles_per_wg;
     if (b_hi > num_wg - 1) b_hi = num_wg - 1;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     const int64_t off = ((int64_t)(t_idx * 4 + q4) * 64 + lane) * 4;
-    for (int b = b_lo; b <= b_hi; b += 16) {
+    for (int b = b_lo + 16 * wq; b <= b_hi; b += 64) {
         f32x4 v[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -817,6 +828,10 @@ __global__ __launch_bounds__(64) void x3p_reduce_kernel(const float* __restrict_
 #pragma unroll
         for (int u = 0; u < 16; ++u) s += v[u];
     }
+    if (wq > 0) part[wq - 1][lane] = s;
+    __syncthreads();
+    if (wq > 0) return;
+    s = ((s + part[0][lane]) + part[1][lane]) + part[2][lane];
     const int kb = t_idx / NCB, cbk = t_idx - kb * NCB;
     const int col = a * DK + 32 * cbk + (lane & 31);
 #pragma unroll
@@ -871,7 +886,7 @@ int x3p_launch(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NKB), lds, s, P);
     int rc = snf::check_launch("sparse_attn_x3p_kernel");
     if (rc || MODE == 1) return rc;
-    hipLaunchKernelGGL((x3p_reduce_kernel<DK>), dim3(NKB * (DK / 32) * 4, P.h, nch), dim3(64), 0, s, P.partial, NKB, pl.num_wg, pl.seg_count,
+    hipLaunchKernelGGL((x3p_reduce_kernel<DK>), dim3(NKB * (DK / 32) * 4, P.h, nch), dim3(256), 0, s, P.partial, NKB, pl.num_wg, pl.seg_count,
                        pl.tiles_per_head, pl.tiles_per_wg, P.k, P.h, out, csize, P.partial_stride);
     return snf::check_launch("x3p_reduce_kernel");
 }
