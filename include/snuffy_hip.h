@@ -276,6 +276,18 @@ size_t snf_sparse_attn_fwd_x3_hl_workspace_bytes(int64_t n, int k, int h, int dk
 int snf_sparse_attn_fwd_x3_hl(const void* q_hl, int64_t ldq, const void* v_hl, int64_t ldv, const float* kp, int64_t n, int k, int h,
                               int dk, float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
                               snf_stream_t stream);
+/* The same with the key projection fused in front (snuffy.py:190 + 160-168): snf_linear_rows_x3_kpfrag_f32 computes
+ * Kp = x w^T + bias for the k selected rows (fp32-class, as snf_linear_rows_x3_f32) and writes it, scaled by scale * log2(e) and
+ * split into bf16 hi / lo, as the MFMA fragment image the attention kernel keeps in registers -- no fp32 Kp tensor, no prep
+ * launch; snf_sparse_attn_fwd_x3_hl_kpfrag then takes that image instead of kp (the scale is already in it).  Results are
+ * bit-identical to the two-step form.  snf_sparse_attn_x3_hl_kpfrag_bytes: size of the image, 0 where the fused form does not
+ * apply (dk != 128, k outside 97 .. 2048, or key chunks that do not start on 32-key boundaries: use the two-step form). */
+size_t snf_sparse_attn_x3_hl_kpfrag_bytes(int k, int h, int dk);
+int snf_linear_rows_x3_kpfrag_f32(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int k_keys, int h, int dk,
+                                  int kdim, float scale, void* kp_frag, size_t kp_frag_bytes, snf_stream_t stream);
+int snf_sparse_attn_fwd_x3_hl_kpfrag(const void* q_hl, int64_t ldq, const void* v_hl, int64_t ldv, const void* kp_frag, int64_t n, int k,
+                                     int h, int dk, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
+                                     snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K7-bwd  sparse attention backward, exact fp32    replaces autograd through attention(), snuffy.py:160-168

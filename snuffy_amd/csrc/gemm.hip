@@ -797,10 +797,18 @@ __device__ __forceinline__ f32x8s skinny_load8(const float* p) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
     return f32x8s{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
-template <bool OUT_BF16>
+// FRAG: the result leaves as the MFMA A-fragment image the pipelined attention kernel keeps in registers (sparse_attn_x3p.hip,
+// x3p_prep_kp_kernel: [chunk][head][key block][dk / 16][hi | lo][64 lanes] x 16 bytes, value * fr.c_exp split into bf16 hi + lo,
+// padded keys zero) instead of as a [r, c] matrix: the key projection then needs no fp32 Kp tensor and no prep launch.
+struct SkinnyFrag {
+    int dk, chunk_size;        // head width; keys per chunk (a multiple of 32, or r when there is one chunk)
+    int64_t chunk_stride;      // u32x4 units between the chunks' images
+    float c_exp;
+};
+template <bool OUT_BF16, bool FRAG = false>
 __global__ __launch_bounds__(512) void skinny_linear_x3_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
                                                                 int64_t ldw, const float* __restrict__ bias, int r, int c, int k,
-                                                                void* __restrict__ out, int64_t ldo) {
+                                                                void* __restrict__ out, int64_t ldo, SkinnyFrag fr = SkinnyFrag{}) {
     constexpr int NW = 8, BATCH = 6;                        // waves splitting the K axis; MFMA steps (16 deep) requested at once
     __shared__ float red[NW - 1][32 * 32];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -866,6 +874,29 @@ __global__ __launch_bounds__(512) void skinny_linear_x3_kernel(const float* __re
     const int bcol = col0 + (threadIdx.x & 31);
     const float bv = (bias && bcol < c) ? bias[bcol] : 0.f;
     __syncthreads();
+    if constexpr (FRAG) {
+        // thread (key j, column group gq of 8): fragment lane 32 hf + j of k-step kb of head a, key block b of chunk ch
+        if (threadIdx.x < 128) {
+            const int gq = threadIdx.x >> 5;
+            const int ch = row0 / fr.chunk_size, b = (row0 - ch * fr.chunk_size) >> 5;
+            int kc = r - ch * fr.chunk_size;                   // keys of this chunk
+            if (kc > fr.chunk_size) kc = fr.chunk_size;
+            const int nkb = (kc + 31) >> 5, nks = fr.dk >> 4;
+            const int a = col0 / fr.dk, cin = col0 - a * fr.dk + 8 * gq;
+            const int kb = cin >> 4, hf2 = (cin >> 3) & 1;
+            f32x8s v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (blk[j][8 * gq + e] + (bias ? bias[col0 + 8 * gq + e] : 0.f)) * fr.c_exp;
+            bf16x8 hi, lo;
+            skinny_split8(v, hi, lo);
+            u32x4 uh = __builtin_bit_cast(u32x4, hi), ul = __builtin_bit_cast(u32x4, lo);
+            if (row0 + j >= r) uh = ul = u32x4{0u, 0u, 0u, 0u};
+            u32x4* dst = reinterpret_cast<u32x4*>(out) + ch * fr.chunk_stride + ((int64_t)(a * nkb + b) * nks * 2 + 2 * kb) * 64 + 32 * hf2 + j;
+            dst[0] = uh;
+            dst[64] = ul;
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < 32 * 32; e += 512) {
         const int rl = e >> 5, cl = e & 31;
         const int row = row0 + rl, col = col0 + cl;
@@ -880,6 +911,16 @@ __global__ __launch_bounds__(512) void skinny_linear_x3_kernel(const float* __re
 }
 
 }  // namespace
+
+// (internal) the key projection of the pipelined attention, written as its fragment image: sparse_attn_x3p.hip owns the layout
+int snf::skinny_linear_x3_kpfrag(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int r, int c, int k, int dk,
+                                 int chunk_size, int64_t chunk_stride, float c_exp, void* frag, hipStream_t s) {
+    const dim3 grid((unsigned)((c + 31) / 32), (unsigned)((r + 31) / 32));
+    SkinnyFrag fr;
+    fr.dk = dk, fr.chunk_size = chunk_size, fr.chunk_stride = chunk_stride, fr.c_exp = c_exp;
+    hipLaunchKernelGGL((skinny_linear_x3_kernel<false, true>), grid, dim3(512), 0, s, x, ldx, w, ldw, bias, r, c, k, frag, (int64_t)0, fr);
+    return snf::check_launch("skinny_linear_x3_kernel<frag>");
+}
 
 extern "C" int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t m, int n,
                              int k, int act, void* c, int64_t ldc, int out_dtype, int tile_n, snf_stream_t stream) {

@@ -875,7 +875,8 @@ int x3p_launch(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s)
     }
     const int nch = P.merged > 1 ? P.merged : 1;
     const int csize = P.merged > 1 ? P.chunk_size : P.k;
-    if (MODE != 2 || P.merged <= 1) {   // (the merged statistics launch has already made the fragments of every chunk)
+    if (P.kp && (MODE != 2 || P.merged <= 1)) {   // (the merged statistics launch has already made the fragments of every chunk;
+                                                   //  no kp: the caller's key projection wrote the fragment image itself)
         hipLaunchKernelGGL((x3p_prep_kp_kernel<DK>), dim3(NKB, P.h, nch), dim3(64), 0, s, P.kp, P.ldkp, P.k, NKB,
                            P.scale * 1.44269504088896340736f, const_cast<u32x4*>(P.kp_frag), csize, P.kpfrag_stride);
         int rc0 = snf::check_launch("x3p_prep_kp_kernel");
@@ -965,10 +966,65 @@ size_t snf_sparse_attn_fwd_x3_hl_workspace_bytes(int64_t n, int k, int h, int dk
     return lay.partial + lay.kpfrag + lay.stats;
 }
 
+// chunk geometry of an external Kp fragment image (snf_linear_rows_x3_kpfrag_f32): chunks must start on key-block boundaries
+static bool x3p_kpfrag_geometry(int k, int h, int dk, X3PChunks* ch, size_t* chunk_bytes) {
+    X3PPlan pl;
+    if (h < 1 || !x3p_chunks(k, dk, ch) || (ch->count > 1 && ch->size % 32) || !x3p_plan(1, ch->size, h, dk, &pl)) return false;
+    *chunk_bytes = x3p_kpfrag_bytes(pl, h, dk);
+    return true;
+}
+
+size_t snf_sparse_attn_x3_hl_kpfrag_bytes(int k, int h, int dk) {
+    X3PChunks ch;
+    size_t cb;
+    return x3p_kpfrag_geometry(k, h, dk, &ch, &cb) ? cb * ch.count : 0;
+}
+
+int snf_linear_rows_x3_kpfrag_f32(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int k_keys, int h, int dk,
+                                  int kdim, float scale, void* kp_frag, size_t kp_frag_bytes, snf_stream_t stream) {
+    SNF_REQUIRE(x && w && kp_frag, "snf_linear_rows_x3_kpfrag_f32: null pointer");
+    X3PChunks ch;
+    size_t cb;
+    if (!x3p_kpfrag_geometry(k_keys, h, dk, &ch, &cb)) {
+        snf::set_error("snf_linear_rows_x3_kpfrag_f32: k=%d h=%d dk=%d outside the fused form (dk = 128, 97 <= k <= 2048, key chunks of a "
+                       "multiple of 32 keys)", k_keys, h, dk);
+        return SNF_EUNSUPPORTED;
+    }
+    SNF_REQUIRE(kp_frag_bytes >= cb * ch.count && (reinterpret_cast<uintptr_t>(kp_frag) & 15) == 0,
+                "snf_linear_rows_x3_kpfrag_f32: fragment buffer %zu < %zu (or not 16-byte aligned)", kp_frag_bytes, cb * ch.count);
+    SNF_REQUIRE(kdim >= 16 && kdim % 16 == 0 && ldx >= kdim && ldw >= kdim && (ldx % 4) == 0 && (ldw % 4) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0,
+                "snf_linear_rows_x3_kpfrag_f32: x / w rows must be 16-byte aligned, k %% 16 == 0");
+    return snf::skinny_linear_x3_kpfrag(x, ldx, w, ldw, bias, k_keys, h * dk, kdim, dk, ch.count > 1 ? ch.size : k_keys,
+                                        (int64_t)(cb / sizeof(u32x4)), scale * 1.44269504088896340736f, kp_frag, snf::as_stream(stream));
+}
+
+static int x3p_forward(const void* q_hl, int64_t ldq, const void* v_hl, int64_t ldv, const float* kp, const void* kp_frag_ext, int64_t n,
+                       int k, int h, int dk, float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
+                       snf_stream_t stream);
+
 int snf_sparse_attn_fwd_x3_hl(const void* q_hl, int64_t ldq, const void* v_hl, int64_t ldv, const float* kp, int64_t n, int k, int h,
                               int dk, float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
                               snf_stream_t stream) {
-    SNF_REQUIRE(q_hl && v_hl && kp && out, "snf_sparse_attn_fwd_x3_hl: null pointer");
+    SNF_REQUIRE(kp, "snf_sparse_attn_fwd_x3_hl: null pointer");
+    return x3p_forward(q_hl, ldq, v_hl, ldv, kp, nullptr, n, k, h, dk, scale, out, attn, lse, workspace, workspace_bytes, stream);
+}
+
+int snf_sparse_attn_fwd_x3_hl_kpfrag(const void* q_hl, int64_t ldq, const void* v_hl, int64_t ldv, const void* kp_frag, int64_t n, int k,
+                                     int h, int dk, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
+                                     snf_stream_t stream) {
+    SNF_REQUIRE(kp_frag && (reinterpret_cast<uintptr_t>(kp_frag) & 15) == 0, "snf_sparse_attn_fwd_x3_hl_kpfrag: null / unaligned fragment image");
+    if (!snf_sparse_attn_x3_hl_kpfrag_bytes(k, h, dk)) {
+        snf::set_error("snf_sparse_attn_fwd_x3_hl_kpfrag: k=%d h=%d dk=%d has no fragment-image form", k, h, dk);
+        return SNF_EUNSUPPORTED;
+    }
+    return x3p_forward(q_hl, ldq, v_hl, ldv, nullptr, kp_frag, n, k, h, dk, 0.f, out, attn, lse, workspace, workspace_bytes, stream);
+}
+
+static int x3p_forward(const void* q_hl, int64_t ldq, const void* v_hl, int64_t ldv, const float* kp, const void* kp_frag_ext, int64_t n,
+                       int k, int h, int dk, float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
+                       snf_stream_t stream) {
+    SNF_REQUIRE(q_hl && v_hl && out, "snf_sparse_attn_fwd_x3_hl: null pointer");
     X3PChunks ch;
     X3PLayout lay;
     if (n < 1 || !x3p_layout(n, k, h, dk, &ch, &lay)) {
@@ -978,7 +1034,7 @@ int snf_sparse_attn_fwd_x3_hl(const void* q_hl, int64_t ldq, const void* v_hl, i
     const int64_t d = (int64_t)h * dk;
     SNF_REQUIRE(ldq >= 2 * d && ldv >= 2 * d && (ldq % 8) == 0 && (ldv % 8) == 0, "snf_sparse_attn_fwd_x3_hl: ldq=%lld / ldv=%lld must be "
                 ">= 2*h*dk bf16 and keep rows 16-byte aligned", (long long)ldq, (long long)ldv);
-    SNF_REQUIRE(((reinterpret_cast<uintptr_t>(q_hl) | reinterpret_cast<uintptr_t>(v_hl) | reinterpret_cast<uintptr_t>(kp)) & 15) == 0,
+    SNF_REQUIRE(((reinterpret_cast<uintptr_t>(q_hl) | reinterpret_cast<uintptr_t>(v_hl) | (kp ? reinterpret_cast<uintptr_t>(kp) : 0)) & 15) == 0,
                 "snf_sparse_attn_fwd_x3_hl: q / v / kp must be 16-byte aligned");
     const size_t need = lay.partial + lay.kpfrag + lay.stats;
     if (!workspace || workspace_bytes < need) {
@@ -995,13 +1051,21 @@ int snf_sparse_attn_fwd_x3_hl(const void* q_hl, int64_t ldq, const void* v_hl, i
     P.partial = reinterpret_cast<float*>(ws);
     P.kp_frag = reinterpret_cast<const u32x4*>(ws + lay.partial);
     P.stats = reinterpret_cast<f32x2*>(ws + lay.partial + lay.kpfrag);
+    size_t ext_stride = 0;   // u32x4 units between the chunks of an external fragment image
+    if (kp_frag_ext) {
+        X3PChunks ch2;
+        size_t cb;
+        if (!x3p_kpfrag_geometry(k, h, dk, &ch2, &cb)) return SNF_EUNSUPPORTED;
+        ext_stride = cb / sizeof(u32x4);
+        P.kp_frag = reinterpret_cast<const u32x4*>(kp_frag_ext);
+    }
     P.nchunks = ch.count, P.chunk = 0;
     P.merged = 0, P.chunk_size = k, P.kpfrag_stride = 0, P.partial_stride = 0;
     hipStream_t s = snf::as_stream(stream);
     if (lay.merged) {   // statistics of all chunks in one launch, then all main passes in one launch (+ one prep, one reduction)
         const X3PPlan& pl = lay.plan;
         P.merged = ch.count, P.chunk_size = ch.size;
-        P.kpfrag_stride = (int64_t)(lay.kpfrag / ch.count / sizeof(u32x4));
+        P.kpfrag_stride = kp_frag_ext ? (int64_t)ext_stride : (int64_t)(lay.kpfrag / ch.count / sizeof(u32x4));
         P.partial_stride = (int64_t)(lay.partial / ch.count / sizeof(float));
         P.tiles_per_head = pl.tiles_per_head, P.tiles_per_wg = pl.tiles_per_wg, P.total_tiles = pl.total_tiles;
         P.seg_count = pl.seg_count;
@@ -1021,7 +1085,8 @@ int snf_sparse_attn_fwd_x3_hl(const void* q_hl, int64_t ldq, const void* v_hl, i
                 return SNF_EUNSUPPORTED;
             }
             X3PParams C = P;
-            C.kp = kp + (int64_t)k0 * d;
+            C.kp = kp ? kp + (int64_t)k0 * d : nullptr;
+            if (kp_frag_ext) C.kp_frag = P.kp_frag + (size_t)c * ext_stride;
             C.k = kc, C.chunk = c;
             C.attn = (pass != 1 && attn) ? attn + k0 : nullptr;
             C.lse = (pass != 1 && c == 0) ? lse : nullptr;

@@ -29,6 +29,8 @@ FP32_ATTENTION = "x3"
 # with FP32_ATTENTION == "x3": the pipelined kernel on pre-split operands (snf_sparse_attn_fwd_x3_hl) wherever the layer runs on the
 # one-pass hl GEMMs and the shape allows (dk = 128, <= 256 keys); False keeps the round-3 kernel on fp32 operands
 X3_HL_ATTENTION = True
+# ... and the key projection in front of it writes the kernel's Kp fragment image itself (no fp32 Kp, no prep launch)
+X3_HL_KPFRAG = True
 # fp32 path, the [N, .] projections: "x3" = split-bf16 products on the hand-written MFMA GEMM (fp32-class: logits within
 # ~1e-5 of the exact path), "library" = fp32 library GEMMs.
 FP32_GEMM = "x3"
@@ -504,7 +506,6 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
         hl = d % 32 == 0 and f % 32 == 0 and ops.hl_eligible(n, 2 * d, d) and ops.hl_eligible(n, f, d) and ops.hl_eligible(n, d, f)
         fh = _hl_weights(layer, fw) if hl else None
         xs, slot = ops.gather_slot_map(x2, sel)                                     # snuffy.py:131,145-147 (+ row -> slot map)
-        kp = _rows_linear(xs, lk)                                       # keys = RAW selected rows (K rows: fp32)
         shared = hl and shared_norm_layer(layer)
         fhf = _hl_weights_folded(layer) if shared else None
         xn3 = _take_xn3(layer, x2, n0, shared)                                      # left by the critic pass, if any
@@ -512,6 +513,12 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
         # hi / lo values the attention kernel would derive from the fp32 tensor, the same 4 bytes per element)
         hl_attn = (hl and ragged is None and packed is None and FP32_ATTENTION == "x3" and X3_HL_ATTENTION
                    and ops.x3_hl_attn_supported(k, d // h))
+        # keys = RAW selected rows (K rows: fp32).  For the pipelined kernel the projection writes its fragment image directly
+        if (hl_attn and X3_HL_KPFRAG and ops.x3_hl_kpfrag_supported(k, h, d // h) and lk.weight.dtype == torch.float32
+                and xs.dtype == torch.float32 and d % 16 == 0):
+            kp = ops.linear_rows_x3_kpfrag(xs, lk.weight.detach(), None if lk.bias is None else lk.bias.detach(), h)
+        else:
+            kp = _rows_linear(xs, lk)
         if hl:
             if xn3 is None:
                 xn3 = ops.layernorm_rows_hl(x2, None if shared else n0.weight, None if shared else n0.bias, n0.eps)   # snuffy.py:107

@@ -645,20 +645,63 @@ def x3_hl_attn_supported(k, dk):
     return dk == 128 and 97 <= k <= 2048
 
 
+class KpFrag:
+    """The key projection of one bag as the fragment image of the pipelined attention kernel (linear_rows_x3_kpfrag): the keys'
+    count and width travel with the opaque buffer; the softmax scale is already folded in."""
+
+    def __init__(self, buf, k, d, h):
+        self.buf, self.k, self.d, self.h = buf, k, d, h
+
+
+def x3_hl_kpfrag_supported(k, h, dk):
+    """The key projection can write the attention kernel's fragment image directly (no fp32 Kp, no prep launch)."""
+    return 1 <= k <= 8192 and _ffi.load().snf_sparse_attn_x3_hl_kpfrag_bytes(int(k), int(h), int(dk)) > 0
+
+
+def linear_rows_x3_kpfrag(x, w, bias, h, scale=None):
+    """Kp = x [k, kdim] f32 @ w [d, kdim]^T f32 + bias, fp32-class (as linear_rows_x3), written as the scaled, split fragment image
+    sparse_attn_fwd_x3_hl takes as `kp` (snf_linear_rows_x3_kpfrag_f32) -> KpFrag."""
+    if x.dtype != torch.float32 or w.dtype != torch.float32:
+        raise TypeError("linear_rows_x3_kpfrag: x and w must be float32")
+    x = _rows16(x, "x")
+    w = _rows16(w, "w")
+    k, kdim = x.shape
+    d = w.shape[0]
+    if w.shape[1] != kdim or d % h:
+        raise ValueError("linear_rows_x3_kpfrag: x %s w %s h %d" % (tuple(x.shape), tuple(w.shape), h))
+    dk = d // h
+    lib = _ffi.load()
+    nbytes = lib.snf_sparse_attn_x3_hl_kpfrag_bytes(k, h, dk)
+    if not nbytes or kdim % 16:
+        raise ValueError("linear_rows_x3_kpfrag: k=%d h=%d dk=%d kdim=%d outside the fused form" % (k, h, dk, kdim))
+    if bias is not None:
+        bias = _req(bias, torch.float32, "bias", 1)
+    scale = 1.0 / math.sqrt(dk) if scale is None else scale
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(lib.snf_linear_rows_x3_kpfrag_f32(_p(x), x.stride(0), _p(w), w.stride(0), _p(bias), k, h, dk, kdim, float(scale), _p(buf),
+                                            nbytes, _stream()), "snf_linear_rows_x3_kpfrag_f32")
+    return KpFrag(buf, k, d, h)
+
+
 def sparse_attn_fwd_x3_hl(q_hl, v_hl, kp, h, scale=None, need_attn=False, need_lse=False):
     """fp32-class sparse attention on PRE-SPLIT operands (snf_sparse_attn_fwd_x3_hl): q_hl, v_hl [n, 2 d] bf16 interleaved split
     images (split_hl_rows / gemm_hl(hl_out=True); row-strided views allowed, e.g. the two halves of the [Q | V] projection's
-    image), kp [k, d] f32 -> (out [k, d] f32, attn [h, n, k] or None, lse [h, n] or None)."""
+    image), kp [k, d] f32 -- or the KpFrag of linear_rows_x3_kpfrag (scale then already applied) -> (out [k, d] f32,
+    attn [h, n, k] or None, lse [h, n] or None)."""
     if q_hl.dtype != torch.bfloat16 or v_hl.dtype != torch.bfloat16:
         raise TypeError("sparse_attn_fwd_x3_hl: q_hl and v_hl must be bfloat16 hl images")
     q_hl = _rows16(q_hl, "q_hl")
     v_hl = _rows16(v_hl, "v_hl")
-    kp = _req(kp, torch.float32, "kp", 2)
+    frag = kp if isinstance(kp, KpFrag) else None
+    if frag is None:
+        kp = _req(kp, torch.float32, "kp", 2)
+    elif frag.h != h or scale is not None:
+        raise ValueError("sparse_attn_fwd_x3_hl: the fragment image was made for h = %d with its scale folded in" % frag.h)
     n, d2 = q_hl.shape
-    k, d = kp.shape
+    k, d = (frag.k, frag.d) if frag is not None else kp.shape
     if d2 != 2 * d or d % h or v_hl.shape != q_hl.shape:
         raise ValueError("sparse_attn_fwd_x3_hl: inconsistent shapes q_hl %s v_hl %s kp %s h %d" % (tuple(q_hl.shape), tuple(v_hl.shape),
-                                                                                                   tuple(kp.shape), h))
+                                                                                                   (k, d), h))
     dk = d // h
     scale = 1.0 / math.sqrt(dk) if scale is None else scale
     lib = _ffi.load()
@@ -667,8 +710,12 @@ def sparse_attn_fwd_x3_hl(q_hl, v_hl, kp, h, scale=None, need_attn=False, need_l
     lse = torch.empty(h, n, dtype=torch.float32, device=q_hl.device) if need_lse else None
     wsb = lib.snf_sparse_attn_fwd_x3_hl_workspace_bytes(n, k, h, dk)
     ws = _ws(wsb, q_hl.device)
-    check(lib.snf_sparse_attn_fwd_x3_hl(_p(q_hl), q_hl.stride(0), _p(v_hl), v_hl.stride(0), _p(kp), n, k, h, dk, float(scale), _p(out),
-                                        _p(attn), _p(lse), _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_x3_hl")
+    if frag is not None:
+        check(lib.snf_sparse_attn_fwd_x3_hl_kpfrag(_p(q_hl), q_hl.stride(0), _p(v_hl), v_hl.stride(0), _p(frag.buf), n, k, h, dk, _p(out),
+                                                   _p(attn), _p(lse), _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_x3_hl_kpfrag")
+    else:
+        check(lib.snf_sparse_attn_fwd_x3_hl(_p(q_hl), q_hl.stride(0), _p(v_hl), v_hl.stride(0), _p(kp), n, k, h, dk, float(scale),
+                                            _p(out), _p(attn), _p(lse), _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_x3_hl")
     return out, attn, lse
 
 

@@ -481,6 +481,40 @@ def test_sparse_attn_x3_hl_config_b_spike_and_domain():
         ops().sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], torch.zeros(200, d, device=DEV), 12)  # dk = 64
 
 
+@pytest.mark.parametrize("n,k,h", [(3000, 200, 6), (5000, 97, 2), (4000, 256, 3), (3000, 512, 6), (900, 1024, 2)])
+def test_sparse_attn_x3_hl_fused_key_projection(n, k, h):
+    """snf_linear_rows_x3_kpfrag_f32 + snf_sparse_attn_fwd_x3_hl_kpfrag: the key projection writes the attention kernel's fragment
+    image itself -- bit-identical to projection -> fp32 Kp -> snf_sparse_attn_fwd_x3_hl (same products, same rounding points)."""
+    o_ = ops()
+    dk = 128
+    d = h * dk
+    g = torch.Generator().manual_seed(n + k)
+    xs = torch.randn(k, d, generator=g).to(DEV)
+    w = (torch.randn(d, d, generator=g) / d ** 0.5).to(DEV)
+    b = torch.randn(d, generator=g).to(DEV)
+    img = o_.split_hl_rows(torch.randn(n, 2 * d, generator=g).to(DEV))
+    assert o_.x3_hl_kpfrag_supported(k, h, dk)
+    kp = o_.linear_rows_x3(xs, w, b)
+    frag = o_.linear_rows_x3_kpfrag(xs, w, b, h)
+    o1, a1, l1 = o_.sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], kp, h, need_attn=True, need_lse=True)
+    o2, a2, l2 = o_.sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], frag, h, need_attn=True, need_lse=True)
+    assert torch.equal(o1, o2) and torch.equal(a1, a2) and torch.equal(l1, l2)
+    o3, _, _ = o_.sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], frag, h)
+    assert torch.equal(o3, o2)
+    nb = o_.linear_rows_x3_kpfrag(xs, w, None, h)                                 # no bias
+    o4, _, _ = o_.sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], nb, h)
+    o5, _, _ = o_.sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], o_.linear_rows_x3(xs, w, None), h)
+    assert torch.equal(o4, o5)
+
+
+def test_sparse_attn_x3_hl_fused_key_projection_domain():
+    assert not ops().x3_hl_kpfrag_supported(257, 2, 128)      # two chunks of 132 keys: not on key-block boundaries
+    assert not ops().x3_hl_kpfrag_supported(200, 12, 64)      # dk = 64
+    assert not ops().x3_hl_kpfrag_supported(96, 6, 128)
+    with pytest.raises(ValueError):
+        ops().linear_rows_x3_kpfrag(torch.zeros(257, 256, device=DEV), torch.zeros(256, 256, device=DEV), None, 2)
+
+
 def test_mfma_rejects_unsupported_shapes():
     from snuffy_amd import SnuffyHipError
     q = torch.zeros(64, 96, device=DEV)

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Copy the judged artefacts of an end-of-round run (tools/run_profiles.sh + tools/sweep.py, merged back under gpurun_out/r03/) into
+# Copy the judged artefacts of an end-of-round run (tools/run_profiles.sh + tools/sweep.py, merged back under gpurun_out/r04/) into
 # profiles/ under their per-round names.  usage (container, repo root): bash tools/collect_profiles.sh
-R=r03; O=gpurun_out/$R; P=profiles
+R=r04; O=gpurun_out/$R; P=profiles
 cp_if() { [ -s "$1" ] && cp "$1" "$2"; }
 cp_if $O/bench_cfgB.json $P/${R}_bench_cfgB.json
 cp_if $O/bench_cfgA.json $P/${R}_bench_cfgA.json
@@ -21,13 +21,17 @@ cp_if $O/varlen_bench.md $P/${R}_varlen_bench.md
 cp_if $O/vit_mfma_pmc.txt $P/${R}_vit_mfma_pmc.txt
 cp_if $O/traffic.txt $P/${R}_attn_traffic_cfgB.txt
 cp_if $O/traffic/attn_traffic.json $P/${R}_attn_traffic_cfgB_bf16.json
-cp_if $O/traffic/attn_traffic_fp32.json $P/${R}_attn_traffic_cfgB_fp32.json
-cp_if $O/attn_x3_pmc_sq.txt $P/${R}_attn_x3_pmc_sq.txt
+cp_if $O/traffic_x3p_cfgB/attn_traffic_cfgB_fp32.json $P/${R}_attn_traffic_cfgB_fp32.json
+cp_if $O/traffic_x3p_cfgC/attn_traffic_cfgC_fp32.json $P/${R}_attn_traffic_cfgC_fp32.json
+cp_if $O/traffic_x3p_cfgB.txt $P/${R}_attn_traffic_cfgB_fp32.txt
+cp_if $O/traffic_x3p_cfgC.txt $P/${R}_attn_traffic_cfgC_fp32.txt
+cp_if $O/attn_x3p_pmc_sq.txt $P/${R}_attn_x3_pmc_sq.txt
+cp_if $O/attn_x3p_timing.txt $P/${R}_attn_x3p_timing.txt
+cp_if $O/gemm_hl_splitk.txt $P/${R}_gemm_hl_splitk.txt
 cp_if $O/attn_mfma_pmc_sq.txt $P/${R}_attn_mfma_pmc_sq.txt
 cp_if $O/attn_x3_timing.txt $P/${R}_attn_x3_timing.txt
 cp_if $O/gemm_bench.txt $P/${R}_gemm_bench.txt
 cp_if $O/gemm_x3_bench.txt $P/${R}_gemm_x3_bench.txt
 cp_if $O/topk_bench.txt $P/${R}_topk_bench.txt
-cp_if $O/dma_pacing_probe.txt $P/${R}_dma_pacing_probe.txt
 cp_if $O/sweep.md $P/${R}_sweep_N_D.md
 ls -la $P | grep ${R}_ | wc -l

@@ -1,6 +1,6 @@
 # End-of-round measurement run (GPU box, repo root): bench lines, rocprofv3 kernel stats, PMC traffic of the attention kernels,
-# micro-benchmarks.  Everything lands under gpurun_out/r03/; copy what is to be judged into profiles/.   bash tools/run_profiles.sh
-R=r03; O=gpurun_out/$R; mkdir -p $O
+# micro-benchmarks.  Everything lands under gpurun_out/r04/; copy what is to be judged into profiles/.   bash tools/run_profiles.sh
+R=r04; O=gpurun_out/$R; mkdir -p $O
 T="timeout 600"
 $T python bench.py > $O/bench_cfgB.json 2> $O/bench_cfgB.err
 $T bash tools/prof_bench.sh ${R}_f32 --precision fp32 --steps 200 > $O/prof_f32.txt 2>&1
@@ -9,7 +9,9 @@ $T bash tools/prof_bench.sh ${R}_train_bf16 --mode train --precision bf16 --step
 $T bash tools/prof_bench.sh ${R}_train_f32 --mode train --precision fp32 --steps 20 --warmup 5 > $O/prof_train_f32.txt 2>&1
 $T bash tools/prof_bench.sh ${R}_vit_bf16 --workload vit --precision bf16 --steps 5 > $O/prof_vit_bf16.txt 2>&1
 $T bash tools/pmc_traffic.sh $O/traffic > $O/traffic.txt 2>&1
-WHAT=x3B $T bash tools/pmc_attn.sh $O/pmc_x3 > /dev/null 2>&1; python tools/pmc_summary.py $O/pmc_x3 sparse_attn_x3 > $O/attn_x3_pmc_sq.txt 2>&1
+$T bash tools/pmc_traffic_x3p.sh cfgB $O/traffic_x3p_cfgB > $O/traffic_x3p_cfgB.txt 2>&1
+$T bash tools/pmc_traffic_x3p.sh cfgC $O/traffic_x3p_cfgC > $O/traffic_x3p_cfgC.txt 2>&1
+$T bash tools/pmc_x3p.sh $O/pmc_x3p > $O/attn_x3p_pmc_sq.txt 2>&1
 WHAT=attnB $T bash tools/pmc_attn.sh $O/pmc_bf16 > /dev/null 2>&1; python tools/pmc_summary.py $O/pmc_bf16 sparse_attn_mfma > $O/attn_mfma_pmc_sq.txt 2>&1
 $T python bench.py --mode train --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_cfgB_train_bf16.json 2>/dev/null
 $T python bench.py --mode train --precision fp32 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_cfgB_train_f32.json 2>/dev/null
@@ -25,6 +27,8 @@ $T python tools/varlen_bench.py > $O/varlen_bench.md 2> $O/varlen_bench.err
 $T bash tools/prof_cmd.sh ${R}_varlen_1k_bf16 python tools/varlen_one.py 1000 384 bf16 64 > $O/prof_varlen_1k_bf16.txt 2>&1
 $T bash tools/prof_cmd.sh ${R}_varlen_8k_f32 python tools/varlen_one.py 8192 384 fp32 16 > $O/prof_varlen_8k_f32.txt 2>&1
 $T bash tools/pmc_vit.sh $O/pmc_vit > $O/vit_mfma_pmc.txt 2>&1
-$T tools/probes/dma_pacing_probe.bin > $O/dma_pacing_probe.txt 2>&1
+$T python tools/gemm_hl_splitk_time.py > $O/gemm_hl_splitk.txt 2>&1
+for k in 128 200 256; do $T python tools/x3p_dev.py 32768 $k 6 --time 2>&1 | grep "x3"; done > $O/attn_x3p_timing.txt
+$T python tools/x3p_dev.py 100000 512 6 --time 2>&1 | grep "x3" >> $O/attn_x3p_timing.txt
 for n in f32 bf16 train_bf16 train_f32 vit_bf16 varlen_1k_bf16 varlen_8k_f32; do cp gpurun_out/prof_${R}_$n/p_kernel_stats.csv $O/${n}_kernel_stats.csv 2>/dev/null; done
 tail -4 $O/traffic.txt; head -c 600 $O/bench_cfgB.json
