@@ -127,11 +127,18 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
         # what functional.encoder_layer dispatches for a bag this size: the pipelined split-bf16 x3 kernel on the hl image the
         # Q | V projection writes (4 bytes per element, like the fp32 tensor); three launches: Kp split, main, reduction
         imgs = [ops.split_hl_rows(qv.float()) for qv in qvs]      # [N, 4 D] bf16 = image of Q | image of V
+        kern = "sparse_attn_x3p_kernel+x3p_prep_kp_kernel+x3p_reduce_kernel"
+        kp_x3p = kp
+        if SF.X3_HL_KPFRAG and ops.x3_hl_kpfrag_supported(K, h, dk):
+            # ... and the key projection in front writes Kp as the kernel's fragment image (no prep launch): two launches
+            wk = (torch.randn(D, D, generator=g) / math.sqrt(D)).to(device)
+            kp_x3p = ops.linear_rows_x3_kpfrag(torch.randn(K, D, generator=g).to(device), wk, None, h)
+            kern = "sparse_attn_x3p_kernel+x3p_reduce_kernel"
+            del wk
 
         def attn():
             i = state["i"] = (state["i"] + 1) % nset
-            ops.sparse_attn_fwd_x3_hl(imgs[i][:, :2 * D], imgs[i][:, 2 * D:], kp, h)
-        kern = "sparse_attn_x3p_kernel+x3p_prep_kp_kernel+x3p_reduce_kernel"
+            ops.sparse_attn_fwd_x3_hl(imgs[i][:, :2 * D], imgs[i][:, 2 * D:], kp_x3p, h)
         elt = 4
     elif precision == "fp32" and ops.x3_attn_supported(K, dk):   # the fp32 path's kernel: split-bf16 x 3 on the matrix cores
         vs = [qv[:, D:].float().contiguous() for qv in qvs]
@@ -169,7 +176,7 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
             buf = torch.empty_like(src)
 
             def run_warm():
-                ops.sparse_attn_fwd_x3_hl(buf[:, :2 * D], buf[:, 2 * D:], kp, h)
+                ops.sparse_attn_fwd_x3_hl(buf[:, :2 * D], buf[:, 2 * D:], kp_x3p, h)
         else:
             def run_warm():
                 ops.sparse_attn_fwd_x3(buf[:, :D], buf[:, D:], kp, h)

@@ -34,7 +34,7 @@ def test_committed_bench_line_has_the_contract_fields():
         line = json.loads(f.read().strip().splitlines()[-1])
     if line["dtype"] == "f32":          # round 3 on: the reference's arithmetic is the headline, bf16 rides beside it
         assert line["value_bf16"] > 0 and line["value_f32_library_gemm"] > 0 and line["value_with_attention_output"] > 0
-        assert line["roofline"]["kernel"].startswith("sparse_attn_x3_kernel")
+        assert line["roofline"]["kernel"].startswith(("sparse_attn_x3_kernel", "sparse_attn_x3p_kernel"))
         assert line["roofline_bf16"]["kernel"].startswith("sparse_attn_mfma_kernel")
         assert line["vit_bf16"]["value"] > 0 and line["vit_f32"]["value"] > 0 and line["vit_bf16"]["roofline"]["bound"] == "mfma"
         line = dict(line, dtype="bf16", value_f32=line["value"], roofline=line["roofline_bf16"], roofline_f32=line["roofline"])
@@ -62,7 +62,7 @@ def test_committed_bench_line_has_the_contract_fields():
         assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["us_per_launch"] * 1e-6) / 1e9) / r["achieved"] < 2e-3
         assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes"]
     assert line["roofline"]["kernel"].startswith("sparse_attn_mfma_kernel")
-    assert line["roofline_f32"]["kernel"].startswith("sparse_attn_x3_kernel")     # the kernel the fp32 model dispatches
+    assert line["roofline_f32"]["kernel"].startswith(("sparse_attn_x3_kernel", "sparse_attn_x3p_kernel"))     # the kernel the fp32 model dispatches
     cpu = line["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cpu, key

@@ -19,6 +19,8 @@ nset = 3 if N > 50000 else 4
 xs = [torch.randn(32768, 768, generator=g).to(dev) for _ in range(2)]
 imgs = [ops.split_hl_rows(torch.randn(N, 2 * D, generator=g).to(dev)) for _ in range(nset)]
 kpf = torch.randn(K, D, generator=g).to(dev)
+if ops.x3_hl_kpfrag_supported(K, h, D // h):   # as the model dispatches it: the key projection writes the fragment image
+    kpf = ops.linear_rows_x3_kpfrag(kpf, (torch.randn(D, D, generator=g) / D ** 0.5).to(dev), None, h)
 w = torch.randn(1, 768, generator=g).to(dev)
 b = torch.zeros(1, device=dev)
 outs = [torch.empty(32768, 768, device=dev) for _ in range(2)]

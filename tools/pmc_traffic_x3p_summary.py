@@ -36,7 +36,11 @@ fr, fw = KNOWN / (sum(cal_r[2:]) / len(cal_r[2:])), KNOWN / (sum(cal_w[2:]) / le
 print("bytes per counter unit: FETCH %.1f (1024 x %.2f) | WRITE %.1f (1024 x %.2f)" % (fr, fr / 1024, fw, fw / 1024))
 out = {}
 tot = 0
-for name in ("sparse_attn_x3p_kernel", "x3p_reduce_kernel", "x3p_prep_kp_kernel"):
+names = []
+for name in ("sparse_attn_x3p_kernel", "x3p_prep_kp_kernel", "x3p_reduce_kernel"):
+    if not pick(fetch, name):
+        continue                   # (no prep launch when the key projection wrote the fragment image)
+    names.append(name)
     rb = sum(sum(v) for v in pick(fetch, name)) * fr / REPS
     wb = sum(sum(v) for v in pick(write, name)) * fw / REPS
     nl = sum(len(v) for v in pick(fetch, name)) / REPS
@@ -46,6 +50,6 @@ for name in ("sparse_attn_x3p_kernel", "x3p_reduce_kernel", "x3p_prep_kp_kernel"
 alg = 8 * N * D + 8 * K * D
 print("attention total HBM-side traffic %.1f MB per call vs %.1f MB algorithmic (x%.2f)" % (tot / 1e6, alg / 1e6, tot / alg))
 out.update(total_bytes=round(tot), algorithmic_bytes=alg, workload="%s N=%d D=%d h=%d K=%d, hl (split bf16) operands = 4 bytes per element" % (wl, N, D, h, K),
-           kernel="sparse_attn_x3p_kernel+x3p_prep_kp_kernel+x3p_reduce_kernel", fetch_bytes_per_unit=fr, write_bytes_per_unit=fw)
+           kernel="+".join(names), fetch_bytes_per_unit=fr, write_bytes_per_unit=fw)
 if len(sys.argv) > 3:
     json.dump(out, open(sys.argv[3], "w"), indent=1)
