@@ -168,15 +168,23 @@ struct Cur {
 
 constexpr int x3p_qslot(int dk) { return ((TR * (4 * dk + 16) + 1023) / 1024) * 1024; }   // padded Q slot, whole DMA instructions
 constexpr int x3p_dma_u(int n, int nw) { return (n + nw - 1) / nw; }
+// Who issues the LDS-DMA.  Waves w and w + 4 share a SIMD; with 5 .. 7 key blocks (one wave each) some SIMDs carry two waves and set
+// the iteration time while wave slot nkb is free on a SIMD that carries one: a LOADER wave sits there and issues all the DMA of the
+// workgroup (nothing else: no MFMA, a few dozen registers), and the key-block waves carry no DMA code at all.  With 4 or 8 key
+// blocks every SIMD carries the same load and every wave issues its share.
+constexpr bool x3p_loader(int nkb) { return nkb > 4 && nkb < 8; }
+constexpr int x3p_issuers(int nkb) { return x3p_loader(nkb) ? 1 : nkb; }
+constexpr int x3p_waves(int nkb) { return nkb + (x3p_loader(nkb) ? 1 : 0); }
 constexpr int x3p_lds_bytes(int dk, int nkb) {
-    const int nq = x3p_qslot(dk) / 1024, nv = TR * 4 * dk / 1024;
-    return 3 * x3p_qslot(dk) + 3 * TR * 4 * dk + nkb * (TR * 64 * 2) + 2 * nkb * TR * 8 + nkb * (x3p_dma_u(nq, nkb) + x3p_dma_u(nv, nkb)) * 256;
+    const int nq = x3p_qslot(dk) / 1024, nv = TR * 4 * dk / 1024, nl = x3p_issuers(nkb);
+    return 3 * x3p_qslot(dk) + 3 * TR * 4 * dk + nkb * (TR * 64 * 2) + 2 * nkb * TR * 8 +
+           (x3p_loader(nkb) ? 0 : nl * (x3p_dma_u(nq, nl) + x3p_dma_u(nv, nl)) * 256);
 }
 
 // MODE 0: all keys in this launch.  MODE 1: statistics pass of one key chunk (GEMM1 + max / sum per row, written to P.stats; no
 // GEMM2, V is not touched).  MODE 2: main pass of one key chunk with the row statistics of ALL chunks taken from P.stats.
 template <int DK, int NKB, bool AUX, int MODE>
-__global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PParams P) {
+__global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel(const X3PParams P) {
     static_assert(DK == 128 && MODE >= 0 && MODE <= 2, "sparse_attn_x3p: dk = 128");
     constexpr bool DRAIN = AUX || MODE != 0;   // global loads / stores of the kernel's own in the loop: no counted DMA waits
     constexpr int NW = NKB;                  // waves: one per key block
@@ -193,11 +201,14 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
     constexpr int NQDMA = QSLOT / 1024;      // LDS-DMA instructions of a Q tile (17)
     constexpr int VSLOT = TR * ROWB;         // 16 KiB, rows of [hi plane 256 B | lo plane 256 B], 64-byte groups XOR-rotated
     constexpr int NVDMA = VSLOT / 1024;      // 16
-    constexpr int UQ = x3p_dma_u(NQDMA, NW), UV = x3p_dma_u(NVDMA, NW);   // DMA instructions per wave and tile, at most
+    constexpr bool LOADER = x3p_loader(NKB);                                // wave NKB issues all the LDS-DMA (else: every wave its share)
+    constexpr int NL = x3p_issuers(NKB);
+    constexpr int UQ = x3p_dma_u(NQDMA, NL), UV = x3p_dma_u(NVDMA, NL);   // DMA instructions per issuing wave and tile, at most
+    static_assert(UQ + UV <= 40, "DMA instructions per wave: 64-bit masks, counted waits up to 40");
     constexpr int Q_OFF = 0, V_OFF = 3 * QSLOT, P_OFF = V_OFF + 3 * VSLOT;
     constexpr int PBUF = TR * 64 * 2;        // the P image of one key block: hi plane 2 KiB | lo plane 2 KiB
     constexpr int ST_OFF = P_OFF + NKB * PBUF;
-    constexpr int TB_OFF = ST_OFF + 2 * NW * TR * 8;        // per-lane DMA source offsets, [NW][UQ + UV][64] ints
+    constexpr int TB_OFF = ST_OFF + 2 * NW * TR * 8;        // per-lane DMA source offsets, [NL][UQ + UV][64] ints
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -241,8 +252,8 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
     //   Q instruction e (0 .. 16): position p = 64 e + lane -> row p / 33, chunk p % 33 of the row's 512-byte line (chunk 32 = pad)
     //   V instruction e (0 .. 15): row 2 e + (lane >> 5), position s = lane & 31: plane s >> 4, 64-byte column group ((s >> 2) & 3) ^ (row & 3)
     //                              (keeps the four rows of a transpose-read in four different 64-byte bank segments)
-    // Every instruction reads whole 128-byte lines of two or three consecutive rows.  Wave w issues Q instructions w, w + NW, ..
-    // and V instructions w, w + NW, ..
+    // Every instruction reads whole 128-byte lines of two or three consecutive rows.  Issuing wave li (= w - L0) issues Q
+    // instructions li, li + NL, .. and V instructions li, li + NL, ..
     const int ldq_b = (int)(P.ldq * 2), ldv_b = (int)(P.ldv * 2);
     auto q_rc = [&](int e, int& row, int& chunk) __attribute__((always_inline)) {
         const int p = 64 * e + lane;
@@ -259,18 +270,22 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
     };
     // The per-lane source offsets of a FULL tile (row_in_tile * ld_bytes + 16 * chunk) are parked in LDS: registers are the scarce
     // resource of this kernel, and an offset is needed once per iteration.
-    int* const dma_tab = reinterpret_cast<int*>(smem + TB_OFF) + w * ((UQ + UV) * 64) + lane;
+    const bool issuer = LOADER ? w == NW : true;
+    const int li = LOADER ? 0 : w;
+    int* const dma_tab = reinterpret_cast<int*>(smem + TB_OFF) + li * ((UQ + UV) * 64) + lane;
+    if (!LOADER) {
 #pragma unroll
-    for (int u = 0; u < UQ; ++u) {
-        int row, chunk;
-        q_rc(w + NW * u, row, chunk);
-        dma_tab[u * 64] = row * ldq_b + 16 * chunk;
-    }
+        for (int u = 0; u < UQ; ++u) {
+            int row, chunk;
+            q_rc(li + NL * u, row, chunk);
+            dma_tab[u * 64] = row * ldq_b + 16 * chunk;
+        }
 #pragma unroll
-    for (int u = 0; u < UV; ++u) {
-        int row, chunk;
-        v_rc(w + NW * u, row, chunk);
-        dma_tab[(UQ + u) * 64] = row * ldv_b + 16 * chunk;
+        for (int u = 0; u < UV; ++u) {
+            int row, chunk;
+            v_rc(li + NL * u, row, chunk);
+            dma_tab[(UQ + u) * 64] = row * ldv_b + 16 * chunk;
+        }
     }
     // one instruction: 32-bit per-lane offset + 64-bit wave-uniform base (SGPR pair) -> 1 KiB at the wave-uniform LDS address dst.
     // Hand-written: behind the builtin hipcc puts s_waitcnt vmcnt(0) in front of the first LDS read it cannot prove disjoint from
@@ -294,34 +309,35 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
     };
     struct DmaCtx {                           // wave-uniform, per tile pair to fetch
         const unsigned char *bq, *bv;
-        unsigned mask;                        // bit u: instruction u of the wave's list (Q: u < UQ, V: UQ + ..) is to be issued
+        uint64_t mask;                        // bit u: instruction u of the wave's list (Q: u < UQ, V: UQ + ..) is to be issued
         int dstq, dstv;
     };
-    unsigned full_mask = 0;                   // the instructions this wave owns
+    uint64_t full_mask = 0;                   // the instructions this wave owns
 #pragma unroll
-    for (int u = 0; u < UQ; ++u) full_mask |= (w + NW * u < NQDMA) ? 1u << u : 0u;
+    for (int u = 0; u < UQ; ++u) full_mask |= (issuer && li + NL * u < NQDMA) ? 1ull << u : 0ull;
 #pragma unroll
-    for (int u = 0; u < UV; ++u) full_mask |= (w + NW * u < NVDMA) ? 1u << (UQ + u) : 0u;
+    for (int u = 0; u < UV; ++u) full_mask |= (issuer && li + NL * u < NVDMA) ? 1ull << (UQ + u) : 0ull;
+    constexpr uint64_t QBITS = (1ull << UQ) - 1ull, VBITS = ((1ull << UV) - 1ull) << UQ;
     const unsigned tile_q_b = (unsigned)(TR * ldq_b), tile_v_b = (unsigned)(TR * ldv_b);
     // instruction u of the wave's list, full tile (the common case: nothing but the table lookup and the instruction)
     auto dma_unit = [&](auto u_t, const DmaCtx& dc, int off) __attribute__((always_inline)) {
         constexpr int u = decltype(u_t)::value;
         constexpr bool isq = u < UQ;
         constexpr int uu = isq ? u : u - UQ;
-        if (dc.mask & (1u << u)) dma_1k(isq ? dc.bq : dc.bv, off, (isq ? dc.dstq : dc.dstv) + NW * uu * 1024);
+        if (dc.mask & (1ull << u)) dma_1k(isq ? dc.bq : dc.bv, off, (isq ? dc.dstq : dc.dstv) + NL * uu * 1024);
     };
     // the same for the last tile of a bag: rows past the end re-read the last row (their P is forced to 0).  Rare: not interleaved.
-    auto dma_partial = [&](const DmaCtx& dc, unsigned mask, int rmaxq, int rmaxv) __attribute__((always_inline)) {
+    auto dma_partial = [&](const DmaCtx& dc, uint64_t mask, int rmaxq, int rmaxv) __attribute__((always_inline)) {
         static_for<0, UQ + UV>([&](auto u_t) __attribute__((always_inline)) {
             constexpr int u = decltype(u_t)::value;
             constexpr bool isq = u < UQ;
             constexpr int uu = isq ? u : u - UQ;
-            if (mask & (1u << u)) {
+            if (mask & (1ull << u)) {
                 int row, chunk;
-                if constexpr (isq) q_rc(w + NW * uu, row, chunk); else v_rc(w + NW * uu, row, chunk);
+                if constexpr (isq) q_rc(li + NL * uu, row, chunk); else v_rc(li + NL * uu, row, chunk);
                 const int rmax = isq ? rmaxq : rmaxv;
                 if (row > rmax) row = rmax;
-                dma_1k(isq ? dc.bq : dc.bv, row * (isq ? ldq_b : ldv_b) + 16 * chunk, (isq ? dc.dstq : dc.dstv) + NW * uu * 1024);
+                dma_1k(isq ? dc.bq : dc.bv, row * (isq ? ldq_b : ldv_b) + 16 * chunk, (isq ? dc.dstq : dc.dstv) + NL * uu * 1024);
             }
         });
     };
@@ -330,12 +346,12 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
         DmaCtx dc;
         dc.bq = reinterpret_cast<const unsigned char*>(P.q) + (uint64_t)((unsigned)cq.t * (uint64_t)tile_q_b) + (unsigned)(cq.a * ROWB);
         dc.bv = reinterpret_cast<const unsigned char*>(P.v) + (uint64_t)((unsigned)cv.t * (uint64_t)tile_v_b) + (unsigned)(cv.a * ROWB);
-        dc.dstq = Q_OFF + sq * QSLOT + w * 1024, dc.dstv = V_OFF + sv * VSLOT + w * 1024;
-        dc.mask = full_mask & ((doq ? (1u << UQ) - 1u : 0u) | (dov ? ((1u << UV) - 1u) << UQ : 0u));
+        dc.dstq = Q_OFF + sq * QSLOT + li * 1024, dc.dstv = V_OFF + sv * VSLOT + li * 1024;
+        dc.mask = full_mask & ((doq ? QBITS : 0ull) | (dov ? VBITS : 0ull));
         const int rmaxq = n32 - 1 - cq.t * TR, rmaxv = n32 - 1 - cv.t * TR;   // last existing row, tile-relative
-        unsigned part = 0;
-        if (rmaxq < TR - 1) part |= (1u << UQ) - 1u;
-        if (rmaxv < TR - 1) part |= ((1u << UV) - 1u) << UQ;
+        uint64_t part = 0;
+        if (rmaxq < TR - 1) part |= QBITS;
+        if (rmaxv < TR - 1) part |= VBITS;
         part &= dc.mask;
         if (part) {
             dma_partial(dc, part, rmaxq, rmaxv);
@@ -377,8 +393,9 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
 
     // ================================================================ the wave program
     // LASTW: this wave owns the last key block (its padded keys are masked)
-    auto run = [&](auto lastw_t) __attribute__((always_inline)) {
-        constexpr bool LASTW = decltype(lastw_t)::value;
+    // ISS: this wave issues LDS-DMA (the others carry no DMA code at all)
+    auto run = [&](auto lastw_t, auto iss_t) __attribute__((always_inline)) {
+        constexpr bool LASTW = decltype(lastw_t)::value, ISS = decltype(iss_t)::value;
         const int klast = kk - 32 * (NKB - 1);                          // valid keys of the last key block
 
         // ---- Kp fragments of the wave's key block: MFMA A operands, hi and lo, for the whole head -- 16-byte loads out of the
@@ -439,7 +456,7 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
         // second-half sequence: offsets | max, max, halves | NXS exp stages with the NDU DMA instructions spread between them | publish
         // exp stages work on PAIRS of scores (v_pk_add_f32 for the subtraction and the running sums; the exponentials are scalar)
         constexpr int NXS = 10;
-        constexpr int NDU = UQ + UV, N_SECOND = 4 + NXS + NDU + 1, NUNITS = N_FIRST + N_SECOND;
+        constexpr int NDU = ISS ? UQ + UV : 0, N_SECOND = 4 + NXS + NDU + 1, NUNITS = N_FIRST + N_SECOND;
         struct SecondMap {
             int kind[N_SECOND], arg[N_SECOND];   // kind 0: offset fetch, 1: max, 2: halves, 3: exp stage, 4: DMA, 5: publish
             constexpr SecondMap() : kind{}, arg{} {
@@ -459,7 +476,7 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
         struct VS {
             float mx0, mx1, m, l, fscale, d0, d1, e0, e1;
             f32x2 l2, x0, x1;
-            int doff[UQ + UV];                // per-lane source offsets of this wave's DMA instructions (fetched from LDS early)
+            int doff;                         // per-lane source offset of the wave's NEXT DMA instruction (fetched from LDS one unit ahead)
             f32x2 sv[NW];
             f32x4 p4;
             unsigned h01, h23;
@@ -556,8 +573,7 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
             } else {
                 constexpr int kind = smap.kind[u - N_FIRST], arg = smap.arg[u - N_FIRST];
                 if constexpr (kind == 0) {
-#pragma unroll
-                    for (int d = 0; d < NDU; ++d) s.doff[d] = dma_tab[d * 64];
+                    if constexpr (NDU > 0) s.doff = dma_tab[0];
                 } else if constexpr (kind == 1) {
                     constexpr int r0 = 8 * arg;
 #pragma unroll
@@ -579,7 +595,9 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
                     }
                     if constexpr (q < 8) ((q & 1) ? s.x1 : s.x0) = f32x2{Ta[2 * q], Ta[2 * q + 1]} - f32x2{mw, mw};
                 } else if constexpr (kind == 4) {
-                    dma_unit(std::integral_constant<int, arg>{}, dc, s.doff[arg]);
+                    const int off = s.doff;
+                    if constexpr (arg + 1 < NDU) s.doff = dma_tab[(arg + 1) * 64];
+                    dma_unit(std::integral_constant<int, arg>{}, dc, off);
                 } else {
                     if constexpr (MODE != 2) {
                         const float lsum = xhalf_sum(s.l2[0] + s.l2[1]);
@@ -678,7 +696,6 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
             if constexpr (DRAIN) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
-                static_assert(UQ + UV <= 40, "wait_dma: more DMA instructions per wave than the switch covers");
 #define X3P_VMC(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
                 switch (n) {
                     X3P_VMC(0) X3P_VMC(1) X3P_VMC(2) X3P_VMC(3) X3P_VMC(4) X3P_VMC(5) X3P_VMC(6) X3P_VMC(7) X3P_VMC(8) X3P_VMC(9)
@@ -702,7 +719,7 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
         c0 = c1;                              // item -1 does not exist (any valid cursor)
         c2 = cur_next(c1);
         c3 = cur_next(c2);
-        {
+        if constexpr (ISS) {
             const DmaCtx d0 = dma_ctx(true, c1, 0, MODE != 1, c1, 0), d1 = dma_ctx(1 < T, c2, 1, false, c2, 1);
             static_for<0, UQ + UV>([&](auto u_t) __attribute__((always_inline)) { dma_unit(u_t, d0, dma_tab[decltype(u_t)::value * 64]); });
             static_for<0, UQ>([&](auto u_t) __attribute__((always_inline)) { dma_unit(u_t, d1, dma_tab[decltype(u_t)::value * 64]); });
@@ -731,11 +748,14 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
                 if (rows_ok > TR) rows_ok = TR;
             }
             const bool dov = MODE != 1 && i + 2 < T;   // a statistics pass never touches V
-            const unsigned want = full_mask & ((i + 3 < T ? (1u << UQ) - 1u : 0u) | (dov ? ((1u << UV) - 1u) << UQ : 0u));
-            const DmaCtx dc = dma_ctx(i + 3 < T, c3, slot_v, dov, c2, slot_q == 2 ? 0 : slot_q + 1);
+            DmaCtx dc = {};
+            if constexpr (ISS) dc = dma_ctx(i + 3 < T, c3, slot_v, dov, c2, slot_q == 2 ? 0 : slot_q + 1);
             iteration(i, slot_q, slot_v, c0, dc, rows_ok);
             // everything issued BEFORE this iteration has landed for this wave; together with the barrier: for every wave
-            wait_dma(__builtin_popcount(want));
+            if constexpr (ISS) {
+                const uint64_t want = full_mask & ((i + 3 < T ? QBITS : 0ull) | (dov ? VBITS : 0ull));
+                wait_dma(__builtin_popcountll(want));
+            }   // (no DMA of this wave's own: nothing to wait for; its global loads / stores are the compiler's to track)
             X3P_STAMP(i + 1, 4);
             __builtin_amdgcn_s_barrier();
             X3P_STAMP(i + 1, 5);
@@ -751,10 +771,68 @@ __global__ __launch_bounds__(64 * NKB, 2) void sparse_attn_x3p_kernel(const X3PP
     // the second-dispatched waves of a SIMD lose every arbitration to the first at equal priority and set the iteration time
     // (in-kernel trace: first half 1450 ticks for waves 0-3, 2480 for waves 4-6): static priority for them (guide T5, static form)
     if (w >= 4) __builtin_amdgcn_s_setprio(1);
-    if (w == NW - 1)
-        run(std::true_type{});
-    else
-        run(std::false_type{});
+    if constexpr (!LOADER) {
+        if (w == NW - 1)
+            run(std::true_type{}, std::true_type{});
+        else
+            run(std::false_type{}, std::true_type{});
+    } else {
+        if (w == NW) {
+            // ---- the loader wave: the DMA schedule of the pipeline (see run()) and its barriers, nothing else.  The per-lane source
+            // offsets of a full tile live in registers (this wave has them to spare).
+            __builtin_amdgcn_s_setprio(2);
+            int offs[UQ + UV];
+#pragma unroll
+            for (int u = 0; u < UQ; ++u) {
+                int row, chunk;
+                q_rc(u, row, chunk);
+                offs[u] = row * ldq_b + 16 * chunk;
+            }
+#pragma unroll
+            for (int u = 0; u < UV; ++u) {
+                int row, chunk;
+                v_rc(u, row, chunk);
+                offs[UQ + u] = row * ldv_b + 16 * chunk;
+            }
+            Cur c1, c2, c3;
+            c1.a = first_head, c1.t = f_begin - first_head * P.tiles_per_head;
+            c2 = cur_next(c1);
+            c3 = cur_next(c2);
+            {
+                const DmaCtx d0 = dma_ctx(true, c1, 0, MODE != 1, c1, 0), d1 = dma_ctx(1 < T, c2, 1, false, c2, 1);
+                static_for<0, UQ + UV>([&](auto u_t) __attribute__((always_inline)) { dma_unit(u_t, d0, offs[decltype(u_t)::value]); });
+                static_for<0, UQ>([&](auto u_t) __attribute__((always_inline)) { dma_unit(u_t, d1, offs[decltype(u_t)::value]); });
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            int slot_q = 0, slot_v = 2;
+            for (int i = -1; i < T; ++i) {
+                const bool dov = MODE != 1 && i + 2 < T;
+                const DmaCtx dc = dma_ctx(i + 3 < T, c3, slot_v, dov, c2, slot_q == 2 ? 0 : slot_q + 1);
+                static_for<0, UQ + UV>([&](auto u_t) __attribute__((always_inline)) { dma_unit(u_t, dc, offs[decltype(u_t)::value]); });
+                // what the PREVIOUS iteration issued has to have landed before this iteration's barrier (run(): wait_dma)
+                const uint64_t want = full_mask & ((i + 3 < T ? QBITS : 0ull) | (dov ? VBITS : 0ull));
+                const int n_own = __builtin_popcountll(want);
+#define X3P_VMC(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+                switch (n_own) {
+                    X3P_VMC(0) X3P_VMC(1) X3P_VMC(2) X3P_VMC(3) X3P_VMC(4) X3P_VMC(5) X3P_VMC(6) X3P_VMC(7) X3P_VMC(8) X3P_VMC(9)
+                    X3P_VMC(10) X3P_VMC(11) X3P_VMC(12) X3P_VMC(13) X3P_VMC(14) X3P_VMC(15) X3P_VMC(16) X3P_VMC(17) X3P_VMC(18) X3P_VMC(19)
+                    X3P_VMC(20) X3P_VMC(21) X3P_VMC(22) X3P_VMC(23) X3P_VMC(24) X3P_VMC(25) X3P_VMC(26) X3P_VMC(27) X3P_VMC(28) X3P_VMC(29)
+                    X3P_VMC(30) X3P_VMC(31) X3P_VMC(32) X3P_VMC(33) X3P_VMC(34) X3P_VMC(35) X3P_VMC(36) X3P_VMC(37) X3P_VMC(38) X3P_VMC(39)
+                    default: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+                }
+#undef X3P_VMC
+                __builtin_amdgcn_s_barrier();
+                slot_v = slot_q;
+                slot_q = slot_q == 2 ? 0 : slot_q + 1;
+                c2 = c3, c3 = cur_next(c3);
+            }
+        } else if (w == NW - 1) {
+            run(std::true_type{}, std::false_type{});
+        } else {
+            run(std::false_type{}, std::false_type{});
+        }
+    }
 }
 
 // Kp [k, h dk] f32 -> the MFMA A fragments the attention waves keep in registers: [h][nkb][dk / 16][hi | lo][64 lanes] x 16 bytes,
@@ -884,7 +962,7 @@ int x3p_launch(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s)
     }
     // merged: 8 XCDs x (row ranges per XCD) x chunks, the chunk index innermost within an XCD's slots
     const int grid = P.merged > 1 ? 8 * ((pl.num_wg + 7) / 8) * nch : pl.num_wg;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NKB), lds, s, P);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * x3p_waves(NKB)), lds, s, P);
     int rc = snf::check_launch("sparse_attn_x3p_kernel");
     if (rc || MODE == 1) return rc;
     hipLaunchKernelGGL((x3p_reduce_kernel<DK>), dim3(NKB * (DK / 32) * 4, P.h, nch), dim3(256), 0, s, P.partial, NKB, pl.num_wg, pl.seg_count,
