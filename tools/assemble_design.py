@@ -31,7 +31,9 @@ for line in table:
 layout = sect(105, 116).replace(
     "| bf16 path | `xhat`",
     "| fp32 path, round 4 | `[Q \\| V]` [N, 4D] bf16 **hl image** (no fp32 Q / V tensor) | written by the Q\\|V projection's epilogue (`gemm_hl` `OUT = 3`), "
-    "streamed by `sparse_attn_x3p_kernel` with LDS-DMA: head a, true column c of Q at byte `2·(2 a dk + 64 (c / 32) + c % 32)` (hi), `+ 64` (lo); V behind Q at column 2D |\n| bf16 path | `xhat`", 1)
+    "streamed by `sparse_attn_x3p_kernel` with LDS-DMA: head a, true column c of Q at byte `2·(2 a dk + 64 (c / 32) + c % 32)` (hi), `+ 64` (lo); V behind Q at column 2D |\n"
+    "| | ONE normalised image `xhat` [N, 2D] bf16 hl (no affine) for both sublayers | as in the bf16 path: γ / β of LN0 / LN1 folded into Wq\\|Wv and W1 (in fp64, rounded once), written by the critic pass on its one read of the bag; after the attention the K patched rows are re-normalised into it (`FP32_SHARED_NORM`; needs equal eps) |\n"
+    "| | Kp as the attention kernel's **fragment image** [h][⌈K/32⌉][dk/16][hi \\| lo][64 lanes] × 16 B | written by the key projection (`snf_linear_rows_x3_kpfrag_f32`), scaled by 1/√dk · log2 e |\n| bf16 path | `xhat`", 1)
 parts = [src("00_head.md"), "", sect(52, 104), "", layout, "",
          "## 4. Kernels, rooflines, algorithmic bytes (§8d)", "", "\n".join(rows), "",
          src("41_x3p.md"), "", src("42_rest.md"), "", src("50_meas.md"), "", sect(699, 774), src("80_scope.md"), ""]
