@@ -361,6 +361,12 @@ int snf_gemm_hl_ws_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t
 int snf_split_hl_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16, snf_stream_t stream);
 int snf_layernorm_rows_hl_f32(const float* x, int64_t n, int d, const int32_t* slot_map, const float* patch_rows,
                               const float* gamma, const float* beta, float eps, void* out_bf16, snf_stream_t stream);
+/* The K patched rows of a bag, re-normalised INTO an existing hl image (snuffy.py:108 + 110 for the selected rows only): row j of
+ * (x [n, d] + addend [n, d] or NULL) is layer-normalised (gamma / beta NULL = no affine) and written as the hl row out_row_idx[j]
+ * of out_hl [*, 2 d].  With one normalised image serving both sublayers of an encoder layer (LayerNorm affines folded into the
+ * projections) this replaces the second full LayerNorm pass over the bag. */
+int snf_layernorm_rows_hl_patch_f32(const float* x, const float* addend, int64_t n, int d, const int64_t* out_row_idx,
+                                    const float* gamma, const float* beta, float eps, void* out_hl, snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K12-K14  ViT patch-embedding extractor (compute_feats.py:239-247 -> IClassifier -> VisionTransformer.forward)

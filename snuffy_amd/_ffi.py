@@ -109,6 +109,8 @@ SIGNATURES = {
     "snf_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
                               c_int, c_int, c_void_p]),
     "snf_split_hl_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "snf_layernorm_rows_hl_patch_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                                c_void_p]),
     "snf_layernorm_rows_hl_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                           c_void_p, c_void_p]),
     "snf_gemm_hl_resid_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,

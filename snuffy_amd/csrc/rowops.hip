@@ -260,7 +260,8 @@ __global__ __launch_bounds__(WG) void layernorm_rows_kernel(const float* __restr
                                                             float* __restrict__ out_f32,
                                                             unsigned short* __restrict__ out_bf16,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            const int64_t* __restrict__ out_row_idx, int split3) {
+                                                            const int64_t* __restrict__ out_row_idx, int split3,
+                                                            const float* __restrict__ addend = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     float g[NV * VEC], bt[NV * VEC];
@@ -275,6 +276,12 @@ __global__ __launch_bounds__(WG) void layernorm_rows_kernel(const float* __restr
         }
         float r[NV * VEC];
         load_row<VEC, NV>(src, d, lane, r);
+        if (addend) {   // row = x + addend (the sublayer's residual sum, snuffy.py:108), rounded once to fp32 like the tensor it replaces
+            float ad[NV * VEC];
+            load_row<VEC, NV>(addend + row * d, d, lane, ad);
+#pragma unroll
+            for (int i = 0; i < NV * VEC; ++i) r[i] += ad[i];
+        }
         float s1 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV * VEC; ++i) s1 += r[i];
@@ -1312,6 +1319,22 @@ int snf_layernorm_rows_hl_f32(const float* x, int64_t n, int d, const int32_t* s
                                               reinterpret_cast<unsigned short*>(out_bf16), (float*)nullptr, (float*)nullptr,
                                               (const int64_t*)nullptr, 2));
     return snf::check_launch("layernorm_rows_kernel<hl>");
+}
+
+int snf_layernorm_rows_hl_patch_f32(const float* x, const float* addend, int64_t n, int d, const int64_t* out_row_idx,
+                                    const float* gamma, const float* beta, float eps, void* out_hl, snf_stream_t stream) {
+    SNF_REQUIRE(x && out_hl && out_row_idx, "snf_layernorm_rows_hl_patch_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && d >= 32 && d % 32 == 0, "snf_layernorm_rows_hl_patch_f32: d=%d must be a multiple of 32", d);
+    SNF_REQUIRE(aligned16(x) && (!addend || aligned16(addend)) && (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)) &&
+                    aligned16(out_hl), "snf_layernorm_rows_hl_patch_f32: buffers must be 16-byte aligned");
+    RowCfg cfg;
+    SNF_REQUIRE(pick_row_cfg(d, true, &cfg) && cfg.vec == 4, "snf_layernorm_rows_hl_patch_f32: d=%d too wide (max 2048)", d);
+    hipStream_t s = snf::as_stream(stream);
+    SNF_ROW_DISPATCH(cfg, hipLaunchKernelGGL((layernorm_rows_kernel<VEC, NV>), dim3(row_grid(n)), dim3(WG), 0, s, x, n, d,
+                                              (const int32_t*)nullptr, (const float*)nullptr, gamma, beta, eps, (float*)nullptr,
+                                              reinterpret_cast<unsigned short*>(out_hl), (float*)nullptr, (float*)nullptr,
+                                              out_row_idx, 2, addend));
+    return snf::check_launch("layernorm_rows_kernel<hl patch>");
 }
 
 int snf_split_hl_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16, snf_stream_t stream) {

@@ -544,19 +544,21 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
             o, attn, _ = ops.sparse_attn_fwd(q.contiguous(), kp, v.contiguous(), h, need_attn=need_attn)
         del q, v, qv
         delta = _rows_linear(o, lo)                                     # snuffy.py:205
-        x_sel = xs + delta                                                          # snuffy.py:108
         if shared:
-            # y differs from x in the K selected rows only: re-normalise those into the image the first sublayer used
-            xn3.index_copy_(0, sel.long(), ops.layernorm_rows_hl(x_sel, None, None, n1.eps))
+            # y differs from x in the K selected rows only (x_sel = xs + delta, snuffy.py:108): re-normalise those into the image
+            # the first sublayer used -- one small launch: sum, statistics, hl rows written at their place
+            ops.layernorm_rows_hl_patch_(xn3, sel, xs, delta, eps=n1.eps)
             hid3 = ops.gemm_hl(xn3, fhf["w1"], fhf["b1"], ff.activation_name, hl_out=True)   # snuffy.py:224-225, [N, 2F] image
             del xn3
             z = ops.gemm_hl(hid3, fh["w2"], fw["b2"], resid=x2)                    # x + W2 hid + b2: the residual rides in the epilogue
         elif hl:
+            x_sel = xs + delta                                                      # snuffy.py:108
             yn3 = ops.layernorm_rows_hl(x2, n1.weight, n1.bias, n1.eps, slot=slot, patch_rows=x_sel)   # LN(y), y never built
             hid3 = ops.gemm_hl(yn3, fh["w1"], fw["b1"], ff.activation_name, hl_out=True)   # snuffy.py:224-225, [N, 2F] image
             del yn3
             z = ops.gemm_hl(hid3, fh["w2"], fw["b2"], resid=x2)                    # x + W2 hid + b2: the residual rides in the epilogue
         else:
+            x_sel = xs + delta                                                      # snuffy.py:108
             yn3 = ops.layernorm_rows_split3(x2, n1.weight, n1.bias, n1.eps, slot=slot, patch_rows=x_sel)
             hid3 = ops.gemm_x3(yn3, fw["w1"], fw["b1"], ff.activation_name, split3=True)   # [N, 3F] image
             del yn3

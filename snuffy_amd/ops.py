@@ -1116,6 +1116,25 @@ def layernorm_rows_hl(x, gamma, beta, eps=1e-5, slot=None, patch_rows=None):
     return out
 
 
+def layernorm_rows_hl_patch_(img, rows, x, addend=None, gamma=None, beta=None, eps=1e-5):
+    """LayerNorm of the rows of (x [k, d] + addend [k, d]) written over rows `rows` [k] int64 of the hl image img [n, 2 d] (in place)."""
+    x = _req(x, torch.float32, "x", 2)
+    k, d = x.shape
+    rows = _req(rows, torch.int64, "rows", 1)
+    if addend is not None:
+        addend = _req(addend, torch.float32, "addend", 2)
+    if img.dtype != torch.bfloat16 or img.dim() != 2 or img.shape[1] != 2 * d or not img.is_contiguous() or rows.shape[0] != k \
+            or (addend is not None and tuple(addend.shape) != (k, d)):
+        raise ValueError("layernorm_rows_hl_patch_: img %s rows %s x %s" % (tuple(img.shape), tuple(rows.shape), tuple(x.shape)))
+    if gamma is not None:
+        gamma = _req(gamma, torch.float32, "gamma", 1)
+    if beta is not None:
+        beta = _req(beta, torch.float32, "beta", 1)
+    check(_ffi.load().snf_layernorm_rows_hl_patch_f32(_p(x), _p(addend), k, d, _p(rows), _p(gamma), _p(beta), float(eps), _p(img),
+                                                      _stream()), "snf_layernorm_rows_hl_patch_f32")
+    return img
+
+
 def gemm_hl(a_hl, w_hl, bias=None, act="none", out_dtype=torch.float32, out=None, hl_out=False, resid=None):
     """fp32-class act(A W^T + bias) in ONE pass over the interleaved split images a_hl [m, 2 k], w_hl [n, 2 k] (split_hl_rows /
     layernorm_rows_hl / a previous call with hl_out=True; split_hl_weight): every product hi hi + hi lo + lo hi, fp32 accumulate.

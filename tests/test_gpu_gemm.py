@@ -240,6 +240,30 @@ def test_layernorm_rows_hl_is_the_interleaved_split_of_the_fp32_rows(n, d):
         assert torch.equal(got[:, :, 0].reshape(n, d), hi) and torch.equal(got[:, :, 1].reshape(n, d), lo)
 
 
+def test_layernorm_rows_hl_patch_writes_the_rows_in_place():
+    """snf_layernorm_rows_hl_patch_f32: LayerNorm(x + addend) of K rows written over chosen rows of an existing hl image == the
+    rows layernorm_rows_hl produces for the sum, bit for bit; the other rows untouched."""
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n, k, d = 5000, 200, 768
+    img = ops.layernorm_rows_hl(torch.randn(n, d, generator=g).to(DEV), None, None, 1e-5)
+    before = img.clone()
+    xs, dl = torch.randn(k, d, generator=g).to(DEV), torch.randn(k, d, generator=g).to(DEV)
+    rows = torch.randperm(n, generator=g)[:k].to(DEV)
+    gam, bet = torch.rand(d, generator=g).to(DEV) + 0.5, torch.randn(d, generator=g).to(DEV)
+    for kw in ({}, {"gamma": gam, "beta": bet}):
+        img.copy_(before)
+        ops.layernorm_rows_hl_patch_(img, rows, xs, dl, eps=1e-5, **kw)
+        want = ops.layernorm_rows_hl(xs + dl, kw.get("gamma"), kw.get("beta"), 1e-5)
+        assert torch.equal(img[rows], want)
+        keep = torch.ones(n, dtype=torch.bool, device=DEV)
+        keep[rows] = False
+        assert torch.equal(img[keep], before[keep])
+    img.copy_(before)
+    ops.layernorm_rows_hl_patch_(img, rows, xs, None)
+    assert torch.equal(img[rows], ops.layernorm_rows_hl(xs, None, None, 1e-5))
+
+
 def test_fp32_path_x3_projections_against_library_projections(monkeypatch):
     """One encoder layer of the fp32 path at config-A size: split-bf16 x3 projections vs the fp32 library GEMMs."""
     from snuffy_amd import functional as SF
