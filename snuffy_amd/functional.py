@@ -85,10 +85,41 @@ def critic_scores(feats, w, b):
     return s.view(*lead, w.shape[0])
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# When is a tensor derived from a parameter (folded / split / bf16 copies, captured graphs) stale?  The caches below key on
+# (data_ptr, _version) of the parameter -- but torch's FUSED optimizers (AdamW(fused=True): what train.py uses on the GPU) update the
+# parameters WITHOUT bumping their version counters (measured, torch 2.10: version 0 -> 0 across step(); foreach / default: +2).
+# Every optimizer step anywhere in the process therefore advances an epoch that is part of every key (a global post-step hook).
+# Edits through ``p.data`` are still invisible: invalidate() is the documented way to announce those.
+# ----------------------------------------------------------------------------------------------------------------------
+_PARAM_EPOCH = [0]
+
+
+def _on_optimizer_step(optimizer, args, kwargs):
+    _PARAM_EPOCH[0] += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook
+    _reg_post_hook(_on_optimizer_step)
+except ImportError:      # a torch without global optimizer hooks: the trainers of this package bump the epoch themselves
+    _reg_post_hook = None
+
+
+def bump_param_epoch():
+    """Announce that parameters were written in a way the version counters do not show (an optimizer this package cannot hook)."""
+    _PARAM_EPOCH[0] += 1
+
+
+def param_key(p):
+    """Cache key of anything derived from parameter p (see above)."""
+    return (id(p), p.data_ptr(), p._version, _PARAM_EPOCH[0])
+
+
 def split3_cached(weight, transposed=False):
     """[Wh | Wl | Wh] image of a parameter (ops.split3_weight) -- or of its transpose -- cached on the parameter until it is
     written again (optimizer step, load_state_dict)."""
-    key = (weight.data_ptr(), weight._version)
+    key = param_key(weight)
     name = "_snf_x3t" if transposed else "_snf_x3"
     hit = getattr(weight, name, None)
     if hit is None or hit[0] != key:
@@ -168,8 +199,7 @@ def shared_norm_layer(layer):
 def _xn3_key(x2, n0, shared):
     if shared:
         return (x2.data_ptr(), tuple(x2.shape), x2._version, float(n0.eps), "xhat")
-    return (x2.data_ptr(), tuple(x2.shape), x2._version, float(n0.eps), n0.weight.data_ptr(), n0.weight._version,
-            n0.bias.data_ptr(), n0.bias._version)
+    return (x2.data_ptr(), tuple(x2.shape), x2._version, float(n0.eps)) + param_key(n0.weight) + param_key(n0.bias)
 
 
 def _take_xn3(layer, x2, n0, shared=False):
@@ -327,7 +357,7 @@ def _folded(layer):
     ff = layer.feed_forward
     plist = [n0.weight, n0.bias, n1.weight, n1.bias, lq.weight, lq.bias, lv.weight, lv.bias, ff.w_1.weight,
              ff.w_1.bias, ff.w_2.weight, lk.weight, lk.bias]
-    key = tuple((id(p), p.data_ptr(), p._version) for p in plist)
+    key = tuple(param_key(p) for p in plist)
     ent = getattr(layer, "_fold", None)
     if ent is not None and ent[0] == key:
         return ent[1]
@@ -372,7 +402,7 @@ def _split_weights(layer):
     lq, lk, lv, lo = layer.self_attn.linears
     ff = layer.feed_forward
     plist = [lq.weight, lq.bias, lv.weight, lv.bias, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias]
-    key = tuple((id(p), p.data_ptr(), p._version) for p in plist)
+    key = tuple(param_key(p) for p in plist)
     ent = getattr(layer, "_fold3", None)
     if ent is not None and ent[0] == key:
         return ent[1]
@@ -407,7 +437,7 @@ def _hl_weights_folded(layer):
     lq, lk, lv, lo = layer.self_attn.linears
     ff = layer.feed_forward
     plist = [n0.weight, n0.bias, n1.weight, n1.bias, lq.weight, lq.bias, lv.weight, lv.bias, ff.w_1.weight, ff.w_1.bias]
-    key = tuple((id(p), p.data_ptr(), p._version) for p in plist)
+    key = tuple(param_key(p) for p in plist)
     ent = getattr(layer, "_fold3f", None)
     if ent is not None and ent[0] == key:
         return ent[1]

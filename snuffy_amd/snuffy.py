@@ -294,13 +294,13 @@ class MILNet(nn.Module):
         return all(type(l) is EncoderLayer and l.random_patch_share == 0 for l in self.b_classifier.encoder.layers)
 
     def _weights_signature(self):
-        """Changes whenever a parameter is written in place (optimizer step, load_state_dict), replaced (.to(), .half(),
+        """Changes whenever a parameter is written in place (optimizer step -- fused ones included, SF.param_key --, load_state_dict), replaced (.to(), .half(),
         load_state_dict(assign=True), module.weight = ...) or a selection knob of a layer is reassigned.  Not seen: edits
         through ``p.data`` (they do not bump the version counter) -- call ``invalidate()`` after those."""
         plist = list(self.parameters())
         knobs = tuple((l.big_lambda, l.random_patch_share) for l in self.b_classifier.encoder.layers)
         knobs += (SF.FP32_GEMM, SF.FP32_ATTENTION)      # module-level arithmetic switches are baked into a capture as well
-        return tuple((id(p), p.data_ptr(), p._version) for p in plist), knobs
+        return tuple(SF.param_key(p) for p in plist), knobs
 
     def invalidate(self):
         """Forget everything derived from the current weights: captured graphs and the folded bf16 weights of every layer."""

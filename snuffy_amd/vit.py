@@ -26,6 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import functional as SF
 from . import ops
 from ._ffi import SnuffyHipError
 
@@ -37,7 +38,7 @@ FP32_GEMM = "x3"
 def _image_of(weight, fmt):
     """Split image of a parameter ("hl": interleaved [hi(32) | lo(32)], ops.split_hl_weight; "cat": [Wh | Wl | Wh],
     ops.split3_weight), cached on the parameter until it is written again."""
-    key = (weight.data_ptr(), weight._version)
+    key = SF.param_key(weight)
     name = "_snf_img_" + fmt
     hit = getattr(weight, name, None)
     if hit is None or hit[0] != key:
@@ -385,7 +386,7 @@ class VisionTransformer(nn.Module):
 
     def _weights_bf16(self):
         params = list(self.parameters())
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = tuple(SF.param_key(p) for p in params)
         if self._bf16_cache is not None and self._bf16_cache[0] == key:
             return self._bf16_cache[1]
         bf = torch.bfloat16

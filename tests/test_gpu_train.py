@@ -444,3 +444,40 @@ def test_linear_x3_fn_forward_and_gradients_vs_fp64(n, k, m):
     for name, got, ref in (("y", y, yd), ("dx", x.grad, xd.grad), ("dw", w.grad, wd.grad), ("db", b.grad, bd.grad)):
         err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
         assert err < 3e-5, (name, err)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_forward_after_fused_optimizer_steps_uses_the_new_weights(precision):
+    """torch's fused AdamW (what the trainers use on the GPU) does not bump the parameters' version counters, which the folded /
+    split / bf16 weight caches and the captured graphs key on: every optimizer step advances SF.param_key's epoch instead.  Losses of
+    consecutive steps -- and an eval forward afterwards -- must equal those of a run that drops every cache after every step."""
+    import torch.nn as nn
+    from snuffy_amd.train import BagParallelStepper
+    from tests.helpers import build_amd_milnet
+
+    def run(inval):
+        torch.manual_seed(0)
+        net = build_amd_milnet(384, 6, "relu", 200, 0.0, 1).to(DEV)
+        for m in net.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+        g = torch.Generator().manual_seed(42)
+        bags = [torch.randn(1, 4096, 384, generator=g).to(DEV) for _ in range(2)]
+        labels = [torch.tensor([float(i % 2)], device=DEV) for i in range(2)]
+        st = BagParallelStepper(net, world_size=1, dist=None, device=DEV, precision=precision)
+        v0 = net.b_classifier.encoder.layers[0].feed_forward.w_1.weight._version
+        losses = []
+        for s in range(4):
+            losses.append(float(st.step(bags[s % 2], labels[s % 2])))
+            if inval:
+                net.invalidate()
+        net.eval()
+        with torch.no_grad():
+            ev = net(bags[0])[1].clone()
+        return losses, ev, net.b_classifier.encoder.layers[0].feed_forward.w_1.weight._version - v0
+
+    la, ea, dv = run(False)
+    lb, eb, _ = run(True)
+    assert la == lb and torch.equal(ea, eb), (la, lb, dv)
+    assert abs(la[2] - la[0]) > 1e-3      # the weights did move between the two sightings of bag 0
+

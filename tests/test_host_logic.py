@@ -160,3 +160,21 @@ def test_weight_gradient_split_k_matches_plain_contraction():
         assert out.dtype == torch.float32 and out.shape == (24, 40)
         # partials are rounded to bf16 once (2^-9 of their own scale ~ sqrt(n / chunks)) before the fp32 sum
         assert (out.double() - ref).abs().max().item() <= 8e-3 * max(1.0, (n / 8) ** 0.5 * 3), n
+
+
+def test_param_key_changes_with_every_optimizer_step():
+    """Cache keys of everything derived from a parameter advance on ANY optimizer step (a global post-step hook): torch's fused
+    optimizers write parameters without bumping their version counters."""
+    import torch
+    from snuffy_amd import functional as SF
+    p = torch.nn.Parameter(torch.randn(4, 4))
+    opt = torch.optim.AdamW([p], lr=1e-3)
+    k0 = SF.param_key(p)
+    assert SF.param_key(p) == k0
+    p.grad = torch.randn(4, 4)
+    opt.step()
+    k1 = SF.param_key(p)
+    assert k1 != k0 and k1[3] == k0[3] + 1
+    SF.bump_param_epoch()
+    assert SF.param_key(p)[3] == k1[3] + 1
+
