@@ -442,7 +442,9 @@ def _encoder_layer_train(x2, sel, layer, need_attn):
     else:
         xs = x2.index_select(0, sel)                                            # snuffy.py:131,145-147
         xn = LayerNormRowsFn.apply(x2, n0.weight, n0.bias, n0.eps)              # snuffy.py:107
-        if linear_x3_ok(xn, lq.weight) and lq.bias is not None and lv.bias is not None:
+        if (linear_x3_ok(xn, lq.weight) and lq.bias is not None and lv.bias is not None
+                and ops.gemm_x3_supported(xn.shape[0], 2 * lq.weight.shape[0], xn.shape[1])      # the fused [2d, d] projection and its dx
+                and ops.gemm_x3_supported(xn.shape[0], xn.shape[1], 2 * lq.weight.shape[0])):
             # fp32: split-bf16 x3 on the MFMA GEMM, forward and backward; Q | V as ONE projection (one image of xn, one dx)
             d = xn.shape[1]
             qv = LinearX3Fn.apply(xn, torch.cat([lq.weight, lv.weight]), torch.cat([lq.bias, lv.bias]))

@@ -11,6 +11,7 @@ void set_error(const char* fmt, ...);
 // Returns SNF_OK or SNF_ELAUNCH (and records the HIP error string) after a kernel launch.
 int check_launch(const char* what);
 int cu_count();
+unsigned long long device_bit();
 // gemm.hip: x [r, k] w [c, k]^T + bias written as the Kp fragment image of sparse_attn_x3p.hip (see SkinnyFrag there)
 int skinny_linear_x3_kpfrag(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int r, int c, int k, int dk,
                             int chunk_size, int64_t chunk_stride, float c_exp, void* frag, hipStream_t s);

@@ -38,6 +38,14 @@ int cu_count() {
     return cached;
 }
 
+// one bit per device id (ids >= 64 share bit 63: their opt-ins are then simply repeated): the key of the per-thread "this kernel has
+// its LDS opt-in on this device" masks -- hipFuncSetAttribute is per device, a thread that moves to another GPU has to repeat it
+unsigned long long device_bit() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev >= 63 ? 0ull : 1ull << dev;     // 0 = never remembered: always set
+}
+
 }  // namespace snf
 
 extern "C" {

@@ -697,7 +697,9 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
 template <int ACT, int OUT>
 int launch_hl(const GemmParams& P, hipStream_t s) {
     constexpr int lds = 2 * 2 * BM * 128;
-    static thread_local bool attr_set = false;
+    static thread_local unsigned long long attr_set_mask = 0;   // devices (bit = device id) that have the opt-in
+    const unsigned long long attr_set_bit = snf::device_bit();
+    const bool attr_set = (attr_set_mask & attr_set_bit) != 0;
     auto kern = gemm_hl_kernel<ACT, OUT>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -705,7 +707,7 @@ int launch_hl(const GemmParams& P, hipStream_t s) {
             (void)hipGetLastError();
             return SNF_ELAUNCH;
         }
-        attr_set = true;
+        attr_set_mask |= attr_set_bit;
     }
     const int ntiles = P.tiles_m * P.tiles_n;
     int grid = snf::cu_count() & ~7;
@@ -720,7 +722,9 @@ int launch_hl(const GemmParams& P, hipStream_t s) {
     int rc = snf::check_launch("gemm_hl_kernel");
     if (rc || P.split_cap < 2) return rc;
     // the last, partly filled round: every remainder tile on 2 .. 4 workgroups, a K range each (same grid: same tile -> XCD map)
-    static thread_local bool attr_set2 = false;
+    static thread_local unsigned long long attr_set2_mask = 0;   // devices (bit = device id) that have the opt-in
+    const unsigned long long attr_set2_bit = snf::device_bit();
+    const bool attr_set2 = (attr_set2_mask & attr_set2_bit) != 0;
     auto kern2 = gemm_hl_kernel<ACT, OUT, true>;
     if (!attr_set2) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -728,7 +732,7 @@ int launch_hl(const GemmParams& P, hipStream_t s) {
             (void)hipGetLastError();
             return SNF_ELAUNCH;
         }
-        attr_set2 = true;
+        attr_set2_mask |= attr_set2_bit;
     }
     hipLaunchKernelGGL(kern2, dim3(grid), dim3(512), lds, s, P);
     return snf::check_launch("gemm_hl_kernel<split>");
@@ -748,7 +752,9 @@ int launch_hl_act(const GemmParams& P, hipStream_t s) {
 template <int NI, int ACT, int OUT>
 int launch(const GemmParams& P, hipStream_t s) {
     constexpr int lds = NBUF * (A_BYTES + 64 * NI * ROWB);
-    static thread_local bool attr_set = false;
+    static thread_local unsigned long long attr_set_mask = 0;   // devices (bit = device id) that have the opt-in
+    const unsigned long long attr_set_bit = snf::device_bit();
+    const bool attr_set = (attr_set_mask & attr_set_bit) != 0;
     auto kern = gemm_bf16_kernel<NI, ACT, OUT>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
@@ -757,7 +763,7 @@ int launch(const GemmParams& P, hipStream_t s) {
             (void)hipGetLastError();
             return SNF_ELAUNCH;
         }
-        attr_set = true;
+        attr_set_mask |= attr_set_bit;
     }
     const int ntiles = P.tiles_m * P.tiles_n;
     int grid = snf::cu_count() & ~7;          // one persistent workgroup per CU, a multiple of the 8 XCDs

@@ -409,7 +409,9 @@ inline bool make_bwd_plan(int64_t n, int k, int h, int dk, BwdPlan* pl) {
 template <int DK, int NKB, typename QT, int MODE>
 int launch_bwd_mode(const BwdParams& P, const BwdPlan& pl, hipStream_t s) {
     const size_t lds = (size_t)2 * 32 * NKB * 2 * DK;
-    static thread_local bool attr_set = false;
+    static thread_local unsigned long long attr_set_mask = 0;   // devices (bit = device id) that have the opt-in
+    const unsigned long long attr_set_bit = snf::device_bit();
+    const bool attr_set = (attr_set_mask & attr_set_bit) != 0;
     auto kern = sparse_attn_bwd_mfma_kernel<DK, NKB, QT, MODE>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -418,7 +420,7 @@ int launch_bwd_mode(const BwdParams& P, const BwdPlan& pl, hipStream_t s) {
             (void)hipGetLastError();
             return SNF_ELAUNCH;
         }
-        attr_set = true;
+        attr_set_mask |= attr_set_bit;
     }
     hipLaunchKernelGGL(kern, dim3(pl.num_wg), dim3(256), lds, s, P);
     return snf::check_launch("sparse_attn_bwd_mfma_kernel");

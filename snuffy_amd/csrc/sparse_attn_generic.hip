@@ -562,6 +562,8 @@ int snf_sparse_attn_fwd_ragged_f32(const float* q, int64_t ldq, const float* v, 
     }
     SNF_REQUIRE(ldq >= (int64_t)h * dk && ldv >= (int64_t)h * dk, "snf_sparse_attn_fwd_ragged_f32: row pitch below h * dk");
     static thread_local size_t lds_set = 0;
+    static thread_local unsigned long long lds_dev = ~0ull;          // the opt-in is per device
+    if (lds_dev != snf::device_bit()) lds_set = 0, lds_dev = snf::device_bit();
     if (lds > lds_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(ragged_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {

@@ -573,7 +573,9 @@ int x3_launch(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s) {
     constexpr int NKS = DK / 16;
     constexpr int q_bytes = (TROWS / 32) * NKS * 1024, p_bytes = TROWS * p_row_bytes(NKB), v_bytes = TROWS * 2 * DK;
     constexpr int lds = 2 * q_bytes + 2 * p_bytes + 4 * v_bytes + 8 * TROWS * 8;   // Q hi|lo, P hi|lo, V 2 x (hi|lo), statistics
-    static thread_local bool attr_set = false;
+    static thread_local unsigned long long attr_set_mask = 0;   // devices (bit = device id) that have the opt-in
+    const unsigned long long attr_set_bit = snf::device_bit();
+    const bool attr_set = (attr_set_mask & attr_set_bit) != 0;
     auto kern = sparse_attn_x3_kernel<DK, NKB, AUX, MODE, VL>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -581,7 +583,7 @@ int x3_launch(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s) {
             (void)hipGetLastError();
             return SNF_ELAUNCH;
         }
-        attr_set = true;
+        attr_set_mask |= attr_set_bit;
     }
     hipLaunchKernelGGL(kern, dim3(pl.num_wg), dim3(512), lds, s, P);
     int rc = snf::check_launch("sparse_attn_x3_kernel");

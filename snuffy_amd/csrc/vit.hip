@@ -471,7 +471,9 @@ __global__ __launch_bounds__(VIT_ATTN_THREADS, 4) void vit_attention_mfma_kernel
 template <int NKB>
 int launch_vit_mfma(const unsigned short* qkv, int B, int T, int h, float scale, unsigned short* out, hipStream_t s) {
     const size_t lds = (size_t)(32 * NKB * (64 + 8)) * sizeof(unsigned short) + (size_t)32 * NKB * 128;
-    static thread_local bool attr_set = false;
+    static thread_local unsigned long long attr_set_mask = 0;   // devices (bit = device id) that have the opt-in
+    const unsigned long long attr_set_bit = snf::device_bit();
+    const bool attr_set = (attr_set_mask & attr_set_bit) != 0;
     auto kern = vit_attention_mfma_kernel<NKB>;
     if (!attr_set && lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -480,7 +482,7 @@ int launch_vit_mfma(const unsigned short* qkv, int B, int T, int h, float scale,
             (void)hipGetLastError();
             return SNF_ELAUNCH;
         }
-        attr_set = true;
+        attr_set_mask |= attr_set_bit;
     }
     hipLaunchKernelGGL(kern, dim3(h, B), dim3(VIT_ATTN_THREADS), lds, s, qkv, B, T, h, scale, out);
     return snf::check_launch("vit_attention_mfma_kernel");

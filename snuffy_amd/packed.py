@@ -96,7 +96,9 @@ def forward_bags(net, bags):
     are launch-latency bound -- ~25 launches per bag whatever its size).  bags: sequence of [1, N_b, D] (or [N_b, D]) fp32 GPU
     tensors.  Returns the list of (classes [1, N_b, 1], prediction_bag [1, C], A [1, h, N_b, K_b] or None) tuples the per-bag
     forwards return: same selections (bit-exact, random share included: the numpy draws are made bag by bag in the order the
-    per-bag forwards make them); a bag's outputs do not depend on what it is packed with.  Against the per-bag forwards the
+    per-bag forwards make them).  At kernel level (top-k, attention, head) a bag's result does not depend on what it is packed
+    with, bit for bit; the projections pick their kernel by the PACKED row count, so a bag's logits move by fp32 / bf16 rounding
+    with the batch composition (metrics computed from packed evaluation carry that rounding).  Against the per-bag forwards the
     top-k and head kernels are bit-identical, the attention sums its partial tiles in another order, and the projections
     run over the packed rows (a library / tile choice that depends on the row count): logits move by fp32 / bf16 rounding.
     Bags that select different numbers of rows (shorter than Lambda) or whose head width the MFMA kernels do not take are

@@ -379,8 +379,9 @@ class MILNet(nn.Module):
     # ---- many bags per launch (varlen path, implementation in packed.py) -------------------------------------------------
     def forward_bags(self, bags):
         """``[self(x) for x in bags]`` with the bags' rows packed into ONE set of launches (bags of <= 8 k patches are bound by the
-        ~25 launches per bag, not by the GPU).  Same selections as the per-bag forwards bit for bit (random share included), a bag's
-        outputs independent of what it is packed with, logits within fp32 / bf16 rounding of the per-bag forward; whatever cannot be
+        ~25 launches per bag, not by the GPU).  Same selections as the per-bag forwards bit for bit (random share included), logits
+        within fp32 / bf16 rounding of the per-bag forward (and of another batch composition: the projections choose their kernel by
+        the packed row count; top-k, attention and head kernels are composition-independent bit for bit); whatever cannot be
         packed takes the per-bag loop.  See packed.forward_bags."""
         from . import packed
         return packed.forward_bags(self, bags)
