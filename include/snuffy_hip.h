@@ -177,7 +177,8 @@ int snf_linear_rows_x3_f32(const float* x, int64_t ldx, const float* w, int64_t 
                            int64_t ldo, int out_dtype, snf_stream_t stream);
 /* critic scores + LayerNorm (with affine) of the same rows in one pass, the normalised rows as the interleaved hi / lo image
  * (= snf_critic_f32 + snf_layernorm_rows_hl_f32 with one read of x; FCLayer.forward snuffy.py:39-41 + SublayerConnection.norm
- * snuffy.py:107).  d % 32 == 0; selector_state nullable (one class: also counts the selector's first radix digit). */
+ * snuffy.py:107).  d % 32 == 0; selector_state nullable (one class: also counts the selector's first radix digit); gamma and beta
+ * both NULL = the affine-free image (x - mean) * rstd (one normalised image for both sublayers, affines folded into the projections). */
 int snf_critic_ln_hl_f32(const float* x, int64_t n, int d, const float* w, const float* b, int c_out, float* scores,
                          const float* gamma, const float* beta, float eps, void* out_hl, void* selector_state,
                          snf_stream_t stream);

@@ -165,12 +165,15 @@ __global__ __launch_bounds__(WG) void critic_kernel(const float* __restrict__ x,
             if constexpr (LN == 2 && VEC == 4) {
                 // affine (the registers that held the critic weights' row are free again only after the loop: gamma / beta are
                 // re-read per row from L1 / L2 -- 2 x d floats against the d floats of the row itself)
-                float g[NV * VEC], bt[NV * VEC];
-                load_row<VEC, NV>(gamma, d, lane, g);
-                load_row<VEC, NV>(beta, d, lane, bt);
+                // gamma == null: the affine-free image (one normalised image for both sublayers, affines folded into the projections)
+                if (gamma) {
+                    float g[NV * VEC], bt[NV * VEC];
+                    load_row<VEC, NV>(gamma, d, lane, g);
+                    load_row<VEC, NV>(beta, d, lane, bt);
 #pragma unroll
-                for (int i = 0; i < NV * VEC; ++i) {
-                    r[i] = fmaf(r[i], g[i], bt[i]);
+                    for (int i = 0; i < NV * VEC; ++i) {
+                        r[i] = fmaf(r[i], g[i], bt[i]);
+                    }
                 }
                 unsigned short* o2 = xhat + row * 2 * d;
 #pragma unroll
@@ -1180,12 +1183,12 @@ int snf_critic_select_f32(const float* x, int64_t n, int d, const float* w, cons
 int snf_critic_ln_hl_f32(const float* x, int64_t n, int d, const float* w, const float* b, int c_out, float* scores,
                          const float* gamma, const float* beta, float eps, void* out_hl, void* selector_state,
                          snf_stream_t stream) {
-    SNF_REQUIRE(x && w && scores && gamma && beta && out_hl, "snf_critic_ln_hl_f32: null pointer");
+    SNF_REQUIRE(x && w && scores && out_hl && (!gamma == !beta), "snf_critic_ln_hl_f32: null pointer (gamma and beta: both or neither)");
     SNF_REQUIRE(n >= 1 && d >= 32 && d % 32 == 0 && c_out >= 1, "snf_critic_ln_hl_f32: bad shape n=%lld d=%d c=%d (d % 32 == 0)",
                 (long long)n, d, c_out);
     SNF_REQUIRE(!selector_state || (c_out == 1 && aligned16(selector_state)), "snf_critic_ln_hl_f32: the selector needs one class "
                 "and a 16-byte aligned state");
-    SNF_REQUIRE(aligned16(x) && aligned16(w) && aligned16(gamma) && aligned16(beta) && aligned16(out_hl),
+    SNF_REQUIRE(aligned16(x) && aligned16(w) && (!gamma || (aligned16(gamma) && aligned16(beta))) && aligned16(out_hl),
                 "snf_critic_ln_hl_f32: buffers must be 16-byte aligned");
     RowCfg cfg;
     SNF_REQUIRE(pick_row_cfg(d, true, &cfg) && cfg.vec == 4, "snf_critic_ln_hl_f32: d=%d too wide (max 2048)", d);

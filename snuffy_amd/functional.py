@@ -171,22 +171,11 @@ def critic_scores_with_hl(feats, w, b, layer):
         layer._xn3_offer = None
         return critic_scores(feats, w, b)
     if shared_norm_layer(layer):
-        one, zero = _unit_affine(f2.device, f2.shape[1])
-        s, img = ops.critic_ln_hl(f2, w, b, one, zero, n0.eps)          # xhat itself: the affine lives in the folded weights
+        s, img = ops.critic_ln_hl(f2, w, b, None, None, n0.eps)         # xhat itself: the affine lives in the folded weights
     else:
         s, img = ops.critic_ln_hl(f2, w, b, n0.weight, n0.bias, n0.eps)
     layer._xn3_offer = (_xn3_key(f2, n0, shared_norm_layer(layer)), img)
     return s.view(*lead, w.shape[0])
-
-
-_UNIT_AFFINE = {}
-
-
-def _unit_affine(device, d):
-    ent = _UNIT_AFFINE.get((str(device), d))
-    if ent is None:
-        ent = _UNIT_AFFINE[(str(device), d)] = (torch.ones(d, device=device), torch.zeros(d, device=device))
-    return ent
 
 
 def shared_norm_layer(layer):

@@ -149,8 +149,11 @@ def critic_ln_hl(x, w, b, gamma, beta, eps):
     w = _req(w, torch.float32, "w", 2)
     if b is not None:
         b = _req(b, torch.float32, "b", 1)
-    gamma = _req(gamma, torch.float32, "gamma", 1)
-    beta = _req(beta, torch.float32, "beta", 1)
+    if (gamma is None) != (beta is None):
+        raise ValueError("critic_ln_hl: gamma and beta: both or neither (neither = the affine-free image)")
+    if gamma is not None:
+        gamma = _req(gamma, torch.float32, "gamma", 1)
+        beta = _req(beta, torch.float32, "beta", 1)
     n, d = x.shape
     c = w.shape[0]
     if w.shape[1] != d or d % 32:
