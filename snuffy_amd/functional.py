@@ -479,14 +479,16 @@ def _rows_linear(x, lin):
     return F.linear(x, lin.weight, lin.bias)
 
 
-def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None):
+def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None, last=False):
     """EncoderLayer.forward (snuffy.py:126-157) for x2 [N, D] and selected rows sel [K].  Returns (Parts, A).
 
     packed (ops.PackedBags, inference only): x2 holds the rows of B bags and sel the B x K selected rows in packed coordinates
     (bag b's K rows at sel[b K : (b + 1) K]).  Everything row-wise runs once over the packed rows; only the attention changes
     kernel entry (one varlen launch: every bag attends to its own K keys).  A is then [1, h, T, K] over the packed rows.
     ragged (ops.RaggedKeys, with packed): the bags select different numbers of rows (sel is their concatenation) -- small bags,
-    exact-fp32 ragged attention kernel, A [1, h, T, Kmax] with bag b's columns 0 .. K_b - 1 valid."""
+    exact-fp32 ragged attention kernel, A [1, h, T, Kmax] with bag b's columns 0 .. K_b - 1 valid.
+    last: the result goes straight to head() (no layer follows): the fp32 paths then leave the K patched rows to the head kernel's
+    read (Parts with slot / delta) instead of scattering them into z with a launch of their own."""
     if packed is None and torch.is_grad_enabled() and (x2.requires_grad or any(p.requires_grad for p in layer.parameters())):
         from . import autograd as SA  # training path (custom backward kernels); also when only the input asks for a gradient
         return SA.encoder_layer_train(x2, sel, layer, need_attn, precision)
@@ -584,6 +586,8 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
             z = ops.gemm_x3(hid3, fw["w2"], fw["b2"], out_dtype=torch.float32)
             z.add_(x2)
         del hid3
+        if last:                                                                    # rows S: x -> x_sel (snuffy.py:155), in the head's read
+            return Parts(z, slot=slot, delta=delta), (attn.unsqueeze(0) if attn is not None else None)
         ops.scatter_add_rows_(z, sel, delta)                                        # rows S: x -> x_sel (snuffy.py:155)
         return Parts(z), (attn.unsqueeze(0) if attn is not None else None)
 

@@ -123,7 +123,8 @@ class Encoder(nn.Module):
                 x2 = SF.materialize(parts)
             if top is None:
                 top = SF.select_top(c1, layer.big_lambda, layer.top_big_lambda_share, x2.shape[0])
-            parts, attn = layer.run(x2, c1, top, need_attn=(li == n_layers - 1) and self.cfg.return_attention)
+            parts, attn = layer.run(x2, c1, top, need_attn=(li == n_layers - 1) and self.cfg.return_attention,
+                                    last=li == n_layers - 1)
         return parts, attn
 
     def forward(self, x, c):
@@ -186,11 +187,11 @@ class EncoderLayer(nn.Module):
         rnd = np.random.choice(remaining, k2, replace=False)
         return top, torch.from_numpy(rnd.astype(np.int64)).to(top.device)
 
-    def run(self, x2, c1, top=None, need_attn=True):
+    def run(self, x2, c1, top=None, need_attn=True, last=False):
         top, rnd = self.select(c1, x2.shape[0], top)
         self.last_selection = (top, rnd)                    # inspection hook (tests / heat-maps)
         sel = top if rnd is None else torch.cat((top, rnd))
-        return SF.encoder_layer(x2, sel, self, need_attn, self.cfg.precision)
+        return SF.encoder_layer(x2, sel, self, need_attn, self.cfg.precision, last=last)
 
     def forward(self, x, c):
         "x [1, N, D], c [1, N, 1] -> (z [1, N, D], A [1, h, N, K])"
