@@ -26,6 +26,8 @@ for line in table:
                     "| 93–96 + 7 µs at config B (0.24) | round-3 kernel, operands split in registers |")
         rows.append("| **`gemm_hl_kernel`** (gemm.hip) | every fp32-class projection that fills the chip (Q\\|V with hl output, FFN-in, FFN-out + residual) | MFMA target "
                     "| Q\\|V 194–216 µs, FFN-in 397–433, FFN-out 386–423 → ≈ 1.1 PF/s issued; 79 % of the fp32 bag | see \"GEMM\" below |")
+    elif line.startswith("| `critic_kernel<ln>`"):
+        rows.append(line.replace("the histogram adds 0–1 µs |", "the histogram adds 0–1 µs; fp32 path (round 4): scores + the affine-free hl image `xhat` in one pass 41 µs (200 MB: 4.9 TB/s) |"))
     else:
         rows.append(line)
 layout = sect(105, 116).replace(
