@@ -1184,7 +1184,9 @@ _HL_WS = {}
 
 def _hl_workspace(device, nbytes):
     """Per-device workspace of the split-K GEMM: tickets (zero between launches; zeroed here once) + partial-tile slabs.  One buffer
-    per device, grown on demand: launches on a device's compute stream are ordered, so they can share it."""
+    per device, grown on demand: launches on a device's compute stream are ordered, so they can share it.  (Callers that drive
+    gemm_hl from SEVERAL streams of one device concurrently must set GEMM_HL_SPLITK = False or serialise those launches: the tickets
+    are shared.  The C entry point takes the workspace from its caller and has no such state.)"""
     key = str(device)
     ws = _HL_WS.get(key)
     if ws is None or ws.numel() < nbytes:
