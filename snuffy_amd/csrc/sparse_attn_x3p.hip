@@ -729,6 +729,7 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel
         X3P_WAIT_VM0();
         __builtin_amdgcn_s_barrier();
         int slot_q = 0, slot_v = 2;           // (i + 1) % 3, i % 3 for i = -1
+#pragma clang loop unroll(disable)
         for (int i = -1; i < T; ++i) {
             // head changes (wave-uniform, rare): accumulators of a finished head out, Kp fragments of the next head in
             if (MODE != 1 && i >= 0 && c0.a != head_g2) {
