@@ -452,7 +452,10 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel
         //     16 + 2          score r: x_r = s_r - max | e_(r-1) = exp2(x_(r-1)) | sum += e_(r-2)
         //     1               sum across the halves, publish (max, sum) of the wave's 32 rows
         //     UQ + UV         one LDS-DMA instruction each: rows of Q(i + 3) / V(i + 2)
-        constexpr int U_CMAX = 1, U_CW = 2, U_FS = U_CW + NW + 2, U_NORM = U_FS + 1, N_FIRST = U_NORM + 12;
+        // (the combine of the waves' (max, sum) pairs is split over the two lane halves, which hold the same rows: half hf takes the
+        //  waves 2 i + hf and the halves meet through v_permlane32_swap -- NH = ceil(NW / 2) pairs per lane instead of NW)
+        constexpr int NH = (NW + 1) / 2;
+        constexpr int U_CMAX = 1, U_CW = 2, U_FS = U_CW + NH + 2, U_NORM = U_FS + 1, N_FIRST = U_NORM + 12;
         // second-half sequence: offsets | max, max, halves | NXS exp stages with the NDU DMA instructions spread between them | publish
         // exp stages work on PAIRS of scores (v_pk_add_f32 for the subtraction and the running sums; the exponentials are scalar)
         constexpr int NXS = 10;
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel
             float mx0, mx1, m, l, fscale, d0, d1, e0, e1;
             f32x2 l2, x0, x1;
             int doff;                         // per-lane source offset of the wave's NEXT DMA instruction (fetched from LDS one unit ahead)
-            f32x2 sv[NW];
+            f32x2 sv[(NW + 1) / 2];
             f32x4 p4;
             unsigned h01, h23;
             float r0, r1, r2, r3;
@@ -508,23 +511,33 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel
                         s.l = fmaf(pr[1], __builtin_amdgcn_exp2f(pr[0] - s.m), s.l);
                     }
                 } else {
+                    const int st_h = st_lane + hf * (TR * 8);
 #pragma unroll
-                    for (int b = 0; b < NW; ++b) s.sv[b] = *reinterpret_cast<const f32x2*>(smem + st_lane + (par_n * NW + b) * (TR * 8));
+                    for (int i = 0; i < NH; ++i) {
+                        constexpr int last = NW - 1;
+                        // wave 2 i + hf; past the last wave (odd NW, upper half, last pair): re-read the last wave's pair and void it
+                        const bool over = 2 * i + 1 > last;         // compile-time per i: only the upper half can be over
+                        const int b_off = over ? (par_n * NW + last) * (TR * 8) - hf * (TR * 8) : (par_n * NW + 2 * i) * (TR * 8);
+                        f32x2 pr = *reinterpret_cast<const f32x2*>(smem + st_h + b_off);
+                        if (over) pr = hf ? f32x2{-INFINITY, 0.f} : pr;
+                        s.sv[i] = pr;
+                    }
                 }
             } else if constexpr (u == U_CMAX) {
                 if constexpr (MODE != 2) {
                     float m = s.sv[0][0];
 #pragma unroll
-                    for (int b = 1; b < NW; ++b) m = fmaxf(m, s.sv[b][0]);
-                    s.m = m, s.l = 0.f;
+                    for (int b = 1; b < NH; ++b) m = fmaxf(m, s.sv[b][0]);
+                    s.m = xhalf_max(m), s.l = 0.f;
                 }
             } else if constexpr (u < U_FS) {
                 if constexpr (MODE == 2) return;
                 constexpr int b = u - U_CW;       // stage b: sub of wave b, exp of wave b - 1, fma of wave b - 2
                 if constexpr (b >= 2) s.l = fmaf(s.sv[b - 2][1], (b & 1) ? s.e1 : s.e0, s.l);
-                if constexpr (b >= 1 && b - 1 < NW) ((b & 1) ? s.e0 : s.e1) = __builtin_amdgcn_exp2f((b & 1) ? s.d0 : s.d1);
-                if constexpr (b < NW) ((b & 1) ? s.d1 : s.d0) = s.sv[b][0] - s.m;
+                if constexpr (b >= 1 && b - 1 < NH) ((b & 1) ? s.e0 : s.e1) = __builtin_amdgcn_exp2f((b & 1) ? s.d0 : s.d1);
+                if constexpr (b < NH) ((b & 1) ? s.d1 : s.d0) = s.sv[b][0] - s.m;
             } else if constexpr (u == U_FS) {
+                if constexpr (MODE != 2) s.l = xhalf_sum(s.l);   // the two halves' partial sums of the row
                 const bool rvalid = j < rows_ok;
                 if constexpr (MODE == 1) {   // this chunk's pair of the row; nothing else happens to tile i in a statistics pass
                     if (rvalid && hf == 0 && w == 0) P.stats[((int64_t)chunk * P.h + cno.a) * P.n + cno.t * TR + j] = f32x2{s.m, s.l};
