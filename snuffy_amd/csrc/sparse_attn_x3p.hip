@@ -186,7 +186,11 @@ constexpr int x3p_lds_bytes(int dk, int nkb) {
 template <int DK, int NKB, bool AUX, int MODE>
 __global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel(const X3PParams P) {
     static_assert(DK == 128 && MODE >= 0 && MODE <= 2, "sparse_attn_x3p: dk = 128");
-    constexpr bool DRAIN = AUX || MODE != 0;   // global loads / stores of the kernel's own in the loop: no counted DMA waits
+    // Counted DMA waits need every other vector-memory operation of the wave to be ordered with the DMA loads.  Global STORES are not
+    // (AUX: the attention matrix; MODE 1: the statistics pairs): those builds drain.  The statistics LOADS of MODE 2 are loads like
+    // the DMA -- returned in order, and waited for by the compiler before their use in the first half of the iteration, long before
+    // the counted wait at its end -- so the main pass of a key-chunked launch keeps its prefetch depth.
+    constexpr bool DRAIN = AUX || MODE == 1;
     constexpr int NW = NKB;                  // waves: one per key block
 #ifndef X3P_NACC
 #define X3P_NACC 1   // measured: 2 (no MFMA behind its predecessor's result) costs 16 registers + 16 adds and buys nothing at 2 waves / SIMD
@@ -413,6 +417,10 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel
         // ---- state
         f32x16 Ta, Tb;                        // score accumulators of GEMM1 (tile i + 1), even / odd MFMAs
         f32x2 E2[8];                          // exp2(s - max) of tile i, as register pairs (packed fp32 arithmetic)
+        constexpr int NPF = 4;                // MODE 2, up to NPF chunks: the chunks' (max, sum) of the NEXT tile's rows, one iteration ahead
+        f32x2 pf[NPF];
+#pragma unroll
+        for (int c = 0; c < NPF; ++c) pf[c] = f32x2{c == 0 ? 0.f : -INFINITY, c == 0 ? 1.f : 0.f};
         float mw = 0.f;                       // the wave's row maximum that belongs to E
         f32x16 acc_o[NCB];
 #pragma unroll
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel
             return x;
         };
         // cno / rows_ok: the (head, tile) of tile i and the number of its rows that exist (0 in the fill iteration: P := 0)
-        auto unit = [&](auto u_t, VS& s, int par_n, const Cur cno, int rows_ok, const DmaCtx& dc) __attribute__((always_inline)) {
+        auto unit = [&](auto u_t, VS& s, int par_n, const Cur cno, const Cur cnx, int rows_ok, const DmaCtx& dc) __attribute__((always_inline)) {
             constexpr int u = decltype(u_t)::value;
 #ifdef X3P_ABL_NO_U1
             if constexpr (u < N_FIRST) return;
@@ -500,15 +508,40 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel
 #endif
             if constexpr (u == 0) {
                 if constexpr (MODE == 2) {   // every chunk's (max, sum) of this lane's row, from the statistics passes
-                    int row = cno.t * TR + j;
-                    if (row > n32 - 1) row = n32 - 1;
-                    const f32x2* st = P.stats + (int64_t)cno.a * P.n + row;
-                    s.m = -INFINITY;
-                    for (int c = 0; c < P.nchunks; ++c) s.m = fmaxf(s.m, st[(int64_t)c * P.h * P.n][0]);
-                    s.l = 0.f;
-                    for (int c = 0; c < P.nchunks; ++c) {
-                        const f32x2 pr = st[(int64_t)c * P.h * P.n];
-                        s.l = fmaf(pr[1], __builtin_amdgcn_exp2f(pr[0] - s.m), s.l);
+                    if (P.nchunks == 2) {   // config C: the two-chunk form without the loop's predicates (485 -> 440 us for its main pass)
+                        s.m = fmaxf(pf[0][0], pf[1][0]);
+                        s.l = fmaf(pf[1][1], __builtin_amdgcn_exp2f(pf[1][0] - s.m), pf[0][1] * __builtin_amdgcn_exp2f(pf[0][0] - s.m));
+                        int row = cnx.t * TR + j;
+                        if (row > n32 - 1) row = n32 - 1;
+                        const f32x2* st = P.stats + (int64_t)cnx.a * P.n + row;
+                        pf[0] = st[0], pf[1] = st[(int64_t)P.h * P.n];
+                    } else if (P.nchunks <= NPF) {
+                        // up to four chunks (config C: two): the pairs of tile i were requested a whole iteration ago (a global round
+                        // trip in the first half of every iteration was a stall of its own: 533 -> 440 us for config C's main
+                        // pass); request tile i + 1's now
+                        s.m = pf[0][0];
+#pragma unroll
+                        for (int c = 1; c < NPF; ++c) s.m = fmaxf(s.m, pf[c][0]);
+                        s.l = 0.f;
+#pragma unroll
+                        for (int c = 0; c < NPF; ++c) s.l = fmaf(pf[c][1], __builtin_amdgcn_exp2f(pf[c][0] - s.m), s.l);
+                        int row = cnx.t * TR + j;
+                        if (row > n32 - 1) row = n32 - 1;
+                        const f32x2* st = P.stats + (int64_t)cnx.a * P.n + row;
+#pragma unroll
+                        for (int c = 0; c < NPF; ++c)
+                            if (c < P.nchunks) pf[c] = st[(int64_t)c * P.h * P.n];   // (absent chunks keep (-inf, 0): no contribution)
+                    } else {
+                        int row = cno.t * TR + j;
+                        if (row > n32 - 1) row = n32 - 1;
+                        const f32x2* st = P.stats + (int64_t)cno.a * P.n + row;
+                        s.m = -INFINITY;
+                        for (int c = 0; c < P.nchunks; ++c) s.m = fmaxf(s.m, st[(int64_t)c * P.h * P.n][0]);
+                        s.l = 0.f;
+                        for (int c = 0; c < P.nchunks; ++c) {
+                            const f32x2 pr = st[(int64_t)c * P.h * P.n];
+                            s.l = fmaf(pr[1], __builtin_amdgcn_exp2f(pr[0] - s.m), s.l);
+                        }
                     }
                 } else {
                     const int st_h = st_lane + hf * (TR * 8);
@@ -633,7 +666,7 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel
         // The SAME body runs the fill (i = -1: tile -1 does not exist -> rows_ok = 0, P = 0; its accumulators are zeroed again
         // before tile 0) and the drain (i = T - 1: GEMM1 / statistics of a tile T that does not exist run on stale operands and
         // are never consumed): one code path means one register allocation, and no spill code anywhere near the loop.
-        auto iteration = [&](int i, int slot_q, int slot_v, const Cur cno, const DmaCtx& dc, int rows_ok) __attribute__((always_inline)) {
+        auto iteration = [&](int i, int slot_q, int slot_v, const Cur cno, const Cur cnx, const DmaCtx& dc, int rows_ok) __attribute__((always_inline)) {
             const int par_n = i & 1;
             const int qa = q_lane + slot_q * QSLOT;         // Q(i + 1): slot (i + 1) % 3
             int va[NCB];                                    // V(i): slot i % 3
@@ -667,7 +700,7 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel
                         if constexpr (mi == 2) vh[0] = v_frag(va[0], 0, 0), vh[1] = v_frag(va[1], 0, 0);
                     }
                     static_for<X3P_UB(k), X3P_UB(k + 1)>([&](auto u_t) __attribute__((always_inline)) {
-                        unit(u_t, vs, par_n, cno, rows_ok, dc);
+                        unit(u_t, vs, par_n, cno, cnx, rows_ok, dc);
                     });
                 });
             });
@@ -696,7 +729,7 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel
                         if constexpr (n0 == 0 && mi == 1) pl[sk1] = p_frag(sk1, 1);
                     }
                     static_for<X3P_UB(k), X3P_UB(k + 1)>([&](auto u_t) __attribute__((always_inline)) {
-                        unit(u_t, vs, par_n, cno, rows_ok, dc);
+                        unit(u_t, vs, par_n, cno, cnx, rows_ok, dc);
                     });
                 });
             });
@@ -764,7 +797,7 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel
             const bool dov = MODE != 1 && i + 2 < T;   // a statistics pass never touches V
             DmaCtx dc = {};
             if constexpr (ISS) dc = dma_ctx(i + 3 < T, c3, slot_v, dov, c2, slot_q == 2 ? 0 : slot_q + 1);
-            iteration(i, slot_q, slot_v, c0, dc, rows_ok);
+            iteration(i, slot_q, slot_v, c0, i + 1 < T ? c1 : c0, dc, rows_ok);   // (item T does not exist: any valid cursor)
             // everything issued BEFORE this iteration has landed for this wave; together with the barrier: for every wave
             if constexpr (ISS) {
                 const uint64_t want = full_mask & ((i + 3 < T ? QBITS : 0ull) | (dov ? VBITS : 0ull));
