@@ -177,8 +177,11 @@ constexpr int x3p_issuers(int nkb) { return x3p_loader(nkb) ? 1 : nkb; }
 constexpr int x3p_waves(int nkb) { return nkb + (x3p_loader(nkb) ? 1 : 0); }
 constexpr int x3p_lds_bytes(int dk, int nkb) {
     const int nq = x3p_qslot(dk) / 1024, nv = TR * 4 * dk / 1024, nl = x3p_issuers(nkb);
+    // (offset table of the issuing waves; the statistics pass of an all-issue configuration has one issuer fewer -- see the kernel)
+    const int t_all = nl * (x3p_dma_u(nq, nl) + x3p_dma_u(nv, nl)) * 256;
+    const int t_m1 = nl > 1 ? (nl - 1) * (x3p_dma_u(nq, nl - 1) + x3p_dma_u(nv, nl - 1)) * 256 : 0;
     return 3 * x3p_qslot(dk) + 3 * TR * 4 * dk + nkb * (TR * 64 * 2) + 2 * nkb * TR * 8 +
-           (x3p_loader(nkb) ? 0 : nl * (x3p_dma_u(nq, nl) + x3p_dma_u(nv, nl)) * 256);
+           (x3p_loader(nkb) ? 0 : (t_all > t_m1 ? t_all : t_m1));
 }
 
 // MODE 0: all keys in this launch.  MODE 1: statistics pass of one key chunk (GEMM1 + max / sum per row, written to P.stats; no
@@ -190,7 +193,9 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel
     // (AUX: the attention matrix; MODE 1: the statistics pairs): those builds drain.  The statistics LOADS of MODE 2 are loads like
     // the DMA -- returned in order, and waited for by the compiler before their use in the first half of the iteration, long before
     // the counted wait at its end -- so the main pass of a key-chunked launch keeps its prefetch depth.
-    constexpr bool DRAIN = AUX || MODE == 1;
+    // A statistics pass stores from wave 0 only: in the all-issue configurations that wave issues no DMA (the others share its part),
+    // and where a loader wave exists the key-block waves issue none anyway.
+    constexpr bool DRAIN = AUX;
     constexpr int NW = NKB;                  // waves: one per key block
 #ifndef X3P_NACC
 #define X3P_NACC 1   // measured: 2 (no MFMA behind its predecessor's result) costs 16 registers + 16 adds and buys nothing at 2 waves / SIMD
@@ -206,7 +211,9 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel
     constexpr int VSLOT = TR * ROWB;         // 16 KiB, rows of [hi plane 256 B | lo plane 256 B], 64-byte groups XOR-rotated
     constexpr int NVDMA = VSLOT / 1024;      // 16
     constexpr bool LOADER = x3p_loader(NKB);                                // wave NKB issues all the LDS-DMA (else: every wave its share)
-    constexpr int NL = x3p_issuers(NKB);
+    constexpr int L0 = (!LOADER && MODE == 1) ? 1 : 0;                      // first issuing wave (all-issue configurations)
+    constexpr int NL = LOADER ? 1 : NW - L0;
+    static_assert(NL >= 1, "sparse_attn_x3p: no wave left to issue the DMA");
     constexpr int UQ = x3p_dma_u(NQDMA, NL), UV = x3p_dma_u(NVDMA, NL);   // DMA instructions per issuing wave and tile, at most
     static_assert(UQ + UV <= 40, "DMA instructions per wave: 64-bit masks, counted waits up to 40");
     constexpr int Q_OFF = 0, V_OFF = 3 * QSLOT, P_OFF = V_OFF + 3 * VSLOT;
@@ -274,10 +281,10 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel
     };
     // The per-lane source offsets of a FULL tile (row_in_tile * ld_bytes + 16 * chunk) are parked in LDS: registers are the scarce
     // resource of this kernel, and an offset is needed once per iteration.
-    const bool issuer = LOADER ? w == NW : true;
-    const int li = LOADER ? 0 : w;
+    const bool issuer = LOADER ? w == NW : w >= L0;
+    const int li = (LOADER || w < L0) ? 0 : w - L0;
     int* const dma_tab = reinterpret_cast<int*>(smem + TB_OFF) + li * ((UQ + UV) * 64) + lane;
-    if (!LOADER) {
+    if (!LOADER && issuer) {
 #pragma unroll
         for (int u = 0; u < UQ; ++u) {
             int row, chunk;
@@ -819,7 +826,9 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB), 2) void sparse_attn_x3p_kernel
     // (in-kernel trace: first half 1450 ticks for waves 0-3, 2480 for waves 4-6): static priority for them (guide T5, static form)
     if (w >= 4) __builtin_amdgcn_s_setprio(1);
     if constexpr (!LOADER) {
-        if (w == NW - 1)
+        if (L0 > 0 && w < L0)
+            run(std::false_type{}, std::false_type{});    // statistics pass, wave 0: stores the pairs, issues no DMA
+        else if (w == NW - 1)
             run(std::true_type{}, std::true_type{});
         else
             run(std::false_type{}, std::true_type{});
