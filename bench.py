@@ -208,6 +208,25 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
             rec = json.load(f)
         if rec.get("kernel", kern) == kern:
             traffic = int(rec["total_bytes"])
+    # the same kernels INSIDE the bag pipeline, from the newest committed rocprofv3 kernel-stats summary of this workload / precision
+    # (profiles/r*_bench_<workload>_<precision>_kernel_stats.csv: AverageNs of every kernel of `kern`) -- the live figure above is
+    # the dispatched unit on cold operands, this one is what the unit costs where the model runs it
+    in_bag = None
+    import csv
+    sfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                           "r*_bench_%s_%s_kernel_stats.csv" % (wl_name, precision))))
+    if sfiles:
+        with open(sfiles[-1]) as f:
+            rows = list(csv.DictReader(f))
+        parts = {}
+        for kname in kern.split("+"):
+            hit = [r for r in rows if kname + "<" in r["Name"] or kname + "(" in r["Name"]]
+            if hit:
+                calls = max(int(r["Calls"]) for r in hit)        # several instantiations of one kernel: per-bag total
+                parts[kname] = round(sum(float(r["TotalDurationNs"]) for r in hit) / calls / 1e3, 2)
+        if parts and kern.split("+")[0] in parts:
+            in_bag = dict(us_per_launch=round(sum(parts.values()), 2), kernels_us=parts, source=os.path.basename(sfiles[-1]),
+                          frac=round(b_attn / (sum(parts.values()) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4))
     # `achieved` / `frac` price the launch at the bytes it has to move at ITS operand width (bf16 Q, V, Kp here).  SURVEY
     # section 8(d) prices the same unit at the reference's fp32 tensors (8ND + 8KD; with the selector 8ND + 4N + 16KD + 8K):
     # that figure is reported next to it as survey_8d_* -- same time, twice the bytes on the bf16 path.
@@ -218,6 +237,8 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
                            us_per_launch=round(t_attn * 1e3, 2), algorithmic_bytes=b_attn,
                            flops=4 * N * K * D * (3 if kern.startswith("sparse_attn_x3") else 1), operand_dtype=precision, survey_8d_bytes=b_attn_8d,
                            survey_8d_frac=round(b_attn_8d / (t_attn * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+    if in_bag is not None:
+        out["roofline"]["in_bag_rocprof"] = in_bag
     if t_warm is not None:
         out["roofline"]["after_producer"] = dict(us_per_launch=round(t_warm * 1e3, 2),
                                                  frac=round(b_attn / (t_warm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -549,7 +570,7 @@ def main():
         dt_name = {"bf16": "bf16", "fp32": "f32"}
         line = {
             "metric": "slides/sec", "value": round(world * args.steps / elapsed, 3), "unit": "slides/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_s": args.preroll_s,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dt_name[args.precision], "data": "synthetic",
             "config": {"workload": "%s: MILNet %s, 1 bag/step/rank, N=%d patches D=%d h=%d Lambda=%d (K=%d) depth=1 relu mlp x4"

@@ -353,8 +353,9 @@ int snf_gemm_hl_resid_bf16(const void* a_hl, int64_t lda, const void* w_hl, int6
 /* The same with split-K of the LAST, partly filled round of 256 x 256 tiles (e.g. the FFN output projection of config B: 384 tiles on
  * 256 CUs): each tile of that round goes to 2..4 workgroups, a K range each; the last one to finish adds the others' fp32 partial tiles
  * in a fixed order and runs the epilogue (bit-reproducible; any activation / output type / residual).  workspace: at least
- * snf_gemm_hl_ws_bytes(m, n, k) bytes (0 = this shape does not split; workspace may then be NULL); its first 4096 bytes must be zero
- * before the first call and are left zero by every call.  NULL workspace = snf_gemm_hl_resid_bf16. */
+ * snf_gemm_hl_ws_bytes(m, n, k) bytes (0 = this shape does not split; workspace may then be NULL); plain scratch memory -- the call
+ * zeroes its own tickets, nothing is expected in the buffer before a call or kept in it after one, so concurrent calls on different
+ * streams only need different buffers.  NULL workspace = snf_gemm_hl_resid_bf16. */
 size_t snf_gemm_hl_ws_bytes(int64_t m, int n, int k);
 int snf_gemm_hl_ws_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ldw, const float* bias, const float* resid,
                         int64_t ldr, int64_t m, int n, int k, int act, void* c, int64_t ldc, int out_dtype, void* workspace,

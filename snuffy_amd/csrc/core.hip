@@ -38,7 +38,7 @@ int cu_count() {
     return cached;
 }
 
-// one bit per device id (ids >= 64 share bit 63: their opt-ins are then simply repeated): the key of the per-thread "this kernel has
+// one bit per device id (ids >= 63 get no bit: their opt-ins are simply repeated on every launch): the key of the per-thread "this kernel has
 // its LDS opt-in on this device" masks -- hipFuncSetAttribute is per device, a thread that moves to another GPU has to repeat it
 unsigned long long device_bit() {
     int dev = 0;

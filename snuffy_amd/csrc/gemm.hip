@@ -56,7 +56,7 @@ struct GemmParams {
     // gemm_hl_kernel, split-K of the LAST, partly filled round of tiles (snf_gemm_hl_ws_bf16): an XCD whose q tiles leave r = q % W of
     // its W workgroups busy in the last round gives each of those tiles to S = min(W / r, split_cap) workgroups, a K range each.
     // Every part but the last to finish parks its accumulators in a slab; the last arriver (ticket) adds them in part order and runs the
-    // epilogue.  ws: [8 * split_rcap] tickets (zero between launches), then [8 * split_rcap][split_cap] slabs of 256 KiB.
+    // epilogue.  ws: [8 * split_rcap] tickets (zeroed by the plain launch), then [8 * split_rcap][split_cap] slabs of 256 KiB.
     unsigned int* split_cnt = nullptr;
     float* split_slab = nullptr;
     int split_cap = 0, split_rcap = 0;
@@ -388,6 +388,14 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
 
     const int ntiles = P.tiles_m * P.tiles_n;
     const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    if constexpr (!SPLIT) {
+        // The plain launch zeroes the tickets of the SPLIT launch that follows it on the stream (the kernel boundary orders the two):
+        // the workspace is plain scratch memory of the caller, no state survives a call and none is expected before it.
+        if (P.split_cap >= 2 && blockIdx.x == 0) {
+            for (int i = threadIdx.x; i < 8 * P.split_rcap; i += 512) P.split_cnt[i] = 0u;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
     int t_lo, t_hi;
     {
         const int q = ntiles >> 3, r = ntiles & 7;
@@ -1012,8 +1020,9 @@ HlSplit hl_split_geometry(int64_t m, int n, int k) {
 constexpr size_t HL_TICKET_BYTES = 4096;
 }  // namespace
 
-// Workspace of snf_gemm_hl_ws_bf16 for this shape; 0 = the shape has no partly filled last round worth splitting.  The first 4096
-// bytes (tickets) must be ZERO before the first call; every call leaves them zero.
+// Workspace of snf_gemm_hl_ws_bf16 for this shape; 0 = the shape has no partly filled last round worth splitting.  Plain scratch
+// memory: the call zeroes its tickets (the first 4096 bytes) itself, so the buffer may come fresh from any allocator and carries no state
+// between calls -- concurrent calls on different streams only need DIFFERENT buffers.
 extern "C" size_t snf_gemm_hl_ws_bytes(int64_t m, int n, int k) {
     const HlSplit g = hl_split_geometry(m, n, k);
     if (g.cap < 2 || 8 * g.rcap * sizeof(unsigned int) > HL_TICKET_BYTES) return 0;

@@ -1002,10 +1002,15 @@ template <int DK, int NKB, bool AUX, int MODE>
 int x3p_launch(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s) {
     constexpr int lds = x3p_lds_bytes(DK, NKB);
     auto kern = sparse_attn_x3p_kernel<DK, NKB, AUX, MODE>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-        snf::set_error("sparse_attn_x3p: cannot reserve %d bytes of LDS", lds);
-        (void)hipGetLastError();
-        return SNF_ELAUNCH;
+    static thread_local unsigned long long attr_set_mask = 0;   // devices (bit = device id) that have the opt-in
+    const unsigned long long attr_set_bit = snf::device_bit();
+    if (!(attr_set_mask & attr_set_bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            snf::set_error("sparse_attn_x3p: cannot reserve %d bytes of LDS", lds);
+            (void)hipGetLastError();
+            return SNF_ELAUNCH;
+        }
+        attr_set_mask |= attr_set_bit;
     }
     const int nch = P.merged > 1 ? P.merged : 1;
     const int csize = P.merged > 1 ? P.chunk_size : P.k;

@@ -27,13 +27,16 @@ ACTIVATIONS = ("relu", "gelu", "leakyrelu", "selu")      # reference snuffy.py:2
 # north_star's 1e-3 fp32 class by 30x, but NOT bit-level fp32 -- "exact" / "library" are the plain-fp32 settings.
 FP32_ATTENTION = "x3"
 # with FP32_ATTENTION == "x3": the pipelined kernel on pre-split operands (snf_sparse_attn_fwd_x3_hl) wherever the layer runs on the
-# one-pass hl GEMMs and the shape allows (dk = 128, <= 256 keys); False keeps the round-3 kernel on fp32 operands
+# one-pass hl GEMMs and the shape allows (ops.x3_hl_attn_supported); False keeps the round-3 kernel on fp32 operands
 X3_HL_ATTENTION = True
 # ... and the key projection in front of it writes the kernel's Kp fragment image itself (no fp32 Kp, no prep launch)
 X3_HL_KPFRAG = True
 # fp32 path, the [N, .] projections: "x3" = split-bf16 products on the hand-written MFMA GEMM (fp32-class: logits within
 # ~1e-5 of the exact path), "library" = fp32 library GEMMs.
 FP32_GEMM = "x3"
+# precision="bf16" on a stack of MORE than one encoder layer: "fp32" = run the fp32-class kernels (snuffy.RuntimeConfig.compute:
+# the K-way softmax of a later layer amplifies the bf16 re-roundings of the layers before it past the 1e-2 class), "bf16" = literal.
+BF16_DEEP_STACKS = "fp32"
 # fp32 path on the one-pass hl GEMMs: ONE normalised image xhat = (x - mean) rstd serves both sublayers (the LayerNorm affines are
 # folded into Wq | Wv and W1, in fp64, rounded once; after the attention only the K patched rows are re-normalised into the image)
 # instead of a second full LayerNorm pass over the bag -- what the bf16 path has always done.  Needs equal eps in both LayerNorms.
@@ -103,12 +106,18 @@ try:
     from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook
     _reg_post_hook(_on_optimizer_step)
 except ImportError:      # a torch without global optimizer hooks: the trainers of this package bump the epoch themselves
-    _reg_post_hook = None
+    _reg_post_hook = None    # (train.Trainer / BagParallelStepper call bump_param_epoch() after every optimizer.step())
 
 
 def bump_param_epoch():
     """Announce that parameters were written in a way the version counters do not show (an optimizer this package cannot hook)."""
     _PARAM_EPOCH[0] += 1
+
+
+def after_optimizer_step():
+    """What the trainers call behind every optimizer.step(): advances the epoch when torch has no global post-step hook to do it."""
+    if _reg_post_hook is None:
+        bump_param_epoch()
 
 
 def param_key(p):

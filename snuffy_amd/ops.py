@@ -1179,19 +1179,13 @@ def gemm_hl(a_hl, w_hl, bias=None, act="none", out_dtype=torch.float32, out=None
 
 
 GEMM_HL_SPLITK = True   # split-K of the last, partly filled round of tiles (snf_gemm_hl_ws_bf16); False: plain tile walk
-_HL_WS = {}
 
 
 def _hl_workspace(device, nbytes):
-    """Per-device workspace of the split-K GEMM: tickets (zero between launches; zeroed here once) + partial-tile slabs.  One buffer
-    per device, grown on demand: launches on a device's compute stream are ordered, so they can share it.  (Callers that drive
-    gemm_hl from SEVERAL streams of one device concurrently must set GEMM_HL_SPLITK = False or serialise those launches: the tickets
-    are shared.  The C entry point takes the workspace from its caller and has no such state.)"""
-    key = str(device)
-    ws = _HL_WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = _HL_WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
-    return ws
+    """Scratch of one split-K call (tickets + partial-tile slabs), taken from the caching allocator PER CALL: the call zeroes its own
+    tickets, so nothing has to survive between calls.  Inside a HIP-graph capture the buffer belongs to the graph's private pool and
+    stays valid for every replay; concurrent calls on different streams get different buffers (stream-ordered allocator)."""
+    return _ws(nbytes, device)
 
 
 def split3_weight(w):

@@ -47,11 +47,11 @@ def pack_groups(net, bags):
             return None
         kb = (k1, k2)
     k1, k2 = kb
-    if cfg.precision == "bf16" and any(l.sublayer[0].norm.eps != l.sublayer[1].norm.eps for l in layers):
+    if cfg.compute == "bf16" and any(l.sublayer[0].norm.eps != l.sublayer[1].norm.eps for l in layers):
         return None
     sizes = [x.shape[-2] for x in bags]
-    uniform_dims = (d % 4 == 0 and SF.ops.varlen_attn_supported(cfg.precision, k1 + k2, d // h)
-                    and (cfg.precision == "bf16" or SF.FP32_ATTENTION == "x3"))
+    uniform_dims = (d % 4 == 0 and SF.ops.varlen_attn_supported(cfg.compute, k1 + k2, d // h)
+                    and (cfg.compute == "bf16" or SF.FP32_ATTENTION == "x3"))
     if k2 > 0:
         ok = (uniform_dims and min(sizes) >= k1 + k2 and max(sizes) <= 65536 and (k1 + k2) * len(bags) <= (1 << 20)
               and sum(sizes) <= getattr(net, "_PACK_MAX_ROWS", PACK_MAX_ROWS))      # one group only: the draws must stay in bag order
@@ -223,7 +223,7 @@ def forward_packed_raw(net, x_cat, packed, ragged=False):
     for layer in layers[:1]:
         layer._xhat_offer = None
         layer._xn3_offer = None
-    if cfg.precision == "bf16":
+    if cfg.compute == "bf16":
         eps = layers[0].sublayer[0].norm.eps
         s, xhat = SF.ops.critic_ln(x_cat, lin.weight, lin.bias, eps)            # same kernel as the per-bag critic pass
         layers[0]._xhat_offer = (x_cat.data_ptr(), tuple(x_cat.shape), x_cat._version, float(eps), xhat)
@@ -268,7 +268,7 @@ def forward_packed_raw(net, x_cat, packed, ragged=False):
         else:
             sel_local = top if rnd is None else torch.cat((top, rnd[li]), dim=1)  # [B, K]: top ++ random, as snuffy.py:145
             sel = (sel_local + first).reshape(-1)
-        parts, attn = SF.encoder_layer(x2, sel, layer, (li == len(layers) - 1) and cfg.return_attention, cfg.precision,
+        parts, attn = SF.encoder_layer(x2, sel, layer, (li == len(layers) - 1) and cfg.return_attention, cfg.compute,
                                        packed=packed, ragged=rag)
     logits = SF.head(parts, enc.norm, net.b_classifier.linear, packed=packed)   # [B, C]
     return s, logits, attn, (rag.kbs if rag is not None else None)

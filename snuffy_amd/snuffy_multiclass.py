@@ -73,7 +73,7 @@ class EncoderLayer(nn.Module):
         sel = torch.cat((topk, rnd), dim=1)
         parts, attns = [], []
         for i in range(x.shape[0]):
-            p, a = SF.encoder_layer(x[i].contiguous(), sel[i].contiguous(), self, need_attn, self.cfg.precision)
+            p, a = SF.encoder_layer(x[i].contiguous(), sel[i].contiguous(), self, need_attn, self.cfg.compute)
             parts.append(p)
             attns.append(a)
         attn = torch.cat(attns, dim=0) if need_attn else None
@@ -101,7 +101,7 @@ class Encoder(nn.Module):
         super(Encoder, self).__init__()
         self.layers = clones(layer, N)
         self.norm = nn.LayerNorm(layer.size)
-        self.cfg = RuntimeConfig()
+        self.cfg = RuntimeConfig().bind_stack(self.layers)
         _share_config(self, self.cfg)
 
     def run_layers(self, x, c):
@@ -128,7 +128,7 @@ class BClassifier(nn.Module):
         self.linear = nn.Linear(input_size, num_classes)
         self.feats_size = input_size
         self.num_class = num_classes
-        self.cfg = RuntimeConfig()
+        self.cfg = RuntimeConfig().bind_stack(getattr(encoder, "layers", None))
         _share_config(self, self.cfg)
 
     def configure(self, precision=None, return_attention=None):

@@ -24,6 +24,7 @@ import torch
 import torch.nn as nn
 from torch import optim
 
+from . import functional as SF
 from . import snuffy, snuffy_multiclass
 from .utils import (OPTIMIZERS, WEIGHT_INITS, compute_pos_weight, dropout_patches, dropout_patches_device,
                     multi_label_roc)
@@ -224,6 +225,7 @@ class Trainer:
         if self.args.clip_grad is not None:
             torch.nn.utils.clip_grad_norm_(self.milnet.parameters(), max_norm=self.args.clip_grad)
         self.optimizer.step()
+        SF.after_optimizer_step()
         self.optimizer.zero_grad()
 
     # -- epoch loops -------------------------------------------------------------------------------------------------
@@ -679,6 +681,7 @@ class BagParallelStepper:
         loss.backward()
         self.sync()
         self.optimizer.step()
+        SF.after_optimizer_step()
         self.optimizer.zero_grad()           # set_to_none: the next backward assigns the gradients, no fill + add per parameter
         return loss.detach()
 

@@ -194,6 +194,24 @@ def test_bag_parallel_stepper_equals_trainer_step_world1():
         assert torch.equal(a, b), k
 
 
+@pytest.mark.parametrize("p", [0.0, 0.2, 0.5])
+@pytest.mark.parametrize("batched", [False, True])
+def test_dropout_patches_device_replays_reference(p, batched):
+    """utils.dropout_patches_device -- what Trainer.train applies to HBM-resident bags -- against the reference's own output (F5,
+    reference utils.py:244-250): the same rows bit for bit AND the same position of the global numpy RNG stream afterwards."""
+    from snuffy_amd.utils import dropout_patches_device
+    z = np.load(golden_files("f5_")[0])
+    feats = torch.from_numpy(z["feats"]).to(DEV)
+    if batched:
+        feats = feats.unsqueeze(0)
+    np.random.seed(11)
+    out = dropout_patches_device(feats, p)
+    assert out.is_cuda and out.dim() == feats.dim()
+    got = out[0] if batched else out
+    assert np.array_equal(got.cpu().numpy(), z[f"out_p{p}"])
+    assert np.random.rand() == float(z[f"next_rand_p{p}"])          # the next draw of the stream is the reference's
+
+
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_bench_rccl_path_on_one_rank(mode):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), here with one rank and the RCCL

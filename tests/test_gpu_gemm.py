@@ -208,8 +208,12 @@ def test_gemm_hl_split_k_of_the_last_round(m, n, k, act, monkeypatch):
     out = ops.gemm_hl(a_hl, w_hl, b, act, resid=res)
     assert torch.equal(out, ops.gemm_hl(a_hl, w_hl, b, act, resid=res))
     if splits:
-        ws = ops._HL_WS[str(a.device)]
-        assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0
+        # the scratch buffer comes from the allocator per call and may be dirty: the call zeroes its own tickets
+        nb = int(_ffi.load().snf_gemm_hl_ws_bytes(m, n, k))
+        for _ in range(2):
+            junk = torch.full((nb,), 0xAB, dtype=torch.uint8, device=DEV)
+            del junk                                   # the next allocation of this size gets the same block back, dirty
+            assert torch.equal(out, ops.gemm_hl(a_hl, w_hl, b, act, resid=res))
     img = ops.gemm_hl(a_hl, w_hl, b, act, hl_out=True) if n % 32 == 0 else None
     ob = ops.gemm_hl(a_hl, w_hl, b, act, out_dtype=torch.bfloat16)
     monkeypatch.setattr(ops, "GEMM_HL_SPLITK", False)
@@ -223,6 +227,52 @@ def test_gemm_hl_split_k_of_the_last_round(m, n, k, act, monkeypatch):
     if img is not None:
         v = img.view(m, n // 32, 2, 32)
         assert ((v[:, :, 0].reshape(m, n).float() + v[:, :, 1].reshape(m, n).float()) - (plain - res)).abs().max().item() <= 2.0 ** -15 * scale
+
+
+def test_gemm_hl_split_k_graph_replay_survives_a_larger_shape_and_other_streams():
+    """ADVICE r4 (high / medium): the split-K scratch used to be ONE growing buffer per device -- a graph captured at shape A replayed
+    against freed memory once a larger shape B had replaced the buffer, and two streams shared one set of tickets.  Now every call
+    takes its scratch from the allocator (a capture: from the graph's pool): capture A, run a larger B eagerly, churn the allocator,
+    replay A == eager A; and two streams running split-K GEMMs concurrently both get the single-stream result."""
+    from snuffy_amd import _ffi, ops
+    lib = _ffi.load()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(900, 768, 3072), (32768, 768, 3072)]             # 12 tiles on 16 workgroups / 384 tiles on 256: both split
+    ops_in = []
+    for m, n, k in shapes:
+        assert int(lib.snf_gemm_hl_ws_bytes(m, n, k)) > 0
+        a = (torch.randn(m, k, generator=g) * 0.5).to(DEV)
+        w = (torch.randn(n, k, generator=g) / k ** 0.5).to(DEV)
+        ops_in.append((ops.split_hl_rows(a), ops.split_hl_weight(w), torch.randn(n, generator=g).to(DEV)))
+    assert int(lib.snf_gemm_hl_ws_bytes(*shapes[1])) > int(lib.snf_gemm_hl_ws_bytes(*shapes[0]))
+    eager = [ops.gemm_hl(a, w, b) for a, w, b in ops_in]
+    torch.cuda.synchronize()
+    a0, w0, b0 = ops_in[0]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_g = ops.gemm_hl(a0, w0, b0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_g, eager[0])
+    big = ops.gemm_hl(*ops_in[1])                                # a larger scratch request after the capture
+    assert torch.equal(big, eager[1])
+    del big
+    junk = [torch.full((64 << 20,), 0xCD, dtype=torch.uint8, device=DEV) for _ in range(4)]   # reuse whatever was freed, dirty
+    del junk
+    torch.cuda.empty_cache()
+    out_g.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_g, eager[0])
+    # two streams, split-K GEMMs in flight on both at once
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    res = {}
+    for rep in range(3):
+        for s, i in ((s1, 1), (s2, 0)):
+            with torch.cuda.stream(s):
+                res[i] = ops.gemm_hl(*ops_in[i])
+        torch.cuda.synchronize()
+        assert torch.equal(res[0], eager[0]) and torch.equal(res[1], eager[1])
 
 
 @pytest.mark.parametrize("n,d", [(700, 384), (513, 768), (64, 96), (1000, 2048)])

@@ -93,6 +93,32 @@ def test_configure_is_shared_and_validated():
     assert net2.b_classifier.cfg is not net.b_classifier.cfg
 
 
+def test_bf16_setting_runs_deep_stacks_on_the_fp32_class_kernels(monkeypatch):
+    """RuntimeConfig.compute: precision="bf16" is literal for ONE encoder layer (the benchmark model) and means the fp32-class kernels
+    for deeper stacks (reference roi.py:318-339 builds depth 5): the 1e-2 gate is flat, not scaled with depth."""
+    import copy
+
+    from snuffy_amd import functional as SF
+    from snuffy_amd import snuffy_multiclass as smc
+    one, deep = build_amd_milnet(64, 2, "relu", 10, 0.0, 1), build_amd_milnet(64, 2, "relu", 10, 0.0, 5)
+    for net in (one, deep):
+        net.configure(precision="bf16")
+    assert one.b_classifier.cfg.compute == "bf16" and deep.b_classifier.cfg.compute == "fp32"
+    assert deep.b_classifier.cfg.precision == "bf16"                       # the user's setting is kept as given
+    assert copy.deepcopy(deep).b_classifier.cfg.compute == "fp32"
+    assert deep.b_classifier.encoder.layers[3].cfg.compute == "fp32"       # every module of the stack sees the same answer
+    deep.configure(precision="fp32")
+    assert deep.b_classifier.cfg.compute == "fp32"
+    deep.configure(precision="bf16")
+    monkeypatch.setattr(SF, "BF16_DEEP_STACKS", "bf16")
+    assert deep.b_classifier.cfg.compute == "bf16"
+    monkeypatch.setattr(SF, "BF16_DEEP_STACKS", "fp32")
+    mc = smc.build_milnet(64, 2, "relu", 10, 0.0, 2, 2) if hasattr(smc, "build_milnet") else None
+    if mc is not None:
+        mc.configure(precision="bf16")
+        assert mc.b_classifier.cfg.compute == "fp32"
+
+
 def test_forward_refuses_cpu_tensors():
     from snuffy_amd import SnuffyHipError
     net = build_amd_milnet(64, 2, "relu", 10, 0.0, 1)
