@@ -333,6 +333,8 @@ int snf_sparse_attn_dkp_f32(const float* ds, const float* q, int64_t n, int k, i
  *   n * ldw < 2^31; outside it SNF_EUNSUPPORTED (the caller keeps its library GEMM).
  *   out_dtype = SNF_DT_BF16_SPLIT3: C is the bf16 image [hi | hi | lo] of the fp32 result, [m, 3 n] (ldc >= 3 n) -- the
  *   hidden activations of the fp32-class FFN go from the first GEMM to the second without an fp32 round trip.
+ *   out_dtype = SNF_DT_BF16_HL: C is the interleaved hl image of the fp32 result, [m, 2 n] (n % 32 == 0, ldc >= 2 n): the Q | V
+ *   projection of bags too small for the one-pass kernel hands its result to snf_sparse_attn_fwd_x3_hl in this form.
  * --------------------------------------------------------------------------------------------------------- */
 int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t m, int n, int k,
                   int act, void* c, int64_t ldc, int out_dtype, int tile_n, snf_stream_t stream);
@@ -471,6 +473,10 @@ int snf_ln_mean_head_varlen_f32(const float* z, const int64_t* offsets, int bags
  * stamp code: the calls only set two host-side variables. */
 void snf_debug_attn_trace(void* buf);
 void snf_debug_attn_trace_wg(int wg);
+/* snf_debug_x3p_kbw(kbw): key blocks per wave of the dk = 128 family of snf_sparse_attn_fwd_x3_hl for 129 .. 256 keys per launch --
+ * 1 (default: one wave per key block, two per SIMD) or 2 (one wave per SIMD carrying two key blocks, round 5); same arithmetic,
+ * results equal up to the fp32 order of the row sums.  For A / B timing (tools/x3p_dev.py) and the parity tests of the second form. */
+void snf_debug_x3p_kbw(int kbw);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,9 @@ EXTRA_FLAGS = {"sparse_attn_mfma.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]
                "sparse_attn_mfma_varlen.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
                "sparse_attn_mfma_varlen_dk64.hip": ["-fno-honor-nans", "-fno-slp-vectorize"], "vit.hip": ["-fno-honor-nans"],
                "sparse_attn_x3.hip": ["-fno-honor-nans"],
-               "sparse_attn_x3p.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
+               "sparse_attn_x3p.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
+               "sparse_attn_x3p_k2.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
+               "sparse_attn_x3p_dk64.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -37,16 +39,40 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _deps_mtime():
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    deps.append(os.path.join(os.path.dirname(HERE), "include", "snuffy_hip.h"))
-    return max(os.path.getmtime(d) for d in deps)
+_INC = None
+
+
+def _deps_mtime(src=None):
+    """Newest modification time among the headers `src` includes (directly or through other headers of csrc/); src=None: among
+    all headers.  The public header include/snuffy_hip.h reaches every source through common.h."""
+    import re
+    global _INC
+    if _INC is None:
+        _INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+    pub = os.path.join(os.path.dirname(HERE), "include", "snuffy_hip.h")
+    if src is None:
+        deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [pub]
+        return max(os.path.getmtime(d) for d in deps)
+    seen, todo = set(), [src]
+    while todo:
+        f = todo.pop()
+        try:
+            with open(f) as fh:
+                text = fh.read()
+        except OSError:
+            continue
+        for inc in _INC.findall(text):
+            path = os.path.normpath(os.path.join(os.path.dirname(f), inc))
+            if path not in seen and os.path.exists(path):
+                seen.add(path)
+                todo.append(path)
+    return max([os.path.getmtime(d) for d in seen] + [0.0])
 
 
 def _compile(src, force, hdr_mtime):
     obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
-            and os.path.getmtime(obj) >= hdr_mtime):
+            and os.path.getmtime(obj) >= _deps_mtime(src)):
         return obj, False
     cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
     if os.environ.get("SNF_ATTN_DEV"):   # development: only the config-B attention variants (7 key blocks)

@@ -106,7 +106,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // NI = 16-column W fragments per wave: 4 -> BN = 256, 2 -> BN = 128.  OUT: 0 = bf16 output, 1 = fp32, 2 = the bf16 image
-// [hi | hi | lo] of the fp32 result (3 n columns, lo = bf16(v - hi)): the A operand of a following split-bf16 x3 GEMM.
+// [hi | hi | lo] of the fp32 result (3 n columns, lo = bf16(v - hi)): the A operand of a following split-bf16 x3 GEMM; 3 = the
+// interleaved hl image of the result (every 32 columns as [hi(32) | lo(32)], 2 n columns): what the pipelined attention streams.
 template <int NI, int ACT, int OUT>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
     constexpr int BN = 64 * NI;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
     constexpr int GL = 2 + WP;                 // LDS-DMA instructions per wave and step
     constexpr int NC = 4 * NI;                 // output columns per lane
     constexpr bool OUT_F32 = OUT == 1;
-    constexpr int NST = OUT == 1 ? NC / 4 : OUT == 2 ? 3 * NC / 8 : NC / 8;   // store instructions per lane and 16-row block
+    constexpr int NST = (OUT == 1 || OUT == 3) ? NC / 4 : OUT == 2 ? 3 * NC / 8 : NC / 8;   // store instructions per lane and 16-row block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NBUF][A image | W image]
 
     const int lane = threadIdx.x & 63;
@@ -272,6 +273,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                     if (ok) {
                         *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    }
+                } else if constexpr (OUT == 3) {   // hl image: the 8 columns sit inside one 32-column chunk: hi at 64 (col / 32) + col % 32, lo 32 further
+                    const u32x4 pk = {cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
+                    float lo[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        lo[e] = v[e] - __uint_as_float((e & 1) ? (pk[e >> 1] & 0xffff0000u) : (pk[e >> 1] << 16));
+                    const u32x4 pl = {cvt_pk_bf16(lo[0], lo[1]), cvt_pk_bf16(lo[2], lo[3]), cvt_pk_bf16(lo[4], lo[5]), cvt_pk_bf16(lo[6], lo[7])};
+                    unsigned short* dst = reinterpret_cast<unsigned short*>(P.c) + (int64_t)row * P.ldc + 64 * (col >> 5) + (col & 31);
+                    if (ok) {
+                        *reinterpret_cast<u32x4*>(dst) = pk;
+                        *reinterpret_cast<u32x4*>(dst + 32) = pl;
                     }
                 } else {
                     unsigned short* dst = reinterpret_cast<unsigned short*>(P.c) + (int64_t)row * P.ldc + col;
@@ -941,10 +954,11 @@ extern "C" int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t 
     SNF_REQUIRE(a && w && c, "snf_gemm_bf16: null pointer");
     SNF_REQUIRE(m >= 1 && n >= 1 && k >= 1, "snf_gemm_bf16: bad shape m=%lld n=%d k=%d", (long long)m, n, k);
     SNF_REQUIRE(act >= SNF_ACT_RELU && act <= SNF_ACT_NONE, "snf_gemm_bf16: bad activation code %d", act);
-    SNF_REQUIRE(out_dtype == SNF_DT_F32 || out_dtype == SNF_DT_BF16 || out_dtype == SNF_DT_BF16_SPLIT3,
+    SNF_REQUIRE(out_dtype == SNF_DT_F32 || out_dtype == SNF_DT_BF16 || out_dtype == SNF_DT_BF16_SPLIT3 || out_dtype == SNF_DT_BF16_HL,
                 "snf_gemm_bf16: bad output dtype %d", out_dtype);
+    SNF_REQUIRE(out_dtype != SNF_DT_BF16_HL || n % 32 == 0, "snf_gemm_bf16: an hl-image output needs n %% 32 == 0 (n = %d)", n);
     if (k % BKS || k < AHEAD * BKS || n % 8 || lda % 8 || ldw % 8 || ldc % (out_dtype == SNF_DT_F32 ? 4 : 8) || lda < k || ldw < k ||
-        ldc < (out_dtype == SNF_DT_BF16_SPLIT3 ? 3 * (int64_t)n : n) || (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(c)) % 16 ||
+        ldc < (out_dtype == SNF_DT_BF16_SPLIT3 ? 3 * (int64_t)n : out_dtype == SNF_DT_BF16_HL ? 2 * (int64_t)n : n) || (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(c)) % 16 ||
         (bias && reinterpret_cast<uintptr_t>(bias) % 16) || m * lda >= 0x7fffffffll || (int64_t)n * ldw >= 0x7fffffffll) {
         snf::set_error("snf_gemm_bf16: shape m=%lld n=%d k=%d (lda %lld ldw %lld ldc %lld) outside the kernel's domain "
                        "(k %% 32, k >= 64, n %% 8, 16-byte aligned rows, 31-bit element offsets)",
@@ -974,6 +988,7 @@ extern "C" int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t 
 #endif
     hipStream_t s = snf::as_stream(stream);
     if (out_dtype == SNF_DT_BF16_SPLIT3) return tile_n == 256 ? launch_act<4, 2>(P, s) : launch_act<2, 2>(P, s);
+    if (out_dtype == SNF_DT_BF16_HL) return tile_n == 256 ? launch_act<4, 3>(P, s) : launch_act<2, 3>(P, s);
     if (tile_n == 256) return out_dtype == SNF_DT_F32 ? launch_act<4, 1>(P, s) : launch_act<4, 0>(P, s);
     return out_dtype == SNF_DT_F32 ? launch_act<2, 1>(P, s) : launch_act<2, 0>(P, s);
 }

@@ -541,7 +541,8 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
         xn3 = _take_xn3(layer, x2, n0, shared)                                      # left by the critic pass, if any
         # pre-split operands for the pipelined attention kernel: the projection's epilogue writes [Q | V] as its hl image (the same
         # hi / lo values the attention kernel would derive from the fp32 tensor, the same 4 bytes per element)
-        hl_attn = (hl and ragged is None and packed is None and FP32_ATTENTION == "x3" and X3_HL_ATTENTION
+        # (bags too small for the one-pass GEMM get the same image out of the concatenated-K GEMM's epilogue)
+        hl_attn = (ragged is None and packed is None and FP32_ATTENTION == "x3" and X3_HL_ATTENTION and d % 32 == 0
                    and ops.x3_hl_attn_supported(k, d // h))
         # keys = RAW selected rows (K rows: fp32).  For the pipelined kernel the projection writes its fragment image directly
         if (hl_attn and X3_HL_KPFRAG and ops.x3_hl_kpfrag_supported(k, h, d // h) and lk.weight.dtype == torch.float32
@@ -558,7 +559,7 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
                 qv = ops.gemm_hl(xn3, fh["wqv"], fw["bqv"], hl_out=hl_attn)         # [N, 2D] f32 = [Q | V] (or its [N, 4D] image)
         else:
             xn3 = ops.layernorm_rows_split3(x2, n0.weight, n0.bias, n0.eps)
-            qv = ops.gemm_x3(xn3, fw["wqv"], fw["bqv"], out_dtype=torch.float32)
+            qv = ops.gemm_x3(xn3, fw["wqv"], fw["bqv"], out_dtype=torch.float32, hl_out=hl_attn)
         if not shared:
             del xn3
         q, v = (None, None) if hl_attn else (qv[:, :d], qv[:, d:])

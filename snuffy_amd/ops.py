@@ -645,7 +645,7 @@ def sparse_attn_fwd_x3(q, v, kp, h, scale=None, need_attn=False, need_lse=False)
 
 def x3_hl_attn_supported(k, dk):
     """Shapes of the pipelined fp32-class attention kernel on pre-split operands (snf_sparse_attn_fwd_x3_hl)."""
-    return dk == 128 and 97 <= k <= 2048
+    return dk in (64, 128) and 97 <= k <= 2048
 
 
 class KpFrag:
@@ -1029,10 +1029,11 @@ def linear_bf16(a, w, bias_f32=None, bias_bf16=None, act="none", prefer_native=N
     return out
 
 
-def gemm_bf16(a, w, bias=None, act="none", out_dtype=torch.bfloat16, out=None, tile_n=0, split3=False):
+def gemm_bf16(a, w, bias=None, act="none", out_dtype=torch.bfloat16, out=None, tile_n=0, split3=False, hl_out=False):
     """act(a @ w.T + bias) on the hand-written MFMA kernel.  a [m, k] bf16 (row-strided views allowed), w [n, k] bf16 (the
     nn.Linear layout), bias [n] f32 or None, act in relu | gelu (erf) | leakyrelu | selu | none -> [m, n] bf16 or f32.
-    split3: the result leaves as its bf16 image [hi | hi | lo], [m, 3 n] (operand of a following x3 GEMM)."""
+    split3: the result leaves as its bf16 image [hi | hi | lo], [m, 3 n] (operand of a following x3 GEMM).
+    hl_out: the result leaves as its interleaved hl image [m, 2 n] (n % 32 == 0; operand of sparse_attn_fwd_x3_hl / gemm_hl)."""
     if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
         raise TypeError("gemm_bf16: a and w must be bfloat16")
     a = _rows16(a, "a")
@@ -1045,7 +1046,15 @@ def gemm_bf16(a, w, bias=None, act="none", out_dtype=torch.bfloat16, out=None, t
         bias = _req(bias, torch.float32, "bias", 1)
         if bias.shape[0] != n:
             raise ValueError("gemm_bf16: bias has %d entries for %d columns" % (bias.shape[0], n))
-    if split3:
+    if hl_out:
+        if split3 or n % 32:
+            raise ValueError("gemm_bf16: an hl-image output needs n %% 32 == 0 and excludes split3 (n = %d)" % n)
+        if out is None:
+            out = torch.empty(m, 2 * n, dtype=torch.bfloat16, device=a.device)
+        elif out.shape != (m, 2 * n) or out.stride(1) != 1 or out.dtype != torch.bfloat16:
+            raise ValueError("gemm_bf16: bad out buffer for the hl image")
+        odt = DT_BF16_HL
+    elif split3:
         if out is None:
             out = torch.empty(m, 3 * n, dtype=torch.bfloat16, device=a.device)
         elif out.shape != (m, 3 * n) or out.stride(1) != 1 or out.dtype != torch.bfloat16:
@@ -1065,10 +1074,10 @@ def gemm_bf16(a, w, bias=None, act="none", out_dtype=torch.bfloat16, out=None, t
 GEMM_HL = True        # one-pass fp32-class GEMM kernel (snf_gemm_hl_bf16) where the shape fills the chip with 256 x 256 tiles
 
 
-def gemm_x3(a_img, w_img, bias=None, act="none", out_dtype=torch.float32, out=None, split3=False):
+def gemm_x3(a_img, w_img, bias=None, act="none", out_dtype=torch.float32, out=None, split3=False, hl_out=False):
     """fp32-class act(A W^T + bias) from the [hi | hi | lo] / [Wh | Wl | Wh] images as ONE bf16 GEMM over the 3 k concatenated
     columns (gemm_bf16): the form for shapes the one-pass kernel (gemm_hl) does not cover."""
-    return gemm_bf16(a_img, w_img, bias, act, out_dtype, out, split3=split3)
+    return gemm_bf16(a_img, w_img, bias, act, out_dtype, out, split3=split3, hl_out=hl_out)
 
 
 def hl_eligible(m, n, k):

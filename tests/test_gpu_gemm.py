@@ -147,6 +147,15 @@ def test_gemm_x3_is_fp32_class(m, n, k, act):
     out128 = ops.gemm_bf16(a3, w3, b.to(DEV), act, torch.float32, tile_n=128)
     hi, lo = _split_host(out128)
     assert torch.equal(img128[:, :n], hi) and (act == "gelu" or torch.equal(img128[:, 2 * n:], lo))
+    # ... and the interleaved hl image (round 5: what the pipelined attention streams when the bag is too small for the one-pass GEMM)
+    for tile_n, ref_out in ((0, out), (128, out128)):
+        hl = ops.gemm_bf16(a3, w3, b.to(DEV), act, hl_out=True, tile_n=tile_n).view(m, n // 32, 2, 32)
+        hi, lo = _split_host(ref_out)
+        assert torch.equal(hl[:, :, 0].reshape(m, n), hi)
+        if act == "gelu":
+            assert ((hl[:, :, 0].reshape(m, n).float() + hl[:, :, 1].reshape(m, n).float()) - ref_out).abs().max().item() <= 2.0 ** -15 * scale
+        else:
+            assert torch.equal(hl[:, :, 1].reshape(m, n), lo)
 
 
 @pytest.mark.parametrize("m,n,k,act", [(1000, 768, 384, "none"), (4096, 1536, 768, "none"), (777, 3072, 768, "relu"),

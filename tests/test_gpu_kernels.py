@@ -422,16 +422,48 @@ def test_sparse_attn_x3_config_b_walks_heads_and_spike():
         ops().sparse_attn_fwd_x3(q.to(DEV), v.to(DEV), torch.zeros(8 * 224 + 1, d, device=DEV), h)   # more than 8 key chunks
 
 
-@pytest.mark.parametrize("n,k,h", [(1000, 200, 6), (4097, 224, 3), (33, 128, 2), (1, 97, 1), (5000, 100, 2), (2000, 256, 2), (777, 129, 2),
-                                   (300, 160, 1), (6401, 200, 6),
-                                   # more than 256 keys: key chunks with exact cross-chunk statistics
-                                   (3000, 512, 6), (700, 257, 2), (1500, 601, 3), (257, 1790, 1), (100, 2048, 2)])
-def test_sparse_attn_x3_hl_fp32_class(n, k, h):
+@pytest.fixture
+def x3p_two_key_blocks_per_wave():
+    """Switches the dk = 128 family of snf_sparse_attn_fwd_x3_hl to its round-5 form (one wave per SIMD, two key blocks per wave)
+    for one test; the default form is restored afterwards."""
+    from snuffy_amd import _ffi
+    _ffi.load().snf_debug_x3p_kbw(2)
+    yield
+    _ffi.load().snf_debug_x3p_kbw(1)
+
+
+X3P_SHAPES = [(1000, 200, 6, 128), (4097, 224, 3, 128), (33, 128, 2, 128), (1, 97, 1, 128), (5000, 100, 2, 128), (2000, 256, 2, 128),
+              (777, 129, 2, 128), (300, 160, 1, 128), (6401, 200, 6, 128),
+              # more than 256 keys: key chunks with exact cross-chunk statistics
+              (3000, 512, 6, 128), (700, 257, 2, 128), (1500, 601, 3, 128), (257, 1790, 1, 128), (100, 2048, 2, 128),
+              # dk = 64 (round 5): config A's head width
+              (1000, 200, 6, 64), (4097, 256, 3, 64), (33, 128, 2, 64), (1, 97, 1, 64), (5000, 100, 12, 64), (777, 129, 2, 64),
+              (300, 160, 1, 64), (8192, 200, 6, 64), (3000, 512, 6, 64), (700, 257, 2, 64), (257, 1790, 1, 64)]
+
+
+@pytest.mark.parametrize("n,k,h,dk", [sh for sh in X3P_SHAPES if sh[3] == 128 and sh[1] > 128])
+def test_sparse_attn_x3_hl_two_key_blocks_per_wave(n, k, h, dk, x3p_two_key_blocks_per_wave):
+    """The round-5 form of the dk = 128 family (5 .. 8 key blocks per launch on 3 .. 4 waves of 512 registers, loader / light-wave /
+    all-issue DMA configurations, key chunks): same bounds against fp64 as the default form, and equal to it up to the order of the
+    fp32 row sums."""
+    test_sparse_attn_x3_hl_fp32_class(n, k, h, dk)
+    from snuffy_amd import _ffi
+    g = torch.Generator().manual_seed(n * 7 + k)
+    d = h * dk
+    q, kp, v = torch.randn(n, d, generator=g), torch.randn(k, d, generator=g), torch.randn(n, d, generator=g)
+    img = ops().split_hl_rows(torch.cat([q, v], dim=1).to(DEV))
+    o2, a2, _ = ops().sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], kp.to(DEV), h, need_attn=True)
+    _ffi.load().snf_debug_x3p_kbw(1)
+    o1, a1, _ = ops().sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], kp.to(DEV), h, need_attn=True)
+    assert (a1 - a2).abs().max() < 2e-6 and rel_err(o2.cpu(), o1.cpu()) < 4e-6
+
+
+@pytest.mark.parametrize("n,k,h,dk", X3P_SHAPES)
+def test_sparse_attn_x3_hl_fp32_class(n, k, h, dk):
     """snf_sparse_attn_fwd_x3_hl (the pipelined split-bf16 x 3 kernel on PRE-SPLIT hl operands) against the fp64 oracle on the
     unrounded operands: same arithmetic class as snf_sparse_attn_fwd_x3 (the hl image carries exactly the hi / lo halves that
     kernel derives from the fp32 tensor), same bounds.  Tile counts from one to several per workgroup, ragged last tiles, every
-    key-block count the kernel is built for (4 .. 8), rows past the end, head changes inside a workgroup's range."""
-    dk = 128
+    key-block count the kernel is built for (4 .. 8), rows past the end, head changes inside a workgroup's range; dk = 128 and 64."""
     g = torch.Generator().manual_seed(n * 7 + k)
     d = h * dk
     q, kp, v = torch.randn(n, d, generator=g), torch.randn(k, d, generator=g), torch.randn(n, d, generator=g)
@@ -439,7 +471,7 @@ def test_sparse_attn_x3_hl_fp32_class(n, k, h):
     qi, vi = img[:, :2 * d], img[:, 2 * d:]
     o, attn, lse = ops().sparse_attn_fwd_x3_hl(qi, vi, kp.to(DEV), h, need_attn=True, need_lse=True)
     o_ref, p_ref = attn_ref(q, kp, v, h)
-    assert (attn.cpu().double() - p_ref).abs().max() < 6e-6
+    assert (attn.cpu().double() - p_ref).abs().max() < (6e-6 if k >= 128 else 1e-5)   # (about 100 keys: probabilities of 1e-2 and more)
     assert rel_err(o.cpu(), o_ref) < (2e-5 if k <= 256 else 4e-5)      # few rows under many keys: O is a short sum of small P
     s_ref = (q.double().view(n, h, dk).transpose(0, 1) @ kp.double().view(k, h, dk).transpose(0, 1).transpose(1, 2)) / dk ** 0.5
     assert (lse.cpu().double() - torch.logsumexp(s_ref, dim=-1)).abs().max() < 3e-5
@@ -451,7 +483,7 @@ def test_sparse_attn_x3_hl_fp32_class(n, k, h):
     # and the round-3 kernel on the fp32 tensors the images were made of
     if k <= 224:
         o4, a4, _ = ops().sparse_attn_fwd_x3(q.to(DEV), v.to(DEV), kp.to(DEV), h, need_attn=True)
-        assert (attn - a4).abs().max() < 6e-6 and rel_err(o.cpu(), o4.cpu()) < 2e-5
+        assert (attn - a4).abs().max() < (6e-6 if k >= 128 else 1e-5) and rel_err(o.cpu(), o4.cpu()) < 2e-5
 
 
 def test_sparse_attn_x3_hl_config_b_spike_and_domain():
@@ -478,15 +510,15 @@ def test_sparse_attn_x3_hl_config_b_spike_and_domain():
     with pytest.raises(SnuffyHipError):
         ops().sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], torch.zeros(2049, d, device=DEV), h)  # more than 8 chunks
     with pytest.raises(SnuffyHipError):
-        ops().sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], torch.zeros(200, d, device=DEV), 12)  # dk = 64
+        ops().sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], torch.zeros(200, d, device=DEV), 24)  # dk = 32
 
 
-@pytest.mark.parametrize("n,k,h", [(3000, 200, 6), (5000, 97, 2), (4000, 256, 3), (3000, 512, 6), (900, 1024, 2)])
-def test_sparse_attn_x3_hl_fused_key_projection(n, k, h):
+@pytest.mark.parametrize("n,k,h,dk", [(3000, 200, 6, 128), (5000, 97, 2, 128), (4000, 256, 3, 128), (3000, 512, 6, 128), (900, 1024, 2, 128),
+                                      (3000, 200, 6, 64), (8192, 200, 6, 64), (2000, 512, 4, 64)])
+def test_sparse_attn_x3_hl_fused_key_projection(n, k, h, dk):
     """snf_linear_rows_x3_kpfrag_f32 + snf_sparse_attn_fwd_x3_hl_kpfrag: the key projection writes the attention kernel's fragment
     image itself -- bit-identical to projection -> fp32 Kp -> snf_sparse_attn_fwd_x3_hl (same products, same rounding points)."""
     o_ = ops()
-    dk = 128
     d = h * dk
     g = torch.Generator().manual_seed(n + k)
     xs = torch.randn(k, d, generator=g).to(DEV)
@@ -509,7 +541,7 @@ def test_sparse_attn_x3_hl_fused_key_projection(n, k, h):
 
 def test_sparse_attn_x3_hl_fused_key_projection_domain():
     assert not ops().x3_hl_kpfrag_supported(257, 2, 128)      # two chunks of 132 keys: not on key-block boundaries
-    assert not ops().x3_hl_kpfrag_supported(200, 12, 64)      # dk = 64
+    assert not ops().x3_hl_kpfrag_supported(200, 24, 32)      # dk = 32
     assert not ops().x3_hl_kpfrag_supported(96, 6, 128)
     with pytest.raises(ValueError):
         ops().linear_rows_x3_kpfrag(torch.zeros(257, 256, device=DEV), torch.zeros(256, 256, device=DEV), None, 2)

@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from snuffy_amd import _ffi, ops  # noqa: E402
 
 WG = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+KBW = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 n, k, h, dk = 32768, 200, 6, 128
 d = h * dk
 lib = _ffi.load()
@@ -16,6 +17,7 @@ lib.snf_debug_attn_trace.argtypes = [ctypes.c_void_p]
 lib.snf_debug_attn_trace.restype = None
 lib.snf_debug_attn_trace_wg.argtypes = [ctypes.c_int]
 lib.snf_debug_attn_trace_wg.restype = None
+lib.snf_debug_x3p_kbw(KBW)
 qv = torch.randn(n, 2 * d, device="cuda")
 img = ops.split_hl_rows(qv)
 kp = torch.randn(k, d, device="cuda")
