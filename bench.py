@@ -35,6 +35,13 @@ WORKLOADS = {
     # clip(round(lognormal(mu = ln 30000 - sigma^2/2, sigma = 0.5)), 1000, 100000), seed 0; sharded over the ranks (rank r takes
     # bags r::W), resident in HBM.  N below is only the nominal length (roofline micro-benchmark shape).
     "cam16": dict(N=30000, D=768, h=6, lam=200, bags=400),
+    # the reference's own published CAMELYON16 recipes (reference README.md:609-669; SURVEY 8(d): "also report h=4, the README recipe"):
+    # 4 heads (dk = 96 / 192), a random patch share, bags of the CAMELYON16 mean length.  The random share comes from the device
+    # sampler (MILNet.configure(sampler="device"): the opt-in fast mode; value_reference_sampler = the same forward with the reference's
+    # numpy draws on the host, the bit-exact parity mode)
+    "readme_dino_scratch": dict(N=30000, D=384, h=4, lam=900, r=0.7777777777777778),
+    "readme_dino_adapter": dict(N=30000, D=384, h=4, lam=500, r=0.5),
+    "readme_mae_adapter": dict(N=30000, D=768, h=4, lam=500, r=0.5),
 }
 # BASELINE.json configs[3]: compute_feats.py's DINO ViT-S/16 + adapter (ffn_num 32, scalar 10) over 224 x 224 tiles, batch 512
 VIT = dict(arch="vit_small", width=384, batch=512, img=224, patch=16, ffn_num=32, scalar="10")
@@ -42,10 +49,10 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
-def build_net(D, h, lam, precision, device):
+def build_net(D, h, lam, precision, device, r=0.0):
     from snuffy_amd.snuffy import build_milnet
     torch.manual_seed(0)
-    net = build_milnet(D, h, "relu", lam, 0.0, 1)
+    net = build_milnet(D, h, "relu", lam, r, 1)
     for _, p in net.named_parameters():
         if p.dim() > 1:
             torch.nn.init.xavier_normal_(p)
@@ -90,24 +97,31 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
     from snuffy_amd import ops
     N, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
     K, dk = min(lam, N), D // h
+    D_true = D
+    if precision == "fp32" and SF.head_pad(dk) not in (None, dk):
+        # head widths between the kernel's ride zero-padded (functional.head_pad: the README recipes' dk = 96 -> 128): the launch
+        # streams the padded Q | V image; algorithmic bytes below stay those of the TRUE width
+        dk = SF.head_pad(dk)
+        D = h * dk
     g = torch.Generator(device="cpu").manual_seed(7)
     dt = torch.bfloat16 if precision == "bf16" else torch.float32
     elt = 2 if precision == "bf16" else 4
     out = {}
     scores = torch.randn(N, generator=g).to(device)
-    t_topk_alone = timed(lambda: ops.topk(scores, K), 20)
+    k_top = max(1, math.ceil(lam * (1.0 - wl.get("r", 0.0))))         # the critic's share of the K selected rows
+    t_topk_alone = timed(lambda: ops.topk(scores, k_top), 20)
     # the selection as the model dispatches it: the first radix digit is counted inside the critic pass (fused selector), so
     # top-Lambda costs the select launch plus whatever the histogram adds to the critic -- timed as
     # (critic + histogram -> select) minus (critic alone) on a resident bag
-    xb = torch.randn(N, D, generator=g).to(device)
-    wc = (torch.randn(1, D, generator=g) / math.sqrt(D)).to(device)
+    xb = torch.randn(N, D_true, generator=g).to(device)
+    wc = (torch.randn(1, D_true, generator=g) / math.sqrt(D_true)).to(device)
     bc = torch.zeros(1, device=device)
     eps = 1e-5 if precision == "bf16" else None        # the bf16 model's critic pass also emits the normalised bf16 copy
     t_topk, fused = t_topk_alone, False
     if ops.critic_select(xb, wc, bc, eps) is not None:
-        ops.topk(ops.critic_select(xb, wc, bc, eps)[0].view(-1), K)
+        ops.topk(ops.critic_select(xb, wc, bc, eps)[0].view(-1), k_top)
         t_crit = timed((lambda: ops.critic_ln(xb, wc, bc, eps)) if eps is not None else (lambda: ops.critic(xb, wc, bc)), 20)
-        t_both = timed(lambda: ops.topk(ops.critic_select(xb, wc, bc, eps)[0].view(-1), K), 20)
+        t_both = timed(lambda: ops.topk(ops.critic_select(xb, wc, bc, eps)[0].view(-1), k_top), 20)
         t_topk, fused = max(t_both - t_crit, 0.0), True
     del xb
     kp = torch.randn(K, D, generator=g).to(device)
@@ -122,8 +136,7 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
             i = state["i"] = (state["i"] + 1) % nset
             ops.sparse_attn_fwd_mfma(qvs[i][:, :D], qvs[i][:, D:], kp_in, N, h)
         kern = "sparse_attn_mfma_kernel+reduce_partials_kernel"
-    elif precision == "fp32" and SF.X3_HL_ATTENTION and SF.FP32_GEMM == "x3" and ops.x3_hl_attn_supported(K, dk) \
-            and ops.hl_eligible(N, 2 * D, D):
+    elif precision == "fp32" and SF.X3_HL_ATTENTION and SF.FP32_GEMM == "x3" and ops.x3_hl_attn_supported(K, dk):
         # what functional.encoder_layer dispatches for a bag this size: the pipelined split-bf16 x3 kernel on the hl image the
         # Q | V projection writes (4 bytes per element, like the fp32 tensor); three launches: Kp split, main, reduction
         imgs = [ops.split_hl_rows(qv.float()) for qv in qvs]      # [N, 4 D] bf16 = image of Q | image of V
@@ -132,7 +145,7 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
         if SF.X3_HL_KPFRAG and ops.x3_hl_kpfrag_supported(K, h, dk):
             # ... and the key projection in front writes Kp as the kernel's fragment image (no prep launch): two launches
             wk = (torch.randn(D, D, generator=g) / math.sqrt(D)).to(device)
-            kp_x3p = ops.linear_rows_x3_kpfrag(torch.randn(K, D, generator=g).to(device), wk, None, h)
+            kp_x3p = ops.linear_rows_x3_kpfrag(torch.randn(K, D, generator=g).to(device), wk, None, h, scale=1.0 / math.sqrt(D_true // h))
             kern = "sparse_attn_x3p_kernel+x3p_reduce_kernel"
             del wk
 
@@ -193,7 +206,9 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
                 acc += e0.elapsed_time(e1)
         t_warm = acc / 10
         del buf, src
-    # algorithmic bytes: read Q and V once, read Kp, write O;  top-k: read N scores, write K indices
+    # algorithmic bytes: read Q and V once, read Kp, write O;  top-k: read N scores, write K indices -- at the TRUE width
+    streamed_width = D
+    D = D_true
     b_attn = 2 * N * D * elt + K * D * elt + K * D * 4
     b_topk = 4 * N + 8 * K
     b_gather = 2 * K * D * 4
@@ -235,7 +250,8 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
     out["roofline"] = dict(bound="hbm", kernel=kern, achieved=round(b_attn / (t_attn * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS,
                            unit="GB/s", frac=round(b_attn / (t_attn * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic=traffic,
                            us_per_launch=round(t_attn * 1e3, 2), algorithmic_bytes=b_attn,
-                           flops=4 * N * K * D * (3 if kern.startswith("sparse_attn_x3") else 1), operand_dtype=precision, survey_8d_bytes=b_attn_8d,
+                           flops=4 * N * K * D * (3 if kern.startswith("sparse_attn_x3") else 1), operand_dtype=precision,
+                           head_width=D // h, head_width_streamed=streamed_width // h, survey_8d_bytes=b_attn_8d,
                            survey_8d_frac=round(b_attn_8d / (t_attn * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
     if in_bag is not None:
         out["roofline"]["in_bag_rocprof"] = in_bag
@@ -304,7 +320,7 @@ def cpu_baseline(wl, budget_s=25.0):
     host's cores.  More threads is not faster on a many-core host (round 1: 0.79 slides/s on 128 threads vs 1.7 on 8): the
     thread count is swept and the best is reported with its count."""
     from oracle import snuffy_oracle as orc          # cpu_baseline leg: the only place bench.py touches oracle/
-    N, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
+    N, D, h, lam, r = wl["N"], wl["D"], wl["h"], wl["lam"], wl.get("r", 0.0)
     cores = os.cpu_count() or 1
     try:
         import psutil
@@ -320,10 +336,10 @@ def cpu_baseline(wl, budget_s=25.0):
     with torch.no_grad():
         for thr in sweep:
             torch.set_num_threads(thr)
-            orc.milnet_forward(x, sd, h, "relu", lam, 0.0, 1)           # warm-up at this thread count
+            orc.milnet_forward(x, sd, h, "relu", lam, r, 1)             # warm-up at this thread count
             t0, n = time.perf_counter(), 0
             while True:
-                orc.milnet_forward(x, sd, h, "relu", lam, 0.0, 1)
+                orc.milnet_forward(x, sd, h, "relu", lam, r, 1)
                 n += 1
                 el = time.perf_counter() - t0
                 if el > per * 0.7 or n >= 8:
@@ -436,6 +452,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     N, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
+    r_share = wl.get("r", 0.0)
     # bags resident in HBM before the timed region; several distinct bags per rank, cycled
     if "bags" in wl:
         import numpy as np
@@ -452,15 +469,17 @@ def main():
         bags = [torch.randn(1, N, D, generator=g).to(device) for _ in range(nbags)]
     labels = [torch.tensor([float(i % 2)], device=device) for i in range(nbags)]
 
-    def measure(precision, return_attention=False, steps=None, warmup=None, use_graph=None, mode=None):
+    def measure(precision, return_attention=False, steps=None, warmup=None, use_graph=None, mode=None, sampler="device"):
         """Times `steps` steps of one configuration (barrier + synchronize on both sides, max over ranks).
         Returns (elapsed seconds, per-rank seconds, launch mode)."""
         steps = args.steps if steps is None else steps
         warmup = args.warmup if warmup is None else warmup
         use_graph = args.graph if use_graph is None else use_graph
         mode = args.mode if mode is None else mode
-        net = build_net(D, h, lam, precision, device)
-        net.configure(return_attention=return_attention)
+        net = build_net(D, h, lam, precision, device, r_share)
+        net.configure(return_attention=return_attention, sampler=sampler)
+        if r_share > 0 and sampler != "device":
+            use_graph = False                  # the reference's numpy draws synchronise with the host on every bag
         launch = "eager"
         if mode == "train":
             from snuffy_amd.train import BagParallelStepper
@@ -479,7 +498,8 @@ def main():
                             for b in bags:
                                 net(b)
                         out = net(bags[0])
-                        same = torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+                        # (with a random share every forward draws other rows: only the critic scores repeat)
+                        same = torch.equal(out[0], ref[0]) and (r_share > 0 or torch.equal(out[1], ref[1]))
                     except Exception:
                         same = False
                     if not same or not getattr(net, "_graphs", None):   # replay unavailable: kernels issued from Python
@@ -552,6 +572,11 @@ def main():
             finally:
                 SF.FP32_GEMM = keep
             extra["f32_library_gemm"] = dict(elapsed=e4, steps=steps_l, launch=l4)
+    if r_share > 0 and args.mode == "eval" and not args.headline_only:
+        # the same forward with the random share drawn by the reference's np.random.choice on the host (bit-exact parity mode)
+        steps_r = max(5, args.steps // 4)
+        e6, _, l6 = measure(args.precision, steps=steps_r, warmup=min(args.warmup, 10), sampler="reference")
+        extra["reference_sampler"] = dict(elapsed=e6, steps=steps_r, launch=l6)
     train_leg = None
     if args.mode == "eval" and (dist is not None or not args.headline_only):   # at N = 1 too: one short leg, so that the
         # driver's single-GPU record also carries a training number (no collective at world 1: the stepper is the trainer)
@@ -573,9 +598,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_s": args.preroll_s,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dt_name[args.precision], "data": "synthetic",
-            "config": {"workload": "%s: MILNet %s, 1 bag/step/rank, N=%d patches D=%d h=%d Lambda=%d (K=%d) depth=1 relu mlp x4"
+            "config": {"workload": "%s: MILNet %s, 1 bag/step/rank, N=%d patches D=%d h=%d Lambda=%d (K=%d%s) depth=1 relu mlp x4"
                                    % (args.workload, "train step (fwd+bwd+AdamW+all-reduce)" if args.mode == "train" else
-                                      "eval forward", N, D, h, lam, K),
+                                      "eval forward", N, D, h, lam, K,
+                                      "" if r_share == 0 else ", random_patch_share %.4g: %d top + %d random rows, device sampler"
+                                      % (r_share, math.ceil(lam * (1 - r_share)), int(lam * r_share))),
                        "parallelism": "bag-parallel x%d" % world, "bags_resident_per_rank": nbags,
                        "launch": launch, "rccl_ranks": world if dist is not None else 0,
                        "per_rank_slides_per_s": [round(args.steps / t, 2) for t in per_rank],
@@ -585,6 +612,8 @@ def main():
         for key, rec in extra.items():
             if key == "with_A":
                 line["value_with_attention_output"] = round(world * rec["steps"] / rec["elapsed"], 3)
+            elif key == "reference_sampler":
+                line["value_reference_sampler"] = round(world * rec["steps"] / rec["elapsed"], 3)
             elif key == "f32_library_gemm":
                 line["value_f32_library_gemm"] = round(world * rec["steps"] / rec["elapsed"], 3)
             else:
@@ -596,7 +625,7 @@ def main():
                 line["value_train" + sfx] = round(world * rec["steps"] / rec["elapsed"], 3)
                 line["ms_per_step_train" + sfx] = round(rec["elapsed"] / rec["steps"] * 1e3, 4)
             line["train_leg"] = {"steps": train_leg[args.precision]["steps"], "rccl_ranks": world,
-                                 "all_reduce_bytes_per_step": 4 * sum(p.numel() for p in build_net(D, h, lam, "fp32", "cpu").parameters()),
+                                 "all_reduce_bytes_per_step": 4 * sum(p.numel() for p in build_net(D, h, lam, "fp32", "cpu", r_share).parameters()),
                                  "what": "fwd + bwd + fused AdamW + ONE flat-gradient all-reduce (sum, /W) per step, 1 bag per rank"}
         line["arithmetic"] = {
             "bf16": "bf16 MFMA operands, fp32 accumulate / softmax / LayerNorm / residual (north_star's 1e-2 class)",

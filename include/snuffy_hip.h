@@ -467,6 +467,19 @@ int snf_ln_mean_head_varlen_f32(const float* z, const int64_t* offsets, int bags
                                 size_t workspace_bytes, snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * K3  device-side random patch share (opt-in fast mode)       replaces snuffy.py:136-147 (np.random.choice on the host behind a
+ *     device -> host copy of the selected rows) when the caller asks for it; the reference's own MT19937 draws stay the default.
+ *   snf_random_share_keys_f32: keys[r] = the non-negative float whose bit pattern is a 30-bit Philox4x32-10 output for row r (key =
+ *     state[0] = seed, counter = (r / 4, state[1] + (layer << 48)), element r & 3), keys[exclude_rows[i]] = -1.  The k2 largest keys
+ *     (snf_topk_f32) are a uniform sample without replacement of the rows not excluded, in random order.
+ *   state: 16-byte device record {u64 seed, u64 offset}, owned by the caller; snf_sampler_advance adds 1 to the offset ON THE DEVICE,
+ *     so a captured graph (advance, keys, top-k) draws fresh rows on every replay.  Host twin: oracle/philox_ref.py.
+ * --------------------------------------------------------------------------------------------------------- */
+int snf_sampler_advance(void* state, snf_stream_t stream);
+int snf_random_share_keys_f32(const void* state, int layer, int64_t n, const int64_t* exclude_rows, int n_exclude, float* keys,
+                              snf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Debug hooks (development tools only: tools/attn_trace.py, tools/x3p_trace.py; nothing in the product path calls them).
  * snf_debug_attn_trace(buf): device buffer of u64 that dev builds of the attention kernels (X3P_TRACE / SNF_ATTN_TRACE defines)
  * fill with s_memtime stamps of workgroup snf_debug_attn_trace_wg(wg); null switches the stamps off.  Shipped builds carry no

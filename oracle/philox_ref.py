@@ -39,3 +39,24 @@ def dropout_mask(h, n, k, p, seed, offset):
     thresh = np.uint64(4294967295 if t >= 4294967295.0 else int(t))
     scale = np.float32(1.0 / (1.0 - p32))
     return np.where(words >= thresh, scale, np.float32(0)).astype(np.float32).reshape(h, n, k)
+
+
+def random_share_keys(n, seed, offset, layer=0, exclude=()):
+    """Host twin of snf_random_share_keys_f32 (csrc/sampler.hip): float32 keys [n]; the k2 largest (ties by ascending row) are the
+    device sampler's random patch share."""
+    g = np.arange((n + 3) // 4, dtype=np.uint64)
+    off = (np.uint64(offset & 0xFFFFFFFFFFFFFFFF) + (np.uint64(layer) << np.uint64(48))) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    sd = np.uint64(seed & 0xFFFFFFFFFFFFFFFF)
+    out = philox4x32_10(g & MASK32, g >> np.uint64(32), np.full_like(g, off & MASK32), np.full_like(g, off >> np.uint64(32)),
+                        sd & MASK32, sd >> np.uint64(32))
+    words = np.stack(out, axis=1).reshape(-1)[:n]
+    keys = (words >> np.uint64(2)).astype(np.uint32).view(np.float32).copy()
+    keys[np.asarray(exclude, dtype=np.int64)] = -1.0
+    return keys
+
+
+def random_share_draw(n, k2, seed, offset, layer=0, exclude=()):
+    """The k2 rows the device sampler selects: descending key, ties by ascending row (snf_topk_f32's rule)."""
+    keys = random_share_keys(n, seed, offset, layer, exclude)
+    order = np.argsort(-keys.astype(np.float64), kind="stable")
+    return order[:k2]

@@ -139,6 +139,8 @@ SIGNATURES = {
     "snf_vit_residual_ln": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_float,
                                     c_void_p, c_void_p, c_void_p]),
     "snf_vit_attention_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "snf_sampler_advance": (c_int, [c_void_p, c_void_p]),
+    "snf_random_share_keys_f32": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "snf_debug_attn_trace": (None, [c_void_p]),
     "snf_debug_attn_trace_wg": (None, [c_int]),
     "snf_debug_x3p_kbw": (None, [c_int]),

@@ -342,7 +342,7 @@ def head(parts, norm, linear, packed=None):
     return logits
 
 
-def _folded(layer):
+def _folded(layer, dkp=None):
     """bf16 path: LayerNorm affine folded into the following projection, cached ON THE LAYER until a parameter changes.
 
     LN(x) W^T + b = xhat (W * gamma)^T + (W beta + b)   with xhat = (x - mean) * rstd.
@@ -355,10 +355,28 @@ def _folded(layer):
     ff = layer.feed_forward
     plist = [n0.weight, n0.bias, n1.weight, n1.bias, lq.weight, lq.bias, lv.weight, lv.bias, ff.w_1.weight,
              ff.w_1.bias, ff.w_2.weight, lk.weight, lk.bias]
-    key = tuple(param_key(p) for p in plist)
+    hh = layer.self_attn.h
+    dk0 = lq.weight.shape[0] // hh
+    dkp = dk0 if dkp is None else dkp                     # head width of the Q | V columns (head_pad; dk0 = not padded)
+    key = tuple(param_key(p) for p in plist) + (dkp,)
     ent = getattr(layer, "_fold", None)
     if ent is not None and ent[0] == key:
         return ent[1]
+    if dkp != dk0:
+        # padded heads (README recipes, dk = 96 -> 128): fold the zero-padded projections; the key projection and the output
+        # projection of the padded form come from _padded_heads (fp32, split-bf16 x3 like the unpadded K-row projections)
+        with torch.no_grad():
+            bf = torch.bfloat16
+            g0, b0, g1, b1 = (t.detach().float() for t in (n0.weight, n0.bias, n1.weight, n1.bias))
+            wqv, bqv = _qv_weights(layer, dkp)
+            w1 = ff.w_1.weight.detach().float()
+            bqv_f = (wqv.float() @ b0 + bqv.float()).contiguous()
+            b1f = (w1 @ b1 + ff.w_1.bias.detach().float()).contiguous()
+            out = dict(wqv=(wqv.float() * g0).to(bf).contiguous(), bqv=bqv_f.to(bf), bqv_f=bqv_f,
+                       w1=(w1 * g1).to(bf).contiguous(), b1=b1f, b1h=b1f.to(bf), w2=ff.w_2.weight.detach().to(bf),
+                       wk=None, bk=None)
+        layer._fold = (key, out)
+        return out
     with torch.no_grad():
         g0, b0, g1, b1 = n0.weight, n0.bias, n1.weight, n1.bias
         d, f = lq.weight.shape[1], ff.w_1.weight.shape[0]
@@ -394,21 +412,84 @@ def _folded(layer):
     return out
 
 
-def _split_weights(layer):
+def head_pad(dk):
+    """Head width the pipelined fp32-class attention runs a head of true width dk at, or None.  The kernels are built for dk = 64 and
+    128; other widths ride zero-padded -- the README recipes train with h = 4 (dk = 96 at D = 384, reference README.md:609-643):
+    zero rows in Wq / Wk / Wv give zero columns in Q, Kp and V, which add nothing to Q Kp^T and produce zero columns of O that zero
+    columns of Wo ignore: bit-for-bit the products of the true width (one third more matrix work and Q | V bytes at dk = 96)."""
+    if dk in (64, 128):
+        return dk
+    if dk % 16 == 0 and 64 < dk < 128:
+        return 128
+    if dk % 16 == 0 and 16 <= dk < 64:
+        return 64
+    return None
+
+
+def _pad_heads_out(w, b, h, dk, dkp):
+    """Rows of w [h dk, d] (and entries of b) regrouped per head and zero-padded to dkp per head -> ([h dkp, d], [h dkp])."""
+    d_in = w.shape[1]
+    wp = w.new_zeros(h, dkp, d_in)
+    wp[:, :dk] = w.detach().view(h, dk, d_in)
+    bp = w.new_zeros(h, dkp)
+    if b is not None:
+        bp[:, :dk] = b.detach().view(h, dk)
+    return wp.view(h * dkp, d_in), bp.view(h * dkp)
+
+
+def _pad_heads_in(w, h, dk, dkp):
+    """Columns of w [n, h dk] regrouped per head and zero-padded -> [n, h dkp]."""
+    n = w.shape[0]
+    wp = w.new_zeros(n, h, dkp)
+    wp[:, :, :dk] = w.detach().view(n, h, dk)
+    return wp.view(n, h * dkp)
+
+
+def _qv_weights(layer, dkp):
+    """(cat[Wq; Wv], cat[bq; bv]) of the layer, its heads zero-padded to dkp columns when that differs from the true width."""
+    lq, lk, lv, lo = layer.self_attn.linears
+    h = layer.self_attn.h
+    dk = lq.weight.shape[0] // h
+    if dkp == dk:
+        return torch.cat([lq.weight, lv.weight]).detach(), torch.cat([lq.bias, lv.bias]).detach()
+    wq, bq = _pad_heads_out(lq.weight, lq.bias, h, dk, dkp)
+    wv, bv = _pad_heads_out(lv.weight, lv.bias, h, dk, dkp)
+    return torch.cat([wq, wv]), torch.cat([bq, bv])
+
+
+def _padded_heads(layer, dkp):
+    """Zero-padded key / output projections of a layer whose head width rides padded to dkp (head_pad): (wk [h dkp, d], bk, wo
+    [d, h dkp]), cached on the layer like the other derived weights."""
+    lq, lk, lv, lo = layer.self_attn.linears
+    key = tuple(param_key(p) for p in (lk.weight, lk.bias, lo.weight)) + (dkp,)
+    ent = getattr(layer, "_fold_pad", None)
+    if ent is not None and ent[0] == key:
+        return ent[1]
+    h = layer.self_attn.h
+    dk = lk.weight.shape[0] // h
+    with torch.no_grad():
+        wk, bk = _pad_heads_out(lk.weight, lk.bias, h, dk, dkp)
+        out = dict(wk=wk.contiguous(), bk=bk.contiguous(), wo=_pad_heads_in(lo.weight, h, dk, dkp).contiguous())
+    layer._fold_pad = (key, out)
+    return out
+
+
+def _split_weights(layer, dkp=None):
     """fp32 path on the matrix cores: every projection weight as its split image [Wh | Wl | Wh] (ops.split3_weight), cached
     on the layer like the bf16 fold (same key rule)."""
     lq, lk, lv, lo = layer.self_attn.linears
     ff = layer.feed_forward
     plist = [lq.weight, lq.bias, lv.weight, lv.bias, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias]
-    key = tuple(param_key(p) for p in plist)
+    dkp = lq.weight.shape[0] // layer.self_attn.h if dkp is None else dkp          # head width of the Q | V columns (head_pad)
+    key = tuple(param_key(p) for p in plist) + (dkp,)
     ent = getattr(layer, "_fold3", None)
     if ent is not None and ent[0] == key:
         return ent[1]
     with torch.no_grad():
-        wqv = torch.cat([lq.weight, lv.weight])
+        wqv, bqv = _qv_weights(layer, dkp)
         out = dict(
             wqv=ops.split3_weight(wqv),                                                # [2D, 3D]: output [Q | V]
-            bqv=torch.cat([lq.bias, lv.bias]).float().contiguous(),
+            bqv=bqv.float().contiguous(),
             w1=ops.split3_weight(ff.w_1.weight), b1=ff.w_1.bias.detach().float().contiguous(),
             w2=ops.split3_weight(ff.w_2.weight), b2=ff.w_2.bias.detach().float().contiguous(),
         )
@@ -428,21 +509,21 @@ def _hl_weights(layer, fw):
     return fw["hl"]
 
 
-def _hl_weights_folded(layer):
+def _hl_weights_folded(layer, dkp=None):
     """hl images of Wq | Wv and W1 with the LayerNorm affines folded in (FP32_SHARED_NORM):  LN(x) W^T + b = xhat (W * gamma)^T +
     (W beta + b).  The fold is done in fp64 and rounded once to fp32 before the hi / lo split; cached like _split_weights."""
     n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
     lq, lk, lv, lo = layer.self_attn.linears
     ff = layer.feed_forward
     plist = [n0.weight, n0.bias, n1.weight, n1.bias, lq.weight, lq.bias, lv.weight, lv.bias, ff.w_1.weight, ff.w_1.bias]
-    key = tuple(param_key(p) for p in plist)
+    dkp = lq.weight.shape[0] // layer.self_attn.h if dkp is None else dkp
+    key = tuple(param_key(p) for p in plist) + (dkp,)
     ent = getattr(layer, "_fold3f", None)
     if ent is not None and ent[0] == key:
         return ent[1]
     with torch.no_grad():
         g0, b0, g1, b1 = (t.double() for t in (n0.weight, n0.bias, n1.weight, n1.bias))
-        wqv = torch.cat([lq.weight, lv.weight]).double()
-        bqv = torch.cat([lq.bias, lv.bias]).double()
+        wqv, bqv = (t.double() for t in _qv_weights(layer, dkp))
         w1, bb1 = ff.w_1.weight.double(), ff.w_1.bias.double()
         out = dict(wqv=ops.split_hl_weight((wqv * g0).float().contiguous()), bqv=(wqv @ b0 + bqv).float().contiguous(),
                    w1=ops.split_hl_weight((w1 * g1).float().contiguous()), b1=(w1 @ b1 + bb1).float().contiguous())
@@ -467,6 +548,7 @@ def invalidate_folded(layer):
     layer._fold = None
     layer._fold3 = None
     layer._fold3f = None
+    layer._fold_pad = None
     layer._xhat_offer = None
     layer._xn3_offer = None
     drop_param_caches(layer)
@@ -529,25 +611,35 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
         # fp32-class arithmetic on the matrix cores: every [N, .] projection is ONE bf16 GEMM over a tripled K axis
         # (activations [hi | hi | lo], weights [Wh | Wl | Wh]; products to ~2^-17, fp32 accumulate) -- the fp32 library
         # GEMMs these replace were 85 % of a config-B bag (profiles/r02_bench_cfgB_fp32_kernel_stats.csv)
-        fw = _split_weights(layer)
         f = ff.w_1.weight.shape[0]
+        dk = d // h
+        # pre-split operands for the pipelined attention kernel: the projection's epilogue writes [Q | V] as its hl image (the same
+        # hi / lo values the attention kernel would derive from the fp32 tensor, the same 4 bytes per element); bags too small for
+        # the one-pass GEMM get the same image out of the concatenated-K GEMM's epilogue.  Head widths between the kernel's (the
+        # README recipes: h = 4, dk = 96) ride zero-padded to the next one (head_pad): dkp columns per head in Q, Kp, V and O.
+        dkp = head_pad(dk) if (FP32_ATTENTION == "x3" and X3_HL_ATTENTION) else None
+        hl_attn = (ragged is None and packed is None and dkp is not None and d % 16 == 0 and ops.x3_hl_attn_supported(k, dkp)
+                   and lk.weight.dtype == torch.float32 and (dkp == dk or ops.gemm_supported(n, 2 * h * dkp, 3 * d)))
+        if not hl_attn:
+            dkp = dk
+        dp = h * dkp                                                                # width of Q, V, Kp, O (d unless padded)
+        fw = _split_weights(layer, dkp)
         # large bags: the one-pass kernel on interleaved [hi(32) | lo(32)] images (one full-line DMA per operand row and K step,
         # 96 MFMAs per 24 fragment reads); otherwise the concatenated form over [hi | hi | lo]
-        hl = d % 32 == 0 and f % 32 == 0 and ops.hl_eligible(n, 2 * d, d) and ops.hl_eligible(n, f, d) and ops.hl_eligible(n, d, f)
+        hl = d % 32 == 0 and f % 32 == 0 and ops.hl_eligible(n, 2 * dp, d) and ops.hl_eligible(n, f, d) and ops.hl_eligible(n, d, f)
         fh = _hl_weights(layer, fw) if hl else None
         xs, slot = ops.gather_slot_map(x2, sel)                                     # snuffy.py:131,145-147 (+ row -> slot map)
         shared = hl and shared_norm_layer(layer)
-        fhf = _hl_weights_folded(layer) if shared else None
+        fhf = _hl_weights_folded(layer, dkp) if shared else None
         xn3 = _take_xn3(layer, x2, n0, shared)                                      # left by the critic pass, if any
-        # pre-split operands for the pipelined attention kernel: the projection's epilogue writes [Q | V] as its hl image (the same
-        # hi / lo values the attention kernel would derive from the fp32 tensor, the same 4 bytes per element)
-        # (bags too small for the one-pass GEMM get the same image out of the concatenated-K GEMM's epilogue)
-        hl_attn = (ragged is None and packed is None and FP32_ATTENTION == "x3" and X3_HL_ATTENTION and d % 32 == 0
-                   and ops.x3_hl_attn_supported(k, d // h))
+        fp = _padded_heads(layer, dkp) if dkp != dk else None
+        wk, bk = (lk.weight.detach(), None if lk.bias is None else lk.bias.detach()) if fp is None else (fp["wk"], fp["bk"])
+        scale = 1.0 / math.sqrt(dk)                                                 # of the TRUE head width (snuffy.py:162)
         # keys = RAW selected rows (K rows: fp32).  For the pipelined kernel the projection writes its fragment image directly
-        if (hl_attn and X3_HL_KPFRAG and ops.x3_hl_kpfrag_supported(k, h, d // h) and lk.weight.dtype == torch.float32
-                and xs.dtype == torch.float32 and d % 16 == 0):
-            kp = ops.linear_rows_x3_kpfrag(xs, lk.weight.detach(), None if lk.bias is None else lk.bias.detach(), h)
+        if hl_attn and X3_HL_KPFRAG and ops.x3_hl_kpfrag_supported(k, h, dkp) and xs.dtype == torch.float32:
+            kp = ops.linear_rows_x3_kpfrag(xs, wk, bk, h, scale=scale)
+        elif fp is not None:
+            kp = ops.linear_rows_x3(xs, wk, bk)
         else:
             kp = _rows_linear(xs, lk)
         if hl:
@@ -564,7 +656,8 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
             del xn3
         q, v = (None, None) if hl_attn else (qv[:, :d], qv[:, d:])
         if hl_attn:
-            o, attn, _ = ops.sparse_attn_fwd_x3_hl(qv[:, :2 * d], qv[:, 2 * d:], kp, h, need_attn=need_attn)   # snuffy.py:160-168
+            o, attn, _ = ops.sparse_attn_fwd_x3_hl(qv[:, :2 * dp], qv[:, 2 * dp:], kp, h, need_attn=need_attn,
+                                                   scale=None if isinstance(kp, ops.KpFrag) else scale)   # snuffy.py:160-168
         elif ragged is not None:
             o, attn, _ = ops.sparse_attn_fwd_ragged(q, v, kp, packed, ragged, h, need_attn=need_attn)
         elif packed is not None:
@@ -574,7 +667,10 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
         else:
             o, attn, _ = ops.sparse_attn_fwd(q.contiguous(), kp, v.contiguous(), h, need_attn=need_attn)
         del q, v, qv
-        delta = _rows_linear(o, lo)                                     # snuffy.py:205
+        if fp is not None:                                              # padded heads: the zero columns of O meet zero columns of Wo
+            delta = ops.linear_rows_x3(o, fp["wo"], None if lo.bias is None else lo.bias.detach())
+        else:
+            delta = _rows_linear(o, lo)                                 # snuffy.py:205
         if shared:
             # y differs from x in the K selected rows only (x_sel = xs + delta, snuffy.py:108): re-normalise those into the image
             # the first sublayer used -- one small launch: sum, statistics, hl rows written at their place
@@ -631,18 +727,28 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
     # ---- bf16 path -------------------------------------------------------------------------------------------------
     if n0.eps != n1.eps:
         raise NotImplementedError("bf16 path shares one normalisation between both sublayers: eps must match")
-    fw = _folded(layer)
+    dk = d // h
+    # head widths between the MFMA kernel's ride zero-padded (head_pad: the README recipes' dk = 96 -> 128), single bags only
+    dkp = head_pad(dk) if (ragged is None and packed is None and lk.weight.dtype == torch.float32) else dk
+    if dkp is None or (dkp != dk and not (ops.mfma_attn_supported(k, dkp, n, 2 * h * dkp) and ops.linear_rows_x3_supported(k, h * dkp, d)
+                                         and ops.gemm_supported(n, 2 * h * dkp, d))):
+        dkp = dk
+    dp = h * dkp
+    fw = _folded(layer, dkp)
+    fp = _padded_heads(layer, dkp) if dkp != dk else None
     xhat = _take_xhat(layer, x2, n0.eps)                                                 # left by the critic pass, if any
     if xhat is None:
         xhat = torch.empty(n, d, dtype=torch.bfloat16, device=x2.device)
         ops.layernorm_rows(x2, None, None, n0.eps, out=xhat)
     qv = ops.linear_bf16(xhat, fw["wqv"], fw["bqv_f"], fw["bqv"])                   # [N, 2D] bf16 = [Q | V], bias epilogue
-    q, v = qv[:, :d], qv[:, d:]                                                     # row-strided views, used in place
-    if ragged is None and (packed is not None or ops.mfma_attn_supported(k, d // h, n, qv.stride(0))):
+    q, v = qv[:, :dp], qv[:, dp:]                                                   # row-strided views, used in place
+    if ragged is None and (packed is not None or ops.mfma_attn_supported(k, dkp, n, qv.stride(0))):
         # keys = RAW selected rows: the gather also leaves them in bf16, the projection runs like Q | V (bf16 operands,
         # fp32 accumulate, bf16 out) and the attention kernel reads Kp as it is
         xs, slot, xs16 = ops.gather_slot_map(x2, sel, bf16_copy=True)               # snuffy.py:131,145-147 (+ row -> slot map)
-        if (FP32_GEMM == "x3" and xs.shape[0] < 2048 and ops.linear_rows_x3_supported(xs.shape[0], d, d)
+        if fp is not None:
+            kp = ops.linear_rows_x3(xs, fp["wk"], fp["bk"], out_dtype=torch.bfloat16)
+        elif (FP32_GEMM == "x3" and xs.shape[0] < 2048 and ops.linear_rows_x3_supported(xs.shape[0], d, d)
                 and lk.weight.dtype == torch.float32):
             # keys of one bag: fp32-class product of the fp32 rows, rounded once to the bf16 the attention kernel reads
             kp = ops.linear_rows_x3(xs, lk.weight.detach(), lk.bias.detach(), out_dtype=torch.bfloat16)
@@ -651,7 +757,7 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
         if packed is not None:
             o, attn, _ = ops.sparse_attn_fwd_mfma_varlen(q, v, kp, packed, kb, h, need_attn=need_attn)
         else:
-            o, attn, _ = ops.sparse_attn_fwd_mfma(q, v, kp, n, h, need_attn=need_attn)
+            o, attn, _ = ops.sparse_attn_fwd_mfma(q, v, kp, n, h, scale=1.0 / math.sqrt(dk), need_attn=need_attn)
     else:
         xs, slot = ops.gather_slot_map(x2, sel)
         kp = _rows_linear(xs, lk)
@@ -662,7 +768,10 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
         else:
             o, attn, _ = ops.sparse_attn_fwd(q.float(), kp, v.float(), h, need_attn=need_attn)
     del q, v, qv
-    delta = _rows_linear(o, lo)
+    if fp is not None:
+        delta = ops.linear_rows_x3(o, fp["wo"], None if lo.bias is None else lo.bias.detach())
+    else:
+        delta = _rows_linear(o, lo)
     x_sel = xs + delta
     ops.layernorm_rows(x_sel, None, None, n1.eps, out=xhat, out_row_idx=sel)        # re-normalise the K rows in place
     # W1 + bias + activation in the GEMM epilogue: [N, F] bf16.  GELU is the reference's erf form (nn.GELU(), snuffy.py:218) --

@@ -91,8 +91,8 @@ def critic_ln(x, w, b, eps):
 
 # ----------------------------------------------------------------------------------------------------------------------
 # fused selector (snf_critic_select_f32 + snf_topk_select_f32): the critic pass counts the first radix digit of its scores
-# into a small device-resident state; the selection that follows starts from it.  One state per device (selections are
-# issued on torch's current stream, one after the other); `pending` remembers which score tensor the state describes.
+# into a small device-resident state; the selection that follows starts from it.  One state per (device, stream) -- a selection is
+# issued on the stream of its critic pass, right behind it; `pending` remembers which score tensor the state describes.
 # ----------------------------------------------------------------------------------------------------------------------
 SELECT_FUSED_MIN_N = 16385       # up to 16 k scores the one-workgroup selection (keys in registers, 9-12 us) is as fast or faster
 _SELECTORS = {}
@@ -106,11 +106,28 @@ class _Selector:
         self.pending = None
 
 
+def _selector_key(device):
+    """One selector state per (device, stream): the critic pass and the selection that consumes its histogram run back to back on ONE
+    stream, and two streams (threads) of a device must not count into the same histogram (re-entrant)."""
+    raw = _raw_stream(device.index) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream
+    return (device.index, int(raw))
+
+
 def selector(device, create=True):
-    """The device's selector state; None while a HIP graph is being captured and none exists yet (allocate it outside)."""
-    sel = _SELECTORS.get(device.index)
+    """The selector state of the current stream of `device`; None while a HIP graph is being captured and none exists yet for the
+    capturing stream (the graph warm-up forwards, which run on that stream, allocate it outside the capture)."""
+    key = _selector_key(device)
+    sel = _SELECTORS.get(key)
     if sel is None and create and not torch.cuda.is_current_stream_capturing():
-        sel = _SELECTORS[device.index] = _Selector(device)
+        sel = _SELECTORS[key] = _Selector(device)
+    return sel
+
+
+def fresh_selector(device):
+    """A NEW selector state for the current stream of `device` (replacing the one registered for it): what a HIP-graph capture calls
+    on its capture stream before the warm-up forwards -- the graph bakes the state's address in, so every graph gets a state of its
+    own (two graphs replayed on different streams never share a histogram) and keeps the returned object alive."""
+    sel = _SELECTORS[_selector_key(device)] = _Selector(device)
     return sel
 
 
@@ -190,7 +207,7 @@ def topk(scores, k, x=None):
         raise ValueError("topk: need 1 <= k <= n (k=%d, n=%d)" % (k, n))
     lib = _ffi.load()
     idx = torch.empty(k, dtype=torch.int64, device=scores.device)
-    sel = _SELECTORS.get(scores.device.index)
+    sel = _SELECTORS.get(_selector_key(scores.device))
     if sel is not None and sel.pending is not None:
         if x is None and stride == 1 and k <= TOPK_MAX_K and sel.pending == (scores.data_ptr(), n, scores._version):
             # these scores came out of critic_select: their first-digit histogram is waiting in the selector state
@@ -222,6 +239,35 @@ def topk_hist_select(scores, k):
     st = _ws(lib.snf_selector_state_bytes(), scores.device)
     check(lib.snf_topk_hist_select_f32(_p(scores), n, stride, int(k), _p(idx), _p(st), _stream()), "snf_topk_hist_select_f32")
     return idx
+
+
+class DeviceSampler:
+    """State of the device-side random patch share (csrc/sampler.hip): a 16-byte device record {seed, offset}.  The seed is torch's
+    CPU seed at construction and the first offset is drawn from torch's CPU generator (reproducible under torch.manual_seed, no
+    device sync); every forward advances the offset ON THE DEVICE, inside a captured graph as well."""
+
+    def __init__(self, device, seed=None, offset=None):
+        seed = int(torch.initial_seed()) if seed is None else int(seed)
+        offset = int(torch.randint(0, 2 ** 40, (1,), dtype=torch.int64).item()) if offset is None else int(offset)
+        self.seed, self.offset0 = seed & (2 ** 63 - 1), offset & (2 ** 47 - 1)
+        self.state = torch.tensor([self.seed, self.offset0], dtype=torch.int64, device=device)
+
+    def advance(self):
+        check(_ffi.load().snf_sampler_advance(_p(self.state), _stream()), "snf_sampler_advance")
+
+    def draw(self, n, k2, exclude, layer=0):
+        """k2 rows of 0 .. n - 1 outside `exclude` [k1] int64: uniform without replacement, random order -> [k2] int64."""
+        keys = torch.empty(n, dtype=torch.float32, device=self.state.device)
+        ne = 0 if exclude is None else int(exclude.shape[0])
+        if ne:
+            exclude = _req(exclude, torch.int64, "exclude", 1)
+        if not (0 <= k2 <= n - ne):
+            raise ValueError("DeviceSampler.draw: %d rows wanted, %d available" % (k2, n - ne))
+        check(_ffi.load().snf_random_share_keys_f32(_p(self.state), int(layer), n, _p(exclude) if ne else None, ne, _p(keys), _stream()),
+              "snf_random_share_keys_f32")
+        if k2 == 0:
+            return torch.empty(0, dtype=torch.int64, device=keys.device)
+        return topk(keys, k2)
 
 
 def gather_rows(x, idx):

@@ -163,16 +163,20 @@ def forward_bags_graph(net, rows, sizes, ragged=False):
         static_x = torch.cat(rows)
         try:
             cur = torch.cuda.current_stream()
-            side = torch.cuda.Stream()
+            side = getattr(net, "_capture_stream", None)
+            if side is None or side.device != dev:
+                side = net._capture_stream = torch.cuda.Stream(dev)      # warm-up AND capture run on this stream
             side.wait_stream(cur)
             with torch.cuda.stream(side):
+                sel_state = SF.ops.fresh_selector(dev)                   # this graph's own selector state
                 for _ in range(2):
                     forward_packed_raw(net, static_x, packed, ragged)
             cur.wait_stream(side)
             if net._graph_pool is None:
                 net._graph_pool = torch.cuda.graph_pool_handle()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, pool=net._graph_pool, capture_error_mode="thread_local"):
+            graph._snf_selector = sel_state
+            with torch.cuda.graph(graph, pool=net._graph_pool, stream=side, capture_error_mode="thread_local"):
                 out = forward_packed_raw(net, static_x, packed, ragged)
         except Exception as exc:
             import warnings

@@ -32,7 +32,23 @@ class RuntimeConfig:
 
     def __init__(self, precision="fp32", return_attention=True):
         self.stack = None
+        self.sampler = "reference"
+        self._device_sampler = None
+        self._draws = 0
         self.set(precision, return_attention)
+
+    def set_sampler(self, sampler):
+        """Who draws the random patch share (snuffy.py:136-147): "reference" (default) = np.random.choice on the host, the
+        reference's own MT19937 stream, bit-exact parity (a device -> host copy per layer, no graph capture); "device" = Philox keys
+        + top-k on the GPU (csrc/sampler.hip): the same distribution from another stream, no host sync, graph-capturable."""
+        if sampler not in ("reference", "device"):
+            raise ValueError("sampler must be 'reference' or 'device', got %r" % (sampler,))
+        self.sampler = sampler
+
+    def device_sampler(self, device):
+        if self._device_sampler is None or self._device_sampler.state.device != device:
+            self._device_sampler = ops.DeviceSampler(device)
+        return self._device_sampler
 
     def bind_stack(self, layers):
         """The encoder stack this configuration drives (its depth decides `compute`)."""
@@ -136,13 +152,15 @@ class Encoder(nn.Module):
         attn = None
         parts = None
         n_layers = len(self.layers)
+        if self.cfg.sampler == "device" and any(l.random_patch_share > 0 for l in self.layers):
+            self.cfg.device_sampler(x2.device).advance()     # a fresh Philox offset per forward (captured: per replay)
         for li, layer in enumerate(self.layers):
             if parts is not None:
                 x2 = SF.materialize(parts)
             if top is None:
                 top = SF.select_top(c1, layer.big_lambda, layer.top_big_lambda_share, x2.shape[0])
             parts, attn = layer.run(x2, c1, top, need_attn=(li == n_layers - 1) and self.cfg.return_attention,
-                                    last=li == n_layers - 1)
+                                    last=li == n_layers - 1, layer_index=li)
         return parts, attn
 
     def forward(self, x, c):
@@ -190,7 +208,7 @@ class EncoderLayer(nn.Module):
         self.cfg = RuntimeConfig()
         _share_config(self, self.cfg)
 
-    def select(self, c1, n, top=None):
+    def select(self, c1, n, top=None, layer_index=0):
         """Selected row indices S = top ++ random (snuffy.py:128-147). The random part follows the reference exactly:
         np.random.choice on the global numpy RNG over the ascending complement of `top`."""
         if top is None:
@@ -199,14 +217,16 @@ class EncoderLayer(nn.Module):
                  max(0, n - math.ceil(self.big_lambda * self.top_big_lambda_share)))
         if k2 == 0:
             return top, None
+        if self.cfg.sampler == "device":                     # opt-in fast mode: no host round trip, graph-capturable
+            return top, self.cfg.device_sampler(top.device).draw(n, k2, top, layer=layer_index)
         mask = np.ones(n, dtype=bool)
         mask[top.cpu().numpy()] = False                      # device->host sync, as .tolist() in snuffy.py:136
         remaining = np.nonzero(mask)[0]
         rnd = np.random.choice(remaining, k2, replace=False)
         return top, torch.from_numpy(rnd.astype(np.int64)).to(top.device)
 
-    def run(self, x2, c1, top=None, need_attn=True, last=False):
-        top, rnd = self.select(c1, x2.shape[0], top)
+    def run(self, x2, c1, top=None, need_attn=True, last=False, layer_index=0):
+        top, rnd = self.select(c1, x2.shape[0], top, layer_index)
         self.last_selection = (top, rnd)                    # inspection hook (tests / heat-maps)
         sel = top if rnd is None else torch.cat((top, rnd))
         return SF.encoder_layer(x2, sel, self, need_attn, self.cfg.compute, last=last)
@@ -270,14 +290,19 @@ class MILNet(nn.Module):
         self.i_classifier = i_classifier
         self.b_classifier = b_classifier
 
-    def configure(self, precision=None, return_attention=None, graph_max_patches=None):
+    def configure(self, precision=None, return_attention=None, graph_max_patches=None, sampler=None):
         """graph_max_patches (opt-in, default off): inference forwards of bags with at most that many patches are captured
         into HIP graphs and replayed -- a bag is ~25 kernel launches, ~0.24 ms of host-side issue, more than the GPU time of
         a bag of <= 8k patches and, on a slow host, of larger ones.  Same kernels, bit-identical results.  Small bags
         (<= 32 MB) are captured once per shape behind a static input buffer; larger ones are bound to their own buffer the
-        second time the same tensor comes in (a dataset resident in HBM), so nothing is copied.  Only for the
-        deterministic selection (random_patch_share == 0: the random share draws from numpy on the host), outside autograd."""
+        second time the same tensor comes in (a dataset resident in HBM), so nothing is copied.  Only for a selection that
+        stays on the device (random_patch_share == 0, or sampler="device"), outside autograd.
+        sampler: "reference" (default: the random patch share is np.random.choice on the host, the reference's MT19937 draws bit
+        for bit) or "device" (opt-in fast mode: Philox keys + top-k on the GPU, same distribution, no host sync; a captured graph
+        draws fresh rows on every replay)."""
         self.b_classifier.configure(precision, return_attention)
+        if sampler is not None:
+            self.b_classifier.cfg.set_sampler(sampler)       # RuntimeConfig.set_sampler: "reference" (parity, default) | "device"
         if graph_max_patches is not None:
             self._graph_max_patches = int(graph_max_patches)
             self._graphs, self._graph_seen, self._graph_pool = {}, set(), None
@@ -308,9 +333,10 @@ class MILNet(nn.Module):
             return False
         if self.b_classifier.cfg.return_attention and x.numel() * 4 > self._GRAPH_COPY_BYTES:
             return False   # the [1, h, N, K] attention tensor would be cloned out of the graph's pool on every forward
-        # only the binary model's deterministic selection can be captured (the multiclass layer and the random share
-        # synchronise with the host)
-        return all(type(l) is EncoderLayer and l.random_patch_share == 0 for l in self.b_classifier.encoder.layers)
+        # only the binary model's selection can be captured, and only when it stays on the device: the deterministic selection, or
+        # the random share drawn by the device sampler (the multiclass layer and the reference's numpy draws synchronise with the host)
+        on_device = self.b_classifier.cfg.sampler == "device"
+        return all(type(l) is EncoderLayer and (l.random_patch_share == 0 or on_device) for l in self.b_classifier.encoder.layers)
 
     def _weights_signature(self):
         """Changes whenever a parameter is written in place (optimizer step -- fused ones included, SF.param_key --, load_state_dict), replaced (.to(), .half(),
@@ -320,7 +346,7 @@ class MILNet(nn.Module):
         knobs = tuple((l.big_lambda, l.random_patch_share) for l in self.b_classifier.encoder.layers)
         # module-level arithmetic switches are baked into a capture as well
         knobs += (SF.FP32_GEMM, SF.FP32_ATTENTION, SF.X3_HL_ATTENTION, SF.X3_HL_KPFRAG, SF.FP32_SHARED_NORM, ops.GEMM_HL_SPLITK,
-                  SF.BF16_DEEP_STACKS)
+                  SF.BF16_DEEP_STACKS, self.b_classifier.cfg.sampler)
         return tuple(SF.param_key(p) for p in plist), knobs
 
     def invalidate(self):
@@ -334,7 +360,7 @@ class MILNet(nn.Module):
         SF.drop_param_caches(self)        # split images cached on the parameters themselves (fp32-class training / key projections)
         return self
 
-    _GRAPH_STATE = ("_graphs", "_graph_seen", "_graph_pool", "_graph_sig", "_packed_bags")
+    _GRAPH_STATE = ("_graphs", "_graph_seen", "_graph_pool", "_graph_sig", "_packed_bags", "_capture_stream")
 
     def __deepcopy__(self, memo):
         """Captured HIP graphs belong to this instance's buffers: a copy starts without them."""
@@ -367,17 +393,21 @@ class MILNet(nn.Module):
             try:
                 static_x = torch.empty_like(x).copy_(x) if small else x
                 cur = torch.cuda.current_stream()
-                side = torch.cuda.Stream()
+                side = getattr(self, "_capture_stream", None)
+                if side is None or side.device != x.device:
+                    side = self._capture_stream = torch.cuda.Stream(x.device)   # warm-up AND capture run on this stream
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):   # warm-up off the capture: kernel attributes, library handles, weight folds
+                    sel_state = ops.fresh_selector(x.device)   # this graph's own selector state (its address is baked in)
                     for _ in range(2):
                         self._forward_eager(static_x)
                 cur.wait_stream(side)
                 if self._graph_pool is None:
                     self._graph_pool = torch.cuda.graph_pool_handle()
                 graph = torch.cuda.CUDAGraph()
+                graph._snf_selector = sel_state
                 # thread_local: a helper thread of the process (e.g. the RCCL watchdog) may touch the runtime meanwhile
-                with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
+                with torch.cuda.graph(graph, pool=self._graph_pool, stream=side, capture_error_mode="thread_local"):
                     out = self._forward_eager(static_x)
             except Exception as exc:   # capture not possible here: stay on the eager path for good, and say so once
                 import warnings

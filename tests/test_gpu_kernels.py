@@ -135,6 +135,34 @@ def test_fused_selector_critic_plus_select(n, d, k):
     assert int(sel.state.view(torch.int32)[4 * 2048 + 3]) == before + 1
 
 
+def test_fused_selector_state_is_per_stream():
+    """SURVEY 8b (re-entrant): two streams of one device run critic + select pipelines at the same time, each on a selector state of
+    its own -- both get the single-stream answer, every time (one shared histogram would mix their counts)."""
+    o = ops()
+    n, d, k = 40000, 384, 300
+    g = torch.Generator().manual_seed(4)
+    xs = [torch.randn(n, d, generator=g).to(DEV) for _ in range(2)]
+    w = (torch.randn(1, d, generator=g) / math.sqrt(d)).to(DEV)
+    b = torch.zeros(1, device=DEV)
+    want = [orc.topk_desc_stable(o.critic(x, w, b).view(-1).cpu(), k).numpy() for x in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    states = []
+    for rep in range(6):
+        got = [None, None]
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                for _ in range(3):                                   # several bags in flight per stream
+                    s, _ = o.critic_select(xs[i], w, b)
+                    got[i] = o.topk(s.view(-1), k)
+                if rep == 0:
+                    states.append(o.selector(xs[i].device))
+        torch.cuda.synchronize()
+        for i in (0, 1):
+            assert np.array_equal(got[i].cpu().numpy(), want[i]), (rep, i)
+    assert states[0] is not states[1] and states[0].state.data_ptr() != states[1].state.data_ptr()
+
+
 # ---------------------------------------------------------------- K1 critic
 @pytest.mark.parametrize("n,d,c", [(1, 64, 1), (1000, 166, 1), (4099, 384, 2), (513, 768, 1), (100, 2048, 3)])
 def test_critic(n, d, c):

@@ -139,6 +139,124 @@ def test_benchmark_sizes_vs_oracle(N, D, lam, precision):
     assert A3 is None and torch.equal(logits2, logits)
 
 
+README_RECIPES = [   # reference README.md:609-669 ("Example Run for CAMELYON16"): h = 4 in all three
+    (8192, 384, 4, 900, 0.7777777777777778),    # DINO from scratch: K = 200 top + 700 random, dk = 96 (rides padded to 128)
+    (30000, 384, 4, 500, 0.5),                  # DINO with adapter: K = 250 + 250, dk = 96
+    (8192, 768, 4, 500, 0.5),                   # MAE with adapter: dk = 192 (no MFMA form: exact fp32 attention kernel)
+    (5000, 96, 2, 200, 0.25),                   # dk = 48 rides padded to 64
+]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("N,D,h,lam,r", README_RECIPES)
+def test_readme_recipes_vs_oracle(N, D, h, lam, r, precision, monkeypatch):
+    """The reference's own published training recipes (h = 4: head widths 96 / 192, a random patch share): selection bit-exact
+    (top AND the numpy draws), logits and attention inside the class against the oracle; the fp32-class path with padded heads equals
+    the same forward on the exact fp32 attention kernel to rounding."""
+    from snuffy_amd import functional as SF
+    net = synth_state(D, h, 1)
+    layer = net.b_classifier.encoder.layers[0]
+    layer.big_lambda, layer.random_patch_share, layer.top_big_lambda_share = lam, r, 1.0 - r
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    x = torch.randn(N, D, generator=torch.Generator().manual_seed(77))
+    x = x / x.norm(dim=1, keepdim=True)                                     # --l2normed_embeddings=1 (train.py:254-256)
+    _, logits_ref, p_ref, sels = orc.milnet_forward(x, sd, h, "relu", lam, r, 1, ReplayRNG(9))
+    net = net.to(DEV).eval().configure(precision=precision, return_attention=True)
+    np.random.seed(9)
+    with torch.no_grad():
+        _, logits, A = net(x.to(DEV).unsqueeze(0))
+    top, rnd = layer.last_selection
+    k1 = math.ceil(lam * (1.0 - r))
+    assert np.array_equal(torch.cat((top, rnd)).cpu().numpy(), sels[0].numpy()) and top.numel() == k1 and rnd.numel() == int(lam * r)
+    tol = TOL[precision]
+    assert (logits.cpu()[0] - logits_ref).abs().max() < tol
+    rows = torch.arange(0, N, 53)
+    assert (A[0][:, rows.to(DEV), :].cpu() - p_ref[:, rows, :]).abs().max() < tol
+    assert (A.sum(-1) - 1).abs().max() < 1e-4
+    if precision == "fp32":
+        assert (logits.cpu()[0] - logits_ref).abs().max() < 3e-5            # fp32-class, as on the kernels' own head widths
+        monkeypatch.setattr(SF, "FP32_ATTENTION", "exact")
+        np.random.seed(9)
+        with torch.no_grad():
+            _, logits_e, A_e = net(x.to(DEV).unsqueeze(0))
+        assert (logits_e - logits).abs().max() < 2e-5 and (A_e - A).abs().max() < 2e-5
+
+
+def test_device_sampler_matches_host_twin_and_samples_uniformly():
+    """csrc/sampler.hip against oracle/philox_ref.py: the keys bit for bit, the drawn rows exactly (descending key, ties by row);
+    the draw avoids the excluded rows, has no duplicates, changes with the offset and the layer, and is uniform over the rest."""
+    from oracle import philox_ref
+    from snuffy_amd import ops
+    n, k1, k2 = 5003, 200, 700
+    top = torch.randperm(n, generator=torch.Generator().manual_seed(1))[:k1].to(DEV)
+    smp = ops.DeviceSampler(torch.device(DEV), seed=1234567, offset=99)
+    got = smp.draw(n, k2, top, layer=0).cpu().numpy()
+    want = philox_ref.random_share_draw(n, k2, 1234567, 99, 0, top.cpu().numpy())
+    assert np.array_equal(got, want)
+    assert len(set(got.tolist())) == k2 and not (set(got.tolist()) & set(top.cpu().tolist()))
+    assert not np.array_equal(got, smp.draw(n, k2, top, layer=1).cpu().numpy())          # another layer: another stream
+    smp.advance()
+    torch.cuda.synchronize()
+    assert int(smp.state.cpu()[1]) == 100
+    got2 = smp.draw(n, k2, top, layer=0).cpu().numpy()
+    assert np.array_equal(got2, philox_ref.random_share_draw(n, k2, 1234567, 100, 0, top.cpu().numpy()))
+    assert not np.array_equal(got, got2)
+    # uniformity: 400 draws of 50 of 1000 rows -> every row's count ~ Binomial(400, 0.05); chi-square over the rows
+    n, k2 = 1000, 50
+    counts = np.zeros(n)
+    smp = ops.DeviceSampler(torch.device(DEV), seed=7, offset=0)
+    for _ in range(400):
+        smp.advance()
+        counts[smp.draw(n, k2, None).cpu().numpy()] += 1
+    exp = 400 * k2 / n
+    chi2 = ((counts - exp) ** 2 / (exp * (1 - k2 / n))).sum()
+    assert 800 < chi2 < 1200, chi2                                     # ~ chi-square with 999 degrees of freedom (sd 45)
+    with pytest.raises(ValueError):
+        smp.draw(10, 11, None)
+
+
+def test_device_sampler_model_fast_mode_and_graph_replay():
+    """configure(sampler="device"): the random share comes from the device sampler (no host sync: numpy's stream is untouched), the
+    model's outputs are those of the oracle given THAT selection, and a captured graph draws fresh rows on every replay."""
+    N, D, h, lam, r = 6000, 384, 4, 500, 0.5
+    net = synth_state(D, h, 1)
+    layer = net.b_classifier.encoder.layers[0]
+    layer.big_lambda, layer.random_patch_share, layer.top_big_lambda_share = lam, r, 1.0 - r
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    x = torch.randn(N, D, generator=torch.Generator().manual_seed(3))
+    torch.manual_seed(11)
+    net = net.to(DEV).eval().configure(precision="fp32", return_attention=True, sampler="device")
+    np.random.seed(5)
+    before = np.random.get_state()[1].copy()
+    with torch.no_grad():
+        _, logits, A = net(x.to(DEV).unsqueeze(0))
+    assert np.array_equal(np.random.get_state()[1], before)             # the global numpy stream was not consumed
+    top, rnd = layer.last_selection
+    assert top.numel() == 250 and rnd.numel() == 250 and not (set(top.cpu().tolist()) & set(rnd.cpu().tolist()))
+
+    # the oracle with the device's draw in place of numpy's (its top rows must be the oracle's own)
+    _, logits_ref, p_ref, sels = orc.milnet_forward(x, sd, h, "relu", lam, r, 1, forced_sel=[torch.cat((top, rnd)).cpu()])
+    assert np.array_equal(torch.cat((top, rnd)).cpu().numpy(), sels[0].numpy())
+    assert (logits.cpu()[0] - logits_ref).abs().max() < 3e-5 and (A.cpu()[0] - p_ref).abs().max() < 1e-4
+    # graph replay: captured once, fresh draws per replay (the offset advances on the device)
+    net.configure(return_attention=False, graph_max_patches=1 << 20)
+    xg = x.to(DEV).unsqueeze(0)
+    outs, sels_seen = [], []
+    with torch.no_grad():
+        for _ in range(5):
+            outs.append(net(xg)[1].clone())
+    assert getattr(net, "_graphs", None), "the forward was not captured"
+    assert len({float(o) for o in outs[2:]}) == 3                        # three replays, three different selections
+    net.configure(sampler="reference")
+    with pytest.raises(ValueError):
+        net.configure(sampler="numpy")
+
+
+def test_head_pad_table():
+    from snuffy_amd import functional as SF
+    assert [SF.head_pad(dk) for dk in (16, 32, 48, 64, 80, 96, 112, 128, 83, 192, 256)] == [64, 64, 64, 64, 128, 128, 128, 128, None, None, None]
+
+
 def test_ragged_and_edge_bags():
     """N < Lambda (K = N), N == 1, depth 5, every activation -- through both precisions, vs the oracle."""
     for N, D, h, lam, r, depth, act in [(1, 64, 2, 10, 0.0, 1, "relu"), (7, 128, 2, 200, 0.0, 2, "gelu"),
