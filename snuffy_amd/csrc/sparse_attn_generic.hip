@@ -150,6 +150,235 @@ __global__ __launch_bounds__(256) void pt_v_kernel(const float* __restrict__ p /
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same two kernels on the matrix cores in EXACT fp32 (round 5): v_mfma_f32_32x32x2_f32 takes f32 operands and is bit for bit
+// a k-ordered fmaf chain (MI355X_MICROARCH.md), at the f32 vector peak -- but as one instruction per 4096 flops instead of 64 FMAs,
+// fed by one 16-byte load per operand and four MFMAs.  Any head width that is a multiple of 8 (96, 192, ... -- the README recipes'
+// h = 4 at D = 768, reference README.md:661-669, which no bf16 / split-bf16 kernel form fits), up to 1024 keys.
+//   scores_softmax_mfma: a workgroup owns 32 query rows of one head (Q tile in LDS), wave w the key blocks w, w + 4, ..;
+//     S^T[32 keys, 32 rows] per block (A = Kp rows straight from L2, B = Q from LDS; the contraction index is walked as
+//     (8 T + 4 half + j) so that a lane's four k-steps are ONE float4), softmax in registers (lane = row), (max, sum) of the four
+//     waves through LDS in wave order, P written once.
+//   pt_v_mfma: a WAVE owns a [64 keys, 32 CT columns] tile of O over a slice of the rows; A = P^T and B = V are single coalesced
+//     dword loads (the lane layouts of the instruction ARE the memory layouts), 2 CT MFMAs per row pair.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float mf32x16 __attribute__((ext_vector_type(16)));
+typedef float mf32x4 __attribute__((ext_vector_type(4)));
+
+template <int KBW>   // key blocks per wave: k <= 128 * KBW
+__global__ __launch_bounds__(256, KBW <= 4 ? 3 : 2) void scores_softmax_mfma_kernel(const float* __restrict__ q, const float* __restrict__ kp, int64_t n,
+                                                                  int k, int h, int dk, float scale, float* __restrict__ p_out,
+                                                                  float* __restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int pitch = dk + 4;                  // floats: 16-byte aligned rows, 4 banks apart (conflict-free float4 reads down a column)
+    float* lq = lds;                           // [32][pitch]
+    float* lst = lds + 32 * pitch;             // [2][4][32]: per-wave row max, then row sum
+    const int a = blockIdx.y;
+    const int d_model = h * dk;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 31, hf = lane >> 5;
+    const int dk4 = dk >> 2;
+    for (int e = threadIdx.x; e < 32 * dk4; e += 256) {
+        const int r = e / dk4, c4 = e - r * dk4;
+        const int64_t row = row0 + r;
+        mf32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (row < n) val = *reinterpret_cast<const mf32x4*>(q + row * d_model + a * dk + 4 * c4);
+        *reinterpret_cast<mf32x4*>(lq + r * pitch + 4 * c4) = val;
+    }
+    __syncthreads();
+    const int nkb = (k + 31) >> 5;
+    const int nt = dk >> 3;
+    mf32x16 S[KBW];
+    const float* qr = lq + j * pitch + 4 * hf;
+#pragma unroll
+    for (int c = 0; c < KBW; ++c) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[c][i] = 0.f;
+        const int kb = w + 4 * c;              // wave-uniform
+        if (kb < nkb) {
+            int key = 32 * kb + j;
+            if (key > k - 1) key = k - 1;      // padded keys read the last row; their scores are masked below
+            const float* kr = kp + (int64_t)key * d_model + a * dk + 4 * hf;
+            int t = 0;
+            for (; t + 4 <= nt; t += 4) {      // four steps' operands requested together (Kp comes from L2)
+                mf32x4 a4[4], b4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a4[u] = *reinterpret_cast<const mf32x4*>(kr + 8 * (t + u));
+                    b4[u] = *reinterpret_cast<const mf32x4*>(qr + 8 * (t + u));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) S[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u][e], b4[u][e], S[c], 0, 0, 0);
+            }
+            for (; t < nt; ++t) {
+                const mf32x4 a4 = *reinterpret_cast<const mf32x4*>(kr + 8 * t);
+                const mf32x4 b4 = *reinterpret_cast<const mf32x4*>(qr + 8 * t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], S[c], 0, 0, 0);
+            }
+        }
+    }
+    // lane (row j, half hf) holds keys 32 kb + (i & 3) + 8 (i >> 2) + 4 hf of ITS row
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < KBW; ++c) {
+        const int kb = w + 4 * c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hf;
+            S[c][i] = (kb < nkb && key < k) ? S[c][i] * scale : -INFINITY;
+            m = fmaxf(m, S[c][i]);
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    if (hf == 0) lst[w * 32 + j] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(lst[j], lst[32 + j]), fmaxf(lst[64 + j], lst[96 + j]));
+    float l = 0.f;
+#pragma unroll
+    for (int c = 0; c < KBW; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float e = __builtin_amdgcn_exp2f((S[c][i] - m) * 1.44269504088896340736f);   // exp2(-inf) = 0 for padded keys
+            S[c][i] = e;
+            l += e;
+        }
+    l += __shfl_xor(l, 32, 64);
+    if (hf == 0) lst[128 + w * 32 + j] = l;
+    __syncthreads();
+    l = ((lst[128 + j] + lst[160 + j]) + lst[192 + j]) + lst[224 + j];
+    const float inv = 1.0f / l;
+    const int64_t row = row0 + j;
+    if (row < n) {
+        float* prow = p_out + ((int64_t)a * n + row) * k;
+        const bool vec = (k & 3) == 0 && (reinterpret_cast<uintptr_t>(p_out) & 15) == 0;
+#pragma unroll
+        for (int c = 0; c < KBW; ++c) {
+            const int kb = w + 4 * c;
+            if (kb < nkb) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int key0 = 32 * kb + 8 * q4 + 4 * hf;
+                    const mf32x4 pv = {S[c][4 * q4] * inv, S[c][4 * q4 + 1] * inv, S[c][4 * q4 + 2] * inv, S[c][4 * q4 + 3] * inv};
+                    if (vec && key0 + 4 <= k) {
+                        *reinterpret_cast<mf32x4*>(prow + key0) = pv;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (key0 + e < k) prow[key0 + e] = pv[e];
+                    }
+                }
+            }
+        }
+        if (lse && w == 0 && hf == 0) lse[(int64_t)a * n + row] = m + logf(l);
+    }
+}
+
+template <int CT>    // 32-column blocks per wave tile
+__global__ __launch_bounds__(256, 2) void pt_v_mfma_kernel(const float* __restrict__ p /*[h,n,k]*/, const float* __restrict__ v, int64_t n,
+                                                           int k, int h, int dk, int64_t rows_per_slice, int slices,
+                                                           float* __restrict__ partial /*[slices,h,k,dk]*/) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, hf = lane >> 5;
+    const int a = blockIdx.z % h;
+    const int slice = 4 * (blockIdx.z / h) + w;          // one wave = one slice of the rows
+    if (slice >= slices) return;
+    const int d_model = h * dk;
+    const int64_t r_begin = (int64_t)slice * rows_per_slice;
+    int64_t r_end = r_begin + rows_per_slice;
+    if (r_end > n) r_end = n;
+    const int kb0 = 2 * blockIdx.x, cb0 = CT * blockIdx.y;
+    // per-lane element offsets inside a row pair (32-bit), on top of a wave-uniform row pointer: lane (j, hf) reads row r + hf
+    int offa[2], offb[CT];
+    bool kok[2], cok[CT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int key = 32 * (kb0 + t) + j;
+        kok[t] = key < k;
+        if (!kok[t]) key = k - 1;
+        offa[t] = hf * k + key;
+    }
+    int col[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        col[c] = 32 * (cb0 + c) + j;
+        cok[c] = col[c] < dk;
+        if (!cok[c]) col[c] = dk - 1;
+        offb[c] = hf * d_model + col[c];
+    }
+    mf32x16 acc[2][CT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][c][i] = 0.f;
+    const float* pa = p + (int64_t)a * n * k;
+    const float* va = v + a * dk;
+    constexpr int U = CT == 4 ? 4 : 8;                   // row pairs per batch: all their loads in flight before the first MFMA
+    int64_t r = r_begin;
+    for (; r + 2 * U <= r_end; r += 2 * U) {             // full batches: wave-uniform row pointers, no row predicate
+        const float* pr = pa + r * k;
+        const float* vr = va + r * d_model;
+        float av[U][2], bv[U][CT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) av[u][t] = pr[(int64_t)(2 * u) * k + offa[t]];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) bv[u][c] = vr[(int64_t)(2 * u) * d_model + offb[c]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) av[u][t] = kok[t] ? av[u][t] : 0.f;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) bv[u][c] = cok[c] ? bv[u][c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][t], bv[u][c], acc[t][c], 0, 0, 0);
+    }
+    for (; r < r_end; r += 2) {                          // the slice's last rows: per-lane row predicate
+        int64_t row = r + hf;
+        const bool rv = row < r_end;
+        if (!rv) row = r_end - 1;
+        float av[2], bv[CT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float x = pa[row * k + (offa[t] - hf * k)];
+            av[t] = (rv && kok[t]) ? x : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float x = va[row * d_model + col[c]];
+            bv[c] = (rv && cok[c]) ? x : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[c], acc[t][c], 0, 0, 0);
+    }
+    float* dst = partial + ((int64_t)slice * h + a) * (int64_t)k * dk;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            if (!cok[c]) continue;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ky = 32 * (kb0 + t) + (i & 3) + 8 * (i >> 2) + 4 * hf;
+                if (ky < k) dst[(int64_t)ky * dk + col[c]] = acc[t][c][i];
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ partial, int slices, int k, int h,
                                                             int dk, float* __restrict__ out /*[k, h*dk]*/) {
     const int64_t total = (int64_t)h * k * dk;
@@ -406,6 +635,24 @@ __global__ __launch_bounds__(256) void ragged_attn_kernel(const float* __restric
     }
 }
 
+// P^T V on the f32 MFMA: one wave per (64 keys, 32 CT columns, row slice)
+int launch_pt_v_mfma(const float* p, const float* v, int64_t n, int k, int h, int dk, int64_t rows_per_slice, int slices, float* partial,
+                     hipStream_t s) {
+    const int ncb = (dk + 31) / 32;
+    const int ct = ncb % 3 == 0 ? 3 : (ncb % 4 == 0 || ncb > 4) ? 4 : ncb;          // 96 / 192 -> 3, 128 / 256 -> 4, 64 -> 2, 32 -> 1
+    dim3 grid((unsigned)(((k + 31) / 32 + 1) / 2), (unsigned)((ncb + ct - 1) / ct), (unsigned)(((slices + 3) / 4) * h));
+    switch (ct) {
+        case 1: hipLaunchKernelGGL((pt_v_mfma_kernel<1>), grid, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, slices, partial); break;
+        case 2: hipLaunchKernelGGL((pt_v_mfma_kernel<2>), grid, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, slices, partial); break;
+        case 3: hipLaunchKernelGGL((pt_v_mfma_kernel<3>), grid, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, slices, partial); break;
+        default: hipLaunchKernelGGL((pt_v_mfma_kernel<4>), grid, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, slices, partial); break;
+    }
+    return snf::check_launch("pt_v_mfma_kernel");
+}
+
+// development / test switch (snf_debug_exact_attn_mfma): false = the round-1 vector-ALU kernels for every shape
+bool g_exact_mfma = true;
+
 }  // namespace
 
 namespace snf {
@@ -461,9 +708,13 @@ int snf_sparse_attn_bwd_f32(const float* q, const float* kp, const float* v, con
     // dKp = dS^T Q: the forward's P^T V machinery on (dS, Q)
     const int slices = generic_slices(n);
     const int64_t rows_per_slice = (((n + slices - 1) / slices) + 15) & ~(int64_t)15;
-    dim3 grid3((unsigned)((k + 63) / 64), (unsigned)((dk + 63) / 64), (unsigned)(slices * h));
-    hipLaunchKernelGGL(pt_v_kernel, grid3, dim3(256), 0, s, ds, q, n, k, h, dk, rows_per_slice, partial);
-    rc = snf::check_launch("pt_v_kernel(dS, Q)");
+    if (g_exact_mfma)
+        rc = launch_pt_v_mfma(ds, q, n, k, h, dk, rows_per_slice, slices, partial, s);
+    else {
+        dim3 grid3((unsigned)((k + 63) / 64), (unsigned)((dk + 63) / 64), (unsigned)(slices * h));
+        hipLaunchKernelGGL(pt_v_kernel, grid3, dim3(256), 0, s, ds, q, n, k, h, dk, rows_per_slice, partial);
+        rc = snf::check_launch("pt_v_kernel(dS, Q)");
+    }
     if (rc) return rc;
     const int64_t total = (int64_t)h * k * dk;
     int rgrid = (int)((total + 255) / 256);
@@ -485,9 +736,14 @@ int snf_sparse_attn_dkp_f32(const float* ds, const float* q, int64_t n, int k, i
     float* partial = reinterpret_cast<float*>(workspace);
     hipStream_t s = snf::as_stream(stream);
     const int64_t rows_per_slice = (((n + slices - 1) / slices) + 15) & ~(int64_t)15;
-    dim3 grid((unsigned)((k + 63) / 64), (unsigned)((dk + 63) / 64), (unsigned)(slices * h));
-    hipLaunchKernelGGL(pt_v_kernel, grid, dim3(256), 0, s, ds, q, n, k, h, dk, rows_per_slice, partial);
-    int rc = snf::check_launch("pt_v_kernel(dS, Q)");
+    int rc;
+    if (g_exact_mfma)
+        rc = launch_pt_v_mfma(ds, q, n, k, h, dk, rows_per_slice, slices, partial, s);
+    else {
+        dim3 grid((unsigned)((k + 63) / 64), (unsigned)((dk + 63) / 64), (unsigned)(slices * h));
+        hipLaunchKernelGGL(pt_v_kernel, grid, dim3(256), 0, s, ds, q, n, k, h, dk, rows_per_slice, partial);
+        rc = snf::check_launch("pt_v_kernel(dS, Q)");
+    }
     if (rc) return rc;
     const int64_t total = (int64_t)h * k * dk;
     int rgrid = (int)((total + 255) / 256);
@@ -517,26 +773,47 @@ int snf_sparse_attn_fwd_f32(const float* q, const float* kp, const float* v, int
     float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (attn ? 0 : pbytes));
     hipStream_t s = snf::as_stream(stream);
 
-    const int dkp = (dk + 3) & ~3;
-    const size_t lds = (size_t)(ROWS_PER_WG * dkp + KCHUNK * (dkp + 4)) * sizeof(float);
-    dim3 grid1((unsigned)((n + ROWS_PER_WG - 1) / ROWS_PER_WG), (unsigned)h);
-    const int kpl = (k + 63) / 64;
+    int rc;
+    const bool mfma_scores = g_exact_mfma && dk % 8 == 0 && k <= 1024 &&
+                             ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(kp)) & 15) == 0;
+    if (mfma_scores) {   // exact fp32 on the matrix cores
+        const size_t lds = (size_t)(32 * (dk + 4) + 256) * sizeof(float);
+        dim3 grid1((unsigned)((n + 31) / 32), (unsigned)h);
+        const int kbw = ((k + 31) / 32 + 3) / 4;
+#define LAUNCH_SM(KBW)                                                                                                                 \
+    hipLaunchKernelGGL((scores_softmax_mfma_kernel<KBW>), grid1, dim3(256), lds, s, q, kp, n, k, h, dk, scale, p, lse)
+        if (kbw <= 1) LAUNCH_SM(1);
+        else if (kbw <= 2) LAUNCH_SM(2);
+        else if (kbw <= 4) LAUNCH_SM(4);
+        else LAUNCH_SM(8);
+#undef LAUNCH_SM
+        rc = snf::check_launch("scores_softmax_mfma_kernel");
+    } else {
+        const int dkp = (dk + 3) & ~3;
+        const size_t lds = (size_t)(ROWS_PER_WG * dkp + KCHUNK * (dkp + 4)) * sizeof(float);
+        dim3 grid1((unsigned)((n + ROWS_PER_WG - 1) / ROWS_PER_WG), (unsigned)h);
+        const int kpl = (k + 63) / 64;
 #define LAUNCH_SS(KPL)                                                                                              \
     hipLaunchKernelGGL((scores_softmax_kernel<KPL>), grid1, dim3(256), lds, s, q, kp, n, k, h, dk, scale, p, lse)
-    if (kpl <= 1) LAUNCH_SS(1);
-    else if (kpl <= 2) LAUNCH_SS(2);
-    else if (kpl <= 4) LAUNCH_SS(4);
-    else if (kpl <= 8) LAUNCH_SS(8);
-    else if (kpl <= 16) LAUNCH_SS(16);
-    else LAUNCH_SS(32);
+        if (kpl <= 1) LAUNCH_SS(1);
+        else if (kpl <= 2) LAUNCH_SS(2);
+        else if (kpl <= 4) LAUNCH_SS(4);
+        else if (kpl <= 8) LAUNCH_SS(8);
+        else if (kpl <= 16) LAUNCH_SS(16);
+        else LAUNCH_SS(32);
 #undef LAUNCH_SS
-    int rc = snf::check_launch("scores_softmax_kernel");
+        rc = snf::check_launch("scores_softmax_kernel");
+    }
     if (rc) return rc;
 
     const int64_t rows_per_slice = (((n + slices - 1) / slices) + 15) & ~(int64_t)15;
-    dim3 grid2((unsigned)((k + 63) / 64), (unsigned)((dk + 63) / 64), (unsigned)(slices * h));
-    hipLaunchKernelGGL(pt_v_kernel, grid2, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, partial);
-    rc = snf::check_launch("pt_v_kernel");
+    if (g_exact_mfma)
+        rc = launch_pt_v_mfma(p, v, n, k, h, dk, rows_per_slice, slices, partial, s);
+    else {
+        dim3 grid2((unsigned)((k + 63) / 64), (unsigned)((dk + 63) / 64), (unsigned)(slices * h));
+        hipLaunchKernelGGL(pt_v_kernel, grid2, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, partial);
+        rc = snf::check_launch("pt_v_kernel");
+    }
     if (rc) return rc;
     const int64_t total = (int64_t)h * k * dk;
     int rgrid = (int)((total + 255) / 256);
@@ -577,5 +854,9 @@ int snf_sparse_attn_fwd_ragged_f32(const float* q, int64_t ldq, const float* v, 
                        kp, desc_dev, h, dk, kmax, scale, out, attn, n_total, lse);
     return snf::check_launch("ragged_attn_kernel");
 }
+
+// development / test hook: 1 (default) = the exact-fp32 attention runs on the f32 matrix-core forms where the shape allows, 0 = the
+// vector-ALU kernels everywhere (the two agree to fp32 rounding: different summation orders of the same fmaf chains)
+void snf_debug_exact_attn_mfma(int on) { g_exact_mfma = on != 0; }
 
 }  // extern "C"

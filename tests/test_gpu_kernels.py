@@ -283,7 +283,9 @@ def attn_ref(q, kp, v, h):
 
 
 @pytest.mark.parametrize("n,k,h,dk", [(40, 40, 2, 83), (1000, 200, 6, 16), (3000, 900, 4, 24), (777, 64, 1, 128),
-                                      (257, 5, 3, 7), (1, 1, 2, 32), (5000, 512, 6, 128), (17, 17, 2, 256)])
+                                      (257, 5, 3, 7), (1, 1, 2, 32), (5000, 512, 6, 128), (17, 17, 2, 256),
+                                      # the README recipes' head widths (h = 4) and the limits of the matrix-core forms
+                                      (8192, 500, 4, 192), (4001, 900, 4, 96), (333, 1024, 2, 192), (600, 1025, 2, 64), (2000, 130, 3, 8)])
 def test_sparse_attn_exact(n, k, h, dk):
     g = torch.Generator().manual_seed(n + k)
     d = h * dk
@@ -297,6 +299,16 @@ def test_sparse_attn_exact(n, k, h, dk):
     assert (lse.cpu().double() - lse_ref).abs().max() < 1e-4
     o2, _, _ = ops().sparse_attn_fwd(q.to(DEV), kp.to(DEV), v.to(DEV), h)     # P in workspace
     assert torch.equal(o2, o)
+    # round 5: the same products on v_mfma_f32_32x32x2_f32 (head widths % 8 == 0, <= 1024 keys; P^T V for every shape) against the
+    # vector-ALU kernels -- exact fp32 both ways, equal up to the order of the fmaf chains
+    from snuffy_amd import _ffi
+    _ffi.load().snf_debug_exact_attn_mfma(0)
+    try:
+        o3, a3, l3 = ops().sparse_attn_fwd(q.to(DEV), kp.to(DEV), v.to(DEV), h, need_attn=True, need_lse=True)
+    finally:
+        _ffi.load().snf_debug_exact_attn_mfma(1)
+    assert (a3 - attn).abs().max() < 5e-7 and rel_err(o3.cpu(), o.cpu()) < 3e-6 and (l3 - lse).abs().max() < 2e-5
+    assert (attn.sum(-1) - 1).abs().max() < 1e-5
 
 
 def bf16r(t):
