@@ -558,6 +558,228 @@ __global__ __launch_bounds__(256) void bwd_dq_dv_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The backward's two large kernels on the f32 matrix-core form (round 5; exact fp32, head widths % 8 == 0, k <= 1024 for dS).
+//   bwd_ds_mfma: the twin of scores_softmax_mfma -- dP^T[32 keys, 32 rows] = dO V^T per key block (A = dO rows from L2, B = the V
+//     tile in LDS), then per row dsum = sum_keys (dP o M) P over the four waves and dS = P (dP o M - dsum) scale, written once.
+//   bwd_dq_dv_mfma: a wave owns 32 rows x 32 CT columns of dV AND of dQ: dV += (P o M)[rows, keys] dO[keys, cols], dQ += dS Kp; a
+//     lane's four k-steps of P / dS are ONE float4 (the contraction index is walked as 8 T + 4 half + j), dO / Kp are coalesced
+//     dword loads; 8 CT MFMAs per 2 + 8 CT loads.
+// ---------------------------------------------------------------------------------------------------------------
+template <int KBW>
+__global__ __launch_bounds__(256, KBW <= 4 ? 3 : 2) void bwd_ds_mfma_kernel(const float* __restrict__ v, const float* __restrict__ dout,
+                                                                            const float* __restrict__ p, const float* __restrict__ mask,
+                                                                            int64_t n, int k, int h, int dk, float scale,
+                                                                            float* __restrict__ ds) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int pitch = dk + 4;
+    float* lv = lds;                           // [32][pitch]
+    float* lst = lds + 32 * pitch;             // [4][32] per-wave partial dsum
+    const int a = blockIdx.y;
+    const int d_model = h * dk;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 31, hf = lane >> 5;
+    const int dk4 = dk >> 2;
+    for (int e = threadIdx.x; e < 32 * dk4; e += 256) {
+        const int r = e / dk4, c4 = e - r * dk4;
+        const int64_t row = row0 + r;
+        mf32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (row < n) val = *reinterpret_cast<const mf32x4*>(v + row * d_model + a * dk + 4 * c4);
+        *reinterpret_cast<mf32x4*>(lv + r * pitch + 4 * c4) = val;
+    }
+    __syncthreads();
+    const int nkb = (k + 31) >> 5;
+    const int nt = dk >> 3;
+    mf32x16 D[KBW];
+    const float* vr = lv + j * pitch + 4 * hf;
+#pragma unroll
+    for (int c = 0; c < KBW; ++c) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) D[c][i] = 0.f;
+        const int kb = w + 4 * c;
+        if (kb < nkb) {
+            int key = 32 * kb + j;
+            if (key > k - 1) key = k - 1;
+            const float* orow = dout + (int64_t)key * d_model + a * dk + 4 * hf;
+            int t = 0;
+            for (; t + 4 <= nt; t += 4) {
+                mf32x4 a4[4], b4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a4[u] = *reinterpret_cast<const mf32x4*>(orow + 8 * (t + u));
+                    b4[u] = *reinterpret_cast<const mf32x4*>(vr + 8 * (t + u));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) D[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u][e], b4[u][e], D[c], 0, 0, 0);
+            }
+            for (; t < nt; ++t) {
+                const mf32x4 a4 = *reinterpret_cast<const mf32x4*>(orow + 8 * t);
+                const mf32x4 b4 = *reinterpret_cast<const mf32x4*>(vr + 8 * t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) D[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], D[c], 0, 0, 0);
+            }
+        }
+    }
+    // lane (row j, half hf): keys 32 kb + (i & 3) + 8 (i >> 2) + 4 hf of its row -- P (and the mask) in the same layout
+    const int64_t row = row0 + j;
+    const bool rvalid = row < n;
+    const int64_t base = ((int64_t)a * n + (rvalid ? row : n - 1)) * k;
+    const bool vec = (k & 3) == 0 && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(ds) |
+                                       (mask ? reinterpret_cast<uintptr_t>(mask) : 0)) & 15) == 0;
+    mf32x16 Pr[KBW];
+    float dsum = 0.f;
+#pragma unroll
+    for (int c = 0; c < KBW; ++c) {
+        const int kb = w + 4 * c;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int key0 = 32 * kb + 8 * q4 + 4 * hf;
+            mf32x4 pv = {0.f, 0.f, 0.f, 0.f}, mv = {1.f, 1.f, 1.f, 1.f};
+            if (kb < nkb) {
+                if (vec && key0 + 4 <= k) {
+                    pv = *reinterpret_cast<const mf32x4*>(p + base + key0);
+                    if (mask) mv = *reinterpret_cast<const mf32x4*>(mask + base + key0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (key0 + e < k) {
+                            pv[e] = p[base + key0 + e];
+                            if (mask) mv[e] = mask[base + key0 + e];
+                        }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * q4 + e;
+                D[c][i] *= mv[e];
+                Pr[c][i] = pv[e];
+                dsum = fmaf(D[c][i], pv[e], dsum);
+            }
+        }
+    }
+    dsum += __shfl_xor(dsum, 32, 64);
+    if (hf == 0) lst[w * 32 + j] = dsum;
+    __syncthreads();
+    dsum = ((lst[j] + lst[32 + j]) + lst[64 + j]) + lst[96 + j];
+    if (!rvalid) return;
+#pragma unroll
+    for (int c = 0; c < KBW; ++c) {
+        const int kb = w + 4 * c;
+        if (kb >= nkb) continue;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int key0 = 32 * kb + 8 * q4 + 4 * hf;
+            mf32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = Pr[c][4 * q4 + e] * (D[c][4 * q4 + e] - dsum) * scale;
+            if (vec && key0 + 4 <= k) {
+                *reinterpret_cast<mf32x4*>(ds + base + key0) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (key0 + e < k) ds[base + key0 + e] = o[e];
+            }
+        }
+    }
+}
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void bwd_dq_dv_mfma_kernel(const float* __restrict__ p, const float* __restrict__ mask,
+                                                                const float* __restrict__ ds, const float* __restrict__ dout,
+                                                                const float* __restrict__ kp, int64_t n, int k, int h, int dk,
+                                                                float* __restrict__ dq, float* __restrict__ dv) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, hf = lane >> 5;
+    const int a = blockIdx.z;
+    const int d_model = h * dk;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + w) * 32;     // one wave = 32 rows
+    if (row0 >= n) return;
+    const int cb0 = CT * blockIdx.y;
+    int64_t row = row0 + j;
+    if (row > n - 1) row = n - 1;                                  // rows past the end: read the last row, never stored
+    const float* prow = p + ((int64_t)a * n + row) * k + 4 * hf;   // lane's four k-steps of a group: keys 8 T + 4 hf .. + 3
+    const float* srow = ds + ((int64_t)a * n + row) * k + 4 * hf;
+    const float* mrow = mask ? mask + ((int64_t)a * n + row) * k + 4 * hf : nullptr;
+    int col[CT];
+    bool cok[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        col[c] = 32 * (cb0 + c) + j;
+        cok[c] = col[c] < dk;
+        if (!cok[c]) col[c] = dk - 1;
+    }
+    mf32x16 av[CT], aq[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) av[c][i] = 0.f, aq[c][i] = 0.f;
+    const bool vec = (k & 3) == 0 && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(ds) |
+                                       (mask ? reinterpret_cast<uintptr_t>(mask) : 0)) & 15) == 0;
+    const float* ob = dout + a * dk;
+    const float* kb_ = kp + a * dk;
+    // operands of one group of 8 keys (4 MFMAs per accumulator); the NEXT group's are requested before the current group's MFMAs
+    struct Grp {
+        mf32x4 p4, s4;
+        float od[4][CT], kd[4][CT];
+    };
+    auto load_grp = [&](int t8, Grp& g) __attribute__((always_inline)) {
+        const int key0 = t8 + 4 * hf;
+        g.p4 = mf32x4{0.f, 0.f, 0.f, 0.f}, g.s4 = mf32x4{0.f, 0.f, 0.f, 0.f};
+        if (vec && key0 + 4 <= k) {
+            g.p4 = *reinterpret_cast<const mf32x4*>(prow + t8);
+            g.s4 = *reinterpret_cast<const mf32x4*>(srow + t8);
+            if (mrow) g.p4 *= *reinterpret_cast<const mf32x4*>(mrow + t8);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (key0 + e < k) {
+                    g.p4[e] = prow[t8 + e] * (mrow ? mrow[t8 + e] : 1.f);
+                    g.s4[e] = srow[t8 + e];
+                }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int key = key0 + e;
+            const bool kok = key < k;
+            if (!kok) key = k - 1;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float x = ob[(int64_t)key * d_model + col[c]], y = kb_[(int64_t)key * d_model + col[c]];
+                g.od[e][c] = (kok && cok[c]) ? x : 0.f;
+                g.kd[e][c] = (kok && cok[c]) ? y : 0.f;
+            }
+        }
+    };
+    Grp cur, nxt;
+    load_grp(0, cur);
+    for (int t8 = 0; t8 < k; t8 += 8) {
+        if (t8 + 8 < k) load_grp(t8 + 8, nxt);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                av[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.p4[e], cur.od[e][c], av[c], 0, 0, 0);
+                aq[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.s4[e], cur.kd[e][c], aq[c], 0, 0, 0);
+            }
+        cur = nxt;
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        if (!cok[c]) continue;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t r = row0 + (i & 3) + 8 * (i >> 2) + 4 * hf;
+            if (r < n) {
+                dv[r * d_model + a * dk + col[c]] = av[c][i];
+                dq[r * d_model + a * dk + col[c]] = aq[c][i];
+            }
+        }
+    }
+}
+
 inline int generic_slices(int64_t n) {
     int64_t s = (n + 511) / 512;
     if (s > 64) s = 64;
@@ -688,22 +910,52 @@ int snf_sparse_attn_bwd_f32(const float* q, const float* kp, const float* v, con
     hipStream_t s = snf::as_stream(stream);
     const int dk4 = (dk + 3) & ~3;
     const size_t lds = (size_t)(ROWS_PER_WG * dk4 + KCHUNK * (dk4 + 4)) * sizeof(float);
-    dim3 grid1((unsigned)((n + ROWS_PER_WG - 1) / ROWS_PER_WG), (unsigned)h);
-    const int kpl = (k + 63) / 64;
+    int rc;
+    const bool mfma_ok = g_exact_mfma && dk % 8 == 0 &&
+                         ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(dout)) & 15) == 0;
+    if (mfma_ok && k <= 1024) {
+        const size_t lds_m = (size_t)(32 * (dk + 4) + 128) * sizeof(float);
+        dim3 grid1((unsigned)((n + 31) / 32), (unsigned)h);
+        const int kbw = ((k + 31) / 32 + 3) / 4;
+#define LAUNCH_DSM(KBW) \
+    hipLaunchKernelGGL((bwd_ds_mfma_kernel<KBW>), grid1, dim3(256), lds_m, s, v, dout, p, mask, n, k, h, dk, scale, ds)
+        if (kbw <= 1) LAUNCH_DSM(1);
+        else if (kbw <= 2) LAUNCH_DSM(2);
+        else if (kbw <= 4) LAUNCH_DSM(4);
+        else LAUNCH_DSM(8);
+#undef LAUNCH_DSM
+        rc = snf::check_launch("bwd_ds_mfma_kernel");
+    } else {
+        dim3 grid1((unsigned)((n + ROWS_PER_WG - 1) / ROWS_PER_WG), (unsigned)h);
+        const int kpl = (k + 63) / 64;
 #define LAUNCH_DS(KPL) \
     hipLaunchKernelGGL((bwd_ds_kernel<KPL>), grid1, dim3(256), lds, s, v, dout, p, mask, n, k, h, dk, scale, ds)
-    if (kpl <= 1) LAUNCH_DS(1);
-    else if (kpl <= 2) LAUNCH_DS(2);
-    else if (kpl <= 4) LAUNCH_DS(4);
-    else if (kpl <= 8) LAUNCH_DS(8);
-    else if (kpl <= 16) LAUNCH_DS(16);
-    else LAUNCH_DS(32);
+        if (kpl <= 1) LAUNCH_DS(1);
+        else if (kpl <= 2) LAUNCH_DS(2);
+        else if (kpl <= 4) LAUNCH_DS(4);
+        else if (kpl <= 8) LAUNCH_DS(8);
+        else if (kpl <= 16) LAUNCH_DS(16);
+        else LAUNCH_DS(32);
 #undef LAUNCH_DS
-    int rc = snf::check_launch("bwd_ds_kernel");
+        rc = snf::check_launch("bwd_ds_kernel");
+    }
     if (rc) return rc;
-    dim3 grid2((unsigned)((n + 63) / 64), (unsigned)((dk + 63) / 64), (unsigned)h);
-    hipLaunchKernelGGL(bwd_dq_dv_kernel, grid2, dim3(256), 0, s, p, mask, ds, dout, kp, n, k, h, dk, dq, dv);
-    rc = snf::check_launch("bwd_dq_dv_kernel");
+    if (g_exact_mfma) {
+        const int ncb = (dk + 31) / 32;
+        const int ct = ncb % 3 == 0 ? 3 : (ncb >= 4 ? 4 : ncb);
+        dim3 grid2((unsigned)((n + 127) / 128), (unsigned)((ncb + ct - 1) / ct), (unsigned)h);
+        switch (ct) {
+            case 1: hipLaunchKernelGGL((bwd_dq_dv_mfma_kernel<1>), grid2, dim3(256), 0, s, p, mask, ds, dout, kp, n, k, h, dk, dq, dv); break;
+            case 2: hipLaunchKernelGGL((bwd_dq_dv_mfma_kernel<2>), grid2, dim3(256), 0, s, p, mask, ds, dout, kp, n, k, h, dk, dq, dv); break;
+            case 3: hipLaunchKernelGGL((bwd_dq_dv_mfma_kernel<3>), grid2, dim3(256), 0, s, p, mask, ds, dout, kp, n, k, h, dk, dq, dv); break;
+            default: hipLaunchKernelGGL((bwd_dq_dv_mfma_kernel<4>), grid2, dim3(256), 0, s, p, mask, ds, dout, kp, n, k, h, dk, dq, dv); break;
+        }
+        rc = snf::check_launch("bwd_dq_dv_mfma_kernel");
+    } else {
+        dim3 grid2((unsigned)((n + 63) / 64), (unsigned)((dk + 63) / 64), (unsigned)h);
+        hipLaunchKernelGGL(bwd_dq_dv_kernel, grid2, dim3(256), 0, s, p, mask, ds, dout, kp, n, k, h, dk, dq, dv);
+        rc = snf::check_launch("bwd_dq_dv_kernel");
+    }
     if (rc) return rc;
     // dKp = dS^T Q: the forward's P^T V machinery on (dS, Q)
     const int slices = generic_slices(n);

@@ -629,7 +629,9 @@ def test_gather_slot_map_equals_separate_kernels(n, d, k):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,k,h,dk,drop", [(1, 1, 1, 8, 0.0), (50, 7, 2, 16, 0.0), (1000, 200, 6, 64, 0.0), (777, 130, 3, 83, 0.0),
-                                           (2048, 200, 6, 128, 0.0), (300, 64, 2, 32, 0.3), (5000, 512, 2, 64, 0.0)])
+                                           (2048, 200, 6, 128, 0.0), (300, 64, 2, 32, 0.3), (5000, 512, 2, 64, 0.0),
+                                           # round 5 (f32 matrix-core forms): the README head widths, a mask at an odd k, k > 1024
+                                           (4100, 500, 4, 192, 0.0), (3001, 900, 4, 96, 0.1), (999, 131, 2, 24, 0.2), (400, 1100, 1, 64, 0.0)])
 def test_sparse_attn_bwd_matches_autograd_reference(n, k, h, dk, drop):
     """snf_sparse_attn_bwd_f32 against torch.autograd through the plain fp64 formulation of snuffy.py:160-168."""
     g = torch.Generator().manual_seed(n + k + dk)
@@ -655,6 +657,16 @@ def test_sparse_attn_bwd_matches_autograd_reference(n, k, h, dk, drop):
     dq2, dkp2, dv2 = ops().sparse_attn_bwd(q.to(DEV), kp.to(DEV), v.to(DEV), p, dout.to(DEV), h,
                                            mask=None if mask is None else mask.to(DEV))
     assert torch.equal(dq, dq2) and torch.equal(dkp, dkp2) and torch.equal(dv, dv2)
+    # the vector-ALU kernels (round 1) compute the same fp32 products in another order
+    from snuffy_amd import _ffi
+    _ffi.load().snf_debug_exact_attn_mfma(0)
+    try:
+        dq3, dkp3, dv3 = ops().sparse_attn_bwd(q.to(DEV), kp.to(DEV), v.to(DEV), p, dout.to(DEV), h,
+                                               mask=None if mask is None else mask.to(DEV))
+    finally:
+        _ffi.load().snf_debug_exact_attn_mfma(1)
+    for a_, b_ in ((dq, dq3), (dkp, dkp3), (dv, dv3)):
+        assert rel_err(a_.cpu(), b_.cpu()) < 5e-6
 
 
 @pytest.mark.gpu

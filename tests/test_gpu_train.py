@@ -368,7 +368,8 @@ def test_snuffy_multiclass_trainer_run_model_and_step(B):
     pred_ref = ((1 - w_ref) * torch.sigmoid(max_ref) + w_ref * torch.sigmoid(logits_ref)).detach().squeeze()
     loss_ref.backward()
     names = [k for k, _ in tr.milnet.named_parameters()]
-    grads_ref = {k: sd[k].grad.detach().clone() for k in names}
+    # what Adam normalises is g + weight_decay * w (L2 form, torch.optim.Adam): kept to tell apart the entries where it nearly cancels
+    grads_ref = {k: (sd[k].grad + args.weight_decay * sd[k]).detach().clone() for k in names}
     opt_ref = torch.optim.Adam([{"params": [w_ref], "lr": args.lr * args.single_weight__lr_multiplier},
                                 {"params": [sd[k] for k in names]}], lr=args.lr, betas=(0.5, 0.9), weight_decay=args.weight_decay)
     opt_ref.step()
@@ -386,8 +387,9 @@ def test_snuffy_multiclass_trainer_run_model_and_step(B):
         ref = sd[k].detach()
         # the key bias has a mathematically zero gradient (softmax is shift-invariant): its Adam step is +-lr of rounding noise
         tol = 2.1 * args.lr if k.endswith("self_attn.linears.1.bias") else 2e-5 * max(1.0, float(ref.abs().max()))
-        # Adam's first step is lr * g / (|g| + 1e-8): an entry whose gradient is of the order of eps moves by a fraction of lr that the
-        # last bits of g decide (the summation order of a kernel) -- those entries are held to the step size, the rest to 2e-5
+        # Adam's first step is lr * g' / (|g'| + 1e-8) with g' = g + weight_decay * w: an entry where g' is of the order of eps moves by
+        # a fraction of lr that the last bits of g decide (the summation order of a kernel) -- those entries are held to the step size,
+        # the rest to 2e-5
         tiny = grads_ref[k].abs() < 1e-6
         diff = (p.detach().cpu() - ref).abs()
         assert float(diff[~tiny].max() if (~tiny).any() else 0.0) <= tol, k
