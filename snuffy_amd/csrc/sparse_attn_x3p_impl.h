@@ -464,7 +464,10 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
         constexpr int NACC = X3P_NACC;
         f32x16 Tacc[R][NACC];
         f32x16 Ta[R];                         // the scores (sum of the accumulators), from the statistics units on
-        f32x2 E2[R][8];                       // exp2(s - max) of tile i, as register pairs (packed fp32 arithmetic)
+        // exp2(s - max) of tile i, as register pairs.  The arithmetic on them is issued as SINGLE fp32 instructions: packed forms
+        // (v_pk_add_f32 / v_pk_mul_f32, -DX3P_PK) save 31 of 356 instructions per tile and measured 2.5 us SLOWER per launch (79.2 ->
+        // 76.7 us under rocprofv3, profiles/r05_attn_x3p_kbw.txt) -- a packed fp32 op beside MFMAs costs more than the two it replaces
+        f32x2 E2[R][8];
         constexpr int NPF = 4;                // MODE 2, up to NPF chunks: the chunks' (max, sum) of the NEXT tile's rows, one iteration ahead
         f32x2 pf[NPF];
 #pragma unroll
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
         constexpr int NH = (NW + 1) / 2;
         constexpr int U_CMAX = 1, U_CW = 2, U_FS = U_CW + NH + 2, U_NORM = U_FS + 1, N_FIRST = U_NORM + 12 * R;
         // second-half sequence: offsets | 2 R max units, halves | NXS exp stages with the NDU DMA instructions spread between them | publish
-        // exp stages work on PAIRS of scores (v_pk_add_f32 for the subtraction and the running sums; the exponentials are scalar)
+        // exp stages work on PAIRS of scores (two single instructions per operation, see E2)
         constexpr int NPAIR = 8 * R, NXS = NPAIR + 2;
         constexpr int NDU = ISS ? UQ + UV : 0, N_SECOND = 2 + 2 * R + NXS + NDU + 1, NUNITS = N_FIRST + N_SECOND;
         struct SecondMap {
@@ -642,7 +645,13 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
                 unsigned char* pb = smem + ((waddr0 ^ (16 * c4)) + r * PBUF);
                 if constexpr (part == 0) {
                     const f32x2 fs2 = {s.fscale, s.fscale};
+#ifndef X3P_PK
+                    const f32x2 e01 = {E2[r][2 * c4][0] * s.fscale, E2[r][2 * c4][1] * s.fscale};
+                    const f32x2 e23 = {E2[r][2 * c4 + 1][0] * s.fscale, E2[r][2 * c4 + 1][1] * s.fscale};
+                    (void)fs2;
+#else
                     const f32x2 e01 = E2[r][2 * c4] * fs2, e23 = E2[r][2 * c4 + 1] * fs2;
+#endif
                     s.p4 = f32x4{e01[0], e01[1], e23[0], e23[1]};
                     // P is ROUNDED to fp32 here in every variant: without this the compiler contracts the product into the subtraction
                     // of the split below (fma) in the variants that do not store A, and their O differs in the last bits
@@ -668,9 +677,14 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
                 }
 #endif
                 else if constexpr (part == 1) {
+#ifndef X3P_PK
+                    s.r0 = s.p4[0] - __uint_as_float(s.h01 << 16), s.r1 = s.p4[1] - __uint_as_float(s.h01 & 0xffff0000u);
+                    s.r2 = s.p4[2] - __uint_as_float(s.h23 << 16), s.r3 = s.p4[3] - __uint_as_float(s.h23 & 0xffff0000u);
+#else
                     const f32x2 ra = f32x2{s.p4[0], s.p4[1]} - f32x2{__uint_as_float(s.h01 << 16), __uint_as_float(s.h01 & 0xffff0000u)};
                     const f32x2 rb = f32x2{s.p4[2], s.p4[3]} - f32x2{__uint_as_float(s.h23 << 16), __uint_as_float(s.h23 & 0xffff0000u)};
                     s.r0 = ra[0], s.r1 = ra[1], s.r2 = rb[0], s.r3 = rb[1];
+#endif
                 } else {
                     *reinterpret_cast<u32x2*>(pb + PBUF / 2) = u32x2{cvt_pk(s.r0, s.r1), cvt_pk(s.r2, s.r3)};
                 }
@@ -701,7 +715,11 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
                 } else if constexpr (kind == 3) {
                     constexpr int q = arg;        // stage q: sub of score pair q, exp of pair q - 1, add of pair q - 2
 #ifndef X3P_ABL_NOSUM
+#ifndef X3P_PK
+                    if constexpr (q >= 2) s.l2[0] += E2[(q - 2) >> 3][(q - 2) & 7][0], s.l2[1] += E2[(q - 2) >> 3][(q - 2) & 7][1];
+#else
                     if constexpr (q >= 2) s.l2 += E2[(q - 2) >> 3][(q - 2) & 7];
+#endif
 #endif
                     if constexpr (q >= 1 && q - 1 < NPAIR) {
                         const f32x2 x = (q & 1) ? s.x0 : s.x1;
@@ -711,7 +729,11 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
                         E2[(q - 1) >> 3][(q - 1) & 7] = f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
 #endif
                     }
+#ifndef X3P_PK
+                    if constexpr (q < NPAIR) ((q & 1) ? s.x1 : s.x0) = f32x2{Ta[q >> 3][2 * (q & 7)] - mw, Ta[q >> 3][2 * (q & 7) + 1] - mw};
+#else
                     if constexpr (q < NPAIR) ((q & 1) ? s.x1 : s.x0) = f32x2{Ta[q >> 3][2 * (q & 7)], Ta[q >> 3][2 * (q & 7) + 1]} - f32x2{mw, mw};
+#endif
                 } else if constexpr (kind == 4) {
                     const int off = s.doff;
                     if constexpr (arg + 1 < NDU) s.doff = dma_tab[(arg + 1) * 64];
@@ -735,7 +757,20 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
 #define X3P_PFV 1
 #endif
         constexpr int PFQ = X3P_PFQ < NKS ? X3P_PFQ : NKS - 1, PFV = X3P_PFV < NCB ? X3P_PFV : NCB - 1;
-        constexpr int F_LO = 0, F_HI = H - 3 * R * PFV, S_LO = H + 2 * R, S_HI = 2 * H;
+#ifndef X3P_FLO
+#define X3P_FLO 0
+#endif
+#ifndef X3P_FHI_EXTRA
+#define X3P_FHI_EXTRA 0
+#endif
+#ifndef X3P_SLO
+#define X3P_SLO 2
+#endif
+#ifndef X3P_SHI_EXTRA
+#define X3P_SHI_EXTRA 0
+#endif
+        // (dev knobs: where the unit windows start / end among the MFMA slots; the defaults are the round-4 placement)
+        constexpr int F_LO = X3P_FLO, F_HI = H - 3 * R * PFV - X3P_FHI_EXTRA, S_LO = H + X3P_SLO * R, S_HI = 2 * H - X3P_SHI_EXTRA;
 #define X3P_UB1(k) ((k) <= F_LO ? 0 : (k) >= F_HI ? N_FIRST : (((k) - F_LO) * N_FIRST + (F_HI - F_LO) / 2) / (F_HI - F_LO))
 #define X3P_UB2(k) ((k) <= S_LO ? N_FIRST : (k) >= S_HI ? NUNITS : N_FIRST + (((k) - S_LO) * (NUNITS - N_FIRST) + (S_HI - S_LO) / 2) / (S_HI - S_LO))
 #define X3P_UB(k) ((k) < H ? X3P_UB1(k) : X3P_UB2(k))

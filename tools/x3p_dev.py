@@ -46,7 +46,7 @@ def check(n, k, h, dk=128, seed=0):
     return e_o < 2e-5 and e_o2 < 2e-5 and e_p < 6e-6
 
 
-def timeit(n, k, h, dk=128, reps=20, nbuf=6):
+def timeit(n, k, h, dk=128, reps=120, nbuf=6):
     d = h * dk
     bufs = []
     for i in range(nbuf):
@@ -68,10 +68,12 @@ def timeit(n, k, h, dk=128, reps=20, nbuf=6):
             fn(bufs[r % nbuf])
             ev[r][1].record()
         torch.cuda.synchronize()
-        ts = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+        ts = sorted(a.elapsed_time(b) * 1e3 for a, b in ev[reps // 6:])     # (the first launches run on the clock ramp)
+        mid = ts[len(ts) // 4: 3 * len(ts) // 4]
+        iqm = sum(mid) / len(mid)                                             # interquartile mean: the figure to compare builds with
         byts = 8 * n * d + 8 * k * d
-        print(f"{name} n={n} k={k} h={h} dk={dk}: median {ts[len(ts) // 2]:.1f} us  min {ts[0]:.1f} us  -> {byts / ts[len(ts) // 2] / 1e6:.2f} TB/s "
-              f"({byts / ts[len(ts) // 2] / 1e6 / 8:.3f} of 8 TB/s)", flush=True)
+        print(f"{name} n={n} k={k} h={h} dk={dk}: median {ts[len(ts) // 2]:.1f} us  min {ts[0]:.1f} us  iqm {iqm:.2f} us  -> "
+              f"{byts / ts[len(ts) // 2] / 1e6:.2f} TB/s ({byts / ts[len(ts) // 2] / 1e6 / 8:.3f} of 8 TB/s)", flush=True)
 
 
 if __name__ == "__main__":
