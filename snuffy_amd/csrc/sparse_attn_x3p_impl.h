@@ -554,8 +554,28 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
             float r0, r1, r2, r3;
         };
         // cno / rows_ok: the (head, tile) of tile i and the number of its rows that exist (0 in the fill iteration: P := 0)
-        auto unit = [&](auto u_t, VS& s, int par_n, const Cur cno, const Cur cnx, int rows_ok, const DmaCtx& dc) __attribute__((always_inline)) {
+#ifdef X3P_NORM_SKEW
+        struct NormMap {
+            int ch[12 * R], part[12 * R];
+            constexpr NormMap() : ch{}, part{} {
+                int v = 0;
+                for (int t = 0; t < 4 * R + 2; ++t)
+                    for (int pp = 0; pp < 3; ++pp)
+                        if (t - pp >= 0 && t - pp < 4 * R) ch[v] = t - pp, part[v++] = pp;
+            }
+        };
+        constexpr NormMap nmap{};
+        struct NS {
+            float fscale;
+            f32x4 p4;
+            unsigned h01, h23;
+            float r0, r1, r2, r3;
+        };
+        NS sv_[4];
+#endif
+        auto unit = [&](auto u_t, VS& s0, int par_n, const Cur cno, const Cur cnx, int rows_ok, const DmaCtx& dc) __attribute__((always_inline)) {
             constexpr int u = decltype(u_t)::value;
+            VS& s = s0;
 #ifdef X3P_ABL_NO_U1
             if constexpr (u < N_FIRST) return;
 #endif
@@ -641,13 +661,19 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
                 s.fscale = rvalid ? fs : 0.f;
             } else if constexpr (u < N_FIRST) {
                 if constexpr (MODE == 1) return;
+#ifdef X3P_NORM_SKEW
+                // skewed order (dev knob): the three parts of a 4-key chunk sit two units apart -- no unit waits for its predecessor
+                constexpr int ch = nmap.ch[u - U_NORM], part = nmap.part[u - U_NORM], r = ch / 4, c4 = ch % 4;
+                NS& s = sv_[ch & 3];                     // (shadows the iteration's state: this chunk's own registers)
+#else
                 constexpr int r = (u - U_NORM) / 12, c4 = ((u - U_NORM) % 12) / 3, part = (u - U_NORM) % 3;
+#endif
                 unsigned char* pb = smem + ((waddr0 ^ (16 * c4)) + r * PBUF);
                 if constexpr (part == 0) {
-                    const f32x2 fs2 = {s.fscale, s.fscale};
+                    const f32x2 fs2 = {s0.fscale, s0.fscale};
 #ifndef X3P_PK
-                    const f32x2 e01 = {E2[r][2 * c4][0] * s.fscale, E2[r][2 * c4][1] * s.fscale};
-                    const f32x2 e23 = {E2[r][2 * c4 + 1][0] * s.fscale, E2[r][2 * c4 + 1][1] * s.fscale};
+                    const f32x2 e01 = {E2[r][2 * c4][0] * s0.fscale, E2[r][2 * c4][1] * s0.fscale};
+                    const f32x2 e23 = {E2[r][2 * c4 + 1][0] * s0.fscale, E2[r][2 * c4 + 1][1] * s0.fscale};
                     (void)fs2;
 #else
                     const f32x2 e01 = E2[r][2 * c4] * fs2, e23 = E2[r][2 * c4 + 1] * fs2;
@@ -952,7 +978,9 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
     };
     // KBW = 1: the second-dispatched waves of a SIMD lose every arbitration to the first at equal priority and set the iteration time
     // (in-kernel trace: first half 1450 ticks for waves 0-3, 2480 for waves 4-6): static priority for them (guide T5, static form)
+#ifndef X3P_NOPRIO
     if (KBW == 1 && w >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     using KB = std::integral_constant<int, KBW>;
     using KL = std::integral_constant<int, RLAST>;
     if constexpr (LOADER) {

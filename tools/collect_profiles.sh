@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the judged artefacts of an end-of-round run (tools/run_profiles.sh + tools/sweep.py, merged back under gpurun_out/r04/) into
 # profiles/ under their per-round names.  usage (container, repo root): bash tools/collect_profiles.sh
-R=r04; O=gpurun_out/$R; P=profiles
+R=r05; O=gpurun_out/$R; P=profiles
 cp_if() { [ -s "$1" ] && cp "$1" "$2"; }
 cp_if $O/bench_cfgB.json $P/${R}_bench_cfgB.json
 cp_if $O/bench_cfgA.json $P/${R}_bench_cfgA.json
@@ -23,6 +23,7 @@ cp_if $O/traffic.txt $P/${R}_attn_traffic_cfgB.txt
 cp_if $O/traffic/attn_traffic.json $P/${R}_attn_traffic_cfgB_bf16.json
 cp_if $O/traffic_x3p_cfgB/attn_traffic_cfgB_fp32.json $P/${R}_attn_traffic_cfgB_fp32.json
 cp_if $O/traffic_x3p_cfgC/attn_traffic_cfgC_fp32.json $P/${R}_attn_traffic_cfgC_fp32.json
+cp_if $O/traffic_x3p_cfgA/attn_traffic_cfgA_fp32.json $P/${R}_attn_traffic_cfgA_fp32.json
 cp_if $O/traffic_x3p_cfgB.txt $P/${R}_attn_traffic_cfgB_fp32.txt
 cp_if $O/traffic_x3p_cfgC.txt $P/${R}_attn_traffic_cfgC_fp32.txt
 cp_if $O/attn_x3p_pmc_sq.txt $P/${R}_attn_x3_pmc_sq.txt
@@ -34,4 +35,10 @@ cp_if $O/gemm_bench.txt $P/${R}_gemm_bench.txt
 cp_if $O/gemm_x3_bench.txt $P/${R}_gemm_x3_bench.txt
 cp_if $O/topk_bench.txt $P/${R}_topk_bench.txt
 cp_if $O/sweep.md $P/${R}_sweep_N_D.md
+for w in readme_dino_scratch readme_dino_adapter readme_mae_adapter; do cp_if $O/bench_$w.json $P/${R}_bench_$w.json; done
+cp_if $O/cfgA_f32_kernel_stats.csv $P/${R}_bench_cfgA_fp32_kernel_stats.csv
+cp_if $O/cfgC_f32_kernel_stats.csv $P/${R}_bench_cfgC_fp32_kernel_stats.csv
+cp_if $O/readme_mae_f32_kernel_stats.csv $P/${R}_bench_readme_mae_adapter_fp32_kernel_stats.csv
+cp_if $O/readme_scratch_f32_kernel_stats.csv $P/${R}_bench_readme_dino_scratch_fp32_kernel_stats.csv
+cp_if $O/exact_attn_bench.txt $P/${R}_exact_attn_bench.txt
 ls -la $P | grep ${R}_ | wc -l

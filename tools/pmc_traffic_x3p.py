@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Workload for the HBM-traffic PMC passes of the pipelined fp32-class attention (snf_sparse_attn_fwd_x3_hl):
 calibration read / write of known size, then REPS calls on operand sets that rotate through more than the Infinity Cache.
-usage: python tools/pmc_traffic_x3p.py cfgB|cfgC     (run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, see pmc_traffic_x3p.sh)"""
+usage: python tools/pmc_traffic_x3p.py cfgA|cfgB|cfgC     (run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, see pmc_traffic_x3p.sh)"""
 import os
 import sys
 
@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from snuffy_amd import ops  # noqa: E402
 
-WL = {"cfgB": (32768, 768, 6, 200), "cfgC": (100000, 768, 6, 512)}
+WL = {"cfgB": (32768, 768, 6, 200), "cfgC": (100000, 768, 6, 512), "cfgA": (8192, 384, 6, 200)}
 REPS = 8
 dev = torch.device("cuda")
 N, D, h, K = WL[sys.argv[1] if len(sys.argv) > 1 else "cfgB"]

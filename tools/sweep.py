@@ -17,18 +17,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import build_net, kernel_rooflines  # noqa: E402
 
 
-def cpu_rate(N, D, lam, threads, budget_s=6.0):
+def cpu_rate(N, D, lam, threads, budget_s=6.0, h=6, r=0.0):
     """slides/s of the CPU port (oracle.milnet_forward, A materialised as the reference does) at `threads` threads."""
     from oracle import snuffy_oracle as orc          # CPU baseline column: the checker, timed -- never the product path
-    net = build_net(D, 6, lam, "fp32", "cpu")
+    net = build_net(D, h, lam, "fp32", "cpu", r)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
     x = torch.randn(N, D, generator=torch.Generator().manual_seed(1234))
     torch.set_num_threads(threads)
     with torch.no_grad():
-        orc.milnet_forward(x, sd, 6, "relu", lam, 0.0, 1)
+        orc.milnet_forward(x, sd, h, "relu", lam, r, 1)
         t0, n = time.perf_counter(), 0
         while True:
-            orc.milnet_forward(x, sd, 6, "relu", lam, 0.0, 1)
+            orc.milnet_forward(x, sd, h, "relu", lam, r, 1)
             n += 1
             el = time.perf_counter() - t0
             if el > budget_s or n >= 50:
@@ -117,6 +117,31 @@ def main():
                   flush=True)
             del bags
             torch.cuda.empty_cache()
+    # the reference's published recipes (reference README.md:609-669; SURVEY 8(d): "also report h=4"): 4 heads, a random patch share
+    # (device sampler, graph replay; "parity" = the reference's numpy draws on the host), bags of the CAMELYON16 mean length
+    from bench import WORKLOADS
+    print("\n| README recipe | N | D | h | dk | K (top + random) | CPU slides/s | fp32-class slides/s | x CPU | fp32-class, parity sampler | bf16 slides/s "
+          "| fp32-class attention µs | frac of 8 TB/s | attention kernel |")
+    print("|" + "---|" * 14)
+    for name in ("readme_dino_scratch", "readme_dino_adapter", "readme_mae_adapter"):
+        wl = WORKLOADS[name]
+        N, D, h, lam, r = wl["N"], wl["D"], wl["h"], wl["lam"], wl["r"]
+        g = torch.Generator().manual_seed(1234)
+        bags = [torch.randn(1, N, D, generator=g).to(dev) for _ in range(4)]
+        ms = {}
+        for prec, smp in (("fp32", "device"), ("fp32", "reference"), ("bf16", "device")):
+            net = build_net(D, h, lam, prec, dev, r).eval().configure(sampler=smp)
+            ms[(prec, smp)] = gpu_ms(net, bags, args.steps, smp == "device")
+            del net
+        rf = kernel_rooflines(wl, "fp32", dev, name)["roofline"]
+        cpu = float("nan") if args.no_cpu else cpu_rate(N, D, lam, args.cpu_threads, h=h, r=r)
+        import math
+        print("| %s | %d | %d | %d | %d | %d (%d + %d) | %.2f | %.0f | %.0f | %.0f | %.0f | %.1f | %.3f | %s |"
+              % (name, N, D, h, D // h, lam, math.ceil(lam * (1 - r)), int(lam * r), cpu, 1e3 / ms[("fp32", "device")],
+                 1e3 / ms[("fp32", "device")] / cpu, 1e3 / ms[("fp32", "reference")], 1e3 / ms[("bf16", "device")], rf["us_per_launch"],
+                 rf["frac"], rf["kernel"]), flush=True)
+        del bags
+        torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":
