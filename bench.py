@@ -98,7 +98,7 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
     N, D, h, lam = wl["N"], wl["D"], wl["h"], wl["lam"]
     K, dk = min(lam, N), D // h
     D_true = D
-    if precision == "fp32" and SF.head_pad(dk) not in (None, dk):
+    if SF.head_pad(dk) not in (None, dk) and (precision == "fp32" or ops.mfma_attn_supported(K, SF.head_pad(dk))):
         # head widths between the kernel's ride zero-padded (functional.head_pad: the README recipes' dk = 96 -> 128): the launch
         # streams the padded Q | V image; algorithmic bytes below stay those of the TRUE width
         dk = SF.head_pad(dk)
@@ -169,7 +169,9 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
         def attn():
             i = state["i"] = (state["i"] + 1) % nset
             ops.sparse_attn_fwd(qf[i], kp, vs[i], h)
-        kern = "scores_softmax_kernel+pt_v_kernel+reduce_slices_kernel"
+        # exact fp32: on the f32 matrix-core forms where the head width allows (round 5), else on the vector ALUs
+        kern = ("scores_softmax_mfma_kernel+pt_v_mfma_kernel+reduce_slices_kernel" if dk % 8 == 0 and K <= 1024 else
+                "scores_softmax_kernel+pt_v_mfma_kernel+reduce_slices_kernel")
         elt = 4
     # 20 launches over rotating operand sets: cold operands (every set is evicted from the 256 MiB Infinity Cache before it comes
     # back).  The bf16 kernel takes the same time inside the bag pipeline (rocprofv3: 37 + 7 us); the fp32-class kernel is faster

@@ -908,7 +908,9 @@ __global__ __launch_bounds__(512) void skinny_linear_x3_kernel(const float* __re
             const int ch = row0 / fr.chunk_size, b = (row0 - ch * fr.chunk_size) >> 5;
             int kc = r - ch * fr.chunk_size;                   // keys of this chunk
             if (kc > fr.chunk_size) kc = fr.chunk_size;
-            const int nkb = (kc + 31) >> 5, nks = fr.dk >> 4;
+            // key blocks per head in the image: the chunk's own, or (chunked launches) those of a FULL chunk -- every chunk of a
+            // merged launch is laid out alike, a shorter last chunk leaves its trailing blocks unwritten (the kernel masks them)
+            const int nkb = fr.chunk_size < r ? (fr.chunk_size + 31) >> 5 : (kc + 31) >> 5, nks = fr.dk >> 4;
             const int a = col0 / fr.dk, cin = col0 - a * fr.dk + 8 * gq;
             const int kb = cin >> 4, hf2 = (cin >> 3) & 1;
             f32x8s v;

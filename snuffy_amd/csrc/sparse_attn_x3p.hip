@@ -70,7 +70,10 @@ struct X3PChunks {
 bool x3p_chunks(int k, int dk, X3PChunks* c) {
     if ((dk != 128 && dk != 64) || k < 97 || k > 8 * 256) return false;
     c->count = (k + 255) / 256;
-    c->size = c->count == 1 ? k : ((k + c->count - 1) / c->count + 3) & ~3;
+    // (round 5: whole key blocks per chunk, so that every chunk starts on a key-block boundary -- the key projection can write the
+    //  fragment image of any chunked launch -- and all chunks share ONE kernel instantiation: a shorter last chunk runs with its
+    //  trailing key blocks masked)
+    c->size = c->count == 1 ? k : (((k + c->count - 1) / c->count + 31) / 32) * 32;
     return true;
 }
 struct X3PLayout {   // workspace: partial accumulators | Kp fragment image | statistics
@@ -82,7 +85,7 @@ struct X3PLayout {   // workspace: partial accumulators | Kp fragment image | st
 int x3p_merged_ranges(const X3PChunks& ch, int k) {
     if (ch.count < 2) return 0;
     const int last = k - (ch.count - 1) * ch.size;
-    if ((last + 31) / 32 != (ch.size + 31) / 32) return 0;
+    if (last < 1) return 0;
     const int per_xcd = snf::cu_count() / 8 / ch.count;
     return per_xcd >= 1 ? 8 * per_xcd : 0;
 }

@@ -437,7 +437,6 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
         constexpr int R = decltype(r_t)::value;
         constexpr bool LASTW = decltype(lastw_t)::value, ISS = decltype(iss_t)::value;
         const int gkb0 = KBW * w;                                       // the wave's first key block
-        const int klast = kk - 32 * (NKB - 1);                          // valid keys of the last key block
 
         // ---- Kp fragments of the wave's key blocks: MFMA A operands, hi and lo, for the whole head -- 16-byte loads out of the
         // fragment-ordered image (scaled and split by its producer: nothing but the loads happens here, so a head change inside a
@@ -722,9 +721,10 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
                     constexpr int r = arg >> 1, r0 = 8 * (arg & 1);
 #pragma unroll
                     for (int i = r0; i < r0 + 8; ++i) Ta[r][i] = NACC == 2 ? Tacc[r][0][i] + Tacc[r][NACC - 1][i] : Tacc[r][0][i];
-                    if constexpr (LASTW && r == R - 1) {            // padded keys of the launch's last key block
+                    if constexpr (LASTW) {            // padded keys (the launch's last key block; every key block past a short last chunk)
 #pragma unroll
-                        for (int i = r0; i < r0 + 8; ++i) Ta[r][i] = ((i & 3) + 8 * (i >> 2) + 4 * hf) < klast ? Ta[r][i] : -INFINITY;
+                        for (int i = r0; i < r0 + 8; ++i)
+                            Ta[r][i] = (32 * (gkb0 + r) + (i & 3) + 8 * (i >> 2) + 4 * hf) < kk ? Ta[r][i] : -INFINITY;
                     }
 #ifdef X3P_ABL_NOMAX
                     float mx = Ta[r][r0];
@@ -737,6 +737,7 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
                     if constexpr (arg == 0) s.mx = mx; else s.mx = fmaxf(s.mx, mx);
                 } else if constexpr (kind == 2) {
                     mw = xhalf_max(s.mx);
+                    if constexpr (LASTW) mw = fmaxf(mw, -1e30f);   // a wave whose keys are all padding: exp2(-inf - mw) = 0, not NaN
                     s.l2 = f32x2{0.f, 0.f};
                 } else if constexpr (kind == 3) {
                     constexpr int q = arg;        // stage q: sub of score pair q, exp of pair q - 1, add of pair q - 2
@@ -983,6 +984,9 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
 #endif
     using KB = std::integral_constant<int, KBW>;
     using KL = std::integral_constant<int, RLAST>;
+    // LASTW (the masking variant) for every wave that holds padded keys: the last wave, and -- in merged key-chunk launches whose last
+    // chunk is shorter -- every wave past that chunk's keys (wave-uniform, decided once)
+    const bool pads = 32 * KBW * (w + 1) > kk;
     if constexpr (LOADER) {
         if (w == NW) {
             // ---- the loader wave: the DMA schedule of the pipeline (see run()) and its barriers, nothing else.  The per-lane source
@@ -1036,6 +1040,8 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
             }
         } else if (w == NW - 1) {
             run(KL{}, std::true_type{}, std::false_type{});
+        } else if (pads) {
+            run(KB{}, std::true_type{}, std::false_type{});
         } else {
             run(KB{}, std::false_type{}, std::false_type{});
         }
@@ -1043,21 +1049,23 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
         // the last wave carries one key block where the others carry two: it issues all the DMA
         if (w == NW - 1)
             run(KL{}, std::true_type{}, std::true_type{});
+        else if (pads)
+            run(KB{}, std::true_type{}, std::false_type{});
         else
             run(KB{}, std::false_type{}, std::false_type{});
     } else {
-        if (w < L0)
-            run(KB{}, std::false_type{}, std::false_type{});    // statistics pass, wave 0: stores the pairs, issues no DMA
-        else if (w == NW - 1)
+        if (w < L0) {                                               // statistics pass, wave 0: stores the pairs, issues no DMA
+            if (pads) run(KB{}, std::true_type{}, std::false_type{}); else run(KB{}, std::false_type{}, std::false_type{});
+        } else if (w == NW - 1) {
             run(KL{}, std::true_type{}, std::true_type{});
-        else
+        } else if (pads) {
+            run(KB{}, std::true_type{}, std::true_type{});
+        } else {
             run(KB{}, std::false_type{}, std::true_type{});
+        }
     }
 }
 
-// Kp [k, h dk] f32 -> the MFMA A fragments the attention waves keep in registers: [h][nkb][dk / 16][hi | lo][64 lanes] x 16 bytes,
-// value = Kp * scale * log2(e) (the softmax runs in base 2), hi = bf16(v), lo = bf16(v - hi); padded keys are zero.
-// One wave per (head, key block).
 template <int DK>
 __global__ __launch_bounds__(64) void x3p_prep_kp_kernel(const float* __restrict__ kp, int64_t ldkp, int k, int nkb, float c_exp,
                                                           u32x4* __restrict__ out, int chunk_size, int64_t out_stride) {

@@ -554,7 +554,10 @@ def test_sparse_attn_x3_hl_config_b_spike_and_domain():
 
 
 @pytest.mark.parametrize("n,k,h,dk", [(3000, 200, 6, 128), (5000, 97, 2, 128), (4000, 256, 3, 128), (3000, 512, 6, 128), (900, 1024, 2, 128),
-                                      (3000, 200, 6, 64), (8192, 200, 6, 64), (2000, 512, 4, 64)])
+                                      (3000, 200, 6, 64), (8192, 200, 6, 64), (2000, 512, 4, 64),
+                                      # round 5: chunks are whole key blocks -- any chunked key count has the fused form (a shorter last chunk
+                                      # runs with its trailing key blocks masked): the README recipe's 900 keys, 257 = 160 + 97, 1790
+                                      (2000, 900, 4, 128), (700, 257, 2, 128), (1500, 601, 3, 64), (300, 1790, 1, 128)])
 def test_sparse_attn_x3_hl_fused_key_projection(n, k, h, dk):
     """snf_linear_rows_x3_kpfrag_f32 + snf_sparse_attn_fwd_x3_hl_kpfrag: the key projection writes the attention kernel's fragment
     image itself -- bit-identical to projection -> fp32 Kp -> snf_sparse_attn_fwd_x3_hl (same products, same rounding points)."""
@@ -580,11 +583,11 @@ def test_sparse_attn_x3_hl_fused_key_projection(n, k, h, dk):
 
 
 def test_sparse_attn_x3_hl_fused_key_projection_domain():
-    assert not ops().x3_hl_kpfrag_supported(257, 2, 128)      # two chunks of 132 keys: not on key-block boundaries
+    assert ops().x3_hl_kpfrag_supported(257, 2, 128)          # (round 5: chunks of 160 + 97 keys, on key-block boundaries)
     assert not ops().x3_hl_kpfrag_supported(200, 24, 32)      # dk = 32
     assert not ops().x3_hl_kpfrag_supported(96, 6, 128)
     with pytest.raises(ValueError):
-        ops().linear_rows_x3_kpfrag(torch.zeros(257, 256, device=DEV), torch.zeros(256, 256, device=DEV), None, 2)
+        ops().linear_rows_x3_kpfrag(torch.zeros(96, 256, device=DEV), torch.zeros(256, 256, device=DEV), None, 2)   # fewer than 97 keys
 
 
 def test_mfma_rejects_unsupported_shapes():
