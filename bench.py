@@ -166,11 +166,15 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
         vs = [qv[:, D:].float().contiguous() for qv in qvs]
         qf = [qv[:, :D].float().contiguous() for qv in qvs]
 
+        x3u = precision == "fp32" and ops.x3u_attn_supported(K, dk)   # functional.encoder_layer's dispatch for such head widths
+
         def attn():
             i = state["i"] = (state["i"] + 1) % nset
-            ops.sparse_attn_fwd(qf[i], kp, vs[i], h)
-        # exact fp32: on the f32 matrix-core forms where the head width allows (round 5), else on the vector ALUs
-        kern = ("scores_softmax_mfma_kernel+pt_v_mfma_kernel+reduce_slices_kernel" if dk % 8 == 0 and K <= 1024 else
+            (ops.sparse_attn_fwd_x3u(qf[i], kp, vs[i], h) if x3u else ops.sparse_attn_fwd(qf[i], kp, vs[i], h))
+        # head widths outside the pipelined kernels: scores + softmax in split-bf16 x 3 (round 5) or exact on the f32 matrix cores,
+        # P^T V exact on the f32 matrix cores; the vector-ALU scores kernel where neither applies
+        kern = ("scores_softmax_x3u_kernel+pt_v_mfma_kernel+reduce_slices_kernel" if x3u else
+                "scores_softmax_mfma_kernel+pt_v_mfma_kernel+reduce_slices_kernel" if dk % 8 == 0 and K <= 1024 else
                 "scores_softmax_kernel+pt_v_mfma_kernel+reduce_slices_kernel")
         elt = 4
     # 20 launches over rotating operand sets: cold operands (every set is evicted from the 256 MiB Infinity Cache before it comes

@@ -379,6 +379,151 @@ __global__ __launch_bounds__(256, 2) void pt_v_mfma_kernel(const float* __restri
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The scores + softmax kernel in the fp32-CLASS arithmetic of the pipelined kernels (split-bf16 x 3 on v_mfma_f32_32x32x16_bf16: every
+// operand hi + lo, hi hi + hi lo + lo hi, fp32 accumulate; ~1e-5 per product) for the head widths those kernels do not take -- any
+// dk % 16 == 0 up to 256 (the README recipe D = 768 / h = 4: dk = 192), up to 1024 keys.
+//   scores_softmax_x3u: as scores_softmax_mfma; the Q tile is staged in LDS already split (hi plane | lo plane per row), the Kp rows are
+//     split in registers (16 vector instructions per 16-deep step and key block, beside its three MFMAs): 214 us against 324 at
+//     (30000, 500, 4, 192).
+//   P^T V stays on pt_v_mfma (exact fp32): a split-in-registers P^T V was built and measured 2.2x SLOWER than the f32 form (684 us
+//   against 313: five operand splits per six tile products, and 40 dword loads per 18 MFMAs) -- that product wants pre-split images,
+//   which is what the pipelined kernels do.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 xbf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 xbf16x4;
+typedef __attribute__((ext_vector_type(8))) float mf32x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int xu32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int xu32x2;
+
+__device__ __forceinline__ void x3u_split8(const mf32x8 x, xbf16x8& hi, xbf16x8& lo) {
+    hi = __builtin_convertvector(x, xbf16x8);
+    lo = __builtin_convertvector(x - __builtin_convertvector(hi, mf32x8), xbf16x8);
+}
+
+template <int KBW>
+__global__ __launch_bounds__(256, KBW <= 4 ? 3 : 2) void scores_softmax_x3u_kernel(const float* __restrict__ q, const float* __restrict__ kp,
+                                                                                   int64_t n, int k, int h, int dk, float scale,
+                                                                                   float* __restrict__ p_out, float* __restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    const int pitch = 4 * dk + 16;             // bytes per row: hi plane (2 dk) | lo plane (2 dk) | pad; 4 banks apart row to row
+    float* lst = reinterpret_cast<float*>(ldsb + 32 * pitch);     // [2][4][32]
+    const int a = blockIdx.y;
+    const int d_model = h * dk;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 31, hf = lane >> 5;
+    const int dk4 = dk >> 2;
+    for (int e = threadIdx.x; e < 32 * dk4; e += 256) {
+        const int r = e / dk4, c4 = e - r * dk4;
+        const int64_t row = row0 + r;
+        mf32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (row < n) val = *reinterpret_cast<const mf32x4*>(q + row * d_model + a * dk + 4 * c4);
+        const xbf16x4 hi = __builtin_convertvector(val, xbf16x4);
+        const xbf16x4 lo = __builtin_convertvector(val - __builtin_convertvector(hi, mf32x4), xbf16x4);
+        *reinterpret_cast<xu32x2*>(ldsb + r * pitch + 8 * c4) = __builtin_bit_cast(xu32x2, hi);
+        *reinterpret_cast<xu32x2*>(ldsb + r * pitch + 2 * dk + 8 * c4) = __builtin_bit_cast(xu32x2, lo);
+    }
+    __syncthreads();
+    const int nkb = (k + 31) >> 5;
+    const int nt = dk >> 4;                    // 16-deep steps
+    mf32x16 S[KBW];
+    const unsigned char* qr = ldsb + j * pitch + 16 * hf;
+#pragma unroll
+    for (int c = 0; c < KBW; ++c) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[c][i] = 0.f;
+        const int kb = w + 4 * c;
+        if (kb < nkb) {
+            int key = 32 * kb + j;
+            if (key > k - 1) key = k - 1;
+            const float* kr = kp + (int64_t)key * d_model + a * dk + 8 * hf;
+            int t = 0;
+            for (; t + 2 <= nt; t += 2) {      // two steps' Kp rows requested together (L2)
+                mf32x4 x[2][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    x[u][0] = *reinterpret_cast<const mf32x4*>(kr + 16 * (t + u));
+                    x[u][1] = *reinterpret_cast<const mf32x4*>(kr + 16 * (t + u) + 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    xbf16x8 kh, kl;
+                    x3u_split8(mf32x8{x[u][0][0], x[u][0][1], x[u][0][2], x[u][0][3], x[u][1][0], x[u][1][1], x[u][1][2], x[u][1][3]}, kh, kl);
+                    const xbf16x8 qh = __builtin_bit_cast(xbf16x8, *reinterpret_cast<const xu32x4*>(qr + 32 * (t + u)));
+                    const xbf16x8 ql = __builtin_bit_cast(xbf16x8, *reinterpret_cast<const xu32x4*>(qr + 2 * dk + 32 * (t + u)));
+                    S[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, S[c], 0, 0, 0);
+                    S[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, S[c], 0, 0, 0);
+                    S[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, S[c], 0, 0, 0);
+                }
+            }
+            for (; t < nt; ++t) {
+                const mf32x4 x0 = *reinterpret_cast<const mf32x4*>(kr + 16 * t), x1 = *reinterpret_cast<const mf32x4*>(kr + 16 * t + 4);
+                xbf16x8 kh, kl;
+                x3u_split8(mf32x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]}, kh, kl);
+                const xbf16x8 qh = __builtin_bit_cast(xbf16x8, *reinterpret_cast<const xu32x4*>(qr + 32 * t));
+                const xbf16x8 ql = __builtin_bit_cast(xbf16x8, *reinterpret_cast<const xu32x4*>(qr + 2 * dk + 32 * t));
+                S[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, S[c], 0, 0, 0);
+                S[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, S[c], 0, 0, 0);
+                S[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, S[c], 0, 0, 0);
+            }
+        }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < KBW; ++c) {
+        const int kb = w + 4 * c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hf;
+            S[c][i] = (kb < nkb && key < k) ? S[c][i] * scale : -INFINITY;
+            m = fmaxf(m, S[c][i]);
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    if (hf == 0) lst[w * 32 + j] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(lst[j], lst[32 + j]), fmaxf(lst[64 + j], lst[96 + j]));
+    float l = 0.f;
+#pragma unroll
+    for (int c = 0; c < KBW; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float e = __builtin_amdgcn_exp2f((S[c][i] - m) * 1.44269504088896340736f);
+            S[c][i] = e;
+            l += e;
+        }
+    l += __shfl_xor(l, 32, 64);
+    if (hf == 0) lst[128 + w * 32 + j] = l;
+    __syncthreads();
+    l = ((lst[128 + j] + lst[160 + j]) + lst[192 + j]) + lst[224 + j];
+    const float inv = 1.0f / l;
+    const int64_t row = row0 + j;
+    if (row < n) {
+        float* prow = p_out + ((int64_t)a * n + row) * k;
+        const bool vec = (k & 3) == 0 && (reinterpret_cast<uintptr_t>(p_out) & 15) == 0;
+#pragma unroll
+        for (int c = 0; c < KBW; ++c) {
+            const int kb = w + 4 * c;
+            if (kb < nkb) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int key0 = 32 * kb + 8 * q4 + 4 * hf;
+                    const mf32x4 pv = {S[c][4 * q4] * inv, S[c][4 * q4 + 1] * inv, S[c][4 * q4 + 2] * inv, S[c][4 * q4 + 3] * inv};
+                    if (vec && key0 + 4 <= k) {
+                        *reinterpret_cast<mf32x4*>(prow + key0) = pv;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (key0 + e < k) prow[key0 + e] = pv[e];
+                    }
+                }
+            }
+        }
+        if (lse && w == 0 && hf == 0) lse[(int64_t)a * n + row] = m + logf(l);
+    }
+}
+
 __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ partial, int slices, int k, int h,
                                                             int dk, float* __restrict__ out /*[k, h*dk]*/) {
     const int64_t total = (int64_t)h * k * dk;
@@ -1066,6 +1211,47 @@ int snf_sparse_attn_fwd_f32(const float* q, const float* kp, const float* v, int
         hipLaunchKernelGGL(pt_v_kernel, grid2, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, partial);
         rc = snf::check_launch("pt_v_kernel");
     }
+    if (rc) return rc;
+    const int64_t total = (int64_t)h * k * dk;
+    int rgrid = (int)((total + 255) / 256);
+    if (rgrid > 2048) rgrid = 2048;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3(rgrid), dim3(256), 0, s, partial, slices, k, h, dk, out);
+    return snf::check_launch("reduce_slices_kernel");
+}
+
+// fp32-CLASS attention for head widths outside the pipelined kernels: scores + softmax in split-bf16 x 3 on the bf16 matrix cores
+// (operands split on the fly), P^T V exact on the f32 matrix cores.  dk % 16 == 0, dk <= 256, k <= 1024; same outputs / workspace as snf_sparse_attn_fwd_f32.
+int snf_sparse_attn_fwd_x3u_f32(const float* q, const float* kp, const float* v, int64_t n, int k, int h, int dk, float scale, float* out,
+                                float* attn, float* lse, void* workspace, size_t workspace_bytes, snf_stream_t stream) {
+    SNF_REQUIRE(q && kp && v && out, "snf_sparse_attn_fwd_x3u_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && k >= 1 && h >= 1 && h <= 65535, "snf_sparse_attn_fwd_x3u_f32: bad shape n=%lld k=%d h=%d", (long long)n, k, h);
+    if (dk < 16 || dk % 16 || dk > 256 || k > 1024 || ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(kp)) & 15)) {
+        snf::set_error("snf_sparse_attn_fwd_x3u_f32: dk=%d k=%d outside the kernel (dk %% 16 == 0, dk <= 256, k <= 1024, 16-byte aligned q / kp)", dk, k);
+        return SNF_EUNSUPPORTED;
+    }
+    const size_t pbytes = ((size_t)h * (size_t)n * (size_t)k * sizeof(float) + 255) & ~(size_t)255;
+    const int slices = generic_slices(n);
+    const size_t need = (attn ? 0 : pbytes) + (size_t)slices * h * (size_t)k * dk * sizeof(float);
+    if (!workspace || workspace_bytes < need) {
+        snf::set_error("snf_sparse_attn_fwd_x3u_f32: workspace %zu < %zu", workspace_bytes, need);
+        return SNF_EWORKSPACE;
+    }
+    float* p = attn ? attn : reinterpret_cast<float*>(workspace);
+    float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (attn ? 0 : pbytes));
+    hipStream_t s = snf::as_stream(stream);
+    const size_t lds = (size_t)32 * (4 * dk + 16) + 256 * sizeof(float);
+    dim3 grid1((unsigned)((n + 31) / 32), (unsigned)h);
+    const int kbw = ((k + 31) / 32 + 3) / 4;
+#define LAUNCH_SX(KBW) hipLaunchKernelGGL((scores_softmax_x3u_kernel<KBW>), grid1, dim3(256), lds, s, q, kp, n, k, h, dk, scale, p, lse)
+    if (kbw <= 1) LAUNCH_SX(1);
+    else if (kbw <= 2) LAUNCH_SX(2);
+    else if (kbw <= 4) LAUNCH_SX(4);
+    else LAUNCH_SX(8);
+#undef LAUNCH_SX
+    int rc = snf::check_launch("scores_softmax_x3u_kernel");
+    if (rc) return rc;
+    const int64_t rows_per_slice = (((n + slices - 1) / slices) + 15) & ~(int64_t)15;
+    rc = launch_pt_v_mfma(p, v, n, k, h, dk, rows_per_slice, slices, partial, s);
     if (rc) return rc;
     const int64_t total = (int64_t)h * k * dk;
     int rgrid = (int)((total + 255) / 256);

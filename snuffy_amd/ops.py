@@ -657,6 +657,36 @@ def sparse_attn_fwd(q, kp, v, h, scale=None, need_attn=False, need_lse=False):
     return out, attn, lse
 
 
+def x3u_attn_supported(k, dk):
+    """Shapes of the unfused fp32-class attention (snf_sparse_attn_fwd_x3u_f32): the head widths outside the pipelined kernels."""
+    return dk % 16 == 0 and 16 <= dk <= 256 and 1 <= k <= 1024
+
+
+def sparse_attn_fwd_x3u(q, kp, v, h, scale=None, need_attn=False, need_lse=False):
+    """fp32-class sparse attention for head widths like 192 (snf_sparse_attn_fwd_x3u_f32: scores + softmax in split-bf16 x 3 on the
+    bf16 matrix cores with the operands split on the fly, P^T V exact on the f32 matrix cores).  q, v [n, d] f32, kp [k, d] f32 -> (out, attn or None, lse or None)."""
+    q = _req(q, torch.float32, "q", 2)
+    kp = _req(kp, torch.float32, "kp", 2)
+    v = _req(v, torch.float32, "v", 2)
+    n, d = q.shape
+    k = kp.shape[0]
+    if d % h:
+        raise ValueError("d_model %d not divisible by h %d" % (d, h))
+    dk = d // h
+    scale = 1.0 / math.sqrt(dk) if scale is None else scale
+    lib = _ffi.load()
+    out = torch.empty(k, d, dtype=torch.float32, device=q.device)
+    attn = torch.empty(h, n, k, dtype=torch.float32, device=q.device) if need_attn else None
+    lse = torch.empty(h, n, dtype=torch.float32, device=q.device) if need_lse else None
+    wsb = lib.snf_sparse_attn_fwd_workspace_bytes(n, k, h, dk, 0)
+    if need_attn:
+        wsb -= ((h * n * k * 4 + 255) // 256) * 256
+    ws = _ws(wsb, q.device)
+    check(lib.snf_sparse_attn_fwd_x3u_f32(_p(q), _p(kp), _p(v), n, k, h, dk, float(scale), _p(out), _p(attn), _p(lse), _p(ws), wsb,
+                                          _stream()), "snf_sparse_attn_fwd_x3u_f32")
+    return out, attn, lse
+
+
 def x3_attn_supported(k, dk):
     """Shapes of the fp32-class (split-bf16 x 3) MFMA attention kernel: 224 (dk = 128) / 256 (dk = 64) keys per launch, up to 8
     key chunks with exact cross-chunk softmax statistics."""

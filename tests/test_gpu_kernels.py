@@ -311,6 +311,30 @@ def test_sparse_attn_exact(n, k, h, dk):
     assert (attn.sum(-1) - 1).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("n,k,h,dk", [(8192, 500, 4, 192), (4001, 900, 4, 96), (333, 1024, 2, 192), (2000, 130, 3, 16), (50, 7, 2, 48),
+                                      (3000, 200, 2, 256), (1, 1, 1, 32)])
+def test_sparse_attn_x3u_fp32_class(n, k, h, dk):
+    """snf_sparse_attn_fwd_x3u_f32 (round 5): scores + softmax in the fp32-class arithmetic of the pipelined kernels -- split-bf16 x 3,
+    fp32 accumulate -- and P^T V exact, for head widths those kernels do not take (dk = 192: reference README.md:661-669).  Same
+    bounds against fp64 as snf_sparse_attn_fwd_x3; deterministic; the same answer with and without the A output."""
+    g = torch.Generator().manual_seed(n * 3 + k + dk)
+    d = h * dk
+    q, kp, v = torch.randn(n, d, generator=g), torch.randn(k, d, generator=g), torch.randn(n, d, generator=g)
+    o_ref, p_ref = attn_ref(q, kp, v, h)
+    assert ops().x3u_attn_supported(k, dk)
+    o, attn, lse = ops().sparse_attn_fwd_x3u(q.to(DEV), kp.to(DEV), v.to(DEV), h, need_attn=True, need_lse=True)
+    assert (attn.cpu().double() - p_ref).abs().max() < 1e-5
+    assert rel_err(o.cpu(), o_ref) < 2e-5
+    s_ref = (q.double().view(n, h, dk).transpose(0, 1) @ kp.double().view(k, h, dk).transpose(0, 1).transpose(1, 2)) / dk ** 0.5
+    assert (lse.cpu().double() - torch.logsumexp(s_ref, dim=-1)).abs().max() < 3e-5
+    assert (attn.sum(-1) - 1).abs().max() < 1e-5
+    o2, a2, _ = ops().sparse_attn_fwd_x3u(q.to(DEV), kp.to(DEV), v.to(DEV), h)
+    assert a2 is None and torch.equal(o2, o)
+    from snuffy_amd import SnuffyHipError
+    with pytest.raises(SnuffyHipError):
+        ops().sparse_attn_fwd_x3u(torch.zeros(8, 2 * 83, device=DEV), torch.zeros(4, 2 * 83, device=DEV), torch.zeros(8, 2 * 83, device=DEV), 2)
+
+
 def bf16r(t):
     return t.to(torch.bfloat16).float()
 

@@ -26,4 +26,16 @@ for n, k, h, dk in shapes:
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 5 * 1e3
         print(f"n={n} k={k} h={h} dk={dk} {'mfma f32' if mode else 'vector ALU'}: {us:.0f} us  {4 * n * k * d / us / 1e6:.1f} TFLOP/s", flush=True)
+    if ops.x3u_attn_supported(k, dk):
+        for _ in range(2):
+            ops.sparse_attn_fwd_x3u(q, kp, v, h)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            ops.sparse_attn_fwd_x3u(q, kp, v, h)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 5 * 1e3
+        print(f"n={n} k={k} h={h} dk={dk} split-bf16 x3 (unfused): {us:.0f} us  {4 * n * k * d / us / 1e6:.1f} TFLOP/s", flush=True)
 _ffi.load().snf_debug_exact_attn_mfma(1)
