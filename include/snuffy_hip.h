@@ -170,6 +170,15 @@ int snf_split3_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16
 int snf_colsum_blocks(int64_t n);
 int snf_colsum_fused(const void* src, int src_dtype, int64_t n, int d, const float* row_weight, int64_t weight_stride,
                      const void* gate_bf16, void* dst_bf16, float* partial, snf_stream_t stream);
+/* The backward of an fp32-class training step (train.py:259 through snuffy.py:187-190, 224-225) needs each gradient matrix as a split
+ * image (operand of the next GEMM and of the weight-gradient contractions) AND its column sums (the bias gradient), the FFN one behind
+ * the ReLU mask: one pass.   v = x[i, c] (f32, row pitch ldx) ; v = 0 where gate_bf16[i, c] <= 0 (nullable; row pitch ldg: the hi
+ * plane of the activation's own split image) ; out[i, c] = out[i, plane + c] = hi(v), out[i, 2 plane + c] = lo(v) (bf16, row pitch
+ * ldo: with plane = k and ldo = 3 k the image of snf_split3_f32; a wider plane lets several matrices share one image, e.g.
+ * [dQ | dV]) ; partial[b, c] (nullable) = sum of v over the rows of workgroup b, [snf_colsum_blocks(m), k] f32, summed by the caller.
+ * k % 8 == 0, k <= 8192, 16-byte aligned rows. */
+int snf_split3_colsum_f32(const float* x, int64_t ldx, int64_t m, int k, const void* gate_bf16, int64_t ldg, void* out_bf16,
+                          int64_t ldo, int64_t plane, float* partial, snf_stream_t stream);
 /* Skinny fp32-class projection for the K selected rows of a bag (key / output projections, snuffy.py:190, 205; the tile GEMMs
  * need thousands of rows): out [r, c] (f32 or bf16: out_dtype) = x [r, k] f32 . w [c, k]^T f32 + bias, every product as split-bf16 x3
  * on the matrix cores with the split done in registers.  r <= 8192, k % 16 == 0, rows 16-byte aligned. */

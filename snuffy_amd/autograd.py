@@ -21,6 +21,8 @@ from . import ops
 # bf16 training: the first encoder layer as one hand-ordered forward / backward chain (EncoderLayer0Bf16Fn) instead of the generic
 # autograd graph; False keeps the generic chain everywhere (tests compare the two)
 FUSED_BF16_TRAINING = True
+# fp32 training: the same for the fp32-class arithmetic (EncoderLayer0X3Fn, round 5)
+FUSED_X3_TRAINING = True
 
 _ACT = {
     "relu": F.relu,
@@ -377,6 +379,191 @@ def fused_layer0_ok(x2, sel, layer, precision):
     return fused_layer0_shape_ok(layer, x2.shape[0], x2.shape[1], sel.numel())
 
 
+def _x3_train_weights(layer):
+    """Operands of EncoderLayer0X3Fn, cached on the layer per parameter version: the LayerNorm affines folded into the following
+    projection in fp32 (LN(x) W^T + b = xhat (W * gamma)^T + (W beta + b)) and the split images [Wh | Wl | Wh] of the folded Q | V and
+    FFN-in weights, of W2 and of W2^T (the operand of the FFN-out input gradient)."""
+    n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
+    lq, lk, lv, lo = layer.self_attn.linears
+    ff = layer.feed_forward
+    plist = [n0.weight, n0.bias, n1.weight, n1.bias, lq.weight, lq.bias, lv.weight, lv.bias, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight]
+    key = tuple(SF.param_key(p) for p in plist)
+    ent = getattr(layer, "_fold3t", None)
+    if ent is not None and ent[0] == key:
+        return ent[1]
+    with torch.no_grad():
+        wqv = torch.cat([lq.weight, lv.weight]).float()
+        w1 = ff.w_1.weight.float()
+        w1f = (w1 * n1.weight).contiguous()
+        out = dict(wqv3=ops.split3_weight(wqv * n0.weight), bqv=(wqv @ n0.bias + torch.cat([lq.bias, lv.bias])).float().contiguous(),
+                   w1f=w1f, w1_3=ops.split3_weight(w1f), b1=(w1 @ n1.bias + ff.w_1.bias).float().contiguous(),
+                   w2_3=ops.split3_weight(ff.w_2.weight), w2t_3=ops.split3_weight(ff.w_2.weight.t().contiguous()))
+    layer._fold3t = (key, out)
+    return out
+
+
+_BMM_OUT = None         # does this torch build take out= together with out_dtype on bmm?
+
+
+def _tn3(a3, b3, p, q, chunks=8):
+    """a^T b over the bag axis for the split images a3 [n, 3 p] = [hi | hi | lo], b3 [n, 3 q] -> [p, q] f32, fp32-class:
+    ah^T bh + ah^T bl + al^T bh on column blocks of the images, in place (lo lo is never computed).  Each product is a batched
+    library GEMM over `chunks` row blocks (see _tn_mm); the 3 x chunks partial results land in ONE buffer and are summed in one
+    pass, in a fixed order."""
+    global _BMM_OUT
+    ah, al = a3[:, p:2 * p], a3[:, 2 * p:]
+    bh, bl = b3[:, q:2 * q], b3[:, 2 * q:]
+    n = a3.shape[0]
+    m = (n // chunks) * chunks
+    if n >= 4096 and m == n and _MM_F32_OUT is not False and _BMM_OUT is not False:
+        buf = torch.empty(3 * chunks, p, q, dtype=torch.float32, device=a3.device)
+        r = n // chunks
+        try:
+            for i, (a, b) in enumerate(((ah, bh), (ah, bl), (al, bh))):
+                torch.bmm(a.view(chunks, r, p).transpose(1, 2), b.view(chunks, r, q), out_dtype=torch.float32,
+                          out=buf[i * chunks:(i + 1) * chunks])
+            _BMM_OUT = True
+            return buf.sum(0)
+        except (TypeError, RuntimeError, NotImplementedError):
+            _BMM_OUT = False
+    out = _tn_mm_f32(ah, bh)
+    out += _tn_mm_f32(ah, bl)
+    out += _tn_mm_f32(al, bh)
+    return out
+
+
+class EncoderLayer0X3Fn(torch.autograd.Function):
+    """EncoderLayer.forward + backward (snuffy.py:126-157) for the FIRST layer of an fp32 training step in fp32-class arithmetic (every
+    large product as split-bf16 x 3 on the matrix cores), as one hand-ordered chain -- the fp32 twin of EncoderLayer0Bf16Fn (round 5).
+
+    The bag x is data there, so nothing upstream of the K selected rows needs d/dx: of the three input-gradient GEMMs of the generic
+    autograd graph only the FFN-out one is left, the LayerNorm backward runs on K rows, and the ~150 elementwise / reduction nodes
+    between the kernels (2 ms of a 7.6 ms step at config B) disappear.  Activations live as split images [hi | hi | lo]: the
+    LayerNorm kernel writes the normalised bag as one (affines folded into the weights, ONE image for both sublayers with the K
+    selected rows re-normalised in place), the FFN-in GEMM writes the hidden layer as one in its epilogue; the weight gradients
+    contract column blocks of those images over the bag axis (three fp32-output library GEMMs per product).  The attention backward
+    is the exact kernel on the materialised P (dropout: the same Philox mask tensor as SparseAttnFn)."""
+
+    @staticmethod
+    def forward(ctx, x2, sel, layer, need_attn, g0, b0, g1, b1, wq, bq, wk, bk, wv, bv, wo, bo, w1, bb1, w2, bb2):
+        n, d = x2.shape
+        mha = layer.self_attn
+        h = mha.h
+        dk = d // h
+        k = sel.numel()
+        eps = layer.sublayer[0].norm.eps
+        fw = _x3_train_weights(layer)
+        xn3 = ops.layernorm_rows_split3(x2, None, None, eps)                          # xhat = LN_0(x) without its affine, [N, 3D]
+        qv = ops.gemm_x3(xn3, fw["wqv3"], fw["bqv"])                                   # [N, 2D] f32 = [Q | V]
+        q, v = qv[:, :d], qv[:, d:]
+        xs, _slot = ops.gather_slot_map(x2, sel)
+        # the K-row projections in plain fp32 (10 us each, as the generic chain runs them under autograd): the gradient that reaches the
+        # attention through LayerNorm 1 of these rows is a small difference of large terms -- a 1e-5 error on x_sel moved it by 4e-4
+        kp = F.linear(xs, wk, bk)
+        if ops.x3_attn_supported(k, dk) and SF.FP32_ATTENTION != "exact":
+            o, p, _ = ops.sparse_attn_fwd_x3(q, v, kp, h, need_attn=True)
+        else:
+            o, p, _ = ops.sparse_attn_fwd(q, kp, v, h, need_attn=True)
+        p_drop = mha.dropout.p if layer.training else 0.0
+        mask = None
+        if p_drop > 0.0:
+            seed, offset = draw_dropout_state()
+            mask = ops.dropout_mask(h, n, k, float(p_drop), seed, offset, x2.device)
+            o = torch.bmm((p * mask).transpose(1, 2), v.reshape(n, h, dk).transpose(0, 1)).transpose(0, 1).reshape(k, d)
+        delta = F.linear(o, wo, bo)
+        x_sel = xs + delta                                                             # snuffy.py:108 at the K rows
+        xhat0_sel = xn3.index_select(0, sel)
+        # LayerNorm_1 sees y = x with the K rows replaced: the image is re-normalised at those rows, every other row is shared
+        xn3.index_copy_(0, sel, ops.split3_rows(ops.layernorm_rows(x_sel, None, None, eps)))
+        hid3 = ops.gemm_x3(xn3, fw["w1_3"], fw["b1"], "relu", split3=True)             # [N, 3F]
+        z = ops.gemm_x3(hid3, fw["w2_3"], bb2.detach().float().contiguous())           # f + b2
+        z.add_(x2)
+        z.index_add_(0, sel, delta)                                                    # snuffy.py:110,154-155
+        ctx.save_for_backward(sel, xhat0_sel, qv, kp, p, mask, o, xs, x_sel, hid3, g0, b0, g1, b1, wq, wv, wo, w1)
+        ctx.xn3, ctx.fw = xn3, fw       # xn3: written in place after the Q | V projection read it (outside the version check)
+        ctx.h, ctx.eps = h, eps
+        attn = (p * mask if mask is not None else p) if need_attn else None
+        if attn is not None:
+            ctx.mark_non_differentiable(attn)
+        return z, attn
+
+    @staticmethod
+    def backward(ctx, dz, _dattn):
+        sel, xhat0_sel, qv, kp, p, mask, o, xs, x_sel, hid3, g0, b0, g1, b1, wq, wv, wo, w1 = ctx.saved_tensors
+        xn3, fw = ctx.xn3, ctx.fw
+        d = xs.shape[1]
+        f = hid3.shape[1] // 3
+        h, eps = ctx.h, ctx.eps
+        dk = d // h
+        dz = dz.float().contiguous()
+        # ---- FFN: z = y + relu(xhat1 W1'^T + b1') W2^T + b2                                                  (snuffy.py:224-225)
+        dz3, db2 = ops.split3_colsum(dz)                                               # operand image + bias gradient, one pass
+        dw2 = _tn3(dz3, hid3, d, f)                                                    # [D, F]
+        dhid = ops.gemm_x3(dz3, fw["w2t_3"])                                           # [N, F] f32, not yet gated
+        del dz3
+        gate = hid3[:, f:2 * f]                                                        # ReLU mask from the hi plane of the output image
+        dhid3, db1f = ops.split3_colsum(dhid, gate=gate)
+        dw1f = _tn3(dhid3, xn3, f, d)                                                  # [F, D], gradient of the FOLDED weight
+        del dhid3
+        # ---- the K selected rows: y[S] = x_sel = xs + o Wo^T + bo; every other row of y is data               (snuffy.py:108,152-155)
+        dyn_s = (dhid.index_select(0, sel) * (gate.index_select(0, sel) > 0)) @ fw["w1f"]      # d loss / d xhat1[S]
+        del dhid
+        dy_s = ops.layernorm_rows_bwd(x_sel, dyn_s, None, eps, residual=dz.index_select(0, sel), want_param_grads=False)[0]
+        dbo = dy_s.sum(0)
+        dwo = dy_s.t() @ o
+        do = dy_s @ wo
+        # ---- attention, exact backward on the materialised P                                                 (snuffy.py:160-168)
+        dq, dkp, dv = ops.sparse_attn_bwd(qv[:, :d], kp, qv[:, d:], p, do.contiguous(), h, mask=mask, scale=1.0 / math.sqrt(dk))
+        # xn3 holds LayerNorm 1's rows at S since the forward re-normalised them in place; the Q | V projection saw LayerNorm 0's:
+        # dW = dqv^T xn3 + dqv[S]^T (xhat0[S] - xhat1[S]), a K-row correction of the big product
+        x1_sel = xn3.index_select(0, sel)
+        corr = (xhat0_sel[:, d:2 * d].float() + xhat0_sel[:, 2 * d:].float()) - (x1_sel[:, d:2 * d].float() + x1_sel[:, 2 * d:].float())
+        dqv3 = torch.empty(xn3.shape[0], 6 * d, dtype=torch.bfloat16, device=dq.device)   # ONE image of [dQ | dV]
+        _, dbq = ops.split3_colsum(dq, out=dqv3, col=0)
+        _, dbv = ops.split3_colsum(dv, out=dqv3, col=d)
+        dwqvf = _tn3(dqv3, xn3, 2 * d, d)                                              # [2D, D] folded
+        del dqv3
+        dwqvf += torch.cat([dq.index_select(0, sel), dv.index_select(0, sel)], dim=1).t() @ corr
+        dwqf, dwvf = dwqvf[:d], dwqvf[d:]
+        dwk = dkp.t() @ xs
+        dbk = dkp.sum(0)
+        # ---- unfold  W' = W * gamma,  b' = W beta + b
+        if d <= 2048:
+            dwq, dgq, dbq0 = ops.unfold_linear(dwqf, wq, g0, b0, dbq)
+            dwv, dgv, dbv0 = ops.unfold_linear(dwvf, wv, g0, b0, dbv)
+            dg0, db0 = dgq + dgv, dbq0 + dbv0
+            dw1, dg1, db1 = ops.unfold_linear(dw1f, w1, g1, b1, db1f)
+        else:
+            dg0 = (dwqf * wq).sum(0) + (dwvf * wv).sum(0)
+            db0 = dbq @ wq + dbv @ wv
+            dg1 = (dw1f * w1).sum(0)
+            db1 = db1f @ w1
+            dwq = dwqf * g0 + torch.outer(dbq, b0)
+            dwv = dwvf * g0 + torch.outer(dbv, b0)
+            dw1 = dw1f * g1 + torch.outer(db1f, b1)
+        return (None, None, None, None, dg0, db0, dg1, db1, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dw1, db1f, dw2, db2)
+
+
+def fused_layer0_x3_ok(x2, sel, layer, precision):
+    """EncoderLayer0X3Fn applies: fp32 with FP32_GEMM = "x3", the bag is data, ReLU FFN, no encoder dropout (attention dropout is
+    handled), shapes in the tile GEMM's domain; everything else keeps the generic autograd chain."""
+    if (not FUSED_X3_TRAINING or precision != "fp32" or SF.FP32_GEMM != "x3" or x2.requires_grad or sel.numel() == 0
+            or torch.is_autocast_enabled() or x2.dtype != torch.float32 or not x2.is_contiguous()):
+        return False
+    mha, ff = layer.self_attn, layer.feed_forward
+    n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
+    n, d = x2.shape
+    f = ff.w_1.weight.shape[0]
+    if ff.activation_name != "relu" or n0.eps != n1.eps or d % mha.h or d % 8 or f % 8 or n < 256:
+        return False
+    if layer.training and (layer.sublayer[0].dropout.p > 0 or layer.sublayer[1].dropout.p > 0 or ff.dropout.p > 0):
+        return False
+    if any(t is None for t in (n0.weight, n0.bias, n1.weight, n1.bias, ff.w_1.bias, ff.w_2.bias) + tuple(l.bias for l in mha.linears)):
+        return False
+    return (ops.gemm_x3_supported(n, 2 * d, d) and ops.gemm_x3_supported(n, f, d) and ops.gemm_x3_supported(n, d, f)
+            and all(p.requires_grad for p in layer.parameters()))
+
+
 class CriticFn(torch.autograd.Function):
     """scores = x w^T + b (FCLayer, snuffy.py:39-41) on the one-pass critic kernel; with `layer` (bf16 training) the same pass
     leaves the normalised bf16 copy of the bag for the first encoder layer, as in inference.  Backward: dW = dS^T x (the loss
@@ -421,6 +608,15 @@ def encoder_layer_train(x2, sel, layer, need_attn, precision):
         z, attn = EncoderLayer0Bf16Fn.apply(x2, sel, layer, bool(need_attn), n0.weight, n0.bias, n1.weight, n1.bias, lq.weight,
                                             lq.bias, lk.weight, lk.bias, lv.weight, lv.bias, lo.weight, lo.bias,
                                             ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias)
+        return Parts(z), (attn.unsqueeze(0) if attn is not None else None)
+    if fused_layer0_x3_ok(x2, sel, layer, precision):
+        layer._xhat_offer = None
+        n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
+        lq, lk, lv, lo = layer.self_attn.linears
+        ff = layer.feed_forward
+        z, attn = EncoderLayer0X3Fn.apply(x2, sel, layer, bool(need_attn), n0.weight, n0.bias, n1.weight, n1.bias, lq.weight,
+                                          lq.bias, lk.weight, lk.bias, lv.weight, lv.bias, lo.weight, lo.bias,
+                                          ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias)
         return Parts(z), (attn.unsqueeze(0) if attn is not None else None)
     layer._xhat_offer = None        # chain declined: a normalised copy the critic may have left must not outlive this bag
     # precision "bf16": the dense projections run under torch.autocast (bf16 operands, fp32 accumulate, fp32 master

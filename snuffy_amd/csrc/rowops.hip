@@ -566,6 +566,66 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
     }
 }
 
+// split3_kernel + the ReLU gate + the column sums of the gated values in one pass (see snf_split3_colsum_f32); row / column ownership as
+// colsum_fused_kernel: a workgroup owns a contiguous row range, thread t columns 8 t .. 8 t + 7 (+ 2048 j).
+template <int NCH>
+__global__ __launch_bounds__(256) void split3_colsum_kernel(const float* __restrict__ x, int64_t ldx, int64_t m, int k,
+                                                            const unsigned short* __restrict__ gate, int64_t ldg,
+                                                            unsigned short* __restrict__ out, int64_t ldo, int64_t plane,
+                                                            float* __restrict__ partial, int rows_per_block) {
+    float acc[NCH][8];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > m) r1 = m;
+    for (int64_t row = r0; row < r1; ++row) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = (j * 256 + threadIdx.x) * 8;
+            if (c < k) {
+                const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c);
+                const float4 b = *reinterpret_cast<const float4*>(x + row * ldx + c + 4);
+                float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                if (gate) {
+                    const uint4 g = *reinterpret_cast<const uint4*>(gate + row * ldg + c);
+                    const unsigned g4[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (!(__uint_as_float(g4[e] << 16) > 0.f)) v[2 * e] = 0.f;
+                        if (!(__uint_as_float(g4[e] & 0xffff0000u) > 0.f)) v[2 * e + 1] = 0.f;
+                    }
+                }
+                unsigned hi[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hi[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                    lo[e] = pack_bf16x2(v[2 * e] - __uint_as_float(hi[e] << 16), v[2 * e + 1] - __uint_as_float(hi[e] & 0xffff0000u));
+                }
+                unsigned short* o = out + row * ldo + c;
+                const uint4 h4 = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                *reinterpret_cast<uint4*>(o) = h4;
+                *reinterpret_cast<uint4*>(o + plane) = h4;
+                *reinterpret_cast<uint4*>(o + 2 * plane) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[j][e] += v[e];
+            }
+        }
+    }
+    if (!partial) return;
+    float* po = partial + (int64_t)blockIdx.x * k;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = (j * 256 + threadIdx.x) * 8;
+        if (c < k) {
+            *reinterpret_cast<float4*>(po + c) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+            *reinterpret_cast<float4*>(po + c + 4) = make_float4(acc[j][4], acc[j][5], acc[j][6], acc[j][7]);
+        }
+    }
+}
+
 // x [m, k] f32 (row pitch ldx) -> out [m, 2 k] bf16, interleaved: columns 32 c .. 32 c + 31 as [hi(32) | lo(32)] (k % 32 == 0)
 __global__ __launch_bounds__(256) void split_hl_kernel(const float* __restrict__ x, int64_t ldx, int64_t m, int k,
                                                        unsigned short* __restrict__ out) {
@@ -1366,6 +1426,29 @@ int snf_split3_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16
     hipLaunchKernelGGL(split3_kernel, dim3((int)blocks), dim3(256), 0, snf::as_stream(stream), x, ldx, m, k,
                        reinterpret_cast<unsigned short*>(out_bf16));
     return snf::check_launch("split3_kernel");
+}
+
+int snf_split3_colsum_f32(const float* x, int64_t ldx, int64_t m, int k, const void* gate_bf16, int64_t ldg, void* out_bf16,
+                          int64_t ldo, int64_t plane, float* partial, snf_stream_t stream) {
+    SNF_REQUIRE(x && out_bf16, "snf_split3_colsum_f32: null pointer");
+    SNF_REQUIRE(m >= 1 && k >= 8 && k % 8 == 0 && k <= 8192 && ldx >= k && ldx % 4 == 0 && plane >= k && plane % 8 == 0 &&
+                    ldo >= 2 * plane + k && ldo % 8 == 0 && (!gate_bf16 || (ldg >= k && ldg % 8 == 0)),
+                "snf_split3_colsum_f32: bad shape m=%lld k=%d ldx=%lld ldg=%lld ldo=%lld plane=%lld (k %% 8 == 0, k <= 8192, 16-byte rows)",
+                (long long)m, k, (long long)ldx, (long long)ldg, (long long)ldo, (long long)plane);
+    SNF_REQUIRE(aligned16(x) && aligned16(out_bf16) && (!gate_bf16 || aligned16(gate_bf16)) && (!partial || aligned16(partial)),
+                "snf_split3_colsum_f32: buffers must be 16-byte aligned");
+    const int blocks = snf_colsum_blocks(m);
+    const int rpb = (int)((m + blocks - 1) / blocks);
+    const int nch = (k + 2047) / 2048;
+    hipStream_t s = snf::as_stream(stream);
+    const unsigned short* g = reinterpret_cast<const unsigned short*>(gate_bf16);
+    unsigned short* o = reinterpret_cast<unsigned short*>(out_bf16);
+    switch (nch) {
+        case 1: hipLaunchKernelGGL(split3_colsum_kernel<1>, dim3(blocks), dim3(256), 0, s, x, ldx, m, k, g, ldg, o, ldo, plane, partial, rpb); break;
+        case 2: hipLaunchKernelGGL(split3_colsum_kernel<2>, dim3(blocks), dim3(256), 0, s, x, ldx, m, k, g, ldg, o, ldo, plane, partial, rpb); break;
+        default: hipLaunchKernelGGL(split3_colsum_kernel<4>, dim3(blocks), dim3(256), 0, s, x, ldx, m, k, g, ldg, o, ldo, plane, partial, rpb); break;
+    }
+    return snf::check_launch("split3_colsum_kernel");
 }
 
 int snf_fold_blocks(int r) {

@@ -548,6 +548,7 @@ def invalidate_folded(layer):
     layer._fold = None
     layer._fold3 = None
     layer._fold3f = None
+    layer._fold3t = None
     layer._fold_pad = None
     layer._xhat_offer = None
     layer._xn3_offer = None

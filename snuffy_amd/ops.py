@@ -1298,6 +1298,39 @@ def split3_rows(x):
     return out
 
 
+def split3_colsum(x, gate=None, out=None, col=0, want_colsum=True):
+    """One pass over a gradient matrix x [m, k] f32 (row-strided views allowed): its split image [hi | hi | lo] (operand of the next
+    fp32-class GEMM and of the weight-gradient contractions) and its column sums (the bias gradient); gate [m, k] bf16 (row-strided:
+    the hi plane of the activation's own split image) zeroes the elements behind a closed ReLU first.  out / col: write into columns
+    col .. col + k of each plane of a wider image out [m, 3 w] ([dQ | dV] share one).  Returns (image, colsum [k] or None).  See
+    snf_split3_colsum_f32."""
+    if x.dtype != torch.float32:
+        raise TypeError("split3_colsum: x must be float32")
+    x = _rows16(x, "x")
+    m, k = x.shape
+    if k % 8 or k > 8192:
+        raise ValueError("split3_colsum: k=%d must be a multiple of 8 and <= 8192" % k)
+    ldg = 0
+    if gate is not None:
+        if gate.dtype != torch.bfloat16 or tuple(gate.shape) != (m, k):
+            raise ValueError("split3_colsum: gate must be bfloat16 of the shape of x")
+        gate = _rows16(gate, "gate")
+        ldg = gate.stride(0)
+    if out is None:
+        out = torch.empty(m, 3 * k, dtype=torch.bfloat16, device=x.device)
+        col = 0
+    elif (out.dtype != torch.bfloat16 or out.dim() != 2 or not out.is_contiguous() or out.shape[0] != m or out.shape[1] % 3
+          or col % 8 or col + k > out.shape[1] // 3):
+        raise ValueError("split3_colsum: bad out image")
+    plane = out.shape[1] // 3
+    lib = _ffi.load()
+    part = torch.empty(lib.snf_colsum_blocks(m), k, dtype=torch.float32, device=x.device) if want_colsum else None
+    dst = out if col == 0 else out[:, col:]
+    check(lib.snf_split3_colsum_f32(_p(x), x.stride(0), m, k, _p(gate), ldg, _p(dst), out.stride(0), plane, _p(part), _stream()),
+          "snf_split3_colsum_f32")
+    return out, (part.sum(0) if part is not None else None)
+
+
 def linear_rows_x3_supported(r, c, k):
     return 1 <= r <= 8192 and c >= 1 and k >= 16 and k % 16 == 0
 

@@ -278,6 +278,58 @@ def test_fused_bf16_layer0_training_matches_generic_and_fp32(n, d, h, lam, monke
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,d,h,lam,share", [(700, 256, 4, 50, 0.0), (3000, 384, 6, 200, 0.0), (2048, 768, 6, 200, 0.0), (4100, 384, 4, 300, 0.5)])
+def test_fused_x3_layer0_training_matches_the_generic_fp32_chain(n, d, h, lam, share, monkeypatch):
+    """EncoderLayer0X3Fn (round 5: hand-ordered forward / backward of the first layer in fp32-class arithmetic) against the generic
+    autograd chain of the same precision (LinearX3Fn + LayerNormRowsFn + SparseAttnFn): logits and every parameter gradient, eval
+    mode and train mode (all draw the same Philox mask tensor for the attention dropout of reference snuffy.py:166-167), and against
+    the generic chain with fp32 library GEMMs (FP32_GEMM = "library")."""
+    from snuffy_amd import autograd as SA
+    from snuffy_amd import functional as SF
+    torch.manual_seed(n)
+    ref = build_amd_milnet(d, h, "relu", lam, share, 1)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.add_(0.3 * torch.randn(d))
+                m.bias.add_(0.2 * torch.randn(d))
+            if isinstance(m, torch.nn.Linear) and m.bias is not None:
+                m.bias.add_(0.1 * torch.randn_like(m.bias))
+    sd = ref.state_dict()
+    x = torch.randn(1, n, d, device=DEV)
+    for train_mode in (False, True):
+        grads, outs = {}, {}
+        for tag, fused, gemm in (("library", False, "library"), ("generic", False, "x3"), ("fused", True, "x3")):
+            monkeypatch.setattr(SA, "FUSED_X3_TRAINING", fused)
+            monkeypatch.setattr(SF, "FP32_GEMM", gemm)
+            net = build_amd_milnet(d, h, "relu", lam, share, 1)
+            net.load_state_dict(sd, strict=True)
+            net = net.to(DEV).configure(precision="fp32", return_attention=False)
+            net.train(train_mode)
+            torch.manual_seed(11)
+            np.random.seed(5)
+            ins, logits, _ = net(x)
+            (logits.sum() * 3 + ins.max()).backward()
+            grads[tag] = {k: p.grad.float().clone() for k, p in net.named_parameters()}
+            outs[tag] = logits.detach().clone()
+        # A ReLU gate whose pre-activation is within rounding of zero may open in one arithmetic and not in the other (0 - 3 of the
+        # N x F hidden elements here): one such element moves the FFN-in gradients by ~1e-4 of their norm at these bag sizes.
+        # Such an element in one of the K selected rows also moves everything upstream of LayerNorm 1 of those rows: ~3e-5 of the
+        # V / output projection gradients and, the query / key gradients being 100 - 1000x smaller in norm, ~2e-3 of those -- in
+        # either chain (measured: fused 2e-3 / generic 7e-6 at (2048, 768), fused 3e-6 / generic 5e-4 at (4100, 384)).
+        gate_keys = ("feed_forward.w_1.weight", "feed_forward.w_1.bias", "sublayer.1.norm.weight", "sublayer.1.norm.bias")
+        small_keys = ("linears.0.weight", "linears.0.bias", "linears.1.weight", "sublayer.0.norm.weight")
+        for other, bound_out, bound in (("library", 5e-5, 2e-4), ("generic", 5e-5, 5e-4 if train_mode else 2e-4)):
+            assert (outs["fused"] - outs[other]).abs().max().item() <= bound_out * max(1.0, outs[other].abs().max().item())
+            for k in grads["fused"]:
+                if k.endswith("self_attn.linears.1.bias"):
+                    continue                           # mathematically zero gradient
+                a, b = grads["fused"][k].double(), grads[other][k].double()
+                rel = float((a - b).norm() / b.norm().clamp_min(1e-12))
+                assert rel < (5e-3 if k.endswith(small_keys) else 3e-3 if k.endswith(gate_keys) else bound), (train_mode, k, other, rel)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,d", [(1000, 768), (4097, 3072), (33, 8), (700, 1536), (5000, 4096)])
 def test_colsum_fused_kernel(n, d):
     """snf_colsum_fused: plain / weighted / gated column sums, the bf16 copy, the in-place form (vs torch in fp64)."""
@@ -302,6 +354,33 @@ def test_colsum_fused_kernel(n, d):
     y = xb.clone()
     s2, c2 = ops.colsum_fused(y, gate=gate, inplace=True)
     assert c2 is y and torch.equal(y, want) and torch.equal(s2, s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k", [(1000, 768), (4097, 3072), (33, 8), (700, 1536), (300, 8192)])
+def test_split3_colsum_kernel(m, k):
+    """snf_split3_colsum_f32 (round 5): split image + ReLU gate + column sums of a gradient matrix in one pass -- bit-exact against
+    snf_split3_f32 of the gated matrix; sums against fp64; strided input / gate views; two matrices sharing one wider image."""
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(m + k)
+    xw = torch.randn(m, k + 8, generator=g).to(DEV)
+    x = xw[:, 8:] if k % 4 == 0 and (8 * 4) % 16 == 0 else xw[:, :k]
+    act = torch.relu(torch.randn(m, k, generator=g)).to(DEV)
+    act3 = ops.split3_rows(act)
+    gate = act3[:, k:2 * k]
+    img, cs = ops.split3_colsum(x)
+    assert torch.equal(img, ops.split3_rows(x.contiguous()))
+    assert (cs.double().cpu() - x.double().sum(0).cpu()).abs().max() <= 1e-5 * max(1.0, float(x.abs().sum(0).max()))
+    xg = x * (gate > 0)
+    img, cs = ops.split3_colsum(x, gate=gate)
+    assert torch.equal(img, ops.split3_rows(xg.contiguous()))
+    assert (cs.double().cpu() - xg.double().sum(0).cpu()).abs().max() <= 1e-5 * max(1.0, float(xg.abs().sum(0).max()))
+    y = torch.randn(m, k, generator=g).to(DEV)
+    wide = torch.full((m, 6 * k), 7.0, dtype=torch.bfloat16, device=DEV)
+    _, none = ops.split3_colsum(x, out=wide, col=0, want_colsum=False)
+    assert none is None
+    ops.split3_colsum(y, out=wide, col=k)
+    assert torch.equal(wide, ops.split3_rows(torch.cat([x, y], dim=1)))
 
 
 @pytest.mark.gpu
