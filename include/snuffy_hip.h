@@ -242,10 +242,12 @@ int snf_sparse_attn_fwd_f32(const float* q, const float* kp, const float* v, int
 /* The same attention with the scores in the fp32-CLASS arithmetic of snf_sparse_attn_fwd_x3 (every product as three bf16 MFMAs of the
  * operands' hi / lo halves, fp32 accumulate / softmax) for head widths the pipelined kernels do not take: dk % 16 == 0, dk <= 256 (the
  * README recipe D = 768 / h = 4 of reference README.md:661-669: dk = 192), k <= 1024; other shapes SNF_EUNSUPPORTED.  P^T V is exact
- * fp32 on the f32 matrix cores.  Two launches + the fixed-order reduction like snf_sparse_attn_fwd_f32 (same arguments, same
- * workspace: snf_sparse_attn_fwd_workspace_bytes(.., 0)), operands split on the fly; P is materialised (`attn`, or in the workspace). */
-int snf_sparse_attn_fwd_x3u_f32(const float* q, const float* kp, const float* v, int64_t n, int k, int h, int dk, float scale,
-                                float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes, snf_stream_t stream);
+ * fp32 on the f32 matrix cores.  Two launches + the fixed-order reduction like snf_sparse_attn_fwd_f32 (same workspace:
+ * snf_sparse_attn_fwd_workspace_bytes(.., 0)), operands split on the fly; P is materialised (`attn`, or in the workspace).  q / v take
+ * row pitches ldq / ldv (elements, >= h dk, ldq % 4 == 0): the halves of a fused [Q | V] projection output are used in place. */
+int snf_sparse_attn_fwd_x3u_f32(const float* q, int64_t ldq, const float* kp, const float* v, int64_t ldv, int64_t n, int k, int h, int dk,
+                                float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
+                                snf_stream_t stream);
 int snf_sparse_attn_fwd_mfma(const void* q, int64_t ldq, const void* v, int64_t ldv, int qv_dtype, const void* kp,
                              int kp_dtype, int64_t n, int k, int h, int dk, float scale, float* out, float* attn,
                              float* lse, void* workspace, size_t workspace_bytes, snf_stream_t stream);

@@ -424,8 +424,10 @@ def _tn3(a3, b3, p, q, chunks=8):
                           out=buf[i * chunks:(i + 1) * chunks])
             _BMM_OUT = True
             return buf.sum(0)
-        except (TypeError, RuntimeError, NotImplementedError):
-            _BMM_OUT = False
+        except (TypeError, RuntimeError, NotImplementedError) as exc:
+            if "out of memory" in str(exc).lower():
+                raise
+            _BMM_OUT = False       # this torch build has no bmm(out_dtype=, out=): three separate products below
     out = _tn_mm_f32(ah, bh)
     out += _tn_mm_f32(ah, bl)
     out += _tn_mm_f32(al, bh)

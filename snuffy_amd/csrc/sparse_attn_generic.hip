@@ -280,13 +280,12 @@ __global__ __launch_bounds__(256, KBW <= 4 ? 3 : 2) void scores_softmax_mfma_ker
 template <int CT>    // 32-column blocks per wave tile
 __global__ __launch_bounds__(256, 2) void pt_v_mfma_kernel(const float* __restrict__ p /*[h,n,k]*/, const float* __restrict__ v, int64_t n,
                                                            int k, int h, int dk, int64_t rows_per_slice, int slices,
-                                                           float* __restrict__ partial /*[slices,h,k,dk]*/) {
+                                                           float* __restrict__ partial /*[slices,h,k,dk]*/, int ldv /* row pitch of v */) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, hf = lane >> 5;
     const int a = blockIdx.z % h;
     const int slice = 4 * (blockIdx.z / h) + w;          // one wave = one slice of the rows
     if (slice >= slices) return;
-    const int d_model = h * dk;
     const int64_t r_begin = (int64_t)slice * rows_per_slice;
     int64_t r_end = r_begin + rows_per_slice;
     if (r_end > n) r_end = n;
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void pt_v_mfma_kernel(const float* __restri
         col[c] = 32 * (cb0 + c) + j;
         cok[c] = col[c] < dk;
         if (!cok[c]) col[c] = dk - 1;
-        offb[c] = hf * d_model + col[c];
+        offb[c] = hf * ldv + col[c];
     }
     mf32x16 acc[2][CT];
 #pragma unroll
@@ -322,14 +321,14 @@ __global__ __launch_bounds__(256, 2) void pt_v_mfma_kernel(const float* __restri
     int64_t r = r_begin;
     for (; r + 2 * U <= r_end; r += 2 * U) {             // full batches: wave-uniform row pointers, no row predicate
         const float* pr = pa + r * k;
-        const float* vr = va + r * d_model;
+        const float* vr = va + r * ldv;
         float av[U][2], bv[U][CT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) av[u][t] = pr[(int64_t)(2 * u) * k + offa[t]];
 #pragma unroll
-            for (int c = 0; c < CT; ++c) bv[u][c] = vr[(int64_t)(2 * u) * d_model + offb[c]];
+            for (int c = 0; c < CT; ++c) bv[u][c] = vr[(int64_t)(2 * u) * ldv + offb[c]];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -357,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void pt_v_mfma_kernel(const float* __restri
         }
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-            const float x = va[row * d_model + col[c]];
+            const float x = va[row * ldv + col[c]];
             bv[c] = (rv && cok[c]) ? x : 0.f;
         }
 #pragma unroll
@@ -404,7 +403,7 @@ __device__ __forceinline__ void x3u_split8(const mf32x8 x, xbf16x8& hi, xbf16x8&
 template <int KBW>
 __global__ __launch_bounds__(256, KBW <= 4 ? 3 : 2) void scores_softmax_x3u_kernel(const float* __restrict__ q, const float* __restrict__ kp,
                                                                                    int64_t n, int k, int h, int dk, float scale,
-                                                                                   float* __restrict__ p_out, float* __restrict__ lse) {
+                                                                                   float* __restrict__ p_out, float* __restrict__ lse, int64_t ldq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     const int pitch = 4 * dk + 16;             // bytes per row: hi plane (2 dk) | lo plane (2 dk) | pad; 4 banks apart row to row
     float* lst = reinterpret_cast<float*>(ldsb + 32 * pitch);     // [2][4][32]
@@ -418,7 +417,7 @@ __global__ __launch_bounds__(256, KBW <= 4 ? 3 : 2) void scores_softmax_x3u_kern
         const int r = e / dk4, c4 = e - r * dk4;
         const int64_t row = row0 + r;
         mf32x4 val = {0.f, 0.f, 0.f, 0.f};
-        if (row < n) val = *reinterpret_cast<const mf32x4*>(q + row * d_model + a * dk + 4 * c4);
+        if (row < n) val = *reinterpret_cast<const mf32x4*>(q + row * ldq + a * dk + 4 * c4);
         const xbf16x4 hi = __builtin_convertvector(val, xbf16x4);
         const xbf16x4 lo = __builtin_convertvector(val - __builtin_convertvector(hi, mf32x4), xbf16x4);
         *reinterpret_cast<xu32x2*>(ldsb + r * pitch + 8 * c4) = __builtin_bit_cast(xu32x2, hi);
@@ -1004,15 +1003,16 @@ __global__ __launch_bounds__(256) void ragged_attn_kernel(const float* __restric
 
 // P^T V on the f32 MFMA: one wave per (64 keys, 32 CT columns, row slice)
 int launch_pt_v_mfma(const float* p, const float* v, int64_t n, int k, int h, int dk, int64_t rows_per_slice, int slices, float* partial,
-                     hipStream_t s) {
+                     hipStream_t s, int ldv = 0) {
+    if (ldv == 0) ldv = h * dk;
     const int ncb = (dk + 31) / 32;
     const int ct = ncb % 3 == 0 ? 3 : (ncb % 4 == 0 || ncb > 4) ? 4 : ncb;          // 96 / 192 -> 3, 128 / 256 -> 4, 64 -> 2, 32 -> 1
     dim3 grid((unsigned)(((k + 31) / 32 + 1) / 2), (unsigned)((ncb + ct - 1) / ct), (unsigned)(((slices + 3) / 4) * h));
     switch (ct) {
-        case 1: hipLaunchKernelGGL((pt_v_mfma_kernel<1>), grid, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, slices, partial); break;
-        case 2: hipLaunchKernelGGL((pt_v_mfma_kernel<2>), grid, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, slices, partial); break;
-        case 3: hipLaunchKernelGGL((pt_v_mfma_kernel<3>), grid, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, slices, partial); break;
-        default: hipLaunchKernelGGL((pt_v_mfma_kernel<4>), grid, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, slices, partial); break;
+        case 1: hipLaunchKernelGGL((pt_v_mfma_kernel<1>), grid, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, slices, partial, ldv); break;
+        case 2: hipLaunchKernelGGL((pt_v_mfma_kernel<2>), grid, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, slices, partial, ldv); break;
+        case 3: hipLaunchKernelGGL((pt_v_mfma_kernel<3>), grid, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, slices, partial, ldv); break;
+        default: hipLaunchKernelGGL((pt_v_mfma_kernel<4>), grid, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, slices, partial, ldv); break;
     }
     return snf::check_launch("pt_v_mfma_kernel");
 }
@@ -1221,10 +1221,13 @@ int snf_sparse_attn_fwd_f32(const float* q, const float* kp, const float* v, int
 
 // fp32-CLASS attention for head widths outside the pipelined kernels: scores + softmax in split-bf16 x 3 on the bf16 matrix cores
 // (operands split on the fly), P^T V exact on the f32 matrix cores.  dk % 16 == 0, dk <= 256, k <= 1024; same outputs / workspace as snf_sparse_attn_fwd_f32.
-int snf_sparse_attn_fwd_x3u_f32(const float* q, const float* kp, const float* v, int64_t n, int k, int h, int dk, float scale, float* out,
-                                float* attn, float* lse, void* workspace, size_t workspace_bytes, snf_stream_t stream) {
+int snf_sparse_attn_fwd_x3u_f32(const float* q, int64_t ldq, const float* kp, const float* v, int64_t ldv, int64_t n, int k, int h, int dk,
+                                float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
+                                snf_stream_t stream) {
     SNF_REQUIRE(q && kp && v && out, "snf_sparse_attn_fwd_x3u_f32: null pointer");
     SNF_REQUIRE(n >= 1 && k >= 1 && h >= 1 && h <= 65535, "snf_sparse_attn_fwd_x3u_f32: bad shape n=%lld k=%d h=%d", (long long)n, k, h);
+    SNF_REQUIRE(ldq >= (int64_t)h * dk && ldv >= (int64_t)h * dk && ldq % 4 == 0 && ldv < (1 << 24),
+                "snf_sparse_attn_fwd_x3u_f32: bad row pitch ldq=%lld ldv=%lld (>= h dk, ldq %% 4 == 0)", (long long)ldq, (long long)ldv);
     if (dk < 16 || dk % 16 || dk > 256 || k > 1024 || ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(kp)) & 15)) {
         snf::set_error("snf_sparse_attn_fwd_x3u_f32: dk=%d k=%d outside the kernel (dk %% 16 == 0, dk <= 256, k <= 1024, 16-byte aligned q / kp)", dk, k);
         return SNF_EUNSUPPORTED;
@@ -1242,7 +1245,7 @@ int snf_sparse_attn_fwd_x3u_f32(const float* q, const float* kp, const float* v,
     const size_t lds = (size_t)32 * (4 * dk + 16) + 256 * sizeof(float);
     dim3 grid1((unsigned)((n + 31) / 32), (unsigned)h);
     const int kbw = ((k + 31) / 32 + 3) / 4;
-#define LAUNCH_SX(KBW) hipLaunchKernelGGL((scores_softmax_x3u_kernel<KBW>), grid1, dim3(256), lds, s, q, kp, n, k, h, dk, scale, p, lse)
+#define LAUNCH_SX(KBW) hipLaunchKernelGGL((scores_softmax_x3u_kernel<KBW>), grid1, dim3(256), lds, s, q, kp, n, k, h, dk, scale, p, lse, ldq)
     if (kbw <= 1) LAUNCH_SX(1);
     else if (kbw <= 2) LAUNCH_SX(2);
     else if (kbw <= 4) LAUNCH_SX(4);
@@ -1251,7 +1254,7 @@ int snf_sparse_attn_fwd_x3u_f32(const float* q, const float* kp, const float* v,
     int rc = snf::check_launch("scores_softmax_x3u_kernel");
     if (rc) return rc;
     const int64_t rows_per_slice = (((n + slices - 1) / slices) + 15) & ~(int64_t)15;
-    rc = launch_pt_v_mfma(p, v, n, k, h, dk, rows_per_slice, slices, partial, s);
+    rc = launch_pt_v_mfma(p, v, n, k, h, dk, rows_per_slice, slices, partial, s, (int)ldv);
     if (rc) return rc;
     const int64_t total = (int64_t)h * k * dk;
     int rgrid = (int)((total + 255) / 256);

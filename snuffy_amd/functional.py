@@ -667,7 +667,7 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
             o, attn, _ = ops.sparse_attn_fwd_x3(q, v, kp, h, need_attn=need_attn)    # snuffy.py:160-168
         elif FP32_ATTENTION == "x3" and ops.x3u_attn_supported(k, d // h):
             # head widths no pipelined kernel takes (dk = 192: the README recipe D = 768 / h = 4): the unfused fp32-class pair
-            o, attn, _ = ops.sparse_attn_fwd_x3u(q.contiguous(), kp, v.contiguous(), h, need_attn=need_attn)
+            o, attn, _ = ops.sparse_attn_fwd_x3u(q, kp, v, h, need_attn=need_attn)      # q, v: halves of the fused projection, in place
         else:
             o, attn, _ = ops.sparse_attn_fwd(q.contiguous(), kp, v.contiguous(), h, need_attn=need_attn)
         del q, v, qv

@@ -664,10 +664,13 @@ def x3u_attn_supported(k, dk):
 
 def sparse_attn_fwd_x3u(q, kp, v, h, scale=None, need_attn=False, need_lse=False):
     """fp32-class sparse attention for head widths like 192 (snf_sparse_attn_fwd_x3u_f32: scores + softmax in split-bf16 x 3 on the
-    bf16 matrix cores with the operands split on the fly, P^T V exact on the f32 matrix cores).  q, v [n, d] f32, kp [k, d] f32 -> (out, attn or None, lse or None)."""
-    q = _req(q, torch.float32, "q", 2)
+    bf16 matrix cores with the operands split on the fly, P^T V exact on the f32 matrix cores).  q, v [n, d] f32 (row-strided views
+    allowed: the halves of a fused [Q | V] projection), kp [k, d] f32 -> (out, attn or None, lse or None)."""
+    if q.dtype != torch.float32 or v.dtype != torch.float32:
+        raise TypeError("sparse_attn_fwd_x3u: q and v must be float32")
+    q = _rows16(q, "q")
+    v = _rows16(v, "v")
     kp = _req(kp, torch.float32, "kp", 2)
-    v = _req(v, torch.float32, "v", 2)
     n, d = q.shape
     k = kp.shape[0]
     if d % h:
@@ -682,8 +685,8 @@ def sparse_attn_fwd_x3u(q, kp, v, h, scale=None, need_attn=False, need_lse=False
     if need_attn:
         wsb -= ((h * n * k * 4 + 255) // 256) * 256
     ws = _ws(wsb, q.device)
-    check(lib.snf_sparse_attn_fwd_x3u_f32(_p(q), _p(kp), _p(v), n, k, h, dk, float(scale), _p(out), _p(attn), _p(lse), _p(ws), wsb,
-                                          _stream()), "snf_sparse_attn_fwd_x3u_f32")
+    check(lib.snf_sparse_attn_fwd_x3u_f32(_p(q), q.stride(0), _p(kp), _p(v), v.stride(0), n, k, h, dk, float(scale), _p(out), _p(attn),
+                                          _p(lse), _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_x3u_f32")
     return out, attn, lse
 
 

@@ -330,6 +330,10 @@ def test_sparse_attn_x3u_fp32_class(n, k, h, dk):
     assert (attn.sum(-1) - 1).abs().max() < 1e-5
     o2, a2, _ = ops().sparse_attn_fwd_x3u(q.to(DEV), kp.to(DEV), v.to(DEV), h)
     assert a2 is None and torch.equal(o2, o)
+    if d % 4 == 0:                       # the halves of a fused [Q | V] projection output, used in place (row pitch 2 d)
+        qv = torch.cat([q, v], dim=1).to(DEV)
+        o3, _, _ = ops().sparse_attn_fwd_x3u(qv[:, :d], kp.to(DEV), qv[:, d:], h)
+        assert torch.equal(o3, o)
     from snuffy_amd import SnuffyHipError
     with pytest.raises(SnuffyHipError):
         ops().sparse_attn_fwd_x3u(torch.zeros(8, 2 * 83, device=DEV), torch.zeros(4, 2 * 83, device=DEV), torch.zeros(8, 2 * 83, device=DEV), 2)
