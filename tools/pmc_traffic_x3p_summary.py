@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""usage: python tools/pmc_traffic_x3p_summary.py <dir with fetch/ and write/> cfgB|cfgC [out.json]
+"""usage: python tools/pmc_traffic_x3p_summary.py <dir with fetch/ and write/> cfgB|cfgC|cfgA [out.json]
 Bytes per CALL of snf_sparse_attn_fwd_x3_hl (all its launches: Kp split, statistics / main passes, reductions), with the unit
 corrections of MI355X_MICROARCH.md: both counters are calibrated on a streaming read / write of known size in the same run
 (FETCH_SIZE reports half the bytes of a wide coalesced read on gfx950: the calibration finds the factor 2)."""
@@ -11,7 +11,7 @@ import sys
 from collections import defaultdict
 
 d, wl = sys.argv[1], sys.argv[2]
-N, D, h, K = {"cfgB": (32768, 768, 6, 200), "cfgC": (100000, 768, 6, 512)}[wl]
+N, D, h, K = {"cfgB": (32768, 768, 6, 200), "cfgC": (100000, 768, 6, 512), "cfgA": (8192, 384, 6, 200)}[wl]
 KNOWN = 32768 * 768 * 4
 REPS = 8
 
