@@ -282,6 +282,13 @@ size_t snf_sparse_attn_fwd_x3_workspace_bytes(int64_t n, int k, int h, int dk);
 int snf_sparse_attn_fwd_x3(const float* q, int64_t ldq, const float* v, int64_t ldv, const float* kp, int64_t n, int k, int h,
                            int dk, float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
                            snf_stream_t stream);
+/* Training forward (snuffy.py:166-167: nn.Dropout on p_attn): the same launch with the Philox keep-mask of snf_dropout_mask_f32 -- the
+ * same (seed, offset) give the same mask, bit for bit -- applied to P in registers: out = (P o M)^T V, while `attn` receives the
+ * UNDROPPED probabilities P (what snf_sparse_attn_bwd_f32 wants next to the mask tensor).  One key chunk only (k <= 224 at dk = 128,
+ * <= 256 at dk = 64; more keys: SNF_EUNSUPPORTED, the caller multiplies and contracts itself); dropout_p == 0 is snf_sparse_attn_fwd_x3. */
+int snf_sparse_attn_fwd_x3_dropout(const float* q, int64_t ldq, const float* v, int64_t ldv, const float* kp, int64_t n, int k, int h,
+                                   int dk, float scale, float dropout_p, uint64_t seed, uint64_t offset, float* out, float* attn,
+                                   float* lse, void* workspace, size_t workspace_bytes, snf_stream_t stream);
 
 /* K7 (fp32-class, pre-split operands)    the same attention() of snuffy.py:160-168, same arithmetic (split-bf16 x3, fp32
  * softmax / accumulate), for operands that already ARE split: q_hl, v_hl = interleaved "hl" images [n, ld] bf16 (every 32 true

@@ -127,17 +127,20 @@ class SparseAttnFn(torch.autograd.Function):
             out, p, lse = ops.sparse_attn_fwd_mfma(q16, v16, kp, n, h, need_attn=want_p, need_lse=True, dropout=drop)
             ctx.save_for_backward(q16, kp, v16, lse)        # P is recomputed from lse, the mask from (seed, offset)
             return out, p
+        in_kernel = False
         if bf16_operands and ops.mfma_attn_supported(k, dk):
             out, p, _ = ops.sparse_attn_fwd_mfma(q.to(torch.bfloat16), v.to(torch.bfloat16), kp, n, h, need_attn=True)
         elif ops.x3_attn_supported(k, dk) and SF.FP32_ATTENTION != "exact":
-            out, p, _ = ops.sparse_attn_fwd_x3(q, v, kp, h, need_attn=True)
+            in_kernel = drop is not None and ops.x3_attn_dropout_supported(k, dk)       # mask applied to P in registers, P written undropped
+            out, p, _ = ops.sparse_attn_fwd_x3(q, v, kp, h, need_attn=True, dropout=drop if in_kernel else None)
         else:
             out, p, _ = ops.sparse_attn_fwd(q, kp, v, h, need_attn=True)
         mask = None
         if drop is not None:
             mask = ops.dropout_mask(h, n, k, drop[0], drop[1], drop[2], q.device)
-            vh = v.float().view(n, h, dk).transpose(0, 1)
-            out = torch.bmm((p * mask).transpose(1, 2), vh).transpose(0, 1).reshape(k, d)
+            if not in_kernel:
+                vh = v.float().reshape(n, h, dk).transpose(0, 1)
+                out = torch.bmm((p * mask).transpose(1, 2), vh).transpose(0, 1).reshape(k, d)
         ctx.save_for_backward(q, kp, v, p, mask)
         return out, (p * mask if mask is not None else p)
 
@@ -462,16 +465,20 @@ class EncoderLayer0X3Fn(torch.autograd.Function):
         # the K-row projections in plain fp32 (10 us each, as the generic chain runs them under autograd): the gradient that reaches the
         # attention through LayerNorm 1 of these rows is a small difference of large terms -- a 1e-5 error on x_sel moved it by 4e-4
         kp = F.linear(xs, wk, bk)
-        if ops.x3_attn_supported(k, dk) and SF.FP32_ATTENTION != "exact":
-            o, p, _ = ops.sparse_attn_fwd_x3(q, v, kp, h, need_attn=True)
+        p_drop = mha.dropout.p if layer.training else 0.0
+        drop = (float(p_drop),) + draw_dropout_state() if p_drop > 0.0 else None
+        x3 = ops.x3_attn_supported(k, dk) and SF.FP32_ATTENTION != "exact"
+        in_kernel = drop is not None and x3 and ops.x3_attn_dropout_supported(k, dk)
+        if x3:
+            # training: the kernel applies the Philox mask to P in registers (O = (P o M)^T V) and writes the undropped P for the backward
+            o, p, _ = ops.sparse_attn_fwd_x3(q, v, kp, h, need_attn=True, dropout=drop if in_kernel else None)
         else:
             o, p, _ = ops.sparse_attn_fwd(q, kp, v, h, need_attn=True)
-        p_drop = mha.dropout.p if layer.training else 0.0
         mask = None
-        if p_drop > 0.0:
-            seed, offset = draw_dropout_state()
-            mask = ops.dropout_mask(h, n, k, float(p_drop), seed, offset, x2.device)
-            o = torch.bmm((p * mask).transpose(1, 2), v.reshape(n, h, dk).transpose(0, 1)).transpose(0, 1).reshape(k, d)
+        if drop is not None:
+            mask = ops.dropout_mask(h, n, k, drop[0], drop[1], drop[2], x2.device)         # the same mask as a tensor: the backward reads it
+            if not in_kernel:
+                o = torch.bmm((p * mask).transpose(1, 2), v.reshape(n, h, dk).transpose(0, 1)).transpose(0, 1).reshape(k, d)
         delta = F.linear(o, wo, bo)
         x_sel = xs + delta                                                             # snuffy.py:108 at the K rows
         xhat0_sel = xn3.index_select(0, sel)

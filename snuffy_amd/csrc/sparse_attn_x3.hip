@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "philox.h"
 
 namespace {
 
@@ -64,6 +65,7 @@ struct X3Params {
     int vl_bags;
     float* out_direct; // varlen: output [rows, h * dk] for bags with one workgroup per head (descriptor flag 10): stored straight from the
                        // accumulators, no partial tile and no reduction pass for that bag; null = always partials
+    snf::DropoutState drop = {0u, 0u, 0u, 0u, 0u, 1.f};   // DROP instantiations (training, snuffy.py:166-167): O = (P o M)^T V, attn = P
 };
 // Varlen launch (many bags in one grid, single key chunk): the grid is the concatenation of per-bag grids -- every bag keeps a
 // plan of its own (x3_plan with packed = true, a function of its length only), so a bag's result does not depend on what it is
@@ -124,7 +126,9 @@ __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __
 // VGPRs at dk = 128) instead of re-reading them from a 112 KiB LDS image every tile.  The LDS that frees holds 64-ROW tiles with
 // separate Q, P and (double-buffered) V images, so a tile costs three workgroup barriers instead of four per 32 rows, the next
 // tile's rows are split and written while this tile's P is published, and their HBM loads have a whole tile of latency cover.
-template <int DK, int NKB, bool AUX, int MODE, bool VL = false>
+// DROP (round 5, single key chunk): the Philox keep-mask of csrc/philox.h (the one snf_dropout_mask_f32 writes out, bit for bit) is applied to
+// P in registers before its split for GEMM2; the probabilities written to `attn` stay the undropped ones the backward wants.
+template <int DK, int NKB, bool AUX, int MODE, bool VL = false, bool DROP = false>
 __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params PA) {
     constexpr int NKS = DK / 16;               // k-steps of GEMM1
     X3Params P = PA;
@@ -446,6 +450,11 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params PA) {
                             }
                         }
                     }
+                    if constexpr (DROP) {
+                        const snf::philox_f4 mk = snf::dropout_mask4(P.drop, a, P.n_stride, rvalid ? row : 0, P.k, 32 * w + 8 * c4 + 4 * hf);
+                        p4 = f32x4{p4[0] * mk[0], p4[1] * mk[1], p4[2] * mk[2], p4[3] * mk[3]};
+                        asm volatile("" : "+v"(p4));
+                    }
                     const bf16x2 h01 = __builtin_convertvector(f32x2{p4[0], p4[1]}, bf16x2);
                     const bf16x2 h23 = __builtin_convertvector(f32x2{p4[2], p4[3]}, bf16x2);
                     const f32x2 r01 = f32x2{p4[0], p4[1]} - __builtin_convertvector(h01, f32x2);
@@ -568,7 +577,7 @@ bool x3_plan(int64_t n, int k, int h, int dk, X3Plan* pl, bool packed = false) {
 }
 size_t x3_workspace(const X3Plan& pl, int dk) { return (size_t)pl.num_wg * pl.seg_count * (size_t)(pl.nkb * (dk / 32)) * 1024 * sizeof(float); }
 
-template <int DK, int NKB, bool AUX, int MODE, bool VL = false>
+template <int DK, int NKB, bool AUX, int MODE, bool VL = false, bool DROP = false>
 int x3_launch(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s) {
     constexpr int NKS = DK / 16;
     constexpr int q_bytes = (TROWS / 32) * NKS * 1024, p_bytes = TROWS * p_row_bytes(NKB), v_bytes = TROWS * 2 * DK;
@@ -576,7 +585,7 @@ int x3_launch(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s) {
     static thread_local unsigned long long attr_set_mask = 0;   // devices (bit = device id) that have the opt-in
     const unsigned long long attr_set_bit = snf::device_bit();
     const bool attr_set = (attr_set_mask & attr_set_bit) != 0;
-    auto kern = sparse_attn_x3_kernel<DK, NKB, AUX, MODE, VL>;
+    auto kern = sparse_attn_x3_kernel<DK, NKB, AUX, MODE, VL, DROP>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             snf::set_error("sparse_attn_x3: cannot reserve %d bytes of LDS", lds);
@@ -651,6 +660,20 @@ int x3_modes(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s, int
     return aux ? x3_launch<DK, NB, true, 0>(P, pl, out, s) : x3_launch<DK, NB, false, 0>(P, pl, out, s);
 }
 template <int DK>
+int x3_dispatch_dropout(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s) {
+    switch (pl.nkb) {
+        case 2: return x3_launch<DK, 2, true, 0, false, true>(P, pl, out, s);
+        case 4: return x3_launch<DK, 4, true, 0, false, true>(P, pl, out, s);
+        case 7: return x3_launch<DK, 7, true, 0, false, true>(P, pl, out, s);
+        case 8:
+            if constexpr (DK == 64) return x3_launch<DK, 8, true, 0, false, true>(P, pl, out, s);
+            break;
+        default: break;
+    }
+    snf::set_error("sparse_attn_x3 (dropout): key-block count %d not built", pl.nkb);
+    return SNF_EUNSUPPORTED;
+}
+template <int DK>
 int x3_dispatch(const X3Params& P, const X3Plan& pl, float* out, hipStream_t s, int mode) {
     switch (pl.nkb) {
         case 2: return x3_modes<DK, 2>(P, pl, out, s, mode);
@@ -689,9 +712,27 @@ size_t snf_sparse_attn_fwd_x3_workspace_bytes(int64_t n, int k, int h, int dk) {
     return x3_workspace(pl, dk) + stats;
 }
 
+static int x3_forward(const float* q, int64_t ldq, const float* v, int64_t ldv, const float* kp, int64_t n, int k, int h, int dk,
+                      float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes, snf_stream_t stream,
+                      const snf::DropoutState* drop);
+
 int snf_sparse_attn_fwd_x3(const float* q, int64_t ldq, const float* v, int64_t ldv, const float* kp, int64_t n, int k, int h,
                            int dk, float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
                            snf_stream_t stream) {
+    return x3_forward(q, ldq, v, ldv, kp, n, k, h, dk, scale, out, attn, lse, workspace, workspace_bytes, stream, nullptr);
+}
+
+int snf_sparse_attn_fwd_x3_dropout(const float* q, int64_t ldq, const float* v, int64_t ldv, const float* kp, int64_t n, int k, int h,
+                                   int dk, float scale, float dropout_p, uint64_t seed, uint64_t offset, float* out, float* attn,
+                                   float* lse, void* workspace, size_t workspace_bytes, snf_stream_t stream) {
+    SNF_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "snf_sparse_attn_fwd_x3_dropout: dropout_p=%g outside [0, 1)", (double)dropout_p);
+    const snf::DropoutState st = snf::make_dropout(dropout_p, seed, offset);
+    return x3_forward(q, ldq, v, ldv, kp, n, k, h, dk, scale, out, attn, lse, workspace, workspace_bytes, stream, st.thresh ? &st : nullptr);
+}
+
+static int x3_forward(const float* q, int64_t ldq, const float* v, int64_t ldv, const float* kp, int64_t n, int k, int h, int dk,
+                      float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes, snf_stream_t stream,
+                      const snf::DropoutState* drop) {
     SNF_REQUIRE(q && v && kp && out, "snf_sparse_attn_fwd_x3: null pointer");
     SNF_REQUIRE(n >= 1 && k >= 1 && h >= 1, "snf_sparse_attn_fwd_x3: bad shape");
     X3Plan pl;
@@ -723,6 +764,15 @@ int snf_sparse_attn_fwd_x3(const float* q, int64_t ldq, const float* v, int64_t 
     P.seg_count = pl.seg_count;
     P.n_stride = n, P.vl = nullptr, P.vl_bags = 0, P.out_direct = nullptr;
     hipStream_t s = snf::as_stream(stream);
+    if (drop) {
+        if (ch.count != 1) {
+            snf::set_error("snf_sparse_attn_fwd_x3_dropout: k=%d needs key chunks; the in-kernel mask covers one launch (k <= %d)", k,
+                           dk == 128 ? 224 : 256);
+            return SNF_EUNSUPPORTED;
+        }
+        P.drop = *drop;
+        return dk == 128 ? x3_dispatch_dropout<128>(P, pl, out, s) : x3_dispatch_dropout<64>(P, pl, out, s);
+    }
     if (ch.count == 1) return dk == 128 ? x3_dispatch<128>(P, pl, out, s, 0) : x3_dispatch<64>(P, pl, out, s, 0);
     // key chunks: statistics of every chunk first, then the chunks' main passes with the softmax exact over all keys
     for (int pass = 1; pass <= 2; ++pass)

@@ -696,9 +696,16 @@ def x3_attn_supported(k, dk):
     return (dk == 128 and 1 <= k <= 8 * 224) or (dk == 64 and 1 <= k <= 8 * 256)
 
 
-def sparse_attn_fwd_x3(q, v, kp, h, scale=None, need_attn=False, need_lse=False):
+def x3_attn_dropout_supported(k, dk):
+    """The fp32-class kernel applies the training dropout mask itself (one key chunk)."""
+    return (dk == 128 and 1 <= k <= 224) or (dk == 64 and 1 <= k <= 256)
+
+
+def sparse_attn_fwd_x3(q, v, kp, h, scale=None, need_attn=False, need_lse=False, dropout=None):
     """fp32-class sparse attention on the matrix cores (snf_sparse_attn_fwd_x3): q, v [n, d] f32 (row-strided views allowed),
-    kp [k, d] f32 -> (out [k, d], attn [h, n, k] or None, lse [h, n] or None)."""
+    kp [k, d] f32 -> (out [k, d], attn [h, n, k] or None, lse [h, n] or None).  dropout = (p, seed, offset): the training forward
+    (snf_sparse_attn_fwd_x3_dropout, x3_attn_dropout_supported shapes): out = (P o M)^T V with M the mask ops.dropout_mask writes for the
+    same (p, seed, offset); attn stays the UNDROPPED P."""
     if q.dtype != torch.float32 or v.dtype != torch.float32:
         raise TypeError("sparse_attn_fwd_x3: q and v must be float32")
     q = _rows16(q, "q")
@@ -717,6 +724,11 @@ def sparse_attn_fwd_x3(q, v, kp, h, scale=None, need_attn=False, need_lse=False)
     lse = torch.empty(h, n, dtype=torch.float32, device=q.device) if need_lse else None
     wsb = lib.snf_sparse_attn_fwd_x3_workspace_bytes(n, k, h, dk)
     ws = _ws(wsb, q.device)
+    if dropout is not None and dropout[0] > 0.0:
+        check(lib.snf_sparse_attn_fwd_x3_dropout(_p(q), q.stride(0), _p(v), v.stride(0), _p(kp), n, k, h, dk, float(scale), float(dropout[0]),
+                                                 int(dropout[1]) & (2 ** 64 - 1), int(dropout[2]) & (2 ** 64 - 1), _p(out), _p(attn), _p(lse), _p(ws), wsb, _stream()),
+              "snf_sparse_attn_fwd_x3_dropout")
+        return out, attn, lse
     check(lib.snf_sparse_attn_fwd_x3(_p(q), q.stride(0), _p(v), v.stride(0), _p(kp), n, k, h, dk, float(scale), _p(out), _p(attn),
                                      _p(lse), _p(ws), wsb, _stream()), "snf_sparse_attn_fwd_x3")
     return out, attn, lse

@@ -339,6 +339,37 @@ def test_sparse_attn_x3u_fp32_class(n, k, h, dk):
         ops().sparse_attn_fwd_x3u(torch.zeros(8, 2 * 83, device=DEV), torch.zeros(4, 2 * 83, device=DEV), torch.zeros(8, 2 * 83, device=DEV), 2)
 
 
+@pytest.mark.parametrize("n,k,h,dk,p_drop", [(4000, 200, 6, 128, 0.1), (1000, 224, 2, 128, 0.5), (3001, 256, 3, 64, 0.1), (700, 37, 4, 64, 0.25),
+                                             (65, 5, 1, 128, 0.1)])
+def test_sparse_attn_x3_in_kernel_dropout(n, k, h, dk, p_drop):
+    """snf_sparse_attn_fwd_x3_dropout (round 5, the training forward of reference snuffy.py:166-167): O = (P o M)^T V with M regenerated
+    in registers from (seed, offset) -- against the mask TENSOR of snf_dropout_mask_f32 for the same state applied to the kernel's own
+    undropped P in fp64; the P written out is the undropped one, bit for bit the plain launch's; more keys than one launch: refused."""
+    from snuffy_amd import SnuffyHipError
+    g = torch.Generator().manual_seed(n + k + dk)
+    d = h * dk
+    q, kp, v = (torch.randn(n, d, generator=g).to(DEV), torch.randn(k, d, generator=g).to(DEV), torch.randn(n, d, generator=g).to(DEV))
+    seed, offset = 1234567 + n, (1 << 40) + 17 * k
+    assert ops().x3_attn_dropout_supported(k, dk)
+    o_plain, p_plain, _ = ops().sparse_attn_fwd_x3(q, v, kp, h, need_attn=True)
+    o, p, _ = ops().sparse_attn_fwd_x3(q, v, kp, h, need_attn=True, dropout=(p_drop, seed, offset))
+    assert torch.equal(p, p_plain)
+    mask = ops().dropout_mask(h, n, k, p_drop, seed, offset, DEV)
+    kept = (mask > 0).float().mean().item()
+    assert abs(kept - (1 - p_drop)) < 0.02 + 2.0 / (h * n * k) ** 0.5
+    ref = torch.bmm((p.double() * mask.double()).transpose(1, 2), v.double().view(n, h, dk).transpose(0, 1)).transpose(0, 1).reshape(k, d)
+    assert rel_err(o.cpu(), ref.cpu()) < 2e-5
+    assert rel_err(o.cpu(), o_plain.cpu()) > 1e-3                      # and it is not the undropped product
+    o2, _, _ = ops().sparse_attn_fwd_x3(q, v, kp, h, need_attn=True, dropout=(p_drop, seed, offset))
+    assert torch.equal(o2, o)
+    o0, _, _ = ops().sparse_attn_fwd_x3(q, v, kp, h, need_attn=True, dropout=(0.0, seed, offset))
+    assert torch.equal(o0, o_plain)
+    if dk == 128:
+        kk = 300
+        with pytest.raises(SnuffyHipError):
+            ops().sparse_attn_fwd_x3(q, v, torch.randn(kk, d, generator=g).to(DEV), h, dropout=(p_drop, seed, offset))
+
+
 def bf16r(t):
     return t.to(torch.bfloat16).float()
 
