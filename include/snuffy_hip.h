@@ -327,6 +327,11 @@ size_t snf_sparse_attn_bwd_workspace_bytes(int64_t n, int k, int h, int dk);
 int snf_sparse_attn_bwd_f32(const float* q, const float* kp, const float* v, const float* p, const float* mask,
                             const float* dout, int64_t n, int k, int h, int dk, float scale, float* dq, float* dkp,
                             float* dv, void* workspace, size_t workspace_bytes, snf_stream_t stream);
+/* The same with row pitches for q / v (elements, >= h dk; round 5): the halves of a fused [Q | V] projection output are read in place.
+ * Pitches other than h dk need the matrix-core kernels (dk % 8 == 0, k <= 1024, 16-byte aligned rows), else SNF_EUNSUPPORTED. */
+int snf_sparse_attn_bwd_ld_f32(const float* q, int64_t ldq, const float* kp, const float* v, int64_t ldv, const float* p, const float* mask,
+                               const float* dout, int64_t n, int k, int h, int dk, float scale, float* dq, float* dkp, float* dv,
+                               void* workspace, size_t workspace_bytes, snf_stream_t stream);
 /* Fast form of the backward for dk == 128 with k <= 224 or dk == 64 with k <= 256 (bf16 MFMA operands, fp32 accumulate): P is recomputed from q, kp
  * and the forward's lse [h, n] (never read back), dQ / dV rows are owned by one wave (no reduction), dS [h, n, k] is
  * written out (ds_dtype f32, or bf16) -- the caller contracts it with q for dKp (snf_sparse_attn_dkp_f32 on f32, or a

@@ -714,7 +714,7 @@ template <int KBW>
 __global__ __launch_bounds__(256, KBW <= 4 ? 3 : 2) void bwd_ds_mfma_kernel(const float* __restrict__ v, const float* __restrict__ dout,
                                                                             const float* __restrict__ p, const float* __restrict__ mask,
                                                                             int64_t n, int k, int h, int dk, float scale,
-                                                                            float* __restrict__ ds) {
+                                                                            float* __restrict__ ds, int64_t ldv /* row pitch of v */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int pitch = dk + 4;
     float* lv = lds;                           // [32][pitch]
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(256, KBW <= 4 ? 3 : 2) void bwd_ds_mfma_kernel(cons
         const int r = e / dk4, c4 = e - r * dk4;
         const int64_t row = row0 + r;
         mf32x4 val = {0.f, 0.f, 0.f, 0.f};
-        if (row < n) val = *reinterpret_cast<const mf32x4*>(v + row * d_model + a * dk + 4 * c4);
+        if (row < n) val = *reinterpret_cast<const mf32x4*>(v + row * ldv + a * dk + 4 * c4);
         *reinterpret_cast<mf32x4*>(lv + r * pitch + 4 * c4) = val;
     }
     __syncthreads();
@@ -1040,7 +1040,16 @@ size_t snf_sparse_attn_bwd_workspace_bytes(int64_t n, int k, int h, int dk) {
 int snf_sparse_attn_bwd_f32(const float* q, const float* kp, const float* v, const float* p, const float* mask,
                             const float* dout, int64_t n, int k, int h, int dk, float scale, float* dq, float* dkp,
                             float* dv, void* workspace, size_t workspace_bytes, snf_stream_t stream) {
+    return snf_sparse_attn_bwd_ld_f32(q, (int64_t)h * dk, kp, v, (int64_t)h * dk, p, mask, dout, n, k, h, dk, scale, dq, dkp, dv, workspace,
+                                      workspace_bytes, stream);
+}
+
+int snf_sparse_attn_bwd_ld_f32(const float* q, int64_t ldq, const float* kp, const float* v, int64_t ldv, const float* p, const float* mask,
+                               const float* dout, int64_t n, int k, int h, int dk, float scale, float* dq, float* dkp,
+                               float* dv, void* workspace, size_t workspace_bytes, snf_stream_t stream) {
     SNF_REQUIRE(q && kp && v && p && dout && dq && dkp && dv, "snf_sparse_attn_bwd_f32: null pointer");
+    SNF_REQUIRE(ldq >= (int64_t)h * dk && ldv >= (int64_t)h * dk && ldq < (1 << 24) && ldv < (1 << 24),
+                "snf_sparse_attn_bwd_ld_f32: bad row pitch ldq=%lld ldv=%lld", (long long)ldq, (long long)ldv);
     SNF_REQUIRE(n >= 1 && k >= 1 && h >= 1 && dk >= 1, "snf_sparse_attn_bwd_f32: bad shape n=%lld k=%d h=%d dk=%d",
                 (long long)n, k, h, dk);
     SNF_REQUIRE(k <= 2048 && dk <= 256 && h <= 65535, "snf_sparse_attn_bwd_f32: k=%d / dk=%d / h=%d out of range", k, dk, h);
@@ -1056,14 +1065,18 @@ int snf_sparse_attn_bwd_f32(const float* q, const float* kp, const float* v, con
     const int dk4 = (dk + 3) & ~3;
     const size_t lds = (size_t)(ROWS_PER_WG * dk4 + KCHUNK * (dk4 + 4)) * sizeof(float);
     int rc;
-    const bool mfma_ok = g_exact_mfma && dk % 8 == 0 &&
+    const bool mfma_ok = g_exact_mfma && dk % 8 == 0 && ldv % 4 == 0 &&
                          ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(dout)) & 15) == 0;
+    if ((ldq != (int64_t)h * dk || ldv != (int64_t)h * dk) && !(mfma_ok && k <= 1024)) {
+        snf::set_error("snf_sparse_attn_bwd_ld_f32: row pitches other than h dk need the matrix-core kernels (dk %% 8 == 0, k <= 1024, 16-byte rows)");
+        return SNF_EUNSUPPORTED;
+    }
     if (mfma_ok && k <= 1024) {
         const size_t lds_m = (size_t)(32 * (dk + 4) + 128) * sizeof(float);
         dim3 grid1((unsigned)((n + 31) / 32), (unsigned)h);
         const int kbw = ((k + 31) / 32 + 3) / 4;
 #define LAUNCH_DSM(KBW) \
-    hipLaunchKernelGGL((bwd_ds_mfma_kernel<KBW>), grid1, dim3(256), lds_m, s, v, dout, p, mask, n, k, h, dk, scale, ds)
+    hipLaunchKernelGGL((bwd_ds_mfma_kernel<KBW>), grid1, dim3(256), lds_m, s, v, dout, p, mask, n, k, h, dk, scale, ds, ldv)
         if (kbw <= 1) LAUNCH_DSM(1);
         else if (kbw <= 2) LAUNCH_DSM(2);
         else if (kbw <= 4) LAUNCH_DSM(4);
@@ -1106,7 +1119,7 @@ int snf_sparse_attn_bwd_f32(const float* q, const float* kp, const float* v, con
     const int slices = generic_slices(n);
     const int64_t rows_per_slice = (((n + slices - 1) / slices) + 15) & ~(int64_t)15;
     if (g_exact_mfma)
-        rc = launch_pt_v_mfma(ds, q, n, k, h, dk, rows_per_slice, slices, partial, s);
+        rc = launch_pt_v_mfma(ds, q, n, k, h, dk, rows_per_slice, slices, partial, s, (int)ldq);
     else {
         dim3 grid3((unsigned)((k + 63) / 64), (unsigned)((dk + 63) / 64), (unsigned)(slices * h));
         hipLaunchKernelGGL(pt_v_kernel, grid3, dim3(256), 0, s, ds, q, n, k, h, dk, rows_per_slice, partial);

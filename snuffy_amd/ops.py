@@ -512,10 +512,15 @@ def ln_mean_head(z, gamma, beta, eps, w_head, b_head, add_bf16=None, add_bias=No
 
 def sparse_attn_bwd(q, kp, v, p, dout, h, mask=None, scale=None):
     """Exact-fp32 backward of sparse_attn_fwd: (dq [n,d], dkp [k,d], dv [n,d]).  p [h,n,k] = forward probabilities,
-    mask (optional) = dropout keep-mask already divided by (1 - p_drop), dout [k, d]."""
-    q = _req(q, torch.float32, "q", 2)
+    mask (optional) = dropout keep-mask already divided by (1 - p_drop), dout [k, d].  q / v may be the row-strided halves of a fused
+    [Q | V] projection output where the matrix-core kernels apply (dk % 8 == 0, k <= 1024); otherwise they are made contiguous."""
+    if q.dtype != torch.float32 or v.dtype != torch.float32:
+        raise TypeError("sparse_attn_bwd: q and v must be float32")
     kp = _req(kp, torch.float32, "kp", 2)
-    v = _req(v, torch.float32, "v", 2)
+    if q.dim() == 2 and kp.dim() == 2 and (q.shape[1] // h) % 8 == 0 and kp.shape[0] <= 1024:
+        q, v = _rows16(q, "q"), _rows16(v, "v")
+    else:
+        q, v = _req(q, torch.float32, "q", 2), _req(v, torch.float32, "v", 2)
     p = _req(p, torch.float32, "p", 3)
     dout = _req(dout, torch.float32, "dout", 2)
     if mask is not None:
@@ -527,13 +532,13 @@ def sparse_attn_bwd(q, kp, v, p, dout, h, mask=None, scale=None):
         raise ValueError("sparse_attn_bwd: inconsistent shapes")
     scale = 1.0 / math.sqrt(dk) if scale is None else scale
     lib = _ffi.load()
-    dq = torch.empty_like(q)
-    dv = torch.empty_like(v)
+    dq = torch.empty(n, d, dtype=torch.float32, device=q.device)
+    dv = torch.empty(n, d, dtype=torch.float32, device=q.device)
     dkp = torch.empty_like(kp)
     wsb = lib.snf_sparse_attn_bwd_workspace_bytes(n, k, h, dk)
     ws = _ws(wsb, q.device)
-    check(lib.snf_sparse_attn_bwd_f32(_p(q), _p(kp), _p(v), _p(p), _p(mask), _p(dout), n, k, h, dk, float(scale), _p(dq),
-                                      _p(dkp), _p(dv), _p(ws), wsb, _stream()), "snf_sparse_attn_bwd_f32")
+    check(lib.snf_sparse_attn_bwd_ld_f32(_p(q), q.stride(0), _p(kp), _p(v), v.stride(0), _p(p), _p(mask), _p(dout), n, k, h, dk, float(scale),
+                                         _p(dq), _p(dkp), _p(dv), _p(ws), wsb, _stream()), "snf_sparse_attn_bwd_ld_f32")
     return dq, dkp, dv
 
 

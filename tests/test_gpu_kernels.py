@@ -370,6 +370,24 @@ def test_sparse_attn_x3_in_kernel_dropout(n, k, h, dk, p_drop):
             ops().sparse_attn_fwd_x3(q, v, torch.randn(kk, d, generator=g).to(DEV), h, dropout=(p_drop, seed, offset))
 
 
+@pytest.mark.parametrize("n,k,h,dk", [(3000, 200, 6, 128), (1001, 77, 3, 64), (500, 300, 2, 96)])
+def test_sparse_attn_bwd_reads_the_halves_of_a_fused_projection_in_place(n, k, h, dk):
+    """snf_sparse_attn_bwd_ld_f32 (round 5): q / v as row-strided column halves of one [n, 2 d] tensor -- bit for bit the gradients of
+    the contiguous call (the training chain hands the Q | V projection's output over without two 100 MB copies per step)."""
+    g = torch.Generator().manual_seed(n + k)
+    d = h * dk
+    qv = torch.randn(n, 2 * d, generator=g).to(DEV)
+    kp, dout = torch.randn(k, d, generator=g).to(DEV), torch.randn(k, d, generator=g).to(DEV)
+    q, v = qv[:, :d], qv[:, d:]
+    _, p, _ = ops().sparse_attn_fwd(q.contiguous(), kp, v.contiguous(), h, need_attn=True)
+    mask = ops().dropout_mask(h, n, k, 0.1, 7, 99, DEV)
+    for m in (None, mask):
+        a = ops().sparse_attn_bwd(q, kp, v, p, dout, h, mask=m)
+        b = ops().sparse_attn_bwd(q.contiguous(), kp, v.contiguous(), p, dout, h, mask=m)
+        for x, y in zip(a, b):
+            assert x.is_contiguous() and torch.equal(x, y)
+
+
 def bf16r(t):
     return t.to(torch.bfloat16).float()
 
