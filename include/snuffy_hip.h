@@ -521,7 +521,9 @@ void snf_debug_attn_trace_wg(int wg);
  * results equal up to the fp32 order of the row sums.  For A / B timing (tools/x3p_dev.py) and the parity tests of the second form. */
 void snf_debug_x3p_kbw(int kbw);
 /* snf_debug_exact_attn_mfma(on): the exact-fp32 attention kernels (snf_sparse_attn_fwd_f32, the dKp contraction of the backward) on
- * v_mfma_f32_32x32x2_f32 (1, default; head widths % 8 == 0, <= 1024 keys for the scores) or on the vector ALUs for every shape (0). */
+ * v_mfma_f32_32x32x2_f32 (1, default; head widths % 8 == 0, <= 1024 keys for the scores) or on the vector ALUs for every shape (0);
+ * 2 = the matrix-core forms with the dQ / dV kernel of the backward reading its operands straight from L2 instead of staging them through
+ * LDS (the round-5 A / B partner; same fmaf chains, bit-identical results). */
 void snf_debug_exact_attn_mfma(int on);
 
 #ifdef __cplusplus

@@ -924,6 +924,143 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_dv_mfma_kernel(const float* __r
     }
 }
 
+// dQ / dV with the operands staged through LDS (round 5).  bwd_dq_dv_mfma_kernel above asks L2 for every operand of every MFMA group (34
+// loads per 32 MFMAs, a quarter of each P / dS cache line used) and hides one group of latency: 489 us at config B for 128 us of
+// matrix-pipe time.  Here a workgroup (4 waves x 32 rows of one head) walks the keys in chunks of 32: the chunk of dO and Kp
+// ([32 keys, 32 CT columns] each) is staged once for the four waves, every wave stages its own [32 rows, 32 keys] tiles of P o M and
+// dS -- all with coalesced 16-byte loads, requested a whole chunk (128 MFMAs per wave) ahead and parked in registers -- and the MFMA
+// operands come out of LDS (A: one 16-byte read per four k-steps, row pitch 36 floats; B: conflict-free dword reads).
+template <int CT, bool MASK>
+__global__ __launch_bounds__(256, 2) void bwd_dq_dv_lds_kernel(const float* __restrict__ p, const float* __restrict__ mask,
+                                                               const float* __restrict__ ds, const float* __restrict__ dout,
+                                                               const float* __restrict__ kp, int64_t n, int k, int h, int dk,
+                                                               float* __restrict__ dq, float* __restrict__ dv) {
+    constexpr int PA = 36, PB = 32 * CT;                      // row pitches (floats) of the A tiles and of the B chunks
+    extern __shared__ __attribute__((aligned(16))) float dql[];
+    float* lds_b = dql;                                        // [2][32][PB]: dO chunk | Kp chunk
+    float* lds_a = dql + 2 * 32 * PB;                          // [4 waves][2][32][PA]: P o M | dS
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, hf = lane >> 5;
+    const int a = blockIdx.z;
+    const int d_model = h * dk;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + w) * 32;
+    const int cb0 = CT * blockIdx.y;
+    float* my_a = lds_a + w * 2 * 32 * PA;
+    // staging roles.  A: lane (r8 = lane >> 3, q4 = lane & 7) fetches keys 4 q4 .. + 3 of rows 8 i + r8 (i = 0 .. 3) of its wave's tile.
+    // B: thread t fetches float4 number t + 256 i (i < CT) of the chunk: key (t + 256 i) / (8 CT), columns 4 ((t + 256 i) % (8 CT)) ..
+    const int r8 = lane >> 3, q4 = lane & 7;
+    struct Stage {
+        mf32x4 pa[4], sa[4], bo[CT], bk[CT];
+    };
+    auto load_stage = [&](int kc0, Stage& st) __attribute__((always_inline)) {
+        const int key = kc0 + 4 * q4;
+        const bool kok = key + 4 <= k;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int64_t row = row0 + 8 * i + r8;
+            if (row > n - 1) row = n - 1;
+            const int64_t off = ((int64_t)a * n + row) * k + key;
+            st.pa[i] = mf32x4{0.f, 0.f, 0.f, 0.f}, st.sa[i] = mf32x4{0.f, 0.f, 0.f, 0.f};
+            if (kok) {
+                st.pa[i] = *reinterpret_cast<const mf32x4*>(p + off);
+                st.sa[i] = *reinterpret_cast<const mf32x4*>(ds + off);
+                if constexpr (MASK) st.pa[i] *= *reinterpret_cast<const mf32x4*>(mask + off);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int bkey = kc0 + idx / (8 * CT), col = 32 * cb0 + 4 * (idx % (8 * CT));
+            st.bo[i] = mf32x4{0.f, 0.f, 0.f, 0.f}, st.bk[i] = mf32x4{0.f, 0.f, 0.f, 0.f};
+            if (bkey < k && col + 4 <= dk) {
+                const int64_t off = (int64_t)bkey * d_model + a * dk + col;
+                st.bo[i] = *reinterpret_cast<const mf32x4*>(dout + off);
+                st.bk[i] = *reinterpret_cast<const mf32x4*>(kp + off);
+            }
+        }
+    };
+    auto park_stage = [&](const Stage& st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<mf32x4*>(my_a + (8 * i + r8) * PA + 4 * q4) = st.pa[i];
+            *reinterpret_cast<mf32x4*>(my_a + 32 * PA + (8 * i + r8) * PA + 4 * q4) = st.sa[i];
+        }
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int o = (idx / (8 * CT)) * PB + 4 * (idx % (8 * CT));
+            *reinterpret_cast<mf32x4*>(lds_b + o) = st.bo[i];
+            *reinterpret_cast<mf32x4*>(lds_b + 32 * PB + o) = st.bk[i];
+        }
+    };
+    mf32x16 av[CT], aq[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) av[c][i] = 0.f, aq[c][i] = 0.f;
+    Stage st;
+    load_stage(0, st);
+    for (int kc0 = 0; kc0 < k; kc0 += 32) {
+        __syncthreads();                                       // the previous chunk's fragment reads are done
+        park_stage(st);
+        __syncthreads();
+        if (kc0 + 32 < k) load_stage(kc0 + 32, st);           // in flight under this chunk's 128 MFMAs
+        const float* ar = my_a + j * PA + 4 * hf;              // lane (row j, half hf): keys 8 T + 4 hf .. + 3 of k-step group T
+        const float* br = lds_b + (4 * hf) * PB + j;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            if (kc0 + 8 * T >= k) break;                      // (wave-uniform) the last chunk's groups of 8 keys past k hold zeros
+            const mf32x4 p4 = *reinterpret_cast<const mf32x4*>(ar + 8 * T);
+            const mf32x4 s4 = *reinterpret_cast<const mf32x4*>(ar + 32 * PA + 8 * T);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const float od = br[(8 * T + e) * PB + 32 * c], kd = br[32 * PB + (8 * T + e) * PB + 32 * c];
+                    av[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(p4[e], od, av[c], 0, 0, 0);
+                    aq[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(s4[e], kd, aq[c], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int col = 32 * (cb0 + c) + j;
+        if (col >= dk) continue;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t r = row0 + (i & 3) + 8 * (i >> 2) + 4 * hf;
+            if (r < n) {
+                dv[r * d_model + a * dk + col] = av[c][i];
+                dq[r * d_model + a * dk + col] = aq[c][i];
+            }
+        }
+    }
+}
+
+template <int CT>
+int launch_dq_dv_lds(const float* p, const float* mask, const float* ds, const float* dout, const float* kp, int64_t n, int k, int h, int dk,
+                     float* dq, float* dv, dim3 grid, hipStream_t s) {
+    constexpr int lds = (2 * 32 * 32 * CT + 4 * 2 * 32 * 36) * (int)sizeof(float);
+    static thread_local unsigned long long set_mask[2] = {0, 0};       // devices that have the LDS opt-in, per instantiation
+    const unsigned long long bit = snf::device_bit();
+    const int which = mask ? 1 : 0;
+    const void* fn = mask ? reinterpret_cast<const void*>(bwd_dq_dv_lds_kernel<CT, true>) : reinterpret_cast<const void*>(bwd_dq_dv_lds_kernel<CT, false>);
+    if (!(set_mask[which] & bit)) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            snf::set_error("bwd_dq_dv_lds: cannot reserve %d bytes of LDS", lds);
+            (void)hipGetLastError();
+            return SNF_ELAUNCH;
+        }
+        set_mask[which] |= bit;
+    }
+    if (mask)
+        hipLaunchKernelGGL((bwd_dq_dv_lds_kernel<CT, true>), grid, dim3(256), lds, s, p, mask, ds, dout, kp, n, k, h, dk, dq, dv);
+    else
+        hipLaunchKernelGGL((bwd_dq_dv_lds_kernel<CT, false>), grid, dim3(256), lds, s, p, mask, ds, dout, kp, n, k, h, dk, dq, dv);
+    return snf::check_launch("bwd_dq_dv_lds_kernel");
+}
+
 inline int generic_slices(int64_t n) {
     int64_t s = (n + 511) / 512;
     if (s > 64) s = 64;
@@ -1019,6 +1156,8 @@ int launch_pt_v_mfma(const float* p, const float* v, int64_t n, int k, int h, in
 
 // development / test switch (snf_debug_exact_attn_mfma): false = the round-1 vector-ALU kernels for every shape
 bool g_exact_mfma = true;
+// ... and 2 = the matrix-core forms with the dQ / dV kernel that reads its operands straight from L2 (the A / B partner of the LDS-staged one)
+bool g_dq_dv_lds = true;
 
 }  // namespace
 
@@ -1102,6 +1241,18 @@ int snf_sparse_attn_bwd_ld_f32(const float* q, int64_t ldq, const float* kp, con
         const int ncb = (dk + 31) / 32;
         const int ct = ncb % 3 == 0 ? 3 : (ncb >= 4 ? 4 : ncb);
         dim3 grid2((unsigned)((n + 127) / 128), (unsigned)((ncb + ct - 1) / ct), (unsigned)h);
+        const bool lds_ok = g_dq_dv_lds && k % 4 == 0 && dk % 4 == 0 &&
+                            ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(ds) | reinterpret_cast<uintptr_t>(dout) |
+                              reinterpret_cast<uintptr_t>(kp) | (mask ? reinterpret_cast<uintptr_t>(mask) : 0)) & 15) == 0;
+        if (lds_ok) {
+            switch (ct) {
+                case 1: rc = launch_dq_dv_lds<1>(p, mask, ds, dout, kp, n, k, h, dk, dq, dv, grid2, s); break;
+                case 2: rc = launch_dq_dv_lds<2>(p, mask, ds, dout, kp, n, k, h, dk, dq, dv, grid2, s); break;
+                case 3: rc = launch_dq_dv_lds<3>(p, mask, ds, dout, kp, n, k, h, dk, dq, dv, grid2, s); break;
+                default: rc = launch_dq_dv_lds<4>(p, mask, ds, dout, kp, n, k, h, dk, dq, dv, grid2, s); break;
+            }
+            if (rc) return rc;
+        } else
         switch (ct) {
             case 1: hipLaunchKernelGGL((bwd_dq_dv_mfma_kernel<1>), grid2, dim3(256), 0, s, p, mask, ds, dout, kp, n, k, h, dk, dq, dv); break;
             case 2: hipLaunchKernelGGL((bwd_dq_dv_mfma_kernel<2>), grid2, dim3(256), 0, s, p, mask, ds, dout, kp, n, k, h, dk, dq, dv); break;
@@ -1311,6 +1462,6 @@ int snf_sparse_attn_fwd_ragged_f32(const float* q, int64_t ldq, const float* v, 
 
 // development / test hook: 1 (default) = the exact-fp32 attention runs on the f32 matrix-core forms where the shape allows, 0 = the
 // vector-ALU kernels everywhere (the two agree to fp32 rounding: different summation orders of the same fmaf chains)
-void snf_debug_exact_attn_mfma(int on) { g_exact_mfma = on != 0; }
+void snf_debug_exact_attn_mfma(int on) { g_exact_mfma = on != 0, g_dq_dv_lds = on == 1; }
 
 }  // extern "C"
