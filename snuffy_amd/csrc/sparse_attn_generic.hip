@@ -1139,10 +1139,124 @@ __global__ __launch_bounds__(256) void ragged_attn_kernel(const float* __restric
 }
 
 // P^T V on the f32 MFMA: one wave per (64 keys, 32 CT columns, row slice)
+// P^T V (and dS^T Q) with the operands staged through LDS (round 5, the twin of bwd_dq_dv_lds_kernel): a workgroup owns ONE slice of the rows,
+// 256 keys (wave w: keys 64 w .. + 63 of them) and 32 CT columns, and walks its rows in chunks of 32: the chunk of P ([32 rows, 256 keys]) and of V
+// ([32 rows, 32 CT columns]) is fetched with coalesced 16-byte loads a whole chunk (128 MFMAs per wave) ahead, parked in registers, then in LDS,
+// and the MFMA operands are conflict-free dword reads.  Against pt_v_mfma_kernel (a wave per slice, every operand straight from L2): V is read
+// k / 256 times instead of k / 64, and nothing waits on L2 inside the MFMA stream.  Same row pairs in the same order: bit-identical partials.
+template <int CT>
+__global__ __launch_bounds__(256, 2) void pt_v_lds_kernel(const float* __restrict__ p /*[h,n,k]*/, const float* __restrict__ v, int64_t n, int k,
+                                                          int h, int dk, int64_t rows_per_slice, float* __restrict__ partial /*[slices,h,k,dk]*/,
+                                                          int ldv) {
+    constexpr int PP = 256, PV = 32 * CT;                      // row pitches (floats) of the staged chunks
+    __shared__ __attribute__((aligned(16))) float lp[32 * PP];
+    __shared__ __attribute__((aligned(16))) float lv[32 * PV];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, hf = lane >> 5;
+    const int a = blockIdx.z % h, slice = blockIdx.z / h;
+    const int64_t r_begin = (int64_t)slice * rows_per_slice;
+    int64_t r_end = r_begin + rows_per_slice;
+    if (r_end > n) r_end = n;
+    const int kt0 = 256 * blockIdx.x, cb0 = CT * blockIdx.y;
+    const float* pa = p + (int64_t)a * n * k;
+    const float* va = v + a * dk;
+    struct Stage {
+        mf32x4 pp[8], vv[CT];
+    };
+    auto load_stage = [&](int64_t r0, Stage& st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int64_t row = r0 + (idx >> 6);
+            const int key = kt0 + 4 * (idx & 63);
+            st.pp[i] = mf32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < r_end && key + 4 <= k) st.pp[i] = *reinterpret_cast<const mf32x4*>(pa + row * k + key);
+        }
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int64_t row = r0 + idx / (8 * CT);
+            const int col = 32 * cb0 + 4 * (idx % (8 * CT));
+            st.vv[i] = mf32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < r_end && col + 4 <= dk) st.vv[i] = *reinterpret_cast<const mf32x4*>(va + row * ldv + col);
+        }
+    };
+    auto park_stage = [&](const Stage& st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            *reinterpret_cast<mf32x4*>(lp + (idx >> 6) * PP + 4 * (idx & 63)) = st.pp[i];
+        }
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            *reinterpret_cast<mf32x4*>(lv + (idx / (8 * CT)) * PV + 4 * (idx % (8 * CT))) = st.vv[i];
+        }
+    };
+    mf32x16 acc[2][CT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][c][i] = 0.f;
+    const bool active = kt0 + 64 * w < k;                      // (wave-uniform) this wave's 64 keys exist
+    Stage st;
+    if (r_begin < r_end) load_stage(r_begin, st);
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 32) {
+        __syncthreads();
+        park_stage(st);
+        __syncthreads();
+        if (r0 + 32 < r_end) load_stage(r0 + 32, st);
+        if (!active) continue;
+        const float* ar = lp + hf * PP + 64 * w + j;            // lane (key j of block t, half hf): rows 2 T + hf
+        const float* br = lv + hf * PV + j;
+#pragma unroll
+        for (int T = 0; T < 16; ++T) {
+            if (r0 + 2 * T >= r_end) break;                    // (wave-uniform) the slice's last chunk
+            const float a0 = ar[2 * T * PP], a1 = ar[2 * T * PP + 32];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float b = br[2 * T * PV + 32 * c];
+                acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][c], 0, 0, 0);
+                acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][c], 0, 0, 0);
+            }
+        }
+    }
+    if (!active) return;
+    float* dst = partial + ((int64_t)slice * h + a) * (int64_t)k * dk;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int col = 32 * (cb0 + c) + j;
+            if (col >= dk) continue;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ky = kt0 + 64 * w + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hf;
+                if (ky < k) dst[(int64_t)ky * dk + col] = acc[t][c][i];
+            }
+        }
+}
+
+bool g_pt_v_lds = true;      // snf_debug_exact_attn_mfma(2): the direct-from-L2 kernels (A / B partners of the LDS-staged ones)
+
 int launch_pt_v_mfma(const float* p, const float* v, int64_t n, int k, int h, int dk, int64_t rows_per_slice, int slices, float* partial,
                      hipStream_t s, int ldv = 0) {
     if (ldv == 0) ldv = h * dk;
     const int ncb = (dk + 31) / 32;
+    if (g_pt_v_lds && k % 4 == 0 && dk % 4 == 0 && ldv % 4 == 0 && (rows_per_slice & 1) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(v)) & 15) == 0 && (int64_t)slices * h <= 65535) {
+        const int ctl = ncb % 3 == 0 ? 3 : (ncb % 4 == 0 || ncb > 4) ? 4 : ncb;
+        dim3 grid((unsigned)((k + 255) / 256), (unsigned)((ncb + ctl - 1) / ctl), (unsigned)(slices * h));
+        switch (ctl) {
+            case 1: hipLaunchKernelGGL((pt_v_lds_kernel<1>), grid, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, partial, ldv); break;
+            case 2: hipLaunchKernelGGL((pt_v_lds_kernel<2>), grid, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, partial, ldv); break;
+            case 3: hipLaunchKernelGGL((pt_v_lds_kernel<3>), grid, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, partial, ldv); break;
+            default: hipLaunchKernelGGL((pt_v_lds_kernel<4>), grid, dim3(256), 0, s, p, v, n, k, h, dk, rows_per_slice, partial, ldv); break;
+        }
+        return snf::check_launch("pt_v_lds_kernel");
+    }
     const int ct = ncb % 3 == 0 ? 3 : (ncb % 4 == 0 || ncb > 4) ? 4 : ncb;          // 96 / 192 -> 3, 128 / 256 -> 4, 64 -> 2, 32 -> 1
     dim3 grid((unsigned)(((k + 31) / 32 + 1) / 2), (unsigned)((ncb + ct - 1) / ct), (unsigned)(((slices + 3) / 4) * h));
     switch (ct) {
@@ -1462,6 +1576,6 @@ int snf_sparse_attn_fwd_ragged_f32(const float* q, int64_t ldq, const float* v, 
 
 // development / test hook: 1 (default) = the exact-fp32 attention runs on the f32 matrix-core forms where the shape allows, 0 = the
 // vector-ALU kernels everywhere (the two agree to fp32 rounding: different summation orders of the same fmaf chains)
-void snf_debug_exact_attn_mfma(int on) { g_exact_mfma = on != 0, g_dq_dv_lds = on == 1; }
+void snf_debug_exact_attn_mfma(int on) { g_exact_mfma = on != 0, g_dq_dv_lds = on == 1, g_pt_v_lds = on == 1; }
 
 }  // extern "C"

@@ -388,6 +388,28 @@ def test_sparse_attn_bwd_reads_the_halves_of_a_fused_projection_in_place(n, k, h
             assert x.is_contiguous() and torch.equal(x, y)
 
 
+@pytest.mark.parametrize("n,k,h,dk", [(5000, 200, 6, 128), (30000, 500, 2, 192), (1001, 36, 3, 64), (700, 300, 2, 96), (40, 8, 1, 32)])
+def test_exact_attention_lds_staged_kernels_are_the_direct_ones_bit_for_bit(n, k, h, dk):
+    """Round 5: P^T V (forward, dKp) and dQ / dV of the exact attention stage their operands through LDS; snf_debug_exact_attn_mfma(2) selects
+    the kernels that read every operand straight from L2 -- the same fmaf chains in the same order, so every output is bit-identical."""
+    from snuffy_amd import _ffi
+    g = torch.Generator().manual_seed(n + k + dk)
+    d = h * dk
+    q, kp, v = (torch.randn(n, d, generator=g).to(DEV), torch.randn(k, d, generator=g).to(DEV), torch.randn(n, d, generator=g).to(DEV))
+    dout = torch.randn(k, d, generator=g).to(DEV)
+    mask = ops().dropout_mask(h, n, k, 0.1, 3, 5, DEV)
+    res = {}
+    try:
+        for mode in (1, 2):
+            _ffi.load().snf_debug_exact_attn_mfma(mode)
+            o, p, _ = ops().sparse_attn_fwd(q, kp, v, h, need_attn=True)
+            res[mode] = (o, p) + tuple(ops().sparse_attn_bwd(q, kp, v, p, dout, h, mask=mask)) + tuple(ops().sparse_attn_bwd(q, kp, v, p, dout, h))
+    finally:
+        _ffi.load().snf_debug_exact_attn_mfma(1)
+    for x, y in zip(res[1], res[2]):
+        assert torch.equal(x, y)
+
+
 def bf16r(t):
     return t.to(torch.bfloat16).float()
 
