@@ -400,20 +400,22 @@ __device__ __forceinline__ void x3u_split8(const mf32x8 x, xbf16x8& hi, xbf16x8&
     lo = __builtin_convertvector(x - __builtin_convertvector(hi, mf32x8), xbf16x8);
 }
 
-template <int KBW>
-__global__ __launch_bounds__(256, KBW <= 4 ? 3 : 2) void scores_softmax_x3u_kernel(const float* __restrict__ q, const float* __restrict__ kp,
-                                                                                   int64_t n, int k, int h, int dk, float scale,
-                                                                                   float* __restrict__ p_out, float* __restrict__ lse, int64_t ldq) {
+// RT = 32-row tiles per workgroup.  At RT = 1 every workgroup of 32 rows pulls the whole Kp of its head through L1 (16 key blocks x 24 KiB at
+// k = 500, dk = 192: the texture path, not the matrix pipe, sets the pace); RT = 2 uses every Kp fragment -- and its split -- for two row tiles.
+template <int KBW, int RT>
+__global__ __launch_bounds__(256, (KBW * RT <= 4) ? 3 : 2) void scores_softmax_x3u_kernel(const float* __restrict__ q, const float* __restrict__ kp,
+                                                                                          int64_t n, int k, int h, int dk, float scale,
+                                                                                          float* __restrict__ p_out, float* __restrict__ lse, int64_t ldq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     const int pitch = 4 * dk + 16;             // bytes per row: hi plane (2 dk) | lo plane (2 dk) | pad; 4 banks apart row to row
-    float* lst = reinterpret_cast<float*>(ldsb + 32 * pitch);     // [2][4][32]
+    float* lst = reinterpret_cast<float*>(ldsb + 32 * RT * pitch);     // [RT][2][4][32]
     const int a = blockIdx.y;
     const int d_model = h * dk;
-    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    const int64_t row0 = (int64_t)blockIdx.x * 32 * RT;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int j = lane & 31, hf = lane >> 5;
     const int dk4 = dk >> 2;
-    for (int e = threadIdx.x; e < 32 * dk4; e += 256) {
+    for (int e = threadIdx.x; e < 32 * RT * dk4; e += 256) {
         const int r = e / dk4, c4 = e - r * dk4;
         const int64_t row = row0 + r;
         mf32x4 val = {0.f, 0.f, 0.f, 0.f};
@@ -426,12 +428,26 @@ __global__ __launch_bounds__(256, KBW <= 4 ? 3 : 2) void scores_softmax_x3u_kern
     __syncthreads();
     const int nkb = (k + 31) >> 5;
     const int nt = dk >> 4;                    // 16-deep steps
-    mf32x16 S[KBW];
-    const unsigned char* qr = ldsb + j * pitch + 16 * hf;
+    mf32x16 S[KBW][RT];
+    const unsigned char* qr = ldsb + j * pitch + 16 * hf;          // + 32 rt pitch: row tile rt
+    auto step = [&](mf32x16 (&Sc)[RT], const mf32x4 x0, const mf32x4 x1, int t) __attribute__((always_inline)) {
+        xbf16x8 kh, kl;
+        x3u_split8(mf32x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]}, kh, kl);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const xbf16x8 qh = __builtin_bit_cast(xbf16x8, *reinterpret_cast<const xu32x4*>(qr + 32 * rt * pitch + 32 * t));
+            const xbf16x8 ql = __builtin_bit_cast(xbf16x8, *reinterpret_cast<const xu32x4*>(qr + 32 * rt * pitch + 2 * dk + 32 * t));
+            Sc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, Sc[rt], 0, 0, 0);
+            Sc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, Sc[rt], 0, 0, 0);
+            Sc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, Sc[rt], 0, 0, 0);
+        }
+    };
 #pragma unroll
     for (int c = 0; c < KBW; ++c) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) S[c][i] = 0.f;
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[c][rt][i] = 0.f;
         const int kb = w + 4 * c;
         if (kb < nkb) {
             int key = 32 * kb + j;
@@ -446,80 +462,78 @@ __global__ __launch_bounds__(256, KBW <= 4 ? 3 : 2) void scores_softmax_x3u_kern
                     x[u][1] = *reinterpret_cast<const mf32x4*>(kr + 16 * (t + u) + 4);
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    xbf16x8 kh, kl;
-                    x3u_split8(mf32x8{x[u][0][0], x[u][0][1], x[u][0][2], x[u][0][3], x[u][1][0], x[u][1][1], x[u][1][2], x[u][1][3]}, kh, kl);
-                    const xbf16x8 qh = __builtin_bit_cast(xbf16x8, *reinterpret_cast<const xu32x4*>(qr + 32 * (t + u)));
-                    const xbf16x8 ql = __builtin_bit_cast(xbf16x8, *reinterpret_cast<const xu32x4*>(qr + 2 * dk + 32 * (t + u)));
-                    S[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, S[c], 0, 0, 0);
-                    S[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, S[c], 0, 0, 0);
-                    S[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, S[c], 0, 0, 0);
-                }
+                for (int u = 0; u < 2; ++u) step(S[c], x[u][0], x[u][1], t + u);
             }
             for (; t < nt; ++t) {
                 const mf32x4 x0 = *reinterpret_cast<const mf32x4*>(kr + 16 * t), x1 = *reinterpret_cast<const mf32x4*>(kr + 16 * t + 4);
-                xbf16x8 kh, kl;
-                x3u_split8(mf32x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]}, kh, kl);
-                const xbf16x8 qh = __builtin_bit_cast(xbf16x8, *reinterpret_cast<const xu32x4*>(qr + 32 * t));
-                const xbf16x8 ql = __builtin_bit_cast(xbf16x8, *reinterpret_cast<const xu32x4*>(qr + 2 * dk + 32 * t));
-                S[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, S[c], 0, 0, 0);
-                S[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, S[c], 0, 0, 0);
-                S[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, S[c], 0, 0, 0);
+                step(S[c], x0, x1, t);
             }
         }
     }
-    float m = -INFINITY;
+    float m[RT], l[RT];
 #pragma unroll
-    for (int c = 0; c < KBW; ++c) {
-        const int kb = w + 4 * c;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hf;
-            S[c][i] = (kb < nkb && key < k) ? S[c][i] * scale : -INFINITY;
-            m = fmaxf(m, S[c][i]);
-        }
-    }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    if (hf == 0) lst[w * 32 + j] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(lst[j], lst[32 + j]), fmaxf(lst[64 + j], lst[96 + j]));
-    float l = 0.f;
-#pragma unroll
-    for (int c = 0; c < KBW; ++c)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float e = __builtin_amdgcn_exp2f((S[c][i] - m) * 1.44269504088896340736f);
-            S[c][i] = e;
-            l += e;
-        }
-    l += __shfl_xor(l, 32, 64);
-    if (hf == 0) lst[128 + w * 32 + j] = l;
-    __syncthreads();
-    l = ((lst[128 + j] + lst[160 + j]) + lst[192 + j]) + lst[224 + j];
-    const float inv = 1.0f / l;
-    const int64_t row = row0 + j;
-    if (row < n) {
-        float* prow = p_out + ((int64_t)a * n + row) * k;
-        const bool vec = (k & 3) == 0 && (reinterpret_cast<uintptr_t>(p_out) & 15) == 0;
+    for (int rt = 0; rt < RT; ++rt) {
+        m[rt] = -INFINITY;
 #pragma unroll
         for (int c = 0; c < KBW; ++c) {
             const int kb = w + 4 * c;
-            if (kb < nkb) {
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int key0 = 32 * kb + 8 * q4 + 4 * hf;
-                    const mf32x4 pv = {S[c][4 * q4] * inv, S[c][4 * q4 + 1] * inv, S[c][4 * q4 + 2] * inv, S[c][4 * q4 + 3] * inv};
-                    if (vec && key0 + 4 <= k) {
-                        *reinterpret_cast<mf32x4*>(prow + key0) = pv;
-                    } else {
+            for (int i = 0; i < 16; ++i) {
+                const int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hf;
+                S[c][rt][i] = (kb < nkb && key < k) ? S[c][rt][i] * scale : -INFINITY;
+                m[rt] = fmaxf(m[rt], S[c][rt][i]);
+            }
+        }
+        m[rt] = fmaxf(m[rt], __shfl_xor(m[rt], 32, 64));
+        if (hf == 0) lst[rt * 256 + w * 32 + j] = m[rt];
+    }
+    __syncthreads();
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (key0 + e < k) prow[key0 + e] = pv[e];
+    for (int rt = 0; rt < RT; ++rt) {
+        const float* ls = lst + rt * 256;
+        m[rt] = fmaxf(fmaxf(ls[j], ls[32 + j]), fmaxf(ls[64 + j], ls[96 + j]));
+        l[rt] = 0.f;
+#pragma unroll
+        for (int c = 0; c < KBW; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = __builtin_amdgcn_exp2f((S[c][rt][i] - m[rt]) * 1.44269504088896340736f);
+                S[c][rt][i] = e;
+                l[rt] += e;
+            }
+        l[rt] += __shfl_xor(l[rt], 32, 64);
+        if (hf == 0) lst[rt * 256 + 128 + w * 32 + j] = l[rt];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const float* ls = lst + rt * 256 + 128;
+        const float lsum = ((ls[j] + ls[32 + j]) + ls[64 + j]) + ls[96 + j];
+        const float inv = 1.0f / lsum;
+        const int64_t row = row0 + 32 * rt + j;
+        if (row < n) {
+            float* prow = p_out + ((int64_t)a * n + row) * k;
+            const bool vec = (k & 3) == 0 && (reinterpret_cast<uintptr_t>(p_out) & 15) == 0;
+#pragma unroll
+            for (int c = 0; c < KBW; ++c) {
+                const int kb = w + 4 * c;
+                if (kb < nkb) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int key0 = 32 * kb + 8 * q4 + 4 * hf;
+                        const mf32x4 pv = {S[c][rt][4 * q4] * inv, S[c][rt][4 * q4 + 1] * inv, S[c][rt][4 * q4 + 2] * inv, S[c][rt][4 * q4 + 3] * inv};
+                        if (vec && key0 + 4 <= k) {
+                            *reinterpret_cast<mf32x4*>(prow + key0) = pv;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (key0 + e < k) prow[key0 + e] = pv[e];
+                        }
                     }
                 }
             }
+            if (lse && w == 0 && hf == 0) lse[(int64_t)a * n + row] = m[rt] + logf(lsum);
         }
-        if (lse && w == 0 && hf == 0) lse[(int64_t)a * n + row] = m + logf(l);
     }
 }
 
@@ -1520,14 +1534,22 @@ int snf_sparse_attn_fwd_x3u_f32(const float* q, int64_t ldq, const float* kp, co
     float* p = attn ? attn : reinterpret_cast<float*>(workspace);
     float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (attn ? 0 : pbytes));
     hipStream_t s = snf::as_stream(stream);
-    const size_t lds = (size_t)32 * (4 * dk + 16) + 256 * sizeof(float);
-    dim3 grid1((unsigned)((n + 31) / 32), (unsigned)h);
+    // two row tiles per workgroup (every Kp fragment used twice) once the bag gives every CU a few such workgroups; up to 4 key blocks per wave
     const int kbw = ((k + 31) / 32 + 3) / 4;
-#define LAUNCH_SX(KBW) hipLaunchKernelGGL((scores_softmax_x3u_kernel<KBW>), grid1, dim3(256), lds, s, q, kp, n, k, h, dk, scale, p, lse, ldq)
-    if (kbw <= 1) LAUNCH_SX(1);
-    else if (kbw <= 2) LAUNCH_SX(2);
-    else if (kbw <= 4) LAUNCH_SX(4);
-    else LAUNCH_SX(8);
+    const int rt = (kbw <= 4 && n * h >= (int64_t)64 * 4 * snf::cu_count() && 64 * (4 * dk + 16) + 2048 <= 64 * 1024) ? 2 : 1;
+    const size_t lds = (size_t)32 * rt * (4 * dk + 16) + (size_t)rt * 256 * sizeof(float);
+    dim3 grid1((unsigned)((n + 32 * rt - 1) / (32 * rt)), (unsigned)h);
+#define LAUNCH_SX(KBW, RT) hipLaunchKernelGGL((scores_softmax_x3u_kernel<KBW, RT>), grid1, dim3(256), lds, s, q, kp, n, k, h, dk, scale, p, lse, ldq)
+    if (rt == 2) {
+        if (kbw <= 1) LAUNCH_SX(1, 2);
+        else if (kbw <= 2) LAUNCH_SX(2, 2);
+        else LAUNCH_SX(4, 2);
+    } else {
+        if (kbw <= 1) LAUNCH_SX(1, 1);
+        else if (kbw <= 2) LAUNCH_SX(2, 1);
+        else if (kbw <= 4) LAUNCH_SX(4, 1);
+        else LAUNCH_SX(8, 1);
+    }
 #undef LAUNCH_SX
     int rc = snf::check_launch("scores_softmax_x3u_kernel");
     if (rc) return rc;
