@@ -986,7 +986,9 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
     using KL = std::integral_constant<int, RLAST>;
     // LASTW (the masking variant) for every wave that holds padded keys: the last wave, and -- in merged key-chunk launches whose last
     // chunk is shorter -- every wave past that chunk's keys (wave-uniform, decided once)
-    const bool pads = 32 * KBW * (w + 1) > kk;
+    // (MODE 0 covers all keys in one launch: only its last wave has padded keys, and that wave's copy of the pipeline is specialised on
+    // its constant wave index; a second, wave-generic masking copy cost the config-B instantiation 21 spilled registers)
+    const bool pads = MODE != 0 && 32 * KBW * (w + 1) > kk;
     if constexpr (LOADER) {
         if (w == NW) {
             // ---- the loader wave: the DMA schedule of the pipeline (see run()) and its barriers, nothing else.  The per-lane source
@@ -1040,8 +1042,8 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
             }
         } else if (w == NW - 1) {
             run(KL{}, std::true_type{}, std::false_type{});
-        } else if (pads) {
-            run(KB{}, std::true_type{}, std::false_type{});
+        } else if (MODE != 0 && pads) {
+            if constexpr (MODE != 0) run(KB{}, std::true_type{}, std::false_type{});
         } else {
             run(KB{}, std::false_type{}, std::false_type{});
         }
@@ -1049,17 +1051,21 @@ __global__ __launch_bounds__(64 * x3p_waves(NKB, KBW), KBW == 2 ? 1 : 2) void sp
         // the last wave carries one key block where the others carry two: it issues all the DMA
         if (w == NW - 1)
             run(KL{}, std::true_type{}, std::true_type{});
-        else if (pads)
-            run(KB{}, std::true_type{}, std::false_type{});
-        else
+        else if (MODE != 0 && pads) {
+            if constexpr (MODE != 0) run(KB{}, std::true_type{}, std::false_type{});
+        } else
             run(KB{}, std::false_type{}, std::false_type{});
     } else {
         if (w < L0) {                                               // statistics pass, wave 0: stores the pairs, issues no DMA
-            if (pads) run(KB{}, std::true_type{}, std::false_type{}); else run(KB{}, std::false_type{}, std::false_type{});
+            if (MODE != 0 && pads) {
+                if constexpr (MODE != 0) run(KB{}, std::true_type{}, std::false_type{});
+            } else {
+                run(KB{}, std::false_type{}, std::false_type{});
+            }
         } else if (w == NW - 1) {
             run(KL{}, std::true_type{}, std::true_type{});
-        } else if (pads) {
-            run(KB{}, std::true_type{}, std::true_type{});
+        } else if (MODE != 0 && pads) {
+            if constexpr (MODE != 0) run(KB{}, std::true_type{}, std::true_type{});
         } else {
             run(KB{}, std::false_type{}, std::true_type{});
         }
