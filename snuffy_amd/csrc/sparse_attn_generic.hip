@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256) void bwd_dq_dv_kernel(const float* __restrict_
 //     dword loads; 8 CT MFMAs per 2 + 8 CT loads.
 // ---------------------------------------------------------------------------------------------------------------
 template <int KBW>
-__global__ __launch_bounds__(256, KBW <= 4 ? 3 : 2) void bwd_ds_mfma_kernel(const float* __restrict__ v, const float* __restrict__ dout,
+__global__ __launch_bounds__(256, KBW <= 2 ? 3 : 2) void bwd_ds_mfma_kernel(const float* __restrict__ v, const float* __restrict__ dout,
                                                                             const float* __restrict__ p, const float* __restrict__ mask,
                                                                             int64_t n, int k, int h, int dk, float scale,
                                                                             float* __restrict__ ds, int64_t ldv /* row pitch of v */) {
