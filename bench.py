@@ -173,9 +173,10 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
             (ops.sparse_attn_fwd_x3u(qf[i], kp, vs[i], h) if x3u else ops.sparse_attn_fwd(qf[i], kp, vs[i], h))
         # head widths outside the pipelined kernels: scores + softmax in split-bf16 x 3 (round 5) or exact on the f32 matrix cores,
         # P^T V exact on the f32 matrix cores; the vector-ALU scores kernel where neither applies
-        kern = ("scores_softmax_x3u_kernel+pt_v_mfma_kernel+reduce_slices_kernel" if x3u else
-                "scores_softmax_mfma_kernel+pt_v_mfma_kernel+reduce_slices_kernel" if dk % 8 == 0 and K <= 1024 else
-                "scores_softmax_kernel+pt_v_mfma_kernel+reduce_slices_kernel")
+        ptv = "pt_v_lds_kernel" if K % 4 == 0 and dk % 4 == 0 else "pt_v_mfma_kernel"       # (operands staged through LDS where rows are 16-byte multiples)
+        kern = ("scores_softmax_x3u_kernel+%s+reduce_slices_kernel" % ptv if x3u else
+                "scores_softmax_mfma_kernel+%s+reduce_slices_kernel" % ptv if dk % 8 == 0 and K <= 1024 else
+                "scores_softmax_kernel+%s+reduce_slices_kernel" % ptv)
         elt = 4
     # 20 launches over rotating operand sets: cold operands (every set is evicted from the 256 MiB Infinity Cache before it comes
     # back).  The bf16 kernel takes the same time inside the bag pipeline (rocprofv3: 37 + 7 us); the fp32-class kernel is faster
