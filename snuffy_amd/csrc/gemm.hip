@@ -460,10 +460,15 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
     };
     auto tile_src_mn = [&](int tm, int tn) __attribute__((always_inline)) -> Src {
         Src s;
-        const int c = lane & 7;
+        // (opaque lane index: the per-lane row / swizzle terms below are a dozen integer instructions.  Hoisted out of the tile loop as
+        // loop invariants they did not fit the K loop's registers: hipcc kept them in scratch and re-read them, one L2 round trip behind
+        // the other, in front of the last step's MFMAs of every tile -- round 5, tools/scan_spills.py)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int c = ln & 7;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int row = (4 * wid + j) * 8 + (lane >> 3);
+            const int row = (4 * wid + j) * 8 + (ln >> 3);
             int grow = tm * BM + row;
             if (grow > P.m - 1) grow = P.m - 1;
             s.a[j] = grow * (int)P.lda + ((c ^ ((row >> 1) & 7)) << 3);
