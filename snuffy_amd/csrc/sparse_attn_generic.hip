@@ -967,6 +967,10 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_dv_lds_kernel(const float* __re
         mf32x4 pa[4], sa[4], bo[CT], bk[CT];
     };
     auto load_stage = [&](int kc0, Stage& st) __attribute__((always_inline)) {
+        // (opaque indices: hoisted out of the chunk loop the per-thread address terms did not fit the registers next to 128 accumulators -- hipcc
+        // parked them in scratch and re-read each one behind a vmcnt(0) that also drained the previous operand load: recomputed per chunk instead)
+        int tix = threadIdx.x, r8 = lane >> 3, q4 = lane & 7;
+        asm volatile("" : "+v"(tix), "+v"(r8), "+v"(q4));
         const int key = kc0 + 4 * q4;
         const bool kok = key + 4 <= k;
 #pragma unroll
@@ -983,7 +987,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_dv_lds_kernel(const float* __re
         }
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
-            const int idx = threadIdx.x + 256 * i;
+            const int idx = tix + 256 * i;
             const int bkey = kc0 + idx / (8 * CT), col = 32 * cb0 + 4 * (idx % (8 * CT));
             st.bo[i] = mf32x4{0.f, 0.f, 0.f, 0.f}, st.bk[i] = mf32x4{0.f, 0.f, 0.f, 0.f};
             if (bkey < k && col + 4 <= dk) {
