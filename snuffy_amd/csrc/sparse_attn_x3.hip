@@ -183,6 +183,11 @@ __global__ __launch_bounds__(512, 2) void sparse_attn_x3_kernel(X3Params PA) {
     f32x8 qpre[QPT], vpre[VPT];                // the rows of the tile after next, in flight for a whole tile
     int fa = a, ft = t;                        // fetch cursor
     auto fetch = [&]() __attribute__((always_inline)) {
+        // (opaque thread index in the DROP instantiation: its per-thread row terms, hoisted out of the tile loop, were spilled next to the
+        // Philox state and re-read behind vmcnt(0) waits that also drained the PREVIOUS row fetch -- the next tile's loads went out one
+        // HBM round trip after the other)
+        int tid = threadIdx.x;
+        if constexpr (DROP) asm volatile("" : "+v"(tid));
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
             const int p = tid + 512 * i;
