@@ -5,10 +5,17 @@ gemm_hl_kernel, bwd_dq_dv_lds_kernel and the dropout instantiation of sparse_att
 make the spilled address terms cheaper to recompute than to keep -- an opaque copy of the lane index inside the address computation).
 Compiles every attention / GEMM translation unit to ISA with the build's flags (a few minutes) and walks the loops.
 usage: python tools/scan_loop_reloads.py"""
-sys.path.insert(0,'/root/repo')
+import glob
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from snuffy_amd import build as B
 res=[]
-for src in sorted(glob.glob('/root/repo/snuffy_amd/csrc/*.hip')):
+for src in sorted(glob.glob(os.path.join(ROOT, 'snuffy_amd', 'csrc', '*.hip'))):
     base=os.path.basename(src)
     if base in ('core.hip','sampler.hip','tiles.hip','vit.hip','rowops.hip'): continue
     flags=[f for f in B.FLAGS if f not in ('-fPIC',)]+B.EXTRA_FLAGS.get(base,[])
