@@ -417,7 +417,11 @@ int snf_layernorm_rows_hl_patch_f32(const float* x, const float* addend, int64_t
  *   snf_vit_attention_f32    exact multi-head self-attention  softmax(q k^T * scale) v                  vd:82-94
  *       qkv [b*t, 3*h*dk] f32 laid out as the reference's qkv Linear output (q | k | v, each [h][dk]);
  *       out [b*t, h*dk]; attn [b, h, t, t] nullable.  dk in {32, 64, 96, 128}.
- *   snf_vit_attention_mfma   same on the matrix cores, bf16 in / bf16 out, dk == 64, t <= 256 (else SNF_EUNSUPPORTED).
+ *   snf_vit_attention_mfma   same on the matrix cores, bf16 in / bf16 out, dk == 64, t <= SNF_VIT_MFMA_MAX_T (else
+ *       SNF_EUNSUPPORTED).  t <= 256: the keys of an (image, head) sit in one LDS image; above (the reference's patch-8 recipe,
+ *       README.md:552-565: t = 785) they are staged 256 at a time and a workgroup keeps its query tiles' softmax state across the chunks.
+ *   snf_vit_attention_x3_f32 same program in the fp32-class arithmetic (every product hi hi + hi lo + lo hi on the bf16 matrix
+ *       cores, fp32 accumulate): fp32 in / fp32 out, dk == 64, t <= SNF_VIT_MFMA_MAX_T.  Does not materialise attn.
  * --------------------------------------------------------------------------------------------------------- */
 int snf_vit_patchify(const float* img, int b, int c, int hgt, int wid, int patch, void* cols, int out_dtype,
                      snf_stream_t stream);
@@ -428,8 +432,10 @@ int snf_vit_residual_ln(float* x, int64_t n, int d, const void* add1_bf16, const
                         snf_stream_t stream);
 int snf_vit_attention_f32(const float* qkv, int b, int t, int h, int dk, float scale, float* out, float* attn,
                           snf_stream_t stream);
+#define SNF_VIT_MFMA_MAX_T 4096
 int snf_vit_attention_mfma(const void* qkv_bf16, int b, int t, int h, int dk, float scale, void* out_bf16,
                            snf_stream_t stream);
+int snf_vit_attention_x3_f32(const float* qkv, int b, int t, int h, int dk, float scale, float* out, snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Tile preprocessing for the extractor, batched on the device     replaces the per-tile CPU transforms of

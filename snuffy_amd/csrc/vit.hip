@@ -4,11 +4,12 @@
 //   snf_vit_assemble_tokens [cls ; patch embeddings] + pos_embed  -> fp32 token matrix
 //   snf_vit_residual_ln     x += a1 + s2*a2 ; LayerNorm(x) -> bf16 ; optional bf16 copy of x   (Block residuals + next norm)
 //   snf_vit_attention_f32   exact fp32 multi-head self-attention, any T / dk <= 128 (parity path, returns attn on request)
-//   snf_vit_attention_mfma  bf16 MFMA self-attention for dk = 64, T <= 256 (ViT-S/B at 224/16: T = 197):
+//   snf_vit_attention_mfma  bf16 MFMA self-attention for dk = 64 (ViT-S/B at 224/16: T = 197; keys in LDS chunks above T = 256):
 //                           S^T = K Q^T  (v_mfma_f32_32x32x16_bf16, A = K fragment from LDS, B = Q fragment from HBM):
 //                           queries land on lanes, keys in registers -> the row softmax is lane-local (+1 cross-half step),
 //                           and P^T in C layout is directly the B operand of  O^T = V^T P^T  (A = V^T fragment from an LDS
 //                           image transposed while staging).  One workgroup per (image, head); K and V^T stay in LDS.
+//   snf_vit_attention_x3_f32 the same program in the fp32-class arithmetic (split-bf16 x3 products), fp32 in / fp32 out
 #include <math.h>
 
 #include <type_traits>
@@ -300,23 +301,42 @@ __global__ __launch_bounds__(256) void vit_attention_f32_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// bf16 MFMA self-attention, dk = 64, T <= 32 * NKB.  qkv bf16 [B*T, 3*h*64]; out bf16 [B*T, h*64].
+// MFMA self-attention, dk = 64 (…dino_version.py:82-94).  qkv [B*T, 3*h*64]; out [B*T, h*64].
+//   X3 = false: bf16 in / bf16 out, one product per term.
+//   X3 = true (round 6): fp32 in / fp32 out in the fp32-class arithmetic of the aggregator -- every operand is hi + lo
+//          (hi = bf16(x), lo = bf16(x - hi)), every product hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_bf16 with fp32
+//          accumulation; Q is split in registers, K and V are staged as two LDS images each, P is split in registers.
+//   CHUNK = false: all keys of the (image, head) fit one LDS image (T <= 32 NKB); a workgroup serves one (image, head), wave
+//          w the query tiles w, w + 8, ..
+//   CHUNK = true (round 6, the reference's patch-8 recipe: T = 785): keys are staged 32 NKB at a time; a workgroup serves `tpw`
+//          query tiles of one (image, head) (blockIdx.z picks them, one per wave) and keeps each tile's running maximum / sum /
+//          output accumulator in registers across the key chunks (that state lives across the staging: 256-register waves,
+//          one workgroup per CU -- under the 128-register bound of the one-image form the chunked bf16 kernel spilled 85).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int VIT_ATTN_THREADS = 512;   // 8 waves: one 32-query tile each (T = 197 -> 7 tiles in one round)
-template <int NKB>
-__global__ __launch_bounds__(VIT_ATTN_THREADS, 4) void vit_attention_mfma_kernel(const unsigned short* __restrict__ qkv, int B,
-                                                                                 int T, int h, float scale,
-                                                                                 unsigned short* __restrict__ out) {
+__device__ __forceinline__ void vit_split8(const f32x8 x, bf16x8& hi, bf16x8& lo) {
+    hi = __builtin_convertvector(x, bf16x8);
+    lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x8), bf16x8);
+}
+template <int NKB, bool CHUNK, bool X3>
+__global__ __launch_bounds__(VIT_ATTN_THREADS, (X3 || CHUNK) ? 2 : 4) void vit_attention_mfma_kernel(const void* __restrict__ qkv_, int B, int T,
+                                                                                          int h, float scale, void* __restrict__ out_,
+                                                                                          int tpw) {
     constexpr int DK = 64;
     constexpr int NW = VIT_ATTN_THREADS / 64;   // waves per workgroup = query tiles in flight
+    constexpr int NP = X3 ? 2 : 1;            // operand planes (hi, lo)
     constexpr int KPITCH = DK + 8;            // bf16 elements; 144 B rows: conflict-free ds_read_b128 of a K fragment
+    constexpr int KBYTES = 32 * NKB * KPITCH * 2, VBYTES = 32 * NKB * 128;
+    typedef typename std::conditional<X3, float, unsigned short>::type elt_t;
+    const elt_t* __restrict__ qkv = reinterpret_cast<const elt_t*>(qkv_);
+    elt_t* __restrict__ out = reinterpret_cast<elt_t*>(out_);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned short* lds_k = reinterpret_cast<unsigned short*>(smem);                       // [32*NKB][KPITCH]
+    // K planes [NP][32*NKB][KPITCH]; V planes [NP][32*NKB][128 B].
     // V stays ROW-major in LDS ([key][64], 128-byte rows, 16-byte chunk c of row r at chunk position (c + 4*((r>>1)&1)) & 7):
     // the A operand of O^T = V^T P^T (lane = d, 8 keys in registers) is read back with the hardware transpose-read
     // ds_read_b64_tr_b16, so staging is one 16-byte store per chunk instead of eight 2-byte transposing stores.  The
     // rotation spreads the 4 rows x 64 bytes a transpose-read group touches over all 64 banks.
-    unsigned char* lds_v = smem + 32 * NKB * KPITCH * 2;                                     // [32*NKB][128 B]
+    unsigned char* const lds_v0 = smem + NP * KBYTES;
     const int a = blockIdx.x, b = blockIdx.y;
     const int D = h * DK;
     const int64_t base = (int64_t)b * T;
@@ -324,57 +344,93 @@ __global__ __launch_bounds__(VIT_ATTN_THREADS, 4) void vit_attention_mfma_kernel
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, hf = lane >> 5;
 
-    // this wave's first query tile is requested before anything else (B operand: lane = query, 8 consecutive dk per k-step)
+    // B operand of S^T = K Q^T: lane = query, 8 consecutive dk per k-step
     const int ntile = (T + 31) / 32;
-    bf16x8 qf[4];
+    bf16x8 qf[4], ql[X3 ? 4 : 1];
     auto load_q = [&](int tile) __attribute__((always_inline)) {
         int qrow = 32 * tile + j;
         if (qrow > T - 1) qrow = T - 1;
-        const unsigned short* qp = qkv + (base + qrow) * 3 * D + a * DK + 8 * hf;
+        const elt_t* qp = qkv + (base + qrow) * 3 * D + a * DK + 8 * hf;
         static_for<0, 4>([&](auto ks) __attribute__((always_inline)) {
-            qf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp + 16 * ks));
+            if constexpr (X3) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + 16 * ks), x1 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
+                vit_split8(f32x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]}, qf[ks], ql[ks]);
+            } else {
+                qf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp + 16 * ks));
+            }
         });
     };
-    if (w < ntile) load_q(w);
-
-    // stage K and V of this (image, head): every global load of the thread is issued before the first LDS store (one
-    // memory latency for the whole tile, not one per chunk); rows >= T are zero
+    // stage the keys k0 .. k0 + 32 NKB - 1 of this (image, head): every global load of the thread is issued before the first
+    // LDS store (one memory latency for the whole image, not one per chunk); rows >= T are zero
     constexpr int NI = (32 * NKB * 8 + VIT_ATTN_THREADS - 1) / VIT_ATTN_THREADS;
-    {
-        u32x4 kst[NI], vst[NI];
+    auto stage = [&](int k0) __attribute__((always_inline)) {
+        if constexpr (X3) {
+            f32x8 kst[NI], vst[NI];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int c = threadIdx.x + VIT_ATTN_THREADS * i;
-            const int key = c >> 3, part = c & 7;
-            kst[i] = u32x4{0u, 0u, 0u, 0u};
-            vst[i] = u32x4{0u, 0u, 0u, 0u};
-            if (key < T) {
-                const unsigned short* rowp = qkv + (base + key) * 3 * D + a * DK + part * 8;
-                kst[i] = *reinterpret_cast<const u32x4*>(rowp + D);
-                vst[i] = *reinterpret_cast<const u32x4*>(rowp + 2 * D);
+            for (int i = 0; i < NI; ++i) {
+                const int c = threadIdx.x + VIT_ATTN_THREADS * i;
+                const int key = k0 + (c >> 3), part = c & 7;
+                kst[i] = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                vst[i] = kst[i];
+                if (key < T && (c >> 3) < 32 * NKB) {
+                    const float* rowp = qkv + (base + key) * 3 * D + a * DK + part * 8;
+                    const f32x4 k0v = *reinterpret_cast<const f32x4*>(rowp + D), k1v = *reinterpret_cast<const f32x4*>(rowp + D + 4);
+                    const f32x4 v0v = *reinterpret_cast<const f32x4*>(rowp + 2 * D), v1v = *reinterpret_cast<const f32x4*>(rowp + 2 * D + 4);
+                    kst[i] = f32x8{k0v[0], k0v[1], k0v[2], k0v[3], k1v[0], k1v[1], k1v[2], k1v[3]};
+                    vst[i] = f32x8{v0v[0], v0v[1], v0v[2], v0v[3], v1v[0], v1v[1], v1v[2], v1v[3]};
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int c = threadIdx.x + VIT_ATTN_THREADS * i;
+                const int key = c >> 3, part = c & 7;
+                if (key < 32 * NKB) {
+                    bf16x8 kh, kl, vh, vl;
+                    vit_split8(kst[i], kh, kl);
+                    vit_split8(vst[i], vh, vl);
+                    unsigned char* kp = smem + (key * KPITCH + part * 8) * 2;
+                    unsigned char* vp = lds_v0 + key * 128 + 16 * ((part + 4 * ((key >> 1) & 1)) & 7);
+                    *reinterpret_cast<u32x4*>(kp) = __builtin_bit_cast(u32x4, kh);
+                    *reinterpret_cast<u32x4*>(kp + KBYTES) = __builtin_bit_cast(u32x4, kl);
+                    *reinterpret_cast<u32x4*>(vp) = __builtin_bit_cast(u32x4, vh);
+                    *reinterpret_cast<u32x4*>(vp + VBYTES) = __builtin_bit_cast(u32x4, vl);
+                }
+            }
+        } else {
+            u32x4 kst[NI], vst[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int c = threadIdx.x + VIT_ATTN_THREADS * i;
+                const int key = k0 + (c >> 3), part = c & 7;
+                kst[i] = u32x4{0u, 0u, 0u, 0u};
+                vst[i] = u32x4{0u, 0u, 0u, 0u};
+                if (key < T && (c >> 3) < 32 * NKB) {
+                    const unsigned short* rowp = qkv + (base + key) * 3 * D + a * DK + part * 8;
+                    kst[i] = *reinterpret_cast<const u32x4*>(rowp + D);
+                    vst[i] = *reinterpret_cast<const u32x4*>(rowp + 2 * D);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int c = threadIdx.x + VIT_ATTN_THREADS * i;
+                const int key = c >> 3, part = c & 7;
+                if (key < 32 * NKB) {
+                    *reinterpret_cast<u32x4*>(smem + (key * KPITCH + part * 8) * 2) = kst[i];
+                    *reinterpret_cast<u32x4*>(lds_v0 + key * 128 + 16 * ((part + 4 * ((key >> 1) & 1)) & 7)) = vst[i];
+                }
             }
         }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int c = threadIdx.x + VIT_ATTN_THREADS * i;
-            const int key = c >> 3, part = c & 7;
-            if (key < 32 * NKB) {
-                *reinterpret_cast<u32x4*>(lds_k + key * KPITCH + part * 8) = kst[i];
-                *reinterpret_cast<u32x4*>(lds_v + key * 128 + 16 * ((part + 4 * ((key >> 1) & 1)) & 7)) = vst[i];
-            }
-        }
-    }
-    __syncthreads();
+    };
     // transpose-read addressing of a V^T fragment (d block db, keys k_base ..): this lane's 16-lane group g covers
     // d = 32 db + 16 (g & 1) + i, keys k_base + 4 (g >> 1) + {0..3} (first read) and the same + 8 (second)
     const int tg = lane >> 4, ti = lane & 15;
     const int vkey = 4 * (tg >> 1) + (ti >> 2);                 // the row this lane's chunk comes from
     const int vch = 2 * (tg & 1) + ((ti & 3) >> 1);             // 16-byte chunk inside the 64-byte d block, + 4 db
     const int vhalf = 8 * (ti & 1);
-    auto v_frag = [&](int k_base, int db) __attribute__((always_inline)) -> bf16x8 {
+    auto v_frag = [&](int plane, int k_base, int db) __attribute__((always_inline)) -> bf16x8 {
         const int r0 = k_base + vkey, r1 = r0 + 8;
-        const unsigned char* p0 = lds_v + r0 * 128 + 16 * ((vch + 4 * db + 4 * ((r0 >> 1) & 1)) & 7) + vhalf;
-        const unsigned char* p1 = lds_v + r1 * 128 + 16 * ((vch + 4 * db + 4 * ((r1 >> 1) & 1)) & 7) + vhalf;
+        const unsigned char* p0 = lds_v0 + plane * VBYTES + r0 * 128 + 16 * ((vch + 4 * db + 4 * ((r0 >> 1) & 1)) & 7) + vhalf;
+        const unsigned char* p1 = lds_v0 + plane * VBYTES + r1 * 128 + 16 * ((vch + 4 * db + 4 * ((r1 >> 1) & 1)) & 7) + vhalf;
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
@@ -383,98 +439,155 @@ __global__ __launch_bounds__(VIT_ATTN_THREADS, 4) void vit_attention_mfma_kernel
     };
 
     const float c_exp = scale * 1.44269504088896340736f;
-    for (int tile = w; tile < ntile; tile += NW) {
-        if (tile != w) load_q(tile);
-        // Flash-style pass over the key blocks: S^T block = K_jb Q^T (keys in registers, this lane's query on the lane), online
-        // softmax with a running maximum, O^T += V^T P^T with P^T straight from the C registers.  ~100 registers per wave
-        // instead of 16*NKB + ... for the whole score row: two workgroups of eight waves stay resident per CU.
-        f32x16 o_acc[2];
+    // Flash-style pass over the key blocks: S^T block = K_jb Q^T (keys in registers, this lane's query on the lane), online
+    // softmax with a running maximum, O^T += V^T P^T with P^T straight from the C registers.  ~100 registers per wave
+    // instead of 16*NKB + ... for the whole score row: two workgroups of eight waves stay resident per CU (bf16 form).
+    f32x16 o_acc[2];
+    float m_run, l_lane;                      // running max (all-reduced over the two half-waves), lane-local sum
+    auto reset = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             o_acc[0][r] = 0.f;
             o_acc[1][r] = 0.f;
         }
-        float m_run = -INFINITY, l_lane = 0.f;   // running max (all-reduced over the two half-waves), lane-local sum
-#pragma unroll 1   // a rolled loop: unrolled, the per-block LDS addresses alone cost ~70 registers (two workgroups per CU need <= 128)
-        for (int jb = 0; jb < NKB; ++jb) {
-            f32x16 s_acc;
+        m_run = -INFINITY, l_lane = 0.f;
+    };
+    // key block jb of the staged image; its first key is key kg0 of the (image, head); first: no accumulator to rescale yet
+    auto block = [&](int jb, int kg0, bool first) __attribute__((always_inline)) {
+        f32x16 s_acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kg0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            s_acc[r] = (key >= T) ? -INFINITY : 0.f;
+        }
+        static_for<0, 4>([&](auto ks) __attribute__((always_inline)) {
+            const unsigned char* kp = smem + ((32 * jb + j) * KPITCH + 16 * ks + 8 * hf) * 2;
+            const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(kp));
+            if constexpr (X3) {
+                const bf16x8 kl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(kp + KBYTES));
+                s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, ql[ks], s_acc, 0, 0, 0);
+                s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[ks], s_acc, 0, 0, 0);
+            }
+            s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc, 0, 0, 0);
+        });
+        float mb0 = fmaxf(s_acc[0], s_acc[1]), mb1 = fmaxf(s_acc[2], s_acc[3]);
+#pragma unroll
+        for (int r = 4; r < 16; r += 4) {
+            mb0 = fmaxf(fmaxf(mb0, s_acc[r]), s_acc[r + 1]);
+            mb1 = fmaxf(fmaxf(mb1, s_acc[r + 2]), s_acc[r + 3]);
+        }
+        float mb = fmaxf(mb0, mb1);
+        mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+        // the first block always holds a valid key, so m_new is finite from the first block on
+        const float m_new = fmaxf(m_run, mb);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);   // exp2(-inf) = 0 on the first block
+        const float mc = m_new * c_exp;
+        m_run = m_new;
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(s_acc[r], c_exp, -mc));
+            s_acc[r] = e;
+            lsum += e;
+        }
+        l_lane = fmaf(l_lane, alpha, lsum);
+        if (!first) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = 32 * jb + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                s_acc[r] = (key >= T) ? -INFINITY : 0.f;
+                o_acc[0][r] *= alpha;
+                o_acc[1][r] *= alpha;
             }
-            static_for<0, 4>([&](auto ks) __attribute__((always_inline)) {
-                bf16x8 kf = __builtin_bit_cast(
-                    bf16x8, *reinterpret_cast<const u32x4*>(lds_k + (32 * jb + j) * KPITCH + 16 * ks + 8 * hf));
-                s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc, 0, 0, 0);
-            });
-            float mb0 = fmaxf(s_acc[0], s_acc[1]), mb1 = fmaxf(s_acc[2], s_acc[3]);
+        }
+        static_for<0, 2>([&](auto u_t) __attribute__((always_inline)) {
+            constexpr int u = decltype(u_t)::value;
+            f32x8 pv;
 #pragma unroll
-            for (int r = 4; r < 16; r += 4) {
-                mb0 = fmaxf(fmaxf(mb0, s_acc[r]), s_acc[r + 1]);
-                mb1 = fmaxf(fmaxf(mb1, s_acc[r + 2]), s_acc[r + 3]);
-            }
-            float mb = fmaxf(mb0, mb1);
-            mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
-            // block 0 always holds a valid key, so m_new is finite from the first block on
-            const float m_new = fmaxf(m_run, mb);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);   // exp2(-inf) = 0 on the first block
-            const float mc = m_new * c_exp;
-            m_run = m_new;
-            float lsum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(s_acc[r], c_exp, -mc));
-                s_acc[r] = e;
-                lsum += e;
-            }
-            l_lane = fmaf(l_lane, alpha, lsum);
-            if (jb > 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    o_acc[0][r] *= alpha;
-                    o_acc[1][r] *= alpha;
-                }
-            }
-            static_for<0, 2>([&](auto u_t) __attribute__((always_inline)) {
-                constexpr int u = decltype(u_t)::value;
-                f32x8 pv;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pv[e] = s_acc[8 * u + e];
-                const bf16x8 pf = __builtin_convertvector(pv, bf16x8);
-                // this lane's 8 keys of the k-step: {16u + 4hf + 0..3} and {16u + 8 + 4hf + 0..3} of block jb
+            for (int e = 0; e < 8; ++e) pv[e] = s_acc[8 * u + e];
+            // this lane's 8 keys of the k-step: {16u + 4hf + 0..3} and {16u + 8 + 4hf + 0..3} of block jb
+            if constexpr (X3) {
+                bf16x8 ph, pl;
+                vit_split8(pv, ph, pl);
                 static_for<0, 2>([&](auto db_t) __attribute__((always_inline)) {
                     constexpr int db = decltype(db_t)::value;
-                    o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(32 * jb + 16 * u, db), pf, o_acc[db], 0, 0, 0);
+                    const bf16x8 vh = v_frag(0, 32 * jb + 16 * u, db), vl = v_frag(1, 32 * jb + 16 * u, db);
+                    o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o_acc[db], 0, 0, 0);
+                    o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o_acc[db], 0, 0, 0);
+                    o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o_acc[db], 0, 0, 0);
                 });
-            });
-        }
+            } else {
+                const bf16x8 pf = __builtin_convertvector(pv, bf16x8);
+                static_for<0, 2>([&](auto db_t) __attribute__((always_inline)) {
+                    constexpr int db = decltype(db_t)::value;
+                    o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(0, 32 * jb + 16 * u, db), pf, o_acc[db], 0, 0, 0);
+                });
+            }
+        });
+    };
+    // store O of query tile `tile`: lane = query row, 4 consecutive d per register group
+    auto finish = [&](int tile) __attribute__((always_inline)) {
         const float l = l_lane + __shfl_xor(l_lane, 32, 64);
         const float inv = __builtin_amdgcn_rcpf(l);
-        // store O: lane = query row, 4 consecutive d per register group
         const int q_out = 32 * tile + j;
         if (q_out < T) {
-            unsigned short* op = out + (base + q_out) * D + a * DK;
+            elt_t* op = out + (base + q_out) * D + a * DK;
             static_for<0, 2>([&](auto db) __attribute__((always_inline)) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int d0 = 32 * db + 8 * g + 4 * hf;
-                    u32x2 o = {pack_bf16x2(o_acc[db][4 * g] * inv, o_acc[db][4 * g + 1] * inv),
-                               pack_bf16x2(o_acc[db][4 * g + 2] * inv, o_acc[db][4 * g + 3] * inv)};
-                    *reinterpret_cast<u32x2*>(op + d0) = o;
+                    if constexpr (X3) {
+                        *reinterpret_cast<f32x4*>(op + d0) = f32x4{o_acc[db][4 * g] * inv, o_acc[db][4 * g + 1] * inv,
+                                                                   o_acc[db][4 * g + 2] * inv, o_acc[db][4 * g + 3] * inv};
+                    } else {
+                        u32x2 o = {pack_bf16x2(o_acc[db][4 * g] * inv, o_acc[db][4 * g + 1] * inv),
+                                   pack_bf16x2(o_acc[db][4 * g + 2] * inv, o_acc[db][4 * g + 3] * inv)};
+                        *reinterpret_cast<u32x2*>(op + d0) = o;
+                    }
                 }
             });
+        }
+    };
+
+    if constexpr (CHUNK) {
+        const int tile = tpw * blockIdx.z + w;
+        const bool active = w < tpw && tile < ntile;   // wave-uniform
+        load_q(active ? tile : ntile - 1);
+        reset();
+        for (int k0 = 0; k0 < T; k0 += 32 * NKB) {
+            if (k0) __syncthreads();              // every wave is done with the previous chunk's image
+            stage(k0);
+            __syncthreads();
+            if (active) {
+#pragma unroll 1
+                for (int jb = 0; jb < NKB; ++jb) {
+                    if (k0 + 32 * jb >= T) break;
+                    block(jb, k0 + 32 * jb, k0 == 0 && jb == 0);
+                }
+            }
+        }
+        if (active) finish(tile);
+    } else {
+        // this wave's first query tile is requested before anything else
+        if (w < ntile) load_q(w);
+        stage(0);
+        __syncthreads();
+        for (int tile = w; tile < ntile; tile += NW) {
+            if (tile != w) load_q(tile);
+            reset();
+#pragma unroll 1   // a rolled loop: unrolled, the per-block LDS addresses alone cost ~70 registers (two workgroups per CU need <= 128)
+            for (int jb = 0; jb < NKB; ++jb) block(jb, 32 * jb, jb == 0);
+            finish(tile);
         }
     }
 }
 
-template <int NKB>
-int launch_vit_mfma(const unsigned short* qkv, int B, int T, int h, float scale, unsigned short* out, hipStream_t s) {
-    const size_t lds = (size_t)(32 * NKB * (64 + 8)) * sizeof(unsigned short) + (size_t)32 * NKB * 128;
+template <int NKB, bool CHUNK, bool X3>
+int launch_vit_mfma(const void* qkv, int B, int T, int h, float scale, void* out, hipStream_t s) {
+    constexpr size_t lds = (size_t)(X3 ? 2 : 1) * ((size_t)(32 * NKB * (64 + 8)) * sizeof(unsigned short) + (size_t)32 * NKB * 128);
+    static_assert(lds <= 160 * 1024, "vit_attention_mfma: LDS budget");
     static thread_local unsigned long long attr_set_mask = 0;   // devices (bit = device id) that have the opt-in
     const unsigned long long attr_set_bit = snf::device_bit();
     const bool attr_set = (attr_set_mask & attr_set_bit) != 0;
-    auto kern = vit_attention_mfma_kernel<NKB>;
+    auto kern = vit_attention_mfma_kernel<NKB, CHUNK, X3>;
     if (!attr_set && lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess) {
@@ -484,7 +597,11 @@ int launch_vit_mfma(const unsigned short* qkv, int B, int T, int h, float scale,
         }
         attr_set_mask |= attr_set_bit;
     }
-    hipLaunchKernelGGL(kern, dim3(h, B), dim3(VIT_ATTN_THREADS), lds, s, qkv, B, T, h, scale, out);
+    // chunked keys: a workgroup serves tpw <= 8 query tiles (one per wave); the tiles are spread evenly over the workgroups
+    const int ntile = (T + 31) / 32;
+    const int nz = CHUNK ? (ntile + 7) / 8 : 1;
+    const int tpw = CHUNK ? (ntile + nz - 1) / nz : 0;
+    hipLaunchKernelGGL(kern, dim3(h, B, nz), dim3(VIT_ATTN_THREADS), lds, s, qkv, B, T, h, scale, out, tpw);
     return snf::check_launch("vit_attention_mfma_kernel");
 }
 
@@ -576,19 +693,34 @@ int snf_vit_attention_mfma(const void* qkv_bf16, int b, int t, int h, int dk, fl
                            snf_stream_t stream) {
     SNF_REQUIRE(qkv_bf16 && out_bf16, "snf_vit_attention_mfma: null pointer");
     SNF_REQUIRE(b >= 1 && t >= 1 && h >= 1, "snf_vit_attention_mfma: bad shape");
-    if (dk != 64 || t > 256 || b > 65535) {
-        snf::set_error("snf_vit_attention_mfma: unsupported shape dk=%d t=%d (need dk == 64, t <= 256)", dk, t);
+    if (dk != 64 || t > SNF_VIT_MFMA_MAX_T || b > 65535) {
+        snf::set_error("snf_vit_attention_mfma: unsupported shape dk=%d t=%d (need dk == 64, t <= %d)", dk, t, SNF_VIT_MFMA_MAX_T);
         return SNF_EUNSUPPORTED;
     }
     SNF_REQUIRE((reinterpret_cast<uintptr_t>(qkv_bf16) & 15) == 0, "snf_vit_attention_mfma: qkv must be 16-byte aligned");
     hipStream_t s = snf::as_stream(stream);
-    const unsigned short* q = reinterpret_cast<const unsigned short*>(qkv_bf16);
-    unsigned short* o = reinterpret_cast<unsigned short*>(out_bf16);
     const int nkb = (t + 31) / 32;
-    if (nkb <= 2) return launch_vit_mfma<2>(q, b, t, h, scale, o, s);
-    if (nkb <= 4) return launch_vit_mfma<4>(q, b, t, h, scale, o, s);
-    if (nkb <= 7) return launch_vit_mfma<7>(q, b, t, h, scale, o, s);
-    return launch_vit_mfma<8>(q, b, t, h, scale, o, s);
+    if (nkb <= 2) return launch_vit_mfma<2, false, false>(qkv_bf16, b, t, h, scale, out_bf16, s);
+    if (nkb <= 4) return launch_vit_mfma<4, false, false>(qkv_bf16, b, t, h, scale, out_bf16, s);
+    if (nkb <= 7) return launch_vit_mfma<7, false, false>(qkv_bf16, b, t, h, scale, out_bf16, s);
+    if (nkb <= 8) return launch_vit_mfma<8, false, false>(qkv_bf16, b, t, h, scale, out_bf16, s);
+    return launch_vit_mfma<8, true, false>(qkv_bf16, b, t, h, scale, out_bf16, s);   // keys in chunks of 256 (patch 8: t = 785)
+}
+
+int snf_vit_attention_x3_f32(const float* qkv, int b, int t, int h, int dk, float scale, float* out, snf_stream_t stream) {
+    SNF_REQUIRE(qkv && out, "snf_vit_attention_x3_f32: null pointer");
+    SNF_REQUIRE(b >= 1 && t >= 1 && h >= 1, "snf_vit_attention_x3_f32: bad shape");
+    if (dk != 64 || t > SNF_VIT_MFMA_MAX_T || b > 65535) {
+        snf::set_error("snf_vit_attention_x3_f32: unsupported shape dk=%d t=%d (need dk == 64, t <= %d)", dk, t, SNF_VIT_MFMA_MAX_T);
+        return SNF_EUNSUPPORTED;
+    }
+    SNF_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15) == 0, "snf_vit_attention_x3_f32: qkv must be 16-byte aligned");
+    hipStream_t s = snf::as_stream(stream);
+    const int nkb = (t + 31) / 32;
+    if (nkb <= 2) return launch_vit_mfma<2, false, true>(qkv, b, t, h, scale, out, s);
+    if (nkb <= 4) return launch_vit_mfma<4, false, true>(qkv, b, t, h, scale, out, s);
+    if (nkb <= 7) return launch_vit_mfma<7, false, true>(qkv, b, t, h, scale, out, s);
+    return launch_vit_mfma<7, true, true>(qkv, b, t, h, scale, out, s);               // keys in chunks of 224
 }
 
 }  // extern "C"

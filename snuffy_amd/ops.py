@@ -1447,9 +1447,10 @@ def vit_residual_ln_(x, add1=None, add2=None, scale2=1.0, gamma=None, beta=None,
     return ln, xb
 
 
-def vit_attention(qkv, b, t, heads, scale=None, need_attn=False):
-    """Multi-head self-attention on the qkv Linear output [B*T, 3*D].  fp32 -> exact kernel (+ optional attn [B,h,T,T]);
-    bf16 -> MFMA kernel (dk == 64, T <= 256)."""
+def vit_attention(qkv, b, t, heads, scale=None, need_attn=False, arithmetic="exact"):
+    """Multi-head self-attention on the qkv Linear output [B*T, 3*D].  fp32 -> exact kernel (+ optional attn [B,h,T,T]), or with
+    arithmetic="x3" (and no attn asked for, dk == 64) the MFMA kernel in split-bf16 x3 products; bf16 -> MFMA kernel (dk == 64,
+    T <= VIT_MFMA_MAX_T; keys in LDS chunks above T = 256)."""
     d3 = qkv.shape[1]
     d = d3 // 3
     dk = d // heads
@@ -1458,6 +1459,9 @@ def vit_attention(qkv, b, t, heads, scale=None, need_attn=False):
     if qkv.dtype == torch.float32:
         qkv = _req(qkv, torch.float32, "qkv", 2)
         out = torch.empty(b * t, d, dtype=torch.float32, device=qkv.device)
+        if arithmetic == "x3" and not need_attn and vit_mfma_attention_supported(t, dk):
+            check(lib.snf_vit_attention_x3_f32(_p(qkv), b, t, heads, dk, float(scale), _p(out), _stream()), "snf_vit_attention_x3_f32")
+            return out, None
         attn = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device) if need_attn else None
         check(lib.snf_vit_attention_f32(_p(qkv), b, t, heads, dk, float(scale), _p(out), _p(attn), _stream()),
               "snf_vit_attention_f32")
@@ -1470,5 +1474,8 @@ def vit_attention(qkv, b, t, heads, scale=None, need_attn=False):
     return out, None
 
 
+VIT_MFMA_MAX_T = 4096    # SNF_VIT_MFMA_MAX_T of include/snuffy_hip.h
+
+
 def vit_mfma_attention_supported(t, dk):
-    return dk == 64 and t <= 256
+    return dk == 64 and t <= VIT_MFMA_MAX_T

@@ -214,7 +214,9 @@ class Attention(nn.Module):
         """x2: [B * N, C] f32 or its SplitImage."""
         C = self.proj.weight.shape[0]
         qkv = linear_f32(x2, self.qkv.weight, self.qkv.bias)
-        o, attn = ops.vit_attention(qkv, B, N, self.num_heads, self.scale, need_attn=need_attn)
+        # fp32-class arithmetic (the projections' own): the attention on the matrix cores too; exact fp32 with the plain-fp32 GEMMs
+        o, attn = ops.vit_attention(qkv, B, N, self.num_heads, self.scale, need_attn=need_attn,
+                                    arithmetic="x3" if FP32_GEMM == "x3" else "exact")
         return linear_f32(o, self.proj.weight, self.proj.bias).view(B, N, C), attn
 
 

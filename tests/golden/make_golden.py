@@ -424,6 +424,11 @@ def run_f7_f8():
             img_size=224, patch_size=16, embed_dim=128, depth=2, num_heads=2, decoder_embed_dim=32, decoder_depth=1,
             decoder_num_heads=2, mlp_ratio=4, norm_layer=ln, adapter_ffn_scalar="1.0", adapter_ffn_num=8,
             adapter_d_model=128), dict(kind="mae_adapter", patch=16, dim=128, depth=2, heads=2, ffn=8, scalar=1.0)),
+        # the reference's own extractor recipe for DINO-adapter is --patch_size=8 (README.md:552-565): 224 / 8 -> T = 785 tokens
+        ("f7_dino_adapter_p8", lambda: vit_adapter.VisionTransformer(
+            patch_size=8, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4, qkv_bias=True, norm_layer=ln,
+            adapter_ffn_layernorm_option="none", adapter_ffn_init_option="lora", adapter_ffn_scalar="10",
+            adapter_ffn_num=32, adapter_d_model=128), dict(kind="dino_adapter", patch=8, dim=128, depth=2, heads=2, ffn=32, scalar=10.0)),
     ]
     for i, (name, ctor, meta) in enumerate(cases):
         torch.manual_seed(40 + i)

@@ -80,7 +80,8 @@ def test_vit_attention_exact(b, t, h, dk):
     assert rel_err(o.cpu(), o_ref) < 1e-5
 
 
-@pytest.mark.parametrize("b,t,h", [(2, 197, 6), (3, 50, 3), (1, 1, 1), (2, 256, 2), (4, 100, 12), (2, 150, 2), (1, 33, 1)])
+@pytest.mark.parametrize("b,t,h", [(2, 197, 6), (3, 50, 3), (1, 1, 1), (2, 256, 2), (4, 100, 12), (2, 150, 2), (1, 33, 1),
+                                   (2, 785, 6), (1, 257, 2), (3, 512, 1), (1, 1030, 2), (2, 300, 3)])   # > 256: keys in LDS chunks
 def test_vit_attention_mfma(b, t, h):
     g = torch.Generator().manual_seed(t + h)
     qkv = (torch.randn(b * t, 3 * h * 64, generator=g) * 1.5).to(torch.bfloat16)
@@ -90,6 +91,24 @@ def test_vit_attention_mfma(b, t, h):
     assert rel_err(o.cpu().float(), o_ref) < 1.5e-2           # P and O are rounded to bf16 (2^-8 relative)
     o2, _ = ops().vit_attention(qkv.to(DEV), b, t, h)
     assert torch.equal(o, o2)
+
+
+@pytest.mark.parametrize("b,t,h", [(2, 197, 6), (3, 50, 3), (1, 1, 1), (2, 224, 2), (2, 225, 2), (4, 100, 12), (1, 33, 1),
+                                   (2, 785, 6), (1, 449, 2), (1, 1030, 1)])
+def test_vit_attention_x3(b, t, h):
+    """fp32-class self-attention on the matrix cores (split-bf16 x3 products) against fp64: the aggregator's arithmetic class."""
+    g = torch.Generator().manual_seed(7 * t + h)
+    qkv = torch.randn(b * t, 3 * h * 64, generator=g) * 1.5
+    o_ref, _ = ref_attention(qkv, b, t, h)
+    o, attn = ops().vit_attention(qkv.to(DEV), b, t, h, arithmetic="x3")
+    assert o.dtype == torch.float32 and attn is None
+    e = rel_err(o.cpu(), o_ref)
+    print("MEASURED vit x3 attention", (b, t, h), e)
+    assert e < 5e-5
+    o2, _ = ops().vit_attention(qkv.to(DEV), b, t, h, arithmetic="x3")
+    assert torch.equal(o, o2)
+    oe, _ = ops().vit_attention(qkv.to(DEV), b, t, h)                       # exact kernel: the cross-check on the device
+    assert rel_err(o.cpu(), oe.cpu()) < 5e-5
 
 
 def build(z):
