@@ -368,6 +368,18 @@ int snf_sparse_attn_dkp_f32(const float* ds, const float* q, int64_t n, int k, i
  * --------------------------------------------------------------------------------------------------------- */
 int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t m, int n, int k,
                   int act, void* c, int64_t ldc, int out_dtype, int tile_n, snf_stream_t stream);
+/* The ViT block without LayerNorm / residual passes (round 6; vd:97-127 "x = x + attn(norm1(x)); x = x + mlp(norm2(x)) + adapter(x)"):
+ *   snf_gemm_bf16_lnfold   the consumer's LayerNorm folded into its GEMM: a = the RAW rows x rounded to bf16, w = W0 diag(gamma) (bf16),
+ *                          c [m, ldc] bf16 = act(rstd[m] (a w^T - mean[m] colsum[n]) + bias[n]);  colsum[n] = sum_k w[n, k] of the ROUNDED w,
+ *                          bias = W0 beta + b0, rowstats [m][2] = (mean, rstd) of the fp32 rows (snf_vit_row_stats).  act: none, gelu.
+ *   snf_gemm_bf16_resid    the residual stream updated by the producer: x [m, ldx] fp32 IN PLACE  x += a w^T + bias; the bf16 copy of
+ *                          the new x goes to x_bf16 [m, ldxb]; stats_part [m][n / 64][2] receives (sum, sum of squares) of the new
+ *                          row over every 64-column group -- summed in group order by snf_vit_row_stats (bit-reproducible).
+ *   domain of both: k % 32 == 0, k >= 96, n % 64 == 0, 16-byte aligned rows. */
+int snf_gemm_bf16_lnfold(const void* a, int64_t lda, const void* w, int64_t ldw, const float* colsum, const float* bias,
+                         const float* rowstats, int64_t m, int n, int k, int act, void* c, int64_t ldc, snf_stream_t stream);
+int snf_gemm_bf16_resid(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t m, int n, int k, float* x,
+                        int64_t ldx, void* x_bf16, int64_t ldxb, float* stats_part, snf_stream_t stream);
 /* The same product in fp32-class arithmetic, ONE pass over the operands.  Both operands are INTERLEAVED split images ("hl"): a
  * row of 2 k bf16 in which every 32 true columns are stored as [hi(32) | lo(32)] (hi = bf16(v), lo = bf16(v - hi)) -- one
  * 128-byte line per K step and the same 4 bytes per element as the fp32 tensor.  C = act(A W^T + bias) with every product taken
@@ -430,6 +442,10 @@ int snf_vit_assemble_tokens(const void* patch_emb, int pe_dtype, const float* cl
 int snf_vit_residual_ln(float* x, int64_t n, int d, const void* add1_bf16, const void* add2_bf16, float scale2,
                         const float* gamma, const float* beta, float eps, void* ln_out_bf16, void* x_bf16,
                         snf_stream_t stream);
+/* (mean, rstd) [n][2] of LayerNorm(eps) for snf_gemm_bf16_lnfold: from the fp32 rows x [n, ldx] (then x_bf16, nullable, receives
+ * their bf16 copy -- the GEMM's operand) or from the moment pairs part [n][slots][2] a snf_gemm_bf16_resid left.  Exactly one of x / part. */
+int snf_vit_row_stats(const float* x, int64_t ldx, const float* part, int slots, int64_t n, int d, float eps, float* stats,
+                      void* x_bf16, int64_t ldxb, snf_stream_t stream);
 int snf_vit_attention_f32(const float* qkv, int b, int t, int h, int dk, float scale, float* out, float* attn,
                           snf_stream_t stream);
 #define SNF_VIT_MFMA_MAX_T 4096

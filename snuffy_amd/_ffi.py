@@ -115,6 +115,11 @@ SIGNATURES = {
                                        c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "snf_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
                               c_int, c_int, c_void_p]),
+    "snf_gemm_bf16_lnfold": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                     c_void_p, c_int64, c_void_p]),
+    "snf_gemm_bf16_resid": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p,
+                                    c_int64, c_void_p, c_void_p]),
+    "snf_vit_row_stats": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     "snf_split_hl_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "snf_layernorm_rows_hl_patch_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                                                 c_void_p]),

@@ -60,6 +60,17 @@ struct GemmParams {
     unsigned int* split_cnt = nullptr;
     float* split_slab = nullptr;
     int split_cap = 0, split_rcap = 0;
+    // gemm_bf16_kernel, EPI = 1 (LayerNorm folded into the consumer, round 6): A holds the RAW rows x (bf16), W = W0 diag(gamma);
+    //   C = act(rstd[m] (A W^T - mean[m] colsum[n]) + bias[n]),  colsum[n] = sum_k W[n, k] (of the rounded W), bias = W0 beta + b0
+    const float* colsum = nullptr;   // [N]
+    const float* rowstats = nullptr; // [M][2] = (mean, rstd) of the fp32 rows A was rounded from
+    // gemm_bf16_kernel, EPI = 2 (residual stream in the producer, round 6): c = x [M, ldc] fp32, IN PLACE  x += A W^T + bias; a bf16
+    // copy of the new x goes to c2 [M, ldc2] and, per row and 64-column group g (tile column 4 tn + wave column), the pair
+    // (sum, sum of squares) of the new values to stats_part[(row * slots + g)] -- what snf_vit_row_stats turns into (mean, rstd)
+    unsigned short* c2 = nullptr;
+    int64_t ldc2 = 0;
+    float* stats_part = nullptr;
+    int slots = 0;
 };
 constexpr int HL_SPLIT_MIN_STEPS = 8;   // a K part is at least this many 32-column steps
 constexpr int HL_SPLIT_MAX = 4;
@@ -108,8 +119,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 // NI = 16-column W fragments per wave: 4 -> BN = 256, 2 -> BN = 128.  OUT: 0 = bf16 output, 1 = fp32, 2 = the bf16 image
 // [hi | hi | lo] of the fp32 result (3 n columns, lo = bf16(v - hi)): the A operand of a following split-bf16 x3 GEMM; 3 = the
 // interleaved hl image of the result (every 32 columns as [hi(32) | lo(32)], 2 n columns): what the pipelined attention streams.
-template <int NI, int ACT, int OUT>
+// EPI (round 6, the ViT block without LayerNorm / residual passes; GemmParams has the formulas): 0 = plain; 1 = the LayerNorm of the
+// consumer folded into the epilogue (A = raw rows, per-row (mean, rstd) and per-column weight sums); 2 = the residual stream updated
+// in place by the producer (accumulators start from x instead of 0; fp32 x, its bf16 copy and the rows' partial moments leave together).
+template <int NI, int ACT, int OUT, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
+    static_assert(EPI == 0 || (NI == 4 && (EPI == 1 ? OUT == 0 : (OUT == 1 && ACT == SNF_ACT_NONE))), "gemm_bf16: epilogue variants are 256-wide");
     constexpr int BN = 64 * NI;
     constexpr int W_BYTES = BN * ROWB;
     constexpr int STEP_BYTES = A_BYTES + W_BYTES;
@@ -117,7 +132,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
     constexpr int GL = 2 + WP;                 // LDS-DMA instructions per wave and step
     constexpr int NC = 4 * NI;                 // output columns per lane
     constexpr bool OUT_F32 = OUT == 1;
-    constexpr int NST = (OUT == 1 || OUT == 3) ? NC / 4 : OUT == 2 ? 3 * NC / 8 : NC / 8;   // store instructions per lane and 16-row block
+    // store instructions per lane and 16-row block (EPI 2: fp32 x + its bf16 copy + one moment pair)
+    constexpr int NST = EPI == 2 ? NC / 4 + NC / 8 + 1 : (OUT == 1 || OUT == 3) ? NC / 4 : OUT == 2 ? 3 * NC / 8 : NC / 8;
+    static_assert((AHEAD - 1) * (2 + NI / 2) + 8 * NST <= 63, "gemm_bf16: counted waits are 6-bit");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NBUF][A image | W image]
 
     const int lane = threadIdx.x & 63;
@@ -224,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                 asm volatile("" : "+v"(acc[mi][ni]) : "v"(wf[ni]), "v"(xf[mi]));
 #else
                 // first step of a tile: C is the constant 0 (no accumulator clearing pass between tiles)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[mi][ni],
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], (FIRST && EPI != 2) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[mi][ni],
                                                                       0, 0, 0);
 #endif
             }
@@ -252,23 +269,90 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
         for (int c4 = 0; c4 < NC / 4; ++c4) asm volatile("" : "+v"(bv4[c4]));
     };
 
+    // EPI 2: the accumulators of a tile start as the residual stream x (plain loads at the tile's first step: the registers are
+    // free since the last epilogue; the MFMAs of that step come behind the step's wait).  Rows / columns past the matrix read a valid
+    // address and are never stored.
+    auto preload_x = [&](int tl) __attribute__((always_inline)) {
+        if constexpr (EPI == 2) {
+            const int tm = tl / P.tiles_n, tn = tl - tm * P.tiles_n;
+            const int n0 = tn * BN + 64 * wc + 8 * fg;
+            const int row0 = tm * BM + 128 * wr + fi;
+            const float* xb = reinterpret_cast<const float*>(P.c);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                int row = row0 + 16 * mi;
+                if (row > P.m - 1) row = P.m - 1;
+#pragma unroll
+                for (int h = 0; h < NI / 2; ++h) {
+                    const int col = n0 + 32 * h;
+                    const float* src = xb + (int64_t)row * P.ldc + (col + 8 <= P.n ? col : 0);
+                    acc[mi][2 * h] = *reinterpret_cast<const f32x4*>(src);
+                    acc[mi][2 * h + 1] = *reinterpret_cast<const f32x4*>(src + 4);
+                }
+            }
+        }
+    };
+
     // epilogue of one tile: lane owns rows 16 mi + fi and columns n0 + {0..7} (+ 32 + {0..7} at BN = 256)
     auto epilogue = [&](int tl, auto full_t) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_t)::value;
         const int tm = tl / P.tiles_n, tn = tl - tm * P.tiles_n;
         const int n0 = tn * BN + (NI == 4 ? 64 : 32) * wc + 8 * fg;
         const int row0 = tm * BM + 128 * wr + fi;
+        f32x2 rst[EPI == 1 ? 8 : 1];          // EPI 1: (mean, rstd) of this lane's rows, weight column sums of its columns
+        f32x4 cs4[EPI == 1 ? NC / 4 : 1];
+        if constexpr (EPI == 1) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                int row = row0 + 16 * mi;
+                if (row > P.m - 1) row = P.m - 1;
+                rst[mi] = *reinterpret_cast<const f32x2*>(P.rowstats + 2 * (int64_t)row);
+            }
+#pragma unroll
+            for (int h = 0; h < NI / 2; ++h) {
+                const int col = n0 + 32 * h;
+                const float* cp = P.colsum + (col + 8 <= P.n ? col : 0);
+                cs4[2 * h] = *reinterpret_cast<const f32x4*>(cp);
+                cs4[2 * h + 1] = *reinterpret_cast<const f32x4*>(cp + 4);
+            }
+        }
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
             const int row = row0 + 16 * mi;
+            float s1 = 0.f, s2 = 0.f;           // EPI 2: moments of the new x over this lane's columns of the row
 #pragma unroll
             for (int h = 0; h < NI / 2; ++h) {   // 8-column group: ni = 2 h, 2 h + 1
                 float v[8];
+                if constexpr (EPI == 1) {
+                    const float rstd = rst[mi][1], nrm = -rst[mi][0] * rstd;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = activate<ACT>(acc[mi][2 * h + (e >> 2)][e & 3] + bv4[2 * h + (e >> 2)][e & 3]);
+                    for (int e = 0; e < 8; ++e)
+                        v[e] = activate<ACT>(fmaf(rstd, acc[mi][2 * h + (e >> 2)][e & 3],
+                                                  fmaf(nrm, cs4[2 * h + (e >> 2)][e & 3], bv4[2 * h + (e >> 2)][e & 3])));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = activate<ACT>(acc[mi][2 * h + (e >> 2)][e & 3] + bv4[2 * h + (e >> 2)][e & 3]);
+                }
                 const int col = n0 + 32 * h;
+#ifdef SNF_GEMM_NOSTORE   // timing ablation: no epilogue stores (and, with them, no epilogue arithmetic); results wrong
+                const bool ok = P.k < 0 && row < P.m && col + 8 <= P.n;
+#else
                 const bool ok = FULL || (row < P.m && col + 8 <= P.n);
-                if constexpr (OUT_F32) {
+#endif
+                if constexpr (EPI == 2) {
+                    float* dst = reinterpret_cast<float*>(P.c) + (int64_t)row * P.ldc + col;
+                    unsigned short* dst2 = P.c2 + (int64_t)row * P.ldc2 + col;
+                    const u32x4 pk = {cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
+                    if (ok) {
+                        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                        *reinterpret_cast<u32x4*>(dst2) = pk;
+                    }
+                    if (FULL || col + 8 <= P.n) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) s1 += v[e], s2 = fmaf(v[e], v[e], s2);
+                    }
+                } else if constexpr (OUT_F32) {
                     float* dst = reinterpret_cast<float*>(P.c) + (int64_t)row * P.ldc + col;
                     if (ok) {
                         *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
@@ -303,6 +387,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                     }
                 }
             }
+            if constexpr (EPI == 2) {
+                // the row's 64 columns of this wave sit on the four lanes fi + 16 g: sum them (fixed order), lane g = 0 writes the pair
+                s1 += __shfl_xor(s1, 16, 64), s2 += __shfl_xor(s2, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64), s2 += __shfl_xor(s2, 32, 64);
+                const int g = 4 * tn + wc;
+                // (in a FULL tile every wave issues this store -- its 16 lanes g = 0 -- which the counted wait behind the epilogue relies on)
+                if (fg == 0 && (FULL || (g < P.slots && row < P.m)))
+                    *reinterpret_cast<f32x2*>(P.stats_part + 2 * ((int64_t)row * P.slots + g)) = f32x2{s1, s2};
+            }
         }
     };
 
@@ -324,6 +417,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
         const bool full = (tile / P.tiles_n + 1) * BM <= P.m && (tile % P.tiles_n + 1) * BN <= P.n;
         for (int s = 0; s < ns; ++s) {
             // ---- load part of step s
+            if constexpr (EPI == 2)
+                if (s == 0) preload_x(tile);
             read_frags(rb);
             if (s == ns - 1) load_bias(tile);
             // queue of this wave, oldest first: stage(+1) .. stage(+AHEAD-1) [, the previous tile's stores], then the
@@ -357,7 +452,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
             barrier();
         }
         bias_landed();
+#ifdef SNF_GEMM_NOSTORE
+        if (false) {
+#else
         if (full) {
+#endif
             epilogue(tile, std::true_type{});
             after_epilogue = true;     // exactly 8 NST stores issued by this wave
         } else {
@@ -775,13 +874,13 @@ int launch_hl_act(const GemmParams& P, hipStream_t s) {
     }
 }
 
-template <int NI, int ACT, int OUT>
+template <int NI, int ACT, int OUT, int EPI = 0>
 int launch(const GemmParams& P, hipStream_t s) {
     constexpr int lds = NBUF * (A_BYTES + 64 * NI * ROWB);
     static thread_local unsigned long long attr_set_mask = 0;   // devices (bit = device id) that have the opt-in
     const unsigned long long attr_set_bit = snf::device_bit();
     const bool attr_set = (attr_set_mask & attr_set_bit) != 0;
-    auto kern = gemm_bf16_kernel<NI, ACT, OUT>;
+    auto kern = gemm_bf16_kernel<NI, ACT, OUT, EPI>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
             hipSuccess) {
@@ -998,6 +1097,65 @@ extern "C" int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t 
     if (out_dtype == SNF_DT_BF16_HL) return tile_n == 256 ? launch_act<4, 3>(P, s) : launch_act<2, 3>(P, s);
     if (tile_n == 256) return out_dtype == SNF_DT_F32 ? launch_act<4, 1>(P, s) : launch_act<4, 0>(P, s);
     return out_dtype == SNF_DT_F32 ? launch_act<2, 1>(P, s) : launch_act<2, 0>(P, s);
+}
+
+namespace {
+// shared argument checks of the epilogue variants (256-wide tiles only)
+int epi_domain(const char* who, const void* a, int64_t lda, const void* w, int64_t ldw, int64_t m, int n, int k) {
+    if (k % BKS || k < (AHEAD + 1) * BKS || n % 64 || lda % 8 || ldw % 8 || lda < k || ldw < k ||
+        (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w)) % 16 || m * lda >= 0x7fffffffll || (int64_t)n * ldw >= 0x7fffffffll) {
+        snf::set_error("%s: shape m=%lld n=%d k=%d (lda %lld ldw %lld) outside the kernel's domain (k %% 32, k >= 96, n %% 64, 16-byte "
+                       "aligned rows, 31-bit element offsets)", who, (long long)m, n, k, (long long)lda, (long long)ldw);
+        return SNF_EUNSUPPORTED;
+    }
+    return SNF_OK;
+}
+GemmParams epi_params(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t m, int n, int k, int act, void* c,
+                      int64_t ldc) {
+    GemmParams P;
+    P.a = reinterpret_cast<const unsigned short*>(a);
+    P.w = reinterpret_cast<const unsigned short*>(w);
+    P.bias = bias;
+    P.c = c;
+    P.lda = lda, P.ldw = ldw, P.ldc = ldc;
+    P.m = (int)m, P.n = n, P.k = k, P.act = act;
+    P.tiles_m = (int)((m + BM - 1) / BM);
+    P.tiles_n = (n + 255) / 256;
+    P.trace = nullptr;
+    return P;
+}
+}  // namespace
+
+extern "C" int snf_gemm_bf16_lnfold(const void* a, int64_t lda, const void* w, int64_t ldw, const float* colsum, const float* bias,
+                                    const float* rowstats, int64_t m, int n, int k, int act, void* c, int64_t ldc, snf_stream_t stream) {
+    SNF_REQUIRE(a && w && c && colsum && bias && rowstats, "snf_gemm_bf16_lnfold: null pointer");
+    SNF_REQUIRE(m >= 1 && n >= 1 && k >= 1, "snf_gemm_bf16_lnfold: bad shape m=%lld n=%d k=%d", (long long)m, n, k);
+    SNF_REQUIRE(act == SNF_ACT_NONE || act == SNF_ACT_GELU, "snf_gemm_bf16_lnfold: activation %d not built (none, gelu)", act);
+    int rc = epi_domain("snf_gemm_bf16_lnfold", a, lda, w, ldw, m, n, k);
+    if (rc) return rc;
+    SNF_REQUIRE(ldc >= n && ldc % 8 == 0 && reinterpret_cast<uintptr_t>(c) % 16 == 0 && reinterpret_cast<uintptr_t>(colsum) % 16 == 0 &&
+                    reinterpret_cast<uintptr_t>(bias) % 16 == 0 && reinterpret_cast<uintptr_t>(rowstats) % 8 == 0,
+                "snf_gemm_bf16_lnfold: output / vector alignment");
+    GemmParams P = epi_params(a, lda, w, ldw, bias, m, n, k, act, c, ldc);
+    P.colsum = colsum, P.rowstats = rowstats;
+    hipStream_t s = snf::as_stream(stream);
+    return act == SNF_ACT_GELU ? launch<4, SNF_ACT_GELU, 0, 1>(P, s) : launch<4, SNF_ACT_NONE, 0, 1>(P, s);
+}
+
+extern "C" int snf_gemm_bf16_resid(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t m, int n, int k,
+                                   float* x, int64_t ldx, void* x_bf16, int64_t ldxb, float* stats_part, snf_stream_t stream) {
+    SNF_REQUIRE(a && w && x && x_bf16 && stats_part && bias, "snf_gemm_bf16_resid: null pointer");
+    SNF_REQUIRE(m >= 1 && n >= 1 && k >= 1, "snf_gemm_bf16_resid: bad shape m=%lld n=%d k=%d", (long long)m, n, k);
+    int rc = epi_domain("snf_gemm_bf16_resid", a, lda, w, ldw, m, n, k);
+    if (rc) return rc;
+    SNF_REQUIRE(ldx >= n && ldx % 4 == 0 && ldxb >= n && ldxb % 8 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+                    reinterpret_cast<uintptr_t>(x_bf16) % 16 == 0 && reinterpret_cast<uintptr_t>(bias) % 16 == 0 &&
+                    reinterpret_cast<uintptr_t>(stats_part) % 8 == 0 && m * ldx < 0x7fffffffll,
+                "snf_gemm_bf16_resid: output / vector alignment");
+    GemmParams P = epi_params(a, lda, w, ldw, bias, m, n, k, SNF_ACT_NONE, x, ldx);
+    P.c2 = reinterpret_cast<unsigned short*>(x_bf16), P.ldc2 = ldxb;
+    P.stats_part = stats_part, P.slots = n / 64;
+    return launch<4, SNF_ACT_NONE, 1, 2>(P, snf::as_stream(stream));
 }
 
 extern "C" int snf_gemm_hl_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ldw, const float* bias, int64_t m, int n,

@@ -22,6 +22,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -225,6 +226,51 @@ __global__ __launch_bounds__(256) void residual_ln_kernel(float* __restrict__ x,
                 *reinterpret_cast<u32x2*>(ln_out + row * d + e) = o;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// (mean, rstd) per row for the LayerNorm folded into the next GEMM (snf_gemm_bf16_lnfold): from the fp32 rows themselves (x, a
+// wave per row; also writes the bf16 copy the GEMM reads) or from the per-64-column moment pairs the producing GEMM left
+// (snf_gemm_bf16_resid: part [n][slots][2], summed in slot order -- bit-reproducible).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ part, int slots,
+                                                        int64_t n, int d, float eps, float* __restrict__ stats,
+                                                        unsigned short* __restrict__ xb, int64_t ldxb) {
+    if (part) {
+        const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (row >= n) return;
+        float s1 = 0.f, s2 = 0.f;
+        for (int g = 0; g < slots; ++g) {
+            const f32x2 p = *reinterpret_cast<const f32x2*>(part + 2 * (row * slots + g));
+            s1 += p[0], s2 += p[1];
+        }
+        const float mean = s1 / d;
+        const float var = fmaxf(s2 / d - mean * mean, 0.f);
+        *reinterpret_cast<f32x2*>(stats + 2 * row) = f32x2{mean, rsqrtf(var + eps)};
+        return;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < n; row += (int64_t)gridDim.x * 4) {
+        const float* xr = x + row * ldx;
+        float s1 = 0.f;
+        for (int c = 4 * lane; c < d; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+            s1 += (v[0] + v[1]) + (v[2] + v[3]);
+            if (xb) *reinterpret_cast<u32x2*>(xb + row * ldxb + c) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+        const float mean = s1 / d;
+        float s2 = 0.f;
+        for (int c = 4 * lane; c < d; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+            const float a0 = v[0] - mean, a1 = v[1] - mean, a2 = v[2] - mean, a3 = v[3] - mean;
+            s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+        if (lane == 0) *reinterpret_cast<f32x2*>(stats + 2 * row) = f32x2{mean, rsqrtf(s2 / d + eps)};
     }
 }
 
@@ -668,6 +714,20 @@ int snf_vit_residual_ln(float* x, int64_t n, int d, const void* add1_bf16, const
     else LAUNCH_RL(8);
 #undef LAUNCH_RL
     return snf::check_launch("residual_ln_kernel");
+}
+
+int snf_vit_row_stats(const float* x, int64_t ldx, const float* part, int slots, int64_t n, int d, float eps, float* stats,
+                      void* x_bf16, int64_t ldxb, snf_stream_t stream) {
+    SNF_REQUIRE(stats && (x || part) && !(x && part), "snf_vit_row_stats: give the fp32 rows OR the producer's moment pairs");
+    SNF_REQUIRE(n >= 1 && d >= 4 && d % 4 == 0, "snf_vit_row_stats: bad shape n=%lld d=%d", (long long)n, d);
+    SNF_REQUIRE(!part || (slots >= 1 && !x_bf16), "snf_vit_row_stats: moment pairs need slots >= 1 (and write no bf16 copy)");
+    SNF_REQUIRE(!x || (ldx >= d && ldx % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0), "snf_vit_row_stats: x alignment");
+    SNF_REQUIRE(!x_bf16 || (ldxb >= d && ldxb % 4 == 0 && reinterpret_cast<uintptr_t>(x_bf16) % 8 == 0), "snf_vit_row_stats: x_bf16 alignment");
+    hipStream_t s = snf::as_stream(stream);
+    const int grid = part ? (int)((n + 255) / 256) : grid_for(n, 4);
+    hipLaunchKernelGGL(row_stats_kernel, dim3(grid), dim3(256), 0, s, x, ldx, part, slots, n, d, eps, stats,
+                       reinterpret_cast<unsigned short*>(x_bf16), ldxb);
+    return snf::check_launch("row_stats_kernel");
 }
 
 int snf_vit_attention_f32(const float* qkv, int b, int t, int h, int dk, float scale, float* out, float* attn,

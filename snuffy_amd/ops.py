@@ -1167,6 +1167,76 @@ def gemm_bf16(a, w, bias=None, act="none", out_dtype=torch.bfloat16, out=None, t
     return out
 
 
+def gemm_lnfold_supported(n, k):
+    """Domain of gemm_bf16_lnfold / gemm_bf16_resid_ (256-wide tiles of the bf16 GEMM with the epilogue variants of round 6)."""
+    return n % 64 == 0 and k % 32 == 0 and k >= 96
+
+
+def gemm_bf16_lnfold(a, w, colsum, bias, rowstats, act="none", out=None):
+    """act(LN(x) W0^T + b0) with the LayerNorm folded into the GEMM: a [m, k] bf16 = the RAW rows x, w [n, k] bf16 = W0 diag(gamma),
+    colsum [n] f32 = row sums of the rounded w, bias [n] f32 = W0 beta + b0, rowstats [m, 2] f32 = (mean, rstd) of the fp32 rows
+    (vit_row_stats).  -> [m, n] bf16 (out: a row-strided view is fine).  act: none | gelu."""
+    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
+        raise TypeError("gemm_bf16_lnfold: a and w must be bfloat16")
+    a = _rows16(a, "a")
+    w = _rows16(w, "w")
+    m, k = a.shape
+    n = w.shape[0]
+    if w.shape[1] != k:
+        raise ValueError("gemm_bf16_lnfold: a is %s but w is %s" % (tuple(a.shape), tuple(w.shape)))
+    colsum = _req(colsum, torch.float32, "colsum", 1)
+    bias = _req(bias, torch.float32, "bias", 1)
+    rowstats = _req(rowstats, torch.float32, "rowstats", 2)
+    if colsum.shape[0] != n or bias.shape[0] != n or tuple(rowstats.shape) != (m, 2):
+        raise ValueError("gemm_bf16_lnfold: colsum / bias need %d entries, rowstats [%d, 2]" % (n, m))
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.bfloat16, device=a.device)
+    elif out.shape != (m, n) or out.stride(1) != 1 or out.dtype != torch.bfloat16:
+        raise ValueError("gemm_bf16_lnfold: bad out buffer")
+    check(_ffi.load().snf_gemm_bf16_lnfold(_p(a), a.stride(0), _p(w), w.stride(0), _p(colsum), _p(bias), _p(rowstats), m, n, k,
+                                           ACT_CODES[act], _p(out), out.stride(0), _stream()), "snf_gemm_bf16_lnfold")
+    return out
+
+
+def gemm_bf16_resid_(x, a, w, bias, x_bf16, stats_part):
+    """x [m, n] f32 IN PLACE  x += a @ w.T + bias; x_bf16 [m, n] bf16 receives the new x rounded; stats_part [m, n / 64, 2] f32 the
+    (sum, sum of squares) of every 64-column group of the new row (vit_row_stats(part=...) turns them into (mean, rstd))."""
+    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
+        raise TypeError("gemm_bf16_resid_: a and w must be bfloat16")
+    a = _rows16(a, "a")
+    w = _rows16(w, "w")
+    m, k = a.shape
+    n = w.shape[0]
+    x = _req(x, torch.float32, "x", 2)
+    bias = _req(bias, torch.float32, "bias", 1)
+    if w.shape[1] != k or tuple(x.shape) != (m, n) or tuple(x_bf16.shape) != (m, n) or x_bf16.dtype != torch.bfloat16 \
+            or not x_bf16.is_contiguous() or tuple(stats_part.shape) != (m, n // 64, 2) or stats_part.dtype != torch.float32 \
+            or not stats_part.is_contiguous() or bias.shape[0] != n:
+        raise ValueError("gemm_bf16_resid_: inconsistent shapes")
+    check(_ffi.load().snf_gemm_bf16_resid(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), m, n, k, _p(x), x.stride(0), _p(x_bf16),
+                                          x_bf16.stride(0), _p(stats_part), _stream()), "snf_gemm_bf16_resid")
+    return x
+
+
+def vit_row_stats(x=None, part=None, d=None, eps=1e-6, want_bf16=False):
+    """(mean, rstd) [n, 2] f32 of LayerNorm(eps) over rows of width d: from the fp32 rows x [n, d] (want_bf16: also their bf16 copy) or
+    from the moment pairs part [n, slots, 2] of gemm_bf16_resid_.  Returns (stats, bf16 copy or None)."""
+    lib = _ffi.load()
+    if part is not None:
+        part = _req(part, torch.float32, "part", 3)
+        n, slots = part.shape[0], part.shape[1]
+        stats = torch.empty(n, 2, dtype=torch.float32, device=part.device)
+        check(lib.snf_vit_row_stats(None, 0, _p(part), slots, n, int(d), float(eps), _p(stats), None, 0, _stream()), "snf_vit_row_stats")
+        return stats, None
+    x = _req(x, torch.float32, "x", 2)
+    n, d = x.shape
+    stats = torch.empty(n, 2, dtype=torch.float32, device=x.device)
+    xb = torch.empty(n, d, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    check(lib.snf_vit_row_stats(_p(x), x.stride(0), None, 0, n, d, float(eps), _p(stats), _p(xb), d if want_bf16 else 0, _stream()),
+          "snf_vit_row_stats")
+    return stats, xb
+
+
 GEMM_HL = True        # one-pass fp32-class GEMM kernel (snf_gemm_hl_bf16) where the shape fills the chip with 256 x 256 tiles
 
 

@@ -15,7 +15,8 @@ patchify, token assembly, LayerNorm, residual+LayerNorm fusion, GELU epilogue, m
 bf16 MFMA).  Every dense contraction of a block -- patch-embed, qkv, proj, fc1 (+ erf GELU), fc2 and the adapter's down / up projections
 (a bottleneck below 64, the DINO recipe's 32 included, is zero-padded to the kernel's 64-deep minimum) -- runs on the hand-written
 MFMA GEMM (csrc/gemm.hip), in both precisions.  ``configure(precision=...)``: "bf16" = bf16 GEMM / MFMA operands with an fp32
-residual stream; "fp32" = fp32 tensors, exact fp32 self-attention, and the projections as split-bf16 x3 products on the matrix cores
+residual stream (round 6: the blocks' LayerNorms folded into the consumer GEMMs, the residual adds into the producers' epilogues);
+"fp32" = fp32 tensors, self-attention and projections as split-bf16 x3 products on the matrix cores
 (FP32_GEMM = "x3": every operand as hi + lo bf16 halves over a tripled K axis, fp32 accumulate -- fp32-class, ~1e-5 per product;
 FP32_GEMM = "library" restores plain fp32 library GEMMs).
 """
@@ -33,6 +34,9 @@ from ._ffi import SnuffyHipError
 # fp32 path, the dense projections: "x3" = split-bf16 x3 products on the hand-written MFMA GEMM (as the aggregator's fp32 path,
 # functional.FP32_GEMM), "library" = plain fp32 library GEMMs
 FP32_GEMM = "x3"
+# bf16 path: the blocks with the LayerNorms folded into the consumer GEMMs and the residual adds into the producers' epilogues
+# (VisionTransformer._blocks_fused, round 6); False = the round-2 block (residual_ln passes between the GEMMs)
+BF16_FUSED_BLOCK = True
 
 
 def _image_of(weight, fmt):
@@ -414,9 +418,73 @@ class VisionTransformer(nn.Module):
                     up_w = torch.cat([up_w, up_w.new_zeros(up_w.shape[0], pad)], dim=1)
                 d.update(dn_w=dn_w.to(bf).contiguous(), dn_b=dn_b.to(bf), dn_bf=dn_b.to(f32).contiguous(),
                          up_w=up_w.to(bf).contiguous(), up_b=up.bias.to(bf), up_bf=up.bias.to(f32))
+            d.update(self._folded_block(blk, d))
             w["blocks"].append(d)
         self._bf16_cache = (key, w)
         return w
+
+    def _folded_block(self, blk, d):
+        """Operands of the fused bf16 block (round 6, forward_cols): the LayerNorms folded into the qkv / fc1 weights
+        (LN(x) W^T + b = rstd (x (W diag(gamma))^T - mean colsum) + (W beta + b), colsum of the ROUNDED product), the adapter's
+        up-projection riding as extra K columns of fc2 ([W2 | s Wup], bias b2 + s b_up)."""
+        bf, f64 = torch.bfloat16, torch.float64
+        out = {}
+        for tag, lin, norm, bias in (("qkv", blk.attn.qkv, blk.norm1, blk.attn.qkv.bias), ("fc1", blk.mlp.fc1, blk.norm2, blk.mlp.fc1.bias)):
+            w64 = lin.weight.detach().to(f64)
+            wf = (w64 * norm.weight.detach().to(f64)).to(torch.float32).to(bf).contiguous()
+            b0 = torch.zeros(w64.shape[0], dtype=f64, device=w64.device) if bias is None else bias.detach().to(f64)
+            out[tag + "_wf"] = wf
+            out[tag + "_cs"] = wf.to(f64).sum(dim=1).to(torch.float32).contiguous()
+            out[tag + "_bfold"] = (w64 @ norm.bias.detach().to(f64) + b0).to(torch.float32).contiguous()
+        if "dn_w" in d:
+            sc = float(blk.adaptmlp.scale)
+            up_w = blk.adaptmlp.up_proj.weight.detach()
+            bott = d["dn_w"].shape[0]
+            up_pad = torch.cat([up_w, up_w.new_zeros(up_w.shape[0], bott - up_w.shape[1])], dim=1) if bott != up_w.shape[1] else up_w
+            out["fc2cat_w"] = torch.cat([blk.mlp.fc2.weight.detach(), sc * up_pad], dim=1).to(bf).contiguous()
+            out["fc2cat_b"] = (blk.mlp.fc2.bias.detach() + sc * blk.adaptmlp.up_proj.bias.detach()).to(torch.float32).contiguous()
+        return out
+
+    def _fused_ok(self):
+        """The fused bf16 block needs the epilogue variants' domain (widths % 64, K >= 96) and equal-width blocks."""
+        blk = self.blocks[0]
+        bott = 0
+        if hasattr(blk, "adaptmlp"):
+            bott = blk.adaptmlp.down_proj.weight.shape[0]
+            bott += (-bott) % 64 if bott < 64 else 0
+            if not ops.gemm_supported(1 << 20, bott, self.embed_dim):
+                return False
+        return _fused_ok_dims(self.embed_dim, blk.mlp.fc1.weight.shape[0], bott)
+
+    def _blocks_fused(self, xt, W, B, T):
+        """The blocks of the bf16 path with no LayerNorm / residual / adapter-sum pass (round 6): per block four GEMMs (+ the adapter's
+        down-projection) and the attention.  qkv and fc1 take the RAW residual stream (bf16 copy) and apply the LayerNorm in their
+        epilogue; proj and fc2 update the fp32 residual stream in place in theirs and leave its bf16 copy and the rows' moments for the
+        next LayerNorm; the adapter's up-projection rides as 64 extra K columns of fc2 ([gelu(fc1) | ReLU(down)] x [W2 | s Wup]).
+        Reference: ...dino_version.py:120-127, adapter.py:74-94."""
+        R, D = xt.shape
+        heads = self.num_heads
+        hidden = self.blocks[0].mlp.fc1.weight.shape[0]
+        has_ad = "dn_w" in W["blocks"][0]
+        bott = W["blocks"][0]["dn_w"].shape[0] if has_ad else 0
+        part = torch.empty(R, D // 64, 2, dtype=torch.float32, device=xt.device)
+        hbuf = torch.empty(R, hidden + bott, dtype=torch.bfloat16, device=xt.device)      # [gelu(fc1) | ReLU(down)]
+        stats, xb = ops.vit_row_stats(xt, eps=self.blocks[0].norm1.eps, want_bf16=True)
+        for i, blk in enumerate(self.blocks):
+            wb = W["blocks"][i]
+            qkv = ops.gemm_bf16_lnfold(xb, wb["qkv_wf"], wb["qkv_cs"], wb["qkv_bfold"], stats)       # [R, 3D] bf16
+            o, _ = ops.vit_attention(qkv, B, T, heads, blk.attn.scale)
+            ops.gemm_bf16_resid_(xt, o, wb["proj_w"], wb["proj_bf"], xb, part)                       # x += proj(attn)
+            stats, _ = ops.vit_row_stats(part=part, d=D, eps=blk.norm2.eps)
+            ops.gemm_bf16_lnfold(xb, wb["fc1_wf"], wb["fc1_cs"], wb["fc1_bfold"], stats, "gelu", out=hbuf[:, :hidden])
+            if has_ad:
+                ops.gemm_bf16(xb, wb["dn_w"], wb["dn_bf"], "relu", out=hbuf[:, hidden:], tile_n=128)
+                ops.gemm_bf16_resid_(xt, hbuf, wb["fc2cat_w"], wb["fc2cat_b"], xb, part)             # x += mlp + s adapter
+            else:
+                ops.gemm_bf16_resid_(xt, hbuf, wb["fc2_w"], wb["fc2_bf"], xb, part)
+            if i + 1 < len(self.blocks):
+                stats, _ = ops.vit_row_stats(part=part, d=D, eps=self.blocks[i + 1].norm1.eps)
+        return self._pool(xt, B, T)
 
     def _forward_bf16(self, x):
         """bf16 GEMM / MFMA operands, fp32 residual stream, LayerNorm fused with the residual adds."""
@@ -444,6 +512,8 @@ class VisionTransformer(nn.Module):
         heads = self.num_heads
         dk = self.embed_dim // heads
         use_mfma = ops.vit_mfma_attention_supported(T, dk)
+        if BF16_FUSED_BLOCK and use_mfma and self._fused_ok():
+            return self._blocks_fused(xt, W, B, T)
         n1 = self.blocks[0].norm1
         ln = ops.layernorm_rows(xt, n1.weight, n1.bias, n1.eps, out_dtype=torch.bfloat16)
         for i, blk in enumerate(self.blocks):
@@ -481,6 +551,11 @@ class VisionTransformer(nn.Module):
             ln, _ = ops.vit_residual_ln_(xt, add1=m, add2=u, scale2=s2, gamma=nxt.weight, beta=nxt.bias, eps=nxt.eps,
                                          want_ln=not last)                                       # x += mlp + s*adapter
         return self._pool(xt, B, T)
+
+
+def _fused_ok_dims(d, hidden, bott):
+    return (ops.gemm_lnfold_supported(3 * d, d) and ops.gemm_lnfold_supported(d, d) and ops.gemm_lnfold_supported(hidden, d)
+            and ops.gemm_lnfold_supported(d, hidden + bott) and d <= 1024)
 
 
 def vit_tiny(patch_size=16, **kwargs):

@@ -387,3 +387,58 @@ def test_linear_rows_x3_skinny_kernel_vs_fp64(r, c, k, out_dtype):
     assert torch.equal(y, ops.linear_rows_x3(x, w, b, out_dtype=out_dtype))
     y0 = ops.linear_rows_x3(x[:, :k], w, None, out_dtype=torch.float32)       # no bias
     assert (y0.double() - (ref - b.double())).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+# ---- round 6: the epilogue variants of the bf16 GEMM behind the fused ViT block (LayerNorm folded into the consumer, residual
+# stream updated by the producer) -- vd:97-127
+@pytest.mark.parametrize("act", ["none", "gelu"])
+@pytest.mark.parametrize("m,n,k", [(394, 384, 128), (1000, 1152, 384), (256, 1536, 384), (1577, 192, 96), (100, 64, 1600), (3000, 768, 768)])
+def test_gemm_bf16_lnfold_is_layernorm_then_linear(m, n, k, act):
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(m + n + k)
+    x = torch.randn(m, k, generator=g) * (0.5 + torch.rand(m, 1, generator=g)) + 0.7 * torch.randn(m, 1, generator=g)   # row means ~ row spreads
+    gam, bet = 1.0 + 0.2 * torch.randn(k, generator=g), 0.3 * torch.randn(k, generator=g)
+    w0, b0 = torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g)
+    eps = 1e-6
+    wf = (w0.double() * gam.double()).float().to(torch.bfloat16)
+    cs = wf.double().sum(1).float()
+    bfold = (w0.double() @ bet.double() + b0.double()).float()
+    stats, xb = ops.vit_row_stats(x.to(DEV), eps=eps, want_bf16=True)
+    mean, var = x.double().mean(1), x.double().var(1, unbiased=False)
+    assert torch.allclose(stats[:, 0].cpu().double(), mean, atol=1e-5) and torch.allclose(stats[:, 1].cpu().double(), (var + eps).rsqrt(), rtol=1e-5)
+    assert torch.equal(xb.cpu(), x.to(torch.bfloat16))
+    out = ops.gemm_bf16_lnfold(xb, wf.to(DEV), cs.to(DEV), bfold.to(DEV), stats, act)
+    # the kernel's own arithmetic in fp64: rounded operands, exact statistics
+    emu = (var + eps).rsqrt()[:, None] * (x.to(torch.bfloat16).double() @ wf.double().t() - mean[:, None] * cs.double()) + bfold.double()
+    emu = ref_act(emu, act)
+    assert (out.cpu().double() - emu).abs().max() <= 4.5e-3 * max(1.0, emu.abs().max().item())        # one bf16 rounding of the result
+    # ... and it IS LayerNorm -> Linear within the bf16 class
+    ref = ref_act(torch.nn.functional.layer_norm(x.double(), (k,), gam.double(), bet.double(), eps) @ w0.double().t() + b0.double(), act)
+    assert (out.cpu().double() - ref).abs().max() <= 2e-2 * max(1.0, ref.abs().max().item())
+    out2 = ops.gemm_bf16_lnfold(xb, wf.to(DEV), cs.to(DEV), bfold.to(DEV), stats, act)
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("m,n,k", [(394, 384, 128), (1000, 384, 1600), (256, 128, 96), (1577, 192, 768), (100, 64, 96), (3000, 768, 3072)])
+def test_gemm_bf16_resid_updates_the_stream_in_place(m, n, k):
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(m * 3 + n + k)
+    x = torch.randn(m, n, generator=g) * 2.0
+    a_full = torch.randn(m, k + 64, generator=g).to(torch.bfloat16)         # a row-strided operand view
+    w, b = (torch.randn(n, k, generator=g) / k ** 0.5).to(torch.bfloat16), torch.randn(n, generator=g)
+    ref = x.double() + a_full[:, :k].double() @ w.double().t() + b.double()
+    xd = x.to(DEV)
+    xb = torch.full((m, n), 7.0, dtype=torch.bfloat16, device=DEV)
+    part = torch.full((m, n // 64, 2), -1.0, device=DEV)
+    ops.gemm_bf16_resid_(xd, a_full.to(DEV)[:, :k], w.to(DEV), b.to(DEV), xb, part)
+    assert (xd.cpu().double() - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(xb.cpu(), xd.cpu().to(torch.bfloat16))
+    xg = xd.cpu().double().view(m, n // 64, 64)
+    assert torch.allclose(part[..., 0].cpu().double(), xg.sum(-1), atol=1e-3) and torch.allclose(part[..., 1].cpu().double(), (xg * xg).sum(-1), rtol=1e-5, atol=1e-3)
+    stats, _ = ops.vit_row_stats(part=part, d=n, eps=1e-6)
+    assert torch.allclose(stats[:, 0].cpu().double(), xd.cpu().double().mean(1), atol=1e-5)
+    assert torch.allclose(stats[:, 1].cpu().double(), (xd.cpu().double().var(1, unbiased=False) + 1e-6).rsqrt(), rtol=2e-4)
+    # bit-reproducible
+    xd2, xb2, part2 = x.to(DEV), torch.empty_like(xb), torch.empty_like(part)
+    ops.gemm_bf16_resid_(xd2, a_full.to(DEV)[:, :k], w.to(DEV), b.to(DEV), xb2, part2)
+    assert torch.equal(xd, xd2) and torch.equal(xb, xb2) and torch.equal(part, part2)

@@ -149,11 +149,13 @@ def test_vit_models_match_reference_goldens(path, gemm, monkeypatch):
                                        atol=5e-5 if tight else 2e-4)
             attn = model.get_last_selfattention(imgs)
             np.testing.assert_allclose(attn[:, :, ::29, :].cpu().numpy(), z["last_attn"], rtol=0, atol=1e-5 if tight else 5e-5)
-    fb = model.configure("bf16")(imgs)
     ref = torch.from_numpy(z["feats"])
-    e = rel_err(fb.cpu(), ref)
-    print("MEASURED vit bf16 golden", path.split("/")[-1] if isinstance(path, str) else "", e)
-    assert e < 1e-2, e                                                                 # north-star bf16 class, no depth allowance
+    for fused in (True, False):       # the fused block (LayerNorm folded into the GEMMs, round 6) and the round-2 block
+        monkeypatch.setattr(vit_mod, "BF16_FUSED_BLOCK", fused)
+        fb = model.configure("bf16")(imgs)
+        e = rel_err(fb.cpu(), ref)
+        print("MEASURED vit bf16 golden", "fused" if fused else "unfused", path.split("/")[-1] if isinstance(path, str) else "", e)
+        assert e < 1e-2, e                                                             # north-star bf16 class, no depth allowance
 
 
 def test_vit_small_shape_and_iclassifier():
@@ -168,10 +170,19 @@ def test_vit_small_shape_and_iclassifier():
         ref = vorc.vit_forward(x.cpu(), sd, 16, 12, 6, 10.0, "dino_adapter")
     assert feats.shape == (4, 384) and c.shape == (4, 2)
     assert (feats.cpu() - ref).abs().max() < 1e-3
+    from snuffy_amd import vit as vit_mod
+    assert vit_mod.BF16_FUSED_BLOCK and model._fused_ok()
     fb = model.configure("bf16")(x)
     e = rel_err(fb.cpu(), ref)
     print("MEASURED vit_small bf16 depth 12", e)
     assert e < 1e-2, e                                                                 # north-star bf16 class at depth 12
+    vit_mod.BF16_FUSED_BLOCK = False
+    try:
+        e2 = rel_err(model(x).cpu(), ref)
+    finally:
+        vit_mod.BF16_FUSED_BLOCK = True
+    print("MEASURED vit_small bf16 depth 12, unfused block", e2)
+    assert e2 < 1e-2, e2
 
 
 def test_compute_feats_end_to_end(tmp_path):
