@@ -311,6 +311,12 @@ int snf_sparse_attn_fwd_x3_hl(const void* q_hl, int64_t ldq, const void* v_hl, i
 size_t snf_sparse_attn_x3_hl_kpfrag_bytes(int k, int h, int dk);
 int snf_linear_rows_x3_kpfrag_f32(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int k_keys, int h, int dk,
                                   int kdim, float scale, void* kp_frag, size_t kp_frag_bytes, snf_stream_t stream);
+/* The same with the gather of the selected rows fused in (snuffy.py:131,145-147 + 190 in ONE launch, round 6): input row i of the
+ * projection is row idx[i] of the bag x [n, ldx].  xs (nullable) [k_keys, kdim] receives the gathered rows, slot_map (nullable) [n] the
+ * row -> slot map of snf_gather_slot_map_f32 -- the two launches this call replaces write the same bytes. */
+int snf_gather_linear_rows_x3_kpfrag_f32(const float* x, int64_t ldx, int64_t n, const int64_t* idx, const float* w, int64_t ldw,
+                                         const float* bias, int k_keys, int h, int dk, int kdim, float scale, void* kp_frag,
+                                         size_t kp_frag_bytes, float* xs, int32_t* slot_map, snf_stream_t stream);
 int snf_sparse_attn_fwd_x3_hl_kpfrag(const void* q_hl, int64_t ldq, const void* v_hl, int64_t ldv, const void* kp_frag, int64_t n, int k,
                                      int h, int dk, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
                                      snf_stream_t stream);

@@ -97,6 +97,8 @@ SIGNATURES = {
     "snf_sparse_attn_x3_hl_kpfrag_bytes": (c_size_t, [c_int, c_int, c_int]),
     "snf_linear_rows_x3_kpfrag_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                               c_void_p, c_size_t, c_void_p]),
+    "snf_gather_linear_rows_x3_kpfrag_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int,
+                                                     c_int, c_float, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "snf_sparse_attn_fwd_x3_hl_kpfrag": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                                  c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "snf_sparse_attn_fwd_x3_hl": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_float,

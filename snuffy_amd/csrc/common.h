@@ -13,8 +13,10 @@ int check_launch(const char* what);
 int cu_count();
 unsigned long long device_bit();
 // gemm.hip: x [r, k] w [c, k]^T + bias written as the Kp fragment image of sparse_attn_x3p.hip (see SkinnyFrag there)
+// idx (nullable): input row i is row idx[i] of x [n_rows, ldx]; xs (nullable) receives the gathered rows, map (nullable) the row -> slot map
 int skinny_linear_x3_kpfrag(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int r, int c, int k, int dk,
-                            int chunk_size, int64_t chunk_stride, float c_exp, void* frag, hipStream_t s);
+                            int chunk_size, int64_t chunk_stride, float c_exp, void* frag, hipStream_t s, const int64_t* idx = nullptr,
+                            int64_t n_rows = 0, float* xs = nullptr, int64_t ldxs = 0, int32_t* map = nullptr);
 
 static inline hipStream_t as_stream(snf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

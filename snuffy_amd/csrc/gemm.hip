@@ -935,6 +935,15 @@ struct SkinnyFrag {
     int dk, chunk_size;        // head width; keys per chunk (a multiple of 32, or r when there is one chunk)
     int64_t chunk_stride;      // u32x4 units between the chunks' images
     float c_exp;
+    // round 6: the gather of the selected rows fused into their key projection (snuffy.py:131,145-147 + 190 in one launch):
+    // idx != null: input row i of the projection is row idx[i] of x (the bag itself); xs (nullable) receives the gathered rows
+    // [r, k] (written by the workgroups of the first column block from the registers they multiply); map (nullable, [n_rows] int32)
+    // receives the row -> slot map (-1 = not selected), built by extra workgroups behind the projection's own
+    const int64_t* idx = nullptr;
+    int64_t n_rows = 0;
+    float* xs = nullptr;
+    int64_t ldxs = 0;
+    int32_t* map = nullptr;
 };
 template <bool OUT_BF16, bool FRAG = false>
 __global__ __launch_bounds__(512) void skinny_linear_x3_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
@@ -942,12 +951,37 @@ __global__ __launch_bounds__(512) void skinny_linear_x3_kernel(const float* __re
                                                                 void* __restrict__ out, int64_t ldo, SkinnyFrag fr = SkinnyFrag{}) {
     constexpr int NW = 8, BATCH = 6;                        // waves splitting the K axis; MFMA steps (16 deep) requested at once
     __shared__ float red[NW - 1][32 * 32];
+    if constexpr (FRAG) {
+        const int nrb = (r + 31) >> 5;
+        if ((int)blockIdx.y >= nrb) {                       // row -> slot map: the selected indices searched in LDS (as gather_slot_map_kernel)
+            int* sel = reinterpret_cast<int*>(&red[0][0]);
+            for (int q = threadIdx.x; q < r; q += 512) sel[q] = (int)fr.idx[q];
+            __syncthreads();
+            const int64_t i = ((int64_t)(blockIdx.y - nrb) * gridDim.x + blockIdx.x) * 512 + threadIdx.x;
+            if (i >= fr.n_rows) return;
+            int slot = -1;
+            const int me = (int)i;
+            for (int q = 0; q < r; ++q) slot = (sel[q] == me) ? q : slot;
+            fr.map[i] = slot;
+            return;
+        }
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 31, hf = lane >> 5;
     const int row0 = blockIdx.y * 32, col0 = blockIdx.x * 32;
     int xr = row0 + j, wr = col0 + j;
     if (xr > r - 1) xr = r - 1;
     if (wr > c - 1) wr = c - 1;
+    const int xr_out = xr;                                  // row of the gathered copy
+    bool xs_out = false;
+    if constexpr (FRAG) {
+        if (fr.idx) {
+            int64_t src = fr.idx[xr];
+            src = src < 0 ? 0 : (src > fr.n_rows - 1 ? fr.n_rows - 1 : src);
+            xr = (int)src;
+            xs_out = fr.xs != nullptr && blockIdx.x == 0 && row0 + j < r;
+        }
+    }
     // the K axis in 16-deep steps, split evenly over the waves: the whole pass is ONE memory round trip per wave when its share
     // fits a batch (k <= 768), so every load of the workgroup is in flight before the first MFMA
     const int steps = k >> 4, per = (steps + NW - 1) / NW;
@@ -970,6 +1004,17 @@ __global__ __launch_bounds__(512) void skinny_linear_x3_kernel(const float* __re
             wvv[u] = skinny_load8(wp + 16 * st);
         }
         __builtin_amdgcn_sched_barrier(0);   // every load of the batch is requested before the first split / MFMA
+        if constexpr (FRAG) {
+            if (xs_out) {                        // the gathered rows leave from the registers they are multiplied from
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u)
+                    if (s0 + u < s_hi) {
+                        float* d8 = fr.xs + (int64_t)xr_out * fr.ldxs + 8 * hf + 16 * (s0 + u);
+                        *reinterpret_cast<f32x4*>(d8) = f32x4{xv[u][0], xv[u][1], xv[u][2], xv[u][3]};
+                        *reinterpret_cast<f32x4*>(d8 + 4) = f32x4{xv[u][4], xv[u][5], xv[u][6], xv[u][7]};
+                    }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
             bf16x8 xh, xl, wh, wl;
@@ -1047,10 +1092,13 @@ __global__ __launch_bounds__(512) void skinny_linear_x3_kernel(const float* __re
 
 // (internal) the key projection of the pipelined attention, written as its fragment image: sparse_attn_x3p.hip owns the layout
 int snf::skinny_linear_x3_kpfrag(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int r, int c, int k, int dk,
-                                 int chunk_size, int64_t chunk_stride, float c_exp, void* frag, hipStream_t s) {
-    const dim3 grid((unsigned)((c + 31) / 32), (unsigned)((r + 31) / 32));
+                                 int chunk_size, int64_t chunk_stride, float c_exp, void* frag, hipStream_t s, const int64_t* idx,
+                                 int64_t n_rows, float* xs, int64_t ldxs, int32_t* map) {
+    dim3 grid((unsigned)((c + 31) / 32), (unsigned)((r + 31) / 32));
     SkinnyFrag fr;
     fr.dk = dk, fr.chunk_size = chunk_size, fr.chunk_stride = chunk_stride, fr.c_exp = c_exp;
+    fr.idx = idx, fr.n_rows = n_rows, fr.xs = xs, fr.ldxs = ldxs, fr.map = idx ? map : nullptr;
+    if (fr.map) grid.y += (unsigned)((n_rows + 512ll * grid.x - 1) / (512ll * grid.x));   // the map's workgroups, behind the projection's
     hipLaunchKernelGGL((skinny_linear_x3_kernel<false, true>), grid, dim3(512), 0, s, x, ldx, w, ldw, bias, r, c, k, frag, (int64_t)0, fr);
     return snf::check_launch("skinny_linear_x3_kernel<frag>");
 }

@@ -145,6 +145,28 @@ int snf_linear_rows_x3_kpfrag_f32(const float* x, int64_t ldx, const float* w, i
                                         (int64_t)(cb / sizeof(u32x4)), scale * 1.44269504088896340736f, kp_frag, snf::as_stream(stream));
 }
 
+int snf_gather_linear_rows_x3_kpfrag_f32(const float* x, int64_t ldx, int64_t n, const int64_t* idx, const float* w, int64_t ldw,
+                                         const float* bias, int k_keys, int h, int dk, int kdim, float scale, void* kp_frag,
+                                         size_t kp_frag_bytes, float* xs, int32_t* slot_map, snf_stream_t stream) {
+    SNF_REQUIRE(x && idx && w && kp_frag, "snf_gather_linear_rows_x3_kpfrag_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && n <= 0x7fffffffll, "snf_gather_linear_rows_x3_kpfrag_f32: bad row count %lld", (long long)n);
+    X3PChunks ch;
+    size_t cb;
+    if (!x3p_kpfrag_geometry(k_keys, h, dk, &ch, &cb)) {
+        snf::set_error("snf_gather_linear_rows_x3_kpfrag_f32: k=%d h=%d dk=%d outside the fused form (dk = 64 / 128, 97 <= k <= 2048, key "
+                       "chunks of a multiple of 32 keys)", k_keys, h, dk);
+        return SNF_EUNSUPPORTED;
+    }
+    SNF_REQUIRE(kp_frag_bytes >= cb * ch.count && (reinterpret_cast<uintptr_t>(kp_frag) & 15) == 0,
+                "snf_gather_linear_rows_x3_kpfrag_f32: fragment buffer %zu < %zu (or not 16-byte aligned)", kp_frag_bytes, cb * ch.count);
+    SNF_REQUIRE(kdim >= 16 && kdim % 16 == 0 && ldx >= kdim && ldw >= kdim && (ldx % 4) == 0 && (ldw % 4) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(xs)) & 15) == 0,
+                "snf_gather_linear_rows_x3_kpfrag_f32: x / w / xs rows must be 16-byte aligned, k %% 16 == 0");
+    return snf::skinny_linear_x3_kpfrag(x, ldx, w, ldw, bias, k_keys, h * dk, kdim, dk, ch.count > 1 ? ch.size : k_keys,
+                                        (int64_t)(cb / sizeof(u32x4)), scale * 1.44269504088896340736f, kp_frag, snf::as_stream(stream), idx, n,
+                                        xs, kdim, slot_map);
+}
+
 static int x3p_forward(const void* q_hl, int64_t ldq, const void* v_hl, int64_t ldv, const float* kp, const void* kp_frag_ext, int64_t n,
                        int k, int h, int dk, float scale, float* out, float* attn, float* lse, void* workspace, size_t workspace_bytes,
                        snf_stream_t stream);

@@ -31,6 +31,8 @@ FP32_ATTENTION = "x3"
 X3_HL_ATTENTION = True
 # ... and the key projection in front of it writes the kernel's Kp fragment image itself (no fp32 Kp, no prep launch)
 X3_HL_KPFRAG = True
+# ... and gathers its input rows itself: gather + row -> slot map + key projection in one launch (round 6); False = gather_slot_map first
+X3_HL_KPFRAG_GATHER = True
 # fp32 path, the [N, .] projections: "x3" = split-bf16 products on the hand-written MFMA GEMM (fp32-class: logits within
 # ~1e-5 of the exact path), "library" = fp32 library GEMMs.
 FP32_GEMM = "x3"
@@ -629,15 +631,23 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
         # 96 MFMAs per 24 fragment reads); otherwise the concatenated form over [hi | hi | lo]
         hl = d % 32 == 0 and f % 32 == 0 and ops.hl_eligible(n, 2 * dp, d) and ops.hl_eligible(n, f, d) and ops.hl_eligible(n, d, f)
         fh = _hl_weights(layer, fw) if hl else None
-        xs, slot = ops.gather_slot_map(x2, sel)                                     # snuffy.py:131,145-147 (+ row -> slot map)
         shared = hl and shared_norm_layer(layer)
         fhf = _hl_weights_folded(layer, dkp) if shared else None
         xn3 = _take_xn3(layer, x2, n0, shared)                                      # left by the critic pass, if any
         fp = _padded_heads(layer, dkp) if dkp != dk else None
         wk, bk = (lk.weight.detach(), None if lk.bias is None else lk.bias.detach()) if fp is None else (fp["wk"], fp["bk"])
         scale = 1.0 / math.sqrt(dk)                                                 # of the TRUE head width (snuffy.py:162)
-        # keys = RAW selected rows (K rows: fp32).  For the pipelined kernel the projection writes its fragment image directly
-        if hl_attn and X3_HL_KPFRAG and ops.x3_hl_kpfrag_supported(k, h, dkp) and xs.dtype == torch.float32:
+        # keys = RAW selected rows (K rows: fp32).  For the pipelined kernel the projection writes its fragment image directly -- and
+        # gathers its rows itself (round 6: gather, row -> slot map and key projection are ONE launch)
+        frag_ok = hl_attn and X3_HL_KPFRAG and ops.x3_hl_kpfrag_supported(k, h, dkp) and x2.dtype == torch.float32
+        fused_gather = frag_ok and X3_HL_KPFRAG_GATHER and d % 16 == 0
+        if fused_gather:
+            kp, xs, slot = ops.gather_linear_rows_x3_kpfrag(x2, sel, wk, bk, h, scale=scale)   # snuffy.py:131,145-147,190
+        else:
+            xs, slot = ops.gather_slot_map(x2, sel)                                 # snuffy.py:131,145-147 (+ row -> slot map)
+        if fused_gather:
+            pass
+        elif frag_ok:
             kp = ops.linear_rows_x3_kpfrag(xs, wk, bk, h, scale=scale)
         elif fp is not None:
             kp = ops.linear_rows_x3(xs, wk, bk)

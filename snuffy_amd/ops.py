@@ -782,6 +782,36 @@ def linear_rows_x3_kpfrag(x, w, bias, h, scale=None):
     return KpFrag(buf, k, d, h)
 
 
+def gather_linear_rows_x3_kpfrag(x, idx, w, bias, h, scale=None, want_map=True):
+    """gather_slot_map + linear_rows_x3_kpfrag in ONE launch (snf_gather_linear_rows_x3_kpfrag_f32): x [n, kdim] f32 (the bag), idx [k]
+    int64 (the selected rows) -> (KpFrag of x[idx] @ w^T + bias, xs = x[idx] [k, kdim] f32, row -> slot map [n] int32 or None).
+    Same bytes as the two launches it replaces."""
+    if x.dtype != torch.float32 or w.dtype != torch.float32:
+        raise TypeError("gather_linear_rows_x3_kpfrag: x and w must be float32")
+    x = _rows16(x, "x")
+    w = _rows16(w, "w")
+    idx = _req(idx, torch.int64, "idx", 1)
+    n, kdim = x.shape
+    k = idx.shape[0]
+    d = w.shape[0]
+    if w.shape[1] != kdim or d % h:
+        raise ValueError("gather_linear_rows_x3_kpfrag: x %s w %s h %d" % (tuple(x.shape), tuple(w.shape), h))
+    dk = d // h
+    lib = _ffi.load()
+    nbytes = lib.snf_sparse_attn_x3_hl_kpfrag_bytes(k, h, dk)
+    if not nbytes or kdim % 16:
+        raise ValueError("gather_linear_rows_x3_kpfrag: k=%d h=%d dk=%d kdim=%d outside the fused form" % (k, h, dk, kdim))
+    if bias is not None:
+        bias = _req(bias, torch.float32, "bias", 1)
+    scale = 1.0 / math.sqrt(dk) if scale is None else scale
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    xs = torch.empty(k, kdim, dtype=torch.float32, device=x.device)
+    slot = torch.empty(n, dtype=torch.int32, device=x.device) if want_map else None
+    check(lib.snf_gather_linear_rows_x3_kpfrag_f32(_p(x), x.stride(0), n, _p(idx), _p(w), w.stride(0), _p(bias), k, h, dk, kdim, float(scale),
+                                                   _p(buf), nbytes, _p(xs), _p(slot), _stream()), "snf_gather_linear_rows_x3_kpfrag_f32")
+    return KpFrag(buf, k, d, h), xs, slot
+
+
 def sparse_attn_fwd_x3_hl(q_hl, v_hl, kp, h, scale=None, need_attn=False, need_lse=False):
     """fp32-class sparse attention on PRE-SPLIT operands (snf_sparse_attn_fwd_x3_hl): q_hl, v_hl [n, 2 d] bf16 interleaved split
     images (split_hl_rows / gemm_hl(hl_out=True); row-strided views allowed, e.g. the two halves of the [Q | V] projection's

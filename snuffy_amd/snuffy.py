@@ -345,7 +345,7 @@ class MILNet(nn.Module):
         plist = list(self.parameters())
         knobs = tuple((l.big_lambda, l.random_patch_share) for l in self.b_classifier.encoder.layers)
         # module-level arithmetic switches are baked into a capture as well
-        knobs += (SF.FP32_GEMM, SF.FP32_ATTENTION, SF.X3_HL_ATTENTION, SF.X3_HL_KPFRAG, SF.FP32_SHARED_NORM, ops.GEMM_HL_SPLITK,
+        knobs += (SF.FP32_GEMM, SF.FP32_ATTENTION, SF.X3_HL_ATTENTION, SF.X3_HL_KPFRAG, SF.X3_HL_KPFRAG_GATHER, SF.FP32_SHARED_NORM, ops.GEMM_HL_SPLITK,
                   SF.BF16_DEEP_STACKS, self.b_classifier.cfg.sampler)
         return tuple(SF.param_key(p) for p in plist), knobs
 

@@ -681,6 +681,35 @@ def test_sparse_attn_x3_hl_fused_key_projection(n, k, h, dk):
     assert torch.equal(o4, o5)
 
 
+@pytest.mark.parametrize("n,k,h,dk", [(3000, 200, 6, 128), (32768, 200, 6, 128), (8192, 200, 6, 64), (700, 257, 2, 128), (5000, 900, 4, 128),
+                                      (100000, 512, 6, 128), (300, 97, 1, 64)])
+def test_gather_fused_into_the_key_projection(n, k, h, dk):
+    """snf_gather_linear_rows_x3_kpfrag_f32 (round 6): gather + row -> slot map + key projection in one launch -- the same bytes as
+    snf_gather_slot_map_f32 followed by snf_linear_rows_x3_kpfrag_f32 (snuffy.py:131,145-147,190)."""
+    o_ = ops()
+    d = h * dk
+    g = torch.Generator().manual_seed(n + 3 * k)
+    x = torch.randn(n, d, generator=g).to(DEV)
+    idx = torch.randperm(n, generator=g)[:k].to(DEV)
+    w = (torch.randn(d, d, generator=g) / d ** 0.5).to(DEV)
+    b = torch.randn(d, generator=g).to(DEV)
+    xs0, slot0 = o_.gather_slot_map(x, idx)
+    frag0 = o_.linear_rows_x3_kpfrag(xs0, w, b, h)
+    frag1, xs1, slot1 = o_.gather_linear_rows_x3_kpfrag(x, idx, w, b, h)
+    assert torch.equal(xs0, xs1) and torch.equal(slot0, slot1)
+    if k <= 256:                                  # one key chunk: every byte of the image is written
+        assert torch.equal(frag0.buf, frag1.buf)
+    m = min(n, 4096)
+    img = o_.split_hl_rows(torch.randn(m, 2 * d, generator=g).to(DEV))
+    o0, a0, _ = o_.sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], frag0, h, need_attn=True)
+    o1, a1, _ = o_.sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], frag1, h, need_attn=True)
+    assert torch.equal(o0, o1) and torch.equal(a0, a1)
+    frag2, xs2, slot2 = o_.gather_linear_rows_x3_kpfrag(x, idx, w, None, h, want_map=False)
+    o2, _, _ = o_.sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], frag2, h)
+    o3, _, _ = o_.sparse_attn_fwd_x3_hl(img[:, :2 * d], img[:, 2 * d:], o_.linear_rows_x3_kpfrag(xs0, w, None, h), h)
+    assert slot2 is None and torch.equal(xs2, xs0) and torch.equal(o2, o3)
+
+
 def test_sparse_attn_x3_hl_fused_key_projection_domain():
     assert ops().x3_hl_kpfrag_supported(257, 2, 128)          # (round 5: chunks of 160 + 97 keys, on key-block boundaries)
     assert not ops().x3_hl_kpfrag_supported(200, 24, 32)      # dk = 32
