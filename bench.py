@@ -123,7 +123,26 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
         t_crit = timed((lambda: ops.critic_ln(xb, wc, bc, eps)) if eps is not None else (lambda: ops.critic(xb, wc, bc)), 20)
         t_both = timed(lambda: ops.topk(ops.critic_select(xb, wc, bc, eps)[0].view(-1), k_top), 20)
         t_topk, fused = max(t_both - t_crit, 0.0), True
-    del xb
+    # gather of the selected rows + row -> slot map + key projection, as the model dispatches them (the unit's time has to
+    # include them).  fp32-class with the pipelined attention: ONE launch (round 6); otherwise gather_slot_map + the K-row projection
+    idx_sel = ops.topk(scores, K)
+    wk_t = (torch.randn(D_true, D_true, generator=g) / math.sqrt(D_true)).to(device)
+    gk_what = "gather_slot_map + key projection (two launches)"
+    if (precision == "fp32" and SF.X3_HL_ATTENTION and SF.FP32_GEMM == "x3" and SF.X3_HL_KPFRAG and SF.X3_HL_KPFRAG_GATHER and dk == D_true // h
+            and ops.x3_hl_attn_supported(K, dk) and ops.x3_hl_kpfrag_supported(K, h, dk) and D_true % 16 == 0):
+        def gather_kproj():
+            ops.gather_linear_rows_x3_kpfrag(xb, idx_sel, wk_t, None, h)
+        gk_what = "gather + row -> slot map + key projection -> fragment image (one launch)"
+    elif ops.linear_rows_x3_supported(K, D_true, D_true):
+        def gather_kproj():
+            xs_, _ = ops.gather_slot_map(xb, idx_sel)[:2]
+            ops.linear_rows_x3(xs_, wk_t, None, out_dtype=dt)
+    else:
+        def gather_kproj():
+            xs_, _ = ops.gather_slot_map(xb, idx_sel)[:2]
+            torch.mm(xs_, wk_t.t())
+    t_gk = timed(gather_kproj, 20, warmup=3)
+    del xb, wk_t
     kp = torch.randn(K, D, generator=g).to(device)
     kp_in = kp.to(dt)   # the bf16 path hands the kernel a bf16 Kp (output of the bf16 key projection), as the model does
     # rotate over several operand sets so the 256 MiB Infinity Cache cannot serve the re-reads
@@ -247,8 +266,9 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
                 calls = max(int(r["Calls"]) for r in hit)        # several instantiations of one kernel: per-bag total
                 parts[kname] = round(sum(float(r["TotalDurationNs"]) for r in hit) / calls / 1e3, 2)
         if parts and kern.split("+")[0] in parts:
-            in_bag = dict(us_per_launch=round(sum(parts.values()), 2), kernels_us=parts, source=os.path.basename(sfiles[-1]),
-                          frac=round(b_attn / (sum(parts.values()) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4))
+            in_bag = dict(recorded=True, source="committed file profiles/" + os.path.basename(sfiles[-1]) + " (rocprofv3 of an earlier run; "
+                          "not measured in this run)", us_per_launch=round(sum(parts.values()), 2), kernels_us=parts,
+                          frac_recorded=round(b_attn / (sum(parts.values()) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4))
     # `achieved` / `frac` price the launch at the bytes it has to move at ITS operand width (bf16 Q, V, Kp here).  SURVEY
     # section 8(d) prices the same unit at the reference's fp32 tensors (8ND + 8KD; with the selector 8ND + 4N + 16KD + 8K):
     # that figure is reported next to it as survey_8d_* -- same time, twice the bytes on the bf16 path.
@@ -259,7 +279,9 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
                            us_per_launch=round(t_attn * 1e3, 2), algorithmic_bytes=b_attn,
                            flops=4 * N * K * D * (3 if kern.startswith("sparse_attn_x3") else 1), operand_dtype=precision,
                            head_width=D // h, head_width_streamed=streamed_width // h, survey_8d_bytes=b_attn_8d,
-                           survey_8d_frac=round(b_attn_8d / (t_attn * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                           survey_8d_frac=round(b_attn_8d / (t_attn * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           traffic_source=("committed file profiles/" + os.path.basename(tfiles[-1]) + " (separate --pmc passes; not measured "
+                                           "in this run)") if traffic is not None else None)
     if in_bag is not None:
         out["roofline"]["in_bag_rocprof"] = in_bag
     if t_warm is not None:
@@ -268,13 +290,17 @@ def kernel_rooflines(wl, precision, device, wl_name="cfgB"):
                                                  what="one launch timed alone right behind an in-place rewrite of its Q | V operands (as in "
                                                       "the bag, behind the projection; includes that launch's dispatch latency); achieved / "
                                                       "frac above are on cold, rotating operand sets")
-    t_unit = t_attn + t_topk
+    # the WHOLE unit of SURVEY 8(d)'s B_sa = 8ND + 4N + 16KD + 8K: select + gather / key projection + attention (round 6: the gather and
+    # the key projection are timed too -- rounds 1-5 counted the gather's bytes but not its launches)
+    t_unit = t_attn + t_topk + t_gk
     b_unit = b_attn + b_topk + b_gather
     out["roofline_topk_attn"] = dict(bound="hbm", achieved=round(b_unit / (t_unit * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS,
                                      unit="GB/s", frac=round(b_unit / (t_unit * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                     us_topk=round(t_topk * 1e3, 2), us_attn=round(t_attn * 1e3, 2),
+                                     us_topk=round(t_topk * 1e3, 2), us_gather_kproj=round(t_gk * 1e3, 2), us_attn=round(t_attn * 1e3, 2),
                                      us_topk_standalone=round(t_topk_alone * 1e3, 2),
                                      topk="fused selector: (critic + histogram -> select) - critic" if fused else "one launch on the scores",
+                                     gather_kproj=gk_what,
+                                     frac_without_gather_kproj=round(b_unit / ((t_attn + t_topk) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                      algorithmic_bytes=b_unit, survey_8d_bytes=b_unit_8d,
                                      survey_8d_frac=round(b_unit_8d / (t_unit * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
     del qvs
@@ -466,7 +492,18 @@ def main():
         rs = np.random.RandomState(0)
         sigma = 0.5
         lens = np.clip(np.round(rs.lognormal(np.log(N) - sigma * sigma / 2, sigma, wl["bags"])), 1000, 100000).astype(int)
-        mine = lens[rank::world]                        # this rank's shard of the slide list (each rank times `steps` of them)
+        # this rank's shard of the slide list (each rank times `steps` of them).  Round 6: length-aware -- the bags are
+        # ranked by patch count and dealt in groups of `world` neighbours (snuffy_amd.balance.step_groups, the trainer's own rule):
+        # step i of every rank is a bag of (nearly) the same length, so neither the per-step all-reduce of a training step nor the
+        # barrier at the end of the timed region waits for one rank's long tail (round-robin lens[rank::world]: a step costs
+        # 1.93x the mean bag at 8 ranks on this list, grouped 1.02x)
+        from snuffy_amd import balance
+        visit = balance.step_groups(lens, world, np.random.RandomState(1).permutation(len(lens)))
+        rr = np.concatenate([np.arange(len(lens)), np.arange((-len(lens)) % world)])
+        wl = dict(wl, length_balance={"rule": "length-ranked groups of %d (snuffy_amd/balance.py)" % world,
+                                      "step_cost_max_over_mean": round(balance.imbalance(lens, visit, world, True), 4),
+                                      "round_robin_would_be": round(balance.imbalance(lens, rr, world, True), 4)})
+        mine = lens[visit.reshape(-1, world)[:, rank]]
         g = torch.Generator().manual_seed(1234 + rank)
         bags = [torch.randn(1, int(n_i), D, generator=g).to(device) for n_i in mine]
         nbags = len(bags)
@@ -613,9 +650,12 @@ def main():
                        "parallelism": "bag-parallel x%d" % world, "bags_resident_per_rank": nbags,
                        "launch": launch, "rccl_ranks": world if dist is not None else 0,
                        "per_rank_slides_per_s": [round(args.steps / t, 2) for t in per_rank],
+                       "rank_time_max_over_mean": round(max(per_rank) / (sum(per_rank) / len(per_rank)), 4),
                        "model_tflops_per_s": round(flops_fwd * (3 if args.mode == "train" else 1) * world * args.steps
                                                    / elapsed / 1e12, 2)},
         }
+        if "length_balance" in wl:
+            line["config"]["length_balance"] = wl["length_balance"]
         for key, rec in extra.items():
             if key == "with_A":
                 line["value_with_attention_output"] = round(world * rec["steps"] / rec["elapsed"], 3)

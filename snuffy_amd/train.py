@@ -24,6 +24,7 @@ import torch
 import torch.nn as nn
 from torch import optim
 
+from . import balance
 from . import functional as SF
 from . import snuffy, snuffy_multiclass
 from .utils import (OPTIMIZERS, WEIGHT_INITS, compute_pos_weight, dropout_patches, dropout_patches_device,
@@ -67,6 +68,9 @@ def get_args_parser():
                         'into one set of launches (MILNet.forward_bags: same selections, same draws of the random share; '
                         'projections over the packed rows, so logits can move by rounding).  1 = one bag per forward, as the reference')
     p.add_argument('--eval_pack_max_patches', default=16384, type=int)
+    p.add_argument('--balance_lengths', default=1, type=int, choices=[0, 1],
+                   help='snuffy_amd, several ranks only: 1 = the bags of one training step are neighbours in patch count and the '
+                        'evaluation bags are dealt longest-first (balance.py; SURVEY 8e); 0 = positions r::W of the shuffle')
     return p
 
 
@@ -249,10 +253,15 @@ class Trainer:
             self._criterion_is_set = True
         num_bags = len(order)
         steps = (num_bags + self.world_size - 1) // self.world_size
+        if self.world_size > 1 and int(getattr(self.args, 'balance_lengths', 1)):
+            # a step ends in ONE all-reduce and costs its LONGEST bag: the ranks' bags of a step are neighbours in length (SURVEY 8e;
+            # balance.step_groups -- every bag once per epoch, the groups in the shuffle's order; identical on every rank)
+            visit = balance.step_groups(balance.bag_lengths(feats), self.world_size, order)
+        else:
+            visit = np.asarray(order)[np.arange(steps * self.world_size) % num_bags]   # wrap: every rank steps every time
         losses, preds, seen = [], [], []
         for s in range(steps):
-            pos = s * self.world_size + self.rank
-            i = int(order[pos % num_bags])                                      # wrap: every rank steps every time
+            i = int(visit[s * self.world_size + self.rank])
             f = feats[i]
             if not torch.is_tensor(f):
                 if self.args.l2normed_embeddings == 1:
@@ -315,7 +324,12 @@ class Trainer:
         self.milnet.eval()
         labels, feats = data[0], data[1]
         num_bags = len(labels)
-        mine = list(range(self.rank, num_bags, self.world_size))
+        if self.world_size > 1 and int(getattr(self.args, 'balance_lengths', 1)):
+            # no collective in the data path: longest-processing-time-first over the bags' patch counts
+            shares = balance.lpt_assignment(balance.bag_lengths(feats), self.world_size)
+        else:
+            shares = [list(range(r, num_bags, self.world_size)) for r in range(self.world_size)]
+        mine = shares[self.rank]
         losses, preds = [], []
 
         def load(i):
@@ -349,7 +363,7 @@ class Trainer:
         rows = torch.cat([torch.cat(losses).view(-1, 1), torch.stack(preds)], dim=1) if mine else \
             torch.zeros(0, 1 + ncls, device=device)
         if self.dist is not None and self.world_size > 1:
-            per = (num_bags + self.world_size - 1) // self.world_size
+            per = max(len(sh) for sh in shares)
             pad = torch.zeros(per, rows.shape[1], device=rows.device, dtype=rows.dtype)
             pad[:rows.shape[0]] = rows
             if self.dist.get_backend() != "nccl":
@@ -358,7 +372,7 @@ class Trainer:
             self.dist.all_gather(gathered, pad)
             full = torch.zeros(num_bags, rows.shape[1], dtype=rows.dtype)
             for r in range(self.world_size):
-                idx = list(range(r, num_bags, self.world_size))
+                idx = shares[r]
                 full[idx] = gathered[r][:len(idx)].cpu()
             rows = full
         rows = rows.cpu().numpy()

@@ -107,7 +107,7 @@ def _toy_bags(n_bags=11):
     return labels, feats, None, None
 
 
-def _trainer_worker(rank, world, port, out):
+def _trainer_worker(rank, world, port, out, balance_lengths=1):
     import numpy as np
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -120,7 +120,7 @@ def _trainer_worker(rank, world, port, out):
             return _TinyMIL()
 
     args = T.get_args_parser().parse_args(["--optimizer", "adamw", "--num_epochs", "4", "--lr", "1e-2", "--dropout_patch",
-                                           "0.1", "--soft_average", "1"])
+                                           "0.1", "--soft_average", "1", "--balance_lengths", str(balance_lengths)])
     args.weight_init__weight_init_i__weight_init_b = [None, None, None]
     torch.manual_seed(100 + rank)            # replicas are built from DIFFERENT seeds: the trainer must sync them
     np.random.seed(7 + rank)                 # and the global numpy RNGs differ from the start
@@ -136,13 +136,28 @@ def _trainer_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_trainer_epoch_partition_replica_sync_and_sharded_valid_world2():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("balance_lengths", [1, 0])
+def test_trainer_epoch_partition_replica_sync_and_sharded_valid_world2(balance_lengths):
+    """balance_lengths = 1 (default, round 6): the two bags of a step are neighbours in patch count, the validation bags are dealt
+    longest-first; 0: positions r::W of the shuffle.  Either way every bag is visited once per epoch and the replicas stay identical."""
     import numpy as np
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_trainer_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_trainer_worker, args=(world, _free_port(), out, balance_lengths), nprocs=world, join=True)
     n_bags = 11
+    if balance_lengths:
+        lens = np.array([f.shape[0] for f in _toy_bags()[1]])
+        for e in range(3):   # step s: no third bag's length lies strictly between the two ranks' bags (but for the wrap-around pad)
+            pads = 0
+            for a, b in zip(out[0]["visited"][e], out[1]["visited"][e]):
+                lo, hi = sorted((lens[a], lens[b]))
+                between = int(((lens > lo) & (lens < hi)).sum())
+                pads += between > 0
+            assert pads <= 1
     for e in range(3):
         seen = out[0]["visited"][e] + out[1]["visited"][e]
         assert len(out[0]["visited"][e]) == len(out[1]["visited"][e]) == (n_bags + 1) // 2

@@ -229,3 +229,50 @@ def test_bench_rccl_path_on_one_rank(mode):
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["config"]["rccl_ranks"] == 1 and line["n_gpus"] == 1 and line["value"] > 0
     assert len(line["config"]["per_rank_slides_per_s"]) == 1
+
+
+def test_bag_parallel_two_ranks_on_rccl(tmp_path):
+    """SURVEY 8e on the device (VERDICT r5 #4 / #5a): two ranks on the "nccl" (= RCCL) backend, the REAL model.  One
+    BagParallelStepper step at world 2 (rank r on bag r, ONE flat-gradient all-reduce) == one process that accumulates both bags'
+    gradients, halves them and steps; the replicas stay bit-identical; sharded Snuffy.valid == the single-process pass.  Needs two
+    GPUs: skipped on a one-GPU box (the driver's multi-GPU node runs it)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (torch.cuda.device_count() = %d)" % torch.cuda.device_count())
+    import subprocess
+    import sys
+    out_path = str(tmp_path / "world2.pt")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "tests", "nccl_world2_worker.py"), out_path]
+    run = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    z = torch.load(out_path, weights_only=False)
+    r0, r1 = z["ranks"]
+    for k in r0["after"]:
+        assert torch.equal(r0["after"][k], r1["after"][k]), k                       # replicas never drift
+    assert np.array_equal(r0["preds"], r1["preds"]) and r0["loss"] == r1["loss"]
+    # single-process reference: same start weights, both bags accumulated at half weight, one AdamW step
+    from snuffy_amd.train import BagParallelStepper, Snuffy
+    args = _snuffy_args(128, num_heads=2, big_lambda=32)
+    torch.manual_seed(1)
+    tr = Snuffy(args)
+    tr.milnet.load_state_dict(z["start"])
+    for m in tr.milnet.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    st = BagParallelStepper(tr.milnet, world_size=1, dist=None, device=DEV, lr=args.lr, betas=tuple(args.betas),
+                            weight_decay=args.weight_decay, precision="fp32")
+    for bag, label in zip(z["bags"], z["labels"]):
+        ins, logits, _ = tr.milnet(bag.to(DEV))
+        max_pred, _ = torch.max(ins, 1)
+        y = label.to(DEV)
+        loss = st.w * st.criterion(logits.view(1, -1), y.view(1, -1)) + (1 - st.w) * st.criterion(max_pred.view(1, -1), y.view(1, -1))
+        (loss / 2).backward()
+    st.optimizer.step()
+    for k, v in tr.milnet.state_dict().items():
+        ref = v.detach().cpu()
+        scale = max(1e-6, float(ref.abs().max()))
+        assert float((r0["after"][k] - ref).abs().max()) <= 2e-6 * scale + 1e-9, k   # (g0 + g1) / 2 in either association
+    tr.milnet.load_state_dict(r0["after"])
+    res = tr.valid((z["vlabels"], z["vfeats"], None, None))
+    assert np.allclose(res["predictions"], r0["preds"], atol=1e-6) and abs(res["epoch_valid_loss"] - r0["loss"]) < 1e-6

@@ -204,3 +204,41 @@ def test_param_key_changes_with_every_optimizer_step():
     SF.bump_param_epoch()
     assert SF.param_key(p)[3] == k1[3] + 1
 
+
+
+# ---- round 6: length-aware work assignment of the bag-parallel path (snuffy_amd/balance.py) -------------------------
+def _cam16_lengths(n_bags=400, mean=30000, sigma=0.5, seed=0):
+    rs = np.random.RandomState(seed)
+    return np.clip(np.round(rs.lognormal(np.log(mean) - sigma * sigma / 2, sigma, n_bags)), 1000, 100000).astype(int)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("n_bags", [400, 399, 7])
+def test_step_groups_visit_every_bag_once_and_balance_the_steps(world, n_bags):
+    from snuffy_amd import balance
+    lens = _cam16_lengths(n_bags)
+    order = np.random.RandomState(3).permutation(n_bags)
+    pos = balance.step_groups(lens, world, order)
+    steps = (n_bags + world - 1) // world
+    assert pos.shape == (steps * world,) and set(pos.tolist()) == set(range(n_bags))
+    assert len(pos) - len(set(pos.tolist())) == (-n_bags) % world                   # only the pad of the last group repeats
+    assert np.array_equal(pos, balance.step_groups(lens, world, order))               # a pure function: identical on every rank
+    if world == 1:
+        assert np.array_equal(pos, order)                                             # one rank: the reference's shuffle itself
+    if n_bags >= 399:
+        # sum over steps of the longest bag <= 1.1 x (sum N / W); positions r::W of a shuffle pay 1.3 ... 1.9
+        assert balance.imbalance(lens, pos, world, True) <= 1.1
+        other = np.random.RandomState(4).permutation(n_bags)
+        assert not np.array_equal(balance.step_groups(lens, world, other), pos) or world == n_bags   # the epoch's shuffle still decides the order
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_lpt_assignment_partitions_and_balances(world):
+    from snuffy_amd import balance
+    lens = _cam16_lengths()
+    shares = balance.lpt_assignment(lens, world)
+    assert sorted(i for sh in shares for i in sh) == list(range(len(lens))) and all(sh == sorted(sh) for sh in shares)
+    assert balance.imbalance(lens, shares, world, False) <= 1.01
+    rr = [list(range(r, len(lens), world)) for r in range(world)]
+    assert balance.imbalance(lens, shares, world, False) <= balance.imbalance(lens, rr, world, False)
+    assert balance.lpt_assignment([5, 5, 5], 2) == [[0, 2], [1]]                      # ties: ascending index, lowest rank first
