@@ -11,7 +11,11 @@
  *   - row-major, contiguous unless a leading dimension is passed; index tensors are int64 (torch.long);
  *   - asynchronous on `stream` (a hipStream_t passed as void*); never synchronises, never allocates;
  *   - returns 0 on success, a negative SNF_E* code on failure; message via snf_last_error() (thread-local);
- *   - stateless, re-entrant, thread-safe; results are deterministic run-to-run (no float atomics).
+ *   - stateless, re-entrant, thread-safe; results are deterministic run-to-run (no float atomics).  The ONE exception is the block
+ *     of snf_debug_* switches at the end of this header: process-wide kernel-variant selectors for the parity tests and the A / B
+ *     timing tools (atomic ints read once at the entry of a call; every variant computes the same function, so a racing switch
+ *     can change which kernel runs, never what a call returns beyond the documented rounding order).  Nothing in snuffy_amd/
+ *     touches them; an embedding that wants the contract above without the footnote simply never calls them.
  */
 #ifndef SNUFFY_HIP_H
 #define SNUFFY_HIP_H
@@ -538,7 +542,8 @@ int snf_random_share_keys_f32(const void* state, int layer, int64_t n, const int
                               snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
- * Debug hooks (development tools only: tools/attn_trace.py, tools/x3p_trace.py; nothing in the product path calls them).
+ * Debug hooks -- PROCESS-WIDE state, outside the stateless / re-entrant contract at the top of this header (see there).  Callers:
+ * tests/ (cross-checks of kernel variants against each other) and tools/ (A / B timing, traces); nothing in snuffy_amd/ calls them.
  * snf_debug_attn_trace(buf): device buffer of u64 that dev builds of the attention kernels (X3P_TRACE / SNF_ATTN_TRACE defines)
  * fill with s_memtime stamps of workgroup snf_debug_attn_trace_wg(wg); null switches the stamps off.  Shipped builds carry no
  * stamp code: the calls only set two host-side variables. */

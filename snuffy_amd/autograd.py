@@ -565,6 +565,8 @@ def fused_layer0_x3_ok(x2, sel, layer, precision):
     f = ff.w_1.weight.shape[0]
     if ff.activation_name != "relu" or n0.eps != n1.eps or d % mha.h or d % 8 or f % 8 or n < 256:
         return False
+    if f > 8192 or d > 8192:        # the backward's ops.split3_colsum runs over dhid [N, F] and dz [N, D]: k % 8 == 0, k <= 8192
+        return False
     if layer.training and (layer.sublayer[0].dropout.p > 0 or layer.sublayer[1].dropout.p > 0 or ff.dropout.p > 0):
         return False
     if any(t is None for t in (n0.weight, n0.bias, n1.weight, n1.bias, ff.w_1.bias, ff.w_2.bias) + tuple(l.bias for l in mha.linears)):

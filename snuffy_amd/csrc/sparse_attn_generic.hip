@@ -11,6 +11,8 @@
 //   3. reduce: out[k, d] = sum over slices in ascending order (deterministic).
 #include <math.h>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -1257,7 +1259,7 @@ __global__ __launch_bounds__(256, 2) void pt_v_lds_kernel(const float* __restric
         }
 }
 
-bool g_pt_v_lds = true;      // snf_debug_exact_attn_mfma(2): the direct-from-L2 kernels (A / B partners of the LDS-staged ones)
+std::atomic<bool> g_pt_v_lds{true};      // snf_debug_exact_attn_mfma(2): the direct-from-L2 kernels (A / B partners of the LDS-staged ones)
 
 int launch_pt_v_mfma(const float* p, const float* v, int64_t n, int k, int h, int dk, int64_t rows_per_slice, int slices, float* partial,
                      hipStream_t s, int ldv = 0) {
@@ -1287,9 +1289,9 @@ int launch_pt_v_mfma(const float* p, const float* v, int64_t n, int k, int h, in
 }
 
 // development / test switch (snf_debug_exact_attn_mfma): false = the round-1 vector-ALU kernels for every shape
-bool g_exact_mfma = true;
+std::atomic<bool> g_exact_mfma{true};
 // ... and 2 = the matrix-core forms with the dQ / dV kernel that reads its operands straight from L2 (the A / B partner of the LDS-staged one)
-bool g_dq_dv_lds = true;
+std::atomic<bool> g_dq_dv_lds{true};
 
 }  // namespace
 

@@ -1,6 +1,8 @@
 // K7, fp32-class: host side of the pipelined split-bf16 x3 sparse attention on pre-split operands (kernels: sparse_attn_x3p_impl.h) --
 // launch plans, key chunks, workspace layout, the C entry points; and the kernel family dk = 128 / one key block per wave (round 4).
 // The other families live in sparse_attn_x3p_k2.hip (dk = 128, two key blocks per wave) and sparse_attn_x3p_dk64.hip (dk = 64).
+#include <atomic>
+
 #include "sparse_attn_x3p_impl.h"
 
 namespace snf {
@@ -9,7 +11,7 @@ namespace x3p {
 // 4), 2 = one wave per SIMD with two key blocks each (round 5: half the LDS fragment reads and no issue sharing, but nothing hides a
 // wave's own latencies -- measured equal at 160 / 200 keys and 10 % behind at 256, profiles/r05_attn_x3p_kbw.txt, so 1 stays the
 // default).  snf_debug_x3p_kbw() switches it for A / B measurements and the parity tests.
-int g_kbw_dk128 = 1;
+std::atomic<int> g_kbw_dk128{1};
 
 int run_dk128_k1(const X3PParams& P, const X3PPlan& pl, float* out, hipStream_t s, int mode) {
 #define SNF_X3P_CASE(NB) \
@@ -93,6 +95,9 @@ bool x3p_layout(int64_t n, int k, int h, int dk, X3PChunks* ch, X3PLayout* lay) 
     if (h < 1 || !x3p_chunks(k, dk, ch)) return false;
     const int ranges = x3p_merged_ranges(*ch, k);
     lay->merged = ranges > 0;
+    // chunks are whole key blocks, so the last one can be short (k = 1345: 5 x 256 + 65).  Only the merged launch masks a short last
+    // chunk; a launch of its own needs the kernel's 97 keys (devices with fewer than 8 x chunks CUs have no merged form)
+    if (!lay->merged && ch->count > 1 && k - (ch->count - 1) * ch->size < 97) return false;
     if (!x3p_plan(n, ch->size, h, dk, &lay->plan, ranges)) return false;
     const size_t copies = lay->merged ? ch->count : 1;
     lay->partial = copies * x3p_partial_bytes(lay->plan, dk);        // the first chunks are the largest

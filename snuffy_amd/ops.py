@@ -739,9 +739,19 @@ def sparse_attn_fwd_x3(q, v, kp, h, scale=None, need_attn=False, need_lse=False,
     return out, attn, lse
 
 
+_X3_HL_OK = {}
+
+
 def x3_hl_attn_supported(k, dk):
-    """Shapes of the pipelined fp32-class attention kernel on pre-split operands (snf_sparse_attn_fwd_x3_hl)."""
-    return dk in (64, 128) and 97 <= k <= 2048
+    """Shapes of the pipelined fp32-class attention kernel on pre-split operands (snf_sparse_attn_fwd_x3_hl): dk = 64 / 128,
+    97 .. 2048 keys -- asked of the library itself, whose answer also depends on the device (a key count whose last chunk is
+    shorter than 97 keys needs the merged launch: >= 8 x chunks CUs)."""
+    if dk not in (64, 128) or not 97 <= k <= 2048:
+        return False
+    key = (int(k), int(dk), torch.cuda.current_device() if torch.cuda.is_available() else -1)
+    if key not in _X3_HL_OK:
+        _X3_HL_OK[key] = _ffi.load().snf_sparse_attn_fwd_x3_hl_workspace_bytes(4096, int(k), 1, int(dk)) > 0
+    return _X3_HL_OK[key]
 
 
 class KpFrag:

@@ -63,6 +63,12 @@ class RuntimeConfig:
         one layer -- roi.py's depth-5 model, reference roi.py:318-339 -- run the fp32-class kernels whatever `precision` says
         (SF.BF16_DEEP_STACKS = "bf16" restores the literal setting for experiments)."""
         if (self.precision == "bf16" and self.stack is not None and len(self.stack) > 1 and SF.BF16_DEEP_STACKS != "bf16"):
+            if not getattr(self, "_warned_deep_bf16", False):
+                import warnings
+                warnings.warn("snuffy_amd: precision='bf16' on a stack of %d encoder layers runs the fp32-class kernels (the 1e-2 class "
+                              "does not survive a stack of softmaxes; RuntimeConfig.compute == 'fp32').  Timings and errors of this "
+                              "model are fp32-class figures." % len(self.stack), RuntimeWarning, stacklevel=3)
+                self._warned_deep_bf16 = True
             return "fp32"
         return self.precision
 
@@ -234,6 +240,8 @@ class EncoderLayer(nn.Module):
     def forward(self, x, c):
         "x [1, N, D], c [1, N, 1] -> (z [1, N, D], A [1, h, N, K])"
         x2, c1 = SF.check_bag(x, c)
+        if self.cfg.sampler == "device" and self.random_patch_share > 0:
+            self.cfg.device_sampler(x2.device).advance()     # a layer called on its own (not through Encoder.run_layers): fresh rows per call
         parts, attn = self.run(x2, c1, None, self.cfg.return_attention)
         return SF.materialize(parts).unsqueeze(0), attn
 
@@ -299,7 +307,8 @@ class MILNet(nn.Module):
         stays on the device (random_patch_share == 0, or sampler="device"), outside autograd.
         sampler: "reference" (default: the random patch share is np.random.choice on the host, the reference's MT19937 draws bit
         for bit) or "device" (opt-in fast mode: Philox keys + top-k on the GPU, same distribution, no host sync; a captured graph
-        draws fresh rows on every replay)."""
+        draws fresh rows on every replay).  "device" applies to the one-bag-per-forward path; forward_bags (packed.py) draws the
+        random share of a packed batch with the reference's host draws whatever this says, and is not graph-captured then."""
         self.b_classifier.configure(precision, return_attention)
         if sampler is not None:
             self.b_classifier.cfg.set_sampler(sampler)       # RuntimeConfig.set_sampler: "reference" (parity, default) | "device"
@@ -371,6 +380,8 @@ class MILNet(nn.Module):
                 new.__dict__[k] = copy.deepcopy(v, memo)
         if getattr(self, "_graph_max_patches", 0):
             new._graphs, new._graph_seen, new._graph_pool = {}, set(), None
+        # the copy draws its own rows: a cloned {seed, offset} record would make both models select identical random shares
+        new.b_classifier.cfg._device_sampler = None
         return new
 
     def _forward_graph(self, x):

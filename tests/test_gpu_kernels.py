@@ -575,6 +575,8 @@ X3P_SHAPES = [(1000, 200, 6, 128), (4097, 224, 3, 128), (33, 128, 2, 128), (1, 9
               (777, 129, 2, 128), (300, 160, 1, 128), (6401, 200, 6, 128),
               # more than 256 keys: key chunks with exact cross-chunk statistics
               (3000, 512, 6, 128), (700, 257, 2, 128), (1500, 601, 3, 128), (257, 1790, 1, 128), (100, 2048, 2, 128),
+              # last chunk far below the 97-key minimum of a launch of its own: 5 x 256 + 65, 7 x 256 + 1 -- masked in the merged launch
+              (400, 1345, 1, 128), (300, 1793, 2, 128), (300, 1345, 2, 64),
               # dk = 64 (round 5): config A's head width
               (1000, 200, 6, 64), (4097, 256, 3, 64), (33, 128, 2, 64), (1, 97, 1, 64), (5000, 100, 12, 64), (777, 129, 2, 64),
               (300, 160, 1, 64), (8192, 200, 6, 64), (3000, 512, 6, 64), (700, 257, 2, 64), (257, 1790, 1, 64)]
