@@ -135,12 +135,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
     // store instructions per lane and 16-row block (EPI 2: fp32 x + its bf16 copy + one moment pair)
     constexpr int NST = EPI == 2 ? NC / 4 + NC / 8 + 1 : (OUT == 1 || OUT == 3) ? NC / 4 : OUT == 2 ? 3 * NC / 8 : NC / 8;
     static_assert((AHEAD - 1) * (2 + NI / 2) + 8 * NST <= 63, "gemm_bf16: counted waits are 6-bit");
+    // bf16 rows leave as full 128-byte lines (epilogue; 4 KiB of LDS per wave) -- where the epilogue is not already bound by its own
+    // arithmetic: behind the erf GELU the LDS round trip measured +3 % (ViT fc1 219 -> 226 us), behind none / ReLU -3 ... -5 %
+    // (ViT qkv 144 -> 137.5 us, config-B FFN-in 193.6 -> 183.1 us; profiles/r06_gemm_line_stores.txt)
+    constexpr bool LINE_STORES = OUT == 0 && NI == 4 && EPI != 2 && ACT != SNF_ACT_GELU && ACT != SNF_ACT_SELU;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NBUF][A image | W image]
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     const int ns = P.k / BKS;                  // steps per tile (>= 2)
+    unsigned char* const scr = smem + NBUF * STEP_BYTES + wid * 4096;   // LINE_STORES: this wave's two 2-KiB transpose buffers
 
     // ---- persistent tile stream, XCD-aware: workgroup b runs on XCD b % 8; every XCD owns a contiguous range of logical
     // tiles and its workgroups take consecutive tiles of it (column tiles of one A row panel first), so a panel is fetched
@@ -370,6 +375,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                         *reinterpret_cast<u32x4*>(dst) = pk;
                         *reinterpret_cast<u32x4*>(dst + 32) = pl;
                     }
+                } else if constexpr (LINE_STORES) {
+                    // bf16 output, 256-wide tile: the wave's 16 rows x 128 bytes of this row block go through a wave-private LDS
+                    // scratch (16-byte chunk c of row r at position c ^ (r & 7): conflict-free both ways) and leave as FULL 128-byte
+                    // lines below -- straight from the accumulator layout a store instruction writes 16 rows x 64 bytes, and the write
+                    // path handles one line REQUEST per ~10 cycles whatever its fill (tools/probes/store_probe.hip: the qkv output in
+                    // bursts 35 us as half lines, 21 us as full lines)
+                    const u32x4 pk = {cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
+                    *reinterpret_cast<u32x4*>(scr + (mi & 1) * 2048 + fi * 128 + (((fg + 4 * h) ^ (fi & 7)) << 4)) = pk;
                 } else {
                     unsigned short* dst = reinterpret_cast<unsigned short*>(P.c) + (int64_t)row * P.ldc + col;
                     const u32x4 pk = {cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
@@ -385,6 +398,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                             *reinterpret_cast<u32x4*>(dst + 2 * (int64_t)P.n) = pl;
                         }
                     }
+                }
+            }
+            if constexpr (LINE_STORES) {
+                const int lr = lane >> 3, lc = lane & 7;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int r = lr + 8 * jj;
+                    const u32x4 val = *reinterpret_cast<const u32x4*>(scr + (mi & 1) * 2048 + r * 128 + ((lc ^ (r & 7)) << 4));
+                    const int orow = tm * BM + 128 * wr + 16 * mi + r, ocol = tn * BN + 64 * wc + 8 * lc;
+#ifdef SNF_GEMM_NOSTORE
+                    const bool ok2 = P.k < 0 && orow < P.m && ocol + 8 <= P.n;
+#else
+                    const bool ok2 = FULL || (orow < P.m && ocol + 8 <= P.n);
+#endif
+                    if (ok2) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(P.c) + (int64_t)orow * P.ldc + ocol) = val;
                 }
             }
             if constexpr (EPI == 2) {
@@ -876,7 +904,8 @@ int launch_hl_act(const GemmParams& P, hipStream_t s) {
 
 template <int NI, int ACT, int OUT, int EPI = 0>
 int launch(const GemmParams& P, hipStream_t s) {
-    constexpr int lds = NBUF * (A_BYTES + 64 * NI * ROWB);
+    constexpr int lds = NBUF * (A_BYTES + 64 * NI * ROWB) +
+                        ((OUT == 0 && NI == 4 && EPI != 2 && ACT != SNF_ACT_GELU && ACT != SNF_ACT_SELU) ? 8 * 4096 : 0);
     static thread_local unsigned long long attr_set_mask = 0;   // devices (bit = device id) that have the opt-in
     const unsigned long long attr_set_bit = snf::device_bit();
     const bool attr_set = (attr_set_mask & attr_set_bit) != 0;
