@@ -519,12 +519,17 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
     constexpr int IMG = BM * ROWL;               // one operand's step image: 32 KiB
     constexpr int STEP_BYTES = 2 * IMG;          // A | W
     constexpr int NC = 4 * NI;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][A | W]
+    // fp32 / hl-image rows leave as FULL 128-byte lines through a wave-private LDS transpose (round 6; as gemm_bf16_kernel's
+    // LINE_STORES): straight from the accumulator layout a store instruction writes 16 rows x 64 (hl: hi or lo half) or 4 x 16
+    // scattered bytes of 16 lines; transposed it writes 4 rows x 256 contiguous bytes.  Not behind the VALU-bound epilogues.
+    constexpr bool LINE_STORES = (OUT == 1 || OUT == 3) && ACT != SNF_ACT_GELU && ACT != SNF_ACT_SELU;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][A | W] (+ 8 x 4 KiB transpose scratch)
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     const int ns_all = P.k / BKS;                // steps per tile (true K)
+    unsigned char* const scr = smem + 2 * STEP_BYTES + wid * 4096;   // LINE_STORES: 16 rows x 256 B of this wave
 
     const int ntiles = P.tiles_m * P.tiles_n;
     const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
@@ -667,6 +672,11 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
         const int tm = tl / P.tiles_n, tn = tl - tm * P.tiles_n;
         const int n0 = tn * BN + 64 * wc + 8 * fg;
         const int row0 = tm * BM + 128 * wr + fi;
+        // (LINE_STORES) the scratch addresses hang on an opaque copy of the lane index: a dozen integer instructions per tile that are
+        // cheaper to redo here than to keep live through the K loop, where hipcc would park them in scratch (round 5's lesson)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int fio = lane_o & 15, fgo = lane_o >> 4;
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
             const int row = row0 + 16 * mi;
@@ -692,7 +702,11 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
                             v[4 + e] += r1[e];
                         }
                     }
-                    if (ok) {
+                    if constexpr (LINE_STORES) {
+                        // 16-byte chunk c = 8 h + 2 fg + half of the wave's 256-byte row span, parked at position c ^ row
+                        *reinterpret_cast<f32x4*>(scr + fio * 256 + (((8 * h + 2 * fgo) ^ fio) << 4)) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(scr + fio * 256 + (((8 * h + 2 * fgo + 1) ^ fio) << 4)) = f32x4{v[4], v[5], v[6], v[7]};
+                    } else if (ok) {
                         *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
                     }
@@ -708,11 +722,35 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
                             lo[e] = v[e] - __uint_as_float((e & 1) ? (pk[e >> 1] & 0xffff0000u) : (pk[e >> 1] << 16));
                         const u32x4 pl = {cvt_pk_bf16(lo[0], lo[1]), cvt_pk_bf16(lo[2], lo[3]), cvt_pk_bf16(lo[4], lo[5]), cvt_pk_bf16(lo[6], lo[7])};
                         unsigned short* dst = reinterpret_cast<unsigned short*>(P.c) + (int64_t)row * P.ldc + 64 * (col >> 5) + (col & 31);
-                        if (ok) {
+                        if constexpr (LINE_STORES) {
+                            // chunk c = 8 h + 4 plane + fg of the wave's 256-byte span of the image row ([hi(32) | lo(32)] per 32 columns)
+                            *reinterpret_cast<u32x4*>(scr + fio * 256 + (((8 * h + fgo) ^ fio) << 4)) = pk;
+                            *reinterpret_cast<u32x4*>(scr + fio * 256 + (((8 * h + 4 + fgo) ^ fio) << 4)) = pl;
+                        } else if (ok) {
                             *reinterpret_cast<u32x4*>(dst) = pk;
                             *reinterpret_cast<u32x4*>(dst + 32) = pl;
                         }
                     }
+                }
+            }
+            if constexpr (LINE_STORES) {
+                const int lr = lane_o >> 4, lc = lane_o & 15;
+                unsigned char* const crow = reinterpret_cast<unsigned char*>(P.c) +
+                                            (OUT == 1 ? 4 * (int64_t)(tn * BN + 64 * wc) : 2 * 2 * (int64_t)(tn * BN + 64 * wc));
+                const int64_t pitch = (OUT == 1 ? 4 : 2) * P.ldc;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int r = lr + 4 * jj;
+                    const u32x4 val = *reinterpret_cast<const u32x4*>(scr + r * 256 + ((lc ^ r) << 4));
+                    const int orow = tm * BM + 128 * wr + 16 * mi + r;
+                    // true columns of chunk lc: fp32 4 lc .. 4 lc + 3; hl image 32 (lc >> 3) + 8 (lc & 3) .. + 7
+                    const int ocol = tn * BN + 64 * wc + (OUT == 1 ? 4 * lc : 32 * (lc >> 3) + 8 * (lc & 3));
+#ifdef X3_NOSTORE
+                    const bool ok2 = val[0] == 0x12345678u && orow < 0;
+#else
+                    const bool ok2 = FULL || (orow < P.m && ocol + (OUT == 1 ? 4 : 8) <= P.n);
+#endif
+                    if (ok2) *reinterpret_cast<u32x4*>(crow + orow * pitch + 16 * lc) = val;
                 }
             }
         }
@@ -849,7 +887,7 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
 
 template <int ACT, int OUT>
 int launch_hl(const GemmParams& P, hipStream_t s) {
-    constexpr int lds = 2 * 2 * BM * 128;
+    constexpr int lds = 2 * 2 * BM * 128 + (((OUT == 1 || OUT == 3) && ACT != SNF_ACT_GELU && ACT != SNF_ACT_SELU) ? 8 * 4096 : 0);
     static thread_local unsigned long long attr_set_mask = 0;   // devices (bit = device id) that have the opt-in
     const unsigned long long attr_set_bit = snf::device_bit();
     const bool attr_set = (attr_set_mask & attr_set_bit) != 0;
