@@ -321,10 +321,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                 cs4[2 * h + 1] = *reinterpret_cast<const f32x4*>(cp + 4);
             }
         }
+        int lane_o = lane;                      // (EPI 2 scratch addresses: recomputed per tile, see gemm_hl_kernel)
+        asm volatile("" : "+v"(lane_o));
+        const int fio = lane_o & 15, fgo = lane_o >> 4;
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
             const int row = row0 + 16 * mi;
             float s1 = 0.f, s2 = 0.f;           // EPI 2: moments of the new x over this lane's columns of the row
+            u32x4 pk2[EPI == 2 ? NI / 2 : 1];
 #pragma unroll
             for (int h = 0; h < NI / 2; ++h) {   // 8-column group: ni = 2 h, 2 h + 1
                 float v[8];
@@ -345,14 +349,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                 const bool ok = FULL || (row < P.m && col + 8 <= P.n);
 #endif
                 if constexpr (EPI == 2) {
-                    float* dst = reinterpret_cast<float*>(P.c) + (int64_t)row * P.ldc + col;
-                    unsigned short* dst2 = P.c2 + (int64_t)row * P.ldc2 + col;
-                    const u32x4 pk = {cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
-                    if (ok) {
-                        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                        *reinterpret_cast<u32x4*>(dst2) = pk;
-                    }
+                    // fp32 rows and their bf16 copy leave as full lines (as LINE_STORES / gemm_hl_kernel): the fp32 chunks of this row
+                    // block go to the wave's scratch now (chunk c = 8 h + 2 fg + half of the 256-byte span at position c ^ row), the
+                    // bf16 chunks follow through the same scratch behind the fp32 reads (below)
+                    (void)ok;
+                    pk2[h] = u32x4{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
+                    *reinterpret_cast<f32x4*>(scr + fio * 256 + (((8 * h + 2 * fgo) ^ fio) << 4)) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(scr + fio * 256 + (((8 * h + 2 * fgo + 1) ^ fio) << 4)) = f32x4{v[4], v[5], v[6], v[7]};
                     if (FULL || col + 8 <= P.n) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) s1 += v[e], s2 = fmaf(v[e], v[e], s2);
@@ -416,6 +419,28 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                 }
             }
             if constexpr (EPI == 2) {
+                {
+                    const int lr = lane_o >> 4, lc = lane_o & 15;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int r = lr + 4 * jj;
+                        const u32x4 val = *reinterpret_cast<const u32x4*>(scr + r * 256 + ((lc ^ r) << 4));
+                        const int orow = tm * BM + 128 * wr + 16 * mi + r, ocol = tn * BN + 64 * wc + 4 * lc;
+                        if (FULL || (orow < P.m && ocol + 4 <= P.n))
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(P.c) + (int64_t)orow * P.ldc + ocol) = val;
+                    }
+                    // the bf16 copy: 16 rows x 128 bytes, chunk c = fg + 4 h at position c ^ (row & 7), behind the reads above (LDS is in order)
+#pragma unroll
+                    for (int h = 0; h < NI / 2; ++h) *reinterpret_cast<u32x4*>(scr + fio * 128 + (((fgo + 4 * h) ^ (fio & 7)) << 4)) = pk2[h];
+                    const int br = lane_o >> 3, bc = lane_o & 7;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int r = br + 8 * jj;
+                        const u32x4 val = *reinterpret_cast<const u32x4*>(scr + r * 128 + ((bc ^ (r & 7)) << 4));
+                        const int orow = tm * BM + 128 * wr + 16 * mi + r, ocol = tn * BN + 64 * wc + 8 * bc;
+                        if (FULL || (orow < P.m && ocol + 8 <= P.n)) *reinterpret_cast<u32x4*>(P.c2 + (int64_t)orow * P.ldc2 + ocol) = val;
+                    }
+                }
                 // the row's 64 columns of this wave sit on the four lanes fi + 16 g: sum them (fixed order), lane g = 0 writes the pair
                 s1 += __shfl_xor(s1, 16, 64), s2 += __shfl_xor(s2, 16, 64);
                 s1 += __shfl_xor(s1, 32, 64), s2 += __shfl_xor(s2, 32, 64);
@@ -943,7 +968,7 @@ int launch_hl_act(const GemmParams& P, hipStream_t s) {
 template <int NI, int ACT, int OUT, int EPI = 0>
 int launch(const GemmParams& P, hipStream_t s) {
     constexpr int lds = NBUF * (A_BYTES + 64 * NI * ROWB) +
-                        ((OUT == 0 && NI == 4 && EPI != 2 && ACT != SNF_ACT_GELU && ACT != SNF_ACT_SELU) ? 8 * 4096 : 0);
+                        ((EPI == 2 || (OUT == 0 && NI == 4 && ACT != SNF_ACT_GELU && ACT != SNF_ACT_SELU)) ? 8 * 4096 : 0);
     static thread_local unsigned long long attr_set_mask = 0;   // devices (bit = device id) that have the opt-in
     const unsigned long long attr_set_bit = snf::device_bit();
     const bool attr_set = (attr_set_mask & attr_set_bit) != 0;
