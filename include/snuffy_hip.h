@@ -443,7 +443,8 @@ int snf_layernorm_rows_hl_patch_f32(const float* x, const float* addend, int64_t
  *       SNF_EUNSUPPORTED).  t <= 256: the keys of an (image, head) sit in one LDS image; above (the reference's patch-8 recipe,
  *       README.md:552-565: t = 785) they are staged 256 at a time and a workgroup keeps its query tiles' softmax state across the chunks.
  *   snf_vit_attention_x3_f32 same program in the fp32-class arithmetic (every product hi hi + hi lo + lo hi on the bf16 matrix
- *       cores, fp32 accumulate): fp32 in / fp32 out, dk == 64, t <= SNF_VIT_MFMA_MAX_T.  Does not materialise attn.
+ *       cores, fp32 accumulate): fp32 in, dk == 64, t <= SNF_VIT_MFMA_MAX_T; out [b*t, h*dk] f32 (out_dtype SNF_DT_F32) or its
+ *       interleaved hl image [b*t, 2*h*dk] bf16 (SNF_DT_BF16_HL: the operand of the one-pass proj GEMM).  Does not materialise attn.
  * --------------------------------------------------------------------------------------------------------- */
 int snf_vit_patchify(const float* img, int b, int c, int hgt, int wid, int patch, void* cols, int out_dtype,
                      snf_stream_t stream);
@@ -461,7 +462,7 @@ int snf_vit_attention_f32(const float* qkv, int b, int t, int h, int dk, float s
 #define SNF_VIT_MFMA_MAX_T 4096
 int snf_vit_attention_mfma(const void* qkv_bf16, int b, int t, int h, int dk, float scale, void* out_bf16,
                            snf_stream_t stream);
-int snf_vit_attention_x3_f32(const float* qkv, int b, int t, int h, int dk, float scale, float* out, snf_stream_t stream);
+int snf_vit_attention_x3_f32(const float* qkv, int b, int t, int h, int dk, float scale, void* out, int out_dtype, snf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Tile preprocessing for the extractor, batched on the device     replaces the per-tile CPU transforms of

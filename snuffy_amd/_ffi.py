@@ -160,7 +160,7 @@ SIGNATURES = {
     "snf_debug_x3p_kbw": (None, [c_int]),
     "snf_debug_exact_attn_mfma": (None, [c_int]),
     "snf_vit_attention_mfma": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
-    "snf_vit_attention_x3_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "snf_vit_attention_x3_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
 }
 
 _lib = None

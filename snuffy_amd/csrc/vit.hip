@@ -367,7 +367,7 @@ __device__ __forceinline__ void vit_split8(const f32x8 x, bf16x8& hi, bf16x8& lo
 template <int NKB, bool CHUNK, bool X3>
 __global__ __launch_bounds__(VIT_ATTN_THREADS, (X3 || CHUNK) ? 2 : 4) void vit_attention_mfma_kernel(const void* __restrict__ qkv_, int B, int T,
                                                                                           int h, float scale, void* __restrict__ out_,
-                                                                                          int tpw) {
+                                                                                          int tpw, int out_hl) {
     constexpr int DK = 64;
     constexpr int NW = VIT_ATTN_THREADS / 64;   // waves per workgroup = query tiles in flight
     constexpr int NP = X3 ? 2 : 1;            // operand planes (hi, lo)
@@ -581,8 +581,18 @@ __global__ __launch_bounds__(VIT_ATTN_THREADS, (X3 || CHUNK) ? 2 : 4) void vit_a
                 for (int g = 0; g < 4; ++g) {
                     const int d0 = 32 * db + 8 * g + 4 * hf;
                     if constexpr (X3) {
-                        *reinterpret_cast<f32x4*>(op + d0) = f32x4{o_acc[db][4 * g] * inv, o_acc[db][4 * g + 1] * inv,
-                                                                   o_acc[db][4 * g + 2] * inv, o_acc[db][4 * g + 3] * inv};
+                        const f32x4 o4 = {o_acc[db][4 * g] * inv, o_acc[db][4 * g + 1] * inv, o_acc[db][4 * g + 2] * inv, o_acc[db][4 * g + 3] * inv};
+                        if (out_hl) {
+                            // the hl image of the row ([hi(32) | lo(32)] bf16 per 32 columns): what the proj GEMM reads -- O never exists in fp32
+                            const u32x2 hi2 = {pack_bf16x2(o4[0], o4[1]), pack_bf16x2(o4[2], o4[3])};
+                            const u32x2 lo2 = {pack_bf16x2(o4[0] - __uint_as_float(hi2[0] << 16), o4[1] - __uint_as_float(hi2[0] & 0xffff0000u)),
+                                               pack_bf16x2(o4[2] - __uint_as_float(hi2[1] << 16), o4[3] - __uint_as_float(hi2[1] & 0xffff0000u))};
+                            unsigned short* oh = reinterpret_cast<unsigned short*>(out_) + (base + q_out) * 2 * D + 2 * a * DK + 64 * db + 8 * g + 4 * hf;
+                            *reinterpret_cast<u32x2*>(oh) = hi2;
+                            *reinterpret_cast<u32x2*>(oh + 32) = lo2;
+                        } else {
+                            *reinterpret_cast<f32x4*>(op + d0) = o4;
+                        }
                     } else {
                         u32x2 o = {pack_bf16x2(o_acc[db][4 * g] * inv, o_acc[db][4 * g + 1] * inv),
                                    pack_bf16x2(o_acc[db][4 * g + 2] * inv, o_acc[db][4 * g + 3] * inv)};
@@ -627,7 +637,7 @@ __global__ __launch_bounds__(VIT_ATTN_THREADS, (X3 || CHUNK) ? 2 : 4) void vit_a
 }
 
 template <int NKB, bool CHUNK, bool X3>
-int launch_vit_mfma(const void* qkv, int B, int T, int h, float scale, void* out, hipStream_t s) {
+int launch_vit_mfma(const void* qkv, int B, int T, int h, float scale, void* out, hipStream_t s, int out_hl = 0) {
     constexpr size_t lds = (size_t)(X3 ? 2 : 1) * ((size_t)(32 * NKB * (64 + 8)) * sizeof(unsigned short) + (size_t)32 * NKB * 128);
     static_assert(lds <= 160 * 1024, "vit_attention_mfma: LDS budget");
     static thread_local unsigned long long attr_set_mask = 0;   // devices (bit = device id) that have the opt-in
@@ -647,7 +657,7 @@ int launch_vit_mfma(const void* qkv, int B, int T, int h, float scale, void* out
     const int ntile = (T + 31) / 32;
     const int nz = CHUNK ? (ntile + 7) / 8 : 1;
     const int tpw = CHUNK ? (ntile + nz - 1) / nz : 0;
-    hipLaunchKernelGGL(kern, dim3(h, B, nz), dim3(VIT_ATTN_THREADS), lds, s, qkv, B, T, h, scale, out, tpw);
+    hipLaunchKernelGGL(kern, dim3(h, B, nz), dim3(VIT_ATTN_THREADS), lds, s, qkv, B, T, h, scale, out, tpw, out_hl);
     return snf::check_launch("vit_attention_mfma_kernel");
 }
 
@@ -767,8 +777,10 @@ int snf_vit_attention_mfma(const void* qkv_bf16, int b, int t, int h, int dk, fl
     return launch_vit_mfma<8, true, false>(qkv_bf16, b, t, h, scale, out_bf16, s);   // keys in chunks of 256 (patch 8: t = 785)
 }
 
-int snf_vit_attention_x3_f32(const float* qkv, int b, int t, int h, int dk, float scale, float* out, snf_stream_t stream) {
+int snf_vit_attention_x3_f32(const float* qkv, int b, int t, int h, int dk, float scale, void* out, int out_dtype, snf_stream_t stream) {
     SNF_REQUIRE(qkv && out, "snf_vit_attention_x3_f32: null pointer");
+    SNF_REQUIRE(out_dtype == SNF_DT_F32 || out_dtype == SNF_DT_BF16_HL, "snf_vit_attention_x3_f32: output is f32 or the hl image (dtype %d)", out_dtype);
+    const int out_hl = out_dtype == SNF_DT_BF16_HL;
     SNF_REQUIRE(b >= 1 && t >= 1 && h >= 1, "snf_vit_attention_x3_f32: bad shape");
     if (dk != 64 || t > SNF_VIT_MFMA_MAX_T || b > 65535) {
         snf::set_error("snf_vit_attention_x3_f32: unsupported shape dk=%d t=%d (need dk == 64, t <= %d)", dk, t, SNF_VIT_MFMA_MAX_T);
@@ -777,10 +789,10 @@ int snf_vit_attention_x3_f32(const float* qkv, int b, int t, int h, int dk, floa
     SNF_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15) == 0, "snf_vit_attention_x3_f32: qkv must be 16-byte aligned");
     hipStream_t s = snf::as_stream(stream);
     const int nkb = (t + 31) / 32;
-    if (nkb <= 2) return launch_vit_mfma<2, false, true>(qkv, b, t, h, scale, out, s);
-    if (nkb <= 4) return launch_vit_mfma<4, false, true>(qkv, b, t, h, scale, out, s);
-    if (nkb <= 7) return launch_vit_mfma<7, false, true>(qkv, b, t, h, scale, out, s);
-    return launch_vit_mfma<7, true, true>(qkv, b, t, h, scale, out, s);               // keys in chunks of 224
+    if (nkb <= 2) return launch_vit_mfma<2, false, true>(qkv, b, t, h, scale, out, s, out_hl);
+    if (nkb <= 4) return launch_vit_mfma<4, false, true>(qkv, b, t, h, scale, out, s, out_hl);
+    if (nkb <= 7) return launch_vit_mfma<7, false, true>(qkv, b, t, h, scale, out, s, out_hl);
+    return launch_vit_mfma<7, true, true>(qkv, b, t, h, scale, out, s, out_hl);               // keys in chunks of 224
 }
 
 }  // extern "C"

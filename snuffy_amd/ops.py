@@ -1557,7 +1557,7 @@ def vit_residual_ln_(x, add1=None, add2=None, scale2=1.0, gamma=None, beta=None,
     return ln, xb
 
 
-def vit_attention(qkv, b, t, heads, scale=None, need_attn=False, arithmetic="exact"):
+def vit_attention(qkv, b, t, heads, scale=None, need_attn=False, arithmetic="exact", hl_out=False):
     """Multi-head self-attention on the qkv Linear output [B*T, 3*D].  fp32 -> exact kernel (+ optional attn [B,h,T,T]), or with
     arithmetic="x3" (and no attn asked for, dk == 64) the MFMA kernel in split-bf16 x3 products; bf16 -> MFMA kernel (dk == 64,
     T <= VIT_MFMA_MAX_T; keys in LDS chunks above T = 256)."""
@@ -1568,10 +1568,16 @@ def vit_attention(qkv, b, t, heads, scale=None, need_attn=False, arithmetic="exa
     lib = _ffi.load()
     if qkv.dtype == torch.float32:
         qkv = _req(qkv, torch.float32, "qkv", 2)
-        out = torch.empty(b * t, d, dtype=torch.float32, device=qkv.device)
         if arithmetic == "x3" and not need_attn and vit_mfma_attention_supported(t, dk):
-            check(lib.snf_vit_attention_x3_f32(_p(qkv), b, t, heads, dk, float(scale), _p(out), _stream()), "snf_vit_attention_x3_f32")
+            # hl_out: the result leaves as its interleaved hl image [b t, 2 d] bf16 (the operand of the proj GEMM), never as fp32
+            out = (torch.empty(b * t, 2 * d, dtype=torch.bfloat16, device=qkv.device) if hl_out else
+                   torch.empty(b * t, d, dtype=torch.float32, device=qkv.device))
+            check(lib.snf_vit_attention_x3_f32(_p(qkv), b, t, heads, dk, float(scale), _p(out), DT_BF16_HL if hl_out else DT_F32, _stream()),
+                  "snf_vit_attention_x3_f32")
             return out, None
+        if hl_out:
+            raise ValueError("vit_attention: hl_out needs arithmetic='x3' (no attn, dk == 64)")
+        out = torch.empty(b * t, d, dtype=torch.float32, device=qkv.device)
         attn = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device) if need_attn else None
         check(lib.snf_vit_attention_f32(_p(qkv), b, t, heads, dk, float(scale), _p(out), _p(attn), _stream()),
               "snf_vit_attention_f32")

@@ -92,14 +92,17 @@ def layernorm_image(x2, norm, fmt):
     return split_image(y, fmt) if fmt else y
 
 
-def linear_f32(x, weight, bias, act="none", image_for=None):
+def linear_f32(x, weight, bias, act="none", image_for=None, resid=None, scale=None):
     """act(x W^T + b) of the fp32 path.  x: [m, k] f32 or a SplitImage.  FP32_GEMM == "x3": split-bf16 x3 products on the hand-written
     MFMA GEMMs -- the one-pass kernel on interleaved images where the shape fills the chip, the concatenated form otherwise -- else
     (or for shapes outside both kernels' domains) the fp32 library GEMM + the activation kernel.  image_for = the weight of the
     NEXT projection: the result is returned as the split image that projection wants, straight from this GEMM's epilogue (it never
-    exists in fp32)."""
+    exists in fp32).  resid [m, n] f32 (fp32 results only): added to the result -- in the one-pass kernel's epilogue, so a block's
+    residual adds cost no pass of their own (round 6).  scale: the result is scale * (x W^T + b) (the adapter's scalar; act "none")."""
     m = x.data.shape[0] if isinstance(x, SplitImage) else x.shape[0]
     n = weight.shape[0]
+    if scale is not None:
+        weight, bias = _scaled(weight, bias, float(scale))
     fmt = image_format(m, weight)
     out_fmt = image_format(m, image_for) if image_for is not None else None
     if out_fmt == "hl" and n % 32:
@@ -114,11 +117,15 @@ def linear_f32(x, weight, bias, act="none", image_for=None):
         if fmt == "hl":
             if out_fmt == "hl":
                 return SplitImage(ops.gemm_hl(x.data, w_img, b, act, hl_out=True), "hl", n)
-            y = ops.gemm_hl(x.data, w_img, b, act)
+            y = ops.gemm_hl(x.data, w_img, b, act, resid=resid if out_fmt is None else None)
+            if resid is not None and out_fmt is not None:
+                y = y + resid
         else:
-            if out_fmt == "cat":
+            if out_fmt == "cat" and resid is None:
                 return SplitImage(ops.gemm_x3(x.data, w_img, b, act, split3=True), "cat", n)
             y = ops.gemm_x3(x.data, w_img, b, act, out_dtype=torch.float32)
+            if resid is not None:
+                y += resid
         return split_image(y, out_fmt) if out_fmt else y
     if isinstance(x, SplitImage):
         x = x.to_f32()
@@ -128,7 +135,26 @@ def linear_f32(x, weight, bias, act="none", image_for=None):
             h += bias
         else:
             ops.bias_act_(h, bias, act)
+    if resid is not None:
+        h += resid
     return split_image(h, out_fmt) if out_fmt else h
+
+
+def _scaled(weight, bias, scale):
+    """(scale * W, scale * b), cached on the weight until it (or the bias) is written again: the adapter's `up * scale`
+    (adapter.py:88) folded into its up-projection."""
+    key = (SF.param_key(weight), None if bias is None else SF.param_key(bias), scale)
+    hit = getattr(weight, "_snf_scaled", None)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            w = (weight.detach() * scale).contiguous()
+            b = None if bias is None else (bias.detach() * scale).contiguous()
+        hit = (key, w, b)
+        try:
+            weight._snf_scaled = hit
+        except (AttributeError, RuntimeError):
+            pass
+    return hit[1], hit[2]
 
 
 class Adapter(nn.Module):
@@ -189,12 +215,13 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
 
-    def forward(self, x):
-        """x: [..., D] f32, or the SplitImage of the normalised tokens (Block.forward)."""
+    def forward(self, x, resid=None):
+        """x: [..., D] f32, or the SplitImage of the normalised tokens (Block.forward).  resid (nullable, [m, D] f32): added to the
+        output in fc2's epilogue."""
         image_in = isinstance(x, SplitImage)
         x2 = x if image_in else x.reshape(-1, x.shape[-1]).float().contiguous()
         h = linear_f32(x2, self.fc1.weight, self.fc1.bias, "gelu", image_for=self.fc2.weight)
-        out = linear_f32(h, self.fc2.weight, self.fc2.bias)
+        out = linear_f32(h, self.fc2.weight, self.fc2.bias, resid=resid)
         return out if image_in else out.view(*x.shape[:-1], -1)
 
 
@@ -214,14 +241,19 @@ class Attention(nn.Module):
     def forward(self, x):
         return self._run(x.reshape(-1, x.shape[-1]).float().contiguous(), x.shape[0], x.shape[1])
 
-    def _run(self, x2, B, N, need_attn=True):
-        """x2: [B * N, C] f32 or its SplitImage."""
+    def _run(self, x2, B, N, need_attn=True, resid=None):
+        """x2: [B * N, C] f32 or its SplitImage.  resid [B * N, C] (nullable): added to the projection's output in its epilogue."""
         C = self.proj.weight.shape[0]
         qkv = linear_f32(x2, self.qkv.weight, self.qkv.bias)
-        # fp32-class arithmetic (the projections' own): the attention on the matrix cores too; exact fp32 with the plain-fp32 GEMMs
+        # fp32-class arithmetic (the projections' own): the attention on the matrix cores too; exact fp32 with the plain-fp32 GEMMs.
+        # Where the proj GEMM is the one-pass kernel the attention writes its operand image directly (no fp32 O, no split pass)
+        x3 = FP32_GEMM == "x3" and not need_attn and ops.vit_mfma_attention_supported(N, C // self.num_heads)
+        hl = x3 and C % 32 == 0 and image_format(B * N, self.proj.weight) == "hl"
         o, attn = ops.vit_attention(qkv, B, N, self.num_heads, self.scale, need_attn=need_attn,
-                                    arithmetic="x3" if FP32_GEMM == "x3" else "exact")
-        return linear_f32(o, self.proj.weight, self.proj.bias).view(B, N, C), attn
+                                    arithmetic="x3" if FP32_GEMM == "x3" else "exact", hl_out=hl)
+        if hl:
+            o = SplitImage(o, "hl", C)
+        return linear_f32(o, self.proj.weight, self.proj.bias, resid=resid).view(B, N, C), attn
 
 
 class Block(nn.Module):
@@ -249,14 +281,21 @@ class Block(nn.Module):
         x2 = x.reshape(B * N, C).float().contiguous()
         # x3: the LayerNorm writes its output straight as the split image the projection GEMM reads
         ln1 = layernorm_image(x2, self.norm1, image_format(B * N, self.attn.qkv.weight))
-        y, attn = self.attn._run(ln1, B, N, need_attn=return_attention)
         if return_attention:
-            return attn
-        x = x + y
-        ad = self.adaptmlp(x, add_residual=False) if hasattr(self, "adaptmlp") else 0.0
-        xc = x.reshape(B * N, C).contiguous()
-        ln2 = layernorm_image(xc, self.norm2, image_format(B * N, self.mlp.fc1.weight))
-        return x + self.mlp(ln2).view(B, N, C) + ad
+            return self.attn._run(ln1, B, N, need_attn=True)[1]
+        # round 6: every residual add of the block rides in the epilogue of the GEMM that produces the addend (one-pass kernel's
+        # `resid`), the adapter's scalar is folded into its up-projection: no elementwise pass is left between the GEMMs
+        x2 = self.attn._run(ln1, B, N, need_attn=False, resid=x2)[0].reshape(B * N, C)            # x + attn(norm1(x))
+        ln2 = layernorm_image(x2, self.norm2, image_format(B * N, self.mlp.fc1.weight))
+        if hasattr(self, "adaptmlp") and self.adaptmlp.adapter_layernorm_option == "none" and not torch.is_grad_enabled() \
+                and not isinstance(self.adaptmlp.scale, nn.Parameter):
+            ad = self.adaptmlp
+            a = linear_f32(x2, ad.down_proj.weight, ad.down_proj.bias, "relu", image_for=ad.up_proj.weight)
+            y = self.mlp(ln2, resid=x2)                                                            # x + mlp(norm2(x))
+            return linear_f32(a, ad.up_proj.weight, ad.up_proj.bias, resid=y, scale=ad.scale).view(B, N, C)   # + s * up(relu(down(x)))
+        if hasattr(self, "adaptmlp"):
+            return (self.mlp(ln2, resid=x2) + self.adaptmlp(x2, add_residual=False)).view(B, N, C)
+        return self.mlp(ln2, resid=x2).view(B, N, C)
 
 
 class PatchEmbed(nn.Module):

@@ -109,6 +109,9 @@ def test_vit_attention_x3(b, t, h):
     assert torch.equal(o, o2)
     oe, _ = ops().vit_attention(qkv.to(DEV), b, t, h)                       # exact kernel: the cross-check on the device
     assert rel_err(o.cpu(), oe.cpu()) < 5e-5
+    # the hl-image output (operand of the one-pass proj GEMM) is the split of the same fp32 rows, bit for bit
+    img, _ = ops().vit_attention(qkv.to(DEV), b, t, h, arithmetic="x3", hl_out=True)
+    assert torch.equal(img, ops().split_hl_rows(o))
 
 
 def build(z):
