@@ -188,6 +188,10 @@ int snf_split3_colsum_f32(const float* x, int64_t ldx, int64_t m, int k, const v
  * on the matrix cores with the split done in registers.  r <= 8192, k % 16 == 0, rows 16-byte aligned. */
 int snf_linear_rows_x3_f32(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int r, int c, int k, void* out,
                            int64_t ldo, int out_dtype, snf_stream_t stream);
+/* The same with a second output out2 [r, c] = out + resid [r, c]: delta = o Wo^T + bo and x_sel = xs + delta (snuffy.py:205, 108) in
+ * one launch (round 6) */
+int snf_linear_rows_x3_resid_f32(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
+                                 int r, int c, int k, float* out, int64_t ldo, float* out2, int64_t ldo2, snf_stream_t stream);
 /* critic scores + LayerNorm (with affine) of the same rows in one pass, the normalised rows as the interleaved hi / lo image
  * (= snf_critic_f32 + snf_layernorm_rows_hl_f32 with one read of x; FCLayer.forward snuffy.py:39-41 + SublayerConnection.norm
  * snuffy.py:107).  d % 32 == 0; selector_state nullable (one class: also counts the selector's first radix digit); gamma and beta
@@ -378,6 +382,10 @@ int snf_sparse_attn_dkp_f32(const float* ds, const float* q, int64_t n, int k, i
  * --------------------------------------------------------------------------------------------------------- */
 int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t m, int n, int k,
                   int act, void* c, int64_t ldc, int out_dtype, int tile_n, snf_stream_t stream);
+/* fp32 output with a residual in the epilogue: c = act(a w^T + bias) + resid [m, ldr] -- z = x + W2 act(W1 LN(y)) of snuffy.py:110 for
+ * bags too small for the one-pass kernel (round 6; snf_gemm_hl_resid_bf16 is the large-bag twin) */
+int snf_gemm_bf16_resid_f32(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
+                            int64_t m, int n, int k, int act, float* c, int64_t ldc, int tile_n, snf_stream_t stream);
 /* The ViT block without LayerNorm / residual passes (round 6; vd:97-127 "x = x + attn(norm1(x)); x = x + mlp(norm2(x)) + adapter(x)"):
  *   snf_gemm_bf16_lnfold   the consumer's LayerNorm folded into its GEMM: a = the RAW rows x rounded to bf16, w = W0 diag(gamma) (bf16),
  *                          c [m, ldc] bf16 = act(rstd[m] (a w^T - mean[m] colsum[n]) + bias[n]);  colsum[n] = sum_k w[n, k] of the ROUNDED w,

@@ -117,6 +117,10 @@ SIGNATURES = {
                                        c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "snf_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
                               c_int, c_int, c_void_p]),
+    "snf_gemm_bf16_resid_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
+                                        c_void_p, c_int64, c_int, c_void_p]),
+    "snf_linear_rows_x3_resid_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                             c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "snf_gemm_bf16_lnfold": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                      c_void_p, c_int64, c_void_p]),
     "snf_gemm_bf16_resid": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p,

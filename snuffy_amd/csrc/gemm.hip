@@ -362,6 +362,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                     }
                 } else if constexpr (OUT_F32) {
                     float* dst = reinterpret_cast<float*>(P.c) + (int64_t)row * P.ldc + col;
+                    if (P.resid && ok) {   // residual added after the activation (round 6: z = x + W2 act(...) of small bags in one pass)
+                        const float* rp = P.resid + (int64_t)row * P.ldr + col;
+                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] += r0[e];
+                            v[4 + e] += r1[e];
+                        }
+                    }
                     if (ok) {
                         *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -1036,6 +1045,11 @@ struct SkinnyFrag {
     float* xs = nullptr;
     int64_t ldxs = 0;
     int32_t* map = nullptr;
+    // plain (non-fragment) f32 output, round 6: out2 [r, c] (nullable) = out + resid [r, c] -- x_sel = xs + delta of snuffy.py:108 in
+    // the output projection's own store pass
+    const float* resid = nullptr;
+    float* out2 = nullptr;
+    int64_t ldr = 0, ldo2 = 0;
 };
 template <bool OUT_BF16, bool FRAG = false>
 __global__ __launch_bounds__(512) void skinny_linear_x3_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
@@ -1172,10 +1186,12 @@ __global__ __launch_bounds__(512) void skinny_linear_x3_kernel(const float* __re
         const int row = row0 + rl, col = col0 + cl;
         if (row < r && col < c) {
             const float v = blk[rl][cl] + bv;
-            if constexpr (OUT_BF16)
+            if constexpr (OUT_BF16) {
                 reinterpret_cast<unsigned short*>(out)[(int64_t)row * ldo + col] = (unsigned short)(cvt_pk_bf16(v, 0.f) & 0xffffu);
-            else
+            } else {
                 reinterpret_cast<float*>(out)[(int64_t)row * ldo + col] = v;
+                if (fr.out2) fr.out2[(int64_t)row * fr.ldo2 + col] = v + fr.resid[(int64_t)row * fr.ldr + col];
+            }
         }
     }
 }
@@ -1195,8 +1211,20 @@ int snf::skinny_linear_x3_kpfrag(const float* x, int64_t ldx, const float* w, in
     return snf::check_launch("skinny_linear_x3_kernel<frag>");
 }
 
+static int gemm_bf16_impl(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
+                          int64_t m, int n, int k, int act, void* c, int64_t ldc, int out_dtype, int tile_n, snf_stream_t stream);
 extern "C" int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t m, int n,
                              int k, int act, void* c, int64_t ldc, int out_dtype, int tile_n, snf_stream_t stream) {
+    return gemm_bf16_impl(a, lda, w, ldw, bias, nullptr, 0, m, n, k, act, c, ldc, out_dtype, tile_n, stream);
+}
+// fp32 output with a residual: c = act(a w^T + bias) + resid [m, ldr]
+extern "C" int snf_gemm_bf16_resid_f32(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* resid,
+                                       int64_t ldr, int64_t m, int n, int k, int act, float* c, int64_t ldc, int tile_n, snf_stream_t stream) {
+    SNF_REQUIRE(resid && ldr >= n && ldr % 4 == 0 && reinterpret_cast<uintptr_t>(resid) % 16 == 0, "snf_gemm_bf16_resid_f32: resid [m, ldr] f32, 16-byte aligned rows");
+    return gemm_bf16_impl(a, lda, w, ldw, bias, resid, ldr, m, n, k, act, c, ldc, SNF_DT_F32, tile_n, stream);
+}
+static int gemm_bf16_impl(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
+                          int64_t m, int n, int k, int act, void* c, int64_t ldc, int out_dtype, int tile_n, snf_stream_t stream) {
     SNF_REQUIRE(a && w && c, "snf_gemm_bf16: null pointer");
     SNF_REQUIRE(m >= 1 && n >= 1 && k >= 1, "snf_gemm_bf16: bad shape m=%lld n=%d k=%d", (long long)m, n, k);
     SNF_REQUIRE(act >= SNF_ACT_RELU && act <= SNF_ACT_NONE, "snf_gemm_bf16: bad activation code %d", act);
@@ -1229,6 +1257,7 @@ extern "C" int snf_gemm_bf16(const void* a, int64_t lda, const void* w, int64_t 
     P.tiles_m = (int)((m + BM - 1) / BM);
     P.tiles_n = (n + tile_n - 1) / tile_n;
     P.trace = nullptr;
+    P.resid = resid, P.ldr = ldr;
 #ifdef SNF_GEMM_TRACE
     if (const char* e = getenv("SNF_GEMM_TRACE_PTR")) P.trace = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
 #endif
@@ -1422,5 +1451,22 @@ extern "C" int snf_linear_rows_x3_f32(const float* x, int64_t ldx, const float* 
         hipLaunchKernelGGL(skinny_linear_x3_kernel<true>, grid, dim3(512), 0, s, x, ldx, w, ldw, bias, r, c, k, out, ldo);
     else
         hipLaunchKernelGGL(skinny_linear_x3_kernel<false>, grid, dim3(512), 0, s, x, ldx, w, ldw, bias, r, c, k, out, ldo);
+    return snf::check_launch("skinny_linear_x3_kernel");
+}
+
+// the same with a second output out2 [r, c] = out + resid [r, c] (f32): delta = o Wo^T + bo AND x_sel = xs + delta (snuffy.py:205, 108)
+extern "C" int snf_linear_rows_x3_resid_f32(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* resid,
+                                            int64_t ldr, int r, int c, int k, float* out, int64_t ldo, float* out2, int64_t ldo2,
+                                            snf_stream_t stream) {
+    SNF_REQUIRE(x && w && out && out2 && resid, "snf_linear_rows_x3_resid_f32: null pointer");
+    SNF_REQUIRE(r >= 1 && r <= 8192 && c >= 1 && k >= 16 && k % 16 == 0, "snf_linear_rows_x3_resid_f32: bad shape r=%d c=%d k=%d "
+                "(r <= 8192, k %% 16 == 0)", r, c, k);
+    SNF_REQUIRE(ldx >= k && ldw >= k && ldo >= c && ldo2 >= c && ldr >= c && (ldx % 4) == 0 && (ldw % 4) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0,
+                "snf_linear_rows_x3_resid_f32: x / w rows must be 16-byte aligned");
+    const dim3 grid((unsigned)((c + 31) / 32), (unsigned)((r + 31) / 32));
+    SkinnyFrag fr;
+    fr.resid = resid, fr.ldr = ldr, fr.out2 = out2, fr.ldo2 = ldo2;
+    hipLaunchKernelGGL(skinny_linear_x3_kernel<false>, grid, dim3(512), 0, snf::as_stream(stream), x, ldx, w, ldw, bias, r, c, k, out, ldo, fr);
     return snf::check_launch("skinny_linear_x3_kernel");
 }

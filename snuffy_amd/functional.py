@@ -681,8 +681,13 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
         else:
             o, attn, _ = ops.sparse_attn_fwd(q.contiguous(), kp, v.contiguous(), h, need_attn=need_attn)
         del q, v, qv
+        x_sel = None
         if fp is not None:                                              # padded heads: the zero columns of O meet zero columns of Wo
             delta = ops.linear_rows_x3(o, fp["wo"], None if lo.bias is None else lo.bias.detach())
+        elif (not shared and FP32_GEMM == "x3" and lo.weight.dtype == torch.float32 and o.shape[0] < 2048
+                and ops.linear_rows_x3_supported(o.shape[0], lo.weight.shape[0], o.shape[1])):
+            # the output projection also writes x_sel = xs + delta (snuffy.py:205, 108): one launch instead of two (round 6)
+            delta, x_sel = ops.linear_rows_x3_resid(o, lo.weight.detach(), None if lo.bias is None else lo.bias.detach(), xs)
         else:
             delta = _rows_linear(o, lo)                                 # snuffy.py:205
         if shared:
@@ -693,18 +698,19 @@ def encoder_layer(x2, sel, layer, need_attn, precision, packed=None, ragged=None
             del xn3
             z = ops.gemm_hl(hid3, fh["w2"], fw["b2"], resid=x2)                    # x + W2 hid + b2: the residual rides in the epilogue
         elif hl:
-            x_sel = xs + delta                                                      # snuffy.py:108
+            if x_sel is None:
+                x_sel = xs + delta                                                  # snuffy.py:108
             yn3 = ops.layernorm_rows_hl(x2, n1.weight, n1.bias, n1.eps, slot=slot, patch_rows=x_sel)   # LN(y), y never built
             hid3 = ops.gemm_hl(yn3, fh["w1"], fw["b1"], ff.activation_name, hl_out=True)   # snuffy.py:224-225, [N, 2F] image
             del yn3
             z = ops.gemm_hl(hid3, fh["w2"], fw["b2"], resid=x2)                    # x + W2 hid + b2: the residual rides in the epilogue
         else:
-            x_sel = xs + delta                                                      # snuffy.py:108
+            if x_sel is None:
+                x_sel = xs + delta                                                  # snuffy.py:108
             yn3 = ops.layernorm_rows_split3(x2, n1.weight, n1.bias, n1.eps, slot=slot, patch_rows=x_sel)
             hid3 = ops.gemm_x3(yn3, fw["w1"], fw["b1"], ff.activation_name, split3=True)   # [N, 3F] image
             del yn3
-            z = ops.gemm_x3(hid3, fw["w2"], fw["b2"], out_dtype=torch.float32)
-            z.add_(x2)
+            z = ops.gemm_x3(hid3, fw["w2"], fw["b2"], out_dtype=torch.float32, resid=x2)   # x + W2 hid + b2: the residual rides in the epilogue
         del hid3
         if last:                                                                    # rows S: x -> x_sel (snuffy.py:155), in the head's read
             return Parts(z, slot=slot, delta=delta), (attn.unsqueeze(0) if attn is not None else None)

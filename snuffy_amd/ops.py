@@ -1280,10 +1280,27 @@ def vit_row_stats(x=None, part=None, d=None, eps=1e-6, want_bf16=False):
 GEMM_HL = True        # one-pass fp32-class GEMM kernel (snf_gemm_hl_bf16) where the shape fills the chip with 256 x 256 tiles
 
 
-def gemm_x3(a_img, w_img, bias=None, act="none", out_dtype=torch.float32, out=None, split3=False, hl_out=False):
+def gemm_x3(a_img, w_img, bias=None, act="none", out_dtype=torch.float32, out=None, split3=False, hl_out=False, resid=None):
     """fp32-class act(A W^T + bias) from the [hi | hi | lo] / [Wh | Wl | Wh] images as ONE bf16 GEMM over the 3 k concatenated
-    columns (gemm_bf16): the form for shapes the one-pass kernel (gemm_hl) does not cover."""
-    return gemm_bf16(a_img, w_img, bias, act, out_dtype, out, split3=split3, hl_out=hl_out)
+    columns (gemm_bf16): the form for shapes the one-pass kernel (gemm_hl) does not cover.  resid [m, n] f32 (fp32 output only): added
+    in the epilogue (snf_gemm_bf16_resid_f32)."""
+    if resid is None:
+        return gemm_bf16(a_img, w_img, bias, act, out_dtype, out, split3=split3, hl_out=hl_out)
+    if split3 or hl_out or out_dtype != torch.float32 or a_img.dtype != torch.bfloat16 or w_img.dtype != torch.bfloat16:
+        raise ValueError("gemm_x3: resid needs a plain fp32 output")
+    a_img, w_img = _rows16(a_img, "a"), _rows16(w_img, "w")
+    m, k = a_img.shape
+    n = w_img.shape[0]
+    resid = _rows16(_req(resid, torch.float32, "resid", 2), "resid")
+    if bias is not None:
+        bias = _req(bias, torch.float32, "bias", 1)
+    if w_img.shape[1] != k or tuple(resid.shape) != (m, n):
+        raise ValueError("gemm_x3: inconsistent shapes")
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=a_img.device)
+    check(_ffi.load().snf_gemm_bf16_resid_f32(_p(a_img), a_img.stride(0), _p(w_img), w_img.stride(0), _p(bias), _p(resid), resid.stride(0),
+                                              m, n, k, ACT_CODES[act], _p(out), out.stride(0), 0, _stream()), "snf_gemm_bf16_resid_f32")
+    return out
 
 
 def hl_eligible(m, n, k):
@@ -1482,6 +1499,26 @@ def linear_rows_x3(x, w, bias=None, out_dtype=torch.float32):
     check(_ffi.load().snf_linear_rows_x3_f32(_p(x), x.stride(0), _p(w), w.stride(0), _p(bias), r, c, k, _p(out), c,
                                              DT_F32 if out_dtype == torch.float32 else DT_BF16, _stream()), "snf_linear_rows_x3_f32")
     return out
+
+
+def linear_rows_x3_resid(x, w, bias, resid):
+    """(delta, resid + delta) with delta = x [r, k] @ w [c, k]^T + bias, fp32-class, in ONE launch (snf_linear_rows_x3_resid_f32):
+    the output projection of the K selected rows and x_sel = xs + delta (snuffy.py:205, 108)."""
+    if x.dtype != torch.float32 or w.dtype != torch.float32:
+        raise TypeError("linear_rows_x3_resid: x and w must be float32")
+    x, w = _rows16(x, "x"), _rows16(w, "w")
+    r, k = x.shape
+    c = w.shape[0]
+    resid = _req(resid, torch.float32, "resid", 2)
+    if w.shape[1] != k or not linear_rows_x3_supported(r, c, k) or tuple(resid.shape) != (r, c):
+        raise ValueError("linear_rows_x3_resid: x %s w %s resid %s outside the kernel" % (tuple(x.shape), tuple(w.shape), tuple(resid.shape)))
+    if bias is not None:
+        bias = _req(bias, torch.float32, "bias", 1)
+    out = torch.empty(r, c, dtype=torch.float32, device=x.device)
+    out2 = torch.empty(r, c, dtype=torch.float32, device=x.device)
+    check(_ffi.load().snf_linear_rows_x3_resid_f32(_p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(resid), resid.stride(0), r, c, k,
+                                                   _p(out), c, _p(out2), c, _stream()), "snf_linear_rows_x3_resid_f32")
+    return out, out2
 
 
 def gemm_x3_supported(m, n, k):
