@@ -1,7 +1,7 @@
 #!/bin/bash
-# Copy the judged artefacts of an end-of-round run (tools/run_profiles.sh + tools/sweep.py, merged back under gpurun_out/r04/) into
+# Copy the judged artefacts of an end-of-round run (tools/run_profiles.sh + tools/sweep.py, merged back under gpurun_out/r06/) into
 # profiles/ under their per-round names.  usage (container, repo root): bash tools/collect_profiles.sh
-R=r05; O=gpurun_out/$R; P=profiles
+R=r06; O=gpurun_out/$R; P=profiles
 cp_if() { [ -s "$1" ] && cp "$1" "$2"; }
 cp_if $O/bench_cfgB.json $P/${R}_bench_cfgB.json
 cp_if $O/bench_cfgA.json $P/${R}_bench_cfgA.json
@@ -15,6 +15,8 @@ cp_if $O/bf16_kernel_stats.csv $P/${R}_bench_cfgB_bf16_kernel_stats.csv
 cp_if $O/train_bf16_kernel_stats.csv $P/${R}_bench_cfgB_train_bf16_kernel_stats.csv
 cp_if $O/train_f32_kernel_stats.csv $P/${R}_bench_cfgB_train_f32_kernel_stats.csv
 cp_if $O/vit_bf16_kernel_stats.csv $P/${R}_vit_small16_adapter_b512_bf16_kernel_stats.csv
+cp_if $O/vit_f32_kernel_stats.csv $P/${R}_vit_small16_adapter_b512_fp32_kernel_stats.csv
+cp_if $O/measured_errors.txt $P/${R}_measured_errors.txt
 cp_if $O/varlen_1k_bf16_kernel_stats.csv $P/${R}_varlen_64x1000_d384_bf16_kernel_stats.csv
 cp_if $O/varlen_8k_f32_kernel_stats.csv $P/${R}_varlen_16x8192_d384_fp32_kernel_stats.csv
 cp_if $O/varlen_bench.md $P/${R}_varlen_bench.md

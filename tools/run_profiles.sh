@@ -1,6 +1,6 @@
 # End-of-round measurement run (GPU box, repo root): bench lines, rocprofv3 kernel stats, PMC traffic of the attention kernels,
-# micro-benchmarks.  Everything lands under gpurun_out/r04/; copy what is to be judged into profiles/.   bash tools/run_profiles.sh
-R=r05; O=gpurun_out/$R; mkdir -p $O
+# micro-benchmarks.  Everything lands under gpurun_out/r06/; copy what is to be judged into profiles/.   bash tools/run_profiles.sh
+R=r06; O=gpurun_out/$R; mkdir -p $O
 T="timeout 600"
 $T python bench.py > $O/bench_cfgB.json 2> $O/bench_cfgB.err
 $T bash tools/prof_bench.sh ${R}_f32 --precision fp32 --steps 200 > $O/prof_f32.txt 2>&1
@@ -8,6 +8,7 @@ $T bash tools/prof_bench.sh ${R}_bf16 --precision bf16 --steps 200 > $O/prof_bf1
 $T bash tools/prof_bench.sh ${R}_train_bf16 --mode train --precision bf16 --steps 20 --warmup 5 > $O/prof_train_bf16.txt 2>&1
 $T bash tools/prof_bench.sh ${R}_train_f32 --mode train --precision fp32 --steps 20 --warmup 5 > $O/prof_train_f32.txt 2>&1
 $T bash tools/prof_bench.sh ${R}_vit_bf16 --workload vit --precision bf16 --steps 5 > $O/prof_vit_bf16.txt 2>&1
+$T bash tools/prof_bench.sh ${R}_vit_f32 --workload vit --precision fp32 --steps 3 > $O/prof_vit_f32.txt 2>&1
 $T bash tools/pmc_traffic.sh $O/traffic > $O/traffic.txt 2>&1
 $T bash tools/pmc_traffic_x3p.sh cfgB $O/traffic_x3p_cfgB > $O/traffic_x3p_cfgB.txt 2>&1
 $T bash tools/pmc_traffic_x3p.sh cfgC $O/traffic_x3p_cfgC > $O/traffic_x3p_cfgC.txt 2>&1
@@ -39,5 +40,7 @@ $T python tools/gemm_hl_splitk_time.py > $O/gemm_hl_splitk.txt 2>&1
 for k in 128 200 256; do $T python tools/x3p_dev.py 32768 $k 6 --time 2>&1 | grep "x3"; done > $O/attn_x3p_timing.txt
 $T python tools/x3p_dev.py 100000 512 6 --time 2>&1 | grep "x3" >> $O/attn_x3p_timing.txt
 for sh in "8192 200 6 64" "32768 200 6 64" "100000 200 6 64" "1000 200 6 64"; do $T python tools/x3p_dev.py $sh --time 2>&1 | grep "x3"; done >> $O/attn_x3p_timing.txt
-for n in f32 bf16 train_bf16 train_f32 vit_bf16 varlen_1k_bf16 varlen_8k_f32 cfgA_f32 cfgC_f32 readme_mae_f32 readme_scratch_f32; do cp gpurun_out/prof_${R}_$n/p_kernel_stats.csv $O/${n}_kernel_stats.csv 2>/dev/null; done
+for n in f32 bf16 train_bf16 train_f32 vit_bf16 vit_f32 varlen_1k_bf16 varlen_8k_f32 cfgA_f32 cfgC_f32 readme_mae_f32 readme_scratch_f32; do cp gpurun_out/prof_${R}_$n/p_kernel_stats.csv $O/${n}_kernel_stats.csv 2>/dev/null; done
+timeout 1500 python tools/sweep.py > $O/sweep.md 2> $O/sweep.err
+python -m pytest tests/test_gpu_vit.py tests/test_gpu_model.py -q -m gpu -s 2>&1 | grep MEASURED > $O/measured_errors.txt
 tail -4 $O/traffic.txt; head -c 600 $O/bench_cfgB.json

@@ -101,7 +101,7 @@ def main():
     print("one MI355X; CPU column: oracle/snuffy_oracle.py (torch-CPU fp32 port of the reference's op sequence) on %s, %d threads of %d cores\n"
           % (cpu_model, args.cpu_threads, os.cpu_count() or 0))
     print("| N | D | K | CPU slides/s | fp32-class slides/s | x CPU | bf16 slides/s | x CPU | fp32 attention µs | frac of 8 TB/s | bf16 attention µs "
-          "| frac (bf16 bytes) | top-Λ µs (in pipeline) | fp32 attn+top-Λ frac (§8(d) bytes) | bf16 attn+top-Λ frac (§8(d) bytes) | bf16 slides/s eager issue "
+          "| frac (bf16 bytes) | top-Λ µs (in pipeline) | fp32 select + gather / key projection + attention frac (§8(d) bytes) | bf16 select + gather / key projection + attention frac (§8(d) bytes) | bf16 slides/s eager issue "
           "| fp32-class packed (64 bags per launch at N = 1000, 16 at 8192) | bf16 packed |")
     print("|" + "---|" * 18)
     for D in (384, 768):
