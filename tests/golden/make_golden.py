@@ -456,3 +456,187 @@ def run_f7_f8():
 
 if "f7" in (sys.argv[1:] or ["f7"]) and __name__ == "__main__":
     run_f7_f8()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# F11 / F12: adapter pre-training (row f-4): DINO self-distillation pieces and the MAE-adapter pre-training forward / loss /
+# gradients, captured from the unmodified reference.  dino_adapter/ has modules named `utils` / `vision_transformer_with_adapter`
+# that shadow the root ones, so F11 runs in a subprocess with its own sys.path; torchvision / wandb (not installed) are stubbed:
+# the pieces captured here never touch them.
+# ----------------------------------------------------------------------------------------------------------------------
+_F11_CHILD = r'''
+import sys, types, os
+import numpy as np, torch
+sys.dont_write_bytecode = True
+for name in ("torchvision", "torchvision.datasets", "torchvision.transforms", "torchvision.models", "wandb"):
+    sys.modules[name] = types.ModuleType(name)
+tv = sys.modules["torchvision"]
+tv.datasets, tv.transforms, tv.models = sys.modules["torchvision.datasets"], sys.modules["torchvision.transforms"], sys.modules["torchvision.models"]
+tv.models.__dict__.update({})
+sys.path.insert(0, "/root/reference/dino_adapter")
+import torch.distributed as dist
+_avail = torch.cuda.is_available
+torch.cuda.is_available = lambda: True   # the script refuses to be imported without a GPU (main_dino_adapter.py:42-44); nothing captured here runs on one
+import main_dino_adapter as M            # DINOLoss, train step semantics
+torch.cuda.is_available = _avail
+import utils as U                        # MultiCropWrapper, cosine_scheduler, clip_gradients, ...
+import vision_transformer_with_adapter as V
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+dist.init_process_group("gloo", rank=0, world_size=1)
+out = {}
+g = torch.Generator().manual_seed(1100)
+# (a) DINOLoss: 2 global + 3 local crops, batch 4, out_dim 48; two consecutive calls (the centre carries over)
+B, ncrops, od = 4, 5, 48
+loss_mod = M.DINOLoss(od, ncrops, 0.04, 0.07, 3, 10)
+for step, epoch in enumerate((0, 2)):
+    s = torch.randn(ncrops * B, od, generator=g, requires_grad=True)
+    t = torch.randn(2 * B, od, generator=g)
+    l = loss_mod(s, t, epoch)
+    l.backward()
+    out[f"dl_s{step}"], out[f"dl_t{step}"], out[f"dl_epoch{step}"] = s.detach().numpy(), t.numpy(), np.int64(epoch)
+    out[f"dl_loss{step}"], out[f"dl_grad{step}"], out[f"dl_center{step}"] = l.detach().numpy(), s.grad.numpy(), loss_mod.center.numpy().copy()
+out["dl_temp_schedule"] = loss_mod.teacher_temp_schedule
+# (b) schedules and gradient helpers
+out["cos_a"] = U.cosine_scheduler(5e-4, 1e-6, 7, 11, warmup_epochs=2)
+out["cos_b"] = U.cosine_scheduler(0.996, 1.0, 7, 11)
+# (c) student = MultiCropWrapper(tiny adapter ViT, DINOHead); one self-distillation step at dropout 0
+torch.manual_seed(1101)
+def make():
+    vit = V.VisionTransformer(patch_size=16, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4, qkv_bias=True,
+                              norm_layer=__import__("functools").partial(torch.nn.LayerNorm, eps=1e-6),
+                              adapter_ffn_layernorm_option="none", adapter_ffn_init_option="lora", adapter_ffn_scalar="10",
+                              adapter_ffn_num=8, adapter_d_model=64, img_size=[64])
+    head = V.DINOHead(64, od, use_bn=False, norm_last_layer=True, nlayers=3, hidden_dim=32, bottleneck_dim=16)
+    return U.MultiCropWrapper(vit, head)
+student, teacher = make(), make()
+gg = torch.Generator().manual_seed(1102)
+with torch.no_grad():
+    for n, p in student.named_parameters():
+        if n.endswith("weight_g"):
+            continue
+        if p.dim() == 1 and "norm" in n and n.endswith("weight"):
+            p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=gg))
+        elif "pos_embed" not in n:
+            p.copy_(0.05 * torch.randn(p.shape, generator=gg))
+teacher.load_state_dict(student.state_dict())
+for m in list(student.modules()) + list(teacher.modules()):
+    if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float):
+        m.dropout = 0.0
+for p in teacher.parameters():
+    p.requires_grad = False
+# adapter tuning: everything frozen but the adapters and the head (main_dino_adapter.py:307-314)
+for n, p in student.named_parameters():
+    p.requires_grad = ("adaptmlp" in n) or n.startswith("head.")
+student.head.last_layer.weight_g.requires_grad = False
+student.train(); teacher.train()
+crops = [torch.rand(3, 3, 64, 64, generator=gg), torch.rand(3, 3, 64, 64, generator=gg),
+         torch.rand(3, 3, 32, 32, generator=gg), torch.rand(3, 3, 32, 32, generator=gg)]
+out.update({f"step_crop{i}": c.numpy() for i, c in enumerate(crops)})
+out.update({"sd." + k: v.detach().numpy().copy() for k, v in student.state_dict().items()})
+lm = M.DINOLoss(od, 4, 0.04, 0.07, 3, 10)
+t_out = teacher(crops[:2]); s_out = student(crops)
+loss = lm(s_out, t_out, 1)
+loss.backward()
+out["step_student_out"], out["step_teacher_out"], out["step_loss"], out["step_center"] = s_out.detach().numpy(), t_out.detach().numpy(), loss.detach().numpy(), lm.center.numpy().copy()
+norms = U.clip_gradients(student, 0.3)
+out["step_clip_norms"] = np.array(norms)
+U.cancel_gradients_last_layer(0, student, 1)
+names = [n for n, p in student.named_parameters() if p.grad is not None]
+out["step_grad_names"] = np.array(names)
+out.update({"grad." + n: p.grad.numpy().copy() for n, p in student.named_parameters() if p.grad is not None})
+groups = U.get_params_groups(student)
+out["groups_sizes"] = np.array([len(groups[0]["params"]), len(groups[1]["params"])])
+opt = torch.optim.AdamW(groups, lr=1e-3, weight_decay=0.04)
+opt.step()
+with torch.no_grad():
+    for pq, pk in zip(student.parameters(), teacher.parameters()):
+        pk.data.mul_(0.99).add_((1 - 0.99) * pq.detach().data)
+out.update({"after_student." + k: v.detach().numpy().copy() for k, v in student.state_dict().items() if "adaptmlp" in k or k.startswith("head.")})
+out.update({"after_teacher." + k: v.detach().numpy().copy() for k, v in teacher.state_dict().items() if "adaptmlp" in k or k.startswith("head.")})
+np.savez_compressed(sys.argv[1], **out)
+print("f11_dino_pretrain: loss", float(loss), "student_out", tuple(s_out.shape), "grads", len(names))
+dist.destroy_process_group()
+'''
+
+
+def run_f11():
+    import subprocess
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(_F11_CHILD)
+        path = f.name
+    try:
+        subprocess.run([sys.executable, path, os.path.join(HERE, "f11_dino_pretrain.npz")], check=True)
+    finally:
+        os.unlink(path)
+
+
+_F12_CHILD = r'''
+import sys, types
+import numpy as np, torch
+sys.dont_write_bytecode = True
+np.float = float                                                    # util/pos_embed.py (numpy 2.x)
+timm = types.ModuleType("timm"); td = types.ModuleType("timm.data")   # the vendored timm_modified imports constants from timm.data
+for n, v in (("IMAGENET_DEFAULT_MEAN", (0.485, 0.456, 0.406)), ("IMAGENET_DEFAULT_STD", (0.229, 0.224, 0.225)),
+             ("IMAGENET_INCEPTION_MEAN", (0.5,) * 3), ("IMAGENET_INCEPTION_STD", (0.5,) * 3),
+             ("IMAGENET_DPN_MEAN", (124 / 255, 117 / 255, 104 / 255)), ("IMAGENET_DPN_STD", (1 / (.0167 * 255),) * 3)):
+    setattr(td, n, v)
+timm.data = td; sys.modules["timm"] = timm; sys.modules["timm.data"] = td
+sys.path.insert(0, "/root/reference/mae_adapter")
+from functools import partial
+import models_mae
+ln = partial(torch.nn.LayerNorm, eps=1e-6)
+torch.manual_seed(1200)
+model = models_mae.MaskedAutoencoderViT(img_size=64, patch_size=16, embed_dim=64, depth=2, num_heads=2, decoder_embed_dim=32,
+                                        decoder_depth=1, decoder_num_heads=2, mlp_ratio=4, norm_layer=ln, norm_pix_loss=True,
+                                        adapter_ffn_scalar="1.0", adapter_ffn_num=8, adapter_d_model=64)
+g = torch.Generator().manual_seed(1201)
+with torch.no_grad():
+    for name, p in model.named_parameters():
+        if p.dim() == 1 and "norm" in name and name.endswith("weight"):
+            p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+        elif name in ("pos_embed", "decoder_pos_embed"):
+            continue
+        else:
+            p.copy_(0.05 * torch.randn(p.shape, generator=g))
+for m in model.modules():
+    if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float):
+        m.dropout = 0.0
+model.train()
+g = torch.Generator().manual_seed(1202)
+imgs = torch.rand(3, 3, 64, 64, generator=g)
+out = dict(imgs=imgs.numpy(), cfg=np.array([64, 16, 64, 2, 2, 32, 1, 2, 8], dtype=np.int64), mask_ratio=np.float64(0.75))
+out.update({"sd." + k: v.detach().numpy().copy() for k, v in model.state_dict().items()})
+torch.manual_seed(1203)
+noise = torch.rand(3, 16)                       # random_masking's first draw under this seed (models_mae.py:150)
+torch.manual_seed(1203)
+loss, pred, mask = model(imgs, mask_ratio=0.75)
+loss.backward()
+out.update(noise=noise.numpy(), loss=loss.detach().numpy(), pred=pred.detach().numpy(), mask=mask.numpy())
+names = [n for n, p in model.named_parameters() if p.grad is not None]
+out["grad_names"] = np.array(names)
+out.update({"grad." + n: p.grad.numpy().copy() for n, p in model.named_parameters() if p.grad is not None})
+model.norm_pix_loss = False                     # the same model without the per-patch normalisation of the target
+torch.manual_seed(1203)
+out["loss_plain"] = model(imgs, mask_ratio=0.75)[0].detach().numpy()
+np.savez_compressed(sys.argv[1], **out)
+print("f12_mae_pretrain: loss", float(loss), "pred", tuple(pred.shape), "kept", int((1 - mask).sum()), "grads", len(names))
+'''
+
+
+def run_f12():
+    import subprocess
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(_F12_CHILD)
+        path = f.name
+    try:
+        subprocess.run([sys.executable, path, os.path.join(HERE, "f12_mae_pretrain.npz")], check=True)
+    finally:
+        os.unlink(path)
+
+
+if "f11" in (sys.argv[1:] or []) and __name__ == "__main__":
+    run_f11()
+if "f12" in (sys.argv[1:] or []) and __name__ == "__main__":
+    run_f12()

@@ -344,3 +344,43 @@ def test_compute_feats_bf16_takes_patch_columns_straight_from_the_tile_kernel(tm
     finally:
         vit.VisionTransformer.forward_cols = orig
     assert outs[1].shape == (4, 192) and np.array_equal(outs[0], outs[1])
+
+
+def test_adapter_pretraining_steps_on_the_device():
+    """snuffy_amd/ssl_pretrain.py on the GPU against the reference fixtures F11 / F12: the DINO self-distillation
+    step (loss, adapter gradients) and the MAE-adapter reconstruction loss / gradients through PyTorch-ROCm autograd."""
+    from tests import test_ssl_pretrain as T
+    from snuffy_amd import ssl_pretrain as S
+    z = T._npz("f11_dino_pretrain.npz")
+    student, teacher = T._student(), T._student()
+    student.load_state_dict(T._sd(z)), teacher.load_state_dict(T._sd(z))
+    student, teacher = student.to(DEV).train(), teacher.to(DEV).train()
+    for p in teacher.parameters():
+        p.requires_grad = False
+    S.freeze_for_adapter_tuning(student)
+    crops = [torch.from_numpy(z[f"step_crop{i}"]).to(DEV) for i in range(4)]
+    lm = S.DINOLoss(48, 4, 0.04, 0.07, 3, 10).to(DEV)
+    with torch.no_grad():
+        t_out = teacher(crops[:2])
+    loss = lm(student(crops), t_out, 1)
+    loss.backward()
+    assert abs(float(loss) - float(z["step_loss"])) < 1e-4
+    S.clip_gradients(student, 0.3)                       # the fixture holds the gradients behind the per-parameter clipping
+    for n, p in student.named_parameters():
+        if p.grad is not None and "adaptmlp" in n:
+            ref = z["grad." + n]
+            assert np.allclose(p.grad.cpu().numpy(), ref, rtol=2e-3, atol=1e-3 * np.abs(ref).max() + 1e-7), n
+    z = T._npz("f12_mae_pretrain.npz")
+    model = T._mae()
+    model.load_state_dict(T._sd(z))
+    model = model.to(DEV).train()
+    loss, pred, mask = model(torch.from_numpy(z["imgs"]).to(DEV), 0.75, torch.from_numpy(z["noise"]).to(DEV))
+    loss.backward()
+    assert np.array_equal(mask.cpu().numpy(), z["mask"]) and abs(float(loss) - float(z["loss"])) < 1e-4
+    ref = z["grad.decoder_pred.weight"]
+    assert np.allclose(model.decoder_pred.weight.grad.cpu().numpy(), ref, rtol=2e-3, atol=1e-3 * np.abs(ref).max())
+    # the trained model is still the extractor: under no_grad / eval its forward is the kernel path of compute_feats
+    model.eval()
+    with torch.no_grad():
+        feats = model(torch.rand(2, 3, 64, 64, device=DEV))
+    assert feats.shape == (2, 64) and bool(torch.isfinite(feats).all())
