@@ -391,8 +391,9 @@ int snf_gemm_bf16_resid_f32(const void* a, int64_t lda, const void* w, int64_t l
  *                          c [m, ldc] bf16 = act(rstd[m] (a w^T - mean[m] colsum[n]) + bias[n]);  colsum[n] = sum_k w[n, k] of the ROUNDED w,
  *                          bias = W0 beta + b0, rowstats [m][2] = (mean, rstd) of the fp32 rows (snf_vit_row_stats).  act: none, gelu.
  *   snf_gemm_bf16_resid    the residual stream updated by the producer: x [m, ldx] fp32 IN PLACE  x += a w^T + bias; the bf16 copy of
- *                          the new x goes to x_bf16 [m, ldxb]; stats_part [m][n / 64][2] receives (sum, sum of squares) of the new
- *                          row over every 64-column group -- summed in group order by snf_vit_row_stats (bit-reproducible).
+ *                          the new x goes to x_bf16 [m, ldxb]; stats_part [m][n / 32][2] receives (sum, sum of squares) of the new
+ *                          row over every 32-column group -- summed in group order by snf_vit_row_stats (bit-reproducible).
+ *                          (256-wide tiles; 128-wide ones where the last 256-wide column tile would be at most half used: n = 384.)
  *   domain of both: k % 32 == 0, k >= 96, n % 64 == 0, 16-byte aligned rows. */
 int snf_gemm_bf16_lnfold(const void* a, int64_t lda, const void* w, int64_t ldw, const float* colsum, const float* bias,
                          const float* rowstats, int64_t m, int n, int k, int act, void* c, int64_t ldc, snf_stream_t stream);

@@ -65,7 +65,7 @@ struct GemmParams {
     const float* colsum = nullptr;   // [N]
     const float* rowstats = nullptr; // [M][2] = (mean, rstd) of the fp32 rows A was rounded from
     // gemm_bf16_kernel, EPI = 2 (residual stream in the producer, round 6): c = x [M, ldc] fp32, IN PLACE  x += A W^T + bias; a bf16
-    // copy of the new x goes to c2 [M, ldc2] and, per row and 64-column group g (tile column 4 tn + wave column), the pair
+    // copy of the new x goes to c2 [M, ldc2] and, per row and 32-column group g (a 256-wide tile: 2 (4 tn + wave column) and the next one), the pair
     // (sum, sum of squares) of the new values to stats_part[(row * slots + g)] -- what snf_vit_row_stats turns into (mean, rstd)
     unsigned short* c2 = nullptr;
     int64_t ldc2 = 0;
@@ -124,7 +124,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 // in place by the producer (accumulators start from x instead of 0; fp32 x, its bf16 copy and the rows' partial moments leave together).
 template <int NI, int ACT, int OUT, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
-    static_assert(EPI == 0 || (NI == 4 && (EPI == 1 ? OUT == 0 : (OUT == 1 && ACT == SNF_ACT_NONE))), "gemm_bf16: epilogue variants are 256-wide");
+    static_assert(EPI == 0 || (EPI == 1 ? (NI == 4 && OUT == 0) : ((NI == 4 || NI == 2) && OUT == 1 && ACT == SNF_ACT_NONE)),
+                  "gemm_bf16: the LayerNorm-fold epilogue is 256-wide, the residual epilogue 256- or 128-wide");
     constexpr int BN = 64 * NI;
     constexpr int W_BYTES = BN * ROWB;
     constexpr int STEP_BYTES = A_BYTES + W_BYTES;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
     auto preload_x = [&](int tl) __attribute__((always_inline)) {
         if constexpr (EPI == 2) {
             const int tm = tl / P.tiles_n, tn = tl - tm * P.tiles_n;
-            const int n0 = tn * BN + 64 * wc + 8 * fg;
+            const int n0 = tn * BN + (NI == 4 ? 64 : 32) * wc + 8 * fg;
             const int row0 = tm * BM + 128 * wr + fi;
             const float* xb = reinterpret_cast<const float*>(P.c);
 #pragma unroll
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
             const int row = row0 + 16 * mi;
-            float s1 = 0.f, s2 = 0.f;           // EPI 2: moments of the new x over this lane's columns of the row
+            float s1[NI / 2], s2[NI / 2];       // EPI 2: moments of the new x over this lane's columns of the row, per 32-column group
             u32x4 pk2[EPI == 2 ? NI / 2 : 1];
 #pragma unroll
             for (int h = 0; h < NI / 2; ++h) {   // 8-column group: ni = 2 h, 2 h + 1
@@ -352,13 +353,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                     // fp32 rows and their bf16 copy leave as full lines (as LINE_STORES / gemm_hl_kernel): the fp32 chunks of this row
                     // block go to the wave's scratch now (chunk c = 8 h + 2 fg + half of the 256-byte span at position c ^ row), the
                     // bf16 chunks follow through the same scratch behind the fp32 reads (below)
+                    // (128-wide tiles: the wave's span of a row is one 128-byte line, chunk c = 2 fg + half at position c ^ (row & 7))
                     (void)ok;
                     pk2[h] = u32x4{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
-                    *reinterpret_cast<f32x4*>(scr + fio * 256 + (((8 * h + 2 * fgo) ^ fio) << 4)) = f32x4{v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(scr + fio * 256 + (((8 * h + 2 * fgo + 1) ^ fio) << 4)) = f32x4{v[4], v[5], v[6], v[7]};
+                    if constexpr (NI == 4) {
+                        *reinterpret_cast<f32x4*>(scr + fio * 256 + (((8 * h + 2 * fgo) ^ fio) << 4)) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(scr + fio * 256 + (((8 * h + 2 * fgo + 1) ^ fio) << 4)) = f32x4{v[4], v[5], v[6], v[7]};
+                    } else {
+                        *reinterpret_cast<f32x4*>(scr + fio * 128 + (((2 * fgo) ^ (fio & 7)) << 4)) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(scr + fio * 128 + (((2 * fgo + 1) ^ (fio & 7)) << 4)) = f32x4{v[4], v[5], v[6], v[7]};
+                    }
+                    s1[h] = 0.f, s2[h] = 0.f;
                     if (FULL || col + 8 <= P.n) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) s1 += v[e], s2 = fmaf(v[e], v[e], s2);
+                        for (int e = 0; e < 8; ++e) s1[h] += v[e], s2[h] = fmaf(v[e], v[e], s2[h]);
                     }
                 } else if constexpr (OUT_F32) {
                     float* dst = reinterpret_cast<float*>(P.c) + (int64_t)row * P.ldc + col;
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                 }
             }
             if constexpr (EPI == 2) {
-                {
+                if constexpr (NI == 4) {
                     const int lr = lane_o >> 4, lc = lane_o & 15;
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
@@ -449,14 +457,36 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                         const int orow = tm * BM + 128 * wr + 16 * mi + r, ocol = tn * BN + 64 * wc + 8 * bc;
                         if (FULL || (orow < P.m && ocol + 8 <= P.n)) *reinterpret_cast<u32x4*>(P.c2 + (int64_t)orow * P.ldc2 + ocol) = val;
                     }
+                } else {
+                    const int lr = lane_o >> 3, lc = lane_o & 7;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int r = lr + 8 * jj;
+                        const u32x4 val = *reinterpret_cast<const u32x4*>(scr + r * 128 + ((lc ^ (r & 7)) << 4));
+                        const int orow = tm * BM + 128 * wr + 16 * mi + r, ocol = tn * BN + 32 * wc + 4 * lc;
+                        if (FULL || (orow < P.m && ocol + 4 <= P.n))
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(P.c) + (int64_t)orow * P.ldc + ocol) = val;
+                    }
+                    // the bf16 copy of the wave's 32 columns is half a line per row: straight from the registers
+                    if (FULL || (row < P.m && n0 + 8 <= P.n)) *reinterpret_cast<u32x4*>(P.c2 + (int64_t)row * P.ldc2 + n0) = pk2[0];
                 }
-                // the row's 64 columns of this wave sit on the four lanes fi + 16 g: sum them (fixed order), lane g = 0 writes the pair
-                s1 += __shfl_xor(s1, 16, 64), s2 += __shfl_xor(s2, 16, 64);
-                s1 += __shfl_xor(s1, 32, 64), s2 += __shfl_xor(s2, 32, 64);
-                const int g = 4 * tn + wc;
+                // a 32-column group of the row sits on the four lanes fi + 16 g: sum them (fixed order), lane g = 0 writes the pair(s) --
+                // slot = 32-column group of the row; a 256-wide tile writes its wave's two adjacent slots in one store
+#pragma unroll
+                for (int h = 0; h < NI / 2; ++h) {
+                    s1[h] += __shfl_xor(s1[h], 16, 64), s2[h] += __shfl_xor(s2[h], 16, 64);
+                    s1[h] += __shfl_xor(s1[h], 32, 64), s2[h] += __shfl_xor(s2[h], 32, 64);
+                }
                 // (in a FULL tile every wave issues this store -- its 16 lanes g = 0 -- which the counted wait behind the epilogue relies on)
-                if (fg == 0 && (FULL || (g < P.slots && row < P.m)))
-                    *reinterpret_cast<f32x2*>(P.stats_part + 2 * ((int64_t)row * P.slots + g)) = f32x2{s1, s2};
+                if constexpr (NI == 4) {
+                    const int g = 2 * (4 * tn + wc);
+                    if (fg == 0 && (FULL || (g < P.slots && row < P.m)))
+                        *reinterpret_cast<f32x4*>(P.stats_part + 2 * ((int64_t)row * P.slots + g)) = f32x4{s1[0], s2[0], s1[1], s2[1]};
+                } else {
+                    const int g = 4 * tn + wc;
+                    if (fg == 0 && (FULL || (g < P.slots && row < P.m)))
+                        *reinterpret_cast<f32x2*>(P.stats_part + 2 * ((int64_t)row * P.slots + g)) = f32x2{s1[0], s2[0]};
+                }
             }
         }
     };
@@ -1319,11 +1349,17 @@ extern "C" int snf_gemm_bf16_resid(const void* a, int64_t lda, const void* w, in
     if (rc) return rc;
     SNF_REQUIRE(ldx >= n && ldx % 4 == 0 && ldxb >= n && ldxb % 8 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
                     reinterpret_cast<uintptr_t>(x_bf16) % 16 == 0 && reinterpret_cast<uintptr_t>(bias) % 16 == 0 &&
-                    reinterpret_cast<uintptr_t>(stats_part) % 8 == 0 && m * ldx < 0x7fffffffll,
+                    reinterpret_cast<uintptr_t>(stats_part) % 16 == 0 && m * ldx < 0x7fffffffll,
                 "snf_gemm_bf16_resid: output / vector alignment");
     GemmParams P = epi_params(a, lda, w, ldw, bias, m, n, k, SNF_ACT_NONE, x, ldx);
     P.c2 = reinterpret_cast<unsigned short*>(x_bf16), P.ldc2 = ldxb;
-    P.stats_part = stats_part, P.slots = n / 64;
+    P.stats_part = stats_part, P.slots = n / 32;
+    // 128-wide tiles where the last 256-wide column tile would be at most half used (ViT-S, n = 384: 3 tiles of 128, not 2 of 256)
+    const int rem = n % 256;
+    if (rem >= 1 && rem <= 128) {
+        P.tiles_n = (n + 127) / 128;
+        return launch<2, SNF_ACT_NONE, 1, 2>(P, snf::as_stream(stream));
+    }
     return launch<4, SNF_ACT_NONE, 1, 2>(P, snf::as_stream(stream));
 }
 

@@ -1239,8 +1239,8 @@ def gemm_bf16_lnfold(a, w, colsum, bias, rowstats, act="none", out=None):
 
 
 def gemm_bf16_resid_(x, a, w, bias, x_bf16, stats_part):
-    """x [m, n] f32 IN PLACE  x += a @ w.T + bias; x_bf16 [m, n] bf16 receives the new x rounded; stats_part [m, n / 64, 2] f32 the
-    (sum, sum of squares) of every 64-column group of the new row (vit_row_stats(part=...) turns them into (mean, rstd))."""
+    """x [m, n] f32 IN PLACE  x += a @ w.T + bias; x_bf16 [m, n] bf16 receives the new x rounded; stats_part [m, n / 32, 2] f32 the
+    (sum, sum of squares) of every 32-column group of the new row (vit_row_stats(part=...) turns them into (mean, rstd))."""
     if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
         raise TypeError("gemm_bf16_resid_: a and w must be bfloat16")
     a = _rows16(a, "a")
@@ -1250,7 +1250,7 @@ def gemm_bf16_resid_(x, a, w, bias, x_bf16, stats_part):
     x = _req(x, torch.float32, "x", 2)
     bias = _req(bias, torch.float32, "bias", 1)
     if w.shape[1] != k or tuple(x.shape) != (m, n) or tuple(x_bf16.shape) != (m, n) or x_bf16.dtype != torch.bfloat16 \
-            or not x_bf16.is_contiguous() or tuple(stats_part.shape) != (m, n // 64, 2) or stats_part.dtype != torch.float32 \
+            or not x_bf16.is_contiguous() or tuple(stats_part.shape) != (m, n // 32, 2) or stats_part.dtype != torch.float32 \
             or not stats_part.is_contiguous() or bias.shape[0] != n:
         raise ValueError("gemm_bf16_resid_: inconsistent shapes")
     check(_ffi.load().snf_gemm_bf16_resid(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), m, n, k, _p(x), x.stride(0), _p(x_bf16),

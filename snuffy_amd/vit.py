@@ -506,7 +506,7 @@ class VisionTransformer(nn.Module):
         hidden = self.blocks[0].mlp.fc1.weight.shape[0]
         has_ad = "dn_w" in W["blocks"][0]
         bott = W["blocks"][0]["dn_w"].shape[0] if has_ad else 0
-        part = torch.empty(R, D // 64, 2, dtype=torch.float32, device=xt.device)
+        part = torch.empty(R, D // 32, 2, dtype=torch.float32, device=xt.device)
         hbuf = torch.empty(R, hidden + bott, dtype=torch.bfloat16, device=xt.device)      # [gelu(fc1) | ReLU(down)]
         stats, xb = ops.vit_row_stats(xt, eps=self.blocks[0].norm1.eps, want_bf16=True)
         for i, blk in enumerate(self.blocks):
