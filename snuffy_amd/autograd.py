@@ -314,10 +314,10 @@ class EncoderLayer0Bf16Fn(torch.autograd.Function):
         dz = dz.float().contiguous()
         # ---- FFN: z = y + act(xhat1 W1'^T + b1') W2^T + b2                                                (snuffy.py:224-225)
         db2, dz16 = ops.colsum_fused(dz, want_bf16=True)                              # bias gradient + the GEMM operand, one pass
-        dw2 = _tn_mm(dz16, hid)                                                      # [D, F]
+        dw2 = _tn_mm(dz16, hid)                                                        # [D, F]
         dhid = torch.mm(dz16, w2f)                                                   # [N, F] bf16
         db1f, _ = ops.colsum_fused(dhid, gate=hid, inplace=True)                     # ReLU mask from the output + bias gradient
-        dw1f = _tn_mm(dhid, xhat)                                                    # [F, D] gradient of the FOLDED weight
+        dw1f = _tn_mm(dhid, xhat)                                                     # [F, D] gradient of the FOLDED weight
         # ---- the K selected rows: y[S] = x_sel = xs + o Wo^T + bo; every other row of y is data             (snuffy.py:108,152-155)
         dyn_s = torch.mm(dhid.index_select(0, sel), w1f, out_dtype=f32)              # d loss / d xhat1[S] (bf16 operands as they are)
         # dy[S] = dz[S] + LayerNorm-1 backward of dyn_s at the rows x_sel (affine folded away): one kernel
@@ -408,12 +408,15 @@ def _x3_train_weights(layer):
 _BMM_OUT = None         # does this torch build take out= together with out_dtype on bmm?
 
 
-def _tn3(a3, b3, p, q, chunks=8):
+def _tn3(a3, b3, p, q, chunks=None):
     """a^T b over the bag axis for the split images a3 [n, 3 p] = [hi | hi | lo], b3 [n, 3 q] -> [p, q] f32, fp32-class:
     ah^T bh + ah^T bl + al^T bh on column blocks of the images, in place (lo lo is never computed).  Each product is a batched
     library GEMM over `chunks` row blocks (see _tn_mm); the 3 x chunks partial results land in ONE buffer and are summed in one
-    pass, in a fixed order."""
+    pass, in a fixed order.  chunks: 4 for the large outputs (the FFN weights at config B: 48 library tiles x 4 chunks fill the chip as
+    well as x 8 and leave half the partials -- 577 -> 540 us, 562 -> 511 us), 8 below 2 M elements (288 vs 369 us; tools/tn_chunks_bench.py)."""
     global _BMM_OUT
+    if chunks is None:
+        chunks = 4 if p * q >= (1 << 21) else 8
     ah, al = a3[:, p:2 * p], a3[:, 2 * p:]
     bh, bl = b3[:, q:2 * q], b3[:, 2 * q:]
     n = a3.shape[0]
@@ -431,9 +434,9 @@ def _tn3(a3, b3, p, q, chunks=8):
             if "out of memory" in str(exc).lower():
                 raise
             _BMM_OUT = False       # this torch build has no bmm(out_dtype=, out=): three separate products below
-    out = _tn_mm_f32(ah, bh)
-    out += _tn_mm_f32(ah, bl)
-    out += _tn_mm_f32(al, bh)
+    out = _tn_mm_f32(ah, bh, chunks)
+    out += _tn_mm_f32(ah, bl, chunks)
+    out += _tn_mm_f32(al, bh, chunks)
     return out
 
 
