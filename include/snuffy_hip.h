@@ -420,6 +420,17 @@ int snf_gemm_hl_resid_bf16(const void* a_hl, int64_t lda, const void* w_hl, int6
  * zeroes its own tickets, nothing is expected in the buffer before a call or kept in it after one, so concurrent calls on different
  * streams only need different buffers.  NULL workspace = snf_gemm_hl_resid_bf16. */
 size_t snf_gemm_hl_ws_bytes(int64_t m, int n, int k);
+/* The weight-gradient contraction of the training step (round 6; the autograd of nn.Linear under train.py:259,468-473: dW = dY^T X):
+ *   c [p, ldc] f32 = A^T B over the n rows of two row-major bf16 images, on the matrix cores straight from those images (transposing
+ *   LDS reads; no transposed copy).  A's operand is the p columns starting at column a_hi of a [n, lda], B's the q columns at b_hi of
+ *   b [n, ldb].  a_lo, b_lo >= 0: the operands are split images with a lo plane at those column offsets (the [hi | hi | lo] images of
+ *   snf_split3_colsum_f32 / snf_layernorm_rows_split3_f32 / a split3 GEMM output) and the product is fp32-class, hi hi + hi lo + lo hi;
+ *   both -1: one bf16 product.  Tiles of 256 x 256 cut into row parts (one workgroup each), summed in part order (bit-reproducible).
+ *   workspace: snf_gemm_tn_ws_bytes(n, p, q) bytes of plain scratch memory.  Domain: n % 32 == 0, p % 8 == 0, q % 8 == 0, plane offsets
+ *   % 8 == 0, 16-byte aligned rows. */
+size_t snf_gemm_tn_ws_bytes(int64_t n, int p, int q);
+int snf_gemm_tn_f32(const void* a, int64_t lda, int a_hi, int a_lo, const void* b, int64_t ldb, int b_hi, int b_lo, int64_t n, int p, int q,
+                    float* c, int64_t ldc, void* workspace, size_t workspace_bytes, snf_stream_t stream);
 int snf_gemm_hl_ws_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ldw, const float* bias, const float* resid,
                         int64_t ldr, int64_t m, int n, int k, int act, void* c, int64_t ldc, int out_dtype, void* workspace,
                         size_t workspace_bytes, snf_stream_t stream);

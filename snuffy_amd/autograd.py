@@ -415,6 +415,10 @@ def _tn3(a3, b3, p, q, chunks=None):
     pass, in a fixed order.  chunks: 4 for the large outputs (the FFN weights at config B: 48 library tiles x 4 chunks fill the chip as
     well as x 8 and leave half the partials -- 577 -> 540 us, 562 -> 511 us), 8 below 2 M elements (288 vs 369 us; tools/tn_chunks_bench.py)."""
     global _BMM_OUT
+    if ops.gemm_tn_supported(a3.shape[0], p, q, a3, b3):
+        # round 6: the contraction on the matrix cores straight from the row-major images (snf_gemm_tn_f32: transposing LDS reads, the
+        # three products per staged step, tiles cut into row parts and summed in part order)
+        return ops.gemm_tn(a3, b3, p, q, (p, 2 * p), (q, 2 * q))
     if chunks is None:
         chunks = 4 if p * q >= (1 << 21) else 8
     ah, al = a3[:, p:2 * p], a3[:, 2 * p:]

@@ -1303,6 +1303,36 @@ def gemm_x3(a_img, w_img, bias=None, act="none", out_dtype=torch.float32, out=No
     return out
 
 
+GEMM_TN = True          # the weight-gradient contractions of the training step on snf_gemm_tn_f32; False: batched library GEMMs
+
+
+def gemm_tn_supported(n, p, q, *images):
+    """Shapes / operands snf_gemm_tn_f32 takes: whole 32-row steps, 8-column granules, bf16 images with 16-byte aligned rows, an
+    output large enough to be worth the matrix cores."""
+    if not GEMM_TN or n < 1024 or n % 32 or p % 8 or q % 8 or p * q < 65536:
+        return False
+    return all(t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
+               and t.shape[0] == n and 33 * t.stride(0) < 2 ** 31 for t in images)
+
+
+def gemm_tn(a_img, b_img, p, q, a_planes=(0, -1), b_planes=(0, -1), out=None):
+    """a^T b over the rows of two bf16 images -> [p, q] f32 (snf_gemm_tn_f32): a = the p columns at column a_planes[0] of a_img [n, .],
+    b = the q columns at b_planes[0] of b_img [n, .]; with lo planes (a_planes[1], b_planes[1] >= 0: split images [hi | hi | lo]) the
+    product is fp32-class (hi hi + hi lo + lo hi), otherwise one bf16 product.  The contraction runs over the BAG axis: the weight
+    gradients of the training step."""
+    n = a_img.shape[0]
+    if not gemm_tn_supported(n, p, q, a_img, b_img):
+        raise ValueError("gemm_tn: shape n=%d p=%d q=%d / operands outside the kernel's domain" % (n, p, q))
+    if out is None:
+        out = torch.empty(p, q, dtype=torch.float32, device=a_img.device)
+    lib = _ffi.load()
+    nb = int(lib.snf_gemm_tn_ws_bytes(n, p, q))
+    ws = _ws(nb, a_img.device)
+    check(lib.snf_gemm_tn_f32(_p(a_img), a_img.stride(0), a_planes[0], a_planes[1], _p(b_img), b_img.stride(0), b_planes[0], b_planes[1],
+                              n, p, q, _p(out), out.stride(0), _p(ws), nb, _stream()), "snf_gemm_tn_f32")
+    return out
+
+
 def hl_eligible(m, n, k):
     """Shapes the one-pass fp32-class GEMM takes: 256 x 256 tiles have to fill the chip (>= 0.7 tiles per CU), k % 32 == 0."""
     if not GEMM_HL or k % 32 or n % 8 or n < 256 or k < 32 or m * 2 * k >= 2 ** 31 or n * 2 * k >= 2 ** 31:

@@ -442,3 +442,30 @@ def test_gemm_bf16_resid_updates_the_stream_in_place(m, n, k):
     xd2, xb2, part2 = x.to(DEV), torch.empty_like(xb), torch.empty_like(part)
     ops.gemm_bf16_resid_(xd2, a_full.to(DEV)[:, :k], w.to(DEV), b.to(DEV), xb2, part2)
     assert torch.equal(xd, xd2) and torch.equal(xb, xb2) and torch.equal(part, part2)
+
+
+@pytest.mark.parametrize("n,p,q", [(32768, 768, 3072), (4096, 256, 256), (2048, 520, 264), (8192, 1536, 768), (1024, 384, 1536)])
+@pytest.mark.parametrize("x3", [True, False])
+def test_gemm_tn_weight_gradient_contraction(n, p, q, x3):
+    """snf_gemm_tn_f32: a^T b over the bag axis straight from row-major bf16 images (transposing LDS reads), fp32-class from split
+    images [hi | hi | lo] or one bf16 product -- against fp64 of the same operands, bit-reproducible, ragged tile edges."""
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(n + p + q)
+    a = torch.randn(n, p, generator=g).to(DEV)
+    b = torch.randn(n, q, generator=g).to(DEV)
+    if x3:
+        a3, b3 = ops.split3_rows(a), ops.split3_rows(b)
+        out = ops.gemm_tn(a3, b3, p, q, (p, 2 * p), (q, 2 * q))
+        ref = a.double().t() @ b.double()
+        tol = 2e-5
+        assert torch.equal(out, ops.gemm_tn(a3, b3, p, q, (0, 2 * p), (q, 2 * q)))       # either copy of the hi plane, run to run
+    else:
+        a16, b16 = a.to(torch.bfloat16), b.to(torch.bfloat16)
+        pad = torch.zeros(n, 8, dtype=torch.bfloat16, device=DEV)
+        a_v = torch.cat([pad, a16, pad], 1)                                                # a plane inside wider rows
+        out = ops.gemm_tn(a_v, b16, p, q, (8, -1), (0, -1))
+        ref = a16.double().t() @ b16.double()
+        tol = 2e-6
+        assert torch.equal(out, ops.gemm_tn(a16, b16, p, q))
+    scale = ref.abs().max().item()
+    assert out.shape == (p, q) and (out.double() - ref).abs().max().item() <= tol * scale

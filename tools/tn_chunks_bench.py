@@ -29,6 +29,7 @@ def main():
     for p, q, what in ((768, 3072, "dW2  = dz^T hid"), (3072, 768, "dW1' = dhid^T xhat"), (1536, 768, "dWqv' = [dQ|dV]^T xhat")):
         a3 = torch.randn(n, 3 * p, device=dev, generator=g).to(torch.bfloat16)
         b3 = torch.randn(n, 3 * q, device=dev, generator=g).to(torch.bfloat16)
+        ops_tn, _ = AG.ops.GEMM_TN, setattr(AG.ops, 'GEMM_TN', False)
         ref = AG._tn3(a3, b3, p, q, chunks=8)
         line = []
         for chunks in (2, 4, 8, 16, 32):
@@ -36,7 +37,13 @@ def main():
             err = ((out - ref).abs().max() / ref.abs().max()).item()
             line.append("chunks %2d %7.1f us (rel diff %.1e)" % (chunks, timed(lambda: AG._tn3(a3, b3, p, q, chunks=chunks)), err))
         print("%-24s n=%d p=%d q=%d : %s" % (what, n, p, q, " | ".join(line)))
+        AG.ops.GEMM_TN = ops_tn
+        from snuffy_amd import ops
+        out = ops.gemm_tn(a3, b3, p, q, (p, 2 * p), (q, 2 * q))
+        print("%-24s snf_gemm_tn_f32 x3     : %7.1f us (rel diff %.1e)" % ("", timed(lambda: ops.gemm_tn(a3, b3, p, q, (p, 2 * p), (q, 2 * q))),
+                                                                      ((out - ref).abs().max() / ref.abs().max()).item()))
         a, b = a3[:, :p].contiguous(), b3[:, :q].contiguous()
+        print("%-24s snf_gemm_tn_f32 bf16   : %7.1f us" % ("", timed(lambda: ops.gemm_tn(a, b, p, q))))
         line = ["chunks %2d %7.1f us" % (c, timed(lambda: AG._tn_mm(a, b, chunks=c))) for c in (2, 4, 8, 16)]
         print("%-24s bf16 (_tn_mm)        : %s" % ("", " | ".join(line)))
 
