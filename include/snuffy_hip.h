@@ -165,6 +165,9 @@ int snf_unfold_linear_f32(const float* dwf, const float* w, int r, int c, const 
 /* x [m, k] f32 (row pitch ldx) -> out [m, 3 k] bf16 = [hi | hi | lo]: the activation image of an fp32-class projection whose
  * producer is not one of the kernels that can emit it directly (ViT fp32 path: patch columns, attention output). */
 int snf_split3_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16, snf_stream_t stream);
+/* w [m, k] f32 (row pitch ldw; the nn.Linear layout) -> out [m, 3 k] bf16 = [Wh | Wl | Wh], the weight operand of the same products;
+ * colscale [k] (nullable): W' = W diag(colscale) formed in fp32 first (a LayerNorm gamma folded into the projection that follows it). */
+int snf_split3_weight_f32(const float* w, int64_t ldw, int64_t m, int k, const float* colscale, void* out_bf16, snf_stream_t stream);
 /* Column sums of a [n, d] matrix fused with the elementwise step of the same pass (training: bias gradients next to the ReLU
  * mask / the bf16 cast / the critic's weight gradient; backward of snuffy.py:39-41, 224-225):
  *   v = src[i, c] (f32 or bf16) * row_weight[i * weight_stride] (nullable) ; v = 0 where gate_bf16[i, c] <= 0 (nullable: the ReLU

@@ -398,7 +398,7 @@ def _x3_train_weights(layer):
         wqv = torch.cat([lq.weight, lv.weight]).float()
         w1 = ff.w_1.weight.float()
         w1f = (w1 * n1.weight).contiguous()
-        out = dict(wqv3=ops.split3_weight(wqv * n0.weight), bqv=(wqv @ n0.bias + torch.cat([lq.bias, lv.bias])).float().contiguous(),
+        out = dict(wqv3=ops.split3_weight(wqv, n0.weight), bqv=(wqv @ n0.bias + torch.cat([lq.bias, lv.bias])).float().contiguous(),
                    w1f=w1f, w1_3=ops.split3_weight(w1f), b1=(w1 @ n1.bias + ff.w_1.bias).float().contiguous(),
                    w2_3=ops.split3_weight(ff.w_2.weight), w2t_3=ops.split3_weight(ff.w_2.weight.t().contiguous()))
     layer._fold3t = (key, out)
@@ -492,8 +492,7 @@ class EncoderLayer0X3Fn(torch.autograd.Function):
         # LayerNorm_1 sees y = x with the K rows replaced: the image is re-normalised at those rows, every other row is shared
         xn3.index_copy_(0, sel, ops.split3_rows(ops.layernorm_rows(x_sel, None, None, eps)))
         hid3 = ops.gemm_x3(xn3, fw["w1_3"], fw["b1"], "relu", split3=True)             # [N, 3F]
-        z = ops.gemm_x3(hid3, fw["w2_3"], bb2.detach().float().contiguous())           # f + b2
-        z.add_(x2)
+        z = ops.gemm_x3(hid3, fw["w2_3"], bb2.detach().float().contiguous(), resid=x2)  # x + f + b2: the residual rides in the epilogue
         z.index_add_(0, sel, delta)                                                    # snuffy.py:110,154-155
         ctx.save_for_backward(sel, xhat0_sel, qv, kp, p, mask, o, xs, x_sel, hid3, g0, b0, g1, b1, wq, wv, wo, w1)
         ctx.xn3, ctx.fw = xn3, fw       # xn3: written in place after the Q | V projection read it (outside the version check)

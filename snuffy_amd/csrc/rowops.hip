@@ -566,6 +566,39 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
     }
 }
 
+// w [m, k] f32 (row pitch ldw), optionally scaled per column (the LayerNorm gamma folded into the projection, W' = W diag(gamma), in fp32)
+// -> out [m, 3 k] bf16 = [Wh | Wl | Wh]: the weight operand of the concatenated-K fp32-class GEMM, in ONE pass (the training step rebuilds
+// its five weight images after every optimizer step: five launches instead of ~25 elementwise ones).
+__global__ __launch_bounds__(256) void split3_weight_kernel(const float* __restrict__ w, int64_t ldw, int64_t m, int k,
+                                                            const float* __restrict__ colscale, unsigned short* __restrict__ out) {
+    const int kq = k >> 3;
+    const int64_t total = m * kq;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / kq;
+        const int c = (int)(i - row * kq) * 8;
+        const float4 a = *reinterpret_cast<const float4*>(w + row * ldw + c);
+        const float4 b = *reinterpret_cast<const float4*>(w + row * ldw + c + 4);
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        if (colscale) {
+            const float4 g0 = *reinterpret_cast<const float4*>(colscale + c), g1 = *reinterpret_cast<const float4*>(colscale + c + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= gg[e];
+        }
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            lo[e] = pack_bf16x2(v[2 * e] - __uint_as_float(hi[e] << 16), v[2 * e + 1] - __uint_as_float(hi[e] & 0xffff0000u));
+        }
+        unsigned short* o = out + row * 3 * k + c;
+        const uint4 h4 = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(o) = h4;
+        *reinterpret_cast<uint4*>(o + k) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        *reinterpret_cast<uint4*>(o + 2 * k) = h4;
+    }
+}
+
 // split3_kernel + the ReLU gate + the column sums of the gated values in one pass (see snf_split3_colsum_f32); row / column ownership as
 // colsum_fused_kernel: a workgroup owns a contiguous row range, thread t columns 8 t .. 8 t + 7 (+ 2048 j).
 template <int NCH>
@@ -1426,6 +1459,20 @@ int snf_split3_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16
     hipLaunchKernelGGL(split3_kernel, dim3((int)blocks), dim3(256), 0, snf::as_stream(stream), x, ldx, m, k,
                        reinterpret_cast<unsigned short*>(out_bf16));
     return snf::check_launch("split3_kernel");
+}
+
+int snf_split3_weight_f32(const float* w, int64_t ldw, int64_t m, int k, const float* colscale, void* out_bf16, snf_stream_t stream) {
+    SNF_REQUIRE(w && out_bf16, "snf_split3_weight_f32: null pointer");
+    SNF_REQUIRE(m >= 1 && k >= 8 && k % 8 == 0 && ldw >= k && ldw % 4 == 0, "snf_split3_weight_f32: bad shape m=%lld k=%d ldw=%lld",
+                (long long)m, k, (long long)ldw);
+    SNF_REQUIRE(aligned16(w) && aligned16(out_bf16) && (!colscale || aligned16(colscale)), "snf_split3_weight_f32: buffers must be 16-byte aligned");
+    const int64_t total = m * (k >> 3);
+    int64_t blocks = (total + 255) / 256;
+    const int64_t cap = (int64_t)snf::cu_count() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(split3_weight_kernel, dim3((int)blocks), dim3(256), 0, snf::as_stream(stream), w, ldw, m, k, colscale,
+                       reinterpret_cast<unsigned short*>(out_bf16));
+    return snf::check_launch("split3_weight_kernel");
 }
 
 int snf_split3_colsum_f32(const float* x, int64_t ldx, int64_t m, int k, const void* gate_bf16, int64_t ldg, void* out_bf16,

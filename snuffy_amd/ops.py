@@ -1450,11 +1450,20 @@ def _hl_workspace(device, nbytes):
     return _ws(nbytes, device)
 
 
-def split3_weight(w):
-    """W [n, k] f32 -> W3 [n, 3 k] bf16 = [Wh | Wl | Wh]: with an activation image [hi | hi | lo] (layernorm_rows_split3,
+def split3_weight(w, colscale=None):
+    """W [n, k] f32 (x diag(colscale), in fp32, if given) -> W3 [n, 3 k] bf16 = [Wh | Wl | Wh]: with an activation image [hi | hi | lo] (layernorm_rows_split3,
     gemm_bf16(split3=True)) one bf16 GEMM over the tripled K axis computes hi Wh^T + hi Wl^T + lo Wh^T, i.e. the fp32
     product to ~2^-17 relative per term with fp32 accumulation."""
     w = w.detach().float()
+    if colscale is not None:
+        colscale = colscale.detach().float().contiguous()
+    if w.is_cuda and w.dim() == 2 and w.shape[1] % 8 == 0 and w.stride(1) == 1 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0:
+        out = torch.empty(w.shape[0], 3 * w.shape[1], dtype=torch.bfloat16, device=w.device)
+        check(_ffi.load().snf_split3_weight_f32(_p(w), w.stride(0), w.shape[0], w.shape[1], _p(colscale), _p(out), _stream()),
+              "snf_split3_weight_f32")
+        return out
+    if colscale is not None:
+        w = w * colscale
     hi = w.to(torch.bfloat16)
     lo = (w - hi.float()).to(torch.bfloat16)
     return torch.cat([hi, lo, hi], dim=1).contiguous()

@@ -469,3 +469,17 @@ def test_gemm_tn_weight_gradient_contraction(n, p, q, x3):
         assert torch.equal(out, ops.gemm_tn(a16, b16, p, q))
     scale = ref.abs().max().item()
     assert out.shape == (p, q) and (out.double() - ref).abs().max().item() <= tol * scale
+
+
+@pytest.mark.parametrize("m,k,scaled", [(1536, 768, True), (3072, 768, False), (768, 3072, False), (100, 40, True)])
+def test_split3_weight_image_in_one_launch(m, k, scaled):
+    """snf_split3_weight_f32 == the elementwise formulation, bit for bit: [Wh | Wl | Wh] of W (x diag(gamma) in fp32)."""
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(m + k)
+    w = torch.randn(m, k, generator=g).to(DEV)
+    gam = (torch.rand(k, generator=g) + 0.5).to(DEV) if scaled else None
+    out = ops.split3_weight(w, gam)
+    wf = w * gam if scaled else w
+    hi = wf.to(torch.bfloat16)
+    lo = (wf - hi.float()).to(torch.bfloat16)
+    assert torch.equal(out, torch.cat([hi, lo, hi], 1))
