@@ -186,6 +186,10 @@ int snf_colsum_fused(const void* src, int src_dtype, int64_t n, int d, const flo
  * k % 8 == 0, k <= 8192, 16-byte aligned rows. */
 int snf_split3_colsum_f32(const float* x, int64_t ldx, int64_t m, int k, const void* gate_bf16, int64_t ldg, void* out_bf16,
                           int64_t ldo, int64_t plane, float* partial, snf_stream_t stream);
+/* The same pass writing the INTERLEAVED image ([hi(32) | lo(32)] per 32 columns, 2 k columns: the operand format of snf_gemm_hl_bf16 and of
+ * snf_gemm_tn_f32's hl layout); gate_hl (nullable): the activation's own hl image, its hi values decide.  k % 32 == 0. */
+int snf_split_hl_colsum_f32(const float* x, int64_t ldx, int64_t m, int k, const void* gate_hl, int64_t ldg, void* out_hl, int64_t ldo,
+                            float* partial, snf_stream_t stream);
 /* Skinny fp32-class projection for the K selected rows of a bag (key / output projections, snuffy.py:190, 205; the tile GEMMs
  * need thousands of rows): out [r, c] (f32 or bf16: out_dtype) = x [r, k] f32 . w [c, k]^T f32 + bias, every product as split-bf16 x3
  * on the matrix cores with the split done in registers.  r <= 8192, k % 16 == 0, rows 16-byte aligned. */
@@ -429,11 +433,13 @@ size_t snf_gemm_hl_ws_bytes(int64_t m, int n, int k);
  *   b [n, ldb].  a_lo, b_lo >= 0: the operands are split images with a lo plane at those column offsets (the [hi | hi | lo] images of
  *   snf_split3_colsum_f32 / snf_layernorm_rows_split3_f32 / a split3 GEMM output) and the product is fp32-class, hi hi + hi lo + lo hi;
  *   both -1: one bf16 product.  Tiles of 256 x 256 cut into row parts (one workgroup each), summed in part order (bit-reproducible).
+ *   hl != 0: both operands are INTERLEAVED images instead ([hi(32) | lo(32)] per 32 columns; a_hi / b_hi = the image column where the
+ *   operand starts, a multiple of 64; a_lo, b_lo ignored; p % 32 == 0, q % 32 == 0) -- full 128-byte lines all the way.
  *   workspace: snf_gemm_tn_ws_bytes(n, p, q) bytes of plain scratch memory.  Domain: n % 32 == 0, p % 8 == 0, q % 8 == 0, plane offsets
  *   % 8 == 0, 16-byte aligned rows. */
 size_t snf_gemm_tn_ws_bytes(int64_t n, int p, int q);
-int snf_gemm_tn_f32(const void* a, int64_t lda, int a_hi, int a_lo, const void* b, int64_t ldb, int b_hi, int b_lo, int64_t n, int p, int q,
-                    float* c, int64_t ldc, void* workspace, size_t workspace_bytes, snf_stream_t stream);
+int snf_gemm_tn_f32(const void* a, int64_t lda, int a_hi, int a_lo, const void* b, int64_t ldb, int b_hi, int b_lo, int hl, int64_t n, int p,
+                    int q, float* c, int64_t ldc, void* workspace, size_t workspace_bytes, snf_stream_t stream);
 int snf_gemm_hl_ws_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ldw, const float* bias, const float* resid,
                         int64_t ldr, int64_t m, int n, int k, int act, void* c, int64_t ldc, int out_dtype, void* workspace,
                         size_t workspace_bytes, snf_stream_t stream);

@@ -23,6 +23,9 @@ from . import ops
 FUSED_BF16_TRAINING = True
 # fp32 training: the same for the fp32-class arithmetic (EncoderLayer0X3Fn, round 5)
 FUSED_X3_TRAINING = True
+# ... on the one-pass kernels (round 6): activations and gradients as interleaved hl images (4 bytes per element instead of the 6 of
+# [hi | hi | lo]), projections on gemm_hl, weight gradients on gemm_tn(hl=True); False: the concatenated-K chain of round 5
+X3_TRAIN_HL = True
 
 _ACT = {
     "relu": F.relu,
@@ -382,27 +385,47 @@ def fused_layer0_ok(x2, sel, layer, precision):
     return fused_layer0_shape_ok(layer, x2.shape[0], x2.shape[1], sel.numel())
 
 
-def _x3_train_weights(layer):
+def _x3_train_weights(layer, hl=False):
     """Operands of EncoderLayer0X3Fn, cached on the layer per parameter version: the LayerNorm affines folded into the following
-    projection in fp32 (LN(x) W^T + b = xhat (W * gamma)^T + (W beta + b)) and the split images [Wh | Wl | Wh] of the folded Q | V and
-    FFN-in weights, of W2 and of W2^T (the operand of the FFN-out input gradient)."""
+    projection in fp32 (LN(x) W^T + b = xhat (W * gamma)^T + (W beta + b)) and the split images [Wh | Wl | Wh] (hl: the interleaved
+    images) of the folded Q | V and FFN-in weights, of W2 and of W2^T (the operand of the FFN-out input gradient)."""
     n0, n1 = layer.sublayer[0].norm, layer.sublayer[1].norm
     lq, lk, lv, lo = layer.self_attn.linears
     ff = layer.feed_forward
     plist = [n0.weight, n0.bias, n1.weight, n1.bias, lq.weight, lq.bias, lv.weight, lv.bias, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight]
     key = tuple(SF.param_key(p) for p in plist)
-    ent = getattr(layer, "_fold3t", None)
+    attr = "_fold3t_hl" if hl else "_fold3t"
+    ent = getattr(layer, attr, None)
     if ent is not None and ent[0] == key:
         return ent[1]
     with torch.no_grad():
         wqv = torch.cat([lq.weight, lv.weight]).float()
         w1 = ff.w_1.weight.float()
         w1f = (w1 * n1.weight).contiguous()
-        out = dict(wqv3=ops.split3_weight(wqv, n0.weight), bqv=(wqv @ n0.bias + torch.cat([lq.bias, lv.bias])).float().contiguous(),
-                   w1f=w1f, w1_3=ops.split3_weight(w1f), b1=(w1 @ n1.bias + ff.w_1.bias).float().contiguous(),
-                   w2_3=ops.split3_weight(ff.w_2.weight), w2t_3=ops.split3_weight(ff.w_2.weight.t().contiguous()))
-    layer._fold3t = (key, out)
+        out = dict(bqv=(wqv @ n0.bias + torch.cat([lq.bias, lv.bias])).float().contiguous(), w1f=w1f,
+                   b1=(w1 @ n1.bias + ff.w_1.bias).float().contiguous())
+        if hl:
+            w2 = ff.w_2.weight.float()
+            out.update(wqv_hl=ops.split_hl_rows((wqv * n0.weight).contiguous()), w1_hl=ops.split_hl_rows(w1f),
+                       w2_hl=ops.split_hl_rows(w2.contiguous()), w2t_hl=ops.split_hl_rows(w2.t().contiguous()))
+        else:
+            out.update(wqv3=ops.split3_weight(wqv, n0.weight), w1_3=ops.split3_weight(w1f), w2_3=ops.split3_weight(ff.w_2.weight),
+                       w2t_3=ops.split3_weight(ff.w_2.weight.t().contiguous()))
+    setattr(layer, attr, (key, out))
     return out
+
+
+def _hl_planes_sum(img):
+    """fp32 value hi + lo of every element of a (small) hl image [r, 2 k] -> [r, k]."""
+    v = img.view(img.shape[0], -1, 2, 32).float()
+    return (v[:, :, 0] + v[:, :, 1]).reshape(img.shape[0], -1)
+
+
+def _x3_train_hl_ok(n, d, f):
+    """The one-pass chain applies: hl images (32-column groups), every projection fills the chip with 256 x 256 tiles, the three weight
+    gradients are in gemm_tn's domain."""
+    return (X3_TRAIN_HL and d % 32 == 0 and f % 32 == 0 and n % 32 == 0 and ops.hl_eligible(n, 2 * d, d) and ops.hl_eligible(n, f, d)
+            and ops.hl_eligible(n, d, f) and ops.GEMM_TN and n >= 1024 and d * f >= 65536)
 
 
 _BMM_OUT = None         # does this torch build take out= together with out_dtype on bmm?
@@ -464,9 +487,14 @@ class EncoderLayer0X3Fn(torch.autograd.Function):
         dk = d // h
         k = sel.numel()
         eps = layer.sublayer[0].norm.eps
-        fw = _x3_train_weights(layer)
-        xn3 = ops.layernorm_rows_split3(x2, None, None, eps)                          # xhat = LN_0(x) without its affine, [N, 3D]
-        qv = ops.gemm_x3(xn3, fw["wqv3"], fw["bqv"])                                   # [N, 2D] f32 = [Q | V]
+        hl = _x3_train_hl_ok(n, d, w1.shape[0])
+        fw = _x3_train_weights(layer, hl)
+        if hl:
+            xn3 = ops.layernorm_rows_hl(x2, None, None, eps)                           # xhat = LN_0(x) without its affine, hl image [N, 2D]
+            qv = ops.gemm_hl(xn3, fw["wqv_hl"], fw["bqv"])                             # [N, 2D] f32 = [Q | V]
+        else:
+            xn3 = ops.layernorm_rows_split3(x2, None, None, eps)                      # ... as [hi | hi | lo], [N, 3D]
+            qv = ops.gemm_x3(xn3, fw["wqv3"], fw["bqv"])
         q, v = qv[:, :d], qv[:, d:]
         xs, _slot = ops.gather_slot_map(x2, sel)
         # the K-row projections in plain fp32 (10 us each, as the generic chain runs them under autograd): the gradient that reaches the
@@ -490,13 +518,18 @@ class EncoderLayer0X3Fn(torch.autograd.Function):
         x_sel = xs + delta                                                             # snuffy.py:108 at the K rows
         xhat0_sel = xn3.index_select(0, sel)
         # LayerNorm_1 sees y = x with the K rows replaced: the image is re-normalised at those rows, every other row is shared
-        xn3.index_copy_(0, sel, ops.split3_rows(ops.layernorm_rows(x_sel, None, None, eps)))
-        hid3 = ops.gemm_x3(xn3, fw["w1_3"], fw["b1"], "relu", split3=True)             # [N, 3F]
-        z = ops.gemm_x3(hid3, fw["w2_3"], bb2.detach().float().contiguous(), resid=x2)  # x + f + b2: the residual rides in the epilogue
+        if hl:
+            ops.layernorm_rows_hl_patch_(xn3, sel, x_sel, None, eps=eps)
+            hid3 = ops.gemm_hl(xn3, fw["w1_hl"], fw["b1"], "relu", hl_out=True)        # [N, 2F] image
+            z = ops.gemm_hl(hid3, fw["w2_hl"], bb2.detach().float().contiguous(), resid=x2)
+        else:
+            xn3.index_copy_(0, sel, ops.split3_rows(ops.layernorm_rows(x_sel, None, None, eps)))
+            hid3 = ops.gemm_x3(xn3, fw["w1_3"], fw["b1"], "relu", split3=True)         # [N, 3F]
+            z = ops.gemm_x3(hid3, fw["w2_3"], bb2.detach().float().contiguous(), resid=x2)  # x + f + b2: the residual rides in the epilogue
         z.index_add_(0, sel, delta)                                                    # snuffy.py:110,154-155
         ctx.save_for_backward(sel, xhat0_sel, qv, kp, p, mask, o, xs, x_sel, hid3, g0, b0, g1, b1, wq, wv, wo, w1)
         ctx.xn3, ctx.fw = xn3, fw       # xn3: written in place after the Q | V projection read it (outside the version check)
-        ctx.h, ctx.eps = h, eps
+        ctx.h, ctx.eps, ctx.hl = h, eps, hl
         attn = (p * mask if mask is not None else p) if need_attn else None
         if attn is not None:
             ctx.mark_non_differentiable(attn)
@@ -507,21 +540,33 @@ class EncoderLayer0X3Fn(torch.autograd.Function):
         sel, xhat0_sel, qv, kp, p, mask, o, xs, x_sel, hid3, g0, b0, g1, b1, wq, wv, wo, w1 = ctx.saved_tensors
         xn3, fw = ctx.xn3, ctx.fw
         d = xs.shape[1]
-        f = hid3.shape[1] // 3
+        hl = ctx.hl
+        f = hid3.shape[1] // (2 if hl else 3)
         h, eps = ctx.h, ctx.eps
         dk = d // h
         dz = dz.float().contiguous()
         # ---- FFN: z = y + relu(xhat1 W1'^T + b1') W2^T + b2                                                  (snuffy.py:224-225)
-        dz3, db2 = ops.split3_colsum(dz)                                               # operand image + bias gradient, one pass
-        dw2 = _tn3(dz3, hid3, d, f)                                                    # [D, F]
-        dhid = ops.gemm_x3(dz3, fw["w2t_3"])                                           # [N, F] f32, not yet gated
-        del dz3
-        gate = hid3[:, f:2 * f]                                                        # ReLU mask from the hi plane of the output image
-        dhid3, db1f = ops.split3_colsum(dhid, gate=gate)
-        dw1f = _tn3(dhid3, xn3, f, d)                                                  # [F, D], gradient of the FOLDED weight
-        del dhid3
+        if hl:
+            dz3, db2 = ops.split_hl_colsum(dz)                                         # operand image + bias gradient, one pass
+            dw2 = ops.gemm_tn(dz3, hid3, d, f, hl=True)                                # [D, F]
+            dhid = ops.gemm_hl(dz3, fw["w2t_hl"])                                      # [N, F] f32, not yet gated
+            del dz3
+            dhid3, db1f = ops.split_hl_colsum(dhid, gate_hl=hid3)                      # ReLU mask from the hi values of the output image
+            dw1f = ops.gemm_tn(dhid3, xn3, f, d, hl=True)                              # [F, D], gradient of the FOLDED weight
+            del dhid3
+            gate_s = hid3.index_select(0, sel).view(sel.numel(), f // 32, 2, 32)[:, :, 0].reshape(sel.numel(), f)
+        else:
+            dz3, db2 = ops.split3_colsum(dz)
+            dw2 = _tn3(dz3, hid3, d, f)
+            dhid = ops.gemm_x3(dz3, fw["w2t_3"])
+            del dz3
+            gate = hid3[:, f:2 * f]                                                    # ReLU mask from the hi plane of the output image
+            dhid3, db1f = ops.split3_colsum(dhid, gate=gate)
+            dw1f = _tn3(dhid3, xn3, f, d)
+            del dhid3
+            gate_s = gate.index_select(0, sel)
         # ---- the K selected rows: y[S] = x_sel = xs + o Wo^T + bo; every other row of y is data               (snuffy.py:108,152-155)
-        dyn_s = (dhid.index_select(0, sel) * (gate.index_select(0, sel) > 0)) @ fw["w1f"]      # d loss / d xhat1[S]
+        dyn_s = (dhid.index_select(0, sel) * (gate_s > 0)) @ fw["w1f"]                 # d loss / d xhat1[S]
         del dhid
         dy_s = ops.layernorm_rows_bwd(x_sel, dyn_s, None, eps, residual=dz.index_select(0, sel), want_param_grads=False)[0]
         dbo = dy_s.sum(0)
@@ -532,11 +577,18 @@ class EncoderLayer0X3Fn(torch.autograd.Function):
         # xn3 holds LayerNorm 1's rows at S since the forward re-normalised them in place; the Q | V projection saw LayerNorm 0's:
         # dW = dqv^T xn3 + dqv[S]^T (xhat0[S] - xhat1[S]), a K-row correction of the big product
         x1_sel = xn3.index_select(0, sel)
-        corr = (xhat0_sel[:, d:2 * d].float() + xhat0_sel[:, 2 * d:].float()) - (x1_sel[:, d:2 * d].float() + x1_sel[:, 2 * d:].float())
-        dqv3 = torch.empty(xn3.shape[0], 6 * d, dtype=torch.bfloat16, device=dq.device)   # ONE image of [dQ | dV]
-        _, dbq = ops.split3_colsum(dq, out=dqv3, col=0)
-        _, dbv = ops.split3_colsum(dv, out=dqv3, col=d)
-        dwqvf = _tn3(dqv3, xn3, 2 * d, d)                                              # [2D, D] folded
+        if hl:
+            corr = _hl_planes_sum(xhat0_sel) - _hl_planes_sum(x1_sel)
+            dqv3 = torch.empty(xn3.shape[0], 4 * d, dtype=torch.bfloat16, device=dq.device)   # ONE image of [dQ | dV]
+            _, dbq = ops.split_hl_colsum(dq, out=dqv3, col=0)
+            _, dbv = ops.split_hl_colsum(dv, out=dqv3, col=d)
+            dwqvf = ops.gemm_tn(dqv3, xn3, 2 * d, d, hl=True)                          # [2D, D] folded
+        else:
+            corr = (xhat0_sel[:, d:2 * d].float() + xhat0_sel[:, 2 * d:].float()) - (x1_sel[:, d:2 * d].float() + x1_sel[:, 2 * d:].float())
+            dqv3 = torch.empty(xn3.shape[0], 6 * d, dtype=torch.bfloat16, device=dq.device)
+            _, dbq = ops.split3_colsum(dq, out=dqv3, col=0)
+            _, dbv = ops.split3_colsum(dv, out=dqv3, col=d)
+            dwqvf = _tn3(dqv3, xn3, 2 * d, d)
         del dqv3
         dwqvf += torch.cat([dq.index_select(0, sel), dv.index_select(0, sel)], dim=1).t() @ corr
         dwqf, dwvf = dwqvf[:d], dwqvf[d:]

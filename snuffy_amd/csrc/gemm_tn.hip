@@ -21,6 +21,11 @@
 // DMA source address: the LDS side of LDS-DMA is lane-linear).  A transposing read of a 16-lane group covers 4 rows x 32 bytes; the
 // two groups of a 32-lane half cover rows with 8 different (r & 7): 8 x 32 bytes on 16 different chunk positions mod 16 -- every
 // bank once.
+//
+// HL (layout of gemm_hl_kernel's operands: [hi(32) | lo(32)] per 32 columns, hi and lo of a column 64 bytes apart in one 128-byte line):
+// an operand's step image is 32 rows x 1024 bytes holding both planes as they lie in HBM -- full-line DMA, one row per instruction --
+// and the same swizzle on 64 chunk positions; only the fragment addresses differ (block bi, plane pl -> chunk 8 (bi >> 1) + 4 pl +
+// 2 (bi & 1) + half).  The training chain's images in this layout are 4 bytes per element instead of 6.
 #include "common.h"
 
 namespace {
@@ -54,17 +59,20 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
+template <int PITCH>
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {   // rows r .. r + 3 and r + 16 .. r + 19 of one 16-column block
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * 512));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * PITCH));
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <bool X3>
+template <bool X3, bool HL>
 __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const TnParams P) {
+    static_assert(X3 || !HL, "gemm_tn: the interleaved layout carries both planes");
     constexpr int NPL = X3 ? 2 : 1;                // planes per operand
-    constexpr int STEP_BYTES = 2 * NPL * IMG;      // [A hi | A lo | B hi | B lo]
+    constexpr int STEP_BYTES = 2 * NPL * IMG;      // [A hi | A lo | B hi | B lo]   (HL: [A rows of 1024 B | B rows of 1024 B])
     constexpr int B_OFF = NPL * IMG;
+    constexpr int PITCH = HL ? 1024 : 512;         // LDS row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -83,8 +91,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const TnParams P) {
     // ---- LDS-DMA sources.  A plane image is 16 pieces of 2 rows x 512 B; wave wid stages pieces 2 wid, 2 wid + 1 (rows 4 wid ..
     // 4 wid + 3) of every image; lane l lands at row 2 piece + (l >> 5), chunk position l & 31 and fetches true chunk
     // (l & 31) ^ 2 (row & 7).  Columns past the plane read a valid address (column 0); their products are never stored.
-    int src_a[2], src_b[2];
-    {
+    // HL: a piece is ONE row of 1024 B (both planes of 256 columns); wave wid stages rows 4 wid .. 4 wid + 3 of A and of B; lane l lands at
+    // chunk position l and fetches chunk l ^ 2 (row & 7) of the tile's 1024-byte span of its row.
+    int src_a[HL ? 4 : 2], src_b[HL ? 4 : 2];
+    if constexpr (HL) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = 4 * wid + j;
+            const int ch = lane ^ (2 * (row & 7));
+            const int tc = 32 * (ch >> 3) + 8 * (ch & 3);          // true column of the chunk inside the tile (either plane)
+            src_a[j] = row * (int)P.lda + 2 * tp * TM + (tp * TM + tc + 8 <= P.p ? 8 * ch : 0);
+            src_b[j] = row * (int)P.ldb + 2 * tq * TN_ + (tq * TN_ + tc + 8 <= P.q ? 8 * ch : 0);
+        }
+    } else {
         const int pos = lane & 31;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -103,8 +122,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const TnParams P) {
         unsigned char* base = smem + buf * STEP_BYTES;
         const unsigned short* ap = a_base + (int64_t)kstep * KS * P.lda;
         const unsigned short* bp = b_base + (int64_t)kstep * KS * P.ldb;
+        if constexpr (HL) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < 4; ++j) {
+                const int piece = (4 * wid + j) * 1024;
+                __builtin_amdgcn_global_load_lds((glb_void*)(ap + src_a[j] + P.a_hi), (lds_void*)(base + piece), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void*)(bp + src_b[j] + P.b_hi), (lds_void*)(base + B_OFF + piece), 16, 0, 0);
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < (HL ? 0 : 2); ++j) {
             const int piece = (2 * wid + j) * 1024;
             __builtin_amdgcn_global_load_lds((glb_void*)(ap + src_a[j] + P.a_hi), (lds_void*)(base + piece), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_void*)(bp + src_b[j] + P.b_hi), (lds_void*)(base + B_OFF + piece), 16, 0, 0);
@@ -119,12 +147,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const TnParams P) {
     // 16-column block; block index bi (16 wr' + ... in units of 16 columns) sits at chunk position 2 (bi ^ s7) + ((i & 3) >> 1)
     const int fi = lane & 15, fg = lane >> 4;
     const int s7 = 4 * (fg & 1) + (fi >> 2);
-    const int frow = (4 * fg + (fi >> 2)) * 512 + 16 * ((fi & 3) >> 1) + 8 * (fi & 1);
+    // from a hi fragment's address to its lo twin: the next plane image, or (HL) the other 64-byte half of the 128-byte column group --
+    // unit u + 2 sits at (u + 2) ^ s7 = (u ^ s7) ^ 2: 64 bytes up or down with bit 1 of s7
+    const int LO = HL ? ((s7 & 2) ? -64 : 64) : IMG;
+    const int frow = (4 * fg + (fi >> 2)) * PITCH + 16 * ((fi & 3) >> 1) + 8 * (fi & 1);
+    // (HL: half-chunk index of block bi's hi values = 8 (bi >> 1) + (bi & 1) in units of 32 bytes, the lo twin 2 units = 64 bytes further)
     auto a_addr = [&](const unsigned char* base, int mi) __attribute__((always_inline)) {
-        return base + frow + 32 * ((8 * wr + mi) ^ s7);
+        const int bi = 8 * wr + mi;
+        return base + frow + 32 * ((HL ? 4 * (bi >> 1) + (bi & 1) : bi) ^ s7);
     };
     auto b_addr = [&](const unsigned char* base, int ni) __attribute__((always_inline)) {
-        return base + B_OFF + frow + 32 * ((4 * wc + ni) ^ s7);
+        const int bi = 4 * wc + ni;
+        return base + B_OFF + frow + 32 * ((HL ? 4 * (bi >> 1) + (bi & 1) : bi) ^ s7);
     };
 
     f32x4 acc[8][4];
@@ -141,12 +175,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const TnParams P) {
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* base = smem + buf * STEP_BYTES;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) bh[ni] = tr_frag(b_addr(base, ni));
+        for (int ni = 0; ni < 4; ++ni) bh[ni] = tr_frag<PITCH>(b_addr(base, ni));
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) af[mi] = tr_frag(a_addr(base, mi));
+        for (int mi = 0; mi < 8; ++mi) af[mi] = tr_frag<PITCH>(a_addr(base, mi));
         if constexpr (X3) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) bl[ni] = tr_frag(b_addr(base, ni) + IMG);
+            for (int ni = 0; ni < 4; ++ni) bl[ni] = tr_frag<PITCH>(b_addr(base, ni) + LO);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < ns) stage(s + 1, buf ^ 1);
@@ -172,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const TnParams P) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[ni], af[mi], acc[mi][ni], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                af[mi] = tr_frag(a_addr(base, mi) + IMG);
+                af[mi] = tr_frag<PITCH>(a_addr(base, mi) + LO);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // lo (A) x hi (B)
@@ -219,12 +253,12 @@ int tn_parts(int64_t steps, int ntiles) {
     return parts;
 }
 
-template <bool X3>
+template <bool X3, bool HL = false>
 int launch_tn(const TnParams& P, hipStream_t s) {
     constexpr int lds = 2 * 2 * (X3 ? 2 : 1) * IMG;
     static thread_local unsigned long long attr_set_mask = 0;   // devices (bit = device id) that have the opt-in
     const unsigned long long bit = snf::device_bit();
-    auto kern = gemm_tn_kernel<X3>;
+    auto kern = gemm_tn_kernel<X3, HL>;
     if (!(attr_set_mask & bit)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             snf::set_error("gemm_tn: cannot reserve %d bytes of LDS", lds);
@@ -251,14 +285,16 @@ extern "C" size_t snf_gemm_tn_ws_bytes(int64_t n, int p, int q) {
     return (size_t)tn_parts(n / KS, ntiles) * ntiles * (size_t)(TM * TN_) * sizeof(float);
 }
 
-extern "C" int snf_gemm_tn_f32(const void* a, int64_t lda, int a_hi, int a_lo, const void* b, int64_t ldb, int b_hi, int b_lo, int64_t n,
-                               int p, int q, float* c, int64_t ldc, void* workspace, size_t workspace_bytes, snf_stream_t stream) {
+extern "C" int snf_gemm_tn_f32(const void* a, int64_t lda, int a_hi, int a_lo, const void* b, int64_t ldb, int b_hi, int b_lo, int hl,
+                               int64_t n, int p, int q, float* c, int64_t ldc, void* workspace, size_t workspace_bytes, snf_stream_t stream) {
     SNF_REQUIRE(a && b && c && workspace, "snf_gemm_tn_f32: null pointer");
     SNF_REQUIRE(n >= 1 && p >= 1 && q >= 1, "snf_gemm_tn_f32: bad shape n=%lld p=%d q=%d", (long long)n, p, q);
+    if (hl) a_lo = a_hi + 32, b_lo = b_hi + 32;
     const bool x3 = a_lo >= 0 || b_lo >= 0;
     SNF_REQUIRE(!x3 || (a_lo >= 0 && b_lo >= 0), "snf_gemm_tn_f32: both operands carry a lo plane, or neither");
-    const int64_t a_w = (int64_t)(a_lo > a_hi ? a_lo : a_hi) + p, b_w = (int64_t)(b_lo > b_hi ? b_lo : b_hi) + q;
-    if (n % KS || p % 8 || q % 8 || a_hi < 0 || b_hi < 0 || a_hi % 8 || b_hi % 8 || (x3 && (a_lo % 8 || b_lo % 8)) || lda % 8 || ldb % 8 ||
+    const int64_t a_w = hl ? (int64_t)a_hi + 2 * (int64_t)p : (int64_t)(a_lo > a_hi ? a_lo : a_hi) + p;
+    const int64_t b_w = hl ? (int64_t)b_hi + 2 * (int64_t)q : (int64_t)(b_lo > b_hi ? b_lo : b_hi) + q;
+    if ((hl && (p % 32 || q % 32 || a_hi % 64 || b_hi % 64)) || n % KS || p % 8 || q % 8 || a_hi < 0 || b_hi < 0 || a_hi % 8 || b_hi % 8 || (x3 && (a_lo % 8 || b_lo % 8)) || lda % 8 || ldb % 8 ||
         lda < a_w || ldb < b_w || ldc < q || ldc % 4 ||
         (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(workspace)) % 16 ||
         (KS + 1) * lda >= 0x7fffffffll || (KS + 1) * ldb >= 0x7fffffffll) {
@@ -283,5 +319,6 @@ extern "C" int snf_gemm_tn_f32(const void* a, int64_t lda, int a_hi, int a_lo, c
     P.slab = reinterpret_cast<float*>(workspace);
     P.c = c, P.ldc = ldc;
     hipStream_t s = snf::as_stream(stream);
+    if (hl) return launch_tn<true, true>(P, s);
     return x3 ? launch_tn<true>(P, s) : launch_tn<false>(P, s);
 }

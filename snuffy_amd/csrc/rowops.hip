@@ -601,7 +601,8 @@ __global__ __launch_bounds__(256) void split3_weight_kernel(const float* __restr
 
 // split3_kernel + the ReLU gate + the column sums of the gated values in one pass (see snf_split3_colsum_f32); row / column ownership as
 // colsum_fused_kernel: a workgroup owns a contiguous row range, thread t columns 8 t .. 8 t + 7 (+ 2048 j).
-template <int NCH>
+// HL: the image (and the gate's) is the interleaved one of gemm_hl / snf_gemm_tn_f32 -- [hi(32) | lo(32)] per 32 columns, 2 k columns wide
+template <int NCH, bool HL = false>
 __global__ __launch_bounds__(256) void split3_colsum_kernel(const float* __restrict__ x, int64_t ldx, int64_t m, int k,
                                                             const unsigned short* __restrict__ gate, int64_t ldg,
                                                             unsigned short* __restrict__ out, int64_t ldo, int64_t plane,
@@ -622,8 +623,9 @@ __global__ __launch_bounds__(256) void split3_colsum_kernel(const float* __restr
                 const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c);
                 const float4 b = *reinterpret_cast<const float4*>(x + row * ldx + c + 4);
                 float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                const int ci = HL ? 64 * (c >> 5) + (c & 31) : c;   // position of the 8 columns' hi values inside an image row
                 if (gate) {
-                    const uint4 g = *reinterpret_cast<const uint4*>(gate + row * ldg + c);
+                    const uint4 g = *reinterpret_cast<const uint4*>(gate + row * ldg + ci);
                     const unsigned g4[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -637,11 +639,15 @@ __global__ __launch_bounds__(256) void split3_colsum_kernel(const float* __restr
                     hi[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
                     lo[e] = pack_bf16x2(v[2 * e] - __uint_as_float(hi[e] << 16), v[2 * e + 1] - __uint_as_float(hi[e] & 0xffff0000u));
                 }
-                unsigned short* o = out + row * ldo + c;
+                unsigned short* o = out + row * ldo + ci;
                 const uint4 h4 = make_uint4(hi[0], hi[1], hi[2], hi[3]);
                 *reinterpret_cast<uint4*>(o) = h4;
-                *reinterpret_cast<uint4*>(o + plane) = h4;
-                *reinterpret_cast<uint4*>(o + 2 * plane) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                if constexpr (HL) {
+                    *reinterpret_cast<uint4*>(o + 32) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                } else {
+                    *reinterpret_cast<uint4*>(o + plane) = h4;
+                    *reinterpret_cast<uint4*>(o + 2 * plane) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[j][e] += v[e];
             }
@@ -1496,6 +1502,29 @@ int snf_split3_colsum_f32(const float* x, int64_t ldx, int64_t m, int k, const v
         default: hipLaunchKernelGGL(split3_colsum_kernel<4>, dim3(blocks), dim3(256), 0, s, x, ldx, m, k, g, ldg, o, ldo, plane, partial, rpb); break;
     }
     return snf::check_launch("split3_colsum_kernel");
+}
+
+int snf_split_hl_colsum_f32(const float* x, int64_t ldx, int64_t m, int k, const void* gate_hl, int64_t ldg, void* out_hl, int64_t ldo,
+                            float* partial, snf_stream_t stream) {
+    SNF_REQUIRE(x && out_hl, "snf_split_hl_colsum_f32: null pointer");
+    SNF_REQUIRE(m >= 1 && k >= 32 && k % 32 == 0 && k <= 8192 && ldx >= k && ldx % 4 == 0 && ldo >= 2 * (int64_t)k && ldo % 8 == 0 &&
+                    (!gate_hl || (ldg >= 2 * (int64_t)k && ldg % 8 == 0)),
+                "snf_split_hl_colsum_f32: bad shape m=%lld k=%d ldx=%lld ldg=%lld ldo=%lld (k %% 32 == 0, k <= 8192, images of 2 k columns, 16-byte rows)",
+                (long long)m, k, (long long)ldx, (long long)ldg, (long long)ldo);
+    SNF_REQUIRE(aligned16(x) && aligned16(out_hl) && (!gate_hl || aligned16(gate_hl)) && (!partial || aligned16(partial)),
+                "snf_split_hl_colsum_f32: buffers must be 16-byte aligned");
+    const int blocks = snf_colsum_blocks(m);
+    const int rpb = (int)((m + blocks - 1) / blocks);
+    const int nch = (k + 2047) / 2048;
+    hipStream_t s = snf::as_stream(stream);
+    const unsigned short* g = reinterpret_cast<const unsigned short*>(gate_hl);
+    unsigned short* o = reinterpret_cast<unsigned short*>(out_hl);
+    switch (nch) {
+        case 1: hipLaunchKernelGGL((split3_colsum_kernel<1, true>), dim3(blocks), dim3(256), 0, s, x, ldx, m, k, g, ldg, o, ldo, (int64_t)0, partial, rpb); break;
+        case 2: hipLaunchKernelGGL((split3_colsum_kernel<2, true>), dim3(blocks), dim3(256), 0, s, x, ldx, m, k, g, ldg, o, ldo, (int64_t)0, partial, rpb); break;
+        default: hipLaunchKernelGGL((split3_colsum_kernel<4, true>), dim3(blocks), dim3(256), 0, s, x, ldx, m, k, g, ldg, o, ldo, (int64_t)0, partial, rpb); break;
+    }
+    return snf::check_launch("split3_colsum_kernel<hl>");
 }
 
 int snf_fold_blocks(int r) {

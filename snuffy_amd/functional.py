@@ -551,6 +551,7 @@ def invalidate_folded(layer):
     layer._fold3 = None
     layer._fold3f = None
     layer._fold3t = None
+    layer._fold3t_hl = None
     layer._fold_pad = None
     layer._xhat_offer = None
     layer._xn3_offer = None

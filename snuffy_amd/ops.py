@@ -1315,13 +1315,14 @@ def gemm_tn_supported(n, p, q, *images):
                and t.shape[0] == n and 33 * t.stride(0) < 2 ** 31 for t in images)
 
 
-def gemm_tn(a_img, b_img, p, q, a_planes=(0, -1), b_planes=(0, -1), out=None):
+def gemm_tn(a_img, b_img, p, q, a_planes=(0, -1), b_planes=(0, -1), out=None, hl=False):
     """a^T b over the rows of two bf16 images -> [p, q] f32 (snf_gemm_tn_f32): a = the p columns at column a_planes[0] of a_img [n, .],
     b = the q columns at b_planes[0] of b_img [n, .]; with lo planes (a_planes[1], b_planes[1] >= 0: split images [hi | hi | lo]) the
-    product is fp32-class (hi hi + hi lo + lo hi), otherwise one bf16 product.  The contraction runs over the BAG axis: the weight
-    gradients of the training step."""
+    product is fp32-class (hi hi + hi lo + lo hi), otherwise one bf16 product.  hl: both images are interleaved ones ([hi(32) | lo(32)]
+    per 32 columns; a_planes[0] / b_planes[0] = the IMAGE column where the operand starts, p % 32 == q % 32 == 0).  The contraction runs
+    over the BAG axis: the weight gradients of the training step."""
     n = a_img.shape[0]
-    if not gemm_tn_supported(n, p, q, a_img, b_img):
+    if not gemm_tn_supported(n, p, q, a_img, b_img) or (hl and (p % 32 or q % 32 or a_planes[0] % 64 or b_planes[0] % 64)):
         raise ValueError("gemm_tn: shape n=%d p=%d q=%d / operands outside the kernel's domain" % (n, p, q))
     if out is None:
         out = torch.empty(p, q, dtype=torch.float32, device=a_img.device)
@@ -1329,7 +1330,7 @@ def gemm_tn(a_img, b_img, p, q, a_planes=(0, -1), b_planes=(0, -1), out=None):
     nb = int(lib.snf_gemm_tn_ws_bytes(n, p, q))
     ws = _ws(nb, a_img.device)
     check(lib.snf_gemm_tn_f32(_p(a_img), a_img.stride(0), a_planes[0], a_planes[1], _p(b_img), b_img.stride(0), b_planes[0], b_planes[1],
-                              n, p, q, _p(out), out.stride(0), _p(ws), nb, _stream()), "snf_gemm_tn_f32")
+                              1 if hl else 0, n, p, q, _p(out), out.stride(0), _p(ws), nb, _stream()), "snf_gemm_tn_f32")
     return out
 
 
@@ -1514,6 +1515,36 @@ def split3_colsum(x, gate=None, out=None, col=0, want_colsum=True):
     dst = out if col == 0 else out[:, col:]
     check(lib.snf_split3_colsum_f32(_p(x), x.stride(0), m, k, _p(gate), ldg, _p(dst), out.stride(0), plane, _p(part), _stream()),
           "snf_split3_colsum_f32")
+    return out, (part.sum(0) if part is not None else None)
+
+
+def split_hl_colsum(x, gate_hl=None, out=None, col=0, want_colsum=True):
+    """split3_colsum writing the INTERLEAVED image ([hi(32) | lo(32)] per 32 columns, [m, 2 k]: operand of gemm_hl and of gemm_tn(hl=True));
+    gate_hl [m, 2 k] bf16: the activation's own hl image (its hi values decide).  out / col: write the k columns at TRUE column col of
+    a wider image out [m, 2 w].  Returns (image, colsum [k] or None).  snf_split_hl_colsum_f32."""
+    if x.dtype != torch.float32:
+        raise TypeError("split_hl_colsum: x must be float32")
+    x = _rows16(x, "x")
+    m, k = x.shape
+    if k % 32 or k > 8192:
+        raise ValueError("split_hl_colsum: k=%d must be a multiple of 32 and <= 8192" % k)
+    ldg = 0
+    if gate_hl is not None:
+        if gate_hl.dtype != torch.bfloat16 or tuple(gate_hl.shape) != (m, 2 * k):
+            raise ValueError("split_hl_colsum: gate must be the bfloat16 hl image of a matrix of the shape of x")
+        gate_hl = _rows16(gate_hl, "gate")
+        ldg = gate_hl.stride(0)
+    if out is None:
+        out = torch.empty(m, 2 * k, dtype=torch.bfloat16, device=x.device)
+        col = 0
+    elif (out.dtype != torch.bfloat16 or out.dim() != 2 or not out.is_contiguous() or out.shape[0] != m or out.shape[1] % 64
+          or col % 32 or 2 * (col + k) > out.shape[1]):
+        raise ValueError("split_hl_colsum: bad out image")
+    lib = _ffi.load()
+    part = torch.empty(lib.snf_colsum_blocks(m), k, dtype=torch.float32, device=x.device) if want_colsum else None
+    dst = out if col == 0 else out[:, 2 * col:]
+    check(lib.snf_split_hl_colsum_f32(_p(x), x.stride(0), m, k, _p(gate_hl), ldg, _p(dst), out.stride(0), _p(part), _stream()),
+          "snf_split_hl_colsum_f32")
     return out, (part.sum(0) if part is not None else None)
 
 

@@ -483,3 +483,41 @@ def test_split3_weight_image_in_one_launch(m, k, scaled):
     hi = wf.to(torch.bfloat16)
     lo = (wf - hi.float()).to(torch.bfloat16)
     assert torch.equal(out, torch.cat([hi, lo, hi], 1))
+
+
+@pytest.mark.parametrize("n,p,q", [(32768, 768, 3072), (2048, 512, 288), (4096, 1536, 768)])
+def test_gemm_tn_interleaved_images(n, p, q):
+    """snf_gemm_tn_f32 on hl images ([hi(32) | lo(32)] per 32 columns): the same products as on plane images, an operand that starts
+    inside a wider image, fp64 reference."""
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(n + p + q + 1)
+    a = torch.randn(n, p, generator=g).to(DEV)
+    b = torch.randn(n, q, generator=g).to(DEV)
+    a_hl, b_hl = ops.split_hl_rows(a), ops.split_hl_rows(b)
+    out = ops.gemm_tn(a_hl, b_hl, p, q, hl=True)
+    ref = a.double().t() @ b.double()
+    assert (out.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    planes = ops.gemm_tn(ops.split3_rows(a), ops.split3_rows(b), p, q, (p, 2 * p), (q, 2 * q))
+    assert (out - planes).abs().max().item() <= 2e-6 * ref.abs().max().item()            # same products, another summation order
+    assert torch.equal(out, ops.gemm_tn(a_hl, b_hl, p, q, hl=True))
+    if p % 64 == 0:
+        half = ops.gemm_tn(a_hl, b_hl, p // 2, q, (p, -1), (0, -1), hl=True)                # the right half of a's columns
+        assert (half.double() - ref[p // 2:]).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("m,k,gated", [(32768, 3072, True), (5000, 768, False), (1000, 1536, True)])
+def test_split_hl_colsum(m, k, gated):
+    """snf_split_hl_colsum_f32 == split_hl_rows of the gated matrix, plus its column sums; two matrices sharing one image."""
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(m + k)
+    x = torch.randn(m, k, generator=g).to(DEV)
+    act = torch.randn(m, k, generator=g).to(DEV)
+    gate_hl = ops.split_hl_rows(torch.relu(act)) if gated else None
+    img, cs = ops.split_hl_colsum(x, gate_hl)
+    xg = x * (torch.relu(act).to(torch.bfloat16) > 0) if gated else x
+    assert torch.equal(img, ops.split_hl_rows(xg.contiguous()))
+    assert torch.allclose(cs.double().cpu(), xg.double().sum(0).cpu(), rtol=1e-5, atol=1e-3)
+    wide = torch.zeros(m, 4 * k, dtype=torch.bfloat16, device=DEV)
+    ops.split_hl_colsum(x, out=wide, col=0, want_colsum=False)
+    ops.split_hl_colsum(xg.contiguous(), out=wide, col=k, want_colsum=False)
+    assert torch.equal(wide[:, :2 * k], ops.split_hl_rows(x)) and torch.equal(wide[:, 2 * k:], ops.split_hl_rows(xg.contiguous()))

@@ -278,7 +278,8 @@ def test_fused_bf16_layer0_training_matches_generic_and_fp32(n, d, h, lam, monke
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,d,h,lam,share", [(700, 256, 4, 50, 0.0), (3000, 384, 6, 200, 0.0), (2048, 768, 6, 200, 0.0), (4100, 384, 4, 300, 0.5)])
+@pytest.mark.parametrize("n,d,h,lam,share", [(700, 256, 4, 50, 0.0), (3000, 384, 6, 200, 0.0), (2048, 768, 6, 200, 0.0), (4100, 384, 4, 300, 0.5),
+                                             (16384, 768, 6, 200, 0.0)])
 def test_fused_x3_layer0_training_matches_the_generic_fp32_chain(n, d, h, lam, share, monkeypatch):
     """EncoderLayer0X3Fn (round 5: hand-ordered forward / backward of the first layer in fp32-class arithmetic) against the generic
     autograd chain of the same precision (LinearX3Fn + LayerNormRowsFn + SparseAttnFn): logits and every parameter gradient, eval
@@ -299,8 +300,16 @@ def test_fused_x3_layer0_training_matches_the_generic_fp32_chain(n, d, h, lam, s
     x = torch.randn(1, n, d, device=DEV)
     for train_mode in (False, True):
         grads, outs = {}, {}
-        for tag, fused, gemm in (("library", False, "library"), ("generic", False, "x3"), ("fused", True, "x3")):
+        # (16384, 768): the bag is large enough for the one-pass chain (hl images, gemm_hl, gemm_tn: round 6) -- "fused" is that chain
+        # there, "fused_cat" the concatenated-K chain of round 5 on the same bag
+        runs = [("library", False, "library", True), ("generic", False, "x3", True), ("fused", True, "x3", True)]
+        if n >= 16384:
+            monkeypatch.setattr(SA, "X3_TRAIN_HL", True)
+            assert SA._x3_train_hl_ok(n, d, 4 * d)
+            runs.append(("fused_cat", True, "x3", False))
+        for tag, fused, gemm, hl_chain in runs:
             monkeypatch.setattr(SA, "FUSED_X3_TRAINING", fused)
+            monkeypatch.setattr(SA, "X3_TRAIN_HL", hl_chain)
             monkeypatch.setattr(SF, "FP32_GEMM", gemm)
             net = build_amd_milnet(d, h, "relu", lam, share, 1)
             net.load_state_dict(sd, strict=True)
@@ -319,7 +328,10 @@ def test_fused_x3_layer0_training_matches_the_generic_fp32_chain(n, d, h, lam, s
         # either chain (measured: fused 2e-3 / generic 7e-6 at (2048, 768), fused 3e-6 / generic 5e-4 at (4100, 384)).
         gate_keys = ("feed_forward.w_1.weight", "feed_forward.w_1.bias", "sublayer.1.norm.weight", "sublayer.1.norm.bias")
         small_keys = ("linears.0.weight", "linears.0.bias", "linears.1.weight", "sublayer.0.norm.weight")
-        for other, bound_out, bound in (("library", 5e-5, 2e-4), ("generic", 5e-5, 5e-4 if train_mode else 2e-4)):
+        others = [("library", 5e-5, 2e-4), ("generic", 5e-5, 5e-4 if train_mode else 2e-4)]
+        if "fused_cat" in outs:
+            others.append(("fused_cat", 5e-5, 2e-4))
+        for other, bound_out, bound in others:
             assert (outs["fused"] - outs[other]).abs().max().item() <= bound_out * max(1.0, outs[other].abs().max().item())
             for k in grads["fused"]:
                 if k.endswith("self_attn.linears.1.bias"):
