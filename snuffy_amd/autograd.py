@@ -237,11 +237,8 @@ class LinearX3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # dyh^T xh + dyh^T xl + dyl^T xh over the bag axis: three fp32-output GEMMs on column blocks of the two images, in place
             # (one GEMM over [dyh | dyl]^T [xh | xl] also computes the dropped lo lo block: a quarter more work, measured 682 vs 3 x 170 us)
-            dyh, dyl = dimg[:, n_out:2 * n_out], dimg[:, 2 * n_out:]
-            xh, xl = img[:, k:2 * k], img[:, 2 * k:]
-            dw = _tn_mm_f32(dyh, xh)
-            dw += _tn_mm_f32(dyh, xl)
-            dw += _tn_mm_f32(dyl, xh)
+            # (round 6: snf_gemm_tn_f32 where the shape allows -- the three products out of each staged step of the two images)
+            dw = _tn3(dimg, img, n_out, k)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum(0)
         return dx, dw, db
