@@ -122,20 +122,27 @@ __device__ __forceinline__ void wait_vmcnt() {
 // EPI (round 6, the ViT block without LayerNorm / residual passes; GemmParams has the formulas): 0 = plain; 1 = the LayerNorm of the
 // consumer folded into the epilogue (A = raw rows, per-row (mean, rstd) and per-column weight sums); 2 = the residual stream updated
 // in place by the producer (accumulators start from x instead of 0; fp32 x, its bf16 copy and the rows' partial moments leave together).
-template <int NI, int ACT, int OUT, int EPI = 0>
+// MI = 16-row blocks per wave: 8 -> the 8 waves as 2 (rows) x 4 (columns), 128 rows x 16 NI columns each; 4 (with NI = 4: the 128-wide tile
+// again) -> 4 x 2 waves of 64 x 64.  A step of the 128 x 32 wave tile reads 8 + 2 KiB of fragments per wave (80 KiB per workgroup), the 64 x 64
+// one 4 + 4 KiB for the same 16 MFMAs: measured -4 % on config A's FFN output projection (85.6 -> 82.5 us), +1.6 % on its bag, level on the
+// ViT shapes -- the 128-wide K loop is not LDS-read bound either; like the 256-wide one it runs at the workgroup's LDS-DMA rate.
+template <int NI, int ACT, int OUT, int EPI = 0, int MI = 8>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
+    static_assert(MI == 8 || (MI == 4 && NI == 4 && EPI != 1), "gemm_bf16: wave tiles are 128 x 16 NI or 64 x 64");
+    constexpr int WC = MI == 8 ? 4 : 2;        // wave columns (wave rows: 8 / WC)
+    constexpr int RW = 16 * MI;                // rows per wave
     static_assert(EPI == 0 || (EPI == 1 ? (NI == 4 && OUT == 0) : ((NI == 4 || NI == 2) && OUT == 1 && ACT == SNF_ACT_NONE)),
                   "gemm_bf16: the LayerNorm-fold epilogue is 256-wide, the residual epilogue 256- or 128-wide");
-    constexpr int BN = 64 * NI;
+    constexpr int BN = WC * 16 * NI;
     constexpr int W_BYTES = BN * ROWB;
     constexpr int STEP_BYTES = A_BYTES + W_BYTES;
-    constexpr int WP = NI / 2;                 // W pieces (16 rows each) staged by one wave per step
+    constexpr int WP = BN / 128;               // W pieces (16 rows each) staged by one wave per step
     constexpr int GL = 2 + WP;                 // LDS-DMA instructions per wave and step
     constexpr int NC = 4 * NI;                 // output columns per lane
     constexpr bool OUT_F32 = OUT == 1;
     // store instructions per lane and 16-row block (EPI 2: fp32 x + its bf16 copy + one moment pair)
     constexpr int NST = EPI == 2 ? NC / 4 + NC / 8 + 1 : (OUT == 1 || OUT == 3) ? NC / 4 : OUT == 2 ? 3 * NC / 8 : NC / 8;
-    static_assert((AHEAD - 1) * (2 + NI / 2) + 8 * NST <= 63, "gemm_bf16: counted waits are 6-bit");
+    static_assert((AHEAD - 1) * GL + MI * NST <= 63, "gemm_bf16: counted waits are 6-bit");
     // bf16 rows leave as full 128-byte lines (epilogue; 4 KiB of LDS per wave) -- where the epilogue is not already bound by its own
     // arithmetic: behind the erf GELU the LDS round trip measured +3 % (ViT fc1 219 -> 226 us), behind none / ReLU -3 ... -5 %
     // (ViT qkv 144 -> 137.5 us, config-B FFN-in 193.6 -> 183.1 us; profiles/r06_gemm_line_stores.txt)
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wid >> 2, wc = wid & 3;
+    const int wr = WC == 4 ? wid >> 2 : wid >> 1, wc = wid & (WC - 1);
     const int ns = P.k / BKS;                  // steps per tile (>= 2)
     unsigned char* const scr = smem + NBUF * STEP_BYTES + wid * 4096;   // LINE_STORES: this wave's two 2-KiB transpose buffers
 
@@ -202,11 +209,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
     // ---- fragment read offsets (bytes inside a step buffer)
     const int fi = lane & 15, fg = lane >> 4;
     const int fsw = (fg ^ ((-(fi >> 2)) & 3)) << 4;                           // same swizzle term for both operands
-    const int xoff = (128 * wr + fi) * ROWB + fsw;                            // + mi * 1024
+    const int xoff = (RW * wr + fi) * ROWB + fsw;                            // + mi * 1024
     const int woff = A_BYTES + ((NI == 4 ? 64 : 32) * wc + 8 * (fi >> 2) + (fi & 3)) * ROWB + fsw;   // + (4 (ni & 1) + 32 (ni >> 1)) * 64
 
-    f32x4 acc[8][NI];
-    bf16x8 xf[8], wf[NI];
+    f32x4 acc[MI][NI];
+    bf16x8 xf[MI], wf[NI];
     f32x4 bv4[NC / 4];   // bias of this lane's columns (hand-counted asm loads in the last step of a tile)
 #pragma unroll
     for (int c4 = 0; c4 < NC / 4; ++c4) bv4[c4] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -233,13 +240,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
         for (int ni = 0; ni < NI; ++ni)
             wf[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + woff + (4 * (ni & 1) + 32 * (ni >> 1)) * ROWB));
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) xf[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + xoff + mi * 1024));
+        for (int mi = 0; mi < MI; ++mi) xf[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + xoff + mi * 1024));
     };
     auto mma = [&](auto first_t) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_t)::value;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
 #ifdef SNF_GEMM_NOMFMA   // timing ablation: operands kept alive, no matrix work
@@ -282,10 +289,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
         if constexpr (EPI == 2) {
             const int tm = tl / P.tiles_n, tn = tl - tm * P.tiles_n;
             const int n0 = tn * BN + (NI == 4 ? 64 : 32) * wc + 8 * fg;
-            const int row0 = tm * BM + 128 * wr + fi;
+            const int row0 = tm * BM + RW * wr + fi;
             const float* xb = reinterpret_cast<const float*>(P.c);
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
+            for (int mi = 0; mi < MI; ++mi) {
                 int row = row0 + 16 * mi;
                 if (row > P.m - 1) row = P.m - 1;
 #pragma unroll
@@ -304,12 +311,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
         constexpr bool FULL = decltype(full_t)::value;
         const int tm = tl / P.tiles_n, tn = tl - tm * P.tiles_n;
         const int n0 = tn * BN + (NI == 4 ? 64 : 32) * wc + 8 * fg;
-        const int row0 = tm * BM + 128 * wr + fi;
+        const int row0 = tm * BM + RW * wr + fi;
         f32x2 rst[EPI == 1 ? 8 : 1];          // EPI 1: (mean, rstd) of this lane's rows, weight column sums of its columns
         f32x4 cs4[EPI == 1 ? NC / 4 : 1];
         if constexpr (EPI == 1) {
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
+            for (int mi = 0; mi < MI; ++mi) {
                 int row = row0 + 16 * mi;
                 if (row > P.m - 1) row = P.m - 1;
                 rst[mi] = *reinterpret_cast<const f32x2*>(P.rowstats + 2 * (int64_t)row);
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
         asm volatile("" : "+v"(lane_o));
         const int fio = lane_o & 15, fgo = lane_o >> 4;
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
             const int row = row0 + 16 * mi;
             float s1[NI / 2], s2[NI / 2];       // EPI 2: moments of the new x over this lane's columns of the row, per 32-column group
             u32x4 pk2[EPI == 2 ? NI / 2 : 1];
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                 for (int jj = 0; jj < 2; ++jj) {
                     const int r = lr + 8 * jj;
                     const u32x4 val = *reinterpret_cast<const u32x4*>(scr + (mi & 1) * 2048 + r * 128 + ((lc ^ (r & 7)) << 4));
-                    const int orow = tm * BM + 128 * wr + 16 * mi + r, ocol = tn * BN + 64 * wc + 8 * lc;
+                    const int orow = tm * BM + RW * wr + 16 * mi + r, ocol = tn * BN + 64 * wc + 8 * lc;
 #ifdef SNF_GEMM_NOSTORE
                     const bool ok2 = P.k < 0 && orow < P.m && ocol + 8 <= P.n;
 #else
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                     for (int jj = 0; jj < 4; ++jj) {
                         const int r = lr + 4 * jj;
                         const u32x4 val = *reinterpret_cast<const u32x4*>(scr + r * 256 + ((lc ^ r) << 4));
-                        const int orow = tm * BM + 128 * wr + 16 * mi + r, ocol = tn * BN + 64 * wc + 4 * lc;
+                        const int orow = tm * BM + RW * wr + 16 * mi + r, ocol = tn * BN + 64 * wc + 4 * lc;
                         if (FULL || (orow < P.m && ocol + 4 <= P.n))
                             *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(P.c) + (int64_t)orow * P.ldc + ocol) = val;
                     }
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                     for (int jj = 0; jj < 2; ++jj) {
                         const int r = br + 8 * jj;
                         const u32x4 val = *reinterpret_cast<const u32x4*>(scr + r * 128 + ((bc ^ (r & 7)) << 4));
-                        const int orow = tm * BM + 128 * wr + 16 * mi + r, ocol = tn * BN + 64 * wc + 8 * bc;
+                        const int orow = tm * BM + RW * wr + 16 * mi + r, ocol = tn * BN + 64 * wc + 8 * bc;
                         if (FULL || (orow < P.m && ocol + 8 <= P.n)) *reinterpret_cast<u32x4*>(P.c2 + (int64_t)orow * P.ldc2 + ocol) = val;
                     }
                 } else {
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                     for (int jj = 0; jj < 2; ++jj) {
                         const int r = lr + 8 * jj;
                         const u32x4 val = *reinterpret_cast<const u32x4*>(scr + r * 128 + ((lc ^ (r & 7)) << 4));
-                        const int orow = tm * BM + 128 * wr + 16 * mi + r, ocol = tn * BN + 32 * wc + 4 * lc;
+                        const int orow = tm * BM + RW * wr + 16 * mi + r, ocol = tn * BN + 32 * wc + 4 * lc;
                         if (FULL || (orow < P.m && ocol + 4 <= P.n))
                             *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(P.c) + (int64_t)orow * P.ldc + ocol) = val;
                     }
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                 }
                 // (in a FULL tile every wave issues this store -- its 16 lanes g = 0 -- which the counted wait behind the epilogue relies on)
                 if constexpr (NI == 4) {
-                    const int g = 2 * (4 * tn + wc);
+                    const int g = 2 * (WC * tn + wc);
                     if (fg == 0 && (FULL || (g < P.slots && row < P.m)))
                         *reinterpret_cast<f32x4*>(P.stats_part + 2 * ((int64_t)row * P.slots + g)) = f32x4{s1[0], s2[0], s1[1], s2[1]};
                 } else {
@@ -498,7 +505,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
     wait_vmcnt<(AHEAD - 1) * GL>();   // step 0 has landed, the others stay in flight
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (wr == 1) __builtin_amdgcn_s_barrier();   // the second wave group runs one barrier behind the first
+    if (wid >= 4) __builtin_amdgcn_s_barrier();   // the second wave group (waves 4 .. 7) runs one barrier behind the first
 
     int rb = 0, sb = AHEAD;        // ring slots of the step being read and of the step being staged (global step mod NBUF)
     bool after_epilogue = false;   // stores of the previous tile may still be in flight (they count in vmcnt)
@@ -524,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
                 stage(nxt, s + AHEAD - ns, sb);
             if (exist == AHEAD) {
                 if (after_epilogue)
-                    wait_vmcnt<(AHEAD - 1) * GL + 8 * NST>();
+                    wait_vmcnt<(AHEAD - 1) * GL + MI * NST>();
                 else
                     wait_vmcnt<(AHEAD - 1) * GL>();
             } else if (AHEAD == 3 && exist == 2) {
@@ -559,7 +566,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
         tile = next;
         cur = nxt;
     }
-    if (wr == 0) __builtin_amdgcn_s_barrier();   // barrier counts of the two wave groups match again
+    if (wid < 4) __builtin_amdgcn_s_barrier();   // barrier counts of the two wave groups match again
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1004,14 +1011,14 @@ int launch_hl_act(const GemmParams& P, hipStream_t s) {
     }
 }
 
-template <int NI, int ACT, int OUT, int EPI = 0>
+template <int NI, int ACT, int OUT, int EPI = 0, int MI = 8>
 int launch(const GemmParams& P, hipStream_t s) {
-    constexpr int lds = NBUF * (A_BYTES + 64 * NI * ROWB) +
+    constexpr int lds = NBUF * (A_BYTES + (MI == 8 ? 64 : 32) * NI * ROWB) +
                         ((EPI == 2 || (OUT == 0 && NI == 4 && ACT != SNF_ACT_GELU && ACT != SNF_ACT_SELU)) ? 8 * 4096 : 0);
     static thread_local unsigned long long attr_set_mask = 0;   // devices (bit = device id) that have the opt-in
     const unsigned long long attr_set_bit = snf::device_bit();
     const bool attr_set = (attr_set_mask & attr_set_bit) != 0;
-    auto kern = gemm_bf16_kernel<NI, ACT, OUT, EPI>;
+    auto kern = gemm_bf16_kernel<NI, ACT, OUT, EPI, MI>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
             hipSuccess) {
@@ -1030,14 +1037,26 @@ int launch(const GemmParams& P, hipStream_t s) {
     return snf::check_launch("gemm_bf16_kernel");
 }
 
+#ifndef SNF_GEMM_128_MI4
+#define SNF_GEMM_128_MI4 1   // 128-wide tiles: 1 = 4 x 2 waves of 64 x 64 (round 6), 0 = 2 x 4 waves of 128 x 32 (dev builds, A / B)
+#endif
+// NI == 2 names the 128-wide tile at the call sites; the instantiation behind it is the 64 x 64 wave layout
+template <int NI, int ACT, int OUT, int EPI = 0>
+int launch_tile(const GemmParams& P, hipStream_t s) {
+    if constexpr (NI == 2 && SNF_GEMM_128_MI4)
+        return launch<4, ACT, OUT, EPI, 4>(P, s);
+    else
+        return launch<NI, ACT, OUT, EPI>(P, s);
+}
+
 template <int NI, int OUT>
 int launch_act(const GemmParams& P, hipStream_t s) {
     switch (P.act) {
-        case SNF_ACT_RELU: return launch<NI, SNF_ACT_RELU, OUT>(P, s);
-        case SNF_ACT_GELU: return launch<NI, SNF_ACT_GELU, OUT>(P, s);
-        case SNF_ACT_LEAKYRELU: return launch<NI, SNF_ACT_LEAKYRELU, OUT>(P, s);
-        case SNF_ACT_SELU: return launch<NI, SNF_ACT_SELU, OUT>(P, s);
-        default: return launch<NI, SNF_ACT_NONE, OUT>(P, s);
+        case SNF_ACT_RELU: return launch_tile<NI, SNF_ACT_RELU, OUT>(P, s);
+        case SNF_ACT_GELU: return launch_tile<NI, SNF_ACT_GELU, OUT>(P, s);
+        case SNF_ACT_LEAKYRELU: return launch_tile<NI, SNF_ACT_LEAKYRELU, OUT>(P, s);
+        case SNF_ACT_SELU: return launch_tile<NI, SNF_ACT_SELU, OUT>(P, s);
+        default: return launch_tile<NI, SNF_ACT_NONE, OUT>(P, s);
     }
 }
 
@@ -1358,7 +1377,7 @@ extern "C" int snf_gemm_bf16_resid(const void* a, int64_t lda, const void* w, in
     const int rem = n % 256;
     if (rem >= 1 && rem <= 128) {
         P.tiles_n = (n + 127) / 128;
-        return launch<2, SNF_ACT_NONE, 1, 2>(P, snf::as_stream(stream));
+        return launch_tile<2, SNF_ACT_NONE, 1, 2>(P, snf::as_stream(stream));
     }
     return launch<4, SNF_ACT_NONE, 1, 2>(P, snf::as_stream(stream));
 }
