@@ -41,6 +41,10 @@ for k in 128 200 256; do $T python tools/x3p_dev.py 32768 $k 6 --time 2>&1 | gre
 $T python tools/x3p_dev.py 100000 512 6 --time 2>&1 | grep "x3" >> $O/attn_x3p_timing.txt
 for sh in "8192 200 6 64" "32768 200 6 64" "100000 200 6 64" "1000 200 6 64"; do $T python tools/x3p_dev.py $sh --time 2>&1 | grep "x3"; done >> $O/attn_x3p_timing.txt
 for n in f32 bf16 train_bf16 train_f32 vit_bf16 vit_f32 varlen_1k_bf16 varlen_8k_f32 cfgA_f32 cfgC_f32 readme_mae_f32 readme_scratch_f32; do cp gpurun_out/prof_${R}_$n/p_kernel_stats.csv $O/${n}_kernel_stats.csv 2>/dev/null; done
+$T python tools/tn_chunks_bench.py > $O/gemm_tn.txt 2>&1
+$T python tools/train_cpu_time.py fp32 >> $O/gemm_tn.txt 2>&1
+$T python tools/train_cpu_time.py bf16 >> $O/gemm_tn.txt 2>&1
+$T python tools/gemm_hl_l2_probe.py > $O/gemm_hl_l2_probe.txt 2>&1
 timeout 1500 python tools/sweep.py > $O/sweep.md 2> $O/sweep.err
 python -m pytest tests/test_gpu_vit.py tests/test_gpu_model.py -q -m gpu -s 2>&1 | grep MEASURED > $O/measured_errors.txt
 tail -4 $O/traffic.txt; head -c 600 $O/bench_cfgB.json
