@@ -427,6 +427,11 @@ int snf_gemm_hl_resid_bf16(const void* a_hl, int64_t lda, const void* w_hl, int6
  * zeroes its own tickets, nothing is expected in the buffer before a call or kept in it after one, so concurrent calls on different
  * streams only need different buffers.  NULL workspace = snf_gemm_hl_resid_bf16. */
 size_t snf_gemm_hl_ws_bytes(int64_t m, int n, int k);
+/* The FFN input gradient of the training step behind its ReLU (backward of snuffy.py:224-225: dhid = (dz W2) o [hid > 0]) in ONE pass:
+ * c_hl [m, 2 n] = the hl image of (a w^T) with every element zeroed whose gate value -- the hi half of gate_hl [m, 2 n], the activation's own
+ * hl image -- is not > 0.  Domain of snf_gemm_hl_bf16 with an hl output (n % 32 == 0). */
+int snf_gemm_hl_gated_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ldw, const void* gate_hl, int64_t ldg, int64_t m, int n,
+                           int k, void* c_hl, int64_t ldc, snf_stream_t stream);
 /* The weight-gradient contraction of the training step (round 6; the autograd of nn.Linear under train.py:259,468-473: dW = dY^T X):
  *   c [p, ldc] f32 = A^T B over the n rows of two row-major bf16 images, on the matrix cores straight from those images (transposing
  *   LDS reads; no transposed copy).  A's operand is the p columns starting at column a_hi of a [n, lda], B's the q columns at b_hi of

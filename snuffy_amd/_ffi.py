@@ -135,6 +135,8 @@ SIGNATURES = {
     "snf_gemm_hl_resid_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                                        c_void_p, c_int64, c_int, c_void_p]),
     "snf_gemm_hl_ws_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "snf_gemm_hl_gated_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64,
+                                       c_void_p]),
     "snf_gemm_tn_ws_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "snf_gemm_tn_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p,
                                 c_int64, c_void_p, c_size_t, c_void_p]),

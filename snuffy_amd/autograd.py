@@ -26,6 +26,8 @@ FUSED_X3_TRAINING = True
 # ... on the one-pass kernels (round 6): activations and gradients as interleaved hl images (4 bytes per element instead of the 6 of
 # [hi | hi | lo]), projections on gemm_hl, weight gradients on gemm_tn(hl=True); False: the concatenated-K chain of round 5
 X3_TRAIN_HL = True
+# ... and, in that chain, the ReLU mask of the FFN input gradient in the GEMM's epilogue (snf_gemm_hl_gated_bf16); False: gemm_hl + split pass
+X3_TRAIN_GATED_GEMM = True
 
 _ACT = {
     "relu": F.relu,
@@ -546,12 +548,24 @@ class EncoderLayer0X3Fn(torch.autograd.Function):
         if hl:
             dz3, db2 = ops.split_hl_colsum(dz)                                         # operand image + bias gradient, one pass
             dw2 = ops.gemm_tn(dz3, hid3, d, f, hl=True)                                # [D, F]
-            dhid = ops.gemm_hl(dz3, fw["w2t_hl"])                                      # [N, F] f32, not yet gated
-            del dz3
-            dhid3, db1f = ops.split_hl_colsum(dhid, gate_hl=hid3)                      # ReLU mask from the hi values of the output image
-            dw1f = ops.gemm_tn(dhid3, xn3, f, d, hl=True)                              # [F, D], gradient of the FOLDED weight
-            del dhid3
-            gate_s = hid3.index_select(0, sel).view(sel.numel(), f // 32, 2, 32)[:, :, 0].reshape(sel.numel(), f)
+            if X3_TRAIN_GATED_GEMM and 2 * f <= 8192:
+                # the ReLU mask (hi values of the output image) in the GEMM's epilogue, which writes the gated gradient as its hl image: no
+                # fp32 dhid, no split pass; the bias gradient is one column-sum pass over the image, the K rows come back out of it
+                dhid3 = ops.gemm_hl_gated(dz3, fw["w2t_hl"], hid3)
+                del dz3
+                db1f = ops.hl_colsum(dhid3)
+                dw1f = ops.gemm_tn(dhid3, xn3, f, d, hl=True)                          # [F, D], gradient of the FOLDED weight
+                dhid_s, gate_s = _hl_planes_sum(dhid3.index_select(0, sel)), None
+                del dhid3
+            else:
+                dhid = ops.gemm_hl(dz3, fw["w2t_hl"])                                  # [N, F] f32, not yet gated
+                del dz3
+                dhid3, db1f = ops.split_hl_colsum(dhid, gate_hl=hid3)
+                dw1f = ops.gemm_tn(dhid3, xn3, f, d, hl=True)
+                del dhid3
+                dhid_s = dhid.index_select(0, sel)
+                gate_s = hid3.index_select(0, sel).view(sel.numel(), f // 32, 2, 32)[:, :, 0].reshape(sel.numel(), f)
+                del dhid
         else:
             dz3, db2 = ops.split3_colsum(dz)
             dw2 = _tn3(dz3, hid3, d, f)
@@ -561,10 +575,10 @@ class EncoderLayer0X3Fn(torch.autograd.Function):
             dhid3, db1f = ops.split3_colsum(dhid, gate=gate)
             dw1f = _tn3(dhid3, xn3, f, d)
             del dhid3
-            gate_s = gate.index_select(0, sel)
+            dhid_s, gate_s = dhid.index_select(0, sel), gate.index_select(0, sel)
+            del dhid
         # ---- the K selected rows: y[S] = x_sel = xs + o Wo^T + bo; every other row of y is data               (snuffy.py:108,152-155)
-        dyn_s = (dhid.index_select(0, sel) * (gate_s > 0)) @ fw["w1f"]                 # d loss / d xhat1[S]
-        del dhid
+        dyn_s = (dhid_s if gate_s is None else dhid_s * (gate_s > 0)) @ fw["w1f"]     # d loss / d xhat1[S]
         dy_s = ops.layernorm_rows_bwd(x_sel, dyn_s, None, eps, residual=dz.index_select(0, sel), want_param_grads=False)[0]
         dbo = dy_s.sum(0)
         dwo = dy_s.t() @ o

@@ -60,6 +60,12 @@ struct GemmParams {
     unsigned int* split_cnt = nullptr;
     float* split_slab = nullptr;
     int split_cap = 0, split_rcap = 0;
+    // gemm_hl_kernel<NONE, 3, false, GATE = true> (the FFN input gradient of the training step, dhid = dz W2 behind the ReLU): elements whose
+    // gate value (the hi half of the activation's own hl image, same position) is not > 0 leave as 0.  (Column sums in the same epilogue were
+    // built and dropped: 16 more live registers there made hipcc spill 147 values around the store burst -- scratch traffic through the very
+    // vector-memory pipeline the epilogue is bound by; the bias gradient is one pass of colsum_fused over the image instead.)
+    const unsigned short* gate = nullptr;
+    int64_t ldg = 0;
     // gemm_bf16_kernel, EPI = 1 (LayerNorm folded into the consumer, round 6): A holds the RAW rows x (bf16), W = W0 diag(gamma);
     //   C = act(rstd[m] (A W^T - mean[m] colsum[n]) + bias[n]),  colsum[n] = sum_k W[n, k] (of the rounded W), bias = W0 beta + b0
     const float* colsum = nullptr;   // [N]
@@ -583,8 +589,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams P) {
 // Register budget: the A-lo fragments are read into the A-hi registers while the second product (hi lo) is still issuing.
 // OUT: 0 bf16, 1 fp32, 3 the hl image of the fp32 result (operand of the next one-pass GEMM).
 // SPLIT (second launch of snf_gemm_hl_ws_bf16): the tiles of the last, partly filled round, one K part per workgroup (see GemmParams).
-template <int ACT, int OUT, bool SPLIT = false>
+template <int ACT, int OUT, bool SPLIT = false, bool GATE = false>
 __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
+    static_assert(!GATE || (OUT == 3 && ACT == SNF_ACT_NONE && !SPLIT), "gemm_hl: the gated form writes an hl image, no activation, no split");
     constexpr int NI = 4, BN = 256;
     constexpr int ROWL = 128;                    // LDS row: hi(32) | lo(32) bf16
     constexpr int IMG = BM * ROWL;               // one operand's step image: 32 KiB
@@ -762,6 +769,15 @@ __global__ __launch_bounds__(512, 2) void gemm_hl_kernel(GemmParams P) {
 #else
                 const bool ok = FULL || (row < P.m && col + 8 <= P.n);
 #endif
+                if constexpr (GATE) {
+                    u32x4 gv = {0u, 0u, 0u, 0u};
+                    if (ok) gv = *reinterpret_cast<const u32x4*>(P.gate + (int64_t)row * P.ldg + 64 * (col >> 5) + (col & 31));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (!(__uint_as_float(gv[e] << 16) > 0.f)) v[2 * e] = 0.f;
+                        if (!(__uint_as_float(gv[e] & 0xffff0000u) > 0.f)) v[2 * e + 1] = 0.f;
+                    }
+                }
                 if constexpr (OUT == 1) {
                     float* dst = reinterpret_cast<float*>(P.c) + (int64_t)row * P.ldc + col;
                     if (P.resid && ok) {   // residual added after the activation: z = x + W2 act(...) in one pass over z
@@ -998,6 +1014,28 @@ int launch_hl(const GemmParams& P, hipStream_t s) {
     }
     hipLaunchKernelGGL(kern2, dim3(grid), dim3(512), lds, s, P);
     return snf::check_launch("gemm_hl_kernel<split>");
+}
+
+int launch_hl_gated(const GemmParams& P, hipStream_t s) {
+    constexpr int lds = 2 * 2 * BM * 128 + 8 * 4096;
+    static thread_local unsigned long long attr_set_mask = 0;   // devices (bit = device id) that have the opt-in
+    const unsigned long long bit = snf::device_bit();
+    auto kern = gemm_hl_kernel<SNF_ACT_NONE, 3, false, true>;
+    if (!(attr_set_mask & bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            snf::set_error("gemm_hl: cannot reserve %d bytes of LDS", lds);
+            (void)hipGetLastError();
+            return SNF_ELAUNCH;
+        }
+        attr_set_mask |= bit;
+    }
+    const int ntiles = P.tiles_m * P.tiles_n;
+    int grid = snf::cu_count() & ~7;
+    if (grid < 8) grid = 8;
+    const int per_xcd = (ntiles + 7) / 8;
+    if (per_xcd * 8 < grid) grid = per_xcd * 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, P);
+    return snf::check_launch("gemm_hl_kernel<gated>");
 }
 
 template <int OUT>
@@ -1487,6 +1525,34 @@ extern "C" int snf_gemm_hl_ws_bf16(const void* a_hl, int64_t lda, const void* w_
     hipStream_t s = snf::as_stream(stream);
     if (hl_out) return launch_hl_act<3>(P, s);
     return out_dtype == SNF_DT_F32 ? launch_hl_act<1>(P, s) : launch_hl_act<0>(P, s);
+}
+
+extern "C" int snf_gemm_hl_gated_bf16(const void* a_hl, int64_t lda, const void* w_hl, int64_t ldw, const void* gate_hl, int64_t ldg, int64_t m,
+                                      int n, int k, void* c_hl, int64_t ldc, snf_stream_t stream) {
+    SNF_REQUIRE(a_hl && w_hl && gate_hl && c_hl, "snf_gemm_hl_gated_bf16: null pointer");
+    SNF_REQUIRE(m >= 1 && n >= 1 && k >= 1, "snf_gemm_hl_gated_bf16: bad shape m=%lld n=%d k=%d", (long long)m, n, k);
+    if (k % BKS || k < BKS || n % 32 || lda % 8 || ldw % 8 || ldc % 8 || ldg % 8 || lda < 2 * (int64_t)k || ldw < 2 * (int64_t)k ||
+        ldc < 2 * (int64_t)n || ldg < 2 * (int64_t)n ||
+        (reinterpret_cast<uintptr_t>(a_hl) | reinterpret_cast<uintptr_t>(w_hl) | reinterpret_cast<uintptr_t>(c_hl) |
+         reinterpret_cast<uintptr_t>(gate_hl)) % 16 ||
+        m * lda >= 0x7fffffffll || (int64_t)n * ldw >= 0x7fffffffll) {
+        snf::set_error("snf_gemm_hl_gated_bf16: shape m=%lld n=%d k=%d (lda %lld ldw %lld ldc %lld ldg %lld) outside the kernel's domain "
+                       "(k %% 32, n %% 32, images of 2 k / 2 n columns, 16-byte aligned rows, 31-bit element offsets)",
+                       (long long)m, n, k, (long long)lda, (long long)ldw, (long long)ldc, (long long)ldg);
+        return SNF_EUNSUPPORTED;
+    }
+    GemmParams P;
+    P.a = reinterpret_cast<const unsigned short*>(a_hl);
+    P.w = reinterpret_cast<const unsigned short*>(w_hl);
+    P.bias = nullptr;
+    P.c = c_hl;
+    P.lda = lda, P.ldw = ldw, P.ldc = ldc;
+    P.m = (int)m, P.n = n, P.k = k, P.act = SNF_ACT_NONE;
+    P.tiles_m = (int)((m + BM - 1) / BM);
+    P.tiles_n = (n + 255) / 256;
+    P.trace = nullptr;
+    P.gate = reinterpret_cast<const unsigned short*>(gate_hl), P.ldg = ldg;
+    return launch_hl_gated(P, snf::as_stream(stream));
 }
 
 // out [r, c] (f32 or bf16, row pitch ldo) = x [r, k] (f32, row pitch ldx) w [c, k]^T (f32, row pitch ldw) + bias [c] (nullable), fp32-class

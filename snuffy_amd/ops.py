@@ -1441,6 +1441,28 @@ def gemm_hl(a_hl, w_hl, bias=None, act="none", out_dtype=torch.float32, out=None
     return out
 
 
+def gemm_hl_gated(a_hl, w_hl, gate_hl):
+    """The hl image [m, 2 n] of (A W^T) o [gate > 0] in one pass (snf_gemm_hl_gated_bf16): the FFN input gradient behind its ReLU; gate_hl
+    [m, 2 n] = the activation's own hl image (its hi values decide)."""
+    a_hl, w_hl, gate_hl = _rows16(a_hl, "a_hl"), _rows16(w_hl, "w_hl"), _rows16(gate_hl, "gate_hl")
+    if a_hl.dtype != torch.bfloat16 or w_hl.dtype != torch.bfloat16 or gate_hl.dtype != torch.bfloat16:
+        raise TypeError("gemm_hl_gated: operands must be bfloat16 hl images")
+    m, k2 = a_hl.shape
+    n = w_hl.shape[0]
+    if w_hl.shape[1] != k2 or k2 % 64 or n % 32 or tuple(gate_hl.shape) != (m, 2 * n):
+        raise ValueError("gemm_hl_gated: inconsistent shapes")
+    out = torch.empty(m, 2 * n, dtype=torch.bfloat16, device=a_hl.device)
+    check(_ffi.load().snf_gemm_hl_gated_bf16(_p(a_hl), a_hl.stride(0), _p(w_hl), w_hl.stride(0), _p(gate_hl), gate_hl.stride(0), m, n,
+                                             k2 // 2, _p(out), out.stride(0), _stream()), "snf_gemm_hl_gated_bf16")
+    return out
+
+
+def hl_colsum(img):
+    """Column sums [k] f32 of the matrix whose hl image is img [m, 2 k] (k <= 4096): one colsum_fused pass over the image, hi + lo per column."""
+    s, _ = colsum_fused(img)
+    return s.view(-1, 2, 32).sum(1).reshape(-1)
+
+
 GEMM_HL_SPLITK = True   # split-K of the last, partly filled round of tiles (snf_gemm_hl_ws_bf16); False: plain tile walk
 
 

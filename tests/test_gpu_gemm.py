@@ -521,3 +521,23 @@ def test_split_hl_colsum(m, k, gated):
     ops.split_hl_colsum(x, out=wide, col=0, want_colsum=False)
     ops.split_hl_colsum(xg.contiguous(), out=wide, col=k, want_colsum=False)
     assert torch.equal(wide[:, :2 * k], ops.split_hl_rows(x)) and torch.equal(wide[:, 2 * k:], ops.split_hl_rows(xg.contiguous()))
+
+
+@pytest.mark.parametrize("m,n,k", [(32768, 3072, 768), (5000, 544, 256), (700, 1024, 96)])
+def test_gemm_hl_gated_epilogue(m, n, k):
+    """snf_gemm_hl_gated_bf16 == the hl image of gemm_hl's result with the elements behind a closed gate zeroed (the gate: hi values of the
+    activation's own hl image), bit for bit; hl_colsum of it == the column sums."""
+    from snuffy_amd import ops
+    g = torch.Generator().manual_seed(m + n + k)
+    a = (torch.randn(m, k, generator=g) * 0.5).to(DEV)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(DEV)
+    act = torch.relu(torch.randn(m, n, generator=g)).to(DEV)
+    a_hl, w_hl, gate_hl = ops.split_hl_rows(a), ops.split_hl_weight(w), ops.split_hl_rows(act)
+    out = ops.gemm_hl_gated(a_hl, w_hl, gate_hl)
+    plain = ops.gemm_hl(a_hl, w_hl)
+    ref = plain * (act.to(torch.bfloat16) > 0)
+    assert torch.equal(out, ops.split_hl_rows(ref.contiguous()))
+    assert torch.equal(out, ops.gemm_hl_gated(a_hl, w_hl, gate_hl))
+    if 2 * n <= 8192:
+        cs = ops.hl_colsum(out)
+        assert torch.allclose(cs.double().cpu(), ref.double().sum(0).cpu(), rtol=1e-4, atol=1e-2 * max(1.0, ref.abs().max().item()))
