@@ -167,6 +167,17 @@ int snf_unfold_linear_f32(const float* dwf, const float* w, int r, int c, const 
 int snf_split3_f32(const float* x, int64_t ldx, int64_t m, int k, void* out_bf16, snf_stream_t stream);
 /* w [m, k] f32 (row pitch ldw; the nn.Linear layout) -> out [m, 3 k] bf16 = [Wh | Wl | Wh], the weight operand of the same products;
  * colscale [k] (nullable): W' = W diag(colscale) formed in fp32 first (a LayerNorm gamma folded into the projection that follows it). */
+/* The loss head of a training step in one launch each way (reference train.py: _run_model of the single-weight trainer -- max over the instance
+ * scores, two BCEWithLogits terms (optional pos_weight) mixed by the weight w, the bag prediction):
+ *   ins [n, c] f32 contiguous, logits [c], label [c], w [1], pos_weight [c] and weight [c] of BCEWithLogitsLoss (nullable; the reference passes
+ *   its class weights POSITIONALLY, i.e. as `weight`: train.py:246), c <= 8
+ *   out [2 + 4 c] = {loss, d loss / d w, bag_pred [c], d loss / d logits [c], d loss / d max [c], max [c]};  argmax [c] (first index on ties)
+ *   _bwd: d_ins [n, c] = grad_out * (d loss / d max) at the argmax rows, 0 elsewhere; d_small [c + 1] = grad_out * {d loss / d logits, d loss / d w}.
+ * A NaN instance score never wins the max (torch.max would return it): documented in DESIGN.md section 7. */
+int snf_mil_loss_f32(const float* ins, int64_t n, int c, const float* logits, const float* label, const float* w, const float* pos_weight,
+                     const float* weight, float* out, int64_t* argmax, snf_stream_t stream);
+int snf_mil_loss_bwd_f32(const float* grad_out, const float* fwd_out, const int64_t* argmax, int64_t n, int c, float* d_ins, float* d_small,
+                         snf_stream_t stream);
 int snf_split3_weight_f32(const float* w, int64_t ldw, int64_t m, int k, const float* colscale, void* out_bf16, snf_stream_t stream);
 /* Column sums of a [n, d] matrix fused with the elementwise step of the same pass (training: bias gradients next to the ReLU
  * mask / the bf16 cast / the critic's weight gradient; backward of snuffy.py:39-41, 224-225):

@@ -58,6 +58,8 @@ SIGNATURES = {
     "snf_unfold_linear_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
     "snf_split3_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "snf_mil_loss_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "snf_mil_loss_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "snf_split3_weight_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "snf_split3_colsum_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "snf_colsum_blocks": (c_int, [c_int64]),

@@ -1222,6 +1222,93 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(snf::DropoutState st,
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------
+// The loss head of a training step (reference train.py: SmallWeightTrainer._run_model -- max over the instance scores, two
+// BCEWithLogits terms mixed by the single weight w, the bag prediction) as ONE launch forward and ONE backward instead of ~30
+// scalar-sized ones:
+//   m_c = max_n ins[n, c] (first index on ties)          bce(x, y) = weight_c ((1 - y) x + (1 + (pw_c - 1) y) (log1p(exp(-|x|)) + max(-x, 0)))
+//   loss = w mean_c bce(logit_c, y_c) + (1 - w) mean_c bce(m_c, y_c)          bag_pred_c = (1 - w) sigmoid(m_c) + w sigmoid(logit_c)
+// out = [loss, g_w, bag_pred[C], g_logit[C], g_max[C], m[C]] with g_* the gradients of loss (what the backward scales by grad_out).
+// One workgroup: the scores are N x C floats (128 KiB at config B).  C <= 8.
+constexpr int MIL_MAXC = 8;
+__global__ __launch_bounds__(1024) void mil_loss_kernel(const float* __restrict__ ins, int64_t n, int c, const float* __restrict__ logits,
+                                                        const float* __restrict__ label, const float* __restrict__ w,
+                                                        const float* __restrict__ pos_weight, const float* __restrict__ weight,
+                                                        float* __restrict__ out, int64_t* __restrict__ argmax) {
+    __shared__ float s_val[MIL_MAXC][16];
+    __shared__ long long s_idx[MIL_MAXC][16];
+    float best[MIL_MAXC];
+    long long bidx[MIL_MAXC];
+#pragma unroll
+    for (int j = 0; j < MIL_MAXC; ++j) best[j] = -INFINITY, bidx[j] = 0x7fffffffffffffffll;
+    for (int64_t row = threadIdx.x; row < n; row += 1024) {
+#pragma unroll
+        for (int j = 0; j < MIL_MAXC; ++j)
+            if (j < c) {
+                const float v = ins[row * c + j];
+                if (v > best[j] || (v == best[j] && row < bidx[j])) best[j] = v, bidx[j] = row;   // (NaN scores never win: documented)
+            }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < MIL_MAXC; ++j) {
+        if (j >= c) continue;
+        float v = best[j];
+        long long ix = bidx[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(v, o, 64);
+            const long long oi = __shfl_xor(ix, o, 64);
+            if (ov > v || (ov == v && oi < ix)) v = ov, ix = oi;
+        }
+        if (lane == 0) s_val[j][wv] = v, s_idx[j][wv] = ix;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const float wt = w[0];
+    float lb = 0.f, lm = 0.f;
+    for (int j = 0; j < c; ++j) {
+        float v = s_val[j][0];
+        long long ix = s_idx[j][0];
+        for (int q = 1; q < 16; ++q)
+            if (s_val[j][q] > v || (s_val[j][q] == v && s_idx[j][q] < ix)) v = s_val[j][q], ix = s_idx[j][q];
+        if (n == 0) ix = 0;
+        argmax[j] = ix;
+        const float y = label[j], lw = 1.f + ((pos_weight ? pos_weight[j] : 1.f) - 1.f) * y, cw = weight ? weight[j] : 1.f;
+        const float xs[2] = {logits[j], v};
+        float l[2], g[2], sg[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float x = xs[t];
+            const float sp = log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.f);          // softplus(-x)
+            l[t] = cw * ((1.f - y) * x + lw * sp);
+            sg[t] = 1.f / (1.f + expf(-x));
+            g[t] = cw * ((1.f - y) - lw * (1.f - sg[t]));                         // d bce / d x
+        }
+        lb += l[0], lm += l[1];
+        out[2 + j] = (1.f - wt) * sg[1] + wt * sg[0];
+        out[2 + c + j] = wt * g[0] / (float)c;
+        out[2 + 2 * c + j] = (1.f - wt) * g[1] / (float)c;
+        out[2 + 3 * c + j] = v;
+    }
+    lb /= (float)c, lm /= (float)c;
+    out[0] = wt * lb + (1.f - wt) * lm;
+    out[1] = lb - lm;
+}
+
+// backward: d_ins = 0 but grad_out g_max[c] at (argmax[c], c); small = [grad_out g_logit[C], grad_out g_w]
+__global__ __launch_bounds__(256) void mil_loss_bwd_kernel(const float* __restrict__ grad_out, const float* __restrict__ fwd, const int64_t* __restrict__ argmax,
+                                                           int64_t n, int c, float* __restrict__ d_ins, float* __restrict__ small) {
+    const float go = grad_out[0];
+    const int64_t total = n * c;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / c;
+        const int j = (int)(i - row * c);
+        d_ins[i] = row == argmax[j] ? go * fwd[2 + 2 * c + j] : 0.f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x <= c) small[threadIdx.x] = go * (threadIdx.x < c ? fwd[2 + c + threadIdx.x] : fwd[1]);
+}
+
 extern "C" {
 
 int snf_critic_f32(const float* x, int64_t n, int d, const float* w, const float* b, int c_out, float* scores,
@@ -1778,6 +1865,24 @@ int snf_dropout_mask_f32(float dropout_p, uint64_t seed, uint64_t offset, int h,
     hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, snf::as_stream(stream), st, h, n, k,
                        mask, groups);
     return snf::check_launch("dropout_mask_kernel");
+}
+
+int snf_mil_loss_f32(const float* ins, int64_t n, int c, const float* logits, const float* label, const float* w, const float* pos_weight,
+                     const float* weight, float* out, int64_t* argmax, snf_stream_t stream) {
+    SNF_REQUIRE(ins && logits && label && w && out && argmax, "snf_mil_loss_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && c >= 1 && c <= MIL_MAXC, "snf_mil_loss_f32: n=%lld c=%d (1 <= c <= %d)", (long long)n, c, MIL_MAXC);
+    hipLaunchKernelGGL(mil_loss_kernel, dim3(1), dim3(1024), 0, snf::as_stream(stream), ins, n, c, logits, label, w, pos_weight, weight, out, argmax);
+    return snf::check_launch("mil_loss_kernel");
+}
+
+int snf_mil_loss_bwd_f32(const float* grad_out, const float* fwd_out, const int64_t* argmax, int64_t n, int c, float* d_ins, float* d_small,
+                         snf_stream_t stream) {
+    SNF_REQUIRE(grad_out && fwd_out && argmax && d_ins && d_small, "snf_mil_loss_bwd_f32: null pointer");
+    SNF_REQUIRE(n >= 1 && c >= 1 && c <= MIL_MAXC, "snf_mil_loss_bwd_f32: n=%lld c=%d (1 <= c <= %d)", (long long)n, c, MIL_MAXC);
+    int64_t blocks = (n * c + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(mil_loss_bwd_kernel, dim3((int)blocks), dim3(256), 0, snf::as_stream(stream), grad_out, fwd_out, argmax, n, c, d_ins, d_small);
+    return snf::check_launch("mil_loss_bwd_kernel");
 }
 
 }  // extern "C"

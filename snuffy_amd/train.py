@@ -24,6 +24,7 @@ import torch
 import torch.nn as nn
 from torch import optim
 
+from . import autograd as SA
 from . import balance
 from . import functional as SF
 from . import snuffy, snuffy_multiclass
@@ -422,6 +423,11 @@ class SmallWeightTrainer(Trainer):
 
     def _run_model(self, bag_feats, bag_label, outputs=None):
         ins_prediction, bag_prediction, _ = self.milnet(bag_feats) if outputs is None else outputs
+        if torch.is_grad_enabled() and ins_prediction.requires_grad:
+            # training: max over the instances, both BCE terms, their mix and the bag prediction in one launch (autograd.MilLossFn)
+            fused = SA.mil_loss(ins_prediction, bag_prediction, bag_label, self.single_weight_parameter, self.criterion)
+            if fused is not None:
+                return fused[1].squeeze(), fused[0], ins_prediction
         max_prediction, _ = torch.max(ins_prediction, 0 if ins_prediction.dim() == 2 else 1)
         bag_loss = self.criterion(bag_prediction.view(1, -1), bag_label.view(1, -1))
         max_loss = self.criterion(max_prediction.view(1, -1), bag_label.view(1, -1))
@@ -689,9 +695,13 @@ class BagParallelStepper:
 
     def step(self, bag, label):
         ins, logits, _ = self.milnet(bag)
-        max_pred, _ = torch.max(ins, 1)
-        loss = self.w * self.criterion(logits.view(1, -1), label.view(1, -1)) + \
-            (1 - self.w) * self.criterion(max_pred.view(1, -1), label.view(1, -1))
+        fused = SA.mil_loss(ins, logits, label, self.w, self.criterion)         # the trainer's loss head (_run_model), one launch each way
+        if fused is not None:
+            loss = fused[0]
+        else:
+            max_pred, _ = torch.max(ins, 1)
+            loss = self.w * self.criterion(logits.view(1, -1), label.view(1, -1)) + \
+                (1 - self.w) * self.criterion(max_pred.view(1, -1), label.view(1, -1))
         loss.backward()
         self.sync()
         self.optimizer.step()

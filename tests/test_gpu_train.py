@@ -580,3 +580,33 @@ def test_forward_after_fused_optimizer_steps_uses_the_new_weights(precision):
     assert la == lb and torch.equal(ea, eb), (la, lb, dv)
     assert abs(la[2] - la[0]) > 1e-3      # the weights did move between the two sightings of bag 0
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,c,pw,three_d", [(32768, 1, False, True), (5000, 2, True, False), (777, 5, True, True), (1, 1, False, False)])
+def test_fused_mil_loss_head_matches_the_torch_formulation(n, c, pw, three_d):
+    """autograd.MilLossFn (snf_mil_loss_f32: max over the instance scores, both BCEWithLogits terms, their mix by the single weight, the bag
+    prediction -- one launch each way) against the reference formulation of train.py's _run_model: loss, bag prediction, every gradient."""
+    from snuffy_amd import autograd as SA
+    g = torch.Generator().manual_seed(n + c)
+    ins0 = torch.randn(n, c, generator=g).to(DEV)
+    logit0 = torch.randn(1, c, generator=g).to(DEV)
+    label = (torch.rand(c, generator=g) > 0.5).float().to(DEV)
+    # (positional = `weight`, as the reference constructs it; the second case also carries a pos_weight)
+    crit = torch.nn.BCEWithLogitsLoss(torch.rand(c, generator=g).to(DEV) * 3 + 0.2 if pw else None,
+                                      pos_weight=torch.rand(c, generator=g).to(DEV) * 2 + 0.5 if (pw and c == 2) else None)
+    res = {}
+    for tag in ("ref", "fused"):
+        ins = (ins0.view(1, n, c) if three_d else ins0).clone().requires_grad_(True)
+        logits = logit0.clone().requires_grad_(True)
+        w = torch.tensor(0.3, device=DEV, requires_grad=True)
+        if tag == "fused":
+            loss, bag_pred = SA.mil_loss(ins, logits, label, w, crit)
+        else:
+            mx, _ = torch.max(ins, 1 if three_d else 0)
+            loss = w * crit(logits.view(1, -1), label.view(1, -1)) + (1 - w) * crit(mx.view(1, -1), label.view(1, -1))
+            bag_pred = ((1 - w) * torch.sigmoid(mx) + w * torch.sigmoid(logits)).detach().reshape(-1)
+        (loss * 1.7).backward()
+        res[tag] = (loss.detach(), bag_pred.detach().reshape(-1), ins.grad.reshape(n, c), logits.grad.reshape(-1), w.grad)
+    for a, b in zip(res["fused"], res["ref"]):
+        assert a.shape == b.shape and torch.allclose(a, b, rtol=2e-6, atol=2e-7), (a, b)
