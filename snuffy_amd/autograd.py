@@ -236,6 +236,9 @@ def _tn_mm(a, b, chunks=8):
     (36 tiles of 256 x 256 at config B: 311 us); split over `chunks` row blocks as ONE batched GEMM plus an fp32 sum of the
     partials (180-190 us, profiles/r02_tn_gemm.txt)."""
     n = a.shape[0]
+    if a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and ops.gemm_tn_supported(n, a.shape[1], b.shape[1], a, b):
+        # round 6: one bf16 product on snf_gemm_tn_f32 (fp32 partials summed in part order: no bf16 rounding of the chunk results)
+        return ops.gemm_tn(a, b, a.shape[1], b.shape[1])
     m = (n // chunks) * chunks
     if n < 4096 or m == 0:
         return torch.mm(a.t(), b).float()
