@@ -1311,7 +1311,7 @@ def gemm_tn_supported(n, p, q, *images):
     output large enough to be worth the matrix cores."""
     if not GEMM_TN or n < 1024 or n % 32 or p % 8 or q % 8 or p * q < 65536:
         return False
-    return all(t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
+    return all(t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
                and t.shape[0] == n and 33 * t.stride(0) < 2 ** 31 for t in images)
 
 

@@ -242,3 +242,17 @@ def test_lpt_assignment_partitions_and_balances(world):
     rr = [list(range(r, len(lens), world)) for r in range(world)]
     assert balance.imbalance(lens, shares, world, False) <= balance.imbalance(lens, rr, world, False)
     assert balance.lpt_assignment([5, 5, 5], 2) == [[0, 2], [1]]                      # ties: ascending index, lowest rank first
+
+
+def test_round6_training_dispatch_stays_off_the_gpu_paths_for_cpu_tensors():
+    """The new training-step entry points are gated on CUDA tensors: CPU operands never reach a kernel (the callers keep the torch formulation)."""
+    import torch
+    from snuffy_amd import autograd as SA
+    from snuffy_amd import ops
+    a = torch.zeros(2048, 3 * 256, dtype=torch.bfloat16)
+    assert not ops.gemm_tn_supported(2048, 256, 256, a, a)
+    ins, logits = torch.randn(50, 1, requires_grad=True), torch.randn(1, 1, requires_grad=True)
+    assert SA.mil_loss(ins, logits, torch.ones(1), torch.tensor(0.5), torch.nn.BCEWithLogitsLoss()) is None
+    # the weight-gradient contraction of the bf16 chain on CPU tensors: the plain product
+    x, y = torch.randn(64, 8).to(torch.bfloat16), torch.randn(64, 16).to(torch.bfloat16)
+    assert torch.allclose(SA._tn_mm(x, y), x.float().t() @ y.float(), rtol=2e-2, atol=5e-2)      # (a bf16 product below the chunking size)
