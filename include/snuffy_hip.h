@@ -364,6 +364,13 @@ int snf_sparse_attn_bwd_f32(const float* q, const float* kp, const float* v, con
 int snf_sparse_attn_bwd_ld_f32(const float* q, int64_t ldq, const float* kp, const float* v, int64_t ldv, const float* p, const float* mask,
                                const float* dout, int64_t n, int k, int h, int dk, float scale, float* dq, float* dkp, float* dv,
                                void* workspace, size_t workspace_bytes, snf_stream_t stream);
+/* ... with the forward's dropout mask REGENERATED in the kernels from its Philox state (dropout_p, seed, offset: the arguments
+ * snf_sparse_attn_fwd_x3_dropout was given) instead of read from a [h, n, k] tensor (round 6: the tensor was 157 MB written once and
+ * read twice per config-B training step).  Only on the matrix-core route (k <= 1024, k % 4 == 0, dk % 8 == 0, 16-byte aligned operands);
+ * SNF_EUNSUPPORTED otherwise -- hand the mask over as a tensor then. */
+int snf_sparse_attn_bwd_dropout_f32(const float* q, int64_t ldq, const float* kp, const float* v, int64_t ldv, const float* p, float dropout_p,
+                                    uint64_t seed, uint64_t offset, const float* dout, int64_t n, int k, int h, int dk, float scale, float* dq,
+                                    float* dkp, float* dv, void* workspace, size_t workspace_bytes, snf_stream_t stream);
 /* Fast form of the backward for dk == 128 with k <= 224 or dk == 64 with k <= 256 (bf16 MFMA operands, fp32 accumulate): P is recomputed from q, kp
  * and the forward's lse [h, n] (never read back), dQ / dV rows are owned by one wave (no reduction), dS [h, n, k] is
  * written out (ds_dtype f32, or bf16) -- the caller contracts it with q for dKp (snf_sparse_attn_dkp_f32 on f32, or a

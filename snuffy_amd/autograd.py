@@ -576,7 +576,9 @@ class EncoderLayer0X3Fn(torch.autograd.Function):
         else:
             o, p, _ = ops.sparse_attn_fwd(q, kp, v, h, need_attn=True)
         mask = None
-        if drop is not None:
+        # the backward regenerates the mask from the same Philox state where it can (round 6: no [h, n, k] tensor written and read twice)
+        regen = in_kernel and not need_attn and ops.attn_bwd_dropout_supported(k, dk)
+        if drop is not None and not regen:
             mask = ops.dropout_mask(h, n, k, drop[0], drop[1], drop[2], x2.device)         # the same mask as a tensor: the backward reads it
             if not in_kernel:
                 o = torch.bmm((p * mask).transpose(1, 2), v.reshape(n, h, dk).transpose(0, 1)).transpose(0, 1).reshape(k, d)
@@ -596,6 +598,7 @@ class EncoderLayer0X3Fn(torch.autograd.Function):
         ctx.save_for_backward(sel, xhat0_sel, qv, kp, p, mask, o, xs, x_sel, hid3, g0, b0, g1, b1, wq, wv, wo, w1)
         ctx.xn3, ctx.fw = xn3, fw       # xn3: written in place after the Q | V projection read it (outside the version check)
         ctx.h, ctx.eps, ctx.hl = h, eps, hl
+        ctx.drop = drop if regen else None
         attn = (p * mask if mask is not None else p) if need_attn else None
         if attn is not None:
             ctx.mark_non_differentiable(attn)
@@ -651,7 +654,8 @@ class EncoderLayer0X3Fn(torch.autograd.Function):
         dwo = dy_s.t() @ o
         do = dy_s @ wo
         # ---- attention, exact backward on the materialised P                                                 (snuffy.py:160-168)
-        dq, dkp, dv = ops.sparse_attn_bwd(qv[:, :d], kp, qv[:, d:], p, do.contiguous(), h, mask=mask, scale=1.0 / math.sqrt(dk))
+        dq, dkp, dv = ops.sparse_attn_bwd(qv[:, :d], kp, qv[:, d:], p, do.contiguous(), h, mask=mask, scale=1.0 / math.sqrt(dk),
+                                          dropout=ctx.drop)
         # xn3 holds LayerNorm 1's rows at S since the forward re-normalised them in place; the Q | V projection saw LayerNorm 0's:
         # dW = dqv^T xn3 + dqv[S]^T (xhat0[S] - xhat1[S]), a K-row correction of the big product
         x1_sel = xn3.index_select(0, sel)

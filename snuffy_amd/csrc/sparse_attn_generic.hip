@@ -14,6 +14,7 @@
 #include <atomic>
 
 #include "common.h"
+#include "philox.h"
 
 namespace {
 
@@ -730,7 +731,8 @@ template <int KBW>
 __global__ __launch_bounds__(256, KBW <= 2 ? 3 : 2) void bwd_ds_mfma_kernel(const float* __restrict__ v, const float* __restrict__ dout,
                                                                             const float* __restrict__ p, const float* __restrict__ mask,
                                                                             int64_t n, int k, int h, int dk, float scale,
-                                                                            float* __restrict__ ds, int64_t ldv /* row pitch of v */) {
+                                                                            float* __restrict__ ds, int64_t ldv /* row pitch of v */,
+                                                                            const snf::DropoutState drop /* mask == null: regenerated here */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int pitch = dk + 4;
     float* lv = lds;                           // [32][pitch]
@@ -799,6 +801,12 @@ __global__ __launch_bounds__(256, KBW <= 2 ? 3 : 2) void bwd_ds_mfma_kernel(cons
             const int key0 = 32 * kb + 8 * q4 + 4 * hf;
             mf32x4 pv = {0.f, 0.f, 0.f, 0.f}, mv = {1.f, 1.f, 1.f, 1.f};
             if (kb < nkb) {
+                // the dropout mask of the forward: a tensor, or (round 6) regenerated from the forward's Philox state -- the same
+                // function of (head, row, key group) the forward kernel applied (philox.h), nothing to read
+                if (!mask && drop.thresh) {
+                    const snf::philox_f4 m4 = snf::dropout_mask4(drop, a, n, rvalid ? row : n - 1, k, key0);
+                    mv = mf32x4{m4[0], m4[1], m4[2], m4[3]};
+                }
                 if (vec && key0 + 4 <= k) {
                     pv = *reinterpret_cast<const mf32x4*>(p + base + key0);
                     if (mask) mv = *reinterpret_cast<const mf32x4*>(mask + base + key0);
@@ -946,11 +954,11 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_dv_mfma_kernel(const float* __r
 // ([32 keys, 32 CT columns] each) is staged once for the four waves, every wave stages its own [32 rows, 32 keys] tiles of P o M and
 // dS -- all with coalesced 16-byte loads, requested a whole chunk (128 MFMAs per wave) ahead and parked in registers -- and the MFMA
 // operands come out of LDS (A: one 16-byte read per four k-steps, row pitch 36 floats; B: conflict-free dword reads).
-template <int CT, bool MASK>
+template <int CT, int MASK /* 0 none, 1 tensor, 2 regenerated from the Philox state */>
 __global__ __launch_bounds__(256, 2) void bwd_dq_dv_lds_kernel(const float* __restrict__ p, const float* __restrict__ mask,
                                                                const float* __restrict__ ds, const float* __restrict__ dout,
                                                                const float* __restrict__ kp, int64_t n, int k, int h, int dk,
-                                                               float* __restrict__ dq, float* __restrict__ dv) {
+                                                               float* __restrict__ dq, float* __restrict__ dv, const snf::DropoutState drop) {
     constexpr int PA = 36, PB = 32 * CT;                      // row pitches (floats) of the A tiles and of the B chunks
     extern __shared__ __attribute__((aligned(16))) float dql[];
     float* lds_b = dql;                                        // [2][32][PB]: dO chunk | Kp chunk
@@ -984,7 +992,11 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_dv_lds_kernel(const float* __re
             if (kok) {
                 st.pa[i] = *reinterpret_cast<const mf32x4*>(p + off);
                 st.sa[i] = *reinterpret_cast<const mf32x4*>(ds + off);
-                if constexpr (MASK) st.pa[i] *= *reinterpret_cast<const mf32x4*>(mask + off);
+                if constexpr (MASK == 1) st.pa[i] *= *reinterpret_cast<const mf32x4*>(mask + off);
+                if constexpr (MASK == 2) {
+                    const snf::philox_f4 m4 = snf::dropout_mask4(drop, a, n, row, k, key);
+                    st.pa[i] *= mf32x4{m4[0], m4[1], m4[2], m4[3]};
+                }
             }
         }
 #pragma unroll
@@ -1060,12 +1072,14 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_dv_lds_kernel(const float* __re
 
 template <int CT>
 int launch_dq_dv_lds(const float* p, const float* mask, const float* ds, const float* dout, const float* kp, int64_t n, int k, int h, int dk,
-                     float* dq, float* dv, dim3 grid, hipStream_t s) {
+                     float* dq, float* dv, dim3 grid, hipStream_t s, const snf::DropoutState drop) {
     constexpr int lds = (2 * 32 * 32 * CT + 4 * 2 * 32 * 36) * (int)sizeof(float);
-    static thread_local unsigned long long set_mask[2] = {0, 0};       // devices that have the LDS opt-in, per instantiation
+    static thread_local unsigned long long set_mask[3] = {0, 0, 0};    // devices that have the LDS opt-in, per instantiation
     const unsigned long long bit = snf::device_bit();
-    const int which = mask ? 1 : 0;
-    const void* fn = mask ? reinterpret_cast<const void*>(bwd_dq_dv_lds_kernel<CT, true>) : reinterpret_cast<const void*>(bwd_dq_dv_lds_kernel<CT, false>);
+    const int which = mask ? 1 : drop.thresh ? 2 : 0;
+    const void* fn = which == 1 ? reinterpret_cast<const void*>(bwd_dq_dv_lds_kernel<CT, 1>)
+                                : which == 2 ? reinterpret_cast<const void*>(bwd_dq_dv_lds_kernel<CT, 2>)
+                                             : reinterpret_cast<const void*>(bwd_dq_dv_lds_kernel<CT, 0>);
     if (!(set_mask[which] & bit)) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             snf::set_error("bwd_dq_dv_lds: cannot reserve %d bytes of LDS", lds);
@@ -1074,10 +1088,12 @@ int launch_dq_dv_lds(const float* p, const float* mask, const float* ds, const f
         }
         set_mask[which] |= bit;
     }
-    if (mask)
-        hipLaunchKernelGGL((bwd_dq_dv_lds_kernel<CT, true>), grid, dim3(256), lds, s, p, mask, ds, dout, kp, n, k, h, dk, dq, dv);
+    if (which == 1)
+        hipLaunchKernelGGL((bwd_dq_dv_lds_kernel<CT, 1>), grid, dim3(256), lds, s, p, mask, ds, dout, kp, n, k, h, dk, dq, dv, drop);
+    else if (which == 2)
+        hipLaunchKernelGGL((bwd_dq_dv_lds_kernel<CT, 2>), grid, dim3(256), lds, s, p, mask, ds, dout, kp, n, k, h, dk, dq, dv, drop);
     else
-        hipLaunchKernelGGL((bwd_dq_dv_lds_kernel<CT, false>), grid, dim3(256), lds, s, p, mask, ds, dout, kp, n, k, h, dk, dq, dv);
+        hipLaunchKernelGGL((bwd_dq_dv_lds_kernel<CT, 0>), grid, dim3(256), lds, s, p, mask, ds, dout, kp, n, k, h, dk, dq, dv, drop);
     return snf::check_launch("bwd_dq_dv_lds_kernel");
 }
 
@@ -1317,9 +1333,38 @@ int snf_sparse_attn_bwd_f32(const float* q, const float* kp, const float* v, con
                                       workspace_bytes, stream);
 }
 
+static int bwd_impl(const float* q, int64_t ldq, const float* kp, const float* v, int64_t ldv, const float* p, const float* mask,
+                    const snf::DropoutState drop, const float* dout, int64_t n, int k, int h, int dk, float scale, float* dq, float* dkp,
+                    float* dv, void* workspace, size_t workspace_bytes, snf_stream_t stream);
+
 int snf_sparse_attn_bwd_ld_f32(const float* q, int64_t ldq, const float* kp, const float* v, int64_t ldv, const float* p, const float* mask,
                                const float* dout, int64_t n, int k, int h, int dk, float scale, float* dq, float* dkp,
                                float* dv, void* workspace, size_t workspace_bytes, snf_stream_t stream) {
+    return bwd_impl(q, ldq, kp, v, ldv, p, mask, snf::make_dropout(0.f, 0, 0), dout, n, k, h, dk, scale, dq, dkp, dv, workspace, workspace_bytes,
+                    stream);
+}
+
+// the same backward with the forward's dropout mask REGENERATED in the kernels from its Philox state (dropout_p, seed, offset: what
+// snf_sparse_attn_fwd_x3_dropout was given) instead of read from a [h, n, k] tensor; only on the matrix-core kernels' route
+int snf_sparse_attn_bwd_dropout_f32(const float* q, int64_t ldq, const float* kp, const float* v, int64_t ldv, const float* p, float dropout_p,
+                                    uint64_t seed, uint64_t offset, const float* dout, int64_t n, int k, int h, int dk, float scale, float* dq,
+                                    float* dkp, float* dv, void* workspace, size_t workspace_bytes, snf_stream_t stream) {
+    SNF_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "snf_sparse_attn_bwd_dropout_f32: dropout_p = %f", (double)dropout_p);
+    const bool route = g_exact_mfma && g_dq_dv_lds && k <= 1024 && k % 4 == 0 && dk % 8 == 0 && ldv % 4 == 0 && v && dout && p && kp &&
+                       ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(p) |
+                         reinterpret_cast<uintptr_t>(kp)) & 15) == 0;
+    if (!route) {
+        snf::set_error("snf_sparse_attn_bwd_dropout_f32: k=%d dk=%d outside the matrix-core route (k <= 1024, k %% 4 == 0, dk %% 8 == 0, 16-byte "
+                       "aligned operands): hand the mask over as a tensor (snf_dropout_mask_f32 + snf_sparse_attn_bwd_ld_f32)", k, dk);
+        return SNF_EUNSUPPORTED;
+    }
+    return bwd_impl(q, ldq, kp, v, ldv, p, nullptr, snf::make_dropout(dropout_p, seed, offset), dout, n, k, h, dk, scale, dq, dkp, dv, workspace,
+                    workspace_bytes, stream);
+}
+
+static int bwd_impl(const float* q, int64_t ldq, const float* kp, const float* v, int64_t ldv, const float* p, const float* mask,
+                    const snf::DropoutState drop, const float* dout, int64_t n, int k, int h, int dk, float scale, float* dq, float* dkp,
+                    float* dv, void* workspace, size_t workspace_bytes, snf_stream_t stream) {
     SNF_REQUIRE(q && kp && v && p && dout && dq && dkp && dv, "snf_sparse_attn_bwd_f32: null pointer");
     SNF_REQUIRE(ldq >= (int64_t)h * dk && ldv >= (int64_t)h * dk && ldq < (1 << 24) && ldv < (1 << 24),
                 "snf_sparse_attn_bwd_ld_f32: bad row pitch ldq=%lld ldv=%lld", (long long)ldq, (long long)ldv);
@@ -1349,7 +1394,7 @@ int snf_sparse_attn_bwd_ld_f32(const float* q, int64_t ldq, const float* kp, con
         dim3 grid1((unsigned)((n + 31) / 32), (unsigned)h);
         const int kbw = ((k + 31) / 32 + 3) / 4;
 #define LAUNCH_DSM(KBW) \
-    hipLaunchKernelGGL((bwd_ds_mfma_kernel<KBW>), grid1, dim3(256), lds_m, s, v, dout, p, mask, n, k, h, dk, scale, ds, ldv)
+    hipLaunchKernelGGL((bwd_ds_mfma_kernel<KBW>), grid1, dim3(256), lds_m, s, v, dout, p, mask, n, k, h, dk, scale, ds, ldv, drop)
         if (kbw <= 1) LAUNCH_DSM(1);
         else if (kbw <= 2) LAUNCH_DSM(2);
         else if (kbw <= 4) LAUNCH_DSM(4);
@@ -1380,10 +1425,10 @@ int snf_sparse_attn_bwd_ld_f32(const float* q, int64_t ldq, const float* kp, con
                               reinterpret_cast<uintptr_t>(kp) | (mask ? reinterpret_cast<uintptr_t>(mask) : 0)) & 15) == 0;
         if (lds_ok) {
             switch (ct) {
-                case 1: rc = launch_dq_dv_lds<1>(p, mask, ds, dout, kp, n, k, h, dk, dq, dv, grid2, s); break;
-                case 2: rc = launch_dq_dv_lds<2>(p, mask, ds, dout, kp, n, k, h, dk, dq, dv, grid2, s); break;
-                case 3: rc = launch_dq_dv_lds<3>(p, mask, ds, dout, kp, n, k, h, dk, dq, dv, grid2, s); break;
-                default: rc = launch_dq_dv_lds<4>(p, mask, ds, dout, kp, n, k, h, dk, dq, dv, grid2, s); break;
+                case 1: rc = launch_dq_dv_lds<1>(p, mask, ds, dout, kp, n, k, h, dk, dq, dv, grid2, s, drop); break;
+                case 2: rc = launch_dq_dv_lds<2>(p, mask, ds, dout, kp, n, k, h, dk, dq, dv, grid2, s, drop); break;
+                case 3: rc = launch_dq_dv_lds<3>(p, mask, ds, dout, kp, n, k, h, dk, dq, dv, grid2, s, drop); break;
+                default: rc = launch_dq_dv_lds<4>(p, mask, ds, dout, kp, n, k, h, dk, dq, dv, grid2, s, drop); break;
             }
             if (rc) return rc;
         } else

@@ -510,10 +510,16 @@ def ln_mean_head(z, gamma, beta, eps, w_head, b_head, add_bf16=None, add_bias=No
     return logits, pooled, z_out
 
 
-def sparse_attn_bwd(q, kp, v, p, dout, h, mask=None, scale=None):
+def attn_bwd_dropout_supported(k, dk):
+    """sparse_attn_bwd regenerates the forward's dropout mask in its kernels (dropout=...) instead of reading a mask tensor."""
+    return 1 <= k <= 1024 and k % 4 == 0 and dk % 8 == 0
+
+
+def sparse_attn_bwd(q, kp, v, p, dout, h, mask=None, scale=None, dropout=None):
     """Exact-fp32 backward of sparse_attn_fwd: (dq [n,d], dkp [k,d], dv [n,d]).  p [h,n,k] = forward probabilities,
     mask (optional) = dropout keep-mask already divided by (1 - p_drop), dout [k, d].  q / v may be the row-strided halves of a fused
-    [Q | V] projection output where the matrix-core kernels apply (dk % 8 == 0, k <= 1024); otherwise they are made contiguous."""
+    [Q | V] projection output where the matrix-core kernels apply (dk % 8 == 0, k <= 1024); otherwise they are made contiguous.
+    dropout = (p_drop, seed, offset) instead of mask: the kernels regenerate the forward's Philox mask (attn_bwd_dropout_supported)."""
     if q.dtype != torch.float32 or v.dtype != torch.float32:
         raise TypeError("sparse_attn_bwd: q and v must be float32")
     kp = _req(kp, torch.float32, "kp", 2)
@@ -537,6 +543,12 @@ def sparse_attn_bwd(q, kp, v, p, dout, h, mask=None, scale=None):
     dkp = torch.empty_like(kp)
     wsb = lib.snf_sparse_attn_bwd_workspace_bytes(n, k, h, dk)
     ws = _ws(wsb, q.device)
+    if dropout is not None and mask is None and float(dropout[0]) > 0.0:
+        check(lib.snf_sparse_attn_bwd_dropout_f32(_p(q), q.stride(0), _p(kp), _p(v), v.stride(0), _p(p), float(dropout[0]),
+                                                  int(dropout[1]) & (2 ** 64 - 1), int(dropout[2]) & (2 ** 64 - 1), _p(dout), n, k, h, dk,
+                                                  float(scale), _p(dq), _p(dkp), _p(dv), _p(ws), wsb, _stream()),
+              "snf_sparse_attn_bwd_dropout_f32")
+        return dq, dkp, dv
     check(lib.snf_sparse_attn_bwd_ld_f32(_p(q), q.stride(0), _p(kp), _p(v), v.stride(0), _p(p), _p(mask), _p(dout), n, k, h, dk, float(scale),
                                          _p(dq), _p(dkp), _p(dv), _p(ws), wsb, _stream()), "snf_sparse_attn_bwd_ld_f32")
     return dq, dkp, dv

@@ -610,3 +610,26 @@ def test_fused_mil_loss_head_matches_the_torch_formulation(n, c, pw, three_d):
         res[tag] = (loss.detach(), bag_pred.detach().reshape(-1), ins.grad.reshape(n, c), logits.grad.reshape(-1), w.grad)
     for a, b in zip(res["fused"], res["ref"]):
         assert a.shape == b.shape and torch.allclose(a, b, rtol=2e-6, atol=2e-7), (a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k,h,dk", [(32768, 200, 6, 128), (3000, 128, 4, 64), (1000, 516, 2, 96)])
+def test_exact_attention_backward_regenerates_the_dropout_mask(n, k, h, dk):
+    """snf_sparse_attn_bwd_dropout_f32: the backward kernels regenerate the forward's Philox mask instead of reading the [h, n, k] tensor --
+    bit-identical gradients to the mask-tensor route."""
+    from snuffy_amd import ops
+    assert ops.attn_bwd_dropout_supported(k, dk)
+    g = torch.Generator().manual_seed(n + k)
+    d = h * dk
+    q, v = torch.randn(n, d, generator=g).to(DEV), torch.randn(n, d, generator=g).to(DEV)
+    kp = (torch.randn(k, d, generator=g) / dk ** 0.5).to(DEV)
+    p = torch.softmax(torch.randn(h, n, k, generator=g), -1).to(DEV)
+    dout = torch.randn(k, d, generator=g).to(DEV)
+    drop = (0.1, 1234567, 42)
+    mask = ops.dropout_mask(h, n, k, *drop, DEV)
+    ref = ops.sparse_attn_bwd(q, kp, v, p, dout, h, mask=mask)
+    out = ops.sparse_attn_bwd(q, kp, v, p, dout, h, dropout=drop)
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    plain = ops.sparse_attn_bwd(q, kp, v, p, dout, h)
+    assert not torch.equal(plain[0], out[0])
