@@ -205,7 +205,9 @@ class SparseAttnFn(torch.autograd.Function):
         else:
             out, p, _ = ops.sparse_attn_fwd(q, kp, v, h, need_attn=True)
         mask = None
-        if drop is not None:
+        # (round 6) nobody asked for the dropped P and the forward applied the mask itself: the backward regenerates it too, no tensor
+        ctx.regen = bool(in_kernel and not want_p and ops.attn_bwd_dropout_supported(k, dk))
+        if drop is not None and not ctx.regen:
             mask = ops.dropout_mask(h, n, k, drop[0], drop[1], drop[2], q.device)
             if not in_kernel:
                 vh = v.float().reshape(n, h, dk).transpose(0, 1)
@@ -226,7 +228,8 @@ class SparseAttnFn(torch.autograd.Function):
         dk = d // h
         scale = 1.0 / math.sqrt(dk)
         # K7-bwd on the HIP kernels (exact fp32): dS never leaves the workspace, P / dP are not re-materialised by bmm's
-        dq, dkp, dv = ops.sparse_attn_bwd(q, kp, v, p, dout.float().contiguous(), h, mask=mask, scale=scale)
+        dq, dkp, dv = ops.sparse_attn_bwd(q, kp, v, p, dout.float().contiguous(), h, mask=mask, scale=scale,
+                                          dropout=ctx.drop if ctx.regen else None)
         return dq, dkp, dv, None, None, None, None
 
 
